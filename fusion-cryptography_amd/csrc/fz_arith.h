@@ -1,0 +1,62 @@
+// fz_arith.h -- exact modular arithmetic on integers carried in IEEE doubles.
+//
+// Why doubles: measured on gfx950 (profiles/r01_instr_rate_microbench.txt) v_mul_lo_u32,
+// v_mul_hi_u32, v_min_u32 and every fp64 op issue at the same ~4 cycles per wave64, so
+// a Shoup/Montgomery int32 butterfly (3 multiplies + 3 range corrections + 5 adds) is not
+// cheaper than an fp64 butterfly (6-op FMA-Barrett multiply + add + sub), and the fp64
+// form needs NO range corrections: with a 31-bit modulus, 53-bit significands leave room
+// for lazy accumulation across all eight butterfly stages and for arbitrary int32 inputs.
+//
+// Every function is exact (no rounding error reaches a result) under the stated operand
+// bounds; results are therefore bit-identical to the reference's Python-integer arithmetic
+// (algebra/ntt.py:93-123 `cent`, :276-290, :356-376).  The same header compiles for the host
+// (tests/test_arith_host.py builds it with g++) so the bounds are exercised on the CPU.
+#ifndef FZ_ARITH_H
+#define FZ_ARITH_H
+
+#if defined(__HIPCC__)
+#define FZ_HD __host__ __device__ __forceinline__
+#else
+#define FZ_HD inline
+#endif
+
+struct FzMod {
+    double q;      // modulus, odd, < 2^31
+    double qinv;   // 1.0 / q rounded to nearest
+};
+
+// r = a*b - c*q exactly, with c = rint(fl(fl(a*b) * qinv)).
+// Exact when a, b are integers with |a*b| < 2^83 (so that |low part| < 2^30) -- in this
+// library |a| < 2^40 and |b| < 2^31.  |r| <= q/2 + q*|a*b/q|*2^-51  (i.e. "almost centred").
+//   h = fl(a*b); l = a*b - h exactly (FMA);  h - c*q is an integer below 2^53 -> exact.
+FZ_HD double fz_mulmod(double a, double b, const FzMod m) {
+    double h = a * b;
+    double l = __builtin_fma(a, b, -h);
+    double c = __builtin_rint(h * m.qinv);
+    double d = __builtin_fma(-c, m.q, h);
+    return d + l;
+}
+
+// Canonical centred residue of an integer-valued x, |x| < 2^19 * q:
+// the unique r == x (mod q) with |r| <= (q-1)/2, i.e. the reference's cent(x).
+// fl(x*qinv) is within 2^-33.. of x/q, and x/q is at least 1/(2q) > 2^-32 away from any
+// half-integer (q odd), so rint picks the true nearest integer.
+FZ_HD double fz_cent(double x, const FzMod m) {
+    double c = __builtin_rint(x * m.qinv);
+    return __builtin_fma(-c, m.q, x);
+}
+
+// cent() for |x| up to 2^62 (int64 accumulators): two steps.
+FZ_HD double fz_cent_wide(double x, const FzMod m) {
+    // first bring |x| below ~q (x integer-valued double, exact FMA as above)
+    double c = __builtin_rint(x * m.qinv);
+    double r = __builtin_fma(-c, m.q, x);
+    return fz_cent(r, m);
+}
+
+// cent(a*b) for int32-range a, b: canonical.
+FZ_HD double fz_mulmod_cent(double a, double b, const FzMod m) {
+    return fz_cent(fz_mulmod(a, b, m), m);
+}
+
+#endif  // FZ_ARITH_H

@@ -1,0 +1,440 @@
+// fz_capi.hip -- the C ABI of libfusion_hip.so (include/fusion_hip.h): context management,
+// table construction, error reporting and the thin wrappers that enqueue kernels.
+#include "fz_internal.h"
+#include "../../include/fusion_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+int fz_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int fz_check_hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return FZ_OK;
+    return fz_set_error(FZ_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define FZ_TRY(x) do { int rc_ = (x); if (rc_ != FZ_OK) return rc_; } while (0)
+#define FZ_HIP(x, what) FZ_TRY(fz_check_hip((x), what))
+#define FZ_REQUIRE(cond, ...) do { if (!(cond)) return fz_set_error(FZ_E_BADARG, __VA_ARGS__); } while (0)
+
+static uint64_t powmod_u64(uint64_t b, uint64_t e, uint64_t q) {
+    unsigned __int128 r = 1, x = b % q;
+    while (e) {
+        if (e & 1) r = (r * x) % q;
+        x = (x * x) % q;
+        e >>= 1;
+    }
+    return (uint64_t)r;
+}
+
+static unsigned bitrev(unsigned i, int k) {
+    unsigned r = 0;
+    for (int b = 0; b < k; ++b) r |= ((i >> b) & 1u) << (k - 1 - b);
+    return r;
+}
+
+int fz_scratch(fz_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->scratch_bytes) {
+        // previous users of the scratch are stream-ordered before this point
+        FZ_HIP(hipStreamSynchronize(ctx->stream), "scratch sync");
+        if (ctx->d_scratch) FZ_HIP(hipFree(ctx->d_scratch), "scratch free");
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        FZ_HIP(hipMalloc(&ctx->d_scratch, want), "scratch alloc");
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->d_scratch;
+    return FZ_OK;
+}
+
+extern "C" {
+
+const char *fz_version(void) { return "fusion_hip 0.1.0 (gfx950)"; }
+const char *fz_last_error(void) { return g_err; }
+
+int fz_device_count(int *out_count) {
+    FZ_REQUIRE(out_count, "out_count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_count = 0;
+        return fz_set_error(FZ_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *out_count = n;
+    return FZ_OK;
+}
+
+static int upload_doubles(const double *h, size_t n, double **d_out) {
+    FZ_HIP(hipMalloc((void **)d_out, (n ? n : 1) * sizeof(double)), "table alloc");
+    if (n) FZ_HIP(hipMemcpy(*d_out, h, n * sizeof(double), hipMemcpyHostToDevice), "table upload");
+    return FZ_OK;
+}
+
+int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t inv_root, fz_ctx **out) {
+    FZ_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    FZ_REQUIRE(q >= 3 && (q & 1u) && q < 0x80000000u, "modulus %u must be odd, >= 3 and < 2^31", q);
+    FZ_REQUIRE(degree >= 2 && (degree & (degree - 1)) == 0, "degree %d must be a power of two >= 2", degree);
+    if (degree > 256) return fz_set_error(FZ_E_UNSUPPORTED, "degree %d > 256 not supported", degree);
+    FZ_REQUIRE(((uint64_t)q - 1) % (2u * (uint64_t)degree) == 0, "2*degree=%d does not divide q-1", 2 * degree);
+    FZ_REQUIRE(root > 0 && root < q && inv_root > 0 && inv_root < q, "root / inv_root must be in (0, q)");
+    // primitive 2*degree-th root (order a power of two): root^degree == -1
+    FZ_REQUIRE(powmod_u64(root, (uint64_t)degree, q) == (uint64_t)q - 1,
+               "root %u is not a primitive %d-th root of unity mod %u", root, 2 * degree, q);
+    FZ_REQUIRE(((uint64_t)root * inv_root) % q == 1, "root * inv_root != 1 mod q");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fz_set_error(FZ_E_NODEVICE, "no HIP device available");
+    FZ_REQUIRE(device_id >= 0 && device_id < ndev, "device_id %d out of range (0..%d)", device_id, ndev - 1);
+    FZ_HIP(hipSetDevice(device_id), "hipSetDevice");
+
+    fz_ctx *c = new (std::nothrow) fz_ctx();
+    if (!c) return fz_set_error(FZ_E_HIP, "out of host memory");
+    memset(c, 0, sizeof(*c));
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    int rc = fz_check_hip(hipGetDeviceProperties(&prop, device_id), "hipGetDeviceProperties");
+    if (rc != FZ_OK) { delete c; return rc; }
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->q = q; c->root = root; c->inv_root = inv_root;
+    c->degree = degree;
+    c->logd = 0;
+    while ((1 << c->logd) < degree) ++c->logd;
+    c->mod.q = (double)q;
+    c->mod.qinv = 1.0 / (double)q;
+
+    const int n = degree, k = c->logd;
+    c->h_tw = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    c->h_itw = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    double *tw = (double *)malloc(sizeof(double) * n), *itw = (double *)malloc(sizeof(double) * n);
+    for (int i = 0; i < n; ++i) {
+        // bit_reverse_copy([pow(root, i, q)])  (algebra/polynomials.py:396-397, :416-417)
+        c->h_tw[i] = (uint32_t)powmod_u64(root, bitrev((unsigned)i, k), q);
+        c->h_itw[i] = (uint32_t)powmod_u64(inv_root, bitrev((unsigned)i, k), q);
+        tw[i] = (double)c->h_tw[i];
+        itw[i] = (double)c->h_itw[i];
+    }
+    const uint64_t n_inv = powmod_u64((uint64_t)n, (uint64_t)q - 2, q);
+    for (int i = 0; i < 16; ++i) {
+        c->twA.w[i] = (i < n) ? tw[i] : 0.0;
+        c->itwA.w[i] = (i < n) ? itw[i] : 0.0;
+    }
+    c->twA.n_inv = c->itwA.n_inv = (double)n_inv;
+    c->twA.w1_n_inv = 0.0;
+    c->itwA.w1_n_inv = (double)(((unsigned __int128)c->h_itw[1] * n_inv) % q);
+
+    // per-lane tables of the contiguous pass ([NE][L]); see fz_ntt.hip / tools/ntt_layout_model.py
+    double *twB = nullptr, *itwB = nullptr;
+    size_t nB = 0;
+    if (k >= 5) {
+        const int L = n / 16, SB = k - 4, NE = 16 - (16 >> SB);
+        nB = (size_t)NE * L;
+        twB = (double *)malloc(sizeof(double) * nB);
+        itwB = (double *)malloc(sizeof(double) * nB);
+        for (int ls = 0; ls < SB; ++ls) {
+            {   // forward: distance 2^(SB-1-ls), ng groups per lane
+                const int t = 1 << (SB - 1 - ls), ng = 16 / (2 * t);
+                const int ebase = (16 >> SB) * ((1 << ls) - 1);
+                for (int g = 0; g < ng; ++g)
+                    for (int b = 0; b < L; ++b) twB[(size_t)(ebase + g) * L + b] = tw[(16 << ls) + b * ng + g];
+            }
+            {   // inverse: distance 2^ls
+                const int ng = 8 >> ls, ebase = 16 - (16 >> ls);
+                for (int g = 0; g < ng; ++g)
+                    for (int b = 0; b < L; ++b) itwB[(size_t)(ebase + g) * L + b] = itw[(n >> (ls + 1)) + b * ng + g];
+            }
+        }
+    }
+
+    rc = fz_check_hip(hipEventCreate(&c->ev0), "event create");
+    if (rc == FZ_OK) rc = fz_check_hip(hipEventCreate(&c->ev1), "event create");
+    if (rc == FZ_OK) rc = upload_doubles(tw, n, &c->d_tw);
+    if (rc == FZ_OK) rc = upload_doubles(itw, n, &c->d_itw);
+    if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
+    if (rc == FZ_OK) rc = upload_doubles(itwB, nB, &c->d_itwB);
+    if (rc == FZ_OK) rc = fz_check_hip(hipMalloc((void **)&c->d_verdict, sizeof(int)), "verdict alloc");
+    if (rc == FZ_OK) rc = fz_ntt_query_grid(c);
+    free(tw); free(itw); free(twB); free(itwB);
+    if (rc != FZ_OK) { fz_ctx_destroy(c); return rc; }
+    *out = c;
+    return FZ_OK;
+}
+
+int fz_ctx_destroy(fz_ctx *ctx) {
+    if (!ctx) return FZ_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_tw) (void)hipFree(ctx->d_tw);
+    if (ctx->d_itw) (void)hipFree(ctx->d_itw);
+    if (ctx->d_twB) (void)hipFree(ctx->d_twB);
+    if (ctx->d_itwB) (void)hipFree(ctx->d_itwB);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_verdict) (void)hipFree(ctx->d_verdict);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    free(ctx->h_tw);
+    free(ctx->h_itw);
+    delete ctx;
+    return FZ_OK;
+}
+
+int fz_ctx_set_stream(fz_ctx *ctx, void *hip_stream) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    ctx->stream = (hipStream_t)hip_stream;
+    return FZ_OK;
+}
+
+int fz_ctx_synchronize(fz_ctx *ctx) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    FZ_HIP(hipStreamSynchronize(ctx->stream), "stream synchronize");
+    return FZ_OK;
+}
+
+int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    if (h_fwd) memcpy(h_fwd, ctx->h_tw, sizeof(uint32_t) * ctx->degree);
+    if (h_inv) memcpy(h_inv, ctx->h_itw, sizeof(uint32_t) * ctx->degree);
+    return FZ_OK;
+}
+
+int fz_malloc(fz_ctx *ctx, size_t bytes, void **d_out) {
+    FZ_REQUIRE(ctx && d_out, "NULL argument");
+    FZ_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    FZ_HIP(hipMalloc(d_out, bytes ? bytes : 1), "hipMalloc");
+    return FZ_OK;
+}
+
+int fz_free(fz_ctx *ctx, void *d_ptr) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    if (d_ptr) FZ_HIP(hipFree(d_ptr), "hipFree");
+    return FZ_OK;
+}
+
+int fz_memcpy_h2d(fz_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    FZ_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "NULL argument");
+    if (bytes) FZ_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream), "memcpy h2d");
+    return FZ_OK;
+}
+
+int fz_memcpy_d2h(fz_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    FZ_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "NULL argument");
+    if (bytes) FZ_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream), "memcpy d2h");
+    FZ_HIP(hipStreamSynchronize(ctx->stream), "memcpy d2h sync");
+    return FZ_OK;
+}
+
+int fz_timer_start(fz_ctx *ctx) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    FZ_HIP(hipEventRecord(ctx->ev0, ctx->stream), "event record");
+    return FZ_OK;
+}
+
+int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms) {
+    FZ_REQUIRE(ctx && out_ms, "NULL argument");
+    FZ_HIP(hipEventRecord(ctx->ev1, ctx->stream), "event record");
+    FZ_HIP(hipEventSynchronize(ctx->ev1), "event synchronize");
+    FZ_HIP(hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1), "event elapsed");
+    return FZ_OK;
+}
+
+// ---- transforms ----------------------------------------------------------------------------
+int fz_ntt_forward(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch) {
+    FZ_REQUIRE(ctx && (batch == 0 || (d_in && d_out)), "NULL argument");
+    return fz_launch_ntt(ctx, d_in, d_out, batch, false);
+}
+
+int fz_ntt_inverse(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch) {
+    FZ_REQUIRE(ctx && (batch == 0 || (d_in && d_out)), "NULL argument");
+    return fz_launch_ntt(ctx, d_in, d_out, batch, true);
+}
+
+static int ntt_host(fz_ctx *ctx, int32_t *h_data, size_t batch, bool inverse) {
+    FZ_REQUIRE(ctx && (batch == 0 || h_data), "NULL argument");
+    if (batch == 0) return FZ_OK;
+    const size_t bytes = batch * (size_t)ctx->degree * sizeof(int32_t);
+    void *d = nullptr;
+    FZ_TRY(fz_scratch(ctx, bytes, &d));
+    FZ_TRY(fz_memcpy_h2d(ctx, d, h_data, bytes));
+    FZ_TRY(fz_launch_ntt(ctx, (const int32_t *)d, (int32_t *)d, batch, inverse));
+    return fz_memcpy_d2h(ctx, h_data, d, bytes);
+}
+int fz_ntt_forward_host(fz_ctx *ctx, int32_t *h_data, size_t batch) { return ntt_host(ctx, h_data, batch, false); }
+int fz_ntt_inverse_host(fz_ctx *ctx, int32_t *h_data, size_t batch) { return ntt_host(ctx, h_data, batch, true); }
+
+// ---- pointwise -------------------------------------------------------------------------------
+int fz_pw_mul(fz_ctx *ctx, const int32_t *a, const int32_t *b, int32_t *out, size_t count) {
+    FZ_REQUIRE(ctx && (count == 0 || (a && b && out)), "NULL argument");
+    return fz_launch_pw(ctx, FZ_OP_MUL, a, b, out, count);
+}
+int fz_pw_add(fz_ctx *ctx, const int32_t *a, const int32_t *b, int32_t *out, size_t count) {
+    FZ_REQUIRE(ctx && (count == 0 || (a && b && out)), "NULL argument");
+    return fz_launch_pw(ctx, FZ_OP_ADD, a, b, out, count);
+}
+int fz_pw_sub(fz_ctx *ctx, const int32_t *a, const int32_t *b, int32_t *out, size_t count) {
+    FZ_REQUIRE(ctx && (count == 0 || (a && b && out)), "NULL argument");
+    return fz_launch_pw(ctx, FZ_OP_SUB, a, b, out, count);
+}
+int fz_pw_neg(fz_ctx *ctx, const int32_t *a, int32_t *out, size_t count) {
+    FZ_REQUIRE(ctx && (count == 0 || (a && out)), "NULL argument");
+    return fz_launch_pw(ctx, FZ_OP_NEG, a, a, out, count);
+}
+int fz_pw_mulacc(fz_ctx *ctx, int32_t *acc, const int32_t *a, const int32_t *b, size_t count) {
+    FZ_REQUIRE(ctx && (count == 0 || (acc && a && b)), "NULL argument");
+    return fz_launch_pw(ctx, FZ_OP_MULACC, a, b, acc, count);
+}
+int fz_pw_mul_bcast(fz_ctx *ctx, const int32_t *a, const int32_t *s, int32_t *out, size_t rows) {
+    FZ_REQUIRE(ctx && (rows == 0 || (a && s && out)), "NULL argument");
+    return fz_launch_pw_bcast(ctx, a, s, out, rows);
+}
+
+int fz_pw_binary_host(fz_ctx *ctx, int op, const int32_t *h_a, const int32_t *h_b, int32_t *h_out, size_t count) {
+    FZ_REQUIRE(ctx && op >= FZ_OP_MUL && op <= FZ_OP_NEG, "bad op %d", op);
+    FZ_REQUIRE(count == 0 || (h_a && h_out && (op == FZ_OP_NEG || h_b)), "NULL argument");
+    if (count == 0) return FZ_OK;
+    const size_t seg = (count * sizeof(int32_t) + 255) & ~(size_t)255;
+    void *d = nullptr;
+    FZ_TRY(fz_scratch(ctx, 3 * seg, &d));
+    int32_t *da = (int32_t *)d, *db = (int32_t *)((char *)d + seg), *dout = (int32_t *)((char *)d + 2 * seg);
+    FZ_TRY(fz_memcpy_h2d(ctx, da, h_a, count * sizeof(int32_t)));
+    if (op != FZ_OP_NEG) FZ_TRY(fz_memcpy_h2d(ctx, db, h_b, count * sizeof(int32_t)));
+    FZ_TRY(fz_launch_pw(ctx, op, da, op == FZ_OP_NEG ? da : db, dout, count));
+    return fz_memcpy_d2h(ctx, h_out, dout, count * sizeof(int32_t));
+}
+
+// ---- matrix-vector ------------------------------------------------------------------------------
+int fz_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *out, size_t batch, int l) {
+    FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (A && S && out)), "bad argument");
+    return fz_launch_matvec(ctx, A, S, out, batch, l);
+}
+
+int fz_matvec_host(fz_ctx *ctx, const int32_t *h_A, const int32_t *h_S, int32_t *h_out, size_t batch, int l) {
+    FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (h_A && h_S && h_out)), "bad argument");
+    if (batch == 0) return FZ_OK;
+    const size_t row = (size_t)ctx->degree * sizeof(int32_t);
+    const size_t bA = (size_t)l * row, bS = batch * (size_t)l * row, bO = batch * row;
+    const size_t oS = (bA + 255) & ~(size_t)255, oO = oS + ((bS + 255) & ~(size_t)255);
+    void *d = nullptr;
+    FZ_TRY(fz_scratch(ctx, oO + bO, &d));
+    char *base = (char *)d;
+    FZ_TRY(fz_memcpy_h2d(ctx, base, h_A, bA));
+    FZ_TRY(fz_memcpy_h2d(ctx, base + oS, h_S, bS));
+    FZ_TRY(fz_launch_matvec(ctx, (const int32_t *)base, (const int32_t *)(base + oS), (int32_t *)(base + oO), batch, l));
+    return fz_memcpy_d2h(ctx, h_out, base + oO, bO);
+}
+
+// ---- fused scheme cores ---------------------------------------------------------------------------
+int fz_keygen_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef, int32_t *d_sk_hat, int32_t *d_vk,
+                   size_t batch, int l) {
+    FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (d_A && d_coef && d_sk_hat && d_vk)), "bad argument");
+    // sk_hat = NTT(every secret row); vk_{L,R} = A . sk_hat_{L,R}   (fusion/fusion.py:363-370)
+    FZ_TRY(fz_launch_ntt(ctx, d_coef, d_sk_hat, batch * 2 * (size_t)l, false));
+    return fz_launch_matvec(ctx, d_A, d_sk_hat, d_vk, batch * 2, l);
+}
+
+int fz_sign_core(fz_ctx *ctx, const int32_t *d_sk_hat, const int32_t *d_c_hat, int32_t *d_sig, size_t batch, int l) {
+    FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (d_sk_hat && d_c_hat && d_sig)), "bad argument");
+    return fz_launch_sign(ctx, d_sk_hat, d_c_hat, d_sig, batch, l);
+}
+
+int fz_aggregate_partial(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, int64_t *d_partial,
+                         size_t N, int l) {
+    FZ_REQUIRE(ctx && l >= 1 && d_partial && (N == 0 || (d_sig && d_alpha_hat)), "bad argument");
+    FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large for exact int64/fp64 accumulation (< 2^21)", N);
+    return fz_launch_aggregate_partial(ctx, d_sig, d_alpha_hat, d_partial, N, l);
+}
+
+int fz_reduce_i64(fz_ctx *ctx, const int64_t *d_in, int32_t *d_out, size_t count) {
+    FZ_REQUIRE(ctx && (count == 0 || (d_in && d_out)), "NULL argument");
+    return fz_launch_reduce_i64(ctx, d_in, d_out, count);
+}
+
+int fz_aggregate_core(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, int32_t *d_out, size_t N, int l) {
+    FZ_REQUIRE(ctx && l >= 1 && N >= 1 && d_sig && d_alpha_hat && d_out, "bad argument");
+    const size_t count = (size_t)l * ctx->degree;
+    void *d = nullptr;
+    FZ_TRY(fz_scratch(ctx, count * sizeof(int64_t), &d));
+    FZ_TRY(fz_aggregate_partial(ctx, d_sig, d_alpha_hat, (int64_t *)d, N, l));
+    return fz_launch_reduce_i64(ctx, (const int64_t *)d, d_out, count);
+}
+
+int fz_target_partial(fz_ctx *ctx, const int32_t *d_vkL, const int32_t *d_vkR, const int32_t *d_c_hat,
+                      const int32_t *d_alpha_hat, int64_t *d_partial, size_t N) {
+    FZ_REQUIRE(ctx && d_partial && (N == 0 || (d_vkL && d_vkR && d_c_hat && d_alpha_hat)), "bad argument");
+    FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large (< 2^21)", N);
+    return fz_launch_target_partial(ctx, d_vkL, d_vkR, d_c_hat, d_alpha_hat, d_partial, N);
+}
+
+int fz_norm_weight(fz_ctx *ctx, const int32_t *d_coef, size_t batch, int64_t *d_max_abs, int32_t *d_weight) {
+    FZ_REQUIRE(ctx && (batch == 0 || (d_coef && d_max_abs && d_weight)), "NULL argument");
+    return fz_launch_norm_weight(ctx, d_coef, batch, d_max_abs, d_weight);
+}
+
+int fz_norm_weight_host(fz_ctx *ctx, const int32_t *h_coef, size_t batch, int64_t *h_max_abs, int32_t *h_weight) {
+    FZ_REQUIRE(ctx && (batch == 0 || (h_coef && h_max_abs && h_weight)), "NULL argument");
+    if (batch == 0) return FZ_OK;
+    const size_t bC = batch * (size_t)ctx->degree * sizeof(int32_t);
+    const size_t oM = (bC + 255) & ~(size_t)255, oW = oM + ((batch * sizeof(int64_t) + 255) & ~(size_t)255);
+    void *d = nullptr;
+    FZ_TRY(fz_scratch(ctx, oW + batch * sizeof(int32_t), &d));
+    char *base = (char *)d;
+    FZ_TRY(fz_memcpy_h2d(ctx, base, h_coef, bC));
+    FZ_TRY(fz_launch_norm_weight(ctx, (const int32_t *)base, batch, (int64_t *)(base + oM), (int32_t *)(base + oW)));
+    FZ_TRY(fz_memcpy_d2h(ctx, h_max_abs, base + oM, batch * sizeof(int64_t)));
+    return fz_memcpy_d2h(ctx, h_weight, base + oW, batch * sizeof(int32_t));
+}
+
+int fz_verify_with_target(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const int32_t *d_target, int l,
+                          int64_t beta_vf, int64_t omega_vf, int *h_verdict) {
+    FZ_REQUIRE(ctx && l >= 1 && d_A && d_sig && d_target && h_verdict, "bad argument");
+    const size_t row = (size_t)ctx->degree * sizeof(int32_t);
+    // scratch: observed [D] i32 | coef [l][D] i32 | max_abs [l] i64 | weight [l] i32
+    const size_t oC = (row + 255) & ~(size_t)255;
+    const size_t oM = oC + (((size_t)l * row + 255) & ~(size_t)255);
+    const size_t oW = oM + (((size_t)l * sizeof(int64_t) + 255) & ~(size_t)255);
+    void *d = nullptr;
+    FZ_TRY(fz_scratch(ctx, oW + (size_t)l * sizeof(int32_t), &d));
+    char *base = (char *)d;
+    int32_t *observed = (int32_t *)base, *coef = (int32_t *)(base + oC);
+    int64_t *mx = (int64_t *)(base + oM);
+    int32_t *wt = (int32_t *)(base + oW);
+    FZ_TRY(fz_launch_matvec(ctx, d_A, d_sig, observed, 1, l));                    // fusion.py:715-717
+    FZ_TRY(fz_launch_ntt(ctx, d_sig, coef, (size_t)l, true));                     // fusion.py:690-692
+    FZ_TRY(fz_launch_norm_weight(ctx, coef, (size_t)l, mx, wt));                  // fusion.py:722-727
+    FZ_TRY(fz_launch_verdict(ctx, d_target, observed, mx, wt, l, beta_vf, omega_vf, ctx->d_verdict));
+    return fz_memcpy_d2h(ctx, h_verdict, ctx->d_verdict, sizeof(int));
+}
+
+int fz_verify_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const int32_t *d_vkL, const int32_t *d_vkR,
+                   const int32_t *d_c_hat, const int32_t *d_alpha_hat, size_t N, int l,
+                   int64_t beta_vf, int64_t omega_vf, int *h_verdict) {
+    FZ_REQUIRE(ctx && l >= 1 && N >= 1 && d_A && d_sig && d_vkL && d_vkR && d_c_hat && d_alpha_hat && h_verdict,
+               "bad argument");
+    // target lives behind the fz_verify_with_target scratch layout: allocate both up front
+    const size_t row = (size_t)ctx->degree * sizeof(int32_t);
+    const size_t inner = ((row + 255) & ~(size_t)255) + (((size_t)l * row + 255) & ~(size_t)255) +
+                         (((size_t)l * sizeof(int64_t) + 255) & ~(size_t)255) + (((size_t)l * sizeof(int32_t) + 255) & ~(size_t)255);
+    const size_t oP = inner, oT = oP + (((size_t)ctx->degree * sizeof(int64_t) + 255) & ~(size_t)255);
+    void *d = nullptr;
+    FZ_TRY(fz_scratch(ctx, oT + row, &d));
+    char *base = (char *)d;
+    int64_t *partial = (int64_t *)(base + oP);
+    int32_t *target = (int32_t *)(base + oT);
+    FZ_TRY(fz_target_partial(ctx, d_vkL, d_vkR, d_c_hat, d_alpha_hat, partial, N));   // fusion.py:706-714
+    FZ_TRY(fz_launch_reduce_i64(ctx, partial, target, (size_t)ctx->degree));
+    return fz_verify_with_target(ctx, d_A, d_sig, target, l, beta_vf, omega_vf, h_verdict);
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// fz_internal.h -- shared declarations between the translation units of libfusion_hip.so.
+#ifndef FZ_INTERNAL_H
+#define FZ_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "fz_arith.h"
+
+// Wave-uniform twiddles of the strided pass, passed BY VALUE so they live in the kernarg
+// segment and reach the kernel as scalar loads (SGPR operands of the fp64 multiplies).
+struct FzTwA {
+    double w[16];      // entries 1..15 of the bit-reversed power table (entry 0 unused)
+    double n_inv;      // degree^{-1} mod q            (inverse only)
+    double w1_n_inv;   // w[1] * degree^{-1} mod q      (inverse only: n^{-1} folded into last stage)
+};
+
+struct fz_ctx {
+    int device;
+    int num_cu;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    uint32_t q, root, inv_root;
+    int degree, logd;
+    FzMod mod;
+    // host tables, bit-reversed powers in [0,q)
+    uint32_t *h_tw, *h_itw;
+    // device tables
+    double *d_tw, *d_itw;        // [degree] as doubles (generic / small kernels)
+    double *d_twB, *d_itwB;      // per-lane tables of the contiguous pass, [NE][L]
+    FzTwA twA, itwA;
+    // growable device scratch (host-pointer entry points, int64 partial sums)
+    void *d_scratch;
+    size_t scratch_bytes;
+    int *d_verdict;
+    int grid_fwd, grid_inv;      // resident-grid caps for the persistent NTT kernels
+};
+
+// error plumbing (fz_capi.hip)
+int fz_set_error(int code, const char *fmt, ...);
+int fz_check_hip(hipError_t e, const char *what);
+int fz_scratch(fz_ctx *ctx, size_t bytes, void **out);
+
+// launchers (fz_ntt.hip)
+int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse);
+int fz_ntt_query_grid(fz_ctx *ctx);
+
+// launchers (fz_pointwise.hip)
+enum { FZ_OP_MUL = 0, FZ_OP_ADD = 1, FZ_OP_SUB = 2, FZ_OP_NEG = 3, FZ_OP_MULACC = 4 };
+int fz_launch_pw(fz_ctx *ctx, int op, const int32_t *a, const int32_t *b, int32_t *out, size_t count);
+int fz_launch_pw_bcast(fz_ctx *ctx, const int32_t *a, const int32_t *s, int32_t *out, size_t rows);
+int fz_launch_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *out, size_t batch, int l);
+int fz_launch_sign(fz_ctx *ctx, const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig, size_t batch, int l);
+int fz_launch_aggregate_partial(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *partial, size_t N, int l);
+int fz_launch_target_partial(fz_ctx *ctx, const int32_t *vkL, const int32_t *vkR, const int32_t *c, const int32_t *alpha,
+                             int64_t *partial, size_t N);
+int fz_launch_reduce_i64(fz_ctx *ctx, const int64_t *in, int32_t *out, size_t count);
+int fz_launch_norm_weight(fz_ctx *ctx, const int32_t *coef, size_t batch, int64_t *max_abs, int32_t *weight);
+int fz_launch_verdict(fz_ctx *ctx, const int32_t *target, const int32_t *observed, const int64_t *max_abs,
+                      const int32_t *weight, int l, int64_t beta, int64_t omega, int *d_verdict);
+
+#endif

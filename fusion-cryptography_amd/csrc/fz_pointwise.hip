@@ -1,0 +1,337 @@
+// fz_pointwise.hip -- streaming kernels: pointwise ring ops, the (1 x l).(l x 1) product and
+// the fused arithmetic of sign / aggregate / verify.  All are HBM-bound (one modular
+// multiply-add per 4..12 bytes moved): 16-byte-per-lane coalesced accesses, grid-stride
+// loops over a grid capped at a few blocks per CU, fp64 exact arithmetic from fz_arith.h.
+//
+// Reference formulas: algebra/polynomials.py:303-385 (pointwise), algebra/matrices.py:108-131
+// (scalar and matrix products), fusion/fusion.py:557 (sign), :670-676 (aggregate),
+// :706-727 (verify).  Every partial result the reference centres is congruent mod q to the
+// lazily accumulated value here, and the final value is centred once -- identical output.
+#include "fz_internal.h"
+#include "../../include/fusion_hip.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ int cent_i32(double x, const FzMod m) { return (int)fz_cent(x, m); }
+
+template <int OP>
+__device__ __forceinline__ int pw_op(int a, int b, int acc, const FzMod m) {
+    if (OP == FZ_OP_MUL) return (int)fz_mulmod_cent((double)a, (double)b, m);
+    if (OP == FZ_OP_ADD) return cent_i32((double)a + (double)b, m);
+    if (OP == FZ_OP_SUB) return cent_i32((double)a - (double)b, m);
+    if (OP == FZ_OP_NEG) {   // -(x mod q), x mod q in [0,q): reference __neg__ (polynomials.py:325-333)
+        double c = fz_cent((double)a, m);
+        double y = c < 0.0 ? c + m.q : c;
+        return (int)(-y);
+    }
+    // MULACC
+    return cent_i32((double)acc + fz_mulmod((double)a, (double)b, m), m);
+}
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void pw_kernel(const int32_t *a, const int32_t *b, int32_t *out,
+                                                    size_t count, int vec, FzMod m) {
+    const size_t n4 = vec ? count / 4 : 0;   // vec == 0: pointers not 16-byte aligned, all scalar
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int4 *a4 = reinterpret_cast<const int4 *>(a);
+    const int4 *b4 = reinterpret_cast<const int4 *>(b);
+    int4 *o4 = reinterpret_cast<int4 *>(out);
+    for (size_t i = gid; i < n4; i += stride) {
+        int4 x = a4[i];
+        int4 y = (OP == FZ_OP_NEG) ? x : b4[i];
+        int4 z = (OP == FZ_OP_MULACC) ? o4[i] : x;
+        int4 o;
+        o.x = pw_op<OP>(x.x, y.x, z.x, m);
+        o.y = pw_op<OP>(x.y, y.y, z.y, m);
+        o.z = pw_op<OP>(x.z, y.z, z.z, m);
+        o.w = pw_op<OP>(x.w, y.w, z.w, m);
+        o4[i] = o;
+    }
+    // ragged tail (count not a multiple of 4) or the whole range when unaligned
+    for (size_t i = n4 * 4 + gid; i < count; i += stride) {
+        int x = a[i];
+        int y = (OP == FZ_OP_NEG) ? x : b[i];
+        int z = (OP == FZ_OP_MULACC) ? out[i] : x;
+        out[i] = pw_op<OP>(x, y, z, m);
+    }
+}
+
+// out[row][j] = cent(a[row][j] * s[j]); d4 = degree/4 (degree >= 4) or scalar path
+__global__ __launch_bounds__(kBlock) void pw_bcast_kernel(const int32_t *a, const int32_t *s, int32_t *out,
+                                                          size_t total, int degree, FzMod m) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int j = (int)(i % (size_t)degree);
+        out[i] = (int)fz_mulmod_cent((double)a[i], (double)s[j], m);
+    }
+}
+
+// out[b][j] = cent(sum_k A[k][j] * S[b][k][j]); one thread per (b, 4 coefficients)
+__global__ __launch_bounds__(kBlock) void matvec_kernel(const int32_t *A, const int32_t *S, int32_t *out,
+                                                        size_t batch, int l, int degree, FzMod m) {
+    const int d4 = degree / 4;
+    const size_t total = batch * (size_t)d4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t b = i / d4;
+        const int j4 = (int)(i % d4);
+        const int4 *Ap = reinterpret_cast<const int4 *>(A) + j4;
+        const int4 *Sp = reinterpret_cast<const int4 *>(S + b * (size_t)l * degree) + j4;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (int k = 0; k < l; ++k) {
+            int4 x = Ap[(size_t)k * d4];
+            int4 y = Sp[(size_t)k * d4];
+            s0 += fz_mulmod((double)x.x, (double)y.x, m);
+            s1 += fz_mulmod((double)x.y, (double)y.y, m);
+            s2 += fz_mulmod((double)x.z, (double)y.z, m);
+            s3 += fz_mulmod((double)x.w, (double)y.w, m);
+        }
+        int4 o;
+        o.x = cent_i32(s0, m); o.y = cent_i32(s1, m); o.z = cent_i32(s2, m); o.w = cent_i32(s3, m);
+        reinterpret_cast<int4 *>(out + b * (size_t)degree)[j4] = o;
+    }
+}
+// degree < 4 fallback (degree 2): scalar
+__global__ __launch_bounds__(kBlock) void matvec_scalar_kernel(const int32_t *A, const int32_t *S, int32_t *out,
+                                                               size_t batch, int l, int degree, FzMod m) {
+    const size_t total = batch * (size_t)degree;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t b = i / degree;
+        const int j = (int)(i % degree);
+        double s = 0;
+        for (int k = 0; k < l; ++k)
+            s += fz_mulmod((double)A[(size_t)k * degree + j], (double)S[(b * l + k) * (size_t)degree + j], m);
+        out[i] = cent_i32(s, m);
+    }
+}
+
+// sig[b][k][j] = cent(cent(L[b][k][j] * c[b][j]) + R[b][k][j]); sk_hat = [batch][2][l][degree]
+__global__ __launch_bounds__(kBlock) void sign_kernel(const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig,
+                                                      size_t batch, int l, int degree, FzMod m) {
+    const int d4 = degree / 4;
+    const size_t per_sig = (size_t)l * d4;
+    const size_t total = batch * per_sig;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t b = i / per_sig;
+        const size_t rem = i % per_sig;          // k*d4 + j4
+        const int j4 = (int)(rem % d4);
+        const int4 *Lp = reinterpret_cast<const int4 *>(sk_hat + b * 2 * (size_t)l * degree);
+        const int4 *Rp = Lp + per_sig;
+        int4 x = Lp[rem], y = Rp[rem];
+        int4 c = reinterpret_cast<const int4 *>(c_hat + b * (size_t)degree)[j4];
+        int4 o;
+        o.x = cent_i32(fz_mulmod((double)x.x, (double)c.x, m) + (double)y.x, m);
+        o.y = cent_i32(fz_mulmod((double)x.y, (double)c.y, m) + (double)y.y, m);
+        o.z = cent_i32(fz_mulmod((double)x.z, (double)c.z, m) + (double)y.z, m);
+        o.w = cent_i32(fz_mulmod((double)x.w, (double)c.w, m) + (double)y.w, m);
+        reinterpret_cast<int4 *>(sig)[i] = o;
+    }
+}
+
+__device__ __forceinline__ void atomic_add_i64(int64_t *p, double v) {
+    atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)(long long)v);
+}
+
+// partial[k][j] += sum_{i in split} sig[i][k][j] * alpha[i][j]  (each product reduced to ~q/2).
+// grid.x covers the l*degree/4 columns, grid.y splits the N signatures.
+__global__ __launch_bounds__(kBlock) void aggregate_kernel(const int32_t *sig, const int32_t *alpha, int64_t *partial,
+                                                           size_t N, int l, int degree, FzMod m) {
+    const int d4 = degree / 4;
+    const size_t cols = (size_t)l * d4;
+    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols) return;
+    const int j4 = (int)(col % d4);
+    const size_t per = (N + gridDim.y - 1) / gridDim.y;
+    const size_t i0 = (size_t)blockIdx.y * per;
+    const size_t i1 = (i0 + per < N) ? i0 + per : N;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (size_t i = i0; i < i1; ++i) {
+        int4 x = reinterpret_cast<const int4 *>(sig + i * (size_t)l * degree)[col];
+        int4 a = reinterpret_cast<const int4 *>(alpha + i * (size_t)degree)[j4];
+        s0 += fz_mulmod((double)x.x, (double)a.x, m);
+        s1 += fz_mulmod((double)x.y, (double)a.y, m);
+        s2 += fz_mulmod((double)x.z, (double)a.z, m);
+        s3 += fz_mulmod((double)x.w, (double)a.w, m);
+    }
+    if (i1 > i0) {
+        int64_t *dst = partial + col * 4;
+        atomic_add_i64(dst + 0, s0);
+        atomic_add_i64(dst + 1, s1);
+        atomic_add_i64(dst + 2, s2);
+        atomic_add_i64(dst + 3, s3);
+    }
+}
+
+// partial[j] += sum_i ((vkL_i*c_i + vkR_i) * alpha_i)[j]; one thread per coefficient, grid.y splits N
+__global__ __launch_bounds__(kBlock) void target_kernel(const int32_t *vkL, const int32_t *vkR, const int32_t *c,
+                                                        const int32_t *alpha, int64_t *partial,
+                                                        size_t N, int degree, FzMod m) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= degree) return;
+    const size_t per = (N + gridDim.y - 1) / gridDim.y;
+    const size_t i0 = (size_t)blockIdx.y * per;
+    const size_t i1 = (i0 + per < N) ? i0 + per : N;
+    double s = 0;
+    for (size_t i = i0; i < i1; ++i) {
+        const size_t o = i * (size_t)degree + j;
+        double t = fz_mulmod((double)vkL[o], (double)c[o], m) + (double)vkR[o];   // |t| < 2^32
+        s += fz_mulmod(t, (double)alpha[o], m);
+    }
+    if (i1 > i0) atomic_add_i64(partial + j, s);
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_i64_kernel(const int64_t *in, int32_t *out, size_t count, FzMod m) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        out[i] = (int)fz_cent_wide((double)in[i], m);
+}
+
+// one wave per row: max |x| over stored values, #{x : x mod q != 0}
+__global__ __launch_bounds__(64) void norm_weight_kernel(const int32_t *coef, size_t batch, int degree, uint32_t q,
+                                                         int64_t *max_abs, int32_t *weight) {
+    for (size_t row = blockIdx.x; row < batch; row += gridDim.x) {
+        long long mx = 0;
+        int w = 0;
+        for (int j = threadIdx.x; j < degree; j += 64) {
+            long long x = coef[row * (size_t)degree + j];
+            long long ax = x < 0 ? -x : x;
+            mx = ax > mx ? ax : mx;
+            // |x| <= 2^31 < 2q, so x mod q == 0 iff x in {0, q, -q}
+            w += (ax != 0 && ax != (long long)q) ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            long long o = __shfl_xor(mx, off);
+            mx = o > mx ? o : mx;
+            w += __shfl_xor(w, off);
+        }
+        if (threadIdx.x == 0) {
+            max_abs[row] = mx;
+            weight[row] = w;
+        }
+    }
+}
+
+// verdict of fusion/fusion.py:718-728, evaluated in the reference's order
+__global__ __launch_bounds__(256) void verdict_kernel(const int32_t *target, const int32_t *observed, int degree,
+                                                      const int64_t *max_abs, const int32_t *weight, int l,
+                                                      int64_t beta, int64_t omega, int *verdict) {
+    __shared__ int s_mis, s_norm, s_wt;
+    if (threadIdx.x == 0) { s_mis = 0; s_norm = 0; s_wt = 0; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < degree; j += blockDim.x)
+        if (target[j] != observed[j]) atomicOr(&s_mis, 1);      // both centred: equal ints <=> equal mod q
+    for (int k = threadIdx.x; k < l; k += blockDim.x) {
+        if (max_abs[k] > beta) atomicOr(&s_norm, 1);
+        if ((int64_t)weight[k] > omega) atomicOr(&s_wt, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *verdict = s_mis ? FZ_VERDICT_TARGET_MISMATCH : (s_norm ? FZ_VERDICT_NORM : (s_wt ? FZ_VERDICT_WEIGHT : FZ_VERDICT_OK));
+}
+
+unsigned grid_for(fz_ctx *ctx, size_t work_items, int per_cu = 8) {
+    size_t blocks = (work_items + kBlock - 1) / kBlock;
+    size_t cap = (size_t)ctx->num_cu * per_cu;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)(blocks < cap ? blocks : cap);
+}
+
+}  // namespace
+
+int fz_launch_pw(fz_ctx *ctx, int op, const int32_t *a, const int32_t *b, int32_t *out, size_t count) {
+    if (count == 0) return FZ_OK;
+    const int vec = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0) ? 1 : 0;
+    const unsigned grid = grid_for(ctx, vec ? count / 4 + 4 : count);
+    switch (op) {
+        case FZ_OP_MUL: hipLaunchKernelGGL(pw_kernel<FZ_OP_MUL>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
+        case FZ_OP_ADD: hipLaunchKernelGGL(pw_kernel<FZ_OP_ADD>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
+        case FZ_OP_SUB: hipLaunchKernelGGL(pw_kernel<FZ_OP_SUB>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
+        case FZ_OP_NEG: hipLaunchKernelGGL(pw_kernel<FZ_OP_NEG>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, a, out, count, vec, ctx->mod); break;
+        case FZ_OP_MULACC: hipLaunchKernelGGL(pw_kernel<FZ_OP_MULACC>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
+        default: return fz_set_error(FZ_E_BADARG, "unknown pointwise op %d", op);
+    }
+    return fz_check_hip(hipGetLastError(), "pointwise launch");
+}
+
+int fz_launch_pw_bcast(fz_ctx *ctx, const int32_t *a, const int32_t *s, int32_t *out, size_t rows) {
+    if (rows == 0) return FZ_OK;
+    const size_t total = rows * (size_t)ctx->degree;
+    hipLaunchKernelGGL(pw_bcast_kernel, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream, a, s, out, total,
+                       ctx->degree, ctx->mod);
+    return fz_check_hip(hipGetLastError(), "pw_bcast launch");
+}
+
+int fz_launch_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *out, size_t batch, int l) {
+    if (batch == 0) return FZ_OK;
+    if (ctx->degree >= 4)
+        hipLaunchKernelGGL(matvec_kernel, dim3(grid_for(ctx, batch * (size_t)(ctx->degree / 4))), dim3(kBlock), 0,
+                           ctx->stream, A, S, out, batch, l, ctx->degree, ctx->mod);
+    else
+        hipLaunchKernelGGL(matvec_scalar_kernel, dim3(grid_for(ctx, batch * (size_t)ctx->degree)), dim3(kBlock), 0,
+                           ctx->stream, A, S, out, batch, l, ctx->degree, ctx->mod);
+    return fz_check_hip(hipGetLastError(), "matvec launch");
+}
+
+int fz_launch_sign(fz_ctx *ctx, const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig, size_t batch, int l) {
+    if (batch == 0) return FZ_OK;
+    if (ctx->degree < 4) return fz_set_error(FZ_E_UNSUPPORTED, "sign_core needs degree >= 4");
+    const size_t total = batch * (size_t)l * (ctx->degree / 4);
+    hipLaunchKernelGGL(sign_kernel, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream, sk_hat, c_hat, sig, batch,
+                       l, ctx->degree, ctx->mod);
+    return fz_check_hip(hipGetLastError(), "sign launch");
+}
+
+int fz_launch_aggregate_partial(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *partial, size_t N, int l) {
+    if (ctx->degree < 4) return fz_set_error(FZ_E_UNSUPPORTED, "aggregate needs degree >= 4");
+    const size_t cols = (size_t)l * (ctx->degree / 4);
+    int rc = fz_check_hip(hipMemsetAsync(partial, 0, cols * 4 * sizeof(int64_t), ctx->stream), "memset partial");
+    if (rc != FZ_OK || N == 0) return rc;
+    const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);
+    size_t want = ((size_t)ctx->num_cu * 8 + gx - 1) / gx;       // ~8 blocks per CU in total
+    if (want > N) want = N;
+    if (want < 1) want = 1;
+    if (want > 65535) want = 65535;
+    hipLaunchKernelGGL(aggregate_kernel, dim3(gx, (unsigned)want), dim3(kBlock), 0, ctx->stream, sig, alpha, partial, N,
+                       l, ctx->degree, ctx->mod);
+    return fz_check_hip(hipGetLastError(), "aggregate launch");
+}
+
+int fz_launch_target_partial(fz_ctx *ctx, const int32_t *vkL, const int32_t *vkR, const int32_t *c, const int32_t *alpha,
+                             int64_t *partial, size_t N) {
+    int rc = fz_check_hip(hipMemsetAsync(partial, 0, (size_t)ctx->degree * sizeof(int64_t), ctx->stream), "memset target");
+    if (rc != FZ_OK || N == 0) return rc;
+    const unsigned gx = (unsigned)((ctx->degree + kBlock - 1) / kBlock);
+    size_t want = (N + 15) / 16;
+    if (want > (size_t)ctx->num_cu * 4) want = (size_t)ctx->num_cu * 4;
+    if (want < 1) want = 1;
+    hipLaunchKernelGGL(target_kernel, dim3(gx, (unsigned)want), dim3(kBlock), 0, ctx->stream, vkL, vkR, c, alpha, partial,
+                       N, ctx->degree, ctx->mod);
+    return fz_check_hip(hipGetLastError(), "target launch");
+}
+
+int fz_launch_reduce_i64(fz_ctx *ctx, const int64_t *in, int32_t *out, size_t count) {
+    if (count == 0) return FZ_OK;
+    hipLaunchKernelGGL(reduce_i64_kernel, dim3(grid_for(ctx, count)), dim3(kBlock), 0, ctx->stream, in, out, count, ctx->mod);
+    return fz_check_hip(hipGetLastError(), "reduce_i64 launch");
+}
+
+int fz_launch_norm_weight(fz_ctx *ctx, const int32_t *coef, size_t batch, int64_t *max_abs, int32_t *weight) {
+    if (batch == 0) return FZ_OK;
+    size_t cap = (size_t)ctx->num_cu * 16;
+    const unsigned grid = (unsigned)(batch < cap ? batch : cap);
+    hipLaunchKernelGGL(norm_weight_kernel, dim3(grid), dim3(64), 0, ctx->stream, coef, batch, ctx->degree, ctx->q, max_abs, weight);
+    return fz_check_hip(hipGetLastError(), "norm_weight launch");
+}
+
+int fz_launch_verdict(fz_ctx *ctx, const int32_t *target, const int32_t *observed, const int64_t *max_abs,
+                      const int32_t *weight, int l, int64_t beta, int64_t omega, int *d_verdict) {
+    hipLaunchKernelGGL(verdict_kernel, dim3(1), dim3(256), 0, ctx->stream, target, observed, ctx->degree, max_abs, weight,
+                       l, beta, omega, d_verdict);
+    return fz_check_hip(hipGetLastError(), "verdict launch");
+}

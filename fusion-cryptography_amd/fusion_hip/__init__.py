@@ -1,0 +1,14 @@
+"""fusion_hip -- Python face of libfusion_hip.so, the MI355X implementation of the algebra
+hot path of fusion-cryptography (batched negacyclic NTT/INTT, pointwise ring ops, the
+small polynomial matrix-vector products and the fused keygen/sign/aggregate/verify cores).
+
+``algebra`` and ``fusion`` (siblings of this package) mirror the reference's own modules on
+top of it.  No CPU fallback exists: without the built library and a gfx950 device every
+compute call raises FusionHipError.
+"""
+from ._lib import FusionHipError, LIB_PATH, SIGNATURES, load_library
+from .context import (Context, DeviceBuffer, VERDICT_REASONS, get_context,
+                      OP_ADD, OP_MUL, OP_NEG, OP_SUB)
+
+__all__ = ["Context", "DeviceBuffer", "FusionHipError", "LIB_PATH", "SIGNATURES", "VERDICT_REASONS",
+           "get_context", "load_library", "OP_ADD", "OP_MUL", "OP_NEG", "OP_SUB"]

@@ -1,0 +1,106 @@
+"""ctypes binding of libfusion_hip.so (C ABI declared in include/fusion_hip.h).
+
+The shared object is built in-tree by ``__graft_entry__.build()`` into
+``fusion-cryptography_amd/lib/``.  There is NO CPU fallback: if the library or a GPU is
+missing every compute entry point raises :class:`FusionHipError`.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t,
+                    c_uint32, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libfusion_hip.so"))
+
+FZ_OK = 0
+FZ_E_BADARG = -1
+FZ_E_UNSUPPORTED = -2
+FZ_E_HIP = -3
+FZ_E_NODEVICE = -4
+
+
+class FusionHipError(RuntimeError):
+    """Raised when libfusion_hip.so is missing, no GPU is usable, or a call fails."""
+
+    def __init__(self, code, message):
+        super().__init__(f"fusion_hip error {code}: {message}")
+        self.code = code
+
+
+_i32p = POINTER(c_int32)
+_i64p = POINTER(c_int64)
+_u32p = POINTER(c_uint32)
+_ctx = c_void_p
+
+# name -> (restype, argtypes); mirrors include/fusion_hip.h one to one
+SIGNATURES = {
+    "fz_version": (c_char_p, []),
+    "fz_last_error": (c_char_p, []),
+    "fz_device_count": (c_int, [POINTER(c_int)]),
+    "fz_ctx_create": (c_int, [c_int, c_uint32, c_int, c_uint32, c_uint32, POINTER(_ctx)]),
+    "fz_ctx_destroy": (c_int, [_ctx]),
+    "fz_ctx_set_stream": (c_int, [_ctx, c_void_p]),
+    "fz_ctx_synchronize": (c_int, [_ctx]),
+    "fz_ctx_twiddles": (c_int, [_ctx, _u32p, _u32p]),
+    "fz_malloc": (c_int, [_ctx, c_size_t, POINTER(c_void_p)]),
+    "fz_free": (c_int, [_ctx, c_void_p]),
+    "fz_memcpy_h2d": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
+    "fz_memcpy_d2h": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
+    "fz_timer_start": (c_int, [_ctx]),
+    "fz_timer_stop_ms": (c_int, [_ctx, POINTER(c_float)]),
+    "fz_ntt_forward": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
+    "fz_ntt_inverse": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
+    "fz_ntt_forward_host": (c_int, [_ctx, _i32p, c_size_t]),
+    "fz_ntt_inverse_host": (c_int, [_ctx, _i32p, c_size_t]),
+    "fz_pw_mul": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fz_pw_add": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fz_pw_sub": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fz_pw_neg": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
+    "fz_pw_mulacc": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fz_pw_binary_host": (c_int, [_ctx, c_int, _i32p, _i32p, _i32p, c_size_t]),
+    "fz_pw_mul_bcast": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fz_matvec": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
+    "fz_matvec_host": (c_int, [_ctx, _i32p, _i32p, _i32p, c_size_t, c_int]),
+    "fz_keygen_core": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
+    "fz_sign_core": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
+    "fz_aggregate_core": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
+    "fz_aggregate_partial": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
+    "fz_target_partial": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fz_reduce_i64": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
+    "fz_verify_core": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_size_t, c_int, c_int64, c_int64, POINTER(c_int)]),
+    "fz_verify_with_target": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64,
+                                      POINTER(c_int)]),
+    "fz_norm_weight": (c_int, [_ctx, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "fz_norm_weight_host": (c_int, [_ctx, _i32p, c_size_t, _i64p, POINTER(c_int32)]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load (once) and return the ctypes handle; raise FusionHipError if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("FUSION_HIP_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise FusionHipError(FZ_E_NODEVICE,
+                             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback)")
+    try:
+        lib = ctypes.CDLL(p)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise FusionHipError(FZ_E_NODEVICE, f"cannot load {p}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here means header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib, rc):
+    if rc != FZ_OK:
+        raise FusionHipError(rc, (lib.fz_last_error() or b"").decode("utf-8", "replace"))

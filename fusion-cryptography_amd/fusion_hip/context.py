@@ -1,0 +1,268 @@
+"""Context: one (device, modulus, degree, root) instance of the HIP library.
+
+Two faces:
+  * device face  -- methods taking raw device pointers (ints, e.g. ``tensor.data_ptr()``);
+    nothing is copied, kernels are enqueued on the context's stream (throughput path).
+  * host face    -- methods taking/returning numpy int32 arrays; staged through the
+    library's own scratch (used by the drop-in object API in ``algebra`` / ``fusion``).
+"""
+import ctypes
+from ctypes import byref, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+
+import numpy as np
+
+from ._lib import FZ_E_BADARG, FusionHipError, check, load_library
+
+_I32P = ctypes.POINTER(c_int32)
+_I64P = ctypes.POINTER(c_int64)
+
+OP_MUL, OP_ADD, OP_SUB, OP_NEG = 0, 1, 2, 3
+
+VERDICT_REASONS = {
+    0: "",
+    1: "Too many keys.",
+    2: "Number of keys and messages must be equal.",
+    3: "Target doesn't match image of aggregate signature.",
+    4: "Norm of aggregate signature too large.",
+    5: "Weight of aggregate signature too large.",
+}
+
+
+def _as_i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(_I32P)
+
+
+class Context:
+    def __init__(self, modulus, degree, root, inv_root, device=0):
+        self._lib = load_library()
+        self._h = c_void_p()
+        self.modulus, self.degree, self.root, self.inv_root = modulus, degree, root, inv_root
+        self.device = device
+        if not (0 < modulus < 2 ** 31):
+            raise FusionHipError(FZ_E_BADARG, f"modulus {modulus} outside (0, 2^31)")
+        check(self._lib, self._lib.fz_ctx_create(device, modulus, degree, root % modulus, inv_root % modulus,
+                                                 byref(self._h)))
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.fz_ctx_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        check(self._lib, self._lib.fz_ctx_set_stream(self._h, c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        check(self._lib, self._lib.fz_ctx_synchronize(self._h))
+
+    def twiddles(self):
+        f = np.empty(self.degree, dtype=np.uint32)
+        i = np.empty(self.degree, dtype=np.uint32)
+        U32P = ctypes.POINTER(c_uint32)
+        check(self._lib, self._lib.fz_ctx_twiddles(self._h, f.ctypes.data_as(U32P), i.ctypes.data_as(U32P)))
+        return f, i
+
+    # -- device memory helpers ----------------------------------------------------------------
+    def malloc(self, nbytes):
+        p = c_void_p()
+        check(self._lib, self._lib.fz_malloc(self._h, nbytes, byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        check(self._lib, self._lib.fz_free(self._h, c_void_p(ptr)))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self._lib, self._lib.fz_memcpy_h2d(self._h, c_void_p(dptr), c_void_p(arr.ctypes.data), arr.nbytes))
+        self.synchronize()   # the numpy buffer may be a temporary
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        check(self._lib, self._lib.fz_memcpy_d2h(self._h, c_void_p(arr.ctypes.data), c_void_p(dptr), arr.nbytes))
+        return arr
+
+    def timer_start(self):
+        check(self._lib, self._lib.fz_timer_start(self._h))
+
+    def timer_stop_ms(self):
+        ms = c_float()
+        check(self._lib, self._lib.fz_timer_stop_ms(self._h, byref(ms)))
+        return ms.value
+
+    # -- device face (raw pointers) -------------------------------------------------------------
+    def ntt_forward_dev(self, d_in, d_out, batch):
+        check(self._lib, self._lib.fz_ntt_forward(self._h, c_void_p(d_in), c_void_p(d_out), batch))
+
+    def ntt_inverse_dev(self, d_in, d_out, batch):
+        check(self._lib, self._lib.fz_ntt_inverse(self._h, c_void_p(d_in), c_void_p(d_out), batch))
+
+    def pw_dev(self, op, d_a, d_b, d_out, count):
+        fn = {OP_MUL: self._lib.fz_pw_mul, OP_ADD: self._lib.fz_pw_add, OP_SUB: self._lib.fz_pw_sub}[op]
+        check(self._lib, fn(self._h, c_void_p(d_a), c_void_p(d_b), c_void_p(d_out), count))
+
+    def pw_neg_dev(self, d_a, d_out, count):
+        check(self._lib, self._lib.fz_pw_neg(self._h, c_void_p(d_a), c_void_p(d_out), count))
+
+    def pw_mulacc_dev(self, d_acc, d_a, d_b, count):
+        check(self._lib, self._lib.fz_pw_mulacc(self._h, c_void_p(d_acc), c_void_p(d_a), c_void_p(d_b), count))
+
+    def pw_mul_bcast_dev(self, d_a, d_s, d_out, rows):
+        check(self._lib, self._lib.fz_pw_mul_bcast(self._h, c_void_p(d_a), c_void_p(d_s), c_void_p(d_out), rows))
+
+    def matvec_dev(self, d_A, d_S, d_out, batch, l):
+        check(self._lib, self._lib.fz_matvec(self._h, c_void_p(d_A), c_void_p(d_S), c_void_p(d_out), batch, l))
+
+    def keygen_core_dev(self, d_A, d_coef, d_sk_hat, d_vk, batch, l):
+        check(self._lib, self._lib.fz_keygen_core(self._h, c_void_p(d_A), c_void_p(d_coef), c_void_p(d_sk_hat),
+                                                  c_void_p(d_vk), batch, l))
+
+    def sign_core_dev(self, d_sk_hat, d_c_hat, d_sig, batch, l):
+        check(self._lib, self._lib.fz_sign_core(self._h, c_void_p(d_sk_hat), c_void_p(d_c_hat), c_void_p(d_sig),
+                                                batch, l))
+
+    def aggregate_core_dev(self, d_sig, d_alpha, d_out, N, l):
+        check(self._lib, self._lib.fz_aggregate_core(self._h, c_void_p(d_sig), c_void_p(d_alpha), c_void_p(d_out), N, l))
+
+    def aggregate_partial_dev(self, d_sig, d_alpha, d_partial, N, l):
+        check(self._lib, self._lib.fz_aggregate_partial(self._h, c_void_p(d_sig), c_void_p(d_alpha),
+                                                        c_void_p(d_partial), N, l))
+
+    def target_partial_dev(self, d_vkL, d_vkR, d_c, d_alpha, d_partial, N):
+        check(self._lib, self._lib.fz_target_partial(self._h, c_void_p(d_vkL), c_void_p(d_vkR), c_void_p(d_c),
+                                                     c_void_p(d_alpha), c_void_p(d_partial), N))
+
+    def reduce_i64_dev(self, d_in, d_out, count):
+        check(self._lib, self._lib.fz_reduce_i64(self._h, c_void_p(d_in), c_void_p(d_out), count))
+
+    def verify_core_dev(self, d_A, d_sig, d_vkL, d_vkR, d_c, d_alpha, N, l, beta_vf, omega_vf):
+        v = c_int(-1)
+        check(self._lib, self._lib.fz_verify_core(self._h, c_void_p(d_A), c_void_p(d_sig), c_void_p(d_vkL),
+                                                  c_void_p(d_vkR), c_void_p(d_c), c_void_p(d_alpha), N, l,
+                                                  beta_vf, omega_vf, byref(v)))
+        return v.value
+
+    def verify_with_target_dev(self, d_A, d_sig, d_target, l, beta_vf, omega_vf):
+        v = c_int(-1)
+        check(self._lib, self._lib.fz_verify_with_target(self._h, c_void_p(d_A), c_void_p(d_sig), c_void_p(d_target),
+                                                         l, beta_vf, omega_vf, byref(v)))
+        return v.value
+
+    def norm_weight_dev(self, d_coef, batch, d_max_abs, d_weight):
+        check(self._lib, self._lib.fz_norm_weight(self._h, c_void_p(d_coef), batch, c_void_p(d_max_abs),
+                                                  c_void_p(d_weight)))
+
+    # -- host face (numpy in, numpy out) --------------------------------------------------------
+    def _rows(self, a):
+        a = _as_i32(a)
+        if a.size % self.degree:
+            raise FusionHipError(FZ_E_BADARG, f"array of {a.size} values is not a whole number of degree-{self.degree} rows")
+        return a, a.size // self.degree
+
+    def ntt_forward(self, x):
+        """cooley_tukey_ntt of every row; returns a new array."""
+        a, rows = self._rows(x)
+        out = a.copy()
+        check(self._lib, self._lib.fz_ntt_forward_host(self._h, _p(out), rows))
+        return out
+
+    def ntt_inverse(self, x):
+        """gentleman_sande_intt of every row; returns a new array."""
+        a, rows = self._rows(x)
+        out = a.copy()
+        check(self._lib, self._lib.fz_ntt_inverse_host(self._h, _p(out), rows))
+        return out
+
+    def _pw(self, op, a, b):
+        a = _as_i32(a)
+        out = np.empty_like(a)
+        if op == OP_NEG:
+            check(self._lib, self._lib.fz_pw_binary_host(self._h, op, _p(a), None, _p(out), a.size))
+            return out
+        b = _as_i32(b)
+        if a.shape != b.shape:
+            raise FusionHipError(FZ_E_BADARG, f"shape mismatch {a.shape} vs {b.shape}")
+        check(self._lib, self._lib.fz_pw_binary_host(self._h, op, _p(a), _p(b), _p(out), a.size))
+        return out
+
+    def pw_mul(self, a, b):
+        return self._pw(OP_MUL, a, b)
+
+    def pw_add(self, a, b):
+        return self._pw(OP_ADD, a, b)
+
+    def pw_sub(self, a, b):
+        return self._pw(OP_SUB, a, b)
+
+    def pw_neg(self, a):
+        return self._pw(OP_NEG, a, None)
+
+    def matvec(self, A, S):
+        """A: [l][d]; S: [batch][l][d] -> [batch][d]."""
+        A = _as_i32(A)
+        S = _as_i32(S)
+        l = A.shape[0]
+        S3 = S.reshape(-1, l, self.degree)
+        out = np.empty((S3.shape[0], self.degree), dtype=np.int32)
+        check(self._lib, self._lib.fz_matvec_host(self._h, _p(A), _p(S3), _p(out), S3.shape[0], l))
+        return out
+
+    def norm_weight(self, coef):
+        a, rows = self._rows(coef)
+        mx = np.empty(rows, dtype=np.int64)
+        wt = np.empty(rows, dtype=np.int32)
+        check(self._lib, self._lib.fz_norm_weight_host(self._h, _p(a), rows, mx.ctypes.data_as(_I64P), _p(wt)))
+        return mx, wt
+
+
+class DeviceBuffer:
+    """Minimal owning wrapper over fz_malloc for callers that do not use torch."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        self.ptr = ctx.malloc(nbytes)
+
+    @classmethod
+    def from_numpy(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(ctx, arr.nbytes)
+        ctx.h2d(buf.ptr, arr)
+        return buf
+
+    def to_numpy(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        return self.ctx.d2h(out, self.ptr)
+
+    def free(self):
+        if self.ptr:
+            self.ctx.free(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+_CTX_CACHE = {}
+
+
+def get_context(modulus, degree, root, inv_root, device=0):
+    """Memoised contexts: the drop-in object API creates one per parameter tuple."""
+    key = (modulus, degree, root % modulus, inv_root % modulus, device)
+    ctx = _CTX_CACHE.get(key)
+    if ctx is None:
+        ctx = _CTX_CACHE[key] = Context(modulus, degree, root, inv_root, device)
+    return ctx

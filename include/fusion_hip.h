@@ -1,0 +1,171 @@
+/*
+ * fusion_hip.h -- C ABI of libfusion_hip.so, the MI355X (gfx950) implementation of the
+ * algebra hot path of geometry-labs/fusion-cryptography.
+ *
+ * The reference is pure Python and has no FFI; its boundary for this path is the Python
+ * surface of algebra/ntt.py, algebra/polynomials.py, algebra/matrices.py as called from
+ * fusion/fusion.py.  Every entry point below names the reference code it replaces
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add to bind them.
+ *
+ * Conventions
+ *  - Plain C: pointers, sizes, int status codes.  No C++/torch types.
+ *  - All polynomial data are int32, row-major [rows][degree].  Inputs may be ANY int32
+ *    (e.g. the non-centred output of the reference's __neg__); outputs are always the
+ *    centred representative in [-(q-1)/2, (q-1)/2], exactly what the reference's
+ *    cent() (algebra/ntt.py:93-123) returns.
+ *  - Pointers named d_* are DEVICE pointers (hipMalloc / torch.Tensor.data_ptr()).
+ *    Pointers named h_* are HOST pointers; the *_host entry points stage through
+ *    device memory internally (PCIe-inclusive; convenience for the object API).
+ *  - Every call returns FZ_OK (0) or a negative FZ_E_* code; fz_last_error() returns a
+ *    thread-local message.  The library never frees or retains caller buffers.
+ *  - Kernels are enqueued on the context's stream (fz_ctx_set_stream) and the device
+ *    entry points do NOT synchronise; *_host entry points return after completion.
+ *  - One context is used by one host thread at a time (one context + stream per GPU).
+ */
+#ifndef FUSION_HIP_H
+#define FUSION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FZ_API __attribute__((visibility("default")))
+
+/* status codes */
+#define FZ_OK              0
+#define FZ_E_BADARG      (-1)   /* null pointer, bad size, q/degree/root inconsistent   */
+#define FZ_E_UNSUPPORTED (-2)   /* parameters outside what the kernels implement        */
+#define FZ_E_HIP         (-3)   /* a HIP runtime call failed (message in fz_last_error) */
+#define FZ_E_NODEVICE    (-4)   /* no usable gfx950 device                              */
+
+/* verify verdict codes (fusion/fusion.py:686-728) */
+#define FZ_VERDICT_OK              0  /* (True, "")                                              */
+#define FZ_VERDICT_TOO_MANY_KEYS   1  /* "Too many keys."                              :687      */
+#define FZ_VERDICT_LEN_MISMATCH    2  /* "Number of keys and messages must be equal."  :689      */
+#define FZ_VERDICT_TARGET_MISMATCH 3  /* "Target doesn't match image of aggregate signature." :721 */
+#define FZ_VERDICT_NORM            4  /* "Norm of aggregate signature too large."      :725      */
+#define FZ_VERDICT_WEIGHT          5  /* "Weight of aggregate signature too large."    :727      */
+
+typedef struct fz_ctx fz_ctx;
+
+/* ---- library / device ----------------------------------------------------------------- */
+FZ_API const char *fz_version(void);
+FZ_API const char *fz_last_error(void);
+FZ_API int fz_device_count(int *out_count);
+
+/* ---- context: one per (device, modulus, degree, root) ------------------------------------
+ * Replaces the per-call parameter plumbing of the reference (modulus, degree, root,
+ * inv_root, root_order carried by every PolynomialRepresentation, algebra/polynomials.py:16-50)
+ * and the per-call twiddle rebuild `bit_reverse_copy([pow(root, i, q) ...])`
+ * (algebra/polynomials.py:396-397, :414-417; algebra/ntt.py:443-449).
+ * Requirements: q odd prime < 2^31, degree a power of two in [2, 256] (kernel limit 1024),
+ * root a primitive 2*degree-th root of unity mod q, root*inv_root == 1 mod q
+ * (the same conditions PolynomialRepresentation.__init__ checks, polynomials.py:36-45). */
+FZ_API int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t inv_root,
+                         fz_ctx **out);
+FZ_API int fz_ctx_destroy(fz_ctx *ctx);
+FZ_API int fz_ctx_set_stream(fz_ctx *ctx, void *hip_stream);   /* NULL = default stream */
+FZ_API int fz_ctx_synchronize(fz_ctx *ctx);
+/* copies the bit-reversed twiddle tables the context uses (each `degree` uint32 in [0,q));
+ * equal to bit_reverse_copy([pow(root,i,q)]) / ([pow(inv_root,i,q)]). Either may be NULL. */
+FZ_API int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv);
+
+/* ---- device memory helpers (so a host language needs no HIP binding of its own) -------- */
+FZ_API int fz_malloc(fz_ctx *ctx, size_t bytes, void **d_out);
+FZ_API int fz_free(fz_ctx *ctx, void *d_ptr);
+FZ_API int fz_memcpy_h2d(fz_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* async on ctx stream */
+FZ_API int fz_memcpy_d2h(fz_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* returns after completion */
+
+/* ---- timing on the context's stream (hipEvent based) ----------------------------------- */
+FZ_API int fz_timer_start(fz_ctx *ctx);
+FZ_API int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms);        /* records, waits, returns elapsed ms */
+
+/* ---- transforms ---------------------------------------------------------------------------
+ * fz_ntt_forward: cooley_tukey_ntt (algebra/ntt.py:216-291) on `batch` rows.
+ *   natural order in, bit-reversed order out, out[i] = cent(sum_j x[j] psi^((2 brv(i)+1) j)).
+ * fz_ntt_inverse: gentleman_sande_intt (algebra/ntt.py:294-377) incl. the n^{-1} scaling.
+ * d_in == d_out (in place) is allowed.  These are also what transform()
+ * (algebra/polynomials.py:391-433) runs for each polynomial. */
+FZ_API int fz_ntt_forward(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch);
+FZ_API int fz_ntt_inverse(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch);
+FZ_API int fz_ntt_forward_host(fz_ctx *ctx, int32_t *h_data, size_t batch);   /* in place */
+FZ_API int fz_ntt_inverse_host(fz_ctx *ctx, int32_t *h_data, size_t batch);   /* in place */
+
+/* ---- pointwise ring operations on `count` int32 values -------------------------------------
+ * PolynomialNTTRepresentation.__mul__/__add__/__neg__/__sub__ (algebra/polynomials.py:341-385,
+ * :282-318, :325-336); same formulas serve PolynomialCoefficientRepresentation.__add__/__neg__
+ * (:114-163).  neg returns -(x mod q) in [-(q-1), 0] like the reference (NOT centred);
+ * sub = cent(a + neg(b)).  mulacc: acc = cent(acc + cent(a*b)), the inner step of
+ * GeneralMatrix.__mul__ (algebra/matrices.py:127-129). */
+FZ_API int fz_pw_mul(fz_ctx *ctx, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, size_t count);
+FZ_API int fz_pw_add(fz_ctx *ctx, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, size_t count);
+FZ_API int fz_pw_sub(fz_ctx *ctx, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, size_t count);
+FZ_API int fz_pw_neg(fz_ctx *ctx, const int32_t *d_a, int32_t *d_out, size_t count);
+FZ_API int fz_pw_mulacc(fz_ctx *ctx, int32_t *d_acc, const int32_t *d_a, const int32_t *d_b, size_t count);
+/* host-pointer forms used by the object API (op: 0 mul, 1 add, 2 sub, 3 neg (h_b ignored)) */
+FZ_API int fz_pw_binary_host(fz_ctx *ctx, int op, const int32_t *h_a, const int32_t *h_b,
+                             int32_t *h_out, size_t count);
+/* out[row] = cent(a[row] * s) for one NTT-domain polynomial s broadcast over rows:
+ * GeneralMatrix.__mul__(element), algebra/matrices.py:109-114 */
+FZ_API int fz_pw_mul_bcast(fz_ctx *ctx, const int32_t *d_a, const int32_t *d_s, int32_t *d_out, size_t rows);
+
+/* ---- (1 x l) . (l x 1) polynomial matrix-vector product ------------------------------------
+ * GeneralMatrix.__mul__(GeneralMatrix), algebra/matrices.py:115-131, for the only shape the
+ * scheme uses (fusion/fusion.py:369-370, :715-717): out[b] = cent(sum_k A[k] (.) S[b][k]).
+ * A: [l][degree] shared; S: [batch][l][degree]; out: [batch][degree]. */
+FZ_API int fz_matvec(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_S, int32_t *d_out,
+                     size_t batch, int l);
+FZ_API int fz_matvec_host(fz_ctx *ctx, const int32_t *h_A, const int32_t *h_S, int32_t *h_out,
+                          size_t batch, int l);
+
+/* ---- fused scheme cores (the arithmetic inside fusion/fusion.py) ---------------------------
+ * keygen (fusion.py:363-370): coef [batch][2][l][degree] (left rows then right rows, coefficient
+ *   domain) -> sk_hat same shape (NTT of every row) and vk [batch][2][degree] = A . sk_hat.
+ * sign (fusion.py:557): sig[b][k] = cent(cent(L[b][k] (.) c_hat[b]) + R[b][k]).
+ *   sk_hat: [batch][2][l][degree] as produced by keygen; c_hat: [batch][degree]; sig: [batch][l][degree].
+ * aggregate (fusion.py:670-676): out[k] = cent(sum_i sig[i][k] (.) alpha_hat[i]); sig [N][l][degree],
+ *   alpha_hat [N][degree], out [l][degree].
+ * aggregate_partial: the same sum WITHOUT the final reduction, as int64 per coefficient
+ *   (|value| < N * q/2), for cross-GPU summation (ncclSum on int64) followed by
+ *   fz_reduce_i64 -- the one exchange step of the path.
+ * verify (fusion.py:690-727): returns the verdict code in *h_verdict (FZ_VERDICT_*).
+ *   A [l][degree], sig [l][degree] aggregate, vkL/vkR/c_hat/alpha_hat [N][degree]. */
+FZ_API int fz_keygen_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef,
+                          int32_t *d_sk_hat, int32_t *d_vk, size_t batch, int l);
+FZ_API int fz_sign_core(fz_ctx *ctx, const int32_t *d_sk_hat, const int32_t *d_c_hat,
+                        int32_t *d_sig, size_t batch, int l);
+FZ_API int fz_aggregate_core(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat,
+                             int32_t *d_out, size_t N, int l);
+FZ_API int fz_aggregate_partial(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat,
+                                int64_t *d_partial, size_t N, int l);
+/* target partial for verify: sum_i (vkL_i (.) c_i + vkR_i) (.) alpha_i as int64 [degree] */
+FZ_API int fz_target_partial(fz_ctx *ctx, const int32_t *d_vkL, const int32_t *d_vkR,
+                             const int32_t *d_c_hat, const int32_t *d_alpha_hat,
+                             int64_t *d_partial, size_t N);
+/* out[i] = cent(in[i]) for int64 sums */
+FZ_API int fz_reduce_i64(fz_ctx *ctx, const int64_t *d_in, int32_t *d_out, size_t count);
+FZ_API int fz_verify_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig,
+                          const int32_t *d_vkL, const int32_t *d_vkR,
+                          const int32_t *d_c_hat, const int32_t *d_alpha_hat,
+                          size_t N, int l, int64_t beta_vf, int64_t omega_vf, int *h_verdict);
+/* verify with a precomputed target [degree] (multi-GPU: target summed across ranks first) */
+FZ_API int fz_verify_with_target(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig,
+                                 const int32_t *d_target, int l,
+                                 int64_t beta_vf, int64_t omega_vf, int *h_verdict);
+
+/* ---- norm / weight of coefficient rows -------------------------------------------------------
+ * PolynomialCoefficientRepresentation.norm("infty") / weight(), algebra/polynomials.py:221-227:
+ * max |x| over the STORED values and #{x : x mod q != 0}, per row. */
+FZ_API int fz_norm_weight(fz_ctx *ctx, const int32_t *d_coef, size_t batch,
+                          int64_t *d_max_abs, int32_t *d_weight);
+FZ_API int fz_norm_weight_host(fz_ctx *ctx, const int32_t *h_coef, size_t batch,
+                               int64_t *h_max_abs, int32_t *h_weight);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUSION_HIP_H */

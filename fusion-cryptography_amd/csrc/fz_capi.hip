@@ -86,14 +86,22 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     FZ_REQUIRE(out, "out is NULL");
     *out = nullptr;
     FZ_REQUIRE(q >= 3 && (q & 1u) && q < 0x80000000u, "modulus %u must be odd, >= 3 and < 2^31", q);
-    FZ_REQUIRE(degree >= 2 && (degree & (degree - 1)) == 0, "degree %d must be a power of two >= 2", degree);
-    if (degree > 256) return fz_set_error(FZ_E_UNSUPPORTED, "degree %d > 256 not supported", degree);
-    FZ_REQUIRE(((uint64_t)q - 1) % (2u * (uint64_t)degree) == 0, "2*degree=%d does not divide q-1", 2 * degree);
-    FZ_REQUIRE(root > 0 && root < q && inv_root > 0 && inv_root < q, "root / inv_root must be in (0, q)");
-    // primitive 2*degree-th root (order a power of two): root^degree == -1
-    FZ_REQUIRE(powmod_u64(root, (uint64_t)degree, q) == (uint64_t)q - 1,
-               "root %u is not a primitive %d-th root of unity mod %u", root, 2 * degree, q);
-    FZ_REQUIRE(((uint64_t)root * inv_root) % q == 1, "root * inv_root != 1 mod q");
+    // root == 0: "ring-only" context (pointwise ops, norm/weight, matvec on rows of `degree` values;
+    // no transform tables).  The reference lets polynomial objects exist for parameter tuples that
+    // admit no NTT (e.g. root_order 1), and their + - * norm weight still work.
+    const bool ring_only = (root == 0);
+    if (ring_only) {
+        FZ_REQUIRE(degree >= 1 && degree <= (1 << 20), "degree %d out of range", degree);
+    } else {
+        FZ_REQUIRE(degree >= 2 && (degree & (degree - 1)) == 0, "degree %d must be a power of two >= 2", degree);
+        if (degree > 256) return fz_set_error(FZ_E_UNSUPPORTED, "degree %d > 256 not supported by the NTT kernels", degree);
+        FZ_REQUIRE(((uint64_t)q - 1) % (2u * (uint64_t)degree) == 0, "2*degree=%d does not divide q-1", 2 * degree);
+        FZ_REQUIRE(root > 0 && root < q && inv_root > 0 && inv_root < q, "root / inv_root must be in (0, q)");
+        // primitive 2*degree-th root (order a power of two): root^degree == -1
+        FZ_REQUIRE(powmod_u64(root, (uint64_t)degree, q) == (uint64_t)q - 1,
+                   "root %u is not a primitive %d-th root of unity mod %u", root, 2 * degree, q);
+        FZ_REQUIRE(((uint64_t)root * inv_root) % q == 1, "root * inv_root != 1 mod q");
+    }
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -111,50 +119,53 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->q = q; c->root = root; c->inv_root = inv_root;
     c->degree = degree;
-    c->logd = 0;
-    while ((1 << c->logd) < degree) ++c->logd;
+    c->logd = ring_only ? -1 : 0;
+    if (!ring_only) while ((1 << c->logd) < degree) ++c->logd;
     c->mod.q = (double)q;
     c->mod.qinv = 1.0 / (double)q;
 
-    const int n = degree, k = c->logd;
-    c->h_tw = (uint32_t *)malloc(sizeof(uint32_t) * n);
-    c->h_itw = (uint32_t *)malloc(sizeof(uint32_t) * n);
-    double *tw = (double *)malloc(sizeof(double) * n), *itw = (double *)malloc(sizeof(double) * n);
-    for (int i = 0; i < n; ++i) {
-        // bit_reverse_copy([pow(root, i, q)])  (algebra/polynomials.py:396-397, :416-417)
-        c->h_tw[i] = (uint32_t)powmod_u64(root, bitrev((unsigned)i, k), q);
-        c->h_itw[i] = (uint32_t)powmod_u64(inv_root, bitrev((unsigned)i, k), q);
-        tw[i] = (double)c->h_tw[i];
-        itw[i] = (double)c->h_itw[i];
-    }
-    const uint64_t n_inv = powmod_u64((uint64_t)n, (uint64_t)q - 2, q);
-    for (int i = 0; i < 16; ++i) {
-        c->twA.w[i] = (i < n) ? tw[i] : 0.0;
-        c->itwA.w[i] = (i < n) ? itw[i] : 0.0;
-    }
-    c->twA.n_inv = c->itwA.n_inv = (double)n_inv;
-    c->twA.w1_n_inv = 0.0;
-    c->itwA.w1_n_inv = (double)(((unsigned __int128)c->h_itw[1] * n_inv) % q);
-
-    // per-lane tables of the contiguous pass ([NE][L]); see fz_ntt.hip / tools/ntt_layout_model.py
-    double *twB = nullptr, *itwB = nullptr;
+    double *tw = nullptr, *itw = nullptr, *twB = nullptr, *itwB = nullptr;
     size_t nB = 0;
-    if (k >= 5) {
-        const int L = n / 16, SB = k - 4, NE = 16 - (16 >> SB);
-        nB = (size_t)NE * L;
-        twB = (double *)malloc(sizeof(double) * nB);
-        itwB = (double *)malloc(sizeof(double) * nB);
-        for (int ls = 0; ls < SB; ++ls) {
-            {   // forward: distance 2^(SB-1-ls), ng groups per lane
-                const int t = 1 << (SB - 1 - ls), ng = 16 / (2 * t);
-                const int ebase = (16 >> SB) * ((1 << ls) - 1);
-                for (int g = 0; g < ng; ++g)
-                    for (int b = 0; b < L; ++b) twB[(size_t)(ebase + g) * L + b] = tw[(16 << ls) + b * ng + g];
-            }
-            {   // inverse: distance 2^ls
-                const int ng = 8 >> ls, ebase = 16 - (16 >> ls);
-                for (int g = 0; g < ng; ++g)
-                    for (int b = 0; b < L; ++b) itwB[(size_t)(ebase + g) * L + b] = itw[(n >> (ls + 1)) + b * ng + g];
+    const int n = ring_only ? 0 : degree, k = c->logd;
+    if (!ring_only) {
+        c->h_tw = (uint32_t *)malloc(sizeof(uint32_t) * n);
+        c->h_itw = (uint32_t *)malloc(sizeof(uint32_t) * n);
+        tw = (double *)malloc(sizeof(double) * n);
+        itw = (double *)malloc(sizeof(double) * n);
+        for (int i = 0; i < n; ++i) {
+            // bit_reverse_copy([pow(root, i, q)])  (algebra/polynomials.py:396-397, :416-417)
+            c->h_tw[i] = (uint32_t)powmod_u64(root, bitrev((unsigned)i, k), q);
+            c->h_itw[i] = (uint32_t)powmod_u64(inv_root, bitrev((unsigned)i, k), q);
+            tw[i] = (double)c->h_tw[i];
+            itw[i] = (double)c->h_itw[i];
+        }
+        const uint64_t n_inv = powmod_u64((uint64_t)n, (uint64_t)q - 2, q);
+        for (int i = 0; i < 16; ++i) {
+            c->twA.w[i] = (i < n) ? tw[i] : 0.0;
+            c->itwA.w[i] = (i < n) ? itw[i] : 0.0;
+        }
+        c->twA.n_inv = c->itwA.n_inv = (double)n_inv;
+        c->twA.w1_n_inv = 0.0;
+        c->itwA.w1_n_inv = (double)(((unsigned __int128)c->h_itw[1] * n_inv) % q);
+
+        // per-lane tables of the contiguous pass ([NE][L]); see fz_ntt.hip / tools/ntt_layout_model.py
+        if (k >= 5) {
+            const int L = n / 16, SB = k - 4, NE = 16 - (16 >> SB);
+            nB = (size_t)NE * L;
+            twB = (double *)malloc(sizeof(double) * nB);
+            itwB = (double *)malloc(sizeof(double) * nB);
+            for (int ls = 0; ls < SB; ++ls) {
+                {   // forward: distance 2^(SB-1-ls), ng groups per lane
+                    const int t = 1 << (SB - 1 - ls), ng = 16 / (2 * t);
+                    const int ebase = (16 >> SB) * ((1 << ls) - 1);
+                    for (int g = 0; g < ng; ++g)
+                        for (int b = 0; b < L; ++b) twB[(size_t)(ebase + g) * L + b] = tw[(16 << ls) + b * ng + g];
+                }
+                {   // inverse: distance 2^ls
+                    const int ng = 8 >> ls, ebase = 16 - (16 >> ls);
+                    for (int g = 0; g < ng; ++g)
+                        for (int b = 0; b < L; ++b) itwB[(size_t)(ebase + g) * L + b] = itw[(n >> (ls + 1)) + b * ng + g];
+                }
             }
         }
     }
@@ -166,7 +177,7 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
     if (rc == FZ_OK) rc = upload_doubles(itwB, nB, &c->d_itwB);
     if (rc == FZ_OK) rc = fz_check_hip(hipMalloc((void **)&c->d_verdict, sizeof(int)), "verdict alloc");
-    if (rc == FZ_OK) rc = fz_ntt_query_grid(c);
+    if (rc == FZ_OK && !ring_only) rc = fz_ntt_query_grid(c);
     free(tw); free(itw); free(twB); free(itwB);
     if (rc != FZ_OK) { fz_ctx_destroy(c); return rc; }
     *out = c;
@@ -205,6 +216,7 @@ int fz_ctx_synchronize(fz_ctx *ctx) {
 
 int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv) {
     FZ_REQUIRE(ctx, "ctx is NULL");
+    if (ctx->logd < 0) return fz_set_error(FZ_E_UNSUPPORTED, "ring-only context has no transform tables");
     if (h_fwd) memcpy(h_fwd, ctx->h_tw, sizeof(uint32_t) * ctx->degree);
     if (h_inv) memcpy(h_inv, ctx->h_itw, sizeof(uint32_t) * ctx->degree);
     return FZ_OK;

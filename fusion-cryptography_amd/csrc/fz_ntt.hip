@@ -314,7 +314,10 @@ int fz_ntt_query_grid(fz_ctx *ctx) {
 }
 
 int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse) {
+    if (ctx->logd < 0) return fz_set_error(FZ_E_UNSUPPORTED, "ring-only context (created with root 0) has no transforms");
     if (batch == 0) return FZ_OK;
+    if ((((uintptr_t)d_in | (uintptr_t)d_out) & 15) != 0 && ctx->logd >= 2)
+        return fz_set_error(FZ_E_BADARG, "transform buffers must be 16-byte aligned");
     switch (ctx->logd) {
         case 1: return launch_small<1>(ctx, d_in, d_out, batch, inverse);
         case 2: return launch_small<2>(ctx, d_in, d_out, batch, inverse);

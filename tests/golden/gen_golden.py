@@ -91,10 +91,17 @@ def algebra_case(out, tag, q, d, root, n_seeded, rank):
     # pointwise ops through the reference's classes (operands: every row against the next)
     def P(vals):
         return PolyN(modulus=q, degree=d, root=root, inv_root=inv_root, root_order=2 * d, values=list(vals))
-    a_rows, b_rows = rows, rows[1:] + rows[:1]
-    out[f"{tag}_pw_mul"] = np.array([(P(a) * P(b)).values for a, b in zip(a_rows, b_rows)], dtype=np.int32)
+    # the all-zero row is never the right operand: `x * zero_poly` returns the int 0 and
+    # `x + zero_poly` returns x itself in the reference (polynomials.py:283-284, :342-343); those
+    # quirks are covered by object-level tests, not by the kernel vectors
+    a_rows, b_rows = rows, rows[1:] + rows[1:2]
+    def vals(r):
+        return [0] * d if isinstance(r, int) else r.values       # `x * zero_poly` is the int 0
+    out[f"{tag}_pw_mul"] = np.array([vals(P(a) * P(b)) for a, b in zip(a_rows, b_rows)], dtype=np.int32)
     out[f"{tag}_pw_add"] = np.array([(P(a) + P(b)).values for a, b in zip(a_rows, b_rows)], dtype=np.int32)
     out[f"{tag}_pw_sub"] = np.array([(P(a) - P(b)).values for a, b in zip(a_rows, b_rows)], dtype=np.int32)
+    # rows whose right operand is == 0 mod q: add/sub return the LEFT operand object unchanged there
+    out[f"{tag}_pw_b_is_zero"] = np.array([all(v % q == 0 for v in b) for b in b_rows])
     out[f"{tag}_pw_neg"] = np.array([(-P(a)).values for a in a_rows], dtype=np.int64)
 
     # coefficient-domain schoolbook product == NTT product (G8)

@@ -1,0 +1,50 @@
+"""Glue between the drop-in object API (lists of Python ints) and the HIP library.
+
+Marshalling only: Python ints -> centred int32 (values are reduced mod q first, which never
+changes a result because every library output depends on its inputs only through their
+residues) and int32 -> Python ints.  All arithmetic happens in libfusion_hip.so; if the
+library or a GPU is missing, the first compute call raises FusionHipError.
+"""
+import numpy as np
+
+from fusion_hip import FusionHipError, get_context
+from fusion_hip._lib import FZ_E_UNSUPPORTED
+
+INT32_MIN, INT32_MAX = -(2 ** 31), 2 ** 31 - 1
+
+
+def check_modulus(q):
+    if not (isinstance(q, int) and 3 <= q < 2 ** 31 and q % 2 == 1):
+        raise FusionHipError(FZ_E_UNSUPPORTED,
+                             f"modulus {q} is outside what the HIP kernels implement (odd, 3 <= q < 2^31); "
+                             "there is no CPU fallback")
+
+
+def to_i32(rows, q):
+    """list (or list of lists) of Python ints -> int32 array; big values are reduced mod q."""
+    try:
+        a = np.array(rows, dtype=np.int64)
+        if a.size and (a.min() < INT32_MIN or a.max() > INT32_MAX):
+            raise OverflowError
+    except OverflowError:
+        half = q // 2
+
+        def red(v):
+            y = v % q
+            return y - q if y > half else y
+        if rows and isinstance(rows[0], (list, tuple)):
+            a = np.array([[red(v) for v in r] for r in rows], dtype=np.int64)
+        else:
+            a = np.array([red(v) for v in rows], dtype=np.int64)
+    return a.astype(np.int32)
+
+
+def ntt_ctx(q, degree, root, inv_root):
+    check_modulus(q)
+    return get_context(q, degree, root % q, inv_root % q)
+
+
+def ring_ctx(q, degree):
+    """pointwise-only context (no transform tables)"""
+    check_modulus(q)
+    return get_context(q, degree, 0, 0)

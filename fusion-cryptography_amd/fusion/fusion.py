@@ -1,0 +1,407 @@
+"""Drop-in for the reference's ``fusion.fusion``: the same parameter tables, key / signature
+types and the ``fusion_setup / keygen / sign / aggregate / verify`` surface, with the algebra
+executed by the fused MI355X cores of libfusion_hip.so.
+
+Reference surface mirrored (file:line in the reference checkout):
+  constants & PREFIX_PARAMETERS :16-141 · sample_coefficient_matrix :144 · sample_ntt_matrix :176 ·
+  Params :204 · fusion_setup :294 · OneTimeSigningKey :298 · OneTimeVerificationKey :320 ·
+  keygen :338 · SignatureChallenge :376 · Signature :392 · hash_message_to_int :405 ·
+  hash_vk_and_int_to_bytes :412 · decode_bytes_to_polynomial_coefficients :422 · parse_challenge :484 ·
+  hash_ch :511 · sign :534 · AggregationCoefficient :560 · hash_vks_and_ints_and_challs_to_bytes :573 ·
+  decode_bytes_to_agg_coefs :594 · hash_ag :632 · aggregate :655 · verify :680
+
+What runs where
+  * host (Python stdlib, byte-for-byte the reference's formats): seeding/sampling with ``random``,
+    SHA3-256 / SHAKE-256 over ``str()`` of the key objects, the byte -> sparse-ternary decoder.
+  * device: every NTT/INTT and all ring arithmetic -- keygen (NTT of 2*rank rows + two
+    matrix-vector products) = fz_keygen_core, sign = fz_sign_core, aggregate = fz_aggregate_core,
+    verify = fz_verify_core (target sum, A.sigma, rank INTTs, norm/weight, verdict).
+"""
+from hashlib import sha3_256, shake_256
+from math import ceil, log2
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from algebra import _backend
+from algebra.matrices import GeneralMatrix
+from algebra.polynomials import (PolynomialCoefficientRepresentation, PolynomialNTTRepresentation,
+                                 sample_polynomial_coefficient_representation,
+                                 sample_polynomial_ntt_representation, transform)
+from fusion_hip import VERDICT_REASONS
+
+# Toy prototype of a research scheme, like the reference: not for production use.
+
+PREFIX_PARAMETERS: dict = {}
+PRIME: int = 2147465729
+DEGREE_128: int = 2 ** 6
+DEGREE_256: int = 2 ** 8
+ROOT_ORDER_128: int = 2 * DEGREE_128
+ROOT_ORDER_256: int = 2 * DEGREE_256
+RANK_128: int = 195
+RANK_256: int = 83
+CAPACITY_128: int = 1796
+CAPACITY_256: int = 2818
+CH_WEIGHT_128: int = 27
+CH_WEIGHT_256: int = 60
+AG_WEIGHT_128: int = 35
+AG_WEIGHT_256: int = 60
+SK_BD_128: int = 52
+SK_BD_256: int = 52
+CH_BD_128: int = 3
+CH_BD_256: int = 1
+AG_BD_128: int = 2
+AG_BD_256: int = 1
+ROOT_128: int = 23584283
+ROOT_256: int = 3337519
+# two-byte domain-separation tags: (security level id, usage id)
+SIGN_PRE_HASH_DST_128: bytes = bytes([1, 0])
+SIGN_PRE_HASH_DST_256: bytes = bytes([3, 0])
+SIGN_HASH_DST_128: bytes = bytes([1, 1])
+SIGN_HASH_DST_256: bytes = bytes([3, 1])
+AGG_XOF_DST_128: bytes = bytes([1, 2])
+AGG_XOF_DST_256: bytes = bytes([3, 2])
+
+VF_BD_INTERMEDIATE_128: int = SK_BD_128 * (1 + min(DEGREE_128, CH_WEIGHT_128) * CH_BD_128)
+VF_BD_INTERMEDIATE_256: int = SK_BD_256 * (1 + min(DEGREE_256, CH_WEIGHT_256) * CH_BD_256)
+VF_BD_128: int = CAPACITY_128 * min(DEGREE_128, AG_WEIGHT_128) * AG_BD_128 * VF_BD_INTERMEDIATE_128
+VF_BD_256: int = CAPACITY_256 * min(DEGREE_256, AG_WEIGHT_256) * AG_BD_256 * VF_BD_INTERMEDIATE_256
+
+
+def _parameter_set(capacity, degree, root, rank, dsts, ch_weight, ag_weight, sk_bd, vf_bd):
+    return {
+        "capacity": capacity, "modulus": PRIME, "degree": degree, "root_order": 2 * degree, "root": root,
+        "inv_root": pow(root, PRIME - 2, PRIME),
+        "num_rows_pub_challenge": 1, "num_rows_sk": rank, "num_rows_vk": 1,
+        "num_cols_pub_challenge": rank, "num_cols_sk": 1, "num_cols_vk": 1,
+        "sign_pre_hash_dst": dsts[0], "sign_hash_dst": dsts[1], "agg_xof_dst": dsts[2],
+        # the live challenge / aggregation-coefficient bounds are 1 for both sets (fusion.py:88-89, :114-115)
+        "beta_sk": sk_bd, "beta_ch": 1, "beta_ag": 1,
+        "omega_sk": degree, "omega_ch": ch_weight, "omega_ag": ag_weight,
+        "beta_vf": vf_bd, "omega_vf": degree,
+    }
+
+
+PREFIX_PARAMETERS[128] = _parameter_set(CAPACITY_128, DEGREE_128, ROOT_128, RANK_128,
+                                        (SIGN_PRE_HASH_DST_128, SIGN_HASH_DST_128, AGG_XOF_DST_128),
+                                        CH_WEIGHT_128, AG_WEIGHT_128, SK_BD_128, VF_BD_128)
+PREFIX_PARAMETERS[256] = _parameter_set(CAPACITY_256, DEGREE_256, ROOT_256, RANK_256,
+                                        (SIGN_PRE_HASH_DST_256, SIGN_HASH_DST_256, AGG_XOF_DST_256),
+                                        CH_WEIGHT_256, AG_WEIGHT_256, SK_BD_256, VF_BD_256)
+
+for _secpar, _set in PREFIX_PARAMETERS.items():
+    # XOF byte budgets (fusion.py:123-141): a coefficient needs its bits plus `secpar` bias bits
+    _set["bytes_for_one_coef_bdd_by_beta_ch"] = ceil(ceil(log2(2 * _set["beta_ch"] + 1) / 8) + _secpar / 8)
+    _set["bytes_for_one_coef_bdd_by_beta_ag"] = ceil(ceil(log2(2 * _set["beta_ag"] + 1) / 8) + _secpar / 8)
+    _set["bytes_for_poly_shuffle"] = _set["degree"] * ceil(ceil(log2(_set["degree"]) / 8) + _secpar / 8)
+
+_PARAM_FIELDS = ("capacity", "modulus", "degree", "root_order", "root", "inv_root", "num_rows_pub_challenge",
+                 "num_rows_sk", "num_rows_vk", "num_cols_pub_challenge", "num_cols_sk", "num_cols_vk",
+                 "sign_pre_hash_dst", "sign_hash_dst", "agg_xof_dst", "bytes_for_one_coef_bdd_by_beta_ch",
+                 "bytes_for_one_coef_bdd_by_beta_ag", "bytes_for_poly_shuffle", "beta_sk", "beta_ch", "beta_ag",
+                 "beta_vf", "omega_sk", "omega_ch", "omega_ag", "omega_vf")
+
+
+def sample_coefficient_matrix(seed: Optional[int], modulus: int, degree: int, root_order: int, root: int,
+                              inv_root: int, num_rows: int, num_cols: int, norm_bound: int,
+                              weight_bound: int) -> GeneralMatrix:
+    """Every entry is sampled with the SAME seed (fusion.py:156-173), so all entries are equal."""
+    return GeneralMatrix(matrix=[[sample_polynomial_coefficient_representation(
+        modulus=modulus, degree=degree, root_order=root_order, root=root, inv_root=inv_root,
+        norm_bound=norm_bound, weight_bound=weight_bound, seed=seed) for _ in range(num_cols)]
+        for _ in range(num_rows)])
+
+
+def sample_ntt_matrix(seed: Optional[int], modulus: int, degree: int, root_order: int, root: int, inv_root: int,
+                      num_rows: int, num_cols: int) -> GeneralMatrix:
+    return GeneralMatrix(matrix=[[sample_polynomial_ntt_representation(
+        modulus=modulus, degree=degree, root_order=root_order, root=root, inv_root=inv_root, seed=seed)
+        for _ in range(num_cols)] for _ in range(num_rows)])
+
+
+class Params(object):
+    def __init__(self, secpar: int, seed: Optional[int]):
+        # an unknown secpar silently yields an attribute-less object, as in the reference (:235)
+        if secpar in PREFIX_PARAMETERS:
+            self.secpar = secpar
+            table = PREFIX_PARAMETERS[secpar]
+            for name in _PARAM_FIELDS:
+                setattr(self, name, table[name])
+            self.public_challenge = sample_ntt_matrix(
+                seed=seed, modulus=self.modulus, degree=self.degree, root_order=self.root_order, root=self.root,
+                inv_root=self.inv_root, num_rows=self.num_rows_pub_challenge, num_cols=self.num_cols_pub_challenge)
+
+    def __str__(self) -> str:
+        order = ("secpar", "capacity", "modulus", "degree", "root_order", "root", "inv_root",
+                 "num_rows_pub_challenge", "num_rows_sk", "num_rows_vk", "num_cols_pub_challenge", "num_cols_sk",
+                 "num_cols_vk", "beta_sk", "beta_ch", "beta_ag", "beta_vf", "omega_sk", "omega_ch", "omega_ag",
+                 "omega_vf", "public_challenge", "sign_pre_hash_dst", "sign_hash_dst", "agg_xof_dst",
+                 "bytes_for_one_coef_bdd_by_beta_ch", "bytes_for_one_coef_bdd_by_beta_ag", "bytes_for_poly_shuffle")
+        return "Params(" + ", ".join(f"{k}={str(getattr(self, k))}" for k in order) + ")"
+
+    def __repr__(self) -> str:
+        return self.__str__()
+
+    def __eq__(self, other):
+        return self.__dict__ == other.__dict__
+
+
+def fusion_setup(secpar: int, seed: Optional[int]) -> Params:
+    return Params(secpar=secpar, seed=seed)
+
+
+class OneTimeSigningKey(object):
+    def __init__(self, seed: Optional[int], left_sk_hat: GeneralMatrix, right_sk_hat: GeneralMatrix):
+        self.seed = seed
+        self.left_sk_hat = left_sk_hat
+        self.right_sk_hat = right_sk_hat
+
+    def __str__(self):
+        return (f"OneTimeSigningKey(seed={self.seed}, left_sk_hat={str(self.left_sk_hat)}, "
+                f"right_sk_hat={str(self.right_sk_hat)})")
+
+    def __repr__(self):
+        return self.__str__()
+
+
+class OneTimeVerificationKey(object):
+    def __init__(self, left_vk_hat: GeneralMatrix, right_vk_hat: GeneralMatrix):
+        self.left_vk_hat = left_vk_hat
+        self.right_vk_hat = right_vk_hat
+
+    def __str__(self):
+        return f"OneTimeVerificationKey(left_vk_hat={self.left_vk_hat}, right_vk_hat={self.right_vk_hat})"
+
+    def __repr__(self):
+        return self.__str__()
+
+
+OneTimeKeyTuple = Tuple[OneTimeSigningKey, OneTimeVerificationKey]
+
+
+# ---- array <-> object marshalling ----------------------------------------------------------------
+def _ctx(params):
+    return _backend.ntt_ctx(params.modulus, params.degree, params.root, params.inv_root)
+
+
+def _ntt_poly(params, values):
+    return PolynomialNTTRepresentation(modulus=params.modulus, degree=params.degree, root=params.root,
+                                       inv_root=params.inv_root, root_order=params.root_order, values=values)
+
+
+def _column(params, arr):
+    """[rows][d] int32 -> rows x 1 GeneralMatrix of NTT-domain polynomials"""
+    return GeneralMatrix(matrix=[[_ntt_poly(params, row)] for row in arr.tolist()])
+
+
+def _rows_of(matrix: GeneralMatrix, q):
+    """GeneralMatrix of polynomials -> [rows*cols][d] int32 (row-major)"""
+    return _backend.to_i32([z._data() for row in matrix.matrix for z in row], q)
+
+
+def keygen(params: Params, seed: Optional[int]) -> OneTimeKeyTuple:
+    """fusion.py:338-373: two coefficient-domain secret vectors (seeds `seed`, `seed + 1`), their
+    NTTs, and vk = public_challenge * sk_hat -- the arithmetic is ONE fz_keygen_core call."""
+    q = params.modulus
+    halves = []
+    for s in (seed, seed + 1):
+        coefs = sample_coefficient_matrix(
+            seed=s, modulus=q, degree=params.degree, root_order=params.root_order, root=params.root,
+            inv_root=params.inv_root, num_rows=params.num_rows_sk, num_cols=params.num_cols_sk,
+            norm_bound=params.beta_sk, weight_bound=params.omega_sk)
+        halves.append(_rows_of(coefs, q))
+    A = _rows_of(params.public_challenge, q)
+    sk_hat, vk = _ctx(params).keygen_core(A, np.stack(halves)[None])
+    sk = OneTimeSigningKey(seed=seed, left_sk_hat=_column(params, sk_hat[0, 0]),
+                           right_sk_hat=_column(params, sk_hat[0, 1]))
+    vkey = OneTimeVerificationKey(left_vk_hat=_column(params, vk[0, 0:1]), right_vk_hat=_column(params, vk[0, 1:2]))
+    return sk, vkey
+
+
+class SignatureChallenge(object):
+    def __init__(self, c_hat: PolynomialNTTRepresentation):
+        self.c_hat = c_hat
+
+    def __str__(self):
+        return f"SignatureChallenge(c_hat={str(self.c_hat)})"
+
+    def __repr__(self):
+        return self.__str__()
+
+    def __eq__(self, other):
+        return self.c_hat == other.c_hat
+
+
+class Signature(object):
+    def __init__(self, signature_hat: GeneralMatrix):
+        self.signature_hat = signature_hat
+
+    def __str__(self):
+        return f"Signature(signature_hat={str(self.signature_hat)})"
+
+    def __repr__(self):
+        return self.__str__()
+
+
+# ---- hash -> challenge pipeline (host; formats are part of the scheme) --------------------------------
+def hash_message_to_int(params: Params, message: str) -> int:
+    salted = (params.sign_pre_hash_dst.decode("utf-8") + "," + message).encode()
+    return int.from_bytes(sha3_256(salted).digest(), byteorder="little")
+
+
+def hash_vk_and_int_to_bytes(params: Params, key: OneTimeVerificationKey, i: int, n: int) -> bytes:
+    x = (params.sign_hash_dst.decode("utf-8") + "," + str(key) + "," + str(i)).encode("utf-8")
+    return shake_256(x).digest(n)
+
+
+def decode_bytes_to_polynomial_coefficients(b: bytes, log2_bias: int, modulus: int, degree: int, norm_bound: int,
+                                            weight_bound: int) -> List[int]:
+    """XOF bytes -> sparse signed coefficient list (fusion.py:422-481): sign bits, then
+    `weight_bound` magnitudes, then a partial Fisher-Yates driven by big-endian index draws."""
+    num_coefs = max(1, min(degree, weight_bound))
+    bound = max(1, min(modulus // 2, norm_bound))
+    coef_bytes = ceil((log2(bound) + 1 + log2_bias) / 8)
+    index_bytes = ceil((log2(degree) + log2_bias) / 8)
+    sign_bytes = ceil(weight_bound / 8)
+    needed = sign_bytes + (coef_bytes + index_bytes) * weight_bound
+    if len(b) < needed:
+        raise ValueError(f"Too few bytes to decode polynomial. Expected {needed} but got {len(b)}")
+    # sign i is bit i (LSB first) of the big-endian integer in the leading bytes; 1 -> +1, 0 -> -1
+    sign_word = int.from_bytes(b[:sign_bytes], byteorder="big")
+    pos = sign_bytes
+    coefficients: List[int] = []
+    for i in range(weight_bound):
+        magnitude = int.from_bytes(b[pos:pos + coef_bytes], byteorder="big") % bound + 1
+        pos += coef_bytes
+        coefficients.append(magnitude if (sign_word >> i) & 1 else -magnitude)
+    coefficients.extend([0] * (degree - len(coefficients)))
+    if num_coefs < degree:
+        for i in range(degree - 1, weight_bound, -1):
+            j = int.from_bytes(b[pos:pos + index_bytes], byteorder="big") % (i + 1)
+            pos += index_bytes
+            coefficients[i], coefficients[j] = coefficients[j], coefficients[i]
+    return coefficients
+
+
+def _challenge_bytes_needed(params: Params) -> int:
+    num_coefs = max(0, min(params.degree, params.omega_ch))
+    bound = max(0, min(params.modulus // 2, params.beta_ch))
+    coef_bytes = ceil((log2(bound) + 1 + params.secpar) / 8)
+    index_bytes = ceil((log2(params.degree) + params.secpar) / 8)
+    return ceil(params.omega_ch / 8) + coef_bytes * num_coefs + params.degree * index_bytes
+
+
+def _coef_poly(params, coefficients):
+    return PolynomialCoefficientRepresentation(modulus=params.modulus, degree=params.degree, root=params.root,
+                                               inv_root=params.inv_root, root_order=params.root_order,
+                                               coefficients=coefficients)
+
+
+def parse_challenge(params: Params, b: bytes) -> PolynomialNTTRepresentation:
+    if len(b) < params.omega_ch * params.bytes_for_one_coef_bdd_by_beta_ch + params.bytes_for_poly_shuffle:
+        raise ValueError("hashed_vk_and_pre_hashed_message is too short")
+    coefs = decode_bytes_to_polynomial_coefficients(b=b, log2_bias=params.secpar, modulus=params.modulus,
+                                                    degree=params.degree, norm_bound=params.beta_ch,
+                                                    weight_bound=params.omega_ch)
+    return transform(_coef_poly(params, coefs))       # one forward NTT on the device
+
+
+def hash_ch(params: Params, key: OneTimeVerificationKey, message: str) -> SignatureChallenge:
+    pre_hashed = hash_message_to_int(params=params, message=message)
+    xof = hash_vk_and_int_to_bytes(params=params, key=key, i=pre_hashed, n=_challenge_bytes_needed(params))
+    return SignatureChallenge(c_hat=parse_challenge(params=params, b=xof))
+
+
+def sign(params: Params, key: OneTimeKeyTuple, message: str) -> Signature:
+    """sigma = left_sk_hat * c_hat + right_sk_hat (fusion.py:534-557) as one fz_sign_core call."""
+    sk, vk = key
+    c_hat = hash_ch(params=params, key=vk, message=message).c_hat
+    q = params.modulus
+    sk_hat = np.stack([_rows_of(sk.left_sk_hat, q), _rows_of(sk.right_sk_hat, q)])[None]
+    sig = _ctx(params).sign_core(sk_hat, c_hat._i32()[None])
+    return Signature(signature_hat=_column(params, sig[0]))
+
+
+class AggregationCoefficient(object):
+    def __init__(self, alpha_hat: PolynomialNTTRepresentation):
+        self.alpha_hat = alpha_hat
+
+    def __str__(self):
+        return f"AggregationCoefficient(alpha_hat={self.alpha_hat})"
+
+    def __repr__(self):
+        return self.__str__()
+
+
+def _agg_coef_bytes(params: Params) -> int:
+    bound = max(0, min(params.modulus // 2, params.beta_ag))
+    coef_bytes = ceil((log2(bound) + 1 + params.secpar) / 8)
+    index_bytes = ceil((log2(params.degree) + params.secpar) / 8)
+    return ceil(params.omega_ag / 8) + (coef_bytes + index_bytes) * params.omega_ag
+
+
+def hash_vks_and_ints_and_challs_to_bytes(params: Params, keys: List[OneTimeVerificationKey],
+                                          prehashed_messages: List[int],
+                                          challenges: List[SignatureChallenge]) -> bytes:
+    n = len(keys) * _agg_coef_bytes(params)
+    salted = str.encode(params.agg_xof_dst.decode("utf-8") + ","
+                        + str(list(zip(keys, prehashed_messages, challenges))))
+    return shake_256(salted).digest(n)
+
+
+def decode_bytes_to_agg_coefs(params: Params, b: bytes) -> List[AggregationCoefficient]:
+    n = _agg_coef_bytes(params)
+    count = len(b) // n
+    coef_rows = [decode_bytes_to_polynomial_coefficients(b=b[i * n:(i + 1) * n], log2_bias=params.secpar,
+                                                         modulus=params.modulus, degree=params.degree,
+                                                         norm_bound=params.beta_ag, weight_bound=params.omega_ag)
+                 for i in range(count)]
+    if not coef_rows:
+        return []
+    # all `count` forward transforms in one batched launch
+    hats = _ctx(params).ntt_forward(_backend.to_i32(coef_rows, params.modulus))
+    return [AggregationCoefficient(alpha_hat=_ntt_poly(params, row)) for row in hats.tolist()]
+
+
+def hash_ag(params: Params, keys: List[OneTimeVerificationKey], messages: List[str]) -> List[AggregationCoefficient]:
+    pairs = list(zip(keys, messages))
+    pre_hashed = [hash_message_to_int(params=params, message=m) for _, m in pairs]
+    challs = [hash_ch(params=params, key=k, message=m) for k, m in pairs]
+    b = hash_vks_and_ints_and_challs_to_bytes(params=params, keys=keys, prehashed_messages=pre_hashed,
+                                              challenges=challs)
+    return decode_bytes_to_agg_coefs(params=params, b=b)
+
+
+def aggregate(params: Params, keys: List[OneTimeVerificationKey], messages: List[str],
+              signatures: List[Signature]) -> Signature:
+    """sum_i sigma_i * alpha_i over the key-sorted inputs (fusion.py:655-677): one fz_aggregate_core."""
+    triples = sorted(list(zip(keys, messages, signatures)), key=lambda x: str(x[0]))
+    alphas = hash_ag(params=params, keys=[t[0] for t in triples], messages=[t[1] for t in triples])
+    q = params.modulus
+    sig = np.stack([_rows_of(t[2].signature_hat, q) for t in triples])
+    alpha = _backend.to_i32([a.alpha_hat.values for a in alphas], q)
+    out = _ctx(params).aggregate_core(sig, alpha)
+    return Signature(signature_hat=_column(params, out))
+
+
+def verify(params: Params, keys: List[OneTimeVerificationKey], messages: List[str],
+           aggregate_signature: Signature) -> Tuple[bool, str]:
+    """fusion.py:680-728.  Never raises for a bad signature: (False, reason) with the reference's
+    reason strings, checked in the reference's order (target, then norm, then weight)."""
+    if len(keys) > params.capacity:
+        return False, VERDICT_REASONS[1]
+    if len(keys) != len(messages):
+        return False, VERDICT_REASONS[2]
+    pairs = sorted(zip(keys, messages), key=lambda x: str(x[0]))
+    sorted_vks = [p[0] for p in pairs]
+    challs = [hash_ch(params=params, key=k, message=m) for k, m in pairs]
+    alphas = hash_ag(params=params, keys=sorted_vks, messages=[p[1] for p in pairs])
+    q = params.modulus
+    code = _ctx(params).verify_core(
+        _rows_of(params.public_challenge, q), _rows_of(aggregate_signature.signature_hat, q),
+        _backend.to_i32([v.left_vk_hat.matrix[0][0].values for v in sorted_vks], q),
+        _backend.to_i32([v.right_vk_hat.matrix[0][0].values for v in sorted_vks], q),
+        _backend.to_i32([c.c_hat.values for c in challs], q),
+        _backend.to_i32([a.alpha_hat.values for a in alphas], q),
+        params.beta_vf, params.omega_vf)
+    return (code == 0), VERDICT_REASONS[code]

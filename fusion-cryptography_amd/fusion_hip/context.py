@@ -225,6 +225,66 @@ class Context:
         return mx, wt
 
 
+    # -- host face of the fused scheme cores (object API of fusion.fusion) -----------------------
+    def _staged(self, arrays):
+        return [DeviceBuffer.from_numpy(self, _as_i32(a)) for a in arrays]
+
+    def keygen_core(self, A, coef):
+        """A [l][d]; coef [batch][2][l][d] -> (sk_hat [batch][2][l][d], vk [batch][2][d])."""
+        A, coef = _as_i32(A), _as_i32(coef)
+        l, d = A.shape
+        c4 = coef.reshape(-1, 2, l, d)
+        batch = c4.shape[0]
+        dA, dC = self._staged([A, c4])
+        dS = DeviceBuffer(self, c4.nbytes)
+        dV = DeviceBuffer(self, batch * 2 * d * 4)
+        try:
+            self.keygen_core_dev(dA.ptr, dC.ptr, dS.ptr, dV.ptr, batch, l)
+            return dS.to_numpy(np.int32, c4.shape), dV.to_numpy(np.int32, (batch, 2, d))
+        finally:
+            for b in (dA, dC, dS, dV):
+                b.free()
+
+    def sign_core(self, sk_hat, c_hat):
+        """sk_hat [batch][2][l][d]; c_hat [batch][d] -> sig [batch][l][d]."""
+        sk, c = _as_i32(sk_hat), _as_i32(c_hat)
+        batch, _, l, d = sk.shape
+        dK, dC = self._staged([sk, c.reshape(batch, d)])
+        dS = DeviceBuffer(self, batch * l * d * 4)
+        try:
+            self.sign_core_dev(dK.ptr, dC.ptr, dS.ptr, batch, l)
+            return dS.to_numpy(np.int32, (batch, l, d))
+        finally:
+            for b in (dK, dC, dS):
+                b.free()
+
+    def aggregate_core(self, sig, alpha_hat):
+        """sig [N][l][d]; alpha_hat [N][d] -> [l][d]."""
+        sig, al = _as_i32(sig), _as_i32(alpha_hat)
+        N, l, d = sig.shape
+        dS, dA = self._staged([sig, al.reshape(N, d)])
+        dO = DeviceBuffer(self, l * d * 4)
+        try:
+            self.aggregate_core_dev(dS.ptr, dA.ptr, dO.ptr, N, l)
+            return dO.to_numpy(np.int32, (l, d))
+        finally:
+            for b in (dS, dA, dO):
+                b.free()
+
+    def verify_core(self, A, sig, vkL, vkR, c_hat, alpha_hat, beta_vf, omega_vf):
+        """-> verdict code (VERDICT_REASONS)."""
+        A, sig = _as_i32(A), _as_i32(sig)
+        l, d = A.shape
+        vkL, vkR, c_hat, alpha_hat = (_as_i32(x).reshape(-1, d) for x in (vkL, vkR, c_hat, alpha_hat))
+        N = vkL.shape[0]
+        bufs = self._staged([A, sig.reshape(l, d), vkL, vkR, c_hat, alpha_hat])
+        try:
+            return self.verify_core_dev(*(b.ptr for b in bufs), N, l, int(beta_vf), int(omega_vf))
+        finally:
+            for b in bufs:
+                b.free()
+
+
 class DeviceBuffer:
     """Minimal owning wrapper over fz_malloc for callers that do not use torch."""
 

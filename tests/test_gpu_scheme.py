@@ -1,0 +1,131 @@
+"""GPU parity of the fused scheme cores and of the drop-in fusion.fusion surface against golden
+data produced by running the reference (tests/golden/scheme_*.npz, scheme.json)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def sha_str(s):
+    return hashlib.sha256(s.encode("utf-8")).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def meta():
+    with open(os.path.join(G, "scheme.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_fused_cores_match_reference_arrays(secpar, meta):
+    import fusion_hip
+    S = np.load(os.path.join(G, f"scheme_{secpar}.npz"))
+    m = meta[str(secpar)]
+    P = O.PARAMS[secpar]
+    ctx = fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"])
+    sk, vk = ctx.keygen_core(S["A"], S["coef"])
+    assert np.array_equal(sk, S["sk_hat"]) and np.array_equal(vk, S["vk"])
+    assert np.array_equal(ctx.sign_core(S["sk_hat"], S["c_hat"]), S["sig"])
+    for n in (1, 2, 4):
+        order = m["agg"][str(n)]["order"]
+        alpha = S[f"alpha_hat_{n}"]
+        agg = ctx.aggregate_core(S["sig"][order], alpha)
+        assert np.array_equal(agg, S[f"agg_{n}"])
+        args = (S["vk"][order, 0], S["vk"][order, 1], S["c_hat"][order], alpha)
+        assert ctx.verify_core(S["A"], agg, *args, m["beta_vf"], m["omega_vf"]) == 0
+        bad = agg.copy()
+        bad[0, 0] += 1
+        assert ctx.verify_core(S["A"], bad, *args, m["beta_vf"], m["omega_vf"]) == 3
+        assert ctx.verify_core(S["A"], agg, *args, 1, m["omega_vf"]) == 4
+        assert ctx.verify_core(S["A"], agg, *args, m["beta_vf"], 1) == 5
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_cores_on_distinct_random_keys(secpar, coracle):
+    """The reference's keys repeat one polynomial rank times; the throughput configs use DISTINCT
+    rows -- check those against the oracle, with a ragged signature count."""
+    import fusion_hip
+    P = O.PARAMS[secpar]
+    q, d, l = P["q"], P["d"], P["rank"]
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    rng = np.random.default_rng(secpar + 1)
+    N = 37
+    A = O.splitmix_centered(3, l * d).reshape(l, d)
+    coef = rng.integers(-52, 53, size=(N, 2, l, d)).astype(np.int32)
+    sk, vk = ctx.keygen_core(A, coef)
+    rsk, rvk = coracle.keygen_core(A, coef, q, P["root"])
+    assert np.array_equal(sk, rsk) and np.array_equal(vk, rvk)
+    c = np.zeros((N, d), np.int32)
+    for i in range(N):
+        c[i, rng.choice(d, P["omega_ch"], replace=False)] = rng.choice([-1, 1], P["omega_ch"])
+    c_hat = ctx.ntt_forward(c)
+    sig = ctx.sign_core(sk, c_hat)
+    assert np.array_equal(sig, coracle.sign_core(sk, c_hat, q))
+    alpha = ctx.ntt_forward(np.roll(c, 1, axis=1))
+    agg = ctx.aggregate_core(sig, alpha)
+    assert np.array_equal(agg, coracle.aggregate_core(sig, alpha, q))
+    beta, omega = P["beta_vf"], d
+    assert ctx.verify_core(A, agg, vk[:, 0], vk[:, 1], c_hat, alpha, beta, omega) == \
+        coracle.verify_core(A, agg, vk[:, 0], vk[:, 1], c_hat, alpha, q, P["inv_root"], beta, omega) == 0
+    # split partial sums (the multi-GPU exchange step) reduce to the same aggregate
+    halves = []
+    for sl in (slice(0, 20), slice(20, N)):
+        ds = fusion_hip.DeviceBuffer.from_numpy(ctx, sig[sl])
+        da = fusion_hip.DeviceBuffer.from_numpy(ctx, alpha[sl])
+        dp = fusion_hip.DeviceBuffer(ctx, l * d * 8)
+        ctx.aggregate_partial_dev(ds.ptr, da.ptr, dp.ptr, sig[sl].shape[0], l)
+        halves.append(dp.to_numpy(np.int64, (l, d)))
+    tot = halves[0] + halves[1]
+    dt = fusion_hip.DeviceBuffer.from_numpy(ctx, tot)
+    do = fusion_hip.DeviceBuffer(ctx, l * d * 4)
+    ctx.reduce_i64_dev(dt.ptr, do.ptr, l * d)
+    assert np.array_equal(do.to_numpy(np.int32, (l, d)), agg)
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_dropin_end_to_end_matches_reference_strings(secpar, meta):
+    """setup -> keygen -> sign -> aggregate -> verify through the drop-in API; every object's str()
+    must hash to what the reference printed (these strings are hashed by the scheme itself)."""
+    import fusion.fusion as F
+    m = meta[str(secpar)]
+    params = F.fusion_setup(secpar, m["setup_seed"])
+    assert sha_str(str(params)) == m["sha256_str_params"]
+    keys = [F.keygen(params, s) for s in m["key_seeds"]]
+    assert [sha_str(str(k[1])) for k in keys] == m["sha256_str_vk"]
+    assert [sha_str(str(k[0])) for k in keys] == m["sha256_str_sk"]
+    msgs = m["messages"]
+    assert [str(F.hash_message_to_int(params, x)) for x in msgs] == m["prehash"]
+    vks = [k[1] for k in keys]
+    assert [sha_str(str(F.hash_ch(params, v, x))) for v, x in zip(vks, msgs)] == m["sha256_str_chall"]
+    sigs = [F.sign(params, k, x) for k, x in zip(keys, msgs)]
+    assert [sha_str(str(s)) for s in sigs] == m["sha256_str_sig"]
+    for n in (1, 2, 4):
+        agg = F.aggregate(params, vks[:n], msgs[:n], sigs[:n])
+        assert sha_str(str(agg)) == m["agg"][str(n)]["sha256_str_agg"]
+        assert list(F.verify(params, vks[:n], msgs[:n], agg)) == m["agg"][str(n)]["verdict"] == [True, ""]
+        # tamper test of the reference (tests/test_fusion.py:860-873): in-place edit of one value
+        agg.signature_hat.matrix[0][0].values[0] += 1
+        assert list(F.verify(params, vks[:n], msgs[:n], agg)) == m["agg"][str(n)]["tampered_verdict"]
+    assert F.verify(params, vks, msgs[:1], sigs[0]) == (False, "Number of keys and messages must be equal.")
+    assert F.verify(params, vks * (params.capacity // 4 + 1), msgs, sigs[0]) == (False, "Too many keys.")
+
+
+def test_config1_demo_flow(meta):
+    """BASELINE config 1 (misc/demo.py plumbing at secpar 128): two keys from the same seed."""
+    import fusion.fusion as F
+    m = meta["demo128"]
+    a = F.fusion_setup(128, m["setup_seed"])
+    keys = [F.keygen(a, m["key_seed"]) for _ in range(2)]
+    sigs = [F.sign(a, k, x) for k, x in zip(keys, m["messages"])]
+    assert [sha_str(str(s)) for s in sigs] == m["sha256_str_sig"]
+    vks = [k[1] for k in keys]
+    agg = F.aggregate(a, vks, m["messages"], sigs)
+    assert sha_str(str(agg)) == m["sha256_str_agg"]
+    assert list(F.verify(a, vks, m["messages"], agg)) == m["verdict"] == [True, ""]

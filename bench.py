@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the algebra hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): secpar=256, one batch of 4096 independent degree-256
+polynomials; a STEP is one pass of the hot path over that batch = forward NTT of the batch
+followed by inverse NTT of the result (two kernel launches, inputs resident in HBM).
+`value` = NTTs per second over the whole job (forward and inverse each count as one NTT,
+summed over all ranks).  With --gpus N every rank owns its own batch (weak scaling, no
+data-path collective for the transforms).
+
+The same JSON line carries
+  roofline      achieved algorithmic GB/s of the dominant kernel (forward NTT: 8*d bytes per
+                polynomial), timed with events on the kernel's own stream inside the timed region;
+                plus the large-batch asymptote of the same kernel under "sweep".
+  cpu_baseline  the pure-Python port of the reference's algebra path (oracle/oracle.py py_*)
+                timed on one host core over a bounded sample of the same workload (rank 0, N=1).
+  sign_verify   the second half of BASELINE's metric: signatures signed + aggregated + verified per
+                second (algebra only; synthetic keys/messages), sharded over the ranks with one RCCL
+                all-reduce of the int64 partial aggregate per step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "fusion-cryptography_amd"))
+sys.path.insert(0, ROOT)
+
+METRIC = "batched NTT/s (deg-256, secpar=256) + aggregate sign+verify/sec at 1/2/4/8 GPU"
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+B = 4096                       # BASELINE configs[1]
+SECPAR = 256
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sign-verify", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the pure-Python baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds):
+    """Pure-Python port (lists of ints, one cent() per reference cent call) on ONE core."""
+    from oracle import oracle as O
+    P = O.PARAMS[SECPAR]
+    q, d = P["q"], P["d"]
+    tw, itw = O.py_twiddles(P["root"], q, d), O.py_twiddles(P["inv_root"], q, d)
+    x = O.splitmix_centered(20261003, B * d).reshape(B, d).tolist()
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:          # bounded sample: as many rows as fit the budget
+        row = list(x[(done // 2) % B])
+        O.py_ntt_inverse(O.py_ntt_forward(row, q, tw), q, itw)
+        done += 2
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
+            "sample": f"{done // 2} of the {B} rows: forward+inverse degree-256 NTT, pure-Python port "
+                      f"(oracle.py_ntt_forward/py_ntt_inverse), {dt:.1f} s on 1 core of {os.cpu_count()}"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import fusion_hip
+    from fusion_hip.dist import allreduce_sum_i64
+    from oracle import oracle as O
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    P = O.PARAMS[SECPAR]
+    q, d, l = P["q"], P["d"], P["rank"]
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- NTT workload: inputs resident in HBM --------------------------------------------------
+    x_host = O.splitmix_centered(20261003 + rank, B * d).reshape(B, d)
+    x = torch.from_numpy(x_host).to(dev)
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+
+    def step():
+        ctx.ntt_forward_dev(x.data_ptr(), y.data_ptr(), B)
+        ctx.ntt_inverse_dev(y.data_ptr(), z.data_ptr(), B)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    assert torch.equal(z, x), "INTT(NTT(x)) != x"
+    barrier()
+    ctx.profile_begin(2 * args.steps)            # event pair bound to every dispatch (kernel begin -> end)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_end()
+    assert prof["fwd_count"] == prof["inv_count"] == args.steps
+    fwd_avg, inv_avg = prof["fwd_avg_us"] * 1e-3, prof["inv_avg_us"] * 1e-3      # ms
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = 2.0 * B * args.steps * world / elapsed
+
+    # ---- large-batch asymptote of the same kernels (context for the roofline) ------------------
+    sweep = {}
+    if rank == 0:
+        for logb in (16, 20):
+            nb = 1 << logb
+            xs = torch.from_numpy(O.splitmix_centered(7, nb * d).reshape(nb, d)).to(dev)
+            ys = torch.empty_like(xs)
+            for name, fn in (("fwd", ctx.ntt_forward_dev), ("inv", ctx.ntt_inverse_dev)):
+                for _ in range(3):
+                    fn(xs.data_ptr(), ys.data_ptr(), nb)
+                torch.cuda.synchronize(dev)
+                reps = 10
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                for _ in range(reps):
+                    fn(xs.data_ptr(), ys.data_ptr(), nb)
+                b_.record(stream)
+                torch.cuda.synchronize(dev)
+                ms = a.elapsed_time(b_) / reps
+                gbs = 8.0 * d * nb / (ms * 1e-3) / 1e9
+                sweep[f"{name}_B2^{logb}"] = {"us": round(ms * 1e3, 2), "GB/s": round(gbs, 1),
+                                              "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            del xs, ys
+    barrier()
+
+    # ---- sign + aggregate + verify (algebra cores; synthetic keys/messages) --------------------
+    sv = None
+    if not args.no_sign_verify:
+        S, GROUPS = 1024, 4                      # per rank: 1024 signatures in 4 aggregates of 256 x world
+        rng = np.random.default_rng(1234 + rank)
+        A = torch.from_numpy(O.splitmix_centered(99, l * d).reshape(l, d)).to(dev)      # same on every rank
+        coef = torch.from_numpy(rng.integers(1, 53, size=(S, 2, l, d)).astype(np.int32) *
+                                rng.choice(np.array([-1, 1], dtype=np.int32), size=(S, 2, l, d))).to(dev)
+        sk_hat = torch.empty_like(coef)
+        vk = torch.empty((S, 2, d), dtype=torch.int32, device=dev)
+        ctx.keygen_core_dev(A.data_ptr(), coef.data_ptr(), sk_hat.data_ptr(), vk.data_ptr(), S, l)
+
+        def sparse(weight):
+            c = np.zeros((S, d), np.int32)
+            for i in range(S):
+                c[i, rng.choice(d, weight, replace=False)] = rng.choice([-1, 1], weight)
+            return torch.from_numpy(c).to(dev)
+        c_hat = torch.empty((S, d), dtype=torch.int32, device=dev)
+        al_hat = torch.empty((S, d), dtype=torch.int32, device=dev)
+        cc, aa = sparse(P["omega_ch"]), sparse(P["omega_ag"])
+        ctx.ntt_forward_dev(cc.data_ptr(), c_hat.data_ptr(), S)
+        ctx.ntt_forward_dev(aa.data_ptr(), al_hat.data_ptr(), S)
+        vkL, vkR = vk[:, 0].contiguous(), vk[:, 1].contiguous()
+        sig = torch.empty((S, l, d), dtype=torch.int32, device=dev)
+        part = torch.zeros((GROUPS, l * d + d), dtype=torch.int64, device=dev)   # aggregate + target, one buffer
+        agg = torch.empty((GROUPS, l, d), dtype=torch.int32, device=dev)
+        tgt = torch.empty((GROUPS, d), dtype=torch.int32, device=dev)
+        per = S // GROUPS
+        verdicts = []
+
+        def sv_step():
+            ctx.sign_core_dev(sk_hat.data_ptr(), c_hat.data_ptr(), sig.data_ptr(), S, l)
+            for g in range(GROUPS):
+                lo = g * per
+                ctx.aggregate_partial_dev(sig[lo].data_ptr(), al_hat[lo].data_ptr(), part[g].data_ptr(), per, l)
+                ctx.target_partial_dev(vkL[lo].data_ptr(), vkR[lo].data_ptr(), c_hat[lo].data_ptr(),
+                                       al_hat[lo].data_ptr(), part[g, l * d:].data_ptr(), per)
+            allreduce_sum_i64(part)              # the ONE exchange step (RCCL over xGMI when world > 1)
+            verdicts.clear()
+            for g in range(GROUPS):
+                if g % world != rank:
+                    continue                     # aggregates are verified round-robin over the ranks
+                ctx.reduce_i64_dev(part[g].data_ptr(), agg[g].data_ptr(), l * d)
+                ctx.reduce_i64_dev(part[g, l * d:].data_ptr(), tgt[g].data_ptr(), d)
+                verdicts.append(ctx.verify_with_target_dev(A.data_ptr(), agg[g].data_ptr(), tgt[g].data_ptr(), l,
+                                                           P["beta_vf"], d))
+        sv_steps = max(3, min(args.steps, 30))
+        for _ in range(2):
+            sv_step()
+        barrier()
+        assert all(v == 0 for v in verdicts), f"verify verdicts {verdicts}"
+        t0 = time.perf_counter()
+        for _ in range(sv_steps):
+            sv_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        sv = {"value": S * world * sv_steps / dt, "unit": "signatures signed+aggregated+verified per s",
+              "signatures_per_rank": S, "aggregates": GROUPS, "signers_per_aggregate": per * world,
+              "steps": sv_steps, "ms_per_step": dt / sv_steps * 1e3,
+              "note": "algebra cores only (sign_core, aggregate/target partials, int64 all-reduce, reduce, verify); "
+                      "host hashing of str(vk) excluded"}
+
+    if rank == 0:
+        fwd_bytes = 8.0 * d * B
+        ach = fwd_bytes / (fwd_avg * 1e-3) / 1e9
+        out = {
+            "metric": METRIC, "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64 (exact integer arithmetic; int32 in/out)", "data": "synthetic",
+            "config": {"workload": f"configs[1]: secpar={SECPAR}, batch of {B} degree-{d} forward+inverse NTTs per GPU",
+                       "batch": B, "degree": d, "modulus": q, "kernels_per_step": 2},
+            "roofline": {"bound": "hbm", "kernel": "ntt_fwd16<8> (forward NTT, B=4096)", "achieved": ach,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": fwd_bytes, "avg_launch_us": fwd_avg * 1e3,
+                         "inverse_avg_launch_us": inv_avg * 1e3, "launches_timed": args.steps, "sweep": sweep},
+            "sign_verify": sv,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

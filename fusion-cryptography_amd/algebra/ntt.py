@@ -177,6 +177,9 @@ def _root_of_table(table, modulus, n):
         if len(table) != n:
             raise ValueError(f"twiddle table has length {len(table)}, expected {n}")
         root = table[n // 2] % modulus
+        if pow(root, n, modulus) != modulus - 1:
+            raise ValueError("twiddle table is not built from a primitive 2n-th root of unity; "
+                             "only such tables are supported by the HIP kernels")
         bits = n.bit_length() - 1
         acc, powers = 1, []
         for _ in range(n):

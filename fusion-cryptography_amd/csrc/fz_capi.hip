@@ -194,6 +194,11 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     if (ctx->d_itwB) (void)hipFree(ctx->d_itwB);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_verdict) (void)hipFree(ctx->d_verdict);
+    if (ctx->prof_ev) {
+        for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
+        free(ctx->prof_ev);
+        free(ctx->prof_kind);
+    }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     free(ctx->h_tw);
@@ -259,6 +264,42 @@ int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms) {
     FZ_HIP(hipEventRecord(ctx->ev1, ctx->stream), "event record");
     FZ_HIP(hipEventSynchronize(ctx->ev1), "event synchronize");
     FZ_HIP(hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1), "event elapsed");
+    return FZ_OK;
+}
+
+int fz_profile_begin(fz_ctx *ctx, int max_launches) {
+    FZ_REQUIRE(ctx && max_launches > 0 && max_launches <= (1 << 20), "bad argument");
+    if (max_launches > ctx->prof_cap) {
+        hipEvent_t *ev = (hipEvent_t *)realloc(ctx->prof_ev, sizeof(hipEvent_t) * 2 * (size_t)max_launches);
+        unsigned char *kind = (unsigned char *)realloc(ctx->prof_kind, (size_t)max_launches);
+        if (!ev || !kind) return fz_set_error(FZ_E_HIP, "out of host memory");
+        ctx->prof_ev = ev;
+        ctx->prof_kind = kind;
+        for (int i = 2 * ctx->prof_cap; i < 2 * max_launches; ++i) FZ_HIP(hipEventCreate(&ctx->prof_ev[i]), "event create");
+        ctx->prof_cap = max_launches;
+    }
+    ctx->prof_n = 0;
+    ctx->prof_on = 1;
+    return FZ_OK;
+}
+
+int fz_profile_end(fz_ctx *ctx, double *fwd_avg_us, int *fwd_count, double *inv_avg_us, int *inv_count) {
+    FZ_REQUIRE(ctx && fwd_avg_us && fwd_count && inv_avg_us && inv_count, "NULL argument");
+    ctx->prof_on = 0;
+    FZ_HIP(hipStreamSynchronize(ctx->stream), "profile sync");
+    double sum[2] = {0, 0};
+    int cnt[2] = {0, 0};
+    for (int i = 0; i < ctx->prof_n; ++i) {
+        float ms = 0;
+        FZ_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]), "event elapsed");
+        sum[ctx->prof_kind[i]] += ms * 1e3;
+        cnt[ctx->prof_kind[i]]++;
+    }
+    *fwd_avg_us = cnt[0] ? sum[0] / cnt[0] : 0.0;
+    *inv_avg_us = cnt[1] ? sum[1] / cnt[1] : 0.0;
+    *fwd_count = cnt[0];
+    *inv_count = cnt[1];
+    ctx->prof_n = 0;
     return FZ_OK;
 }
 

@@ -21,6 +21,7 @@
 // D <= 16 uses a thread-per-polynomial kernel (all twiddles uniform).
 #include "fz_internal.h"
 #include "../../include/fusion_hip.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -37,6 +38,49 @@ struct Geom {
 __device__ __forceinline__ int pad16(int j) { return j + 2 * (j >> 4); }
 
 // ------------------------------------------------------------------------------------------
+// Global <-> LDS staging shared by both directions.
+// A wave-task covers PPW consecutive polynomials = ONE contiguous chunk of 1024 int32 (4 KiB) of
+// the batch, whatever the degree.  All global traffic is 16 bytes per lane, 1 KiB contiguous per
+// wave instruction (4 instructions per task); the lane <-> coefficient mappings the passes need are
+// produced by LDS reads/writes.  int32 staging image: chunk element j at word j + 4*(j>>4)
+// (20-word rows: the 16-byte-per-lane accesses at a 64-byte lane stride stay conflict free).
+// ------------------------------------------------------------------------------------------
+constexpr int kChunk = 1024;                         // int32 per wave-task
+constexpr int kStageWords = kChunk + 4 * (kChunk / 16);   // 1280 words = 5 KiB
+
+__device__ __forceinline__ int pad4(int j) { return j + 4 * (j >> 4); }
+
+struct Chunk { int4 v0, v1, v2, v3; };
+
+// issue the task's 4 coalesced 16-byte loads (clamped to the last valid 16-byte piece)
+__device__ __forceinline__ Chunk chunk_load(const int32_t *in, size_t task, size_t total, int lane) {
+    const size_t base = task * kChunk + 4 * lane;
+    const size_t last = total - 4;
+    Chunk c;
+    c.v0 = *reinterpret_cast<const int4 *>(in + (base < total ? base : last));
+    c.v1 = *reinterpret_cast<const int4 *>(in + (base + 256 < total ? base + 256 : last));
+    c.v2 = *reinterpret_cast<const int4 *>(in + (base + 512 < total ? base + 512 : last));
+    c.v3 = *reinterpret_cast<const int4 *>(in + (base + 768 < total ? base + 768 : last));
+    return c;
+}
+
+__device__ __forceinline__ void chunk_to_lds(int32_t *stage, int lane, const Chunk &c) {
+    *reinterpret_cast<int4 *>(stage + pad4(4 * lane)) = c.v0;
+    *reinterpret_cast<int4 *>(stage + pad4(256 + 4 * lane)) = c.v1;
+    *reinterpret_cast<int4 *>(stage + pad4(512 + 4 * lane)) = c.v2;
+    *reinterpret_cast<int4 *>(stage + pad4(768 + 4 * lane)) = c.v3;
+}
+
+__device__ __forceinline__ void chunk_store(int32_t *out, size_t task, size_t total, int lane, const int32_t *stage) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const size_t off = task * kChunk + 256 * m + 4 * lane;
+        const int4 v = *reinterpret_cast<const int4 *>(stage + pad4(256 * m + 4 * lane));
+        if (off < total) *reinterpret_cast<int4 *>(out + off) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // forward: strided pass -> transpose -> contiguous pass
 // ------------------------------------------------------------------------------------------
 template <int LOGD>
@@ -44,23 +88,36 @@ __global__ __launch_bounds__(64) void ntt_fwd16(const int32_t *in, int32_t *out,
                                                 const double *__restrict__ twB, FzTwA twA, FzMod m) {
     using G = Geom<LOGD>;
     constexpr int D = G::D, L = G::L, PPW = G::PPW, SB = G::SB, NE = G::NE, PS = G::PS;
+    static_assert(PPW * PS * 2 >= kStageWords, "staging image must fit in the transpose buffer");
     __shared__ __attribute__((aligned(16))) double lds[PPW * PS + NE * L];
     double *s_tw = lds + PPW * PS;
+    int32_t *stage = reinterpret_cast<int32_t *>(lds);
 
     const int lane = threadIdx.x;
     const int p = lane / L, r = lane % L;
     for (int i = lane; i < NE * L; i += 64) s_tw[i] = twB[i];
     double *row = lds + p * PS;
+
+    const size_t total = batch * D;
+    const size_t tasks = (total + kChunk - 1) / kChunk;
+    Chunk raw = chunk_load(in, blockIdx.x < tasks ? blockIdx.x : 0, total, lane);
     __syncthreads();
 
-    const size_t tasks = (batch + PPW - 1) / PPW;
     for (size_t task = blockIdx.x; task < tasks; task += gridDim.x) {
-        const size_t poly = task * PPW + p;
-        const bool valid = poly < batch;
-        const int32_t *src = in + poly * D + r;
+        // stage the chunk, then prefetch the next task's chunk into registers (in flight during
+        // the whole compute phase)
+        chunk_to_lds(stage, lane, raw);
+        if (task + gridDim.x < tasks) raw = chunk_load(in, task + gridDim.x, total, lane);
+        __syncthreads();
         double a[16];
+        {
+            int x[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = valid ? (double)src[k * L] : 0.0;
+            for (int k = 0; k < 16; ++k) x[k] = stage[pad4(p * D + r + L * k)];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = (double)x[k];
+        }
+        __syncthreads();
 
         // strided pass: a 16-point LN transform over k with table entries 1..15
 #pragma unroll
@@ -90,6 +147,7 @@ __global__ __launch_bounds__(64) void ntt_fwd16(const int32_t *in, int32_t *out,
                 a[2 * k + 1] = t.y;
             }
         }
+        __syncthreads();
 
         // contiguous pass: stages with distance 2^(SB-1) .. 1, per-lane twiddles
 #pragma unroll
@@ -108,19 +166,19 @@ __global__ __launch_bounds__(64) void ntt_fwd16(const int32_t *in, int32_t *out,
             }
         }
 
-        if (valid) {
-            int4 *dst = reinterpret_cast<int4 *>(out + poly * D + 16 * r);
+        // lane holds chunk elements [16*lane, 16*lane + 16): centre, stage, store coalesced
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int4 o;
-                o.x = (int)fz_cent(a[4 * k + 0], m);
-                o.y = (int)fz_cent(a[4 * k + 1], m);
-                o.z = (int)fz_cent(a[4 * k + 2], m);
-                o.w = (int)fz_cent(a[4 * k + 3], m);
-                dst[k] = o;
-            }
+        for (int k = 0; k < 4; ++k) {
+            int4 o;
+            o.x = (int)fz_cent(a[4 * k + 0], m);
+            o.y = (int)fz_cent(a[4 * k + 1], m);
+            o.z = (int)fz_cent(a[4 * k + 2], m);
+            o.w = (int)fz_cent(a[4 * k + 3], m);
+            *reinterpret_cast<int4 *>(stage + pad4(16 * lane + 4 * k)) = o;
         }
-        __syncthreads();   // LDS rows are rewritten by the next task
+        __syncthreads();
+        chunk_store(out, task, total, lane, stage);
+        __syncthreads();   // the staging image is rewritten by the next task
     }
 }
 
@@ -134,29 +192,32 @@ __global__ __launch_bounds__(64) void ntt_inv16(const int32_t *in, int32_t *out,
     constexpr int D = G::D, L = G::L, PPW = G::PPW, SB = G::SB, NE = G::NE, PS = G::PS;
     __shared__ __attribute__((aligned(16))) double lds[PPW * PS + NE * L];
     double *s_tw = lds + PPW * PS;
+    int32_t *stage = reinterpret_cast<int32_t *>(lds);
 
     const int lane = threadIdx.x;
     const int p = lane / L, r = lane % L;
     for (int i = lane; i < NE * L; i += 64) s_tw[i] = itwB[i];
     double *row = lds + p * PS;
+
+    const size_t total = batch * D;
+    const size_t tasks = (total + kChunk - 1) / kChunk;
+    Chunk raw = chunk_load(in, blockIdx.x < tasks ? blockIdx.x : 0, total, lane);
     __syncthreads();
 
-    const size_t tasks = (batch + PPW - 1) / PPW;
     for (size_t task = blockIdx.x; task < tasks; task += gridDim.x) {
-        const size_t poly = task * PPW + p;
-        const bool valid = poly < batch;
+        chunk_to_lds(stage, lane, raw);
+        if (task + gridDim.x < tasks) raw = chunk_load(in, task + gridDim.x, total, lane);
+        __syncthreads();
         double a[16];
-        {
-            const int4 *src = reinterpret_cast<const int4 *>(in + poly * D + 16 * r);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int4 t = valid ? src[k] : make_int4(0, 0, 0, 0);
-                a[4 * k + 0] = (double)t.x;
-                a[4 * k + 1] = (double)t.y;
-                a[4 * k + 2] = (double)t.z;
-                a[4 * k + 3] = (double)t.w;
-            }
+        for (int k = 0; k < 4; ++k) {
+            const int4 t = *reinterpret_cast<const int4 *>(stage + pad4(16 * lane + 4 * k));
+            a[4 * k + 0] = (double)t.x;
+            a[4 * k + 1] = (double)t.y;
+            a[4 * k + 2] = (double)t.z;
+            a[4 * k + 3] = (double)t.w;
         }
+        __syncthreads();
 
         // contiguous pass: GS stages with distance 1, 2, .. 2^(SB-1)
 #pragma unroll
@@ -183,6 +244,7 @@ __global__ __launch_bounds__(64) void ntt_inv16(const int32_t *in, int32_t *out,
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 16; ++k) a[k] = row[pad16(r + L * k)];
+        __syncthreads();
 
         // strided pass: GS stages with distance L, 2L, 4L, 8L; uniform twiddles
 #pragma unroll
@@ -204,11 +266,10 @@ __global__ __launch_bounds__(64) void ntt_inv16(const int32_t *in, int32_t *out,
             }
         }
 
-        if (valid) {
-            int32_t *dst = out + poly * D + r;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) dst[k * L] = (int)fz_cent(a[k], m);
-        }
+        for (int k = 0; k < 16; ++k) stage[pad4(p * D + r + L * k)] = (int)fz_cent(a[k], m);
+        __syncthreads();
+        chunk_store(out, task, total, lane, stage);
         __syncthreads();
     }
 }
@@ -262,16 +323,21 @@ __global__ __launch_bounds__(256) void ntt_small(const int32_t *in, int32_t *out
 
 template <int LOGD>
 int launch16(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
-    using G = Geom<LOGD>;
-    const size_t tasks = (batch + G::PPW - 1) / G::PPW;
+    const size_t tasks = (batch * Geom<LOGD>::D + kChunk - 1) / kChunk;
     const int cap = inverse ? ctx->grid_inv : ctx->grid_fwd;
     const unsigned grid = (unsigned)(tasks < (size_t)cap ? tasks : (size_t)cap);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->prof_on && ctx->prof_n < ctx->prof_cap) {
+        e0 = ctx->prof_ev[2 * ctx->prof_n];
+        e1 = ctx->prof_ev[2 * ctx->prof_n + 1];
+        ctx->prof_kind[ctx->prof_n++] = inverse ? 1 : 0;
+    }
     if (!inverse)
-        hipLaunchKernelGGL(ntt_fwd16<LOGD>, dim3(grid), dim3(64), 0, ctx->stream, in, out, batch,
-                           ctx->d_twB, ctx->twA, ctx->mod);
+        hipExtLaunchKernelGGL(ntt_fwd16<LOGD>, dim3(grid), dim3(64), 0, ctx->stream, e0, e1, 0, in, out, batch,
+                              (const double *)ctx->d_twB, ctx->twA, ctx->mod);
     else
-        hipLaunchKernelGGL(ntt_inv16<LOGD>, dim3(grid), dim3(64), 0, ctx->stream, in, out, batch,
-                           ctx->d_itwB, ctx->itwA, ctx->mod);
+        hipExtLaunchKernelGGL(ntt_inv16<LOGD>, dim3(grid), dim3(64), 0, ctx->stream, e0, e1, 0, in, out, batch,
+                              (const double *)ctx->d_itwB, ctx->itwA, ctx->mod);
     return fz_check_hip(hipGetLastError(), "ntt16 launch");
 }
 

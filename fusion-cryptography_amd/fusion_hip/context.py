@@ -100,6 +100,16 @@ class Context:
         check(self._lib, self._lib.fz_timer_stop_ms(self._h, byref(ms)))
         return ms.value
 
+    def profile_begin(self, max_launches):
+        check(self._lib, self._lib.fz_profile_begin(self._h, max_launches))
+
+    def profile_end(self):
+        """-> dict(fwd_avg_us, fwd_count, inv_avg_us, inv_count): kernel begin->end per dispatch"""
+        fa, ia = ctypes.c_double(), ctypes.c_double()
+        fc, ic = c_int(), c_int()
+        check(self._lib, self._lib.fz_profile_end(self._h, byref(fa), byref(fc), byref(ia), byref(ic)))
+        return dict(fwd_avg_us=fa.value, fwd_count=fc.value, inv_avg_us=ia.value, inv_count=ic.value)
+
     # -- device face (raw pointers) -------------------------------------------------------------
     def ntt_forward_dev(self, d_in, d_out, batch):
         check(self._lib, self._lib.fz_ntt_forward(self._h, c_void_p(d_in), c_void_p(d_out), batch))

@@ -1,0 +1,169 @@
+"""The properties the reference's own unit tests assert (tests/test_ntt.py, test_polynomials.py,
+test_matrices.py, test_fusion.py of the reference), restated against the drop-in package running on
+the GPU -- same (degree, prime) grid: d in {4..64}, primes q < 2^17 with 2d | q-1."""
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def pairs():
+    from algebra.ntt import is_odd_prime
+    out = []
+    for d in (4, 8, 16, 32, 64):
+        q, found = 2 * d + 1, 0
+        while found < 2 and q < 2**17:
+            if is_odd_prime(q) and (q - 1) % (2 * d) == 0:
+                out.append((d, q))
+                found += 1
+            q += 2 * d
+    return out + [(2, 5)]
+
+
+def schoolbook(f, g, q):
+    d = len(f)
+    c = [0] * (2 * d)
+    for i, x in enumerate(f):
+        for j, y in enumerate(g):
+            c[i + j] += x * y
+    return [(c[k] - c[k + d]) % q for k in range(d)]
+
+
+def ring(d, q):
+    from algebra.ntt import find_primitive_root
+    root = find_primitive_root(modulus=q, root_order=2 * d)
+    return dict(modulus=q, degree=d, root=root, inv_root=pow(root, q - 2, q), root_order=2 * d)
+
+
+def test_ntt_poly_mult_is_negacyclic_product():
+    from algebra.ntt import bit_reverse_copy, cooley_tukey_ntt, gentleman_sande_intt, ntt_poly_mult
+    rng = random.Random(1)
+    for d, q in pairs():
+        p = ring(d, q)
+        # scalars, monomial pairs (X^i * X^j = +-X^(i+j mod d)), scaled monomials, random polynomials
+        cases = [([3] + [0] * (d - 1), [5] + [0] * (d - 1))]
+        for i in (0, 1, d // 2, d - 1):
+            for j in (0, 1, d - 1):
+                f, g = [0] * d, [0] * d
+                f[i], g[j] = rng.randrange(1, q), rng.randrange(1, q)
+                cases.append((f, g))
+        cases += [([rng.randrange(q) for _ in range(d)], [rng.randrange(-q, q) for _ in range(d)]) for _ in range(8)]
+        cases.append(([rng.randrange(-2**70, 2**70) for _ in range(d)], [rng.randrange(2**40) for _ in range(d)]))
+        for f, g in cases:
+            f0, g0 = list(f), list(g)
+            fg = ntt_poly_mult(f, g, q, p["root"], p["inv_root"], 2 * d)
+            assert [(x - y) % q for x, y in zip(fg, schoolbook(f0, g0, q))] == [0] * d
+            assert all(-(q // 2) <= x <= q // 2 for x in fg + f + g)
+            assert [(x - y) % q for x, y in zip(f, f0)] == [0] * d          # inputs come back as centred equivalents
+            assert [(x - y) % q for x, y in zip(g, g0)] == [0] * d
+        tw = bit_reverse_copy([pow(p["root"], i, q) for i in range(d)])
+        itw = bit_reverse_copy([pow(p["inv_root"], i, q) for i in range(d)])
+        v = [rng.randrange(q) for _ in range(d)]
+        v0 = list(v)
+        assert cooley_tukey_ntt(v, q, 2 * d, tw) is v                      # in place, returns the same list
+        assert gentleman_sande_intt(v, q, 2 * d, itw) is v
+        assert [(x - y) % q for x, y in zip(v, v0)] == [0] * d
+        with pytest.raises(ValueError):
+            cooley_tukey_ntt(list(v0), q, 2 * d, [1] * d)                  # not a power table of one root
+
+
+def test_hand_example_q17_d8():
+    """(1 + 2X + ... + 8X^7)^2 mod (X^8 + 1, 17) computed by hand-expansion."""
+    from algebra.ntt import ntt_poly_mult
+    f = list(range(1, 9))
+    want = schoolbook(f, f, 17)
+    got = ntt_poly_mult(list(f), list(f), 17, 3, 6, 16)
+    assert [(x - y) % 17 for x, y in zip(got, want)] == [0] * 8
+    assert got == [x - 17 if x > 8 else x for x in want]
+
+
+def test_polynomial_classes_arithmetic():
+    from algebra.polynomials import (PolynomialCoefficientRepresentation as PC, PolynomialNTTRepresentation as PN,
+                                     transform)
+    rng = random.Random(2)
+    for d, q in pairs():
+        p = ring(d, q)
+        for _ in range(3):
+            fa, fb = [rng.randrange(q) for _ in range(d)], [rng.randrange(1, q) for _ in range(d)]
+            a, b = PC(**p, coefficients=list(fa)), PC(**p, coefficients=list(fb))
+            assert (a + b).coefficients == [((x + y + q // 2) % q) - q // 2 for x, y in zip(fa, fb)]
+            assert (-a).coefficients == [-(x % q) for x in fa]
+            assert all((z - (x - y)) % q == 0 for x, y, z in zip(fa, fb, (a - b).coefficients))
+            assert (a - 0) == a and (0 - a) == -a
+            prod = a * b
+            assert isinstance(prod, PC) and [x % q for x in prod.coefficients] == schoolbook(fa, fb, q)
+            a_hat, b_hat = transform(a), transform(b)
+            assert isinstance(a_hat, PN) and transform(a_hat) == a and transform(a_hat).coefficients == \
+                [((x + q // 2) % q) - q // 2 for x in fa]
+            assert transform(a_hat * b_hat) == prod
+            assert all((z - x * y) % q == 0 for x, y, z in zip(a_hat.values, b_hat.values, (a_hat * b_hat).values))
+            assert all((z - (x + y)) % q == 0 for x, y, z in zip(a_hat.values, b_hat.values, (a_hat + b_hat).values))
+            assert (-a_hat).values == [-(x % q) for x in a_hat.values]
+            assert (a_hat - b_hat) == (a_hat + (-b_hat)) and 1 * b_hat == b_hat * 1
+            assert a.norm("infty") == max(abs(x) for x in fa) and a.weight() == sum(1 for x in fa if x % q)
+            assert a.coefficients == fa and b.coefficients == fb            # operands untouched
+            big = PC(**p, coefficients=[x + q * rng.randrange(2**40) for x in fa])
+            assert big + b == a + b and big * b == prod and big.weight() == a.weight()
+            with pytest.raises(OverflowError):
+                big.norm("infty")
+
+
+def test_matrix_products():
+    """2x2 matrix of monomials times 2x2 matrix of monomials equals the hand-expanded sums, in the
+    coefficient domain (generic element path) and in the NTT domain (batched path)."""
+    from algebra.matrices import GeneralMatrix
+    from algebra.polynomials import PolynomialCoefficientRepresentation as PC, transform
+    rng = random.Random(3)
+    for d, q in pairs()[:6]:
+        p = ring(d, q)
+
+        def mono():
+            c = [0] * d
+            c[rng.randrange(d)] = rng.randrange(1, q)
+            return c
+        A = [[mono(), mono()], [mono(), mono()]]
+        B = [[mono(), mono()], [mono(), mono()]]
+        want = [[[(x + y) % q for x, y in zip(schoolbook(A[i][0], B[0][j], q), schoolbook(A[i][1], B[1][j], q))]
+                 for j in range(2)] for i in range(2)]
+        Ac = GeneralMatrix(matrix=[[PC(**p, coefficients=list(c)) for c in row] for row in A])
+        Bc = GeneralMatrix(matrix=[[PC(**p, coefficients=list(c)) for c in row] for row in B])
+        C = Ac * Bc
+        assert [[[x % q for x in z.coefficients] for z in row] for row in C.matrix] == want
+        Ah = GeneralMatrix(matrix=[[transform(z) for z in row] for row in Ac.matrix])
+        Bh = GeneralMatrix(matrix=[[transform(z) for z in row] for row in Bc.matrix])
+        Ch = Ah * Bh
+        assert [[[x % q for x in transform(z).coefficients] for z in row] for row in Ch.matrix] == want
+        assert all(-(q // 2) <= x <= q // 2 for row in Ch.matrix for z in row for x in z.values)
+        s = Ah.matrix[0][1]
+        assert (Bh * s).matrix[1][0] == Bh.matrix[1][0] * s and (Ah + Bh).matrix[0][0] == Ah.matrix[0][0] + Bh.matrix[0][0]
+        assert (Ah - Bh) == Ah + (-Bh) and Ac.norm("infty") == max(max(c) for row in A for c in row) and Ac.weight() == 1
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_scheme_properties(secpar):
+    """keygen: INTT(sk) within (beta_sk, omega_sk) and A.sk == vk; sign: A.sigma == vk_L*c + vk_R with
+    bounded INTT(sigma); challenge weights (reference tests/test_fusion.py:308-349, :660-731)."""
+    import fusion.fusion as F
+    from algebra.polynomials import transform
+    params = F.fusion_setup(secpar, 8675309)
+    sk, vk = F.keygen(params, 1234)
+    for m in (sk.left_sk_hat, sk.right_sk_hat):
+        coef = [transform(z) for row in m.matrix for z in row]
+        assert len(coef) == params.num_rows_sk
+        assert all(c.norm("infty") <= params.beta_sk and c.weight() <= params.omega_sk for c in coef)
+    A = params.public_challenge
+    assert A * sk.left_sk_hat == vk.left_vk_hat and A * sk.right_sk_hat == vk.right_vk_hat
+    msg = "the quick brown fox"
+    c = F.hash_ch(params, vk, msg)
+    cc = transform(c.c_hat)
+    assert cc.norm("infty") <= params.beta_ch and cc.weight() == params.omega_ch
+    sig = F.sign(params, (sk, vk), msg)
+    assert A * sig.signature_hat == vk.left_vk_hat * c.c_hat + vk.right_vk_hat
+    bound = params.beta_sk * (1 + min(params.degree, params.omega_ch) * params.beta_ch)
+    assert all(transform(z).norm("infty") <= bound for row in sig.signature_hat.matrix for z in row)
+    alphas = F.hash_ag(params, [vk], [msg])
+    assert len(alphas) == 1 and transform(alphas[0].alpha_hat).weight() == params.omega_ag
+    agg = F.aggregate(params, [vk], [msg], [sig])
+    assert F.verify(params, [vk], [msg], agg) == (True, "")
+    assert F.verify(params, [vk], [msg + "!"], agg) == (False, "Target doesn't match image of aggregate signature.")

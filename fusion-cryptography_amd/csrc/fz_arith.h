@@ -23,7 +23,27 @@
 struct FzMod {
     double q;      // modulus, odd, < 2^31
     double qinv;   // 1.0 / q rounded to nearest
+    // pseudo-Mersenne form q = K - delta, K = 2^k the smallest power of two >= q
+    double K;      // 2^k
+    double kq;     // K / q rounded to nearest (w2 = w * kq is the "quotient twiddle" of fz_mulmod4)
+    double kappa;  // delta / K, exact (delta < 2^k, power-of-two scaling)
+    double magic;  // 1.5 * 2^52 * K: adding it rounds to the nearest multiple of K
+    int fast;      // 1 when delta < 2^15, i.e. fz_mulmod4 is exact for |a| <= 2^38
 };
+
+FZ_HD FzMod fz_make_mod(unsigned q) {
+    FzMod m;
+    m.q = (double)q;
+    m.qinv = 1.0 / (double)q;
+    unsigned long long K = 1;
+    while (K < q) K <<= 1;
+    m.K = (double)K;
+    m.kq = (double)K / (double)q;
+    m.kappa = (double)(K - q) / (double)K;
+    m.magic = 6755399441055744.0 * (double)K;      // 1.5 * 2^52 * K
+    m.fast = (K - q) < 32768ull ? 1 : 0;
+    return m;
+}
 
 // r = a*b - c*q exactly, with c = rint(fl(fl(a*b) * qinv)).
 // Exact when a, b are integers with |a*b| < 2^83 (so that |low part| < 2^30) -- in this
@@ -35,6 +55,20 @@ FZ_HD double fz_mulmod(double a, double b, const FzMod m) {
     double c = __builtin_rint(h * m.qinv);
     double d = __builtin_fma(-c, m.q, h);
     return d + l;
+}
+
+// 4-op variant for pseudo-Mersenne moduli (q = K - delta, delta < 2^15; the scheme's prime is
+// 2^31 - 17919).  w2 = fl(w * K / q) is precomputed per twiddle.
+//   u  = fma(a, w2, magic)      -> magic + K*c,  c = round(a*w2/K) ~ round(a*w/q)   (ulp there is K)
+//   cK = u - magic              -> K*c exactly
+//   t  = fma(a, w, -cK)         -> a*w - c*K = (a*w - c*q) - c*delta: an integer below 2^53, exact
+//   r  = fma(cK, kappa, t)      -> t + c*delta = a*w - c*q, exact
+// Exact for integers |a| <= 2^38, 0 <= w < q (then |c|*delta + q < 2^53).  |r| <= q/2 + q*2^-13.
+FZ_HD double fz_mulmod4(double a, double w, double w2, const FzMod m) {
+    double u = __builtin_fma(a, w2, m.magic);
+    double cK = u - m.magic;
+    double t = __builtin_fma(a, w, -cK);
+    return __builtin_fma(cK, m.kappa, t);
 }
 
 // Canonical centred residue of an integer-valued x, |x| < 2^19 * q:

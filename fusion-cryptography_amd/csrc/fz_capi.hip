@@ -121,8 +121,7 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     c->degree = degree;
     c->logd = ring_only ? -1 : 0;
     if (!ring_only) while ((1 << c->logd) < degree) ++c->logd;
-    c->mod.q = (double)q;
-    c->mod.qinv = 1.0 / (double)q;
+    c->mod = fz_make_mod(q);
 
     double *tw = nullptr, *itw = nullptr, *twB = nullptr, *itwB = nullptr;
     size_t nB = 0;
@@ -143,6 +142,8 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         for (int i = 0; i < 16; ++i) {
             c->twA.w[i] = (i < n) ? tw[i] : 0.0;
             c->itwA.w[i] = (i < n) ? itw[i] : 0.0;
+            c->twA.w2[i] = c->twA.w[i] * c->mod.kq;
+            c->itwA.w2[i] = c->itwA.w[i] * c->mod.kq;
         }
         c->twA.n_inv = c->itwA.n_inv = (double)n_inv;
         c->twA.w1_n_inv = 0.0;
@@ -151,7 +152,7 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         // per-lane tables of the contiguous pass ([NE][L]); see fz_ntt.hip / tools/ntt_layout_model.py
         if (k >= 5) {
             const int L = n / 16, SB = k - 4, NE = 16 - (16 >> SB);
-            nB = (size_t)NE * L;
+            nB = (size_t)NE * L * 2;                       // (w, w * K / q) pairs
             twB = (double *)malloc(sizeof(double) * nB);
             itwB = (double *)malloc(sizeof(double) * nB);
             for (int ls = 0; ls < SB; ++ls) {
@@ -159,12 +160,20 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
                     const int t = 1 << (SB - 1 - ls), ng = 16 / (2 * t);
                     const int ebase = (16 >> SB) * ((1 << ls) - 1);
                     for (int g = 0; g < ng; ++g)
-                        for (int b = 0; b < L; ++b) twB[(size_t)(ebase + g) * L + b] = tw[(16 << ls) + b * ng + g];
+                        for (int b = 0; b < L; ++b) {
+                            const double w = tw[(16 << ls) + b * ng + g];
+                            twB[((size_t)(ebase + g) * L + b) * 2] = w;
+                            twB[((size_t)(ebase + g) * L + b) * 2 + 1] = w * c->mod.kq;
+                        }
                 }
                 {   // inverse: distance 2^ls
                     const int ng = 8 >> ls, ebase = 16 - (16 >> ls);
                     for (int g = 0; g < ng; ++g)
-                        for (int b = 0; b < L; ++b) itwB[(size_t)(ebase + g) * L + b] = itw[(n >> (ls + 1)) + b * ng + g];
+                        for (int b = 0; b < L; ++b) {
+                            const double w = itw[(n >> (ls + 1)) + b * ng + g];
+                            itwB[((size_t)(ebase + g) * L + b) * 2] = w;
+                            itwB[((size_t)(ebase + g) * L + b) * 2 + 1] = w * c->mod.kq;
+                        }
                 }
             }
         }

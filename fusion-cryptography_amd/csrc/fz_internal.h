@@ -11,6 +11,7 @@
 // segment and reach the kernel as scalar loads (SGPR operands of the fp64 multiplies).
 struct FzTwA {
     double w[16];      // entries 1..15 of the bit-reversed power table (entry 0 unused)
+    double w2[16];     // w[i] * K / q (quotient twiddles of fz_mulmod4)
     double n_inv;      // degree^{-1} mod q            (inverse only)
     double w1_n_inv;   // w[1] * degree^{-1} mod q      (inverse only: n^{-1} folded into last stage)
 };
@@ -27,7 +28,7 @@ struct fz_ctx {
     uint32_t *h_tw, *h_itw;
     // device tables
     double *d_tw, *d_itw;        // [degree] as doubles (generic / small kernels)
-    double *d_twB, *d_itwB;      // per-lane tables of the contiguous pass, [NE][L]
+    double *d_twB, *d_itwB;      // per-lane tables of the contiguous pass, [NE][L] pairs (w, w*K/q)
     FzTwA twA, itwA;
     // growable device scratch (host-pointer entry points, int64 partial sums)
     void *d_scratch;

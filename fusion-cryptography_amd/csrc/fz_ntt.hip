@@ -83,32 +83,58 @@ __device__ __forceinline__ void chunk_store(int32_t *out, size_t task, size_t to
 // ------------------------------------------------------------------------------------------
 // forward: strided pass -> transpose -> contiguous pass
 // ------------------------------------------------------------------------------------------
-template <int LOGD>
-__global__ __launch_bounds__(64) void ntt_fwd16(const int32_t *in, int32_t *out, size_t batch,
-                                                const double *__restrict__ twB, FzTwA twA, FzMod m) {
+// Wave-local synchronisation.  Every LDS exchange in these kernels is between lanes of ONE wave
+// (each wave owns a private staging region), and a wave's DS instructions execute in order, so no
+// s_barrier is needed: the release/acquire pair makes the compiler wait for the outstanding LDS
+// operations (s_waitcnt lgkmcnt(0)) and keeps it from moving LDS accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+constexpr int kWavesPerBlock = 4;
+
+// one twiddle multiply: 4-op pseudo-Mersenne form when FAST (operand bound |a| <= 2^38), else 6-op
+template <bool FAST>
+__device__ __forceinline__ double tw_mul(double a, double w, double w2, const FzMod m) {
+    return FAST ? fz_mulmod4(a, w, w2, m) : fz_mulmod(a, w, m);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: strided pass -> transpose -> contiguous pass
+// ------------------------------------------------------------------------------------------
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd16(const int32_t *in, int32_t *out, size_t batch,
+                                                                 const double2 *__restrict__ twB, FzTwA twA, FzMod m) {
     using G = Geom<LOGD>;
     constexpr int D = G::D, L = G::L, PPW = G::PPW, SB = G::SB, NE = G::NE, PS = G::PS;
-    static_assert(PPW * PS * 2 >= kStageWords, "staging image must fit in the transpose buffer");
-    __shared__ __attribute__((aligned(16))) double lds[PPW * PS + NE * L];
-    double *s_tw = lds + PPW * PS;
-    int32_t *stage = reinterpret_cast<int32_t *>(lds);
+    constexpr int REGION = PPW * PS;                      // doubles per wave
+    static_assert(REGION * 2 >= kStageWords, "staging image must fit in the transpose buffer");
+    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * REGION + 2 * NE * L];
+    double2 *s_tw = reinterpret_cast<double2 *>(lds + kWavesPerBlock * REGION);      // (w, w2) pairs, [NE][L]
 
-    const int lane = threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane / L, r = lane % L;
-    for (int i = lane; i < NE * L; i += 64) s_tw[i] = twB[i];
-    double *row = lds + p * PS;
+    for (int i = threadIdx.x; i < NE * L; i += 64 * kWavesPerBlock) s_tw[i] = twB[i];
+    __syncthreads();                                      // the only workgroup-wide barrier
+    double *region = lds + wave * REGION;
+    int32_t *stage = reinterpret_cast<int32_t *>(region);
+    double *row = region + p * PS;
 
     const size_t total = batch * D;
     const size_t tasks = (total + kChunk - 1) / kChunk;
-    Chunk raw = chunk_load(in, blockIdx.x < tasks ? blockIdx.x : 0, total, lane);
-    __syncthreads();
+    const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave;
+    const size_t stride = (size_t)gridDim.x * kWavesPerBlock;
+    if (first >= tasks) return;
+    Chunk raw = chunk_load(in, first, total, lane);
 
-    for (size_t task = blockIdx.x; task < tasks; task += gridDim.x) {
+    for (size_t task = first; task < tasks; task += stride) {
         // stage the chunk, then prefetch the next task's chunk into registers (in flight during
         // the whole compute phase)
         chunk_to_lds(stage, lane, raw);
-        if (task + gridDim.x < tasks) raw = chunk_load(in, task + gridDim.x, total, lane);
-        __syncthreads();
+        if (task + stride < tasks) raw = chunk_load(in, task + stride, total, lane);
+        wave_sync();
         double a[16];
         {
             int x[16];
@@ -117,17 +143,17 @@ __global__ __launch_bounds__(64) void ntt_fwd16(const int32_t *in, int32_t *out,
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = (double)x[k];
         }
-        __syncthreads();
+        wave_sync();
 
-        // strided pass: a 16-point LN transform over k with table entries 1..15
+        // strided pass: a 16-point LN transform over k with table entries 1..15 (|a| < 2^34 throughout)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int tk = 8 >> s;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 if (k & tk) continue;
-                const double w = twA.w[(1 << s) + (k >> (4 - s))];
-                const double v = fz_mulmod(a[k + tk], w, m);
+                const int e = (1 << s) + (k >> (4 - s));
+                const double v = tw_mul<FAST>(a[k + tk], twA.w[e], twA.w2[e], m);
                 const double u = a[k];
                 a[k] = u + v;
                 a[k + tk] = u - v;
@@ -137,7 +163,7 @@ __global__ __launch_bounds__(64) void ntt_fwd16(const int32_t *in, int32_t *out,
         // transpose: element j = r + L*k  ->  lane j/16, register j%16
 #pragma unroll
         for (int k = 0; k < 16; ++k) row[pad16(r + L * k)] = a[k];
-        __syncthreads();
+        wave_sync();
         {
             const double2 *blk = reinterpret_cast<const double2 *>(row + 18 * r);
 #pragma unroll
@@ -147,7 +173,7 @@ __global__ __launch_bounds__(64) void ntt_fwd16(const int32_t *in, int32_t *out,
                 a[2 * k + 1] = t.y;
             }
         }
-        __syncthreads();
+        wave_sync();
 
         // contiguous pass: stages with distance 2^(SB-1) .. 1, per-lane twiddles
 #pragma unroll
@@ -158,8 +184,8 @@ __global__ __launch_bounds__(64) void ntt_fwd16(const int32_t *in, int32_t *out,
             for (int k = 0; k < 16; ++k) {
                 if (k & t) continue;
                 const int g = k >> (SB - ls);
-                const double w = s_tw[(ebase + g) * L + r];
-                const double v = fz_mulmod(a[k + t], w, m);
+                const double2 w = s_tw[(ebase + g) * L + r];
+                const double v = tw_mul<FAST>(a[k + t], w.x, w.y, m);
                 const double u = a[k];
                 a[k] = u + v;
                 a[k + t] = u - v;
@@ -176,38 +202,43 @@ __global__ __launch_bounds__(64) void ntt_fwd16(const int32_t *in, int32_t *out,
             o.w = (int)fz_cent(a[4 * k + 3], m);
             *reinterpret_cast<int4 *>(stage + pad4(16 * lane + 4 * k)) = o;
         }
-        __syncthreads();
+        wave_sync();
         chunk_store(out, task, total, lane, stage);
-        __syncthreads();   // the staging image is rewritten by the next task
+        wave_sync();   // the staging image is rewritten by the next task
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // inverse: contiguous pass -> transpose -> strided pass (n^{-1} folded into the last stage)
 // ------------------------------------------------------------------------------------------
-template <int LOGD>
-__global__ __launch_bounds__(64) void ntt_inv16(const int32_t *in, int32_t *out, size_t batch,
-                                                const double *__restrict__ itwB, FzTwA twA, FzMod m) {
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *in, int32_t *out, size_t batch,
+                                                                 const double2 *__restrict__ itwB, FzTwA twA, FzMod m) {
     using G = Geom<LOGD>;
     constexpr int D = G::D, L = G::L, PPW = G::PPW, SB = G::SB, NE = G::NE, PS = G::PS;
-    __shared__ __attribute__((aligned(16))) double lds[PPW * PS + NE * L];
-    double *s_tw = lds + PPW * PS;
-    int32_t *stage = reinterpret_cast<int32_t *>(lds);
+    constexpr int REGION = PPW * PS;
+    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * REGION + 2 * NE * L];
+    double2 *s_tw = reinterpret_cast<double2 *>(lds + kWavesPerBlock * REGION);
 
-    const int lane = threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane / L, r = lane % L;
-    for (int i = lane; i < NE * L; i += 64) s_tw[i] = itwB[i];
-    double *row = lds + p * PS;
+    for (int i = threadIdx.x; i < NE * L; i += 64 * kWavesPerBlock) s_tw[i] = itwB[i];
+    __syncthreads();
+    double *region = lds + wave * REGION;
+    int32_t *stage = reinterpret_cast<int32_t *>(region);
+    double *row = region + p * PS;
 
     const size_t total = batch * D;
     const size_t tasks = (total + kChunk - 1) / kChunk;
-    Chunk raw = chunk_load(in, blockIdx.x < tasks ? blockIdx.x : 0, total, lane);
-    __syncthreads();
+    const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave;
+    const size_t stride = (size_t)gridDim.x * kWavesPerBlock;
+    if (first >= tasks) return;
+    Chunk raw = chunk_load(in, first, total, lane);
 
-    for (size_t task = blockIdx.x; task < tasks; task += gridDim.x) {
+    for (size_t task = first; task < tasks; task += stride) {
         chunk_to_lds(stage, lane, raw);
-        if (task + gridDim.x < tasks) raw = chunk_load(in, task + gridDim.x, total, lane);
-        __syncthreads();
+        if (task + stride < tasks) raw = chunk_load(in, task + stride, total, lane);
+        wave_sync();
         double a[16];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -217,9 +248,9 @@ __global__ __launch_bounds__(64) void ntt_inv16(const int32_t *in, int32_t *out,
             a[4 * k + 2] = (double)t.z;
             a[4 * k + 3] = (double)t.w;
         }
-        __syncthreads();
+        wave_sync();
 
-        // contiguous pass: GS stages with distance 1, 2, .. 2^(SB-1)
+        // contiguous pass: GS stages with distance 1, 2, .. 2^(SB-1); operands |u - v| <= 2^(32+ls)
 #pragma unroll
         for (int ls = 0; ls < SB; ++ls) {
             const int t = 1 << ls;
@@ -228,10 +259,10 @@ __global__ __launch_bounds__(64) void ntt_inv16(const int32_t *in, int32_t *out,
             for (int k = 0; k < 16; ++k) {
                 if (k & t) continue;
                 const int g = k >> (ls + 1);
-                const double w = s_tw[(ebase + g) * L + r];
+                const double2 w = s_tw[(ebase + g) * L + r];
                 const double u = a[k], v = a[k + t];
                 a[k] = u + v;
-                a[k + t] = fz_mulmod(u - v, w, m);
+                a[k + t] = tw_mul<FAST>(u - v, w.x, w.y, m);
             }
         }
 
@@ -241,12 +272,14 @@ __global__ __launch_bounds__(64) void ntt_inv16(const int32_t *in, int32_t *out,
 #pragma unroll
             for (int k = 0; k < 8; ++k) blk[k] = make_double2(a[2 * k], a[2 * k + 1]);
         }
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int k = 0; k < 16; ++k) a[k] = row[pad16(r + L * k)];
-        __syncthreads();
+        wave_sync();
 
-        // strided pass: GS stages with distance L, 2L, 4L, 8L; uniform twiddles
+        // strided pass: GS stages with distance L, 2L, 4L, 8L; uniform twiddles.  With raw int32
+        // inputs the lazily accumulated operands reach 2^(32+SB+s): the last stage (up to 2^39) is
+        // beyond the 4-op multiply's bound and uses the general 6-op form.
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int tk = 1 << s;
@@ -259,18 +292,19 @@ __global__ __launch_bounds__(64) void ntt_inv16(const int32_t *in, int32_t *out,
                     a[k] = fz_mulmod(u + v, twA.n_inv, m);
                     a[k + tk] = fz_mulmod(u - v, twA.w1_n_inv, m);
                 } else {
-                    const double w = twA.w[h + (k >> (s + 1))];
+                    const int e = h + (k >> (s + 1));
                     a[k] = u + v;
-                    a[k + tk] = fz_mulmod(u - v, w, m);
+                    a[k + tk] = (SB + s <= 6) ? tw_mul<FAST>(u - v, twA.w[e], twA.w2[e], m)
+                                              : fz_mulmod(u - v, twA.w[e], m);
                 }
             }
         }
 
 #pragma unroll
         for (int k = 0; k < 16; ++k) stage[pad4(p * D + r + L * k)] = (int)fz_cent(a[k], m);
-        __syncthreads();
+        wave_sync();
         chunk_store(out, task, total, lane, stage);
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -321,24 +355,32 @@ __global__ __launch_bounds__(256) void ntt_small(const int32_t *in, int32_t *out
     for (int k = 0; k < D; ++k) out[poly * D + k] = (int)fz_cent(a[k], m);
 }
 
-template <int LOGD>
-int launch16(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
+template <int LOGD, bool FAST>
+int launch16f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
     const size_t tasks = (batch * Geom<LOGD>::D + kChunk - 1) / kChunk;
+    const size_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
     const int cap = inverse ? ctx->grid_inv : ctx->grid_fwd;
-    const unsigned grid = (unsigned)(tasks < (size_t)cap ? tasks : (size_t)cap);
+    const unsigned grid = (unsigned)(blocks < (size_t)cap ? blocks : (size_t)cap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_on && ctx->prof_n < ctx->prof_cap) {
         e0 = ctx->prof_ev[2 * ctx->prof_n];
         e1 = ctx->prof_ev[2 * ctx->prof_n + 1];
         ctx->prof_kind[ctx->prof_n++] = inverse ? 1 : 0;
     }
+    const dim3 block(64 * kWavesPerBlock);
     if (!inverse)
-        hipExtLaunchKernelGGL(ntt_fwd16<LOGD>, dim3(grid), dim3(64), 0, ctx->stream, e0, e1, 0, in, out, batch,
-                              (const double *)ctx->d_twB, ctx->twA, ctx->mod);
+        hipExtLaunchKernelGGL((ntt_fwd16<LOGD, FAST>), dim3(grid), block, 0, ctx->stream, e0, e1, 0, in, out, batch,
+                              (const double2 *)ctx->d_twB, ctx->twA, ctx->mod);
     else
-        hipExtLaunchKernelGGL(ntt_inv16<LOGD>, dim3(grid), dim3(64), 0, ctx->stream, e0, e1, 0, in, out, batch,
-                              (const double *)ctx->d_itwB, ctx->itwA, ctx->mod);
+        hipExtLaunchKernelGGL((ntt_inv16<LOGD, FAST>), dim3(grid), block, 0, ctx->stream, e0, e1, 0, in, out, batch,
+                              (const double2 *)ctx->d_itwB, ctx->itwA, ctx->mod);
     return fz_check_hip(hipGetLastError(), "ntt16 launch");
+}
+
+template <int LOGD>
+int launch16(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
+    return ctx->mod.fast ? launch16f<LOGD, true>(ctx, in, out, batch, inverse)
+                         : launch16f<LOGD, false>(ctx, in, out, batch, inverse);
 }
 
 template <int LOGD>
@@ -353,18 +395,24 @@ int launch_small(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, boo
     return fz_check_hip(hipGetLastError(), "ntt_small launch");
 }
 
-template <int LOGD>
-int query16(fz_ctx *ctx) {
+template <int LOGD, bool FAST>
+int query16f(fz_ctx *ctx) {
     int nf = 0, ni = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, ntt_fwd16<LOGD>, 64, 0);
+    const int threads = 64 * kWavesPerBlock;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, ntt_fwd16<LOGD, FAST>, threads, 0);
     if (e != hipSuccess) return fz_check_hip(e, "occupancy query (fwd)");
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&ni, ntt_inv16<LOGD>, 64, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&ni, ntt_inv16<LOGD, FAST>, threads, 0);
     if (e != hipSuccess) return fz_check_hip(e, "occupancy query (inv)");
     if (nf < 1) nf = 1;
     if (ni < 1) ni = 1;
     ctx->grid_fwd = nf * ctx->num_cu;
     ctx->grid_inv = ni * ctx->num_cu;
     return FZ_OK;
+}
+
+template <int LOGD>
+int query16(fz_ctx *ctx) {
+    return ctx->mod.fast ? query16f<LOGD, true>(ctx) : query16f<LOGD, false>(ctx);
 }
 
 }  // namespace

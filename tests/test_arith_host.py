@@ -60,3 +60,42 @@ def test_cent_and_mulmod(q, lib):
         r = lib.t_mulmod(float(a), float(b), float(q))
         assert r == int(r) and (int(r) - a * b) % q == 0
         assert abs(r) <= q / 2 + q * 2.0**-10 + 1
+
+
+SRC4 = r'''
+#include "fz_arith.h"
+extern "C" {
+double t_mulmod4(double a, double w, unsigned q) { FzMod m = fz_make_mod(q); return fz_mulmod4(a, w, w * m.kq, m); }
+int t_fast(unsigned q) { return fz_make_mod(q).fast; }
+double t_kappa_times_K(unsigned q) { FzMod m = fz_make_mod(q); return m.kappa * m.K; }
+}
+'''
+
+
+def test_mulmod4_exact_at_its_bounds(tmp_path):
+    src = tmp_path / "t4.cpp"
+    src.write_text(SRC4)
+    so = tmp_path / "libt4.so"
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I",
+                           os.path.join(ROOT, "fusion-cryptography_amd", "csrc"), "-o", str(so), str(src)])
+    L = ctypes.CDLL(str(so))
+    L.t_mulmod4.restype = ctypes.c_double
+    L.t_mulmod4.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_uint]
+    L.t_fast.argtypes = [ctypes.c_uint]
+    L.t_kappa_times_K.restype = ctypes.c_double
+    L.t_kappa_times_K.argtypes = [ctypes.c_uint]
+    assert L.t_fast(2147465729) == 1 and L.t_fast(12289) == 1 and L.t_fast(65537) == 0 and L.t_fast(40961) == 1
+    assert L.t_kappa_times_K(2147465729) == 17919.0
+    for q in (2147465729, 12289, 7681, 257, 97, 17, 5, 3, 40961, 2147483647 - 32766 * 0 - 18):
+        if not L.t_fast(q):
+            continue
+        rng = random.Random(q + 1)
+        A = [0, 1, -1, 2**38, -2**38, 2**38 - 1, 2**31, -2**31, q, q // 2, -(q // 2), 2**37 + 12345]
+        A += [rng.randrange(-2**38, 2**38 + 1) for _ in range(6000)]
+        W = [0, 1, q - 1, q // 2, q // 2 + 1] + [rng.randrange(q) for _ in range(12)]
+        for a in A:
+            for w in W:
+                r = L.t_mulmod4(float(a), float(w), q)
+                assert r == int(r), (q, a, w)
+                assert (int(r) - a * w) % q == 0, (q, a, w)
+                assert abs(r) <= q / 2 + q * 2.0**-12 + 1, (q, a, w, r)

@@ -1,0 +1,24 @@
+"""Minimal launcher for profiling: runs the forward and inverse NTT kernels a few times on a large
+device-resident batch.  usage: prof_ntt.py [log2_batch] [reps] [secpar]"""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fusion-cryptography_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import fusion_hip
+from oracle import oracle as O
+
+logB = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+secpar = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+P = O.PARAMS[secpar]
+d = P["d"]
+ctx = fusion_hip.Context(P["q"], d, P["root"], P["inv_root"])
+B = 1 << logB
+x = O.splitmix_centered(5, B * d).reshape(B, d)
+din = fusion_hip.DeviceBuffer.from_numpy(ctx, x)
+dout = fusion_hip.DeviceBuffer(ctx, x.nbytes)
+for _ in range(reps):
+    ctx.ntt_forward_dev(din.ptr, dout.ptr, B)
+    ctx.ntt_inverse_dev(dout.ptr, din.ptr, B)
+ctx.synchronize()
+print("done", B, reps)

@@ -276,8 +276,8 @@ int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms) {
     return FZ_OK;
 }
 
-int fz_profile_begin(fz_ctx *ctx, int max_launches) {
-    FZ_REQUIRE(ctx && max_launches > 0 && max_launches <= (1 << 20), "bad argument");
+int fz_profile_begin(fz_ctx *ctx, int max_launches, int sample_every) {
+    FZ_REQUIRE(ctx && max_launches > 0 && max_launches <= (1 << 20) && sample_every >= 1, "bad argument");
     if (max_launches > ctx->prof_cap) {
         hipEvent_t *ev = (hipEvent_t *)realloc(ctx->prof_ev, sizeof(hipEvent_t) * 2 * (size_t)max_launches);
         unsigned char *kind = (unsigned char *)realloc(ctx->prof_kind, (size_t)max_launches);
@@ -288,6 +288,8 @@ int fz_profile_begin(fz_ctx *ctx, int max_launches) {
         ctx->prof_cap = max_launches;
     }
     ctx->prof_n = 0;
+    ctx->prof_every = sample_every;
+    ctx->prof_seen[0] = ctx->prof_seen[1] = 0;
     ctx->prof_on = 1;
     return FZ_OK;
 }

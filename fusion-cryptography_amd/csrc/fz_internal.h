@@ -37,7 +37,7 @@ struct fz_ctx {
     int grid_fwd, grid_inv;      // resident-grid caps for the persistent NTT kernels
     // per-dispatch timing of the NTT kernels (fz_profile_begin/end): event pairs bound to the
     // dispatch itself via hipExtLaunchKernelGGL, i.e. kernel begin -> kernel end on its own stream
-    int prof_on, prof_cap, prof_n;
+    int prof_on, prof_cap, prof_n, prof_every, prof_seen[2];
     hipEvent_t *prof_ev;         // 2 * prof_cap events
     unsigned char *prof_kind;    // 0 forward, 1 inverse
 };

@@ -362,7 +362,7 @@ int launch16f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool i
     const int cap = inverse ? ctx->grid_inv : ctx->grid_fwd;
     const unsigned grid = (unsigned)(blocks < (size_t)cap ? blocks : (size_t)cap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->prof_on && ctx->prof_n < ctx->prof_cap) {
+    if (ctx->prof_on && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen[inverse ? 1 : 0]++ % ctx->prof_every) == 0) {
         e0 = ctx->prof_ev[2 * ctx->prof_n];
         e1 = ctx->prof_ev[2 * ctx->prof_n + 1];
         ctx->prof_kind[ctx->prof_n++] = inverse ? 1 : 0;

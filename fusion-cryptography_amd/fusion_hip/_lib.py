@@ -48,7 +48,7 @@ SIGNATURES = {
     "fz_memcpy_d2h": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
     "fz_timer_start": (c_int, [_ctx]),
     "fz_timer_stop_ms": (c_int, [_ctx, POINTER(c_float)]),
-    "fz_profile_begin": (c_int, [_ctx, c_int]),
+    "fz_profile_begin": (c_int, [_ctx, c_int, c_int]),
     "fz_profile_end": (c_int, [_ctx, POINTER(ctypes.c_double), POINTER(c_int), POINTER(ctypes.c_double), POINTER(c_int)]),
     "fz_ntt_forward": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
     "fz_ntt_inverse": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),

@@ -100,8 +100,8 @@ class Context:
         check(self._lib, self._lib.fz_timer_stop_ms(self._h, byref(ms)))
         return ms.value
 
-    def profile_begin(self, max_launches):
-        check(self._lib, self._lib.fz_profile_begin(self._h, max_launches))
+    def profile_begin(self, max_launches, sample_every=1):
+        check(self._lib, self._lib.fz_profile_begin(self._h, max_launches, sample_every))
 
     def profile_end(self):
         """-> dict(fwd_avg_us, fwd_count, inv_avg_us, inv_count): kernel begin->end per dispatch"""

@@ -84,10 +84,11 @@ FZ_API int fz_memcpy_d2h(fz_ctx *ctx, void *h_dst, const void *d_src, size_t byt
 FZ_API int fz_timer_start(fz_ctx *ctx);
 FZ_API int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms);        /* records, waits, returns elapsed ms */
 
-/* per-dispatch timing of the transform kernels: while enabled, every fz_ntt_forward / fz_ntt_inverse
- * launch carries a start/stop event pair bound to the dispatch (kernel begin -> kernel end on the
- * context's stream).  fz_profile_end synchronises and returns the average durations in microseconds. */
-FZ_API int fz_profile_begin(fz_ctx *ctx, int max_launches);
+/* per-dispatch timing of the transform kernels: while enabled, every `sample_every`-th
+ * fz_ntt_forward / fz_ntt_inverse launch carries a start/stop event pair bound to the dispatch
+ * (kernel begin -> kernel end on the context's stream; at most max_launches pairs).
+ * fz_profile_end synchronises and returns the average durations in microseconds. */
+FZ_API int fz_profile_begin(fz_ctx *ctx, int max_launches, int sample_every);
 FZ_API int fz_profile_end(fz_ctx *ctx, double *fwd_avg_us, int *fwd_count, double *inv_avg_us, int *inv_count);
 
 /* ---- transforms ---------------------------------------------------------------------------

@@ -148,6 +148,9 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         c->twA.n_inv = c->itwA.n_inv = (double)n_inv;
         c->twA.w1_n_inv = 0.0;
         c->itwA.w1_n_inv = (double)(((unsigned __int128)c->h_itw[1] * n_inv) % q);
+        c->twA.n_inv2 = c->itwA.n_inv2 = c->itwA.n_inv * c->mod.kq;
+        c->twA.w1_n_inv2 = 0.0;
+        c->itwA.w1_n_inv2 = c->itwA.w1_n_inv * c->mod.kq;
 
         // per-lane tables of the contiguous pass ([NE][L]); see fz_ntt.hip / tools/ntt_layout_model.py
         if (k >= 5) {
@@ -183,6 +186,26 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     if (rc == FZ_OK) rc = fz_check_hip(hipEventCreate(&c->ev1), "event create");
     if (rc == FZ_OK) rc = upload_doubles(tw, n, &c->d_tw);
     if (rc == FZ_OK) rc = upload_doubles(itw, n, &c->d_itw);
+    if (rc == FZ_OK && !ring_only) {
+        double *pairs = (double *)malloc(sizeof(double) * 4 * (size_t)n);
+        for (int i = 0; i < n; ++i) {
+            pairs[2 * i] = tw[i];
+            pairs[2 * i + 1] = tw[i] * c->mod.kq;
+            pairs[2 * n + 2 * i] = itw[i];
+            pairs[2 * n + 2 * i + 1] = itw[i] * c->mod.kq;
+        }
+        rc = upload_doubles(pairs, 2 * (size_t)n, &c->d_tw2);
+        if (rc == FZ_OK) rc = upload_doubles(pairs + 2 * n, 2 * (size_t)n, &c->d_itw2);
+        free(pairs);
+    }
+    {
+        const char *e = getenv("FZ_NTT_KERNEL");
+        c->force_kernel = e ? atoi(e) : 0;
+        e = getenv("FZ_NTT_SMALL_ROWS");
+        // measured crossover (profiles/README.md): degree 256 -- radix-4 wins up to 2^16 rows (cache-
+        // resident batches), the 16-per-lane kernel from 2^20 rows; degree 64 -- radix-4 at every size
+        c->small_batch_rows = e ? atoi(e) : (degree == 256 ? (1 << 17) : 0x7fffffff);
+    }
     if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
     if (rc == FZ_OK) rc = upload_doubles(itwB, nB, &c->d_itwB);
     if (rc == FZ_OK) rc = fz_check_hip(hipMalloc((void **)&c->d_verdict, sizeof(int)), "verdict alloc");
@@ -199,6 +222,8 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_tw) (void)hipFree(ctx->d_tw);
     if (ctx->d_itw) (void)hipFree(ctx->d_itw);
+    if (ctx->d_tw2) (void)hipFree(ctx->d_tw2);
+    if (ctx->d_itw2) (void)hipFree(ctx->d_itw2);
     if (ctx->d_twB) (void)hipFree(ctx->d_twB);
     if (ctx->d_itwB) (void)hipFree(ctx->d_itwB);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);

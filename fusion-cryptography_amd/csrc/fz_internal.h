@@ -14,6 +14,7 @@ struct FzTwA {
     double w2[16];     // w[i] * K / q (quotient twiddles of fz_mulmod4)
     double n_inv;      // degree^{-1} mod q            (inverse only)
     double w1_n_inv;   // w[1] * degree^{-1} mod q      (inverse only: n^{-1} folded into last stage)
+    double n_inv2, w1_n_inv2;   // their quotient twiddles
 };
 
 struct fz_ctx {
@@ -29,6 +30,9 @@ struct fz_ctx {
     // device tables
     double *d_tw, *d_itw;        // [degree] as doubles (generic / small kernels)
     double *d_twB, *d_itwB;      // per-lane tables of the contiguous pass, [NE][L] pairs (w, w*K/q)
+    double *d_tw2, *d_itw2;      // full tables as (w, w*K/q) pairs, [degree] (radix-4 kernels)
+    int small_batch_rows;        // below this many rows the radix-4 (4 coefficients per lane) kernels run
+    int force_kernel;            // 0 auto, 4 radix-4, 16 sixteen-per-lane (env FZ_NTT_KERNEL; benchmarking)
     FzTwA twA, itwA;
     // growable device scratch (host-pointer entry points, int64 partial sums)
     void *d_scratch;

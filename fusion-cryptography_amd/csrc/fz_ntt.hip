@@ -309,6 +309,190 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
 }
 
 // ------------------------------------------------------------------------------------------
+// 4 coefficients per lane ("radix-4 in place"): the low-latency schedule for batches that give the
+// 16-per-lane kernels less than a few waves per SIMD (BASELINE's B = 4096 is one wave per SIMD
+// there).  D/4 lanes own a polynomial; log4(D) passes of two stages each on 4 registers
+// {base + k*s}, s = D/4, D/16, .., 1; between passes the polynomial lives in LDS as doubles at
+// XOR-swizzled natural positions (conflict-free ds_read/write_b64 for every pass stride, 2-way on
+// the final 16-byte accesses).  Global traffic needs no staging: the first pass reads
+// x[m + (D/4)k] (256 B contiguous per wave instruction), the last leaves 4 contiguous outputs per
+// lane (16-byte coalesced stores); mirrored for the inverse.  Pass 0 twiddles are wave-uniform
+// (SGPR); each later pass uses 3 per-lane twiddles kept in registers across tasks.
+// Only even log2(D) (the scheme's degrees 64 and 256).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz4(int j) { return j ^ (((j >> 4) & 7) << 2); }
+
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *in, int32_t *out, size_t batch,
+                                                                const double2 *__restrict__ tw2, FzTwA twA, FzMod m) {
+    constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
+    static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
+    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = lane / LP, mm = lane % LP;
+    double *region = lds + wave * 256 + p * D;
+
+    const size_t tasks = (batch + PPW - 1) / PPW;
+    const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave;
+    const size_t stride = (size_t)gridDim.x * kWavesPerBlock;
+    if (first >= tasks) return;
+
+    // per-lane twiddles of passes 1..P-1 (independent of the data: issued before the first load returns)
+    double2 twl[P - 1][3];
+#pragma unroll
+    for (int i = 1; i < P; ++i) {
+        const int s = D >> (2 * i + 2), g = mm / s, pw = 1 << (2 * i);
+        twl[i - 1][0] = tw2[pw + g];
+        twl[i - 1][1] = tw2[2 * pw + 2 * g];
+        twl[i - 1][2] = tw2[2 * pw + 2 * g + 1];
+    }
+
+    for (size_t task = first; task < tasks; task += stride) {
+        const size_t poly = task * PPW + p;
+        const bool valid = poly < batch;
+        const int32_t *src = in + (valid ? poly : batch - 1) * D + mm;
+        double a[4];
+        {
+            int x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = src[k * LP];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = (double)x[k];
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int s = D >> (2 * i + 2);
+            const int base = (mm / s) * 4 * s + mm % s;
+            double wA, wA2, wB0, wB02, wB1, wB12;
+            if (i == 0) {
+                wA = twA.w[1]; wA2 = twA.w2[1]; wB0 = twA.w[2]; wB02 = twA.w2[2]; wB1 = twA.w[3]; wB12 = twA.w2[3];
+            } else {
+                wA = twl[i - 1][0].x; wA2 = twl[i - 1][0].y;
+                wB0 = twl[i - 1][1].x; wB02 = twl[i - 1][1].y;
+                wB1 = twl[i - 1][2].x; wB12 = twl[i - 1][2].y;
+                wave_sync();
+                if (s == 1) {
+                    const double2 lo = *reinterpret_cast<const double2 *>(region + swz4(base));
+                    const double2 hi = *reinterpret_cast<const double2 *>(region + swz4(base + 2));
+                    a[0] = lo.x; a[1] = lo.y; a[2] = hi.x; a[3] = hi.y;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[k] = region[swz4(base + k * s)];
+                }
+            }
+            // stage 2i: distance 2s, one twiddle; stage 2i+1: distance s, two twiddles
+            double v = tw_mul<FAST>(a[2], wA, wA2, m), u = a[0];
+            a[0] = u + v; a[2] = u - v;
+            v = tw_mul<FAST>(a[3], wA, wA2, m); u = a[1];
+            a[1] = u + v; a[3] = u - v;
+            v = tw_mul<FAST>(a[1], wB0, wB02, m); u = a[0];
+            a[0] = u + v; a[1] = u - v;
+            v = tw_mul<FAST>(a[3], wB1, wB12, m); u = a[2];
+            a[2] = u + v; a[3] = u - v;
+            if (i < P - 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) region[swz4(base + k * s)] = a[k];
+            }
+        }
+        if (valid) {
+            int4 o;
+            o.x = (int)fz_cent(a[0], m);
+            o.y = (int)fz_cent(a[1], m);
+            o.z = (int)fz_cent(a[2], m);
+            o.w = (int)fz_cent(a[3], m);
+            *reinterpret_cast<int4 *>(out + poly * D + 4 * mm) = o;
+        }
+        wave_sync();      // the next task's first-pass writes must not overtake this task's last reads
+    }
+}
+
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *in, int32_t *out, size_t batch,
+                                                                const double2 *__restrict__ itw2, FzTwA twA, FzMod m) {
+    constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
+    static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
+    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = lane / LP, mm = lane % LP;
+    double *region = lds + wave * 256 + p * D;
+
+    const size_t tasks = (batch + PPW - 1) / PPW;
+    const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave;
+    const size_t stride = (size_t)gridDim.x * kWavesPerBlock;
+    if (first >= tasks) return;
+
+    // per-lane twiddles of passes 0..P-2 (the last pass is wave-uniform)
+    double2 twl[P - 1][3];
+#pragma unroll
+    for (int i = 0; i < P - 1; ++i) {
+        const int s = 1 << (2 * i), g = mm / s;
+        twl[i][0] = itw2[D / (2 * s) + 2 * g];
+        twl[i][1] = itw2[D / (2 * s) + 2 * g + 1];
+        twl[i][2] = itw2[D / (4 * s) + g];
+    }
+
+    for (size_t task = first; task < tasks; task += stride) {
+        const size_t poly = task * PPW + p;
+        const bool valid = poly < batch;
+        double a[4];
+        {
+            const int4 x = *reinterpret_cast<const int4 *>(in + (valid ? poly : batch - 1) * D + 4 * mm);
+            a[0] = (double)x.x; a[1] = (double)x.y; a[2] = (double)x.z; a[3] = (double)x.w;
+        }
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int s = 1 << (2 * i);
+            const int base = (mm / s) * 4 * s + mm % s;
+            if (i > 0) {
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = region[swz4(base + k * s)];
+            }
+            if (i < P - 1) {
+                // GS stage 2i (distance s, two twiddles) then stage 2i+1 (distance 2s, one twiddle);
+                // operands stay below 2^(33+2i+1) <= 2^38
+                double u = a[0], v = a[1];
+                a[0] = u + v; a[1] = tw_mul<FAST>(u - v, twl[i][0].x, twl[i][0].y, m);
+                u = a[2]; v = a[3];
+                a[2] = u + v; a[3] = tw_mul<FAST>(u - v, twl[i][1].x, twl[i][1].y, m);
+                u = a[0]; v = a[2];
+                a[0] = u + v; a[2] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
+                u = a[1]; v = a[3];
+                a[1] = u + v; a[3] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
+                if (s == 1) {
+                    *reinterpret_cast<double2 *>(region + swz4(base)) = make_double2(a[0], a[1]);
+                    *reinterpret_cast<double2 *>(region + swz4(base + 2)) = make_double2(a[2], a[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) region[swz4(base + k * s)] = a[k];
+                }
+            } else {
+                // last pass: uniform twiddles itw[2], itw[3], itw[1]; n^-1 folded into the final stage.
+                // With raw int32 inputs the operands of the final stage reach 2^(31+LOGD): beyond the 4-op
+                // multiply's 2^38 bound for degree 256, so that stage uses the general 6-op form.
+                constexpr bool LAST4 = FAST && (31 + LOGD <= 38);
+                double u = a[0], v = a[1];
+                a[0] = u + v; a[1] = tw_mul<FAST>(u - v, twA.w[2], twA.w2[2], m);
+                u = a[2]; v = a[3];
+                a[2] = u + v; a[3] = tw_mul<FAST>(u - v, twA.w[3], twA.w2[3], m);
+                u = a[0]; v = a[2];
+                a[0] = LAST4 ? fz_mulmod4(u + v, twA.n_inv, twA.n_inv2, m) : fz_mulmod(u + v, twA.n_inv, m);
+                a[2] = LAST4 ? fz_mulmod4(u - v, twA.w1_n_inv, twA.w1_n_inv2, m) : fz_mulmod(u - v, twA.w1_n_inv, m);
+                u = a[1]; v = a[3];
+                a[1] = LAST4 ? fz_mulmod4(u + v, twA.n_inv, twA.n_inv2, m) : fz_mulmod(u + v, twA.n_inv, m);
+                a[3] = LAST4 ? fz_mulmod4(u - v, twA.w1_n_inv, twA.w1_n_inv2, m) : fz_mulmod(u - v, twA.w1_n_inv, m);
+            }
+        }
+        if (valid) {
+            int32_t *dst = out + poly * D + mm;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[k * LP] = (int)fz_cent(a[k], m);
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // D <= 16: one thread per polynomial, everything in registers, twiddles uniform
 // ------------------------------------------------------------------------------------------
 template <int LOGD, bool INVERSE>
@@ -377,8 +561,38 @@ int launch16f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool i
     return fz_check_hip(hipGetLastError(), "ntt16 launch");
 }
 
+template <int LOGD, bool FAST>
+int launch4f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
+    constexpr int PPW = 64 / ((1 << LOGD) / 4);
+    const size_t tasks = (batch + PPW - 1) / PPW;
+    const size_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const size_t cap = (size_t)ctx->num_cu * 8;           // up to 8 waves per SIMD resident
+    const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->prof_on && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen[inverse ? 1 : 0]++ % ctx->prof_every) == 0) {
+        e0 = ctx->prof_ev[2 * ctx->prof_n];
+        e1 = ctx->prof_ev[2 * ctx->prof_n + 1];
+        ctx->prof_kind[ctx->prof_n++] = inverse ? 1 : 0;
+    }
+    const dim3 block(64 * kWavesPerBlock);
+    if (!inverse)
+        hipExtLaunchKernelGGL((ntt_fwd4<LOGD, FAST>), dim3(grid), block, 0, ctx->stream, e0, e1, 0, in, out, batch,
+                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod);
+    else
+        hipExtLaunchKernelGGL((ntt_inv4<LOGD, FAST>), dim3(grid), block, 0, ctx->stream, e0, e1, 0, in, out, batch,
+                              (const double2 *)ctx->d_itw2, ctx->itwA, ctx->mod);
+    return fz_check_hip(hipGetLastError(), "ntt4 launch");
+}
+
 template <int LOGD>
 int launch16(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
+    if constexpr (LOGD == 6 || LOGD == 8) {
+        // schedule choice: the radix-4 kernel below `small_batch_rows` rows (latency-bound regime)
+        const bool small = ctx->force_kernel == 4 || (ctx->force_kernel == 0 && batch < (size_t)ctx->small_batch_rows);
+        if (small)
+            return ctx->mod.fast ? launch4f<LOGD, true>(ctx, in, out, batch, inverse)
+                                 : launch4f<LOGD, false>(ctx, in, out, batch, inverse);
+    }
     return ctx->mod.fast ? launch16f<LOGD, true>(ctx, in, out, batch, inverse)
                          : launch16f<LOGD, false>(ctx, in, out, batch, inverse);
 }

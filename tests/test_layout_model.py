@@ -40,3 +40,15 @@ def test_small_model(d, coracle):
     root = root_for(q, d)
     x = O.splitmix_centered(d, d, q)
     assert M.fwd_small([int(v) for v in x], q, root) == coracle.ntt_forward(x, q, root).tolist()
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_radix4_model(secpar, coracle):
+    P = O.PARAMS[secpar]
+    q, d = P["q"], P["d"]
+    x = O.splitmix_centered(secpar, 2 * d, q).reshape(2, d)
+    f, g = coracle.ntt_forward(x, q, P["root"]), coracle.ntt_inverse(x, q, P["inv_root"])
+    for i in range(2):
+        row = [int(v) for v in x[i]]
+        assert M.fwd_radix4(row, q, P["root"]) == f[i].tolist()
+        assert M.inv_radix4(row, q, P["inv_root"]) == g[i].tolist()

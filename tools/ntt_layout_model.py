@@ -122,3 +122,58 @@ def fwd_small(x, q, root):
                 a[j], a[j + t] = (u + v) % q, (u - v) % q
         m *= 2
     return [cent(v, q) for v in a]
+
+
+def fwd_radix4(x, q, root):
+    """4 coefficients per lane, log4(D) in-place passes; mirrors ntt_fwd4<LOGD>."""
+    D = len(x)
+    logd = D.bit_length() - 1
+    assert logd in (6, 8)
+    P, LP = logd // 2, D // 4
+    tw = table(root, q, D)
+    mem = list(x)                       # the LDS image (natural positions; the swizzle is a relabelling)
+    for i in range(P):
+        s = D >> (2 * i + 2)
+        nxt = list(mem)
+        for mm in range(LP):
+            base = (mm // s) * 4 * s + mm % s
+            a = [mem[base + k * s] for k in range(4)]
+            g, pw = mm // s, 1 << (2 * i)
+            wA, wB0, wB1 = tw[pw + g], tw[2 * pw + 2 * g], tw[2 * pw + 2 * g + 1]
+            for (lo, hi, w) in ((0, 2, wA), (1, 3, wA), (0, 1, wB0), (2, 3, wB1)):
+                u, v = a[lo], a[hi] * w
+                a[lo], a[hi] = (u + v) % q, (u - v) % q
+            for k in range(4):
+                nxt[base + k * s] = a[k]
+        mem = nxt
+    return [cent(v, q) for v in mem]
+
+
+def inv_radix4(x, q, inv_root):
+    """mirrors ntt_inv4<LOGD> (n^-1 folded into the final stage)."""
+    D = len(x)
+    logd = D.bit_length() - 1
+    assert logd in (6, 8)
+    P, LP = logd // 2, D // 4
+    itw = table(inv_root, q, D)
+    n_inv = pow(D, q - 2, q)
+    mem = list(x)
+    for i in range(P):
+        s = 1 << (2 * i)
+        nxt = list(mem)
+        for mm in range(LP):
+            base = (mm // s) * 4 * s + mm % s
+            a = [mem[base + k * s] for k in range(4)]
+            g = mm // s
+            wA0, wA1, wB = itw[D // (2 * s) + 2 * g], itw[D // (2 * s) + 2 * g + 1], itw[D // (4 * s) + g]
+            last = i == P - 1
+            for (lo, hi, w, fin) in ((0, 1, wA0, False), (2, 3, wA1, False), (0, 2, wB, last), (1, 3, wB, last)):
+                u, v = a[lo], a[hi]
+                if fin:
+                    a[lo], a[hi] = ((u + v) * n_inv) % q, ((u - v) * (w * n_inv % q)) % q
+                else:
+                    a[lo], a[hi] = (u + v) % q, ((u - v) * w) % q
+            for k in range(4):
+                nxt[base + k * s] = a[k]
+        mem = nxt
+    return [cent(v, q) for v in mem]

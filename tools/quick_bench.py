@@ -9,18 +9,18 @@ from oracle import oracle as O
 
 q = O.PRIME
 orc = O.COracle()
-variants = [0]
+variants = [16, 4]
 secpars = (256, 128)
 for secpar in secpars:
     P = O.PARAMS[secpar]; d = P["d"]
     for var in variants:
-        os.environ["FZ_NTT_VARIANT"] = str(var)
+        os.environ["FZ_NTT_KERNEL"] = str(var)
         ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
         xs = O.splitmix_centered(9, 1003 * d).reshape(1003, d)
         ok = np.array_equal(ctx.ntt_forward(xs), orc.ntt_forward(xs, q, P["root"])) and \
             np.array_equal(ctx.ntt_inverse(xs), orc.ntt_inverse(xs, q, P["inv_root"]))
         line = f"secpar={secpar} var={var} parity={'OK' if ok else 'FAIL'}"
-        for logB in (12, 16, 20):
+        for logB in (12, 14, 16, 20):
             B = 1 << logB
             x = O.splitmix_centered(5, B * d).reshape(B, d)
             din = fusion_hip.DeviceBuffer.from_numpy(ctx, x)

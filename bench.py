@@ -182,28 +182,28 @@ def main():
         ctx.ntt_forward_dev(aa.data_ptr(), al_hat.data_ptr(), S)
         vkL, vkR = vk[:, 0].contiguous(), vk[:, 1].contiguous()
         sig = torch.empty((S, l, d), dtype=torch.int32, device=dev)
-        part = torch.zeros((GROUPS, l * d + d), dtype=torch.int64, device=dev)   # aggregate + target, one buffer
-        agg = torch.empty((GROUPS, l, d), dtype=torch.int32, device=dev)
-        tgt = torch.empty((GROUPS, d), dtype=torch.int32, device=dev)
         per = S // GROUPS
+        # one flat int64 buffer: [GROUPS][l*d] aggregate partials followed by [GROUPS][d] target partials
+        part = torch.zeros(GROUPS * (l * d + d), dtype=torch.int64, device=dev)
+        part_t = part[GROUPS * l * d:]
+        red = torch.empty(GROUPS * (l * d + d), dtype=torch.int32, device=dev)
+        red_t = red[GROUPS * l * d:]
+        from fusion_hip.dist import shard_range
+        g_lo, g_hi = shard_range(GROUPS, rank, world)      # aggregates verified by this rank
         verdicts = []
 
         def sv_step():
             ctx.sign_core_dev(sk_hat.data_ptr(), c_hat.data_ptr(), sig.data_ptr(), S, l)
-            for g in range(GROUPS):
-                lo = g * per
-                ctx.aggregate_partial_dev(sig[lo].data_ptr(), al_hat[lo].data_ptr(), part[g].data_ptr(), per, l)
-                ctx.target_partial_dev(vkL[lo].data_ptr(), vkR[lo].data_ptr(), c_hat[lo].data_ptr(),
-                                       al_hat[lo].data_ptr(), part[g, l * d:].data_ptr(), per)
+            ctx.aggregate_partial_batch_dev(sig.data_ptr(), al_hat.data_ptr(), part.data_ptr(), l * d, GROUPS, per, l)
+            ctx.target_partial_batch_dev(vkL.data_ptr(), vkR.data_ptr(), c_hat.data_ptr(), al_hat.data_ptr(),
+                                         part_t.data_ptr(), d, GROUPS, per)
             allreduce_sum_i64(part)              # the ONE exchange step (RCCL over xGMI when world > 1)
+            ctx.reduce_i64_dev(part.data_ptr(), red.data_ptr(), part.numel())
             verdicts.clear()
-            for g in range(GROUPS):
-                if g % world != rank:
-                    continue                     # aggregates are verified round-robin over the ranks
-                ctx.reduce_i64_dev(part[g].data_ptr(), agg[g].data_ptr(), l * d)
-                ctx.reduce_i64_dev(part[g, l * d:].data_ptr(), tgt[g].data_ptr(), d)
-                verdicts.append(ctx.verify_with_target_dev(A.data_ptr(), agg[g].data_ptr(), tgt[g].data_ptr(), l,
-                                                           P["beta_vf"], d))
+            if g_hi > g_lo:
+                verdicts.extend(ctx.verify_with_target_batch_dev(
+                    A.data_ptr(), red[g_lo * l * d:].data_ptr(), red_t[g_lo * d:].data_ptr(), g_hi - g_lo, l,
+                    P["beta_vf"], d))
         sv_steps = max(3, min(args.steps, 30))
         for _ in range(2):
             sv_step()

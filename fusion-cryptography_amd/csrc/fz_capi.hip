@@ -208,7 +208,8 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     }
     if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
     if (rc == FZ_OK) rc = upload_doubles(itwB, nB, &c->d_itwB);
-    if (rc == FZ_OK) rc = fz_check_hip(hipMalloc((void **)&c->d_verdict, sizeof(int)), "verdict alloc");
+    if (rc == FZ_OK) rc = fz_check_hip(hipMalloc((void **)&c->d_verdict, 64 * sizeof(int)), "verdict alloc");
+    c->verdict_cap = 64;
     if (rc == FZ_OK && !ring_only) rc = fz_ntt_query_grid(c);
     free(tw); free(itw); free(twB); free(itwB);
     if (rc != FZ_OK) { fz_ctx_destroy(c); return rc; }
@@ -438,11 +439,17 @@ int fz_sign_core(fz_ctx *ctx, const int32_t *d_sk_hat, const int32_t *d_c_hat, i
     return fz_launch_sign(ctx, d_sk_hat, d_c_hat, d_sig, batch, l);
 }
 
+int fz_aggregate_partial_batch(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, int64_t *d_partial,
+                               size_t partial_stride, size_t groups, size_t N, int l) {
+    FZ_REQUIRE(ctx && l >= 1 && d_partial && (N == 0 || groups == 0 || (d_sig && d_alpha_hat)), "bad argument");
+    FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large for exact int64/fp64 accumulation (< 2^21)", N);
+    FZ_REQUIRE(groups <= 65535 && (groups <= 1 || partial_stride >= (size_t)l * ctx->degree), "bad groups / stride");
+    return fz_launch_aggregate_partial(ctx, d_sig, d_alpha_hat, d_partial, partial_stride, groups, N, l);
+}
+
 int fz_aggregate_partial(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, int64_t *d_partial,
                          size_t N, int l) {
-    FZ_REQUIRE(ctx && l >= 1 && d_partial && (N == 0 || (d_sig && d_alpha_hat)), "bad argument");
-    FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large for exact int64/fp64 accumulation (< 2^21)", N);
-    return fz_launch_aggregate_partial(ctx, d_sig, d_alpha_hat, d_partial, N, l);
+    return fz_aggregate_partial_batch(ctx, d_sig, d_alpha_hat, d_partial, 0, 1, N, l);
 }
 
 int fz_reduce_i64(fz_ctx *ctx, const int64_t *d_in, int32_t *d_out, size_t count) {
@@ -459,11 +466,18 @@ int fz_aggregate_core(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_
     return fz_launch_reduce_i64(ctx, (const int64_t *)d, d_out, count);
 }
 
+int fz_target_partial_batch(fz_ctx *ctx, const int32_t *d_vkL, const int32_t *d_vkR, const int32_t *d_c_hat,
+                            const int32_t *d_alpha_hat, int64_t *d_partial, size_t partial_stride, size_t groups,
+                            size_t N) {
+    FZ_REQUIRE(ctx && d_partial && (N == 0 || groups == 0 || (d_vkL && d_vkR && d_c_hat && d_alpha_hat)), "bad argument");
+    FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large (< 2^21)", N);
+    FZ_REQUIRE(groups <= 65535 && (groups <= 1 || partial_stride >= (size_t)ctx->degree), "bad groups / stride");
+    return fz_launch_target_partial(ctx, d_vkL, d_vkR, d_c_hat, d_alpha_hat, d_partial, partial_stride, groups, N);
+}
+
 int fz_target_partial(fz_ctx *ctx, const int32_t *d_vkL, const int32_t *d_vkR, const int32_t *d_c_hat,
                       const int32_t *d_alpha_hat, int64_t *d_partial, size_t N) {
-    FZ_REQUIRE(ctx && d_partial && (N == 0 || (d_vkL && d_vkR && d_c_hat && d_alpha_hat)), "bad argument");
-    FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large (< 2^21)", N);
-    return fz_launch_target_partial(ctx, d_vkL, d_vkR, d_c_hat, d_alpha_hat, d_partial, N);
+    return fz_target_partial_batch(ctx, d_vkL, d_vkR, d_c_hat, d_alpha_hat, d_partial, 0, 1, N);
 }
 
 int fz_norm_weight(fz_ctx *ctx, const int32_t *d_coef, size_t batch, int64_t *d_max_abs, int32_t *d_weight) {
@@ -485,25 +499,38 @@ int fz_norm_weight_host(fz_ctx *ctx, const int32_t *h_coef, size_t batch, int64_
     return fz_memcpy_d2h(ctx, h_weight, base + oW, batch * sizeof(int32_t));
 }
 
-int fz_verify_with_target(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const int32_t *d_target, int l,
-                          int64_t beta_vf, int64_t omega_vf, int *h_verdict) {
-    FZ_REQUIRE(ctx && l >= 1 && d_A && d_sig && d_target && h_verdict, "bad argument");
-    const size_t row = (size_t)ctx->degree * sizeof(int32_t);
-    // scratch: observed [D] i32 | coef [l][D] i32 | max_abs [l] i64 | weight [l] i32
-    const size_t oC = (row + 255) & ~(size_t)255;
-    const size_t oM = oC + (((size_t)l * row + 255) & ~(size_t)255);
-    const size_t oW = oM + (((size_t)l * sizeof(int64_t) + 255) & ~(size_t)255);
+int fz_verify_with_target_batch(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const int32_t *d_target,
+                                size_t groups, int l, int64_t beta_vf, int64_t omega_vf, int *h_verdicts) {
+    FZ_REQUIRE(ctx && l >= 1 && groups >= 1 && groups <= 65535 && d_A && d_sig && d_target && h_verdicts, "bad argument");
+    const size_t row = (size_t)ctx->degree * sizeof(int32_t), rows = groups * (size_t)l;
+    // scratch: observed [G][D] i32 | coef [G][l][D] i32 | max_abs [G][l] i64 | weight [G][l] i32
+    const size_t oC = (groups * row + 255) & ~(size_t)255;
+    const size_t oM = oC + ((rows * row + 255) & ~(size_t)255);
+    const size_t oW = oM + ((rows * sizeof(int64_t) + 255) & ~(size_t)255);
     void *d = nullptr;
-    FZ_TRY(fz_scratch(ctx, oW + (size_t)l * sizeof(int32_t), &d));
+    FZ_TRY(fz_scratch(ctx, oW + rows * sizeof(int32_t), &d));
+    if (groups > ctx->verdict_cap) {
+        FZ_HIP(hipStreamSynchronize(ctx->stream), "verdict sync");
+        FZ_HIP(hipFree(ctx->d_verdict), "verdict free");
+        ctx->d_verdict = nullptr;
+        ctx->verdict_cap = 0;
+        FZ_HIP(hipMalloc((void **)&ctx->d_verdict, groups * sizeof(int)), "verdict alloc");
+        ctx->verdict_cap = groups;
+    }
     char *base = (char *)d;
     int32_t *observed = (int32_t *)base, *coef = (int32_t *)(base + oC);
     int64_t *mx = (int64_t *)(base + oM);
     int32_t *wt = (int32_t *)(base + oW);
-    FZ_TRY(fz_launch_matvec(ctx, d_A, d_sig, observed, 1, l));                    // fusion.py:715-717
-    FZ_TRY(fz_launch_ntt(ctx, d_sig, coef, (size_t)l, true));                     // fusion.py:690-692
-    FZ_TRY(fz_launch_norm_weight(ctx, coef, (size_t)l, mx, wt));                  // fusion.py:722-727
-    FZ_TRY(fz_launch_verdict(ctx, d_target, observed, mx, wt, l, beta_vf, omega_vf, ctx->d_verdict));
-    return fz_memcpy_d2h(ctx, h_verdict, ctx->d_verdict, sizeof(int));
+    FZ_TRY(fz_launch_matvec(ctx, d_A, d_sig, observed, groups, l));               // fusion.py:715-717
+    FZ_TRY(fz_launch_ntt(ctx, d_sig, coef, rows, true));                          // fusion.py:690-692
+    FZ_TRY(fz_launch_norm_weight(ctx, coef, rows, mx, wt));                       // fusion.py:722-727
+    FZ_TRY(fz_launch_verdict(ctx, d_target, observed, mx, wt, groups, l, beta_vf, omega_vf, ctx->d_verdict));
+    return fz_memcpy_d2h(ctx, h_verdicts, ctx->d_verdict, groups * sizeof(int));
+}
+
+int fz_verify_with_target(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const int32_t *d_target, int l,
+                          int64_t beta_vf, int64_t omega_vf, int *h_verdict) {
+    return fz_verify_with_target_batch(ctx, d_A, d_sig, d_target, 1, l, beta_vf, omega_vf, h_verdict);
 }
 
 int fz_verify_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const int32_t *d_vkL, const int32_t *d_vkR,

@@ -37,7 +37,8 @@ struct fz_ctx {
     // growable device scratch (host-pointer entry points, int64 partial sums)
     void *d_scratch;
     size_t scratch_bytes;
-    int *d_verdict;
+    int *d_verdict;              // [verdict_cap]
+    size_t verdict_cap;
     int grid_fwd, grid_inv;      // resident-grid caps for the persistent NTT kernels
     // per-dispatch timing of the NTT kernels (fz_profile_begin/end): event pairs bound to the
     // dispatch itself via hipExtLaunchKernelGGL, i.e. kernel begin -> kernel end on its own stream
@@ -61,12 +62,13 @@ int fz_launch_pw(fz_ctx *ctx, int op, const int32_t *a, const int32_t *b, int32_
 int fz_launch_pw_bcast(fz_ctx *ctx, const int32_t *a, const int32_t *s, int32_t *out, size_t rows);
 int fz_launch_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *out, size_t batch, int l);
 int fz_launch_sign(fz_ctx *ctx, const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig, size_t batch, int l);
-int fz_launch_aggregate_partial(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *partial, size_t N, int l);
+int fz_launch_aggregate_partial(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *partial, size_t pstride,
+                                size_t groups, size_t N, int l);
 int fz_launch_target_partial(fz_ctx *ctx, const int32_t *vkL, const int32_t *vkR, const int32_t *c, const int32_t *alpha,
-                             int64_t *partial, size_t N);
+                             int64_t *partial, size_t pstride, size_t groups, size_t N);
 int fz_launch_reduce_i64(fz_ctx *ctx, const int64_t *in, int32_t *out, size_t count);
 int fz_launch_norm_weight(fz_ctx *ctx, const int32_t *coef, size_t batch, int64_t *max_abs, int32_t *weight);
 int fz_launch_verdict(fz_ctx *ctx, const int32_t *target, const int32_t *observed, const int64_t *max_abs,
-                      const int32_t *weight, int l, int64_t beta, int64_t omega, int *d_verdict);
+                      const int32_t *weight, size_t groups, int l, int64_t beta, int64_t omega, int *d_verdict);
 
 #endif

@@ -137,19 +137,23 @@ __device__ __forceinline__ void atomic_add_i64(int64_t *p, double v) {
     atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)(long long)v);
 }
 
-// partial[k][j] += sum_{i in split} sig[i][k][j] * alpha[i][j]  (each product reduced to ~q/2).
-// grid.x covers the l*degree/4 columns, grid.y splits the N signatures.
+// partial[g][k][j] += sum_{i in split} sig[g][i][k][j] * alpha[g][i][j]  (each product reduced to ~q/2).
+// grid.x covers the l*degree/4 columns, grid.y splits the N signatures of a group, grid.z = group.
 __global__ __launch_bounds__(kBlock) void aggregate_kernel(const int32_t *sig, const int32_t *alpha, int64_t *partial,
-                                                           size_t N, int l, int degree, FzMod m) {
+                                                           size_t pstride, size_t N, int l, int degree, FzMod m) {
     const int d4 = degree / 4;
     const size_t cols = (size_t)l * d4;
     const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= cols) return;
     const int j4 = (int)(col % d4);
+    const size_t g = blockIdx.z;
+    sig += g * N * (size_t)l * degree;
+    alpha += g * N * (size_t)degree;
     const size_t per = (N + gridDim.y - 1) / gridDim.y;
     const size_t i0 = (size_t)blockIdx.y * per;
     const size_t i1 = (i0 + per < N) ? i0 + per : N;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll 4
     for (size_t i = i0; i < i1; ++i) {
         int4 x = reinterpret_cast<const int4 *>(sig + i * (size_t)l * degree)[col];
         int4 a = reinterpret_cast<const int4 *>(alpha + i * (size_t)degree)[j4];
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void aggregate_kernel(const int32_t *sig, c
         s3 += fz_mulmod((double)x.w, (double)a.w, m);
     }
     if (i1 > i0) {
-        int64_t *dst = partial + col * 4;
+        int64_t *dst = partial + g * pstride + col * 4;
         atomic_add_i64(dst + 0, s0);
         atomic_add_i64(dst + 1, s1);
         atomic_add_i64(dst + 2, s2);
@@ -167,22 +171,31 @@ __global__ __launch_bounds__(kBlock) void aggregate_kernel(const int32_t *sig, c
     }
 }
 
-// partial[j] += sum_i ((vkL_i*c_i + vkR_i) * alpha_i)[j]; one thread per coefficient, grid.y splits N
+// partial[g][j] += sum_i ((vkL_i*c_i + vkR_i) * alpha_i)[j]; one thread per coefficient, grid.y splits N
 __global__ __launch_bounds__(kBlock) void target_kernel(const int32_t *vkL, const int32_t *vkR, const int32_t *c,
-                                                        const int32_t *alpha, int64_t *partial,
+                                                        const int32_t *alpha, int64_t *partial, size_t pstride,
                                                         size_t N, int degree, FzMod m) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= degree) return;
+    const size_t g = blockIdx.z, goff = g * N * (size_t)degree;
     const size_t per = (N + gridDim.y - 1) / gridDim.y;
     const size_t i0 = (size_t)blockIdx.y * per;
     const size_t i1 = (i0 + per < N) ? i0 + per : N;
     double s = 0;
+#pragma unroll 4
     for (size_t i = i0; i < i1; ++i) {
-        const size_t o = i * (size_t)degree + j;
+        const size_t o = goff + i * (size_t)degree + j;
         double t = fz_mulmod((double)vkL[o], (double)c[o], m) + (double)vkR[o];   // |t| < 2^32
         s += fz_mulmod(t, (double)alpha[o], m);
     }
-    if (i1 > i0) atomic_add_i64(partial + j, s);
+    if (i1 > i0) atomic_add_i64(partial + g * pstride + j, s);
+}
+
+// zero `count` int64 at partial + g*pstride for every group (one launch instead of G memsets)
+__global__ __launch_bounds__(kBlock) void zero_i64_kernel(int64_t *partial, size_t pstride, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    int64_t *p = partial + (size_t)blockIdx.z * pstride;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) p[i] = 0;
 }
 
 __global__ __launch_bounds__(kBlock) void reduce_i64_kernel(const int64_t *in, int32_t *out, size_t count, FzMod m) {
@@ -217,11 +230,16 @@ __global__ __launch_bounds__(64) void norm_weight_kernel(const int32_t *coef, si
     }
 }
 
-// verdict of fusion/fusion.py:718-728, evaluated in the reference's order
+// verdict of fusion/fusion.py:718-728, evaluated in the reference's order; one block per aggregate
 __global__ __launch_bounds__(256) void verdict_kernel(const int32_t *target, const int32_t *observed, int degree,
                                                       const int64_t *max_abs, const int32_t *weight, int l,
                                                       int64_t beta, int64_t omega, int *verdict) {
     __shared__ int s_mis, s_norm, s_wt;
+    const size_t g = blockIdx.x;
+    target += g * degree;
+    observed += g * degree;
+    max_abs += g * l;
+    weight += g * l;
     if (threadIdx.x == 0) { s_mis = 0; s_norm = 0; s_wt = 0; }
     __syncthreads();
     for (int j = threadIdx.x; j < degree; j += blockDim.x)
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(256) void verdict_kernel(const int32_t *target, con
     }
     __syncthreads();
     if (threadIdx.x == 0)
-        *verdict = s_mis ? FZ_VERDICT_TARGET_MISMATCH : (s_norm ? FZ_VERDICT_NORM : (s_wt ? FZ_VERDICT_WEIGHT : FZ_VERDICT_OK));
+        verdict[g] = s_mis ? FZ_VERDICT_TARGET_MISMATCH : (s_norm ? FZ_VERDICT_NORM : (s_wt ? FZ_VERDICT_WEIGHT : FZ_VERDICT_OK));
 }
 
 unsigned grid_for(fz_ctx *ctx, size_t work_items, int per_cu = 8) {
@@ -287,31 +305,41 @@ int fz_launch_sign(fz_ctx *ctx, const int32_t *sk_hat, const int32_t *c_hat, int
     return fz_check_hip(hipGetLastError(), "sign launch");
 }
 
-int fz_launch_aggregate_partial(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *partial, size_t N, int l) {
-    if (ctx->degree < 4) return fz_set_error(FZ_E_UNSUPPORTED, "aggregate needs degree >= 4");
-    const size_t cols = (size_t)l * (ctx->degree / 4);
-    int rc = fz_check_hip(hipMemsetAsync(partial, 0, cols * 4 * sizeof(int64_t), ctx->stream), "memset partial");
-    if (rc != FZ_OK || N == 0) return rc;
-    const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);
-    size_t want = ((size_t)ctx->num_cu * 8 + gx - 1) / gx;       // ~8 blocks per CU in total
-    if (want > N) want = N;
+static unsigned split_count(fz_ctx *ctx, size_t N, unsigned gx, size_t groups, size_t min_per_thread) {
+    // enough blocks to fill the chip (~8 per CU over all groups) but at least `min_per_thread` items each
+    size_t want = ((size_t)ctx->num_cu * 8 + gx * groups - 1) / (gx * groups);
+    const size_t most = (N + min_per_thread - 1) / min_per_thread;
+    if (want > most) want = most;
     if (want < 1) want = 1;
     if (want > 65535) want = 65535;
-    hipLaunchKernelGGL(aggregate_kernel, dim3(gx, (unsigned)want), dim3(kBlock), 0, ctx->stream, sig, alpha, partial, N,
-                       l, ctx->degree, ctx->mod);
+    return (unsigned)want;
+}
+
+int fz_launch_aggregate_partial(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *partial, size_t pstride,
+                                size_t groups, size_t N, int l) {
+    if (ctx->degree < 4) return fz_set_error(FZ_E_UNSUPPORTED, "aggregate needs degree >= 4");
+    if (groups == 0) return FZ_OK;
+    const size_t cols = (size_t)l * (ctx->degree / 4);
+    hipLaunchKernelGGL(zero_i64_kernel, dim3(grid_for(ctx, cols * 4, 1), 1, (unsigned)groups), dim3(kBlock), 0, ctx->stream,
+                       partial, pstride, cols * 4);
+    int rc = fz_check_hip(hipGetLastError(), "zero partial");
+    if (rc != FZ_OK || N == 0) return rc;
+    const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(aggregate_kernel, dim3(gx, split_count(ctx, N, gx, groups, 8), (unsigned)groups), dim3(kBlock), 0,
+                       ctx->stream, sig, alpha, partial, pstride, N, l, ctx->degree, ctx->mod);
     return fz_check_hip(hipGetLastError(), "aggregate launch");
 }
 
 int fz_launch_target_partial(fz_ctx *ctx, const int32_t *vkL, const int32_t *vkR, const int32_t *c, const int32_t *alpha,
-                             int64_t *partial, size_t N) {
-    int rc = fz_check_hip(hipMemsetAsync(partial, 0, (size_t)ctx->degree * sizeof(int64_t), ctx->stream), "memset target");
+                             int64_t *partial, size_t pstride, size_t groups, size_t N) {
+    if (groups == 0) return FZ_OK;
+    hipLaunchKernelGGL(zero_i64_kernel, dim3(1, 1, (unsigned)groups), dim3(kBlock), 0, ctx->stream, partial, pstride,
+                       (size_t)ctx->degree);
+    int rc = fz_check_hip(hipGetLastError(), "zero target");
     if (rc != FZ_OK || N == 0) return rc;
     const unsigned gx = (unsigned)((ctx->degree + kBlock - 1) / kBlock);
-    size_t want = (N + 15) / 16;
-    if (want > (size_t)ctx->num_cu * 4) want = (size_t)ctx->num_cu * 4;
-    if (want < 1) want = 1;
-    hipLaunchKernelGGL(target_kernel, dim3(gx, (unsigned)want), dim3(kBlock), 0, ctx->stream, vkL, vkR, c, alpha, partial,
-                       N, ctx->degree, ctx->mod);
+    hipLaunchKernelGGL(target_kernel, dim3(gx, split_count(ctx, N, gx, groups, 8), (unsigned)groups), dim3(kBlock), 0,
+                       ctx->stream, vkL, vkR, c, alpha, partial, pstride, N, ctx->degree, ctx->mod);
     return fz_check_hip(hipGetLastError(), "target launch");
 }
 
@@ -330,8 +358,8 @@ int fz_launch_norm_weight(fz_ctx *ctx, const int32_t *coef, size_t batch, int64_
 }
 
 int fz_launch_verdict(fz_ctx *ctx, const int32_t *target, const int32_t *observed, const int64_t *max_abs,
-                      const int32_t *weight, int l, int64_t beta, int64_t omega, int *d_verdict) {
-    hipLaunchKernelGGL(verdict_kernel, dim3(1), dim3(256), 0, ctx->stream, target, observed, ctx->degree, max_abs, weight,
+                      const int32_t *weight, size_t groups, int l, int64_t beta, int64_t omega, int *d_verdict) {
+    hipLaunchKernelGGL(verdict_kernel, dim3((unsigned)groups), dim3(256), 0, ctx->stream, target, observed, ctx->degree, max_abs, weight,
                        l, beta, omega, d_verdict);
     return fz_check_hip(hipGetLastError(), "verdict launch");
 }

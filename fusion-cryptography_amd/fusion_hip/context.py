@@ -152,6 +152,21 @@ class Context:
         check(self._lib, self._lib.fz_target_partial(self._h, c_void_p(d_vkL), c_void_p(d_vkR), c_void_p(d_c),
                                                      c_void_p(d_alpha), c_void_p(d_partial), N))
 
+    def aggregate_partial_batch_dev(self, d_sig, d_alpha, d_partial, partial_stride, groups, N, l):
+        check(self._lib, self._lib.fz_aggregate_partial_batch(self._h, c_void_p(d_sig), c_void_p(d_alpha),
+                                                              c_void_p(d_partial), partial_stride, groups, N, l))
+
+    def target_partial_batch_dev(self, d_vkL, d_vkR, d_c, d_alpha, d_partial, partial_stride, groups, N):
+        check(self._lib, self._lib.fz_target_partial_batch(self._h, c_void_p(d_vkL), c_void_p(d_vkR), c_void_p(d_c),
+                                                           c_void_p(d_alpha), c_void_p(d_partial), partial_stride,
+                                                           groups, N))
+
+    def verify_with_target_batch_dev(self, d_A, d_sig, d_target, groups, l, beta_vf, omega_vf):
+        v = (c_int * groups)()
+        check(self._lib, self._lib.fz_verify_with_target_batch(self._h, c_void_p(d_A), c_void_p(d_sig),
+                                                               c_void_p(d_target), groups, l, beta_vf, omega_vf, v))
+        return list(v)
+
     def reduce_i64_dev(self, d_in, d_out, count):
         check(self._lib, self._lib.fz_reduce_i64(self._h, c_void_p(d_in), c_void_p(d_out), count))
 

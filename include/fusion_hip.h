@@ -149,10 +149,17 @@ FZ_API int fz_aggregate_core(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d
                              int32_t *d_out, size_t N, int l);
 FZ_API int fz_aggregate_partial(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat,
                                 int64_t *d_partial, size_t N, int l);
+/* `groups` independent aggregates in one launch: sig [groups][N][l][degree], alpha_hat [groups][N][degree],
+ * partial of group g at d_partial + g * partial_stride (int64 elements). */
+FZ_API int fz_aggregate_partial_batch(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat,
+                                      int64_t *d_partial, size_t partial_stride, size_t groups, size_t N, int l);
 /* target partial for verify: sum_i (vkL_i (.) c_i + vkR_i) (.) alpha_i as int64 [degree] */
 FZ_API int fz_target_partial(fz_ctx *ctx, const int32_t *d_vkL, const int32_t *d_vkR,
                              const int32_t *d_c_hat, const int32_t *d_alpha_hat,
                              int64_t *d_partial, size_t N);
+FZ_API int fz_target_partial_batch(fz_ctx *ctx, const int32_t *d_vkL, const int32_t *d_vkR,
+                                   const int32_t *d_c_hat, const int32_t *d_alpha_hat,
+                                   int64_t *d_partial, size_t partial_stride, size_t groups, size_t N);
 /* out[i] = cent(in[i]) for int64 sums */
 FZ_API int fz_reduce_i64(fz_ctx *ctx, const int64_t *d_in, int32_t *d_out, size_t count);
 FZ_API int fz_verify_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig,
@@ -163,6 +170,11 @@ FZ_API int fz_verify_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig,
 FZ_API int fz_verify_with_target(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig,
                                  const int32_t *d_target, int l,
                                  int64_t beta_vf, int64_t omega_vf, int *h_verdict);
+/* `groups` aggregates against one public challenge: sig [groups][l][degree], target [groups][degree],
+ * h_verdicts [groups]. */
+FZ_API int fz_verify_with_target_batch(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig,
+                                       const int32_t *d_target, size_t groups, int l,
+                                       int64_t beta_vf, int64_t omega_vf, int *h_verdicts);
 
 /* ---- norm / weight of coefficient rows -------------------------------------------------------
  * PolynomialCoefficientRepresentation.norm("infty") / weight(), algebra/polynomials.py:221-227:

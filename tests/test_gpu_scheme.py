@@ -129,3 +129,46 @@ def test_config1_demo_flow(meta):
     agg = F.aggregate(a, vks, m["messages"], sigs)
     assert sha_str(str(agg)) == m["sha256_str_agg"]
     assert list(F.verify(a, vks, m["messages"], agg)) == m["verdict"] == [True, ""]
+
+
+def test_batched_aggregate_target_verify(coracle):
+    """group-batched entry points (one launch for G aggregates) == the single-aggregate ones == oracle"""
+    import fusion_hip
+    P = O.PARAMS[256]
+    q, d, l = P["q"], P["d"], 7
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    rng = np.random.default_rng(5)
+    G, N = 3, 13
+    A = O.splitmix_centered(3, l * d).reshape(l, d)
+    coef = rng.integers(-52, 53, size=(G * N, 2, l, d)).astype(np.int32)
+    sk, vk = ctx.keygen_core(A, coef)
+    c = np.zeros((G * N, d), np.int32)
+    for i in range(G * N):
+        c[i, rng.choice(d, 60, replace=False)] = rng.choice([-1, 1], 60)
+    c_hat = ctx.ntt_forward(c)
+    al_hat = ctx.ntt_forward(np.roll(c, 3, axis=1))
+    sig = ctx.sign_core(sk, c_hat)
+    DB = fusion_hip.DeviceBuffer
+    d_sig, d_al, d_c = DB.from_numpy(ctx, sig), DB.from_numpy(ctx, al_hat), DB.from_numpy(ctx, c_hat)
+    d_vkL, d_vkR = DB.from_numpy(ctx, np.ascontiguousarray(vk[:, 0])), DB.from_numpy(ctx, np.ascontiguousarray(vk[:, 1]))
+    d_A = DB.from_numpy(ctx, A)
+    n_agg, n_tgt = G * l * d, G * d
+    d_part = DB(ctx, (n_agg + n_tgt) * 8)
+    ctx.aggregate_partial_batch_dev(d_sig.ptr, d_al.ptr, d_part.ptr, l * d, G, N, l)
+    ctx.target_partial_batch_dev(d_vkL.ptr, d_vkR.ptr, d_c.ptr, d_al.ptr, d_part.ptr + n_agg * 8, d, G, N)
+    d_red = DB(ctx, (n_agg + n_tgt) * 4)
+    ctx.reduce_i64_dev(d_part.ptr, d_red.ptr, n_agg + n_tgt)
+    red = d_red.to_numpy(np.int32, (n_agg + n_tgt,))
+    agg = red[:n_agg].reshape(G, l, d)
+    for g in range(G):
+        sl = slice(g * N, (g + 1) * N)
+        assert np.array_equal(agg[g], coracle.aggregate_core(sig[sl], al_hat[sl], q))
+        assert np.array_equal(agg[g], ctx.aggregate_core(sig[sl], al_hat[sl]))
+    v = ctx.verify_with_target_batch_dev(d_A.ptr, d_red.ptr, d_red.ptr + n_agg * 4, G, l, P["beta_vf"], d)
+    assert v == [0, 0, 0]
+    # corrupt the middle aggregate only
+    bad = red.copy()
+    bad[l * d + 5] += 1
+    ctx.h2d(d_red.ptr, bad)
+    assert ctx.verify_with_target_batch_dev(d_A.ptr, d_red.ptr, d_red.ptr + n_agg * 4, G, l, P["beta_vf"], d) == [0, 3, 0]
+    assert ctx.verify_with_target_batch_dev(d_A.ptr, d_red.ptr, d_red.ptr + n_agg * 4, G, l, 1, d) == [4, 3, 4]

@@ -133,6 +133,18 @@ def main():
         elapsed = float(t.item())
     value = 2.0 * B * args.steps * world / elapsed
 
+    # ---- host-pointer path (PCIe-inclusive; informational, never `value`) -----------------------
+    pcie = None
+    if rank == 0:
+        hx = x_host.copy()
+        ctx.ntt_forward(hx[:64])
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            ctx.ntt_forward(hx)
+        dt = (time.perf_counter() - t0) / reps
+        pcie = {"value": B / dt, "unit": "NTT/s", "what": "fz_ntt_forward_host on 4096x256 host rows (H2D + kernel + D2H)"}
+
     # ---- large-batch asymptote of the same kernels (context for the roofline) ------------------
     sweep = {}
     if rank == 0 and not args.no_sweep:
@@ -225,6 +237,14 @@ def main():
                       "host hashing of str(vk) excluded"}
 
     if rank == 0:
+        # HBM-side traffic of this launch from the PMC counters (rocprofv3 --pmc, separate passes; FETCH_SIZE
+        # corrected x2 for gfx950): cannot be collected live, so the committed measurement is reported
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_ntt.json")) as fh:
+                traffic = json.load(fh)["kernels"]["ntt_fwd4<8> B=4096"]["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         fwd_bytes = 8.0 * d * B
         ach = fwd_bytes / (fwd_avg * 1e-3) / 1e9
         out = {
@@ -233,13 +253,13 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 (exact integer arithmetic; int32 in/out)", "data": "synthetic",
             "config": {"workload": f"configs[1]: secpar={SECPAR}, batch of {B} degree-{d} forward+inverse NTTs per GPU",
                        "batch": B, "degree": d, "modulus": q, "kernels_per_step": 2},
-            "roofline": {"bound": "hbm", "kernel": "ntt_fwd16<8> (forward NTT, B=4096)", "achieved": ach,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8> (forward NTT, B=4096)", "achieved": ach,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": fwd_bytes, "avg_launch_us": fwd_avg * 1e3,
                          "inverse_avg_launch_us": inv_avg * 1e3, "launches_timed": prof["fwd_count"],
                          "timing": f"hipExtLaunchKernelGGL start/stop events on every {args.sample_every}th dispatch inside the timed region",
                          "sweep": sweep},
-            "sign_verify": sv,
+            "sign_verify": sv, "pcie_inclusive": pcie,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

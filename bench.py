@@ -107,9 +107,15 @@ def main():
     y = torch.empty_like(x)
     z = torch.empty_like(x)
 
+    # the timed loop calls the C ABI directly with pre-built arguments: at ~4.5 us per kernel the Python
+    # wrapper layers (attribute lookups, argument boxing) would otherwise be part of the measurement
+    import ctypes
+    lib, h = ctx._lib, ctx._h
+    xp, yp, zp = (ctypes.c_void_p(t.data_ptr()) for t in (x, y, z))
+    fz_fwd, fz_inv, nB = lib.fz_ntt_forward, lib.fz_ntt_inverse, ctypes.c_size_t(B)
+
     def step():
-        ctx.ntt_forward_dev(x.data_ptr(), y.data_ptr(), B)
-        ctx.ntt_inverse_dev(y.data_ptr(), z.data_ptr(), B)
+        return fz_fwd(h, xp, yp, nB) | fz_inv(h, yp, zp, nB)
 
     for _ in range(args.warmup):
         step()
@@ -119,11 +125,13 @@ def main():
     # events bound to every k-th dispatch (kernel begin -> end on its own stream); sampling keeps the
     # instrumentation from throttling the launch rate of the timed region
     ctx.profile_begin(2 * args.steps, args.sample_every)
+    rc = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        rc |= step()
     barrier()
     elapsed = time.perf_counter() - t0
+    assert rc == 0, f"launch failed: {lib.fz_last_error()}"
     prof = ctx.profile_end()
     assert prof["fwd_count"] == prof["inv_count"] == (args.steps + args.sample_every - 1) // args.sample_every
     fwd_avg, inv_avg = prof["fwd_avg_us"] * 1e-3, prof["inv_avg_us"] * 1e-3      # ms

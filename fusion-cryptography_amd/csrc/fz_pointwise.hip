@@ -94,6 +94,38 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const int32_t *A, const 
         reinterpret_cast<int4 *>(out + b * (size_t)degree)[j4] = o;
     }
 }
+// Few products (verify: one per aggregate): one 1024-thread block per product, the k-loop split over
+// 1024/(degree/4) slices and reduced through LDS -- 83 dependent-latency iterations become 6.
+__global__ __launch_bounds__(1024) void matvec_split_kernel(const int32_t *A, const int32_t *S, int32_t *out,
+                                                            int l, int degree, FzMod m) {
+    __shared__ double red[1024 * 4];
+    const int d4 = degree / 4, slices = 1024 / d4;
+    const int j4 = threadIdx.x % d4, sl = threadIdx.x / d4;
+    const size_t b = blockIdx.x;
+    const int4 *Ap = reinterpret_cast<const int4 *>(A) + j4;
+    const int4 *Sp = reinterpret_cast<const int4 *>(S + b * (size_t)l * degree) + j4;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int k = sl; k < l; k += slices) {
+        int4 x = Ap[(size_t)k * d4];
+        int4 y = Sp[(size_t)k * d4];
+        s0 += fz_mulmod((double)x.x, (double)y.x, m);
+        s1 += fz_mulmod((double)x.y, (double)y.y, m);
+        s2 += fz_mulmod((double)x.z, (double)y.z, m);
+        s3 += fz_mulmod((double)x.w, (double)y.w, m);
+    }
+    double *mine = red + (size_t)threadIdx.x * 4;
+    mine[0] = s0; mine[1] = s1; mine[2] = s2; mine[3] = s3;
+    __syncthreads();
+    if (sl == 0) {
+        for (int t = 1; t < slices; ++t) {
+            const double *o = red + (size_t)(t * d4 + j4) * 4;
+            s0 += o[0]; s1 += o[1]; s2 += o[2]; s3 += o[3];
+        }
+        int4 r;
+        r.x = cent_i32(s0, m); r.y = cent_i32(s1, m); r.z = cent_i32(s2, m); r.w = cent_i32(s3, m);
+        reinterpret_cast<int4 *>(out + b * (size_t)degree)[j4] = r;
+    }
+}
 // degree < 4 fallback (degree 2): scalar
 __global__ __launch_bounds__(kBlock) void matvec_scalar_kernel(const int32_t *A, const int32_t *S, int32_t *out,
                                                                size_t batch, int l, int degree, FzMod m) {
@@ -287,7 +319,11 @@ int fz_launch_pw_bcast(fz_ctx *ctx, const int32_t *a, const int32_t *s, int32_t 
 
 int fz_launch_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *out, size_t batch, int l) {
     if (batch == 0) return FZ_OK;
-    if (ctx->degree >= 4)
+    if (ctx->degree >= 16 && ctx->degree <= 4096 && (ctx->degree & (ctx->degree - 1)) == 0 &&
+        batch * (size_t)(ctx->degree / 4) < (size_t)ctx->num_cu * 256)
+        hipLaunchKernelGGL(matvec_split_kernel, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, A, S, out, l,
+                           ctx->degree, ctx->mod);
+    else if (ctx->degree >= 4)
         hipLaunchKernelGGL(matvec_kernel, dim3(grid_for(ctx, batch * (size_t)(ctx->degree / 4))), dim3(kBlock), 0,
                            ctx->stream, A, S, out, batch, l, ctx->degree, ctx->mod);
     else

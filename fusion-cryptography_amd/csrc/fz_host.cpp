@@ -1,0 +1,397 @@
+// fz_host.cpp -- host side of the hash -> challenge pipeline, exported through the
+// same C ABI (include/fusion_hip.h, "challenge pipeline" section).  Pure C++17, no GPU.
+//
+// What it restates (reference file:line):
+//   hash_message_to_int                     fusion/fusion.py:405-409   SHA3-256 of dst + "," + message
+//   hash_vk_and_int_to_bytes                fusion/fusion.py:412-419   SHAKE-256 over dst + "," + str(vk) + "," + str(i)
+//   decode_bytes_to_polynomial_coefficients fusion/fusion.py:422-481   signs, magnitudes, partial Fisher-Yates
+//   hash_vks_and_ints_and_challs_to_bytes   fusion/fusion.py:573-591   one XOF over str(list(zip(keys, ints, challs)))
+//   decode_bytes_to_agg_coefs               fusion/fusion.py:594-629   (decoding part; the NTTs run on the device)
+//   sorted(..., key=str(vk))                fusion/fusion.py:661-663, :693
+// and the exact text the reference hashes: str(OneTimeVerificationKey) (fusion.py:328-329) ->
+// str(GeneralMatrix) (algebra/matrices.py:40-41) -> str(PolynomialNTTRepresentation)
+// (algebra/polynomials.py:257-258), str(SignatureChallenge) (fusion.py:382-383).
+// Keccak-f[1600] / SHA-3 / SHAKE follow FIPS 202 (CPython's hashlib is the oracle in the tests).
+#include "../../include/fusion_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+int fz_set_error(int code, const char *fmt, ...);
+
+namespace {
+
+// ---- Keccak-f[1600] -------------------------------------------------------------------------------
+const uint64_t RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+    0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+    0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+    0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+
+inline uint64_t rotl(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+
+void keccak_f(uint64_t s[25]) {
+    for (int round = 0; round < 24; ++round) {
+        uint64_t c[5], d[5], b[25];
+        for (int x = 0; x < 5; ++x) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+        for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ rotl(c[(x + 1) % 5], 1);
+        for (int i = 0; i < 25; ++i) s[i] ^= d[i % 5];
+        for (int x = 0; x < 5; ++x)
+            for (int y = 0; y < 5; ++y) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl(s[x + 5 * y], ROT[x + 5 * y]);
+        for (int y = 0; y < 5; ++y)
+            for (int x = 0; x < 5; ++x) s[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        s[0] ^= RC[round];
+    }
+}
+
+struct Sponge {
+    uint64_t s[25];
+    size_t rate, pos;
+    explicit Sponge(size_t rate_bytes) : rate(rate_bytes), pos(0) { memset(s, 0, sizeof(s)); }
+    void absorb(const uint8_t *p, size_t n) {
+        uint8_t *st = reinterpret_cast<uint8_t *>(s);       // little-endian host (x86-64)
+        while (n) {
+            size_t take = std::min(n, rate - pos);
+            for (size_t i = 0; i < take; ++i) st[pos + i] ^= p[i];
+            pos += take; p += take; n -= take;
+            if (pos == rate) { keccak_f(s); pos = 0; }
+        }
+    }
+    void finish(uint8_t suffix) {
+        uint8_t *st = reinterpret_cast<uint8_t *>(s);
+        st[pos] ^= suffix;
+        st[rate - 1] ^= 0x80;
+        keccak_f(s);
+        pos = 0;
+    }
+    void squeeze(uint8_t *out, size_t n) {
+        const uint8_t *st = reinterpret_cast<const uint8_t *>(s);
+        while (n) {
+            if (pos == rate) { keccak_f(s); pos = 0; }
+            size_t take = std::min(n, rate - pos);
+            memcpy(out, st + pos, take);
+            pos += take; out += take; n -= take;
+        }
+    }
+};
+
+void sha3_256(const uint8_t *p, size_t n, uint8_t out[32]) {
+    Sponge sp(136);
+    sp.absorb(p, n);
+    sp.finish(0x06);
+    sp.squeeze(out, 32);
+}
+
+void shake256(const uint8_t *p, size_t n, uint8_t *out, size_t outlen) {
+    Sponge sp(136);
+    sp.absorb(p, n);
+    sp.finish(0x1f);
+    sp.squeeze(out, outlen);
+}
+
+// ---- exact text formats -----------------------------------------------------------------------------
+inline void put_int(std::string &s, long long v) {
+    char buf[24];
+    int n = snprintf(buf, sizeof(buf), "%lld", v);
+    s.append(buf, (size_t)n);
+}
+
+// str(int) of a 256-bit little-endian value
+std::string u256_decimal(const uint8_t le[32]) {
+    uint32_t limb[8];
+    for (int i = 0; i < 8; ++i) memcpy(&limb[i], le + 4 * i, 4);
+    std::vector<uint32_t> chunks;          // base 1e9, least significant first
+    bool nonzero = true;
+    while (nonzero) {
+        uint64_t rem = 0;
+        nonzero = false;
+        for (int i = 7; i >= 0; --i) {
+            uint64_t cur = (rem << 32) | limb[i];
+            limb[i] = (uint32_t)(cur / 1000000000u);
+            rem = cur % 1000000000u;
+            if (limb[i]) nonzero = true;
+        }
+        chunks.push_back((uint32_t)rem);
+    }
+    std::string out;
+    char buf[16];
+    for (size_t i = chunks.size(); i-- > 0;) {
+        int n = snprintf(buf, sizeof(buf), i + 1 == chunks.size() ? "%u" : "%09u", chunks[i]);
+        out.append(buf, (size_t)n);
+    }
+    return out;
+}
+
+// "PolynomialNTTRepresentation(modulus=.., degree=.., root=.., inv_root=.., root_order=.., values=[..])"
+void put_poly(std::string &s, const fz_scheme_params &P, const int32_t *v) {
+    s += "PolynomialNTTRepresentation(modulus=";
+    put_int(s, P.modulus);
+    s += ", degree=";
+    put_int(s, P.degree);
+    s += ", root=";
+    put_int(s, P.root);
+    s += ", inv_root=";
+    put_int(s, P.inv_root);
+    s += ", root_order=";
+    put_int(s, P.root_order);
+    s += ", values=[";
+    for (int j = 0; j < P.degree; ++j) {
+        if (j) s += ", ";
+        put_int(s, v[j]);
+    }
+    s += "])";
+}
+
+// a 1x1 GeneralMatrix of one NTT-domain polynomial
+void put_matrix_1x1(std::string &s, const fz_scheme_params &P, const int32_t *v) {
+    s += "GeneralMatrix(elem_class=<class 'algebra.polynomials.PolynomialNTTRepresentation'>, matrix=[[";
+    put_poly(s, P, v);
+    s += "]])";
+}
+
+void put_vk(std::string &s, const fz_scheme_params &P, const int32_t *left, const int32_t *right) {
+    s += "OneTimeVerificationKey(left_vk_hat=";
+    put_matrix_1x1(s, P, left);
+    s += ", right_vk_hat=";
+    put_matrix_1x1(s, P, right);
+    s += ")";
+}
+
+// ---- byte decoder -------------------------------------------------------------------------------------
+inline uint64_t be_mod(const uint8_t *p, int n, uint64_t m) {       // int.from_bytes(p[:n], "big") % m, m < 2^32
+    uint64_t r = 0;
+    for (int i = 0; i < n; ++i) r = ((r << 8) | p[i]) % m;
+    return r;
+}
+
+struct DecodeShape {
+    int coef_bytes, index_bytes, sign_bytes;
+    long long bound;
+    size_t needed;                       // bytes consumed by decode() = the reference's length check
+};
+
+DecodeShape decode_shape(int log2_bias, long long modulus, int degree, long long norm_bound, int weight_bound) {
+    DecodeShape d;
+    d.bound = std::max<long long>(1, std::min<long long>(modulus / 2, norm_bound));
+    d.coef_bytes = (int)std::ceil((std::log2((double)d.bound) + 1 + log2_bias) / 8.0);
+    d.index_bytes = (int)std::ceil((std::log2((double)degree) + log2_bias) / 8.0);
+    d.sign_bytes = (weight_bound + 7) / 8;
+    d.needed = (size_t)d.sign_bytes + (size_t)(d.coef_bytes + d.index_bytes) * (size_t)weight_bound;
+    return d;
+}
+
+// returns 0, or -1 when the input is shorter than the reference's check requires
+int decode(const uint8_t *b, size_t len, int log2_bias, long long modulus, int degree, long long norm_bound,
+           int weight_bound, int32_t *out) {
+    const DecodeShape d = decode_shape(log2_bias, modulus, degree, norm_bound, weight_bound);
+    if (len < d.needed) return -1;
+    const int num_coefs = std::max(1, std::min(degree, weight_bound));
+    // the shuffle below may read past `needed` (degree - 1 - weight_bound index draws): Python slicing
+    // past the end yields b"" -> 0; mirror that by bounds-checking every chunk
+    auto chunk_mod = [&](size_t pos, int n, uint64_t m) -> uint64_t {
+        if (pos >= len) return 0;
+        int avail = (int)std::min<size_t>((size_t)n, len - pos);
+        return be_mod(b + pos, avail, m);
+    };
+    size_t pos = (size_t)d.sign_bytes;
+    for (int j = 0; j < degree; ++j) out[j] = 0;
+    for (int i = 0; i < weight_bound; ++i) {
+        // sign i = bit i (LSB first) of the big-endian integer in the leading sign_bytes bytes
+        const int byte_from_end = i / 8;
+        const int bit = (b[d.sign_bytes - 1 - byte_from_end] >> (i % 8)) & 1;
+        const long long mag = (long long)chunk_mod(pos, d.coef_bytes, (uint64_t)d.bound) + 1;
+        pos += (size_t)d.coef_bytes;
+        if (i < degree) out[i] = (int32_t)(bit ? mag : -mag);
+    }
+    if (num_coefs < degree) {
+        for (int i = degree - 1; i > weight_bound; --i) {
+            const int j = (int)chunk_mod(pos, d.index_bytes, (uint64_t)(i + 1));
+            pos += (size_t)d.index_bytes;
+            std::swap(out[i], out[j]);
+        }
+    }
+    return 0;
+}
+
+size_t challenge_bytes(const fz_scheme_params &P) {          // n of hash_ch / sign (fusion.py:515-524)
+    const int num_coefs = std::max(0, std::min(P.degree, P.omega_ch));
+    const long long bound = std::max<long long>(0, std::min<long long>((long long)P.modulus / 2, P.beta_ch));
+    const int cb = (int)std::ceil((std::log2((double)bound) + 1 + P.secpar) / 8.0);
+    const int ib = (int)std::ceil((std::log2((double)P.degree) + P.secpar) / 8.0);
+    return (size_t)((P.omega_ch + 7) / 8) + (size_t)cb * num_coefs + (size_t)P.degree * ib;
+}
+
+size_t agg_coef_bytes(const fz_scheme_params &P) {           // per-signer n of hash_vks_and_ints_and_challs (fusion.py:579-585)
+    const long long bound = std::max<long long>(0, std::min<long long>((long long)P.modulus / 2, P.beta_ag));
+    const int cb = (int)std::ceil((std::log2((double)bound) + 1 + P.secpar) / 8.0);
+    const int ib = (int)std::ceil((std::log2((double)P.degree) + P.secpar) / 8.0);
+    return (size_t)((P.omega_ag + 7) / 8) + (size_t)(cb + ib) * P.omega_ag;
+}
+
+void prehash(const fz_scheme_params &P, const char *msg, size_t len, uint8_t out[32]) {
+    std::string salted;
+    salted.reserve(len + 3);
+    salted.append(reinterpret_cast<const char *>(P.sign_pre_hash_dst), 2);
+    salted += ",";
+    salted.append(msg, len);
+    sha3_256(reinterpret_cast<const uint8_t *>(salted.data()), salted.size(), out);
+}
+
+template <typename F>
+void parallel_for(size_t n, int threads, F f) {
+    if (threads <= 1 || n < 2) {
+        for (size_t i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t T = std::min<size_t>((size_t)threads, n);
+    for (size_t t = 0; t < T; ++t)
+        pool.emplace_back([=]() {
+            for (size_t i = t; i < n; i += T) f(i);
+        });
+    for (auto &th : pool) th.join();
+}
+
+bool params_ok(const fz_scheme_params *P) {
+    return P && P->degree >= 2 && P->degree <= (1 << 16) && P->modulus >= 3 && P->secpar > 0 && P->omega_ch >= 1 &&
+           P->omega_ag >= 1 && P->beta_ch >= 1 && P->beta_ag >= 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fz_sha3_256(const uint8_t *h_data, size_t len, uint8_t *h_out32) {
+    if ((!h_data && len) || !h_out32) return fz_set_error(FZ_E_BADARG, "NULL argument");
+    sha3_256(h_data, len, h_out32);
+    return FZ_OK;
+}
+
+int fz_shake256(const uint8_t *h_data, size_t len, uint8_t *h_out, size_t out_len) {
+    if ((!h_data && len) || (!h_out && out_len)) return fz_set_error(FZ_E_BADARG, "NULL argument");
+    shake256(h_data, len, h_out, out_len);
+    return FZ_OK;
+}
+
+int fz_format_vk(const fz_scheme_params *P, const int32_t *h_vk_left, const int32_t *h_vk_right, char *h_out,
+                 size_t cap, size_t *out_len) {
+    if (!params_ok(P) || !h_vk_left || !h_vk_right || !out_len) return fz_set_error(FZ_E_BADARG, "bad argument");
+    std::string s;
+    put_vk(s, *P, h_vk_left, h_vk_right);
+    *out_len = s.size();
+    if (h_out) {
+        if (cap < s.size()) return fz_set_error(FZ_E_BADARG, "buffer of %zu bytes too small for %zu", cap, s.size());
+        memcpy(h_out, s.data(), s.size());
+    }
+    return FZ_OK;
+}
+
+int fz_decode_coefficients(const uint8_t *h_bytes, size_t len, int log2_bias, int64_t modulus, int degree,
+                           int64_t norm_bound, int weight_bound, int32_t *h_out) {
+    if (!h_bytes || !h_out || degree < 1 || weight_bound < 1 || modulus < 2)
+        return fz_set_error(FZ_E_BADARG, "bad argument");
+    if (decode(h_bytes, len, log2_bias, modulus, degree, norm_bound, weight_bound, h_out) != 0)
+        return fz_set_error(FZ_E_BADARG, "Too few bytes to decode polynomial");
+    return FZ_OK;
+}
+
+int fz_hash_messages(const fz_scheme_params *P, const char *h_msgs, const size_t *h_msg_off, size_t N,
+                     uint8_t *h_prehash) {
+    if (!params_ok(P) || !h_msg_off || !h_prehash || (N && !h_msgs)) return fz_set_error(FZ_E_BADARG, "bad argument");
+    for (size_t i = 0; i < N; ++i) prehash(*P, h_msgs + h_msg_off[i], h_msg_off[i + 1] - h_msg_off[i], h_prehash + 32 * i);
+    return FZ_OK;
+}
+
+int fz_challenge_coefficients(const fz_scheme_params *P, const int32_t *h_vk_left, const int32_t *h_vk_right,
+                              const char *h_msgs, const size_t *h_msg_off, size_t N, int32_t *h_coefs,
+                              uint8_t *h_prehash, int threads) {
+    if (!params_ok(P) || !h_vk_left || !h_vk_right || !h_msg_off || !h_coefs || (N && !h_msgs))
+        return fz_set_error(FZ_E_BADARG, "bad argument");
+    const size_t n = challenge_bytes(*P);
+    const size_t need = (size_t)P->omega_ch * P->bytes_for_one_coef_bdd_by_beta_ch + P->bytes_for_poly_shuffle;
+    if (n < need) return fz_set_error(FZ_E_BADARG, "hashed_vk_and_pre_hashed_message is too short");
+    const int d = P->degree;
+    int bad = 0;
+    parallel_for(N, threads, [&](size_t i) {
+        uint8_t ph[32];
+        prehash(*P, h_msgs + h_msg_off[i], h_msg_off[i + 1] - h_msg_off[i], ph);
+        if (h_prehash) memcpy(h_prehash + 32 * i, ph, 32);
+        std::string x;
+        x.reserve(16384);
+        x.append(reinterpret_cast<const char *>(P->sign_hash_dst), 2);
+        x += ",";
+        put_vk(x, *P, h_vk_left + i * (size_t)d, h_vk_right + i * (size_t)d);
+        x += ",";
+        x += u256_decimal(ph);
+        std::vector<uint8_t> xof(n);
+        shake256(reinterpret_cast<const uint8_t *>(x.data()), x.size(), xof.data(), n);
+        if (decode(xof.data(), n, P->secpar, P->modulus, d, P->beta_ch, P->omega_ch, h_coefs + i * (size_t)d) != 0)
+            bad = 1;
+    });
+    return bad ? fz_set_error(FZ_E_BADARG, "Too few bytes to decode polynomial") : FZ_OK;
+}
+
+int fz_sort_by_vk_string(const fz_scheme_params *P, const int32_t *h_vk_left, const int32_t *h_vk_right, size_t N,
+                         size_t *h_order, int threads) {
+    if (!params_ok(P) || !h_order || (N && (!h_vk_left || !h_vk_right))) return fz_set_error(FZ_E_BADARG, "bad argument");
+    const int d = P->degree;
+    std::vector<std::string> keys(N);
+    parallel_for(N, threads, [&](size_t i) { put_vk(keys[i], *P, h_vk_left + i * (size_t)d, h_vk_right + i * (size_t)d); });
+    std::iota(h_order, h_order + N, (size_t)0);
+    // Python's sorted() is stable and compares str by code point; the text is ASCII
+    std::stable_sort(h_order, h_order + N, [&](size_t a, size_t b) { return keys[a] < keys[b]; });
+    return FZ_OK;
+}
+
+int fz_aggregation_coefficients(const fz_scheme_params *P, const int32_t *h_vk_left, const int32_t *h_vk_right,
+                                const uint8_t *h_prehash, const int32_t *h_c_hat, size_t N, int32_t *h_coefs,
+                                int threads) {
+    if (!params_ok(P) || !h_coefs || (N && (!h_vk_left || !h_vk_right || !h_prehash || !h_c_hat)))
+        return fz_set_error(FZ_E_BADARG, "bad argument");
+    const int d = P->degree;
+    // str(list(zip(keys, prehashed, challs))): "[(vk, int, SignatureChallenge(c_hat=poly)), (...)]"
+    std::vector<std::string> items(N);
+    parallel_for(N, threads, [&](size_t i) {
+        std::string &s = items[i];
+        s.reserve(16384);
+        s += "(";
+        put_vk(s, *P, h_vk_left + i * (size_t)d, h_vk_right + i * (size_t)d);
+        s += ", ";
+        s += u256_decimal(h_prehash + 32 * i);
+        s += ", SignatureChallenge(c_hat=";
+        put_poly(s, *P, h_c_hat + i * (size_t)d);
+        s += "))";
+    });
+    Sponge sp(136);
+    uint8_t head[3] = {P->agg_xof_dst[0], P->agg_xof_dst[1], ','};
+    sp.absorb(head, 3);
+    sp.absorb(reinterpret_cast<const uint8_t *>("["), 1);
+    for (size_t i = 0; i < N; ++i) {
+        if (i) sp.absorb(reinterpret_cast<const uint8_t *>(", "), 2);
+        sp.absorb(reinterpret_cast<const uint8_t *>(items[i].data()), items[i].size());
+        std::string().swap(items[i]);
+    }
+    sp.absorb(reinterpret_cast<const uint8_t *>("]"), 1);
+    sp.finish(0x1f);
+    const size_t n = agg_coef_bytes(*P);
+    std::vector<uint8_t> xof(n * N);
+    sp.squeeze(xof.data(), xof.size());
+    int bad = 0;
+    parallel_for(N, threads, [&](size_t i) {
+        if (decode(xof.data() + i * n, n, P->secpar, P->modulus, d, P->beta_ag, P->omega_ag, h_coefs + i * (size_t)d) != 0)
+            bad = 1;
+    });
+    return bad ? fz_set_error(FZ_E_BADARG, "Too few bytes to decode polynomial") : FZ_OK;
+}
+
+}  // extern "C"

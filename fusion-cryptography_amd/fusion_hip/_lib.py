@@ -81,6 +81,33 @@ SIGNATURES = {
     "fz_norm_weight_host": (c_int, [_ctx, _i32p, c_size_t, _i64p, POINTER(c_int32)]),
 }
 
+
+
+class SchemeParams(ctypes.Structure):
+    """fz_scheme_params of include/fusion_hip.h"""
+    _fields_ = [("modulus", c_int64), ("root", c_int64), ("inv_root", c_int64),
+                ("degree", c_int32), ("root_order", c_int32), ("secpar", c_int32),
+                ("omega_ch", c_int32), ("omega_ag", c_int32),
+                ("beta_ch", c_int64), ("beta_ag", c_int64),
+                ("bytes_for_one_coef_bdd_by_beta_ch", c_int32), ("bytes_for_poly_shuffle", c_int32),
+                ("sign_pre_hash_dst", ctypes.c_uint8 * 2), ("sign_hash_dst", ctypes.c_uint8 * 2),
+                ("agg_xof_dst", ctypes.c_uint8 * 2)]
+
+
+_u8p = POINTER(ctypes.c_uint8)
+_szp = POINTER(c_size_t)
+_spp = POINTER(SchemeParams)
+SIGNATURES.update({
+    "fz_sha3_256": (c_int, [c_char_p, c_size_t, _u8p]),
+    "fz_shake256": (c_int, [c_char_p, c_size_t, _u8p, c_size_t]),
+    "fz_format_vk": (c_int, [_spp, _i32p, _i32p, c_char_p, c_size_t, _szp]),
+    "fz_decode_coefficients": (c_int, [c_char_p, c_size_t, c_int, c_int64, c_int, c_int64, c_int, _i32p]),
+    "fz_hash_messages": (c_int, [_spp, c_char_p, _szp, c_size_t, _u8p]),
+    "fz_challenge_coefficients": (c_int, [_spp, _i32p, _i32p, c_char_p, _szp, c_size_t, _i32p, _u8p, c_int]),
+    "fz_sort_by_vk_string": (c_int, [_spp, _i32p, _i32p, c_size_t, _szp, c_int]),
+    "fz_aggregation_coefficients": (c_int, [_spp, _i32p, _i32p, _u8p, _i32p, c_size_t, _i32p, c_int]),
+})
+
 _lib = None
 
 

@@ -1,0 +1,125 @@
+"""Array-backed batch API of the scheme (SURVEY.md 8f rows N1 + N2): keys, challenges and signatures
+are int32 arrays instead of lists of polynomial objects, hashing/decoding runs in the C host pipeline
+(hostpipe) and all algebra on the device.  Results are the same integers the object API
+(fusion.fusion.keygen / sign / aggregate / verify) produces -- tests/test_gpu_batch_scheme.py checks both
+against the reference's golden arrays.
+
+Layouts: sk_hat [N][2][l][d] (left rows then right rows), vk [N][2][d], c_hat / alpha_hat [N][d],
+sig [N][l][d], aggregate [l][d]; all int32, centred.
+"""
+import random
+
+import numpy as np
+
+from . import hostpipe
+from .context import VERDICT_REASONS, get_context
+
+
+class BatchScheme:
+    def __init__(self, params, device=0, threads=None):
+        """params: a fusion.fusion.Params (or any object with the same attributes)."""
+        self.params = params
+        self.P = hostpipe.scheme_params(params)
+        self.threads = threads or hostpipe.default_threads()
+        self.d, self.l, self.q = params.degree, params.num_rows_sk, params.modulus
+        self.ctx = get_context(params.modulus, params.degree, params.root, params.inv_root, device)
+        self.A = np.array([z.values for row in params.public_challenge.matrix for z in row], dtype=np.int32)
+
+    # ---- keygen ------------------------------------------------------------------------------------
+    def sample_secret_rows(self, seed):
+        """The reference samples every entry of a secret matrix with the SAME seed (fusion.py:156-173), so
+        a matrix is one polynomial repeated l times: draw it once with the same `random` calls
+        (algebra/polynomials.py:447-459) and tile it."""
+        p = self.params
+        random.seed(seed)
+        count = max(0, min(p.degree, p.omega_sk))
+        bound = max(0, min(p.modulus // 2, p.beta_sk))
+        coefs = []
+        for _ in range(count):
+            magnitude = 1 + random.randrange(bound)
+            coefs.append(magnitude * (1 - 2 * random.randrange(2)))
+        coefs.extend([0] * (p.degree - count))
+        if count < p.degree:
+            for i in range(p.degree - 1, 0, -1):
+                j = random.randrange(i + 1)
+                coefs[i], coefs[j] = coefs[j], coefs[i]
+        # the reference re-seeds and re-draws l times; the global generator ends in the same state
+        return np.tile(np.array(coefs, dtype=np.int32), (self.l, 1))
+
+    def keygen_batch(self, seeds):
+        """-> (sk_hat [N][2][l][d], vk [N][2][d]); key i equals keygen(params, seeds[i])."""
+        coef = np.stack([np.stack([self.sample_secret_rows(s), self.sample_secret_rows(s + 1)]) for s in seeds])
+        return self.ctx.keygen_core(self.A, coef)
+
+    # ---- sign --------------------------------------------------------------------------------------
+    def challenges(self, vk, messages):
+        """hash_ch for every (key, message): -> (c_hat [N][d], prehash [N][32])"""
+        vk = np.ascontiguousarray(vk, dtype=np.int32).reshape(-1, 2, self.d)
+        coefs, pre = hostpipe.challenge_coefficients(self.P, np.ascontiguousarray(vk[:, 0]),
+                                                     np.ascontiguousarray(vk[:, 1]), messages, self.threads)
+        return self.ctx.ntt_forward(coefs), pre
+
+    def sign_batch(self, sk_hat, vk, messages):
+        """-> sig [N][l][d]; row i equals sign(params, key_i, messages[i]).signature_hat"""
+        c_hat, _ = self.challenges(vk, messages)
+        return self.ctx.sign_core(np.ascontiguousarray(sk_hat, dtype=np.int32).reshape(-1, 2, self.l, self.d), c_hat)
+
+    # ---- aggregate / verify ----------------------------------------------------------------------------
+    def _sorted_inputs(self, vk, messages):
+        vk = np.ascontiguousarray(vk, dtype=np.int32).reshape(-1, 2, self.d)
+        L, R = np.ascontiguousarray(vk[:, 0]), np.ascontiguousarray(vk[:, 1])
+        order = hostpipe.sort_by_vk_string(self.P, L, R, self.threads)
+        L, R = L[order], R[order]
+        msgs = [messages[i] for i in order]
+        coefs, pre = hostpipe.challenge_coefficients(self.P, L, R, msgs, self.threads)
+        c_hat = self.ctx.ntt_forward(coefs)
+        alpha = hostpipe.aggregation_coefficients(self.P, L, R, pre, c_hat, self.threads)
+        return order, L, R, c_hat, self.ctx.ntt_forward(alpha)
+
+    def aggregate(self, vk, messages, sig):
+        """-> aggregate [l][d] == aggregate(params, keys, messages, signatures).signature_hat"""
+        order, _, _, _, alpha_hat = self._sorted_inputs(vk, messages)
+        sig = np.ascontiguousarray(sig, dtype=np.int32).reshape(-1, self.l, self.d)[order]
+        return self.ctx.aggregate_core(sig, alpha_hat)
+
+    def verify(self, vk, messages, aggregate):
+        """-> (bool, reason) with the reference's reason strings (fusion.py:680-728)"""
+        n = np.asarray(vk).reshape(-1, 2, self.d).shape[0]
+        if n > self.params.capacity:
+            return False, VERDICT_REASONS[1]
+        if n != len(messages):
+            return False, VERDICT_REASONS[2]
+        _, L, R, c_hat, alpha_hat = self._sorted_inputs(vk, messages)
+        code = self.ctx.verify_core(self.A, aggregate, L, R, c_hat, alpha_hat, self.params.beta_vf,
+                                    self.params.omega_vf)
+        return code == 0, VERDICT_REASONS[code]
+
+
+# ---- conversions between the array face and the drop-in object face ----------------------------------------
+def vk_to_object(params, vk_row):
+    """vk [2][d] -> fusion.fusion.OneTimeVerificationKey"""
+    import fusion.fusion as F
+    return F.OneTimeVerificationKey(left_vk_hat=F._column(params, np.asarray(vk_row[0:1])),
+                                    right_vk_hat=F._column(params, np.asarray(vk_row[1:2])))
+
+
+def sk_to_object(params, seed, sk_rows):
+    """sk_hat [2][l][d] -> fusion.fusion.OneTimeSigningKey"""
+    import fusion.fusion as F
+    return F.OneTimeSigningKey(seed=seed, left_sk_hat=F._column(params, np.asarray(sk_rows[0])),
+                               right_sk_hat=F._column(params, np.asarray(sk_rows[1])))
+
+
+def signature_to_object(params, sig_rows):
+    import fusion.fusion as F
+    return F.Signature(signature_hat=F._column(params, np.asarray(sig_rows)))
+
+
+def signature_from_object(params, sig):
+    import fusion.fusion as F
+    return F._rows_of(sig.signature_hat, params.modulus)
+
+
+def vk_from_object(params, vk):
+    import fusion.fusion as F
+    return np.concatenate([F._rows_of(vk.left_vk_hat, params.modulus), F._rows_of(vk.right_vk_hat, params.modulus)])

@@ -184,6 +184,49 @@ FZ_API int fz_norm_weight(fz_ctx *ctx, const int32_t *d_coef, size_t batch,
 FZ_API int fz_norm_weight_host(fz_ctx *ctx, const int32_t *h_coef, size_t batch,
                                int64_t *h_max_abs, int32_t *h_weight);
 
+/* ---- challenge pipeline on the host -----------------------------------------
+ * The scheme's hash -> challenge path: exact-format serialisation of the key objects, SHA3-256 /
+ * SHAKE-256 (FIPS 202) and the byte decoder.  Host memory only (h_*), no GPU involved; `threads` > 1
+ * spreads independent signers over host threads.  The forward NTT of the decoded coefficient rows is
+ * fz_ntt_forward.
+ *   fz_scheme_params mirrors the fields of fusion.fusion.Params that the path reads (fusion.py:204-282). */
+typedef struct fz_scheme_params {
+    int64_t modulus, root, inv_root;
+    int32_t degree, root_order, secpar;
+    int32_t omega_ch, omega_ag;
+    int64_t beta_ch, beta_ag;
+    int32_t bytes_for_one_coef_bdd_by_beta_ch, bytes_for_poly_shuffle;
+    uint8_t sign_pre_hash_dst[2], sign_hash_dst[2], agg_xof_dst[2];
+} fz_scheme_params;
+
+FZ_API int fz_sha3_256(const uint8_t *h_data, size_t len, uint8_t *h_out32);
+FZ_API int fz_shake256(const uint8_t *h_data, size_t len, uint8_t *h_out, size_t out_len);
+/* str(OneTimeVerificationKey) (fusion.py:328-329 -> matrices.py:40-41 -> polynomials.py:257-258) of a key
+ * given as its two degree-long rows; h_out may be NULL to query the length. */
+FZ_API int fz_format_vk(const fz_scheme_params *P, const int32_t *h_vk_left, const int32_t *h_vk_right,
+                        char *h_out, size_t cap, size_t *out_len);
+/* decode_bytes_to_polynomial_coefficients (fusion.py:422-481) */
+FZ_API int fz_decode_coefficients(const uint8_t *h_bytes, size_t len, int log2_bias, int64_t modulus, int degree,
+                                  int64_t norm_bound, int weight_bound, int32_t *h_out);
+/* hash_message_to_int (fusion.py:405-409) for N messages (UTF-8, concatenated; h_msg_off has N+1 entries):
+ * the 32-byte digests, i.e. the integers in little-endian byte order. */
+FZ_API int fz_hash_messages(const fz_scheme_params *P, const char *h_msgs, const size_t *h_msg_off, size_t N,
+                            uint8_t *h_prehash);
+/* hash_ch up to (not including) the NTT (fusion.py:511-531 = :405-409, :412-419, :484-506): coefficient rows
+ * [N][degree] of the challenges of N (key, message) pairs; h_prehash [N][32] may be NULL. */
+FZ_API int fz_challenge_coefficients(const fz_scheme_params *P, const int32_t *h_vk_left, const int32_t *h_vk_right,
+                                     const char *h_msgs, const size_t *h_msg_off, size_t N, int32_t *h_coefs,
+                                     uint8_t *h_prehash, int threads);
+/* the order sorted(..., key=str(vk)) puts the keys in (fusion.py:661-663, :693): h_order[i] = index of the
+ * i-th key in sorted order (stable). */
+FZ_API int fz_sort_by_vk_string(const fz_scheme_params *P, const int32_t *h_vk_left, const int32_t *h_vk_right,
+                                size_t N, size_t *h_order, int threads);
+/* hash_ag up to the NTTs (fusion.py:573-629): keys, pre-hashed messages and NTT-domain challenges c_hat
+ * [N][degree], all already in sorted key order -> coefficient rows [N][degree] of the aggregation coefficients. */
+FZ_API int fz_aggregation_coefficients(const fz_scheme_params *P, const int32_t *h_vk_left,
+                                       const int32_t *h_vk_right, const uint8_t *h_prehash,
+                                       const int32_t *h_c_hat, size_t N, int32_t *h_coefs, int threads);
+
 #ifdef __cplusplus
 }
 #endif

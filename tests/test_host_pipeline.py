@@ -1,0 +1,120 @@
+"""The C host pipeline (csrc/fz_host.cpp: serialiser, SHA3/SHAKE, decoder -- SURVEY 8f row N1) against
+CPython's hashlib, the drop-in Python host functions (themselves pinned by the reference's KAT rows in
+tests/test_host_logic.py) and the KAT rows directly.  No GPU needed."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def hp():
+    import __graft_entry__ as g
+    g.build()
+    from fusion_hip import hostpipe
+    return hostpipe
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(G, "kat.json")) as fh:
+        return json.load(fh)
+
+
+def test_keccak_against_hashlib(hp):
+    rng = random.Random(7)
+    for n in [0, 1, 3, 135, 136, 137, 271, 272, 273, 1000, 6344, 100000]:
+        data = rng.randbytes(n)
+        assert hp.sha3_256(data) == hashlib.sha3_256(data).digest()
+        for out in (0, 1, 32, 135, 136, 137, 1551, 10436, 3968 * 3 + 1):
+            assert hp.shake256(data, out) == hashlib.shake_256(data).digest(out)
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_formats_and_decoder_match_dropin(secpar, hp):
+    import fusion.fusion as F
+    from algebra.matrices import GeneralMatrix
+    from algebra.polynomials import PolynomialNTTRepresentation as PN
+    params = F.fusion_setup(secpar, 3)
+    P = hp.scheme_params(params)
+    rng = np.random.default_rng(secpar)
+    d, q = params.degree, params.modulus
+    N = 5
+    vkL = rng.integers(-(q // 2), q // 2 + 1, size=(N, d)).astype(np.int32)
+    vkR = rng.integers(-(q // 2), q // 2 + 1, size=(N, d)).astype(np.int32)
+    vkL[0, :4] = [0, -1, q // 2, -(q // 2)]
+    msgs = ["", "a", "message number 0003 !!", "ünï¢ode ✓", "x" * 1000]
+
+    def poly(v):
+        return PN(modulus=q, degree=d, root=params.root, inv_root=params.inv_root, root_order=params.root_order,
+                  values=[int(t) for t in v])
+    keys = [F.OneTimeVerificationKey(left_vk_hat=GeneralMatrix(matrix=[[poly(vkL[i])]]),
+                                     right_vk_hat=GeneralMatrix(matrix=[[poly(vkR[i])]])) for i in range(N)]
+    for i in range(N):
+        assert hp.format_vk(P, vkL[i], vkR[i]) == str(keys[i])
+    pre = hp.hash_messages(P, msgs)
+    for i in range(N):
+        assert int.from_bytes(bytes(pre[i]), "little") == F.hash_message_to_int(params, msgs[i])
+    coefs, pre2 = hp.challenge_coefficients(P, vkL, vkR, msgs, threads=3)
+    assert np.array_equal(pre, pre2)
+    n = F._challenge_bytes_needed(params)
+    for i in range(N):
+        xof = F.hash_vk_and_int_to_bytes(params, keys[i], F.hash_message_to_int(params, msgs[i]), n)
+        want = F.decode_bytes_to_polynomial_coefficients(xof, secpar, q, d, params.beta_ch, params.omega_ch)
+        assert coefs[i].tolist() == want
+        assert hp.decode_coefficients(xof, secpar, q, d, params.beta_ch, params.omega_ch).tolist() == want
+    # sorted(key=str(vk))
+    order = hp.sort_by_vk_string(P, vkL, vkR)
+    assert order.tolist() == sorted(range(N), key=lambda i: str(keys[i]))
+    # aggregation coefficients: one XOF over str(list(zip(keys, ints, challs)))
+    c_hat = rng.integers(-(q // 2), q // 2 + 1, size=(N, d)).astype(np.int32)
+    challs = [F.SignatureChallenge(c_hat=poly(c_hat[i])) for i in range(N)]
+    ints = [F.hash_message_to_int(params, m) for m in msgs]
+    b = F.hash_vks_and_ints_and_challs_to_bytes(params, keys, ints, challs)
+    per = F._agg_coef_bytes(params)
+    want = [F.decode_bytes_to_polynomial_coefficients(b[i * per:(i + 1) * per], secpar, q, d, params.beta_ag,
+                                                      params.omega_ag) for i in range(N)]
+    got = hp.aggregation_coefficients(P, vkL, vkR, pre, c_hat, threads=2)
+    assert got.tolist() == want
+
+
+def test_decoder_general_bounds(hp):
+    import fusion.fusion as F
+    rng = random.Random(11)
+    for (q, d, beta, omega, bias) in [(65537, 1024, 1000, 100, 256), (2147465729, 64, 3, 27, 128),
+                                      (2147465729, 256, 52, 256, 256), (17, 8, 5, 3, 16), (257, 16, 1, 16, 8)]:
+        from math import ceil, log2
+        bound = max(1, min(q // 2, beta))
+        cb, ib, sb = ceil((log2(bound) + 1 + bias) / 8), ceil((log2(d) + bias) / 8), ceil(omega / 8)
+        for extra in (0, ib * d):
+            b = rng.randbytes(sb + (cb + ib) * omega + extra)
+            want = F.decode_bytes_to_polynomial_coefficients(b, bias, q, d, beta, omega)
+            assert hp.decode_coefficients(b, bias, q, d, beta, omega).tolist() == want[:d]
+        with pytest.raises(ValueError):
+            hp.decode_coefficients(b"\x00" * (sb + (cb + ib) * omega - 1), bias, q, d, beta, omega)
+
+
+def test_reference_kats_through_c_pipeline(hp, kat, coracle):
+    """intermediate_hash_message_to_int / hash_vk_and_int_to_bytes / hash_ch KAT rows of the reference,
+    replayed through the C pipeline (forward NTT from the oracle: this test runs without a GPU)."""
+    import fusion.fusion as F
+    from oracle import oracle as O
+    params = F.fusion_setup(128, 1)
+    P = hp.scheme_params(params)
+    rows = kat["hash_message_to_int"]
+    pre = hp.hash_messages(P, [r["message"] for r in rows])
+    assert [str(int.from_bytes(bytes(p), "little")) for p in pre] == [r["expected"] for r in rows]
+    rows = kat["hash_vk_and_int_to_bytes"]
+    for r in rows:
+        x = (params.sign_hash_dst + b"," + hp.format_vk(P, r["vk_left"], r["vk_right"]).encode() + b"," + r["i"].encode())
+        assert hashlib.sha256(hp.shake256(x, r["n"])).hexdigest() == r["sha256_expected_bytes"]
+    rows = kat["hash_ch"]
+    coefs, _ = hp.challenge_coefficients(P, [r["vk_left"] for r in rows], [r["vk_right"] for r in rows],
+                                         [r["message"] for r in rows])
+    c_hat = coracle.ntt_forward(coefs, O.PRIME, O.PARAMS[128]["root"])
+    assert c_hat.tolist() == [r["c_hat"] for r in rows]

@@ -83,15 +83,23 @@ def main():
             sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    # one rank per GPU; the modulo only matters for a rehearsal of the N>1 path on a box with fewer GPUs
+    # (FZ_BENCH_BACKEND=gloo), where ranks share a device
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("FZ_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     P = O.PARAMS[SECPAR]
     q, d, l = P["q"], P["d"], P["rank"]
-    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=local_rank)
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -250,7 +258,7 @@ def main():
         import fusion.fusion as F
         from fusion_hip.scheme import BatchScheme
         params = F.fusion_setup(SECPAR, 2026)
-        bs = BatchScheme(params, device=local_rank)
+        bs = BatchScheme(params, device=dev_index)
         bs.ctx.set_stream(stream.cuda_stream)
         n_e2e = 256
         seeds = [10_000 + 2 * i for i in range(n_e2e)]

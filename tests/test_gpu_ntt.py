@@ -70,3 +70,55 @@ def test_ntt_roundtrip_large_batch(secpar, coracle):
     sel = [0, 1, 2, 3, 4, 1000, 4095, 4096, 4097, 4098]
     assert np.array_equal(f[sel], coracle.ntt_forward(x[sel], Q, root))
     assert np.array_equal(f, coracle.ntt_forward(x, Q, root))
+
+
+@pytest.mark.parametrize("kernel", ["4", "16"])
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_both_schedules_ragged_and_in_place(kernel, secpar, coracle, monkeypatch):
+    """Both NTT schedules (radix-4 and 16-per-lane; forced through FZ_NTT_KERNEL, which the context reads
+    at creation) on every small batch size 0..9 and a few ragged larger ones, out of place and in place."""
+    import fusion_hip
+    monkeypatch.setenv("FZ_NTT_KERNEL", kernel)
+    P = O.PARAMS[secpar]
+    d, root, inv = P["d"], P["root"], P["inv_root"]
+    ctx = fusion_hip.Context(Q, d, root, inv)          # not the cached one: picks up the env override
+    rng = np.random.default_rng(int(kernel) * 1000 + secpar)
+    for B in list(range(0, 10)) + [15, 16, 17, 63, 65, 255, 1025]:
+        x = rng.integers(-2**31, 2**31, size=(B, d), dtype=np.int64).astype(np.int32)
+        assert np.array_equal(ctx.ntt_forward(x), coracle.ntt_forward(x, Q, root).reshape(B, d)), (kernel, B)
+        assert np.array_equal(ctx.ntt_inverse(x), coracle.ntt_inverse(x, Q, inv).reshape(B, d)), (kernel, B)
+    # device face, in place (d_in == d_out) and out of place into a poisoned buffer
+    B = 1000 + 3
+    x = O.splitmix_centered(4, B * d).reshape(B, d)
+    buf = fusion_hip.DeviceBuffer.from_numpy(ctx, x)
+    out = fusion_hip.DeviceBuffer.from_numpy(ctx, np.full((B + 1, d), 123456789, np.int32))
+    ctx.ntt_forward_dev(buf.ptr, out.ptr, B)
+    got = out.to_numpy(np.int32, (B + 1, d))
+    want = coracle.ntt_forward(x, Q, root)
+    assert np.array_equal(got[:B], want) and np.all(got[B] == 123456789)       # nothing written past the batch
+    ctx.ntt_forward_dev(buf.ptr, buf.ptr, B)
+    assert np.array_equal(buf.to_numpy(np.int32, (B, d)), want)
+    ctx.ntt_inverse_dev(buf.ptr, buf.ptr, B)
+    assert np.array_equal(buf.to_numpy(np.int32, (B, d)), x)
+    ctx.close()
+
+
+def test_error_codes_on_device():
+    import ctypes
+    import fusion_hip
+    lib = fusion_hip.load_library()
+    ctx = fusion_hip.Context(Q, 256, 3337519, pow(3337519, Q - 2, Q))
+    buf = fusion_hip.DeviceBuffer(ctx, 4096)
+    with pytest.raises(fusion_hip.FusionHipError) as e:
+        ctx.ntt_forward_dev(buf.ptr + 4, buf.ptr, 1)              # misaligned
+    assert e.value.code == -1
+    with pytest.raises(fusion_hip.FusionHipError) as e:
+        ctx.ntt_forward_dev(0, buf.ptr, 1)                        # NULL
+    assert e.value.code == -1
+    ring = fusion_hip.Context(Q, 100, 0, 0)                       # ring-only context: no transforms
+    with pytest.raises(fusion_hip.FusionHipError) as e:
+        ring.ntt_forward(np.zeros(100, np.int32))
+    assert e.value.code == -2
+    with pytest.raises(fusion_hip.FusionHipError):
+        fusion_hip.Context(Q, 256, 5, 1)                          # not a primitive root
+    assert lib.fz_ctx_destroy(None) == 0

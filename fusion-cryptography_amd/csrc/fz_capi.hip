@@ -59,6 +59,20 @@ int fz_scratch(fz_ctx *ctx, size_t bytes, void **out) {
     return FZ_OK;
 }
 
+int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->scratch2_bytes) {
+        FZ_HIP(hipStreamSynchronize(ctx->stream), "scratch2 sync");
+        if (ctx->d_scratch2) FZ_HIP(hipFree(ctx->d_scratch2), "scratch2 free");
+        ctx->d_scratch2 = nullptr;
+        ctx->scratch2_bytes = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        FZ_HIP(hipMalloc(&ctx->d_scratch2, want), "scratch2 alloc");
+        ctx->scratch2_bytes = want;
+    }
+    *out = ctx->d_scratch2;
+    return FZ_OK;
+}
+
 extern "C" {
 
 const char *fz_version(void) { return "fusion_hip 0.1.0 (gfx950)"; }
@@ -201,6 +215,9 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     {
         const char *e = getenv("FZ_NTT_KERNEL");
         c->force_kernel = e ? atoi(e) : 0;
+        e = getenv("FZ_NTT_GRID_MULT");
+        c->grid_mult = e ? atoi(e) : 1;
+        if (c->grid_mult < 1) c->grid_mult = 1;
         e = getenv("FZ_NTT_SMALL_ROWS");
         // measured crossover (profiles/README.md): degree 256 -- radix-4 wins up to 2^16 rows (cache-
         // resident batches), the 16-per-lane kernel from 2^20 rows; degree 64 -- radix-4 at every size
@@ -228,6 +245,7 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     if (ctx->d_twB) (void)hipFree(ctx->d_twB);
     if (ctx->d_itwB) (void)hipFree(ctx->d_itwB);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_scratch2) (void)hipFree(ctx->d_scratch2);
     if (ctx->d_verdict) (void)hipFree(ctx->d_verdict);
     if (ctx->prof_ev) {
         for (int i = 0; i < 2 * ctx->prof_cap; ++i) (void)hipEventDestroy(ctx->prof_ev[i]);
@@ -444,7 +462,7 @@ int fz_aggregate_partial_batch(fz_ctx *ctx, const int32_t *d_sig, const int32_t 
     FZ_REQUIRE(ctx && l >= 1 && d_partial && (N == 0 || groups == 0 || (d_sig && d_alpha_hat)), "bad argument");
     FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large for exact int64/fp64 accumulation (< 2^21)", N);
     FZ_REQUIRE(groups <= 65535 && (groups <= 1 || partial_stride >= (size_t)l * ctx->degree), "bad groups / stride");
-    return fz_launch_aggregate_partial(ctx, d_sig, d_alpha_hat, d_partial, partial_stride, groups, N, l);
+    return fz_launch_aggregate(ctx, d_sig, d_alpha_hat, d_partial, partial_stride, nullptr, groups, N, l);
 }
 
 int fz_aggregate_partial(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, int64_t *d_partial,
@@ -459,11 +477,8 @@ int fz_reduce_i64(fz_ctx *ctx, const int64_t *d_in, int32_t *d_out, size_t count
 
 int fz_aggregate_core(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, int32_t *d_out, size_t N, int l) {
     FZ_REQUIRE(ctx && l >= 1 && N >= 1 && d_sig && d_alpha_hat && d_out, "bad argument");
-    const size_t count = (size_t)l * ctx->degree;
-    void *d = nullptr;
-    FZ_TRY(fz_scratch(ctx, count * sizeof(int64_t), &d));
-    FZ_TRY(fz_aggregate_partial(ctx, d_sig, d_alpha_hat, (int64_t *)d, N, l));
-    return fz_launch_reduce_i64(ctx, (const int64_t *)d, d_out, count);
+    FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large for exact fp64 accumulation (< 2^21)", N);
+    return fz_launch_aggregate(ctx, d_sig, d_alpha_hat, nullptr, 0, d_out, 1, N, l);
 }
 
 int fz_target_partial_batch(fz_ctx *ctx, const int32_t *d_vkL, const int32_t *d_vkR, const int32_t *d_c_hat,

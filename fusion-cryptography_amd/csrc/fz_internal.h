@@ -35,11 +35,13 @@ struct fz_ctx {
     int force_kernel;            // 0 auto, 4 radix-4, 16 sixteen-per-lane (env FZ_NTT_KERNEL; benchmarking)
     FzTwA twA, itwA;
     // growable device scratch (host-pointer entry points, int64 partial sums)
-    void *d_scratch;
-    size_t scratch_bytes;
+    void *d_scratch, *d_scratch2;
+    size_t scratch_bytes, scratch2_bytes;
     int *d_verdict;              // [verdict_cap]
     size_t verdict_cap;
     int grid_fwd, grid_inv;      // resident-grid caps for the persistent NTT kernels
+    int grid_fwd4, grid_inv4;    // same for the radix-4 kernels
+    int grid_mult;               // grid = resident blocks x grid_mult (env FZ_NTT_GRID_MULT; 1 = persistent)
     // per-dispatch timing of the NTT kernels (fz_profile_begin/end): event pairs bound to the
     // dispatch itself via hipExtLaunchKernelGGL, i.e. kernel begin -> kernel end on its own stream
     int prof_on, prof_cap, prof_n, prof_every, prof_seen[2];
@@ -51,6 +53,7 @@ struct fz_ctx {
 int fz_set_error(int code, const char *fmt, ...);
 int fz_check_hip(hipError_t e, const char *what);
 int fz_scratch(fz_ctx *ctx, size_t bytes, void **out);
+int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out);   // second, independent scratch (per-split partial sums)
 
 // launchers (fz_ntt.hip)
 int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse);
@@ -62,8 +65,8 @@ int fz_launch_pw(fz_ctx *ctx, int op, const int32_t *a, const int32_t *b, int32_
 int fz_launch_pw_bcast(fz_ctx *ctx, const int32_t *a, const int32_t *s, int32_t *out, size_t rows);
 int fz_launch_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *out, size_t batch, int l);
 int fz_launch_sign(fz_ctx *ctx, const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig, size_t batch, int l);
-int fz_launch_aggregate_partial(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *partial, size_t pstride,
-                                size_t groups, size_t N, int l);
+int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *out64, size_t pstride,
+                        int32_t *out32, size_t groups, size_t N, int l);
 int fz_launch_target_partial(fz_ctx *ctx, const int32_t *vkL, const int32_t *vkR, const int32_t *c, const int32_t *alpha,
                              int64_t *partial, size_t pstride, size_t groups, size_t N);
 int fz_launch_reduce_i64(fz_ctx *ctx, const int64_t *in, int32_t *out, size_t count);

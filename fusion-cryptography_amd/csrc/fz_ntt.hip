@@ -347,18 +347,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *i
         twl[i - 1][2] = tw2[2 * pw + 2 * g + 1];
     }
 
+    int xn[4];                                   // next task's coefficients, in flight during the passes
+    auto fetch = [&](size_t task) {
+        const size_t poly = task * PPW + p;
+        const int32_t *src = in + (poly < batch ? poly : batch - 1) * D + mm;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xn[k] = src[k * LP];
+    };
+    fetch(first);
     for (size_t task = first; task < tasks; task += stride) {
         const size_t poly = task * PPW + p;
         const bool valid = poly < batch;
-        const int32_t *src = in + (valid ? poly : batch - 1) * D + mm;
         double a[4];
-        {
-            int x[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = src[k * LP];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = (double)x[k];
-        }
+        for (int k = 0; k < 4; ++k) a[k] = (double)xn[k];
+        if (task + stride < tasks) fetch(task + stride);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int s = D >> (2 * i + 2);
@@ -431,14 +434,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *i
         twl[i][2] = itw2[D / (4 * s) + g];
     }
 
+    int4 xn;
+    auto fetch = [&](size_t task) {
+        const size_t poly = task * PPW + p;
+        xn = *reinterpret_cast<const int4 *>(in + (poly < batch ? poly : batch - 1) * D + 4 * mm);
+    };
+    fetch(first);
     for (size_t task = first; task < tasks; task += stride) {
         const size_t poly = task * PPW + p;
         const bool valid = poly < batch;
         double a[4];
-        {
-            const int4 x = *reinterpret_cast<const int4 *>(in + (valid ? poly : batch - 1) * D + 4 * mm);
-            a[0] = (double)x.x; a[1] = (double)x.y; a[2] = (double)x.z; a[3] = (double)x.w;
-        }
+        a[0] = (double)xn.x; a[1] = (double)xn.y; a[2] = (double)xn.z; a[3] = (double)xn.w;
+        if (task + stride < tasks) fetch(task + stride);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int s = 1 << (2 * i);
@@ -543,8 +550,8 @@ template <int LOGD, bool FAST>
 int launch16f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
     const size_t tasks = (batch * Geom<LOGD>::D + kChunk - 1) / kChunk;
     const size_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int cap = inverse ? ctx->grid_inv : ctx->grid_fwd;
-    const unsigned grid = (unsigned)(blocks < (size_t)cap ? blocks : (size_t)cap);
+    const size_t cap = (size_t)(inverse ? ctx->grid_inv : ctx->grid_fwd) * (size_t)ctx->grid_mult;
+    const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_on && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen[inverse ? 1 : 0]++ % ctx->prof_every) == 0) {
         e0 = ctx->prof_ev[2 * ctx->prof_n];
@@ -566,7 +573,7 @@ int launch4f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool in
     constexpr int PPW = 64 / ((1 << LOGD) / 4);
     const size_t tasks = (batch + PPW - 1) / PPW;
     const size_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const size_t cap = (size_t)ctx->num_cu * 8;           // up to 8 waves per SIMD resident
+    const size_t cap = (size_t)(inverse ? ctx->grid_inv4 : ctx->grid_fwd4) * (size_t)ctx->grid_mult;
     const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_on && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen[inverse ? 1 : 0]++ % ctx->prof_every) == 0) {
@@ -624,8 +631,25 @@ int query16f(fz_ctx *ctx) {
     return FZ_OK;
 }
 
+template <int LOGD, bool FAST>
+int query4f(fz_ctx *ctx) {
+    int nf = 0, ni = 0;
+    const int threads = 64 * kWavesPerBlock;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, ntt_fwd4<LOGD, FAST>, threads, 0);
+    if (e != hipSuccess) return fz_check_hip(e, "occupancy query (fwd4)");
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&ni, ntt_inv4<LOGD, FAST>, threads, 0);
+    if (e != hipSuccess) return fz_check_hip(e, "occupancy query (inv4)");
+    ctx->grid_fwd4 = (nf < 1 ? 1 : nf) * ctx->num_cu;
+    ctx->grid_inv4 = (ni < 1 ? 1 : ni) * ctx->num_cu;
+    return FZ_OK;
+}
+
 template <int LOGD>
 int query16(fz_ctx *ctx) {
+    if constexpr (LOGD == 6 || LOGD == 8) {
+        int rc = ctx->mod.fast ? query4f<LOGD, true>(ctx) : query4f<LOGD, false>(ctx);
+        if (rc != FZ_OK) return rc;
+    }
     return ctx->mod.fast ? query16f<LOGD, true>(ctx) : query16f<LOGD, false>(ctx);
 }
 

@@ -169,10 +169,12 @@ __device__ __forceinline__ void atomic_add_i64(int64_t *p, double v) {
     atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)(long long)v);
 }
 
-// partial[g][k][j] += sum_{i in split} sig[g][i][k][j] * alpha[g][i][j]  (each product reduced to ~q/2).
-// grid.x covers the l*degree/4 columns, grid.y splits the N signatures of a group, grid.z = group.
-__global__ __launch_bounds__(kBlock) void aggregate_kernel(const int32_t *sig, const int32_t *alpha, int64_t *partial,
-                                                           size_t pstride, size_t N, int l, int degree, FzMod m) {
+// Two-pass, atomics-free aggregation (exact and deterministic):
+//   pass 1  split[g][s][k][j] = sum_{i in split s} sig[g][i][k][j] * alpha[g][i][j]   (fp64-lazy, each product
+//           reduced to ~q/2; |sum| < 2^53)  -- grid.x columns of 4 coefficients, grid.y splits, grid.z groups
+//   pass 2  partial[g][e] = sum_s split[g][s][e]  as int64 (for the cross-GPU all-reduce) or centred int32
+__global__ __launch_bounds__(kBlock) void aggregate_split_kernel(const int32_t *sig, const int32_t *alpha, double *split,
+                                                                 size_t N, int l, int degree, FzMod m) {
     const int d4 = degree / 4;
     const size_t cols = (size_t)l * d4;
     const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void aggregate_kernel(const int32_t *sig, c
     const size_t i0 = (size_t)blockIdx.y * per;
     const size_t i1 = (i0 + per < N) ? i0 + per : N;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll 4
+#pragma unroll 8
     for (size_t i = i0; i < i1; ++i) {
         int4 x = reinterpret_cast<const int4 *>(sig + i * (size_t)l * degree)[col];
         int4 a = reinterpret_cast<const int4 *>(alpha + i * (size_t)degree)[j4];
@@ -194,12 +196,22 @@ __global__ __launch_bounds__(kBlock) void aggregate_kernel(const int32_t *sig, c
         s2 += fz_mulmod((double)x.z, (double)a.z, m);
         s3 += fz_mulmod((double)x.w, (double)a.w, m);
     }
-    if (i1 > i0) {
-        int64_t *dst = partial + g * pstride + col * 4;
-        atomic_add_i64(dst + 0, s0);
-        atomic_add_i64(dst + 1, s1);
-        atomic_add_i64(dst + 2, s2);
-        atomic_add_i64(dst + 3, s3);
+    double2 *dst = reinterpret_cast<double2 *>(split + ((g * gridDim.y + blockIdx.y) * cols + col) * 4);
+    dst[0] = make_double2(s0, s1);
+    dst[1] = make_double2(s2, s3);
+}
+
+template <bool CENTRE>
+__global__ __launch_bounds__(kBlock) void sum_splits_kernel(const double *split, size_t splits, size_t count,
+                                                            int64_t *out64, size_t pstride, int32_t *out32, FzMod m) {
+    const size_t g = blockIdx.z;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const double *base = split + g * splits * count;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
+        double s = 0;
+        for (size_t t = 0; t < splits; ++t) s += base[t * count + e];
+        if (CENTRE) out32[g * count + e] = (int)fz_cent_wide(s, m);
+        else out64[g * pstride + e] = (int64_t)s;
     }
 }
 
@@ -351,19 +363,33 @@ static unsigned split_count(fz_ctx *ctx, size_t N, unsigned gx, size_t groups, s
     return (unsigned)want;
 }
 
-int fz_launch_aggregate_partial(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *partial, size_t pstride,
-                                size_t groups, size_t N, int l) {
+// out64 != nullptr: int64 partial sums at out64 + g*pstride; else centred int32 at out32 + g*l*degree
+int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *out64, size_t pstride,
+                        int32_t *out32, size_t groups, size_t N, int l) {
     if (ctx->degree < 4) return fz_set_error(FZ_E_UNSUPPORTED, "aggregate needs degree >= 4");
     if (groups == 0) return FZ_OK;
-    const size_t cols = (size_t)l * (ctx->degree / 4);
-    hipLaunchKernelGGL(zero_i64_kernel, dim3(grid_for(ctx, cols * 4, 1), 1, (unsigned)groups), dim3(kBlock), 0, ctx->stream,
-                       partial, pstride, cols * 4);
-    int rc = fz_check_hip(hipGetLastError(), "zero partial");
-    if (rc != FZ_OK || N == 0) return rc;
+    const size_t cols = (size_t)l * (ctx->degree / 4), count = cols * 4;
     const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(aggregate_kernel, dim3(gx, split_count(ctx, N, gx, groups, 8), (unsigned)groups), dim3(kBlock), 0,
-                       ctx->stream, sig, alpha, partial, pstride, N, l, ctx->degree, ctx->mod);
-    return fz_check_hip(hipGetLastError(), "aggregate launch");
+    // ~4 blocks per CU over all groups, at least 8 signatures per thread
+    size_t splits = ((size_t)ctx->num_cu * 4 + gx * groups - 1) / (gx * groups);
+    const size_t most = (N + 7) / 8;
+    if (splits > most) splits = most;
+    if (splits < 1) splits = 1;
+    void *scr = nullptr;
+    int rc = fz_scratch2(ctx, groups * splits * count * sizeof(double), &scr);
+    if (rc != FZ_OK) return rc;
+    hipLaunchKernelGGL(aggregate_split_kernel, dim3(gx, (unsigned)splits, (unsigned)groups), dim3(kBlock), 0, ctx->stream,
+                       sig, alpha, (double *)scr, N, l, ctx->degree, ctx->mod);
+    rc = fz_check_hip(hipGetLastError(), "aggregate launch");
+    if (rc != FZ_OK) return rc;
+    const dim3 grid2(grid_for(ctx, count, 2), 1, (unsigned)groups);
+    if (out64)
+        hipLaunchKernelGGL(sum_splits_kernel<false>, grid2, dim3(kBlock), 0, ctx->stream, (const double *)scr, splits, count,
+                           out64, pstride, (int32_t *)nullptr, ctx->mod);
+    else
+        hipLaunchKernelGGL(sum_splits_kernel<true>, grid2, dim3(kBlock), 0, ctx->stream, (const double *)scr, splits, count,
+                           (int64_t *)nullptr, (size_t)0, out32, ctx->mod);
+    return fz_check_hip(hipGetLastError(), "aggregate sum launch");
 }
 
 int fz_launch_target_partial(fz_ctx *ctx, const int32_t *vkL, const int32_t *vkR, const int32_t *c, const int32_t *alpha,

@@ -10,17 +10,19 @@ from oracle import oracle as O
 q = O.PRIME
 orc = O.COracle()
 variants = [16, 4]
-secpars = (256, 128)
+secpars = (256,)
+mults = [int(v) for v in sys.argv[1:]] or [1]
 for secpar in secpars:
     P = O.PARAMS[secpar]; d = P["d"]
-    for var in variants:
+    for var, mult in [(v, m) for v in variants for m in mults]:
         os.environ["FZ_NTT_KERNEL"] = str(var)
+        os.environ["FZ_NTT_GRID_MULT"] = str(mult)
         ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
         xs = O.splitmix_centered(9, 1003 * d).reshape(1003, d)
         ok = np.array_equal(ctx.ntt_forward(xs), orc.ntt_forward(xs, q, P["root"])) and \
             np.array_equal(ctx.ntt_inverse(xs), orc.ntt_inverse(xs, q, P["inv_root"]))
-        line = f"secpar={secpar} var={var} parity={'OK' if ok else 'FAIL'}"
-        for logB in (12, 14, 16, 20):
+        line = f"secpar={secpar} var={var} mult={mult} parity={'OK' if ok else 'FAIL'}"
+        for logB in (16, 18, 20):
             B = 1 << logB
             x = O.splitmix_centered(5, B * d).reshape(B, d)
             din = fusion_hip.DeviceBuffer.from_numpy(ctx, x)

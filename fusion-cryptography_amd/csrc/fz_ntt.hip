@@ -71,18 +71,6 @@ __device__ __forceinline__ void chunk_to_lds(int32_t *stage, int lane, const Chu
     *reinterpret_cast<int4 *>(stage + pad4(768 + 4 * lane)) = c.v3;
 }
 
-__device__ __forceinline__ void chunk_store(int32_t *out, size_t task, size_t total, int lane, const int32_t *stage) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const size_t off = task * kChunk + 256 * m + 4 * lane;
-        const int4 v = *reinterpret_cast<const int4 *>(stage + pad4(256 * m + 4 * lane));
-        if (off < total) *reinterpret_cast<int4 *>(out + off) = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// forward: strided pass -> transpose -> contiguous pass
-// ------------------------------------------------------------------------------------------
 // Wave-local synchronisation.  Every LDS exchange in these kernels is between lanes of ONE wave
 // (each wave owns a private staging region), and a wave's DS instructions execute in order, so no
 // s_barrier is needed: the release/acquire pair makes the compiler wait for the outstanding LDS
@@ -127,13 +115,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd16(const int32_t *
     const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave;
     const size_t stride = (size_t)gridDim.x * kWavesPerBlock;
     if (first >= tasks) return;
-    Chunk raw = chunk_load(in, first, total, lane);
+    // Software pipeline.  gfx9 has ONE in-order counter (vmcnt) for loads and stores, so a wait for a
+    // prefetched load also waits for every store issued before... and, at a loop header, the compiler must
+    // assume the worst over all entry paths.  Each iteration therefore (1) issues the NEXT chunk's loads
+    // first, (2) computes, (3) moves the finished outputs LDS -> registers, (4) waits for the prefetched
+    // chunk and stages it into LDS, and only then (5) issues the global stores: the stores are always the
+    // youngest outstanding operations and nothing waits for their completion until a whole iteration later.
+    {
+        const Chunk raw0 = chunk_load(in, first, total, lane);
+        chunk_to_lds(stage, lane, raw0);
+    }
 
     for (size_t task = first; task < tasks; task += stride) {
-        // stage the chunk, then prefetch the next task's chunk into registers (in flight during
-        // the whole compute phase)
-        chunk_to_lds(stage, lane, raw);
-        if (task + stride < tasks) raw = chunk_load(in, task + stride, total, lane);
+        const bool more = task + stride < tasks;
+        const Chunk raw = chunk_load(in, more ? task + stride : task, total, lane);   // unconditional: no divergent state
         wave_sync();
         double a[16];
         {
@@ -203,8 +198,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd16(const int32_t *
             *reinterpret_cast<int4 *>(stage + pad4(16 * lane + 4 * k)) = o;
         }
         wave_sync();
-        chunk_store(out, task, total, lane, stage);
-        wave_sync();   // the staging image is rewritten by the next task
+        const int4 o0 = *reinterpret_cast<const int4 *>(stage + pad4(4 * lane));
+        const int4 o1 = *reinterpret_cast<const int4 *>(stage + pad4(256 + 4 * lane));
+        const int4 o2 = *reinterpret_cast<const int4 *>(stage + pad4(512 + 4 * lane));
+        const int4 o3 = *reinterpret_cast<const int4 *>(stage + pad4(768 + 4 * lane));
+        wave_sync();
+        chunk_to_lds(stage, lane, raw);          // waits for the prefetched loads (no store is younger)
+        {
+            const size_t base = task * kChunk + 4 * lane;
+            if (base < total) *reinterpret_cast<int4 *>(out + base) = o0;
+            if (base + 256 < total) *reinterpret_cast<int4 *>(out + base + 256) = o1;
+            if (base + 512 < total) *reinterpret_cast<int4 *>(out + base + 512) = o2;
+            if (base + 768 < total) *reinterpret_cast<int4 *>(out + base + 768) = o3;
+        }
     }
 }
 
@@ -233,11 +239,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
     const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave;
     const size_t stride = (size_t)gridDim.x * kWavesPerBlock;
     if (first >= tasks) return;
-    Chunk raw = chunk_load(in, first, total, lane);
+    {
+        const Chunk raw0 = chunk_load(in, first, total, lane);
+        chunk_to_lds(stage, lane, raw0);
+    }
 
-    for (size_t task = first; task < tasks; task += stride) {
-        chunk_to_lds(stage, lane, raw);
-        if (task + stride < tasks) raw = chunk_load(in, task + stride, total, lane);
+    for (size_t task = first; task < tasks; task += stride) {       // pipeline: see ntt_fwd16
+        const bool more = task + stride < tasks;
+        const Chunk raw = chunk_load(in, more ? task + stride : task, total, lane);
         wave_sync();
         double a[16];
 #pragma unroll
@@ -303,8 +312,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
 #pragma unroll
         for (int k = 0; k < 16; ++k) stage[pad4(p * D + r + L * k)] = (int)fz_cent(a[k], m);
         wave_sync();
-        chunk_store(out, task, total, lane, stage);
+        const int4 o0 = *reinterpret_cast<const int4 *>(stage + pad4(4 * lane));
+        const int4 o1 = *reinterpret_cast<const int4 *>(stage + pad4(256 + 4 * lane));
+        const int4 o2 = *reinterpret_cast<const int4 *>(stage + pad4(512 + 4 * lane));
+        const int4 o3 = *reinterpret_cast<const int4 *>(stage + pad4(768 + 4 * lane));
         wave_sync();
+        chunk_to_lds(stage, lane, raw);
+        {
+            const size_t base = task * kChunk + 4 * lane;
+            if (base < total) *reinterpret_cast<int4 *>(out + base) = o0;
+            if (base + 256 < total) *reinterpret_cast<int4 *>(out + base + 256) = o1;
+            if (base + 512 < total) *reinterpret_cast<int4 *>(out + base + 512) = o2;
+            if (base + 768 < total) *reinterpret_cast<int4 *>(out + base + 768) = o3;
+        }
     }
 }
 
@@ -355,13 +375,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *i
         for (int k = 0; k < 4; ++k) xn[k] = src[k * LP];
     };
     fetch(first);
+    double an[4];                                // ... converted BEFORE this task's store is issued (see ntt_fwd16)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) an[k] = (double)xn[k];
     for (size_t task = first; task < tasks; task += stride) {
         const size_t poly = task * PPW + p;
         const bool valid = poly < batch;
+        const bool more = task + stride < tasks;
         double a[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = (double)xn[k];
-        if (task + stride < tasks) fetch(task + stride);
+        for (int k = 0; k < 4; ++k) a[k] = an[k];
+        if (more) fetch(task + stride);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int s = D >> (2 * i + 2);
@@ -397,14 +421,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *i
                 for (int k = 0; k < 4; ++k) region[swz4(base + k * s)] = a[k];
             }
         }
-        if (valid) {
-            int4 o;
-            o.x = (int)fz_cent(a[0], m);
-            o.y = (int)fz_cent(a[1], m);
-            o.z = (int)fz_cent(a[2], m);
-            o.w = (int)fz_cent(a[3], m);
-            *reinterpret_cast<int4 *>(out + poly * D + 4 * mm) = o;
+        int4 o;
+        o.x = (int)fz_cent(a[0], m);
+        o.y = (int)fz_cent(a[1], m);
+        o.z = (int)fz_cent(a[2], m);
+        o.w = (int)fz_cent(a[3], m);
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) an[k] = (double)xn[k];
         }
+        if (valid) *reinterpret_cast<int4 *>(out + poly * D + 4 * mm) = o;
         wave_sync();      // the next task's first-pass writes must not overtake this task's last reads
     }
 }
@@ -440,12 +466,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *i
         xn = *reinterpret_cast<const int4 *>(in + (poly < batch ? poly : batch - 1) * D + 4 * mm);
     };
     fetch(first);
+    double an[4] = {(double)xn.x, (double)xn.y, (double)xn.z, (double)xn.w};
     for (size_t task = first; task < tasks; task += stride) {
         const size_t poly = task * PPW + p;
         const bool valid = poly < batch;
-        double a[4];
-        a[0] = (double)xn.x; a[1] = (double)xn.y; a[2] = (double)xn.z; a[3] = (double)xn.w;
-        if (task + stride < tasks) fetch(task + stride);
+        const bool more = task + stride < tasks;
+        double a[4] = {an[0], an[1], an[2], an[3]};
+        if (more) fetch(task + stride);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int s = 1 << (2 * i);
@@ -490,10 +517,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *i
                 a[3] = LAST4 ? fz_mulmod4(u - v, twA.w1_n_inv, twA.w1_n_inv2, m) : fz_mulmod(u - v, twA.w1_n_inv, m);
             }
         }
+        int o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (int)fz_cent(a[k], m);
+        if (more) {
+            an[0] = (double)xn.x; an[1] = (double)xn.y; an[2] = (double)xn.z; an[3] = (double)xn.w;
+        }
         if (valid) {
             int32_t *dst = out + poly * D + mm;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dst[k * LP] = (int)fz_cent(a[k], m);
+            for (int k = 0; k < 4; ++k) dst[k * LP] = o[k];
         }
         wave_sync();
     }

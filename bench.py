@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sign-verify", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the large-batch runs of the same kernels")
+    ap.add_argument("--no-two-stream", action="store_true", help="skip the two-stream pipelined variant")
     ap.add_argument("--sample-every", type=int, default=8,
                     help="bind begin/end events to every k-th dispatch of each kernel inside the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the pure-Python baseline sample")
@@ -148,6 +149,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = 2.0 * B * args.steps * world / elapsed
+
+    # ---- the same steps pipelined over two HIP streams (independent batches overlap; informational) ----
+    two_stream = None
+    if rank == 0 and not args.no_two_stream:
+        s2 = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        c2 = [fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index) for _ in s2]
+        b2 = [(torch.empty_like(x), torch.empty_like(x)) for _ in s2]
+        for c_, s_ in zip(c2, s2):
+            c_.set_stream(s_.cuda_stream)
+        a2 = [(c_._h, xp, ctypes.c_void_p(y_.data_ptr()), ctypes.c_void_p(z_.data_ptr())) for c_, (y_, z_) in zip(c2, b2)]
+
+        def run2(k):
+            for i in range(k):
+                h_, xp_, yp_, zp_ = a2[i & 1]
+                fz_fwd(h_, xp_, yp_, nB)
+                fz_inv(h_, yp_, zp_, nB)
+        run2(args.warmup)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run2(args.steps)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        assert all(torch.equal(z_, x) for _, z_ in b2)
+        two_stream = {"value": 2.0 * B * args.steps / dt, "unit": "NTT/s", "ms_per_step": dt / args.steps * 1e3,
+                      "what": "the same K steps issued alternately on two HIP streams with private output buffers"}
+        for c_ in c2:
+            c_.close()
 
     # ---- host-pointer path (PCIe-inclusive; informational, never `value`) -----------------------
     pcie = None
@@ -306,7 +334,7 @@ def main():
                          "inverse_avg_launch_us": inv_avg * 1e3, "launches_timed": prof["fwd_count"],
                          "timing": f"hipExtLaunchKernelGGL start/stop events on every {args.sample_every}th dispatch inside the timed region",
                          "sweep": sweep},
-            "sign_verify": sv, "end_to_end": e2e, "pcie_inclusive": pcie,
+            "two_stream_pipelined": two_stream, "sign_verify": sv, "end_to_end": e2e, "pcie_inclusive": pcie,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

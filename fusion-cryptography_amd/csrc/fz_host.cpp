@@ -262,6 +262,59 @@ void parallel_for(size_t n, int threads, F f) {
     for (auto &th : pool) th.join();
 }
 
+// ---- CPython's `random` (MT19937) as the reference's samplers use it ------------------------------------
+// random.seed(int) -> init_by_array over the 32-bit little-endian words of |seed|
+// randrange(n)     -> _randbelow_with_getrandbits: k = n.bit_length(); draw getrandbits(k) until < n
+// getrandbits(k)   -> k <= 32: genrand_uint32() >> (32 - k)            (Modules/_randommodule.c)
+struct PyRandom {
+    uint32_t mt[624];
+    int idx;
+    void init_genrand(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    void seed(uint64_t value) {
+        uint32_t key[2] = {(uint32_t)value, (uint32_t)(value >> 32)};
+        const int len = key[1] ? 2 : 1;
+        init_genrand(19650218u);
+        int i = 1, j = 0;
+        for (int k = 624 > len ? 624 : len; k; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (++j >= len) j = 0;
+        }
+        for (int k = 623; k; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+        idx = 624;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; ++k) {
+                uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    uint32_t randbelow(uint32_t n) {          // 1 <= n < 2^32
+        int k = 0;
+        for (uint32_t t = n; t; t >>= 1) ++k;
+        uint32_t r = next() >> (32 - k);
+        while (r >= n) r = next() >> (32 - k);
+        return r;
+    }
+};
+
 bool params_ok(const fz_scheme_params *P) {
     return P && P->degree >= 2 && P->degree <= (1 << 16) && P->modulus >= 3 && P->secpar > 0 && P->omega_ch >= 1 &&
            P->omega_ag >= 1 && P->beta_ch >= 1 && P->beta_ag >= 1;
@@ -392,6 +445,51 @@ int fz_aggregation_coefficients(const fz_scheme_params *P, const int32_t *h_vk_l
             bad = 1;
     });
     return bad ? fz_set_error(FZ_E_BADARG, "Too few bytes to decode polynomial") : FZ_OK;
+}
+
+/* sample_polynomial_ntt_representation (algebra/polynomials.py:470-488) with an int seed:
+ * values randrange(q) - q//2 */
+int fz_sample_ntt_values(uint64_t seed, int64_t modulus, int degree, int32_t *h_out) {
+    if (!h_out || degree < 1 || modulus < 2 || modulus >= (1ll << 32)) return fz_set_error(FZ_E_BADARG, "bad argument");
+    PyRandom rng;
+    rng.seed(seed);
+    const int64_t shift = modulus / 2;
+    for (int j = 0; j < degree; ++j) h_out[j] = (int32_t)((int64_t)rng.randbelow((uint32_t)modulus) - shift);
+    return FZ_OK;
+}
+
+/* sample_polynomial_coefficient_representation (algebra/polynomials.py:436-467) with an int seed */
+int fz_sample_coefficients(uint64_t seed, int64_t modulus, int degree, int64_t norm_bound, int64_t weight_bound,
+                           int32_t *h_out) {
+    if (!h_out || degree < 1 || modulus < 2) return fz_set_error(FZ_E_BADARG, "bad argument");
+    PyRandom rng;
+    rng.seed(seed);
+    const int count = (int)std::max<int64_t>(0, std::min<int64_t>(degree, weight_bound));
+    const int64_t bound = std::max<int64_t>(0, std::min<int64_t>(modulus / 2, norm_bound));
+    if (count > 0 && (bound < 1 || bound >= (1ll << 32))) return fz_set_error(FZ_E_BADARG, "empty range for randrange()");
+    for (int j = 0; j < degree; ++j) h_out[j] = 0;
+    for (int j = 0; j < count; ++j) {
+        const int64_t mag = 1 + (int64_t)rng.randbelow((uint32_t)bound);
+        const int64_t sign = 1 - 2 * (int64_t)rng.randbelow(2);
+        h_out[j] = (int32_t)(mag * sign);
+    }
+    if (count < degree)
+        for (int i = degree - 1; i > 0; --i) std::swap(h_out[i], h_out[rng.randbelow((uint32_t)i + 1)]);
+    return FZ_OK;
+}
+
+/* the 2 distinct secret polynomials of keygen(params, seed) for N keys (fusion.py:339-362: every entry of a
+ * secret matrix is drawn with the same seed): h_out [N][2][degree] from seeds[i] and seeds[i] + 1 */
+int fz_sample_secret_polys(const uint64_t *h_seeds, size_t N, int64_t modulus, int degree, int64_t norm_bound,
+                           int64_t weight_bound, int32_t *h_out, int threads) {
+    if ((N && !h_seeds) || !h_out) return fz_set_error(FZ_E_BADARG, "NULL argument");
+    int bad = 0;
+    parallel_for(2 * N, threads, [&](size_t i) {
+        if (fz_sample_coefficients(h_seeds[i / 2] + (i & 1), modulus, degree, norm_bound, weight_bound,
+                                   h_out + i * (size_t)degree) != FZ_OK)
+            bad = 1;
+    });
+    return bad ? FZ_E_BADARG : FZ_OK;
 }
 
 }  // extern "C"

@@ -129,3 +129,29 @@ def aggregation_coefficients(P: SchemeParams, vk_left, vk_right, prehash, c_hat,
     if rc != 0:
         raise ValueError(lib.fz_last_error().decode())
     return out
+
+
+def sample_ntt_values(seed, modulus, degree):
+    """sample_polynomial_ntt_representation(...).values for a non-negative int seed"""
+    lib = load_library()
+    out = np.empty(degree, dtype=np.int32)
+    check(lib, lib.fz_sample_ntt_values(seed, modulus, degree, _p(out)))
+    return out
+
+
+def sample_coefficients(seed, modulus, degree, norm_bound, weight_bound):
+    """sample_polynomial_coefficient_representation(...).coefficients for a non-negative int seed"""
+    lib = load_library()
+    out = np.empty(degree, dtype=np.int32)
+    check(lib, lib.fz_sample_coefficients(seed, modulus, degree, norm_bound, weight_bound, _p(out)))
+    return out
+
+
+def sample_secret_polys(seeds, modulus, degree, norm_bound, weight_bound, threads=None):
+    """[N][2][degree]: the left (seed) and right (seed + 1) secret polynomial of each key"""
+    lib = load_library()
+    sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+    out = np.empty((sd.size, 2, degree), dtype=np.int32)
+    check(lib, lib.fz_sample_secret_polys(sd.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), sd.size, modulus, degree,
+                                          norm_bound, weight_bound, _p(out), threads or default_threads()))
+    return out

@@ -7,8 +7,6 @@ against the reference's golden arrays.
 Layouts: sk_hat [N][2][l][d] (left rows then right rows), vk [N][2][d], c_hat / alpha_hat [N][d],
 sig [N][l][d], aggregate [l][d]; all int32, centred.
 """
-import random
-
 import numpy as np
 
 from . import hostpipe
@@ -26,29 +24,16 @@ class BatchScheme:
         self.A = np.array([z.values for row in params.public_challenge.matrix for z in row], dtype=np.int32)
 
     # ---- keygen ------------------------------------------------------------------------------------
-    def sample_secret_rows(self, seed):
-        """The reference samples every entry of a secret matrix with the SAME seed (fusion.py:156-173), so
-        a matrix is one polynomial repeated l times: draw it once with the same `random` calls
-        (algebra/polynomials.py:447-459) and tile it."""
-        p = self.params
-        random.seed(seed)
-        count = max(0, min(p.degree, p.omega_sk))
-        bound = max(0, min(p.modulus // 2, p.beta_sk))
-        coefs = []
-        for _ in range(count):
-            magnitude = 1 + random.randrange(bound)
-            coefs.append(magnitude * (1 - 2 * random.randrange(2)))
-        coefs.extend([0] * (p.degree - count))
-        if count < p.degree:
-            for i in range(p.degree - 1, 0, -1):
-                j = random.randrange(i + 1)
-                coefs[i], coefs[j] = coefs[j], coefs[i]
-        # the reference re-seeds and re-draws l times; the global generator ends in the same state
-        return np.tile(np.array(coefs, dtype=np.int32), (self.l, 1))
-
     def keygen_batch(self, seeds):
-        """-> (sk_hat [N][2][l][d], vk [N][2][d]); key i equals keygen(params, seeds[i])."""
-        coef = np.stack([np.stack([self.sample_secret_rows(s), self.sample_secret_rows(s + 1)]) for s in seeds])
+        """-> (sk_hat [N][2][l][d], vk [N][2][d]); key i equals keygen(params, seeds[i]).
+        Sampling: the reference draws every entry of a secret matrix with the SAME seed (fusion.py:156-173),
+        so a matrix is one polynomial repeated l times; the polynomial itself comes from the C clone of
+        CPython's MT19937 `random` (hostpipe.sample_secret_polys, pinned against `random` in the tests).
+        Unlike the reference this does not leave the process-global `random` generator re-seeded."""
+        p = self.params
+        polys = hostpipe.sample_secret_polys([int(s) for s in seeds], p.modulus, p.degree, p.beta_sk, p.omega_sk,
+                                             self.threads)                       # [N][2][d]
+        coef = np.ascontiguousarray(np.broadcast_to(polys[:, :, None, :], (polys.shape[0], 2, self.l, self.d)))
         return self.ctx.keygen_core(self.A, coef)
 
     # ---- sign --------------------------------------------------------------------------------------

@@ -227,6 +227,16 @@ FZ_API int fz_aggregation_coefficients(const fz_scheme_params *P, const int32_t 
                                        const int32_t *h_vk_right, const uint8_t *h_prehash,
                                        const int32_t *h_c_hat, size_t N, int32_t *h_coefs, int threads);
 
+/* ---- reference-exact sampling on the host -----------------------------------------
+ * CPython's MT19937 `random` exactly as the reference's samplers drive it (random.seed(int), randrange):
+ * the same seed yields the same polynomial as algebra/polynomials.py:436-488.  Non-negative int seeds. */
+FZ_API int fz_sample_ntt_values(uint64_t seed, int64_t modulus, int degree, int32_t *h_out);
+FZ_API int fz_sample_coefficients(uint64_t seed, int64_t modulus, int degree, int64_t norm_bound,
+                                  int64_t weight_bound, int32_t *h_out);
+/* the two distinct secret polynomials of keygen(params, seed) for N keys: [N][2][degree] */
+FZ_API int fz_sample_secret_polys(const uint64_t *h_seeds, size_t N, int64_t modulus, int degree,
+                                  int64_t norm_bound, int64_t weight_bound, int32_t *h_out, int threads);
+
 #ifdef __cplusplus
 }
 #endif

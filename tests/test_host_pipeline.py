@@ -118,3 +118,33 @@ def test_reference_kats_through_c_pipeline(hp, kat, coracle):
                                          [r["message"] for r in rows])
     c_hat = coracle.ntt_forward(coefs, O.PRIME, O.PARAMS[128]["root"])
     assert c_hat.tolist() == [r["c_hat"] for r in rows]
+
+
+def test_sampler_clone_matches_cpython_random(hp, kat):
+    """C clone of CPython's MT19937 seeding + randrange against the drop-in samplers
+    (which call CPython's own `random`) and the reference's fusion_setup KAT rows."""
+    from algebra.polynomials import (sample_polynomial_coefficient_representation as samp_c,
+                                     sample_polynomial_ntt_representation as samp_n)
+    q = 2147465729
+    ring = dict(modulus=q, degree=256, root=3337519, inv_root=pow(3337519, q - 2, q), root_order=512)
+    for seed in (0, 1, 42, 2**31, 2**32 - 1, 2**32, 2**32 + 5, 2**40 + 12345, 2173728648):
+        assert hp.sample_ntt_values(seed, q, 256).tolist() == samp_n(**ring, seed=seed).values
+        assert hp.sample_coefficients(seed, q, 256, 52, 256).tolist() == \
+            samp_c(**ring, norm_bound=52, weight_bound=256, seed=seed).coefficients
+        # sparse case: exercises the Fisher-Yates shuffle
+        assert hp.sample_coefficients(seed, q, 256, 3, 60).tolist() == \
+            samp_c(**ring, norm_bound=3, weight_bound=60, seed=seed).coefficients
+    r64 = dict(modulus=q, degree=64, root=23584283, inv_root=pow(23584283, q - 2, q), root_order=128)
+    assert hp.sample_coefficients(7, q, 64, 52, 64).tolist() == samp_c(**r64, norm_bound=52, weight_bound=64, seed=7).coefficients
+    small = dict(modulus=65537, degree=1024, root=None, inv_root=None, root_order=2048)
+    from algebra.ntt import find_primitive_root
+    small["root"] = find_primitive_root(65537, 2048)
+    small["inv_root"] = pow(small["root"], 65535, 65537)
+    assert hp.sample_coefficients(123456789, 65537, 1024, 1000, 100).tolist() == \
+        samp_c(**small, norm_bound=1000, weight_bound=100, seed=123456789).coefficients
+    for row in kat["setup"]:                      # fusion_setup_KAT_{128,256}.csv
+        d = 64 if row["secpar"] == 128 else 256
+        assert hp.sample_ntt_values(row["seed"], q, d).tolist() == row["first_poly"]
+    polys = hp.sample_secret_polys([5, 2**32 - 1], q, 256, 52, 256, threads=2)
+    assert polys[1, 1].tolist() == samp_c(**ring, norm_bound=52, weight_bound=256, seed=2**32).coefficients
+    assert polys[0, 0].tolist() == samp_c(**ring, norm_bound=52, weight_bound=256, seed=5).coefficients

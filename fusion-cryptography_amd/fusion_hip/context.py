@@ -341,6 +341,34 @@ class DeviceBuffer:
             pass
 
 
+class DeviceArray:
+    """An int32/int64 array that lives in device memory (shape + owning DeviceBuffer): the device-resident
+    face of BatchScheme, so that keys and signatures do not cross PCIe between calls."""
+
+    def __init__(self, ctx, shape, dtype=np.int32):
+        self.ctx, self.shape, self.dtype = ctx, tuple(int(x) for x in shape), np.dtype(dtype)
+        self.buf = DeviceBuffer(ctx, max(1, int(np.prod(self.shape)) * self.dtype.itemsize))
+
+    @classmethod
+    def from_numpy(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr)
+        out = cls(ctx, arr.shape, arr.dtype)
+        if arr.size:
+            ctx.h2d(out.buf.ptr, arr)
+        return out
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        return self.ctx.d2h(out, self.buf.ptr) if out.size else out
+
+    def free(self):
+        self.buf.free()
+
+
 _CTX_CACHE = {}
 
 

@@ -10,7 +10,7 @@ sig [N][l][d], aggregate [l][d]; all int32, centred.
 import numpy as np
 
 from . import hostpipe
-from .context import VERDICT_REASONS, get_context
+from .context import DeviceArray, VERDICT_REASONS, get_context
 
 
 class BatchScheme:
@@ -24,8 +24,15 @@ class BatchScheme:
         self.A = np.array([z.values for row in params.public_challenge.matrix for z in row], dtype=np.int32)
 
     # ---- keygen ------------------------------------------------------------------------------------
-    def keygen_batch(self, seeds):
-        """-> (sk_hat [N][2][l][d], vk [N][2][d]); key i equals keygen(params, seeds[i]).
+    def _dev(self, a, shape):
+        """numpy array or DeviceArray -> (DeviceArray, owned?)"""
+        if isinstance(a, DeviceArray):
+            return a, False
+        return DeviceArray.from_numpy(self.ctx, np.ascontiguousarray(a, dtype=np.int32).reshape(shape)), True
+
+    def keygen_batch(self, seeds, device=False):
+        """-> (sk_hat [N][2][l][d], vk [N][2][d]); key i equals keygen(params, seeds[i]).  With device=True
+        sk_hat stays in device memory (a DeviceArray) -- vk always comes back (it is hashed on the host).
         Sampling: the reference draws every entry of a secret matrix with the SAME seed (fusion.py:156-173),
         so a matrix is one polynomial repeated l times; the polynomial itself comes from the C clone of
         CPython's MT19937 `random` (hostpipe.sample_secret_polys, pinned against `random` in the tests).
@@ -33,8 +40,22 @@ class BatchScheme:
         p = self.params
         polys = hostpipe.sample_secret_polys([int(s) for s in seeds], p.modulus, p.degree, p.beta_sk, p.omega_sk,
                                              self.threads)                       # [N][2][d]
-        coef = np.ascontiguousarray(np.broadcast_to(polys[:, :, None, :], (polys.shape[0], 2, self.l, self.d)))
-        return self.ctx.keygen_core(self.A, coef)
+        n = polys.shape[0]
+        coef = DeviceArray.from_numpy(self.ctx, np.broadcast_to(polys[:, :, None, :], (n, 2, self.l, self.d)))
+        dA = DeviceArray.from_numpy(self.ctx, self.A)
+        sk = DeviceArray(self.ctx, (n, 2, self.l, self.d))
+        vk = DeviceArray(self.ctx, (n, 2, self.d))
+        try:
+            self.ctx.keygen_core_dev(dA.ptr, coef.ptr, sk.ptr, vk.ptr, n, self.l)
+            vk_host = vk.numpy()
+            if device:
+                return sk, vk_host
+            out = sk.numpy()
+            sk.free()
+            return out, vk_host
+        finally:
+            for b in (coef, dA, vk):
+                b.free()
 
     # ---- sign --------------------------------------------------------------------------------------
     def challenges(self, vk, messages):
@@ -44,10 +65,26 @@ class BatchScheme:
                                                      np.ascontiguousarray(vk[:, 1]), messages, self.threads)
         return self.ctx.ntt_forward(coefs), pre
 
-    def sign_batch(self, sk_hat, vk, messages):
-        """-> sig [N][l][d]; row i equals sign(params, key_i, messages[i]).signature_hat"""
+    def sign_batch(self, sk_hat, vk, messages, device=False):
+        """-> sig [N][l][d]; row i equals sign(params, key_i, messages[i]).signature_hat.
+        sk_hat may be a numpy array or a DeviceArray; with device=True the signatures stay on the device."""
         c_hat, _ = self.challenges(vk, messages)
-        return self.ctx.sign_core(np.ascontiguousarray(sk_hat, dtype=np.int32).reshape(-1, 2, self.l, self.d), c_hat)
+        n = c_hat.shape[0]
+        dK, own = self._dev(sk_hat, (n, 2, self.l, self.d))
+        dC = DeviceArray.from_numpy(self.ctx, c_hat)
+        dS = DeviceArray(self.ctx, (n, self.l, self.d))
+        try:
+            self.ctx.sign_core_dev(dK.ptr, dC.ptr, dS.ptr, n, self.l)
+            if device:
+                self.ctx.synchronize()
+                return dS
+            out = dS.numpy()
+            dS.free()
+            return out
+        finally:
+            dC.free()
+            if own:
+                dK.free()
 
     # ---- aggregate / verify ----------------------------------------------------------------------------
     def _sorted_inputs(self, vk, messages):
@@ -62,10 +99,25 @@ class BatchScheme:
         return order, L, R, c_hat, self.ctx.ntt_forward(alpha)
 
     def aggregate(self, vk, messages, sig):
-        """-> aggregate [l][d] == aggregate(params, keys, messages, signatures).signature_hat"""
-        order, _, _, _, alpha_hat = self._sorted_inputs(vk, messages)
-        sig = np.ascontiguousarray(sig, dtype=np.int32).reshape(-1, self.l, self.d)[order]
-        return self.ctx.aggregate_core(sig, alpha_hat)
+        """-> aggregate [l][d] == aggregate(params, keys, messages, signatures).signature_hat.
+        sig may be a numpy array or a DeviceArray.  The aggregation coefficients are derived in sorted key
+        order (as the reference does) and scattered back to the callers' order: the aggregate is a sum, so
+        the signatures themselves never have to be permuted."""
+        order, _, _, _, alpha_sorted = self._sorted_inputs(vk, messages)
+        n = alpha_sorted.shape[0]
+        alpha = np.empty_like(alpha_sorted)
+        alpha[order] = alpha_sorted
+        dS, own = self._dev(sig, (n, self.l, self.d))
+        dA = DeviceArray.from_numpy(self.ctx, alpha)
+        dO = DeviceArray(self.ctx, (self.l, self.d))
+        try:
+            self.ctx.aggregate_core_dev(dS.ptr, dA.ptr, dO.ptr, n, self.l)
+            return dO.numpy()
+        finally:
+            dA.free()
+            dO.free()
+            if own:
+                dS.free()
 
     def verify(self, vk, messages, aggregate):
         """-> (bool, reason) with the reference's reason strings (fusion.py:680-728)"""

@@ -68,3 +68,27 @@ def test_batch_scheme_many_distinct_signers():
     agg_obj = F.aggregate(params, [k[1] for k in keys], [msgs[i] for i in sub], sigs)
     agg_arr = bs.aggregate(vk[sub], [msgs[i] for i in sub], sig[sub])
     assert np.array_equal(signature_from_object(params, agg_obj), agg_arr)
+
+
+def test_device_resident_path_equals_host_path():
+    """keys / signatures kept in device memory between calls (DeviceArray) give the same integers."""
+    import fusion.fusion as F
+    import fusion_hip
+    from fusion_hip.scheme import BatchScheme
+    params = F.fusion_setup(256, 5)
+    bs = BatchScheme(params, threads=4)
+    seeds = [900 + i for i in range(9)]
+    msgs = [f"m{i}" for i in range(9)]
+    sk_h, vk_h = bs.keygen_batch(seeds)
+    sk_d, vk_d = bs.keygen_batch(seeds, device=True)
+    assert isinstance(sk_d, fusion_hip.DeviceArray) and np.array_equal(vk_d, vk_h)
+    assert np.array_equal(sk_d.numpy(), sk_h)
+    sig_h = bs.sign_batch(sk_h, vk_h, msgs)
+    sig_d = bs.sign_batch(sk_d, vk_h, msgs, device=True)
+    assert np.array_equal(sig_d.numpy(), sig_h)
+    agg_h = bs.aggregate(vk_h, msgs, sig_h)
+    agg_d = bs.aggregate(vk_h, msgs, sig_d)
+    assert np.array_equal(agg_h, agg_d)
+    assert bs.verify(vk_h, msgs, agg_d) == (True, "")
+    sk_d.free()
+    sig_d.free()

@@ -36,22 +36,35 @@ const uint64_t RC[24] = {
     0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
     0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
     0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
 
-inline uint64_t rotl(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+// one round with every index a compile-time constant (theta, rho+pi, chi, iota)
+#define FZ_ROL(x, n) (((x) << (n)) | ((x) >> (64 - (n))))
+inline void keccak_round(uint64_t *a, uint64_t rc) {
+    const uint64_t c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20], c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21],
+                   c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22], c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23],
+                   c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
+    const uint64_t d0 = c4 ^ FZ_ROL(c1, 1), d1 = c0 ^ FZ_ROL(c2, 1), d2 = c1 ^ FZ_ROL(c3, 1), d3 = c2 ^ FZ_ROL(c4, 1),
+                   d4 = c3 ^ FZ_ROL(c0, 1);
+    // b[y][2x+3y] = rol(a[x][y] ^ d[x], r[x][y])
+    const uint64_t b00 = a[0] ^ d0, b01 = FZ_ROL(a[6] ^ d1, 44), b02 = FZ_ROL(a[12] ^ d2, 43), b03 = FZ_ROL(a[18] ^ d3, 21),
+                   b04 = FZ_ROL(a[24] ^ d4, 14);
+    const uint64_t b10 = FZ_ROL(a[3] ^ d3, 28), b11 = FZ_ROL(a[9] ^ d4, 20), b12 = FZ_ROL(a[10] ^ d0, 3),
+                   b13 = FZ_ROL(a[16] ^ d1, 45), b14 = FZ_ROL(a[22] ^ d2, 61);
+    const uint64_t b20 = FZ_ROL(a[1] ^ d1, 1), b21 = FZ_ROL(a[7] ^ d2, 6), b22 = FZ_ROL(a[13] ^ d3, 25),
+                   b23 = FZ_ROL(a[19] ^ d4, 8), b24 = FZ_ROL(a[20] ^ d0, 18);
+    const uint64_t b30 = FZ_ROL(a[4] ^ d4, 27), b31 = FZ_ROL(a[5] ^ d0, 36), b32 = FZ_ROL(a[11] ^ d1, 10),
+                   b33 = FZ_ROL(a[17] ^ d2, 15), b34 = FZ_ROL(a[23] ^ d3, 56);
+    const uint64_t b40 = FZ_ROL(a[2] ^ d2, 62), b41 = FZ_ROL(a[8] ^ d3, 55), b42 = FZ_ROL(a[14] ^ d4, 39),
+                   b43 = FZ_ROL(a[15] ^ d0, 41), b44 = FZ_ROL(a[21] ^ d1, 2);
+    a[0] = b00 ^ (~b01 & b02) ^ rc; a[1] = b01 ^ (~b02 & b03); a[2] = b02 ^ (~b03 & b04); a[3] = b03 ^ (~b04 & b00); a[4] = b04 ^ (~b00 & b01);
+    a[5] = b10 ^ (~b11 & b12); a[6] = b11 ^ (~b12 & b13); a[7] = b12 ^ (~b13 & b14); a[8] = b13 ^ (~b14 & b10); a[9] = b14 ^ (~b10 & b11);
+    a[10] = b20 ^ (~b21 & b22); a[11] = b21 ^ (~b22 & b23); a[12] = b22 ^ (~b23 & b24); a[13] = b23 ^ (~b24 & b20); a[14] = b24 ^ (~b20 & b21);
+    a[15] = b30 ^ (~b31 & b32); a[16] = b31 ^ (~b32 & b33); a[17] = b32 ^ (~b33 & b34); a[18] = b33 ^ (~b34 & b30); a[19] = b34 ^ (~b30 & b31);
+    a[20] = b40 ^ (~b41 & b42); a[21] = b41 ^ (~b42 & b43); a[22] = b42 ^ (~b43 & b44); a[23] = b43 ^ (~b44 & b40); a[24] = b44 ^ (~b40 & b41);
+}
 
 void keccak_f(uint64_t s[25]) {
-    for (int round = 0; round < 24; ++round) {
-        uint64_t c[5], d[5], b[25];
-        for (int x = 0; x < 5; ++x) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
-        for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ rotl(c[(x + 1) % 5], 1);
-        for (int i = 0; i < 25; ++i) s[i] ^= d[i % 5];
-        for (int x = 0; x < 5; ++x)
-            for (int y = 0; y < 5; ++y) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl(s[x + 5 * y], ROT[x + 5 * y]);
-        for (int y = 0; y < 5; ++y)
-            for (int x = 0; x < 5; ++x) s[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
-        s[0] ^= RC[round];
-    }
+    for (int round = 0; round < 24; ++round) keccak_round(s, RC[round]);
 }
 
 struct Sponge {
@@ -61,6 +74,16 @@ struct Sponge {
     void absorb(const uint8_t *p, size_t n) {
         uint8_t *st = reinterpret_cast<uint8_t *>(s);       // little-endian host (x86-64)
         while (n) {
+            if (pos == 0 && n >= rate) {                    // whole blocks: lane-wise XOR
+                for (size_t i = 0; i < rate / 8; ++i) {
+                    uint64_t w;
+                    memcpy(&w, p + 8 * i, 8);
+                    s[i] ^= w;
+                }
+                keccak_f(s);
+                p += rate; n -= rate;
+                continue;
+            }
             size_t take = std::min(n, rate - pos);
             for (size_t i = 0; i < take; ++i) st[pos + i] ^= p[i];
             pos += take; p += take; n -= take;

@@ -532,6 +532,11 @@ int fz_verify_with_target_batch(fz_ctx *ctx, const int32_t *d_A, const int32_t *
         FZ_HIP(hipMalloc((void **)&ctx->d_verdict, groups * sizeof(int)), "verdict alloc");
         ctx->verdict_cap = groups;
     }
+    if ((ctx->logd == 6 || ctx->logd == 8) && !getenv("FZ_VERIFY_UNFUSED")) {
+        // one launch: sigma read once (matvec + inverse transforms + norm/weight + verdict fused)
+        FZ_TRY(fz_launch_verify_fused(ctx, d_A, d_sig, d_target, groups, l, beta_vf, omega_vf, ctx->d_verdict));
+        return fz_memcpy_d2h(ctx, h_verdicts, ctx->d_verdict, groups * sizeof(int));
+    }
     char *base = (char *)d;
     int32_t *observed = (int32_t *)base, *coef = (int32_t *)(base + oC);
     int64_t *mx = (int64_t *)(base + oM);
@@ -541,6 +546,14 @@ int fz_verify_with_target_batch(fz_ctx *ctx, const int32_t *d_A, const int32_t *
     FZ_TRY(fz_launch_norm_weight(ctx, coef, rows, mx, wt));                       // fusion.py:722-727
     FZ_TRY(fz_launch_verdict(ctx, d_target, observed, mx, wt, groups, l, beta_vf, omega_vf, ctx->d_verdict));
     return fz_memcpy_d2h(ctx, h_verdicts, ctx->d_verdict, groups * sizeof(int));
+}
+
+int fz_verify_with_target_batch_async(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const int32_t *d_target,
+                                      size_t groups, int l, int64_t beta_vf, int64_t omega_vf, int *d_verdicts) {
+    FZ_REQUIRE(ctx && l >= 1 && groups >= 1 && groups <= 65535 && d_A && d_sig && d_target && d_verdicts, "bad argument");
+    if (ctx->logd != 6 && ctx->logd != 8)
+        return fz_set_error(FZ_E_UNSUPPORTED, "asynchronous verification needs the fused kernel (degree 64 or 256)");
+    return fz_launch_verify_fused(ctx, d_A, d_sig, d_target, groups, l, beta_vf, omega_vf, d_verdicts);
 }
 
 int fz_verify_with_target(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const int32_t *d_target, int l,

@@ -59,6 +59,9 @@ int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out);   // second, independent
 int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse);
 int fz_ntt_query_grid(fz_ctx *ctx);
 
+int fz_launch_verify_fused(fz_ctx *ctx, const int32_t *A, const int32_t *sig, const int32_t *target, size_t groups, int l,
+                           int64_t beta, int64_t omega, int *d_verdict);
+
 // launchers (fz_pointwise.hip)
 enum { FZ_OP_MUL = 0, FZ_OP_ADD = 1, FZ_OP_SUB = 2, FZ_OP_NEG = 3, FZ_OP_MULACC = 4 };
 int fz_launch_pw(fz_ctx *ctx, int op, const int32_t *a, const int32_t *b, int32_t *out, size_t count);

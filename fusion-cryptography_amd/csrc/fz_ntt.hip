@@ -435,6 +435,70 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *i
     }
 }
 
+// the log4(D) in-place passes of the radix-4 inverse on one lane's 4 values (bit-reversed positions
+// 4mm..4mm+3 in, natural positions mm + (D/4)k out, n^-1 applied, NOT yet centred)
+template <int LOGD, bool FAST>
+__device__ __forceinline__ void inv4_passes(double (&a)[4], double *region, const double2 (&twl)[LOGD / 2 - 1][3],
+                                            const FzTwA &twA, const FzMod &m, int mm) {
+    constexpr int P = LOGD / 2;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int s = 1 << (2 * i);
+        const int base = (mm / s) * 4 * s + mm % s;
+        if (i > 0) {
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = region[swz4(base + k * s)];
+        }
+        if (i < P - 1) {
+            // GS stage 2i (distance s, two twiddles) then stage 2i+1 (distance 2s, one twiddle);
+            // operands stay below 2^(33+2i+1) <= 2^38
+            double u = a[0], v = a[1];
+            a[0] = u + v; a[1] = tw_mul<FAST>(u - v, twl[i][0].x, twl[i][0].y, m);
+            u = a[2]; v = a[3];
+            a[2] = u + v; a[3] = tw_mul<FAST>(u - v, twl[i][1].x, twl[i][1].y, m);
+            u = a[0]; v = a[2];
+            a[0] = u + v; a[2] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
+            u = a[1]; v = a[3];
+            a[1] = u + v; a[3] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
+            if (s == 1) {
+                *reinterpret_cast<double2 *>(region + swz4(base)) = make_double2(a[0], a[1]);
+                *reinterpret_cast<double2 *>(region + swz4(base + 2)) = make_double2(a[2], a[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) region[swz4(base + k * s)] = a[k];
+            }
+        } else {
+            // last pass: uniform twiddles itw[2], itw[3], itw[1]; n^-1 folded into the final stage.
+            // With raw int32 inputs the operands of the final stage reach 2^(31+LOGD): beyond the 4-op
+            // multiply's 2^38 bound for degree 256, so that stage uses the general 6-op form.
+            constexpr bool LAST4 = FAST && (31 + LOGD <= 38);
+            double u = a[0], v = a[1];
+            a[0] = u + v; a[1] = tw_mul<FAST>(u - v, twA.w[2], twA.w2[2], m);
+            u = a[2]; v = a[3];
+            a[2] = u + v; a[3] = tw_mul<FAST>(u - v, twA.w[3], twA.w2[3], m);
+            u = a[0]; v = a[2];
+            a[0] = LAST4 ? fz_mulmod4(u + v, twA.n_inv, twA.n_inv2, m) : fz_mulmod(u + v, twA.n_inv, m);
+            a[2] = LAST4 ? fz_mulmod4(u - v, twA.w1_n_inv, twA.w1_n_inv2, m) : fz_mulmod(u - v, twA.w1_n_inv, m);
+            u = a[1]; v = a[3];
+            a[1] = LAST4 ? fz_mulmod4(u + v, twA.n_inv, twA.n_inv2, m) : fz_mulmod(u + v, twA.n_inv, m);
+            a[3] = LAST4 ? fz_mulmod4(u - v, twA.w1_n_inv, twA.w1_n_inv2, m) : fz_mulmod(u - v, twA.w1_n_inv, m);
+        }
+    }
+}
+
+template <int LOGD>
+__device__ __forceinline__ void inv4_load_twiddles(double2 (&twl)[LOGD / 2 - 1][3], const double2 *__restrict__ itw2, int mm) {
+    constexpr int D = 1 << LOGD, P = LOGD / 2;
+#pragma unroll
+    for (int i = 0; i < P - 1; ++i) {
+        const int s = 1 << (2 * i), g = mm / s;
+        twl[i][0] = itw2[D / (2 * s) + 2 * g];
+        twl[i][1] = itw2[D / (2 * s) + 2 * g + 1];
+        twl[i][2] = itw2[D / (4 * s) + g];
+    }
+}
+
 template <int LOGD, bool FAST>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *in, int32_t *out, size_t batch,
                                                                 const double2 *__restrict__ itw2, FzTwA twA, FzMod m) {
@@ -452,13 +516,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *i
 
     // per-lane twiddles of passes 0..P-2 (the last pass is wave-uniform)
     double2 twl[P - 1][3];
-#pragma unroll
-    for (int i = 0; i < P - 1; ++i) {
-        const int s = 1 << (2 * i), g = mm / s;
-        twl[i][0] = itw2[D / (2 * s) + 2 * g];
-        twl[i][1] = itw2[D / (2 * s) + 2 * g + 1];
-        twl[i][2] = itw2[D / (4 * s) + g];
-    }
+    inv4_load_twiddles<LOGD>(twl, itw2, mm);
 
     int4 xn;
     auto fetch = [&](size_t task) {
@@ -473,50 +531,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *i
         const bool more = task + stride < tasks;
         double a[4] = {an[0], an[1], an[2], an[3]};
         if (more) fetch(task + stride);
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const int s = 1 << (2 * i);
-            const int base = (mm / s) * 4 * s + mm % s;
-            if (i > 0) {
-                wave_sync();
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] = region[swz4(base + k * s)];
-            }
-            if (i < P - 1) {
-                // GS stage 2i (distance s, two twiddles) then stage 2i+1 (distance 2s, one twiddle);
-                // operands stay below 2^(33+2i+1) <= 2^38
-                double u = a[0], v = a[1];
-                a[0] = u + v; a[1] = tw_mul<FAST>(u - v, twl[i][0].x, twl[i][0].y, m);
-                u = a[2]; v = a[3];
-                a[2] = u + v; a[3] = tw_mul<FAST>(u - v, twl[i][1].x, twl[i][1].y, m);
-                u = a[0]; v = a[2];
-                a[0] = u + v; a[2] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
-                u = a[1]; v = a[3];
-                a[1] = u + v; a[3] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
-                if (s == 1) {
-                    *reinterpret_cast<double2 *>(region + swz4(base)) = make_double2(a[0], a[1]);
-                    *reinterpret_cast<double2 *>(region + swz4(base + 2)) = make_double2(a[2], a[3]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) region[swz4(base + k * s)] = a[k];
-                }
-            } else {
-                // last pass: uniform twiddles itw[2], itw[3], itw[1]; n^-1 folded into the final stage.
-                // With raw int32 inputs the operands of the final stage reach 2^(31+LOGD): beyond the 4-op
-                // multiply's 2^38 bound for degree 256, so that stage uses the general 6-op form.
-                constexpr bool LAST4 = FAST && (31 + LOGD <= 38);
-                double u = a[0], v = a[1];
-                a[0] = u + v; a[1] = tw_mul<FAST>(u - v, twA.w[2], twA.w2[2], m);
-                u = a[2]; v = a[3];
-                a[2] = u + v; a[3] = tw_mul<FAST>(u - v, twA.w[3], twA.w2[3], m);
-                u = a[0]; v = a[2];
-                a[0] = LAST4 ? fz_mulmod4(u + v, twA.n_inv, twA.n_inv2, m) : fz_mulmod(u + v, twA.n_inv, m);
-                a[2] = LAST4 ? fz_mulmod4(u - v, twA.w1_n_inv, twA.w1_n_inv2, m) : fz_mulmod(u - v, twA.w1_n_inv, m);
-                u = a[1]; v = a[3];
-                a[1] = LAST4 ? fz_mulmod4(u + v, twA.n_inv, twA.n_inv2, m) : fz_mulmod(u + v, twA.n_inv, m);
-                a[3] = LAST4 ? fz_mulmod4(u - v, twA.w1_n_inv, twA.w1_n_inv2, m) : fz_mulmod(u - v, twA.w1_n_inv, m);
-            }
-        }
+        inv4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
         int o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = (int)fz_cent(a[k], m);
@@ -529,6 +544,84 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *i
             for (int k = 0; k < 4; ++k) dst[k * LP] = o[k];
         }
         wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused verification of one aggregate per workgroup (fusion/fusion.py:690-727): sigma is read ONCE.
+// While a row of sigma is in registers it feeds both (a) observed += A[k] (.) sigma[k] and (b) the radix-4
+// inverse transform, whose centred outputs are only reduced (max |x| per aggregate, weight per row) and
+// never stored.  Then observed is compared with the target and the reference's verdict order applied
+// (target mismatch, norm, weight).  16 waves per workgroup share the l rows.
+// ------------------------------------------------------------------------------------------
+constexpr int kVerifyWaves = 16;
+
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t *A, const int32_t *sig,
+                                                                  const int32_t *target, int l, long long beta,
+                                                                  long long omega, const double2 *__restrict__ itw2,
+                                                                  FzTwA twA, FzMod m, int *verdict) {
+    constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
+    __shared__ __attribute__((aligned(16))) double lds[kVerifyWaves * 256 * 2];
+    __shared__ int s_flags;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = lane / LP, mm = lane % LP;
+    double *region = lds + wave * 256 + p * D;
+    double *accbuf = lds + kVerifyWaves * 256;
+    if (threadIdx.x == 0) s_flags = 0;
+    sig += (size_t)blockIdx.x * l * D;
+    target += (size_t)blockIdx.x * D;
+
+    double2 twl[LOGD / 2 - 1][3];
+    inv4_load_twiddles<LOGD>(twl, itw2, mm);
+
+    double acc[4] = {0, 0, 0, 0};
+    int mx = 0, wfail = 0;
+    const int tasks = (l + PPW - 1) / PPW;
+    for (int task = wave; task < tasks; task += kVerifyWaves) {
+        const int row = task * PPW + p;
+        const bool valid = row < l;
+        const size_t off = (size_t)(valid ? row : l - 1) * D + 4 * mm;
+        const int4 x = *reinterpret_cast<const int4 *>(sig + off);
+        const int4 ak = *reinterpret_cast<const int4 *>(A + off);
+        double a[4] = {(double)x.x, (double)x.y, (double)x.z, (double)x.w};
+        if (valid) {
+            acc[0] += fz_mulmod(a[0], (double)ak.x, m);
+            acc[1] += fz_mulmod(a[1], (double)ak.y, m);
+            acc[2] += fz_mulmod(a[2], (double)ak.z, m);
+            acc[3] += fz_mulmod(a[3], (double)ak.w, m);
+        }
+        inv4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = (int)fz_cent(a[k], m);          // canonical: zero mod q <=> 0
+            const int ao = o < 0 ? -o : o;
+            if (valid) mx = ao > mx ? ao : mx;
+            cnt += (o != 0) ? 1 : 0;
+        }
+#pragma unroll
+        for (int w = 1; w < LP; w <<= 1) cnt += __shfl_xor(cnt, w);       // weight of this lane group's row
+        if (valid && (long long)cnt > omega) wfail = 1;
+        wave_sync();      // the next row's first-pass writes must not overtake this row's last reads
+    }
+    // partial products of this wave, indexed by (row slot p, position)
+    double *mine = accbuf + wave * 256 + p * D + 4 * mm;
+    mine[0] = acc[0]; mine[1] = acc[1]; mine[2] = acc[2]; mine[3] = acc[3];
+    if ((long long)mx > beta) atomicOr(&s_flags, 2);
+    if (wfail) atomicOr(&s_flags, 4);
+    __syncthreads();
+    if (threadIdx.x < D) {
+        double sum = 0;
+        for (int w = 0; w < kVerifyWaves; ++w)
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) sum += accbuf[w * 256 + q * D + threadIdx.x];
+        if ((int)fz_cent(sum, m) != target[threadIdx.x]) atomicOr(&s_flags, 1);   // both centred: equal <=> equal mod q
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int f = s_flags;
+        verdict[blockIdx.x] = (f & 1) ? FZ_VERDICT_TARGET_MISMATCH : ((f & 2) ? FZ_VERDICT_NORM : ((f & 4) ? FZ_VERDICT_WEIGHT : FZ_VERDICT_OK));
     }
 }
 
@@ -687,6 +780,18 @@ int query16(fz_ctx *ctx) {
 }
 
 }  // namespace
+
+int fz_launch_verify_fused(fz_ctx *ctx, const int32_t *A, const int32_t *sig, const int32_t *target, size_t groups, int l,
+                           int64_t beta, int64_t omega, int *d_verdict) {
+    const dim3 grid((unsigned)groups), block(64 * kVerifyWaves);
+#define FZ_VF(LOGD, FAST) hipLaunchKernelGGL((verify_fused<LOGD, FAST>), grid, block, 0, ctx->stream, A, sig, target, l, \
+                                             (long long)beta, (long long)omega, (const double2 *)ctx->d_itw2, ctx->itwA, ctx->mod, d_verdict)
+    if (ctx->logd == 8) { if (ctx->mod.fast) FZ_VF(8, true); else FZ_VF(8, false); }
+    else if (ctx->logd == 6) { if (ctx->mod.fast) FZ_VF(6, true); else FZ_VF(6, false); }
+    else return fz_set_error(FZ_E_UNSUPPORTED, "fused verify: degree 64 or 256 only");
+#undef FZ_VF
+    return fz_check_hip(hipGetLastError(), "verify_fused launch");
+}
 
 int fz_ntt_query_grid(fz_ctx *ctx) {
     switch (ctx->logd) {

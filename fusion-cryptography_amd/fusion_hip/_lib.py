@@ -71,6 +71,8 @@ SIGNATURES = {
     "fz_target_partial_batch": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t]),
     "fz_verify_with_target_batch": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int64, c_int64,
                                             POINTER(c_int)]),
+    "fz_verify_with_target_batch_async": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int64, c_int64,
+                                                  c_void_p]),
     "fz_target_partial": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fz_reduce_i64": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
     "fz_verify_core": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -167,6 +167,11 @@ class Context:
                                                                c_void_p(d_target), groups, l, beta_vf, omega_vf, v))
         return list(v)
 
+    def verify_with_target_batch_async_dev(self, d_A, d_sig, d_target, groups, l, beta_vf, omega_vf, d_verdicts):
+        check(self._lib, self._lib.fz_verify_with_target_batch_async(self._h, c_void_p(d_A), c_void_p(d_sig),
+                                                                     c_void_p(d_target), groups, l, beta_vf,
+                                                                     omega_vf, c_void_p(d_verdicts)))
+
     def reduce_i64_dev(self, d_in, d_out, count):
         check(self._lib, self._lib.fz_reduce_i64(self._h, c_void_p(d_in), c_void_p(d_out), count))
 

@@ -176,6 +176,12 @@ FZ_API int fz_verify_with_target_batch(fz_ctx *ctx, const int32_t *d_A, const in
                                        const int32_t *d_target, size_t groups, int l,
                                        int64_t beta_vf, int64_t omega_vf, int *h_verdicts);
 
+/* the same without the device-to-host copy: verdict codes are written to d_verdicts [groups] on the context's
+ * stream and nothing is synchronised (pipelined verification; degree 64 or 256) */
+FZ_API int fz_verify_with_target_batch_async(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig,
+                                             const int32_t *d_target, size_t groups, int l,
+                                             int64_t beta_vf, int64_t omega_vf, int *d_verdicts);
+
 /* ---- norm / weight of coefficient rows -------------------------------------------------------
  * PolynomialCoefficientRepresentation.norm("infty") / weight(), algebra/polynomials.py:221-227:
  * max |x| over the STORED values and #{x : x mod q != 0}, per row. */

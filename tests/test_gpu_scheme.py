@@ -172,3 +172,36 @@ def test_batched_aggregate_target_verify(coracle):
     ctx.h2d(d_red.ptr, bad)
     assert ctx.verify_with_target_batch_dev(d_A.ptr, d_red.ptr, d_red.ptr + n_agg * 4, G, l, P["beta_vf"], d) == [0, 3, 0]
     assert ctx.verify_with_target_batch_dev(d_A.ptr, d_red.ptr, d_red.ptr + n_agg * 4, G, l, 1, d) == [4, 3, 4]
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_fused_verify_equals_unfused_path(secpar, coracle, monkeypatch):
+    """verify_fused (sigma read once) vs the four-kernel path (FZ_VERIFY_UNFUSED=1) vs the oracle, on every
+    verdict branch, with non-centred raw int32 rows in the aggregate as well."""
+    import fusion_hip
+    P = O.PARAMS[secpar]
+    q, d, l = P["q"], P["d"], P["rank"]
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    rng = np.random.default_rng(secpar + 9)
+    N = 5
+    A = O.splitmix_centered(8, l * d).reshape(l, d)
+    coef = rng.integers(-52, 53, size=(N, 2, l, d)).astype(np.int32)
+    sk, vk = ctx.keygen_core(A, coef)
+    c = np.zeros((N, d), np.int32)
+    for i in range(N):
+        c[i, rng.choice(d, P["omega_ch"], replace=False)] = rng.choice([-1, 1], P["omega_ch"])
+    c_hat, al_hat = ctx.ntt_forward(c), ctx.ntt_forward(np.roll(c, 2, axis=1))
+    agg = ctx.aggregate_core(ctx.sign_core(sk, c_hat), al_hat)
+    cases = [(agg, P["beta_vf"], d), (agg, 1, d), (agg, P["beta_vf"], 1)]
+    bad = agg.copy()
+    bad[l - 1, d - 1] += 1
+    cases.append((bad, P["beta_vf"], d))
+    raw = rng.integers(-2**31, 2**31, size=(l, d), dtype=np.int64).astype(np.int32)   # arbitrary int32 "aggregate"
+    cases += [(raw, P["beta_vf"], d), (raw, 2**31, d)]
+    for sigma, beta, omega in cases:
+        want = coracle.verify_core(A, sigma, vk[:, 0], vk[:, 1], c_hat, al_hat, q, P["inv_root"], beta, omega)
+        monkeypatch.delenv("FZ_VERIFY_UNFUSED", raising=False)
+        fused = ctx.verify_core(A, sigma, vk[:, 0], vk[:, 1], c_hat, al_hat, beta, omega)
+        monkeypatch.setenv("FZ_VERIFY_UNFUSED", "1")
+        unfused = ctx.verify_core(A, sigma, vk[:, 0], vk[:, 1], c_hat, al_hat, beta, omega)
+        assert fused == unfused == want, (beta, omega)

@@ -448,6 +448,10 @@ int fz_keygen_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef, int32
                    size_t batch, int l) {
     FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (d_A && d_coef && d_sk_hat && d_vk)), "bad argument");
     // sk_hat = NTT(every secret row); vk_{L,R} = A . sk_hat_{L,R}   (fusion/fusion.py:363-370)
+    if (batch == 0) return FZ_OK;
+    if ((ctx->logd == 6 || ctx->logd == 8) && batch * 2 <= 0x7fffffffu && !getenv("FZ_KEYGEN_UNFUSED") &&
+        ((((uintptr_t)d_A | (uintptr_t)d_coef | (uintptr_t)d_sk_hat) & 15) == 0))
+        return fz_launch_keygen_fused(ctx, d_A, d_coef, d_sk_hat, d_vk, batch * 2, l);   // one launch, sk_hat not re-read
     FZ_TRY(fz_launch_ntt(ctx, d_coef, d_sk_hat, batch * 2 * (size_t)l, false));
     return fz_launch_matvec(ctx, d_A, d_sk_hat, d_vk, batch * 2, l);
 }

@@ -59,6 +59,8 @@ int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out);   // second, independent
 int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse);
 int fz_ntt_query_grid(fz_ctx *ctx);
 
+int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,
+                           int l);
 int fz_launch_verify_fused(fz_ctx *ctx, const int32_t *A, const int32_t *sig, const int32_t *target, size_t groups, int l,
                            int64_t beta, int64_t omega, int *d_verdict);
 

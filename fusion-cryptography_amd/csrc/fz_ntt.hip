@@ -342,6 +342,61 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz4(int j) { return j ^ (((j >> 4) & 7) << 2); }
 
+// the log4(D) in-place passes of the radix-4 forward transform on one lane's 4 values (natural positions
+// mm + (D/4)k in, bit-reversed-order positions 4mm..4mm+3 out, NOT yet centred)
+template <int LOGD, bool FAST>
+__device__ __forceinline__ void fwd4_passes(double (&a)[4], double *region, const double2 (&twl)[LOGD / 2 - 1][3],
+                                            const FzTwA &twA, const FzMod &m, int mm) {
+    constexpr int D = 1 << LOGD, P = LOGD / 2;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int s = D >> (2 * i + 2);
+        const int base = (mm / s) * 4 * s + mm % s;
+        double wA, wA2, wB0, wB02, wB1, wB12;
+        if (i == 0) {
+            wA = twA.w[1]; wA2 = twA.w2[1]; wB0 = twA.w[2]; wB02 = twA.w2[2]; wB1 = twA.w[3]; wB12 = twA.w2[3];
+        } else {
+            wA = twl[i - 1][0].x; wA2 = twl[i - 1][0].y;
+            wB0 = twl[i - 1][1].x; wB02 = twl[i - 1][1].y;
+            wB1 = twl[i - 1][2].x; wB12 = twl[i - 1][2].y;
+            wave_sync();
+            if (s == 1) {
+                const double2 lo = *reinterpret_cast<const double2 *>(region + swz4(base));
+                const double2 hi = *reinterpret_cast<const double2 *>(region + swz4(base + 2));
+                a[0] = lo.x; a[1] = lo.y; a[2] = hi.x; a[3] = hi.y;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = region[swz4(base + k * s)];
+            }
+        }
+        // stage 2i: distance 2s, one twiddle; stage 2i+1: distance s, two twiddles
+        double v = tw_mul<FAST>(a[2], wA, wA2, m), u = a[0];
+        a[0] = u + v; a[2] = u - v;
+        v = tw_mul<FAST>(a[3], wA, wA2, m); u = a[1];
+        a[1] = u + v; a[3] = u - v;
+        v = tw_mul<FAST>(a[1], wB0, wB02, m); u = a[0];
+        a[0] = u + v; a[1] = u - v;
+        v = tw_mul<FAST>(a[3], wB1, wB12, m); u = a[2];
+        a[2] = u + v; a[3] = u - v;
+        if (i < P - 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) region[swz4(base + k * s)] = a[k];
+        }
+    }
+}
+
+template <int LOGD>
+__device__ __forceinline__ void fwd4_load_twiddles(double2 (&twl)[LOGD / 2 - 1][3], const double2 *__restrict__ tw2, int mm) {
+    constexpr int D = 1 << LOGD, P = LOGD / 2;
+#pragma unroll
+    for (int i = 1; i < P; ++i) {
+        const int s = D >> (2 * i + 2), g = mm / s, pw = 1 << (2 * i);
+        twl[i - 1][0] = tw2[pw + g];
+        twl[i - 1][1] = tw2[2 * pw + 2 * g];
+        twl[i - 1][2] = tw2[2 * pw + 2 * g + 1];
+    }
+}
+
 template <int LOGD, bool FAST>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *in, int32_t *out, size_t batch,
                                                                 const double2 *__restrict__ tw2, FzTwA twA, FzMod m) {
@@ -359,13 +414,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *i
 
     // per-lane twiddles of passes 1..P-1 (independent of the data: issued before the first load returns)
     double2 twl[P - 1][3];
-#pragma unroll
-    for (int i = 1; i < P; ++i) {
-        const int s = D >> (2 * i + 2), g = mm / s, pw = 1 << (2 * i);
-        twl[i - 1][0] = tw2[pw + g];
-        twl[i - 1][1] = tw2[2 * pw + 2 * g];
-        twl[i - 1][2] = tw2[2 * pw + 2 * g + 1];
-    }
+    fwd4_load_twiddles<LOGD>(twl, tw2, mm);
 
     int xn[4];                                   // next task's coefficients, in flight during the passes
     auto fetch = [&](size_t task) {
@@ -386,41 +435,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *i
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = an[k];
         if (more) fetch(task + stride);
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const int s = D >> (2 * i + 2);
-            const int base = (mm / s) * 4 * s + mm % s;
-            double wA, wA2, wB0, wB02, wB1, wB12;
-            if (i == 0) {
-                wA = twA.w[1]; wA2 = twA.w2[1]; wB0 = twA.w[2]; wB02 = twA.w2[2]; wB1 = twA.w[3]; wB12 = twA.w2[3];
-            } else {
-                wA = twl[i - 1][0].x; wA2 = twl[i - 1][0].y;
-                wB0 = twl[i - 1][1].x; wB02 = twl[i - 1][1].y;
-                wB1 = twl[i - 1][2].x; wB12 = twl[i - 1][2].y;
-                wave_sync();
-                if (s == 1) {
-                    const double2 lo = *reinterpret_cast<const double2 *>(region + swz4(base));
-                    const double2 hi = *reinterpret_cast<const double2 *>(region + swz4(base + 2));
-                    a[0] = lo.x; a[1] = lo.y; a[2] = hi.x; a[3] = hi.y;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) a[k] = region[swz4(base + k * s)];
-                }
-            }
-            // stage 2i: distance 2s, one twiddle; stage 2i+1: distance s, two twiddles
-            double v = tw_mul<FAST>(a[2], wA, wA2, m), u = a[0];
-            a[0] = u + v; a[2] = u - v;
-            v = tw_mul<FAST>(a[3], wA, wA2, m); u = a[1];
-            a[1] = u + v; a[3] = u - v;
-            v = tw_mul<FAST>(a[1], wB0, wB02, m); u = a[0];
-            a[0] = u + v; a[1] = u - v;
-            v = tw_mul<FAST>(a[3], wB1, wB12, m); u = a[2];
-            a[2] = u + v; a[3] = u - v;
-            if (i < P - 1) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) region[swz4(base + k * s)] = a[k];
-            }
-        }
+        fwd4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
         int4 o;
         o.x = (int)fz_cent(a[0], m);
         o.y = (int)fz_cent(a[1], m);
@@ -544,6 +559,71 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *i
             for (int k = 0; k < 4; ++k) dst[k * LP] = o[k];
         }
         wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused keygen arithmetic (fusion/fusion.py:363-370), one workgroup per (key, half): every secret row is
+// transformed (radix-4 forward), written to sk_hat, and -- while still in registers -- multiplied by the
+// matching row of the public challenge A and accumulated; the l partial products are reduced through LDS
+// into the verification-key row.  sk_hat is never re-read: 342 KB of HBM traffic per key instead of 508 KB.
+// ------------------------------------------------------------------------------------------
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_t *A, const int32_t *coef, int32_t *sk_hat,
+                                                                    int32_t *vk, int l, const double2 *__restrict__ tw2,
+                                                                    FzTwA twA, FzMod m) {
+    constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
+    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256 * 2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = lane / LP, mm = lane % LP;
+    double *region = lds + wave * 256 + p * D;
+    double *accbuf = lds + kWavesPerBlock * 256;
+    const size_t seg = blockIdx.x;                      // (key, half)
+    coef += seg * (size_t)l * D;
+    sk_hat += seg * (size_t)l * D;
+
+    double2 twl[LOGD / 2 - 1][3];
+    fwd4_load_twiddles<LOGD>(twl, tw2, mm);
+
+    double acc[4] = {0, 0, 0, 0};
+    const int tasks = (l + PPW - 1) / PPW;
+    int xn[4];
+    auto fetch = [&](int task) {
+        const int row = task * PPW + p;
+        const int32_t *src = coef + (size_t)(row < l ? row : l - 1) * D + mm;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xn[k] = src[k * LP];
+    };
+    if (wave < tasks) fetch(wave);
+    for (int task = wave; task < tasks; task += kWavesPerBlock) {
+        const int row = task * PPW + p;
+        const bool valid = row < l;
+        double a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = (double)xn[k];
+        const int4 ak = *reinterpret_cast<const int4 *>(A + (size_t)(valid ? row : l - 1) * D + 4 * mm);
+        if (task + kWavesPerBlock < tasks) fetch(task + kWavesPerBlock);
+        fwd4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
+        const double y0 = fz_cent(a[0], m), y1 = fz_cent(a[1], m), y2 = fz_cent(a[2], m), y3 = fz_cent(a[3], m);
+        if (valid) {
+            *reinterpret_cast<int4 *>(sk_hat + (size_t)row * D + 4 * mm) = make_int4((int)y0, (int)y1, (int)y2, (int)y3);
+            acc[0] += fz_mulmod(y0, (double)ak.x, m);
+            acc[1] += fz_mulmod(y1, (double)ak.y, m);
+            acc[2] += fz_mulmod(y2, (double)ak.z, m);
+            acc[3] += fz_mulmod(y3, (double)ak.w, m);
+        }
+        wave_sync();
+    }
+    double *mine = accbuf + wave * 256 + p * D + 4 * mm;
+    mine[0] = acc[0]; mine[1] = acc[1]; mine[2] = acc[2]; mine[3] = acc[3];
+    __syncthreads();
+    if (threadIdx.x < D) {
+        double sum = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w)
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) sum += accbuf[w * 256 + q * D + threadIdx.x];
+        vk[seg * D + threadIdx.x] = (int)fz_cent(sum, m);
     }
 }
 
@@ -780,6 +860,18 @@ int query16(fz_ctx *ctx) {
 }
 
 }  // namespace
+
+int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,
+                           int l) {
+    const dim3 grid((unsigned)segments), block(64 * kWavesPerBlock);
+#define FZ_KF(LOGD, FAST) hipLaunchKernelGGL((keygen_fused<LOGD, FAST>), grid, block, 0, ctx->stream, A, coef, sk_hat, vk, l, \
+                                             (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod)
+    if (ctx->logd == 8) { if (ctx->mod.fast) FZ_KF(8, true); else FZ_KF(8, false); }
+    else if (ctx->logd == 6) { if (ctx->mod.fast) FZ_KF(6, true); else FZ_KF(6, false); }
+    else return fz_set_error(FZ_E_UNSUPPORTED, "fused keygen: degree 64 or 256 only");
+#undef FZ_KF
+    return fz_check_hip(hipGetLastError(), "keygen_fused launch");
+}
 
 int fz_launch_verify_fused(fz_ctx *ctx, const int32_t *A, const int32_t *sig, const int32_t *target, size_t groups, int l,
                            int64_t beta, int64_t omega, int *d_verdict) {

@@ -205,3 +205,24 @@ def test_fused_verify_equals_unfused_path(secpar, coracle, monkeypatch):
         monkeypatch.setenv("FZ_VERIFY_UNFUSED", "1")
         unfused = ctx.verify_core(A, sigma, vk[:, 0], vk[:, 1], c_hat, al_hat, beta, omega)
         assert fused == unfused == want, (beta, omega)
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_fused_keygen_equals_unfused_path(secpar, coracle, monkeypatch):
+    """keygen_fused (one launch; sk_hat never re-read) vs NTT + matvec launches vs the oracle; ragged key
+    counts and arbitrary int32 coefficient rows."""
+    import fusion_hip
+    P = O.PARAMS[secpar]
+    q, d, l = P["q"], P["d"], P["rank"]
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    rng = np.random.default_rng(secpar + 21)
+    A = O.splitmix_centered(6, l * d).reshape(l, d)
+    for n, lo, hi in ((1, -52, 53), (3, -52, 53), (2, -2**31, 2**31)):
+        coef = rng.integers(lo, hi, size=(n, 2, l, d), dtype=np.int64).astype(np.int32)
+        want_sk, want_vk = coracle.keygen_core(A, coef, q, P["root"])
+        monkeypatch.delenv("FZ_KEYGEN_UNFUSED", raising=False)
+        sk, vk = ctx.keygen_core(A, coef)
+        assert np.array_equal(sk, want_sk) and np.array_equal(vk, want_vk)
+        monkeypatch.setenv("FZ_KEYGEN_UNFUSED", "1")
+        sk2, vk2 = ctx.keygen_core(A, coef)
+        assert np.array_equal(sk2, want_sk) and np.array_equal(vk2, want_vk)

@@ -215,6 +215,8 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     {
         const char *e = getenv("FZ_NTT_KERNEL");
         c->force_kernel = e ? atoi(e) : 0;
+        e = getenv("FZ_NTT_TPB");
+        c->tasks_per_block = e ? atoi(e) : 0;
         e = getenv("FZ_NTT_GRID_MULT");
         c->grid_mult = e ? atoi(e) : 1;
         if (c->grid_mult < 1) c->grid_mult = 1;

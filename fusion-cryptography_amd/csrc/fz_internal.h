@@ -41,6 +41,7 @@ struct fz_ctx {
     size_t verdict_cap;
     int grid_fwd, grid_inv;      // resident-grid caps for the persistent NTT kernels
     int grid_fwd4, grid_inv4;    // same for the radix-4 kernels
+    int tasks_per_block;         // radix-4 kernels: contiguous tasks per workgroup for non-persistent launches (0 = persistent)
     int grid_mult;               // grid = resident blocks x grid_mult (env FZ_NTT_GRID_MULT; 1 = persistent)
     // per-dispatch timing of the NTT kernels (fz_profile_begin/end): event pairs bound to the
     // dispatch itself via hipExtLaunchKernelGGL, i.e. kernel begin -> kernel end on its own stream

@@ -399,7 +399,7 @@ __device__ __forceinline__ void fwd4_load_twiddles(double2 (&twl)[LOGD / 2 - 1][
 
 template <int LOGD, bool FAST>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *in, int32_t *out, size_t batch,
-                                                                const double2 *__restrict__ tw2, FzTwA twA, FzMod m) {
+                                                                const double2 *__restrict__ tw2, FzTwA twA, FzMod m, unsigned tpb) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
     __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256];
@@ -407,9 +407,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *i
     const int p = lane / LP, mm = lane % LP;
     double *region = lds + wave * 256 + p * D;
 
-    const size_t tasks = (batch + PPW - 1) / PPW;
-    const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave;
-    const size_t stride = (size_t)gridDim.x * kWavesPerBlock;
+    // task -> wave mapping: tpb == 0: persistent grid, tasks strided over the whole batch; tpb > 0: workgroup b
+    // owns the contiguous tasks [b*tpb, (b+1)*tpb), its waves interleaved inside (non-persistent launch)
+    const size_t all_tasks = (batch + PPW - 1) / PPW;
+    const size_t first = tpb ? (size_t)blockIdx.x * tpb + wave : (size_t)blockIdx.x * kWavesPerBlock + wave;
+    const size_t stride = tpb ? (size_t)kWavesPerBlock : (size_t)gridDim.x * kWavesPerBlock;
+    const size_t tasks = tpb ? (((size_t)blockIdx.x + 1) * tpb < all_tasks ? ((size_t)blockIdx.x + 1) * tpb : all_tasks) : all_tasks;
     if (first >= tasks) return;
 
     // per-lane twiddles of passes 1..P-1 (independent of the data: issued before the first load returns)
@@ -516,7 +519,7 @@ __device__ __forceinline__ void inv4_load_twiddles(double2 (&twl)[LOGD / 2 - 1][
 
 template <int LOGD, bool FAST>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *in, int32_t *out, size_t batch,
-                                                                const double2 *__restrict__ itw2, FzTwA twA, FzMod m) {
+                                                                const double2 *__restrict__ itw2, FzTwA twA, FzMod m, unsigned tpb) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
     __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256];
@@ -524,9 +527,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *i
     const int p = lane / LP, mm = lane % LP;
     double *region = lds + wave * 256 + p * D;
 
-    const size_t tasks = (batch + PPW - 1) / PPW;
-    const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave;
-    const size_t stride = (size_t)gridDim.x * kWavesPerBlock;
+    // task -> wave mapping: tpb == 0: persistent grid, tasks strided over the whole batch; tpb > 0: workgroup b
+    // owns the contiguous tasks [b*tpb, (b+1)*tpb), its waves interleaved inside (non-persistent launch)
+    const size_t all_tasks = (batch + PPW - 1) / PPW;
+    const size_t first = tpb ? (size_t)blockIdx.x * tpb + wave : (size_t)blockIdx.x * kWavesPerBlock + wave;
+    const size_t stride = tpb ? (size_t)kWavesPerBlock : (size_t)gridDim.x * kWavesPerBlock;
+    const size_t tasks = tpb ? (((size_t)blockIdx.x + 1) * tpb < all_tasks ? ((size_t)blockIdx.x + 1) * tpb : all_tasks) : all_tasks;
     if (first >= tasks) return;
 
     // per-lane twiddles of passes 0..P-2 (the last pass is wave-uniform)
@@ -780,7 +786,12 @@ int launch4f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool in
     const size_t tasks = (batch + PPW - 1) / PPW;
     const size_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
     const size_t cap = (size_t)(inverse ? ctx->grid_inv4 : ctx->grid_fwd4) * (size_t)ctx->grid_mult;
-    const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
+    unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
+    unsigned tpb = 0;
+    if (ctx->tasks_per_block > 0 && blocks > cap) {          // more work than one resident wave of blocks: contiguous chunks
+        tpb = (unsigned)ctx->tasks_per_block;
+        grid = (unsigned)((tasks + tpb - 1) / tpb);
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_on && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen[inverse ? 1 : 0]++ % ctx->prof_every) == 0) {
         e0 = ctx->prof_ev[2 * ctx->prof_n];
@@ -790,10 +801,10 @@ int launch4f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool in
     const dim3 block(64 * kWavesPerBlock);
     if (!inverse)
         hipExtLaunchKernelGGL((ntt_fwd4<LOGD, FAST>), dim3(grid), block, 0, ctx->stream, e0, e1, 0, in, out, batch,
-                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod);
+                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod, tpb);
     else
         hipExtLaunchKernelGGL((ntt_inv4<LOGD, FAST>), dim3(grid), block, 0, ctx->stream, e0, e1, 0, in, out, batch,
-                              (const double2 *)ctx->d_itw2, ctx->itwA, ctx->mod);
+                              (const double2 *)ctx->d_itw2, ctx->itwA, ctx->mod, tpb);
     return fz_check_hip(hipGetLastError(), "ntt4 launch");
 }
 

@@ -1,5 +1,6 @@
-"""Scratch timing of the NTT kernel variants (device-resident buffers, HIP events on the ctx stream).
-usage: quick_bench.py [variants...]   (FZ_NTT_VARIANT values; default 0..7)"""
+"""Timing of both NTT schedules (FZ_NTT_KERNEL = 16 | 4) over batch sizes, device-resident buffers, HIP events
+on the context's stream, oracle parity on a ragged batch first.
+usage: quick_bench.py [tpb...]   (FZ_NTT_TPB values to sweep for the radix-4 kernels; default 0 = persistent)"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "fusion-cryptography_amd"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -11,18 +12,18 @@ q = O.PRIME
 orc = O.COracle()
 variants = [16, 4]
 secpars = (256,)
-mults = [int(v) for v in sys.argv[1:]] or [1]
+mults = [int(v) for v in sys.argv[1:]] or [0]
 for secpar in secpars:
     P = O.PARAMS[secpar]; d = P["d"]
     for var, mult in [(v, m) for v in variants for m in mults]:
         os.environ["FZ_NTT_KERNEL"] = str(var)
-        os.environ["FZ_NTT_GRID_MULT"] = str(mult)
+        os.environ["FZ_NTT_TPB"] = str(mult)
         ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
         xs = O.splitmix_centered(9, 1003 * d).reshape(1003, d)
         ok = np.array_equal(ctx.ntt_forward(xs), orc.ntt_forward(xs, q, P["root"])) and \
             np.array_equal(ctx.ntt_inverse(xs), orc.ntt_inverse(xs, q, P["inv_root"]))
-        line = f"secpar={secpar} var={var} mult={mult} parity={'OK' if ok else 'FAIL'}"
-        for logB in (16, 18, 20):
+        line = f"secpar={secpar} var={var} tpb={mult} parity={'OK' if ok else 'FAIL'}"
+        for logB in (12, 16, 18, 20):
             B = 1 << logB
             x = O.splitmix_centered(5, B * d).reshape(B, d)
             din = fusion_hip.DeviceBuffer.from_numpy(ctx, x)

@@ -63,7 +63,7 @@ def cpu_baseline(seconds):
         done += 2
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
-            "sample": f"{done // 2} of the {B} rows: forward+inverse degree-256 NTT, pure-Python port "
+            "sample": f"{done // 2} rows (taken in order from the {B}-row batch, cycled): forward+inverse degree-256 NTT, pure-Python port "
                       f"(oracle.py_ntt_forward/py_ntt_inverse), {dt:.1f} s on 1 core of {os.cpu_count()}"}
 
 
@@ -321,7 +321,9 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_ntt.json")) as fh:
-                traffic = json.load(fh)["kernels"]["ntt_fwd4<8> B=4096"]["traffic_bytes_per_launch"]
+                kernels = json.load(fh)["kernels"]
+            key = next(k for k in kernels if k.startswith("ntt_fwd4<8") and "B=4096" in k)
+            traffic = kernels[key]["traffic_bytes_per_launch"]
         except Exception:
             pass
         fwd_bytes = 8.0 * d * B

@@ -123,10 +123,30 @@ void shake256(const uint8_t *p, size_t n, uint8_t *out, size_t outlen) {
 }
 
 // ---- exact text formats -----------------------------------------------------------------------------
+// str(int): two digits per step from a 200-byte table (the serialiser writes 512 integers per key)
+const char kDigitPairs[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839"
+    "40414243444546474849505152535455565758596061626364656667686970717273747576777879"
+    "8081828384858687888990919293949596979899";
+
 inline void put_int(std::string &s, long long v) {
     char buf[24];
-    int n = snprintf(buf, sizeof(buf), "%lld", v);
-    s.append(buf, (size_t)n);
+    char *p = buf + sizeof(buf);
+    unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    while (u >= 100) {
+        const unsigned r = (unsigned)(u % 100);
+        u /= 100;
+        p -= 2;
+        memcpy(p, kDigitPairs + 2 * r, 2);
+    }
+    if (u >= 10) {
+        p -= 2;
+        memcpy(p, kDigitPairs + 2 * u, 2);
+    } else {
+        *--p = (char)('0' + u);
+    }
+    if (v < 0) *--p = '-';
+    s.append(p, (size_t)(buf + sizeof(buf) - p));
 }
 
 // str(int) of a 256-bit little-endian value
@@ -192,8 +212,15 @@ void put_vk(std::string &s, const fz_scheme_params &P, const int32_t *left, cons
 
 // ---- byte decoder -------------------------------------------------------------------------------------
 inline uint64_t be_mod(const uint8_t *p, int n, uint64_t m) {       // int.from_bytes(p[:n], "big") % m, m < 2^32
+    if (m == 1) return 0;
     uint64_t r = 0;
-    for (int i = 0; i < n; ++i) r = ((r << 8) | p[i]) % m;
+    int i = 0;
+    for (const int head = n & 3; i < head; ++i) r = (r << 8) | p[i];     // < 2^24: no reduction needed yet
+    r %= m;
+    for (; i < n; i += 4) {                                              // r < m < 2^32: (r << 32 | word) fits 64 bits
+        const uint64_t w = ((uint64_t)p[i] << 24) | ((uint64_t)p[i + 1] << 16) | ((uint64_t)p[i + 2] << 8) | p[i + 3];
+        r = ((r << 32) | w) % m;
+    }
     return r;
 }
 
@@ -422,7 +449,7 @@ int fz_sort_by_vk_string(const fz_scheme_params *P, const int32_t *h_vk_left, co
     if (!params_ok(P) || !h_order || (N && (!h_vk_left || !h_vk_right))) return fz_set_error(FZ_E_BADARG, "bad argument");
     const int d = P->degree;
     std::vector<std::string> keys(N);
-    parallel_for(N, threads, [&](size_t i) { put_vk(keys[i], *P, h_vk_left + i * (size_t)d, h_vk_right + i * (size_t)d); });
+    parallel_for(N, threads, [&](size_t i) { keys[i].reserve(8192); put_vk(keys[i], *P, h_vk_left + i * (size_t)d, h_vk_right + i * (size_t)d); });
     std::iota(h_order, h_order + N, (size_t)0);
     // Python's sorted() is stable and compares str by code point; the text is ASCII
     std::stable_sort(h_order, h_order + N, [&](size_t a, size_t b) { return keys[a] < keys[b]; });

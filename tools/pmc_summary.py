@@ -1,0 +1,55 @@
+"""Summarise the rocprofv3 --pmc passes written by tools/collect_profiles.sh into <tag>_pmc_ntt.json.
+usage: pmc_summary.py gpurun_out/<tag> <tag>
+Per kernel and launch: HBM-side traffic = FETCH_SIZE (KB, doubled: MI355X_MICROARCH.md's gfx950 correction for
+16 B/lane coalesced reads) + WRITE_SIZE (KB); busy cycles per XCD (GRBM_GUI_ACTIVE / 8); an fp64-VALU issue
+estimate = SQ_INSTS_VALU x 4 cycles / (cycles per XCD x 128 SIMDs per XCD).  Counters are summed over the
+dimension rows rocprofv3 emits per dispatch and averaged over the dispatches of the kernel (the first two
+dispatches of each kernel are dropped as warm-up when there are more than four)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+root, tag = sys.argv[1], sys.argv[2]
+GROUPS = {"pmcb": ("B=4096 (bench launch)", 4096), "pmc20": ("B=2^20", 1 << 20)}
+out = {"source": "rocprofv3 --pmc <one set per pass> --output-format csv (tools/collect_profiles.sh, tools/pmc_summary.py); "
+                 "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane coalesced reads on gfx950; KB -> bytes x1024",
+       "kernels": {}}
+for sub, (label, rows) in GROUPS.items():
+    per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))       # kernel -> counter -> dispatch -> value
+    dur = defaultdict(dict)
+    for path in glob.glob(os.path.join(root, sub, "*", "*", "*_counter_collection.csv")):
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                k = r["Kernel_Name"]
+                if "ntt_" not in k:
+                    continue
+                short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+                per[short][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+                dur[short][int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+    for k, counters in per.items():
+        e = {}
+        for c, by_dispatch in counters.items():
+            ids = sorted(by_dispatch)
+            if len(ids) > 4:
+                ids = ids[2:]
+            e[c] = sum(by_dispatch[i] for i in ids) / len(ids)
+            e.setdefault("dispatches_averaged", len(ids))
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["read_bytes_corrected"] = e["FETCH_SIZE"] * 1024 * 2
+            e["write_bytes"] = e["WRITE_SIZE"] * 1024
+            e["traffic_bytes_per_launch"] = e["read_bytes_corrected"] + e["write_bytes"]
+            e["algorithmic_bytes_per_launch"] = rows * 2048
+            e["traffic_over_algorithmic"] = e["traffic_bytes_per_launch"] / e["algorithmic_bytes_per_launch"]
+        if "GRBM_GUI_ACTIVE" in e:
+            e["cycles_per_launch_per_xcd"] = e["GRBM_GUI_ACTIVE"] / 8
+            if "SQ_INSTS_VALU" in e:
+                e["valu_issue_utilisation_est"] = e["SQ_INSTS_VALU"] * 4 / (e["cycles_per_launch_per_xcd"] * 128 * 8)
+        ds = sorted(dur[k])
+        ds = ds[2:] if len(ds) > 4 else ds
+        e["serialised_duration_us_under_pmc"] = sum(dur[k][i] for i in ds) / len(ds)
+        if "cycles_per_launch_per_xcd" in e and e["serialised_duration_us_under_pmc"] > 100:     # the counter window of a
+            # few-microsecond dispatch is longer than the kernel, so the ratio only means something for long kernels
+            e["effective_clock_ghz_under_pmc"] = e["cycles_per_launch_per_xcd"] / e["serialised_duration_us_under_pmc"] * 1e-3
+        out["kernels"][f"{k} {label}"] = e
+with open(os.path.join(root, f"{tag}_pmc_ntt.json"), "w") as fh:
+    json.dump(out, fh, indent=1)
+print(json.dumps(out, indent=1))

@@ -1,7 +1,7 @@
 """Timing of both NTT schedules (FZ_NTT_KERNEL = 16 | 4) over batch sizes, device-resident buffers, HIP events
 on the context's stream, oracle parity on a ragged batch first.
 usage: quick_bench.py [tpb...]   (FZ_NTT_TPB values to sweep for the radix-4 kernels; default 0 = persistent)"""
-import sys, os
+import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "fusion-cryptography_amd"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np
@@ -29,9 +29,11 @@ for secpar in secpars:
             din = fusion_hip.DeviceBuffer.from_numpy(ctx, x)
             dout = fusion_hip.DeviceBuffer(ctx, x.nbytes)
             for name, fn in (("f", ctx.ntt_forward_dev), ("i", ctx.ntt_inverse_dev)):
-                for _ in range(3): fn(din.ptr, dout.ptr, B)
-                ctx.synchronize()
-                reps = 20
+                t_end = time.perf_counter() + 0.04      # 40 ms of the same launches first (clock ramp after idle)
+                while time.perf_counter() < t_end:
+                    for _ in range(3): fn(din.ptr, dout.ptr, B)
+                    ctx.synchronize()
+                reps = 400 if logB <= 12 else (100 if logB <= 16 else 20)
                 ctx.timer_start()
                 for _ in range(reps): fn(din.ptr, dout.ptr, B)
                 ms = ctx.timer_stop_ms() / reps

@@ -14,10 +14,13 @@ DB = fusion_hip.DeviceBuffer
 rng = np.random.default_rng(1)
 
 
-def timeit(fn, reps=10):
-    for _ in range(2):
-        fn()
-    ctx.synchronize()
+def timeit(fn, reps=50):
+    import time
+    t_end = time.perf_counter() + 0.04      # 40 ms of the same launches first: the GPU ramps its clocks for ~15 ms after idle
+    while time.perf_counter() < t_end:
+        for _ in range(3):
+            fn()
+        ctx.synchronize()
     ctx.timer_start()
     for _ in range(reps):
         fn()
@@ -46,7 +49,7 @@ for N in (256, 1024):
 vkL = DB.from_numpy(ctx, O.splitmix_centered(4, S * d).reshape(S, d))
 vkR = DB.from_numpy(ctx, O.splitmix_centered(5, S * d).reshape(S, d))
 for N in (256, 1024):
-    t = timeit(lambda: ctx.verify_core_dev(A.ptr, out.ptr, vkL.ptr, vkR.ptr, c_hat.ptr, al_hat.ptr, N, l, P["beta_vf"], d), reps=5)
+    t = timeit(lambda: ctx.verify_core_dev(A.ptr, out.ptr, vkL.ptr, vkR.ptr, c_hat.ptr, al_hat.ptr, N, l, P["beta_vf"], d), reps=20)
     print(f"verify_core   N={N}: {t*1e6:9.1f} us per call (incl. the verdict D2H)")
 mv = DB(ctx, S * 2 * d * 4)
 t = timeit(lambda: ctx.matvec_dev(A.ptr, sk.ptr, mv.ptr, 2 * S, l))

@@ -3,7 +3,10 @@
 
 Workload (BASELINE.json configs[1]): secpar=256, one batch of 4096 independent degree-256
 polynomials; a STEP is one pass of the hot path over that batch = forward NTT of the batch
-followed by inverse NTT of the result (two kernel launches, inputs resident in HBM).
+followed by inverse NTT of the result (two kernel launches, inputs resident in HBM).  The K timed
+steps are recorded into hipGraphs beforehand (the library's fz_graph_* capture) and replayed inside the
+timed region: the same 2K kernels in the same order on one stream, without a host round trip per launch
+(--no-graph launches them one by one).
 `value` = NTTs per second over the whole job (forward and inverse each count as one NTT,
 summed over all ranks).  With --gpus N every rank owns its own batch (weak scaling, no
 data-path collective for the transforms).
@@ -43,6 +46,7 @@ def parse():
     ap.add_argument("--no-sign-verify", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the large-batch runs of the same kernels")
     ap.add_argument("--no-two-stream", action="store_true", help="skip the two-stream pipelined variant")
+    ap.add_argument("--no-graph", action="store_true", help="launch the timed steps one by one instead of replaying hipGraphs")
     ap.add_argument("--sample-every", type=int, default=8,
                     help="bind begin/end events to every k-th dispatch of each kernel inside the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the pure-Python baseline sample")
@@ -104,7 +108,9 @@ def main():
     P = O.PARAMS[SECPAR]
     q, d, l = P["q"], P["d"], P["rank"]
     ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
-    stream = torch.cuda.current_stream(dev)
+    # a non-default stream, made torch's current one: graph capture needs it, and torch ops / RCCL order on it too
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
 
     def barrier():
@@ -129,11 +135,11 @@ def main():
     def step():
         return fz_fwd(h, xp, yp, nB) | fz_inv(h, yp, zp, nB)
 
-    def prewarm(fn, ms):
+    def prewarm(fn, ms, inner=50):
         """untimed: keep the device busy for `ms` so the timed region starts at steady clocks"""
         t_end = time.perf_counter() + ms * 1e-3
         while time.perf_counter() < t_end:
-            for _ in range(50):
+            for _ in range(inner):
                 fn()
             torch.cuda.synchronize(dev)
 
@@ -144,18 +150,53 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # events bound to every k-th dispatch (kernel begin -> end on its own stream); sampling keeps the
-    # instrumentation from throttling the launch rate of the timed region
-    ctx.profile_begin(2 * args.steps, args.sample_every)
-    rc = 0
+    # The timed region replays the K steps from hipGraphs recorded beforehand (fz_graph_*): the same 2K kernels in
+    # the same order on the same stream, without a host round trip per launch.  Chunks of <= 1000 steps.
+    chunk = min(args.steps, 1000)
+    graphs = []
+    if not args.no_graph:
+        for n_steps in ([chunk] if args.steps % chunk == 0 else [chunk, args.steps % chunk]):
+            ctx.graph_begin()
+            rc = 0
+            for _ in range(n_steps):
+                rc |= step()
+            g = ctx.graph_end()
+            assert rc == 0, f"capture failed: {lib.fz_last_error()}"
+            g.launch()                                   # untimed first replay (upload)
+            graphs.append((n_steps, g))
+        barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rc |= step()
+    ev0.record(stream)
+    if graphs:
+        for _ in range(args.steps // chunk):
+            graphs[0][1].launch()
+        if len(graphs) > 1:
+            graphs[1][1].launch()
+    else:
+        rc = 0
+        for _ in range(args.steps):
+            rc |= step()
+        assert rc == 0, f"launch failed: {lib.fz_last_error()}"
+    ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
+    region_launch_us = ev0.elapsed_time(ev1) * 1e3 / (2 * args.steps)     # HIP events over the timed region / launches
+    assert torch.equal(z, x), "INTT(NTT(x)) != x after the timed region"
+    for _, g in graphs:
+        g.destroy()
+    # Per-dispatch durations (kernel begin -> end, events bound to the dispatch on its own stream) cannot be taken
+    # inside a graph: an instrumented pass of the same steps, launched one by one right after the timed region,
+    # samples every k-th dispatch.  This is the figure rocprofv3's per-kernel average corresponds to.
+    n_inst = max(args.sample_every, min(args.steps, 400))
+    ctx.profile_begin(2 * n_inst, args.sample_every)
+    rc = 0
+    for _ in range(n_inst):
+        rc |= step()
     assert rc == 0, f"launch failed: {lib.fz_last_error()}"
     prof = ctx.profile_end()
-    assert prof["fwd_count"] == prof["inv_count"] == (args.steps + args.sample_every - 1) // args.sample_every
+    assert prof["fwd_count"] == prof["inv_count"] == (n_inst + args.sample_every - 1) // args.sample_every
     fwd_avg, inv_avg = prof["fwd_avg_us"] * 1e-3, prof["inv_avg_us"] * 1e-3      # ms
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -163,33 +204,51 @@ def main():
         elapsed = float(t.item())
     value = 2.0 * B * args.steps * world / elapsed
 
-    # ---- the same steps pipelined over two HIP streams (independent batches overlap; informational) ----
+    # ---- the same steps as two independent pipelines (two HIP streams / two branches of one graph; informational) ----
     two_stream = None
     if rank == 0 and not args.no_two_stream:
-        s2 = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-        c2 = [fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index) for _ in s2]
-        b2 = [(torch.empty_like(x), torch.empty_like(x)) for _ in s2]
-        for c_, s_ in zip(c2, s2):
-            c_.set_stream(s_.cuda_stream)
-        a2 = [(c_._h, xp, ctypes.c_void_p(y_.data_ptr()), ctypes.c_void_p(z_.data_ptr())) for c_, (y_, z_) in zip(c2, b2)]
+        side = torch.cuda.Stream(dev)
+        cs = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
+        cs.set_stream(side.cuda_stream)
+        y2, z2 = torch.empty_like(x), torch.empty_like(x)
+        hs, y2p, z2p = cs._h, ctypes.c_void_p(y2.data_ptr()), ctypes.c_void_p(z2.data_ptr())
+        k2 = min(args.steps, 1000) & ~1                    # steps per replay, half on each branch
+        torch.cuda.synchronize(dev)
 
         def run2(k):
-            for i in range(k):
-                h_, xp_, yp_, zp_ = a2[i & 1]
-                fz_fwd(h_, xp_, yp_, nB)
-                fz_inv(h_, yp_, zp_, nB)
-        prewarm(lambda: run2(2), args.prewarm_ms / 3)
-        run2(args.warmup)
+            for _ in range(k // 2):
+                fz_fwd(h, xp, yp, nB)
+                fz_inv(h, yp, zp, nB)
+                fz_fwd(hs, xp, y2p, nB)
+                fz_inv(hs, y2p, z2p, nB)
+        g2 = None
+        if not args.no_graph and k2 >= 2:
+            g2 = torch.cuda.CUDAGraph()                      # fork/join across streams: torch's capture does the plumbing
+            with torch.cuda.graph(g2, stream=stream):
+                side.wait_stream(stream)
+                run2(k2)
+                stream.wait_stream(side)
+            replay = g2.replay
+        else:
+            k2 = 50
+
+            def replay():
+                run2(k2)
+        reps2 = max(1, args.steps // k2)
+        prewarm(replay, args.prewarm_ms / 3, inner=1 if g2 is not None else 50)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        run2(args.steps)
+        for _ in range(reps2):
+            replay()
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
-        assert all(torch.equal(z_, x) for _, z_ in b2)
-        two_stream = {"value": 2.0 * B * args.steps / dt, "unit": "NTT/s", "ms_per_step": dt / args.steps * 1e3,
-                      "what": "the same K steps issued alternately on two HIP streams with private output buffers"}
-        for c_ in c2:
-            c_.close()
+        assert torch.equal(z2, x) and torch.equal(z, x)
+        two_stream = {"value": 2.0 * B * reps2 * k2 / dt, "unit": "NTT/s", "ms_per_step": dt / (reps2 * k2) * 1e3,
+                      "steps": reps2 * k2,
+                      "what": "steps issued alternately on two HIP streams with private output buffers"
+                              + (" (two branches of one hipGraph)" if g2 is not None else "")}
+        del g2
+        cs.close()
 
     # ---- host-pointer path (PCIe-inclusive; informational, never `value`) -----------------------
     pcie = None
@@ -352,12 +411,17 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 (exact integer arithmetic; int32 in/out)", "data": "synthetic",
             "config": {"workload": f"configs[1]: secpar={SECPAR}, batch of {B} degree-{d} forward+inverse NTTs per GPU",
                        "batch": B, "degree": d, "modulus": q, "kernels_per_step": 2,
-                       "prewarm_ms": args.prewarm_ms},
+                       "launch": "one by one" if args.no_graph else "hipGraph replay (fz_graph_*)", "prewarm_ms": args.prewarm_ms},
             "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8> (forward NTT, B=4096)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": fwd_bytes, "avg_launch_us": fwd_avg * 1e3,
                          "inverse_avg_launch_us": inv_avg * 1e3, "launches_timed": prof["fwd_count"],
-                         "timing": f"hipExtLaunchKernelGGL start/stop events on every {args.sample_every}th dispatch inside the timed region",
+                         "timing": f"per-dispatch begin/end events (hipExtLaunchKernelGGL) on every {args.sample_every}th dispatch of "
+                                   f"{n_inst} steps launched one by one right after the timed region (a hipGraph cannot carry them)",
+                         "region": {"avg_launch_us": region_launch_us, "achieved": fwd_bytes / (region_launch_us * 1e-6) / 1e9,
+                                    "frac": fwd_bytes / (region_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                    "what": "HIP events around the timed region on the kernels' stream / 2K launches "
+                                            "(consecutive dispatches overlap their launch and drain phases)"},
                          "sweep": sweep},
             "two_stream_pipelined": two_stream, "sign_verify": sv, "end_to_end": e2e, "pcie_inclusive": pcie,
         }

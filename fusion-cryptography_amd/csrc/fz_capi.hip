@@ -46,6 +46,8 @@ static unsigned bitrev(unsigned i, int k) {
 
 int fz_scratch(fz_ctx *ctx, size_t bytes, void **out) {
     if (bytes > ctx->scratch_bytes) {
+        if (ctx->capturing)
+            return fz_set_error(FZ_E_BADARG, "scratch would grow during graph capture: run the sequence once before fz_graph_begin");
         // previous users of the scratch are stream-ordered before this point
         FZ_HIP(hipStreamSynchronize(ctx->stream), "scratch sync");
         if (ctx->d_scratch) FZ_HIP(hipFree(ctx->d_scratch), "scratch free");
@@ -61,6 +63,8 @@ int fz_scratch(fz_ctx *ctx, size_t bytes, void **out) {
 
 int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out) {
     if (bytes > ctx->scratch2_bytes) {
+        if (ctx->capturing)
+            return fz_set_error(FZ_E_BADARG, "scratch would grow during graph capture: run the sequence once before fz_graph_begin");
         FZ_HIP(hipStreamSynchronize(ctx->stream), "scratch2 sync");
         if (ctx->d_scratch2) FZ_HIP(hipFree(ctx->d_scratch2), "scratch2 free");
         ctx->d_scratch2 = nullptr;
@@ -264,13 +268,82 @@ int fz_ctx_destroy(fz_ctx *ctx) {
 
 int fz_ctx_set_stream(fz_ctx *ctx, void *hip_stream) {
     FZ_REQUIRE(ctx, "ctx is NULL");
+    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the stream cannot change during graph capture");
     ctx->stream = (hipStream_t)hip_stream;
     return FZ_OK;
 }
 
 int fz_ctx_synchronize(fz_ctx *ctx) {
     FZ_REQUIRE(ctx, "ctx is NULL");
+    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "synchronisation is not allowed during graph capture");
     FZ_HIP(hipStreamSynchronize(ctx->stream), "stream synchronize");
+    return FZ_OK;
+}
+
+int fz_stream_create(fz_ctx *ctx, void **out_stream) {
+    FZ_REQUIRE(ctx && out_stream, "NULL argument");
+    FZ_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    hipStream_t s = nullptr;
+    FZ_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "stream create");
+    *out_stream = (void *)s;
+    return FZ_OK;
+}
+
+int fz_stream_destroy(fz_ctx *ctx, void *hip_stream) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    if (!hip_stream) return FZ_OK;
+    if (ctx->stream == (hipStream_t)hip_stream) return fz_set_error(FZ_E_BADARG, "the stream is still attached to this context");
+    FZ_HIP(hipStreamDestroy((hipStream_t)hip_stream), "stream destroy");
+    return FZ_OK;
+}
+
+// ---- graph capture: a launch-bound sequence of device-pointer calls recorded once, replayed with one call ------
+int fz_graph_begin(fz_ctx *ctx) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "a capture is already open on this context");
+    if (ctx->stream == nullptr)
+        return fz_set_error(FZ_E_BADARG, "graph capture needs a non-default stream (fz_ctx_set_stream)");
+    if (ctx->prof_on) return fz_set_error(FZ_E_BADARG, "per-dispatch profiling is on: events cannot be captured");
+    FZ_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    FZ_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed), "begin capture");
+    ctx->capturing = 1;
+    return FZ_OK;
+}
+
+int fz_graph_end(fz_ctx *ctx, fz_graph **out_graph) {
+    FZ_REQUIRE(ctx && out_graph, "NULL argument");
+    if (!ctx->capturing) return fz_set_error(FZ_E_BADARG, "no capture is open on this context");
+    ctx->capturing = 0;
+    hipGraph_t g = nullptr;
+    FZ_HIP(hipStreamEndCapture(ctx->stream, &g), "end capture");
+    if (!g) return fz_set_error(FZ_E_HIP, "the capture produced no graph (a captured call failed)");
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return fz_check_hip(e, "graph instantiate");
+    }
+    fz_graph *G = new fz_graph;
+    G->graph = g;
+    G->exec = ex;
+    G->device = ctx->device;
+    *out_graph = G;
+    return FZ_OK;
+}
+
+int fz_graph_launch(fz_ctx *ctx, fz_graph *graph) {
+    FZ_REQUIRE(ctx && graph, "NULL argument");
+    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "a graph cannot be launched into its own capture");
+    if (graph->device != ctx->device) return fz_set_error(FZ_E_BADARG, "graph was captured on device %d", graph->device);
+    FZ_HIP(hipGraphLaunch(graph->exec, ctx->stream), "graph launch");
+    return FZ_OK;
+}
+
+int fz_graph_destroy(fz_graph *graph) {
+    if (!graph) return FZ_OK;
+    (void)hipGraphExecDestroy(graph->exec);
+    (void)hipGraphDestroy(graph->graph);
+    delete graph;
     return FZ_OK;
 }
 
@@ -303,6 +376,7 @@ int fz_memcpy_h2d(fz_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
 
 int fz_memcpy_d2h(fz_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     FZ_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "NULL argument");
+    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "a synchronous device-to-host copy cannot be captured");
     if (bytes) FZ_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream), "memcpy d2h");
     FZ_HIP(hipStreamSynchronize(ctx->stream), "memcpy d2h sync");
     return FZ_OK;
@@ -316,6 +390,7 @@ int fz_timer_start(fz_ctx *ctx) {
 
 int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms) {
     FZ_REQUIRE(ctx && out_ms, "NULL argument");
+    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the timer cannot be read during graph capture");
     FZ_HIP(hipEventRecord(ctx->ev1, ctx->stream), "event record");
     FZ_HIP(hipEventSynchronize(ctx->ev1), "event synchronize");
     FZ_HIP(hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1), "event elapsed");
@@ -324,6 +399,7 @@ int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms) {
 
 int fz_profile_begin(fz_ctx *ctx, int max_launches, int sample_every) {
     FZ_REQUIRE(ctx && max_launches > 0 && max_launches <= (1 << 20) && sample_every >= 1, "bad argument");
+    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "per-dispatch profiling cannot start during graph capture");
     if (max_launches > ctx->prof_cap) {
         hipEvent_t *ev = (hipEvent_t *)realloc(ctx->prof_ev, sizeof(hipEvent_t) * 2 * (size_t)max_launches);
         unsigned char *kind = (unsigned char *)realloc(ctx->prof_kind, (size_t)max_launches);

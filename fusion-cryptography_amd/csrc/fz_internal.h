@@ -48,6 +48,13 @@ struct fz_ctx {
     int prof_on, prof_cap, prof_n, prof_every, prof_seen[2];
     hipEvent_t *prof_ev;         // 2 * prof_cap events
     unsigned char *prof_kind;    // 0 forward, 1 inverse
+    int capturing;               // between fz_graph_begin and fz_graph_end: nothing may allocate or synchronise
+};
+
+struct fz_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    int device;
 };
 
 // error plumbing (fz_capi.hip)

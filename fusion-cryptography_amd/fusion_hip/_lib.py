@@ -42,6 +42,12 @@ SIGNATURES = {
     "fz_ctx_set_stream": (c_int, [_ctx, c_void_p]),
     "fz_ctx_synchronize": (c_int, [_ctx]),
     "fz_ctx_twiddles": (c_int, [_ctx, _u32p, _u32p]),
+    "fz_stream_create": (c_int, [_ctx, POINTER(c_void_p)]),
+    "fz_stream_destroy": (c_int, [_ctx, c_void_p]),
+    "fz_graph_begin": (c_int, [_ctx]),
+    "fz_graph_end": (c_int, [_ctx, POINTER(c_void_p)]),
+    "fz_graph_launch": (c_int, [_ctx, c_void_p]),
+    "fz_graph_destroy": (c_int, [c_void_p]),
     "fz_malloc": (c_int, [_ctx, c_size_t, POINTER(c_void_p)]),
     "fz_free": (c_int, [_ctx, c_void_p]),
     "fz_memcpy_h2d": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),

@@ -66,6 +66,26 @@ class Context:
     def synchronize(self):
         check(self._lib, self._lib.fz_ctx_synchronize(self._h))
 
+    def stream_create(self):
+        """-> raw hipStream_t (int) on this context's device"""
+        p = c_void_p()
+        check(self._lib, self._lib.fz_stream_create(self._h, byref(p)))
+        return p.value
+
+    def stream_destroy(self, stream_ptr):
+        check(self._lib, self._lib.fz_stream_destroy(self._h, c_void_p(stream_ptr)))
+
+    # -- graph capture ---------------------------------------------------------------------------
+    def graph_begin(self):
+        """Start recording the device-pointer calls issued on this context (needs a non-default stream)."""
+        check(self._lib, self._lib.fz_graph_begin(self._h))
+
+    def graph_end(self):
+        """-> Graph: the recorded sequence, replayable with .launch()"""
+        g = c_void_p()
+        check(self._lib, self._lib.fz_graph_end(self._h, byref(g)))
+        return Graph(self, g)
+
     def twiddles(self):
         f = np.empty(self.degree, dtype=np.uint32)
         i = np.empty(self.degree, dtype=np.uint32)
@@ -313,6 +333,27 @@ class Context:
         finally:
             for b in bufs:
                 b.free()
+
+
+class Graph:
+    """A captured sequence of device calls (fz_graph_*)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self._g = ctx, handle
+
+    def launch(self):
+        check(self.ctx._lib, self.ctx._lib.fz_graph_launch(self.ctx._h, self._g))
+
+    def destroy(self):
+        if self._g:
+            self.ctx._lib.fz_graph_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:

@@ -122,3 +122,45 @@ def test_error_codes_on_device():
     with pytest.raises(fusion_hip.FusionHipError):
         fusion_hip.Context(Q, 256, 5, 1)                          # not a primitive root
     assert lib.fz_ctx_destroy(None) == 0
+
+
+@pytest.mark.gpu
+def test_graph_capture_replays_a_recorded_sequence(coracle):
+    """fz_graph_*: forward -> pointwise square -> inverse recorded once, replayed on fresh contents; capture
+    refuses what cannot be recorded (default stream, synchronisation, host copies)"""
+    import fusion_hip
+    P = O.PARAMS[256]
+    q, d = P["q"], P["d"]
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    with pytest.raises(fusion_hip.FusionHipError, match="non-default stream"):
+        ctx.graph_begin()
+    s = ctx.stream_create()
+    ctx.set_stream(s)
+    rows = 77
+    x = O.splitmix_centered(31, rows * d).reshape(rows, d)
+    dx = fusion_hip.DeviceBuffer.from_numpy(ctx, x)
+    dy = fusion_hip.DeviceBuffer(ctx, x.nbytes)
+    dz = fusion_hip.DeviceBuffer(ctx, x.nbytes)
+    ctx.graph_begin()
+    ctx.ntt_forward_dev(dx.ptr, dy.ptr, rows)
+    ctx.pw_dev(fusion_hip.OP_MUL, dy.ptr, dy.ptr, dy.ptr, rows * d)
+    ctx.ntt_inverse_dev(dy.ptr, dz.ptr, rows)
+    with pytest.raises(fusion_hip.FusionHipError, match="capture"):
+        ctx.synchronize()
+    g = ctx.graph_end()
+    for seed in (31, 32):                       # same graph, new contents
+        x = O.splitmix_centered(seed, rows * d).reshape(rows, d)
+        ctx.h2d(dx.ptr, x)
+        g.launch()
+        got = ctx.d2h(np.empty_like(x), dz.ptr)
+        f = coracle.ntt_forward(x, q, P["root"])
+        want = coracle.ntt_inverse(coracle.pw_mul(f, f, q), q, P["inv_root"])
+        assert np.array_equal(got, want)
+    g.destroy()
+    with pytest.raises(fusion_hip.FusionHipError, match="still attached"):
+        ctx.stream_destroy(s)
+    ctx.set_stream(0)
+    ctx.stream_destroy(s)
+    for b in (dx, dy, dz):
+        b.free()
+    ctx.close()

@@ -40,7 +40,7 @@ SECPAR = 256
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sign-verify", action="store_true")
@@ -234,7 +234,7 @@ def main():
 
             def replay():
                 run2(k2)
-        reps2 = max(1, args.steps // k2)
+        reps2 = max(10, args.steps // k2)              # a single replay would mostly measure its own start-up
         prewarm(replay, args.prewarm_ms / 3, inner=1 if g2 is not None else 50)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()

@@ -225,9 +225,10 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         c->grid_mult = e ? atoi(e) : 1;
         if (c->grid_mult < 1) c->grid_mult = 1;
         e = getenv("FZ_NTT_SMALL_ROWS");
-        // measured crossover (profiles/README.md): degree 256 -- radix-4 wins up to 2^16 rows (cache-
-        // resident batches), the 16-per-lane kernel from 2^20 rows; degree 64 -- radix-4 at every size
-        c->small_batch_rows = e ? atoi(e) : (degree == 256 ? (1 << 17) : 0x7fffffff);
+        // measured crossover at steady clocks (profiles/README.md): degree 256 -- the two schedules are within 3 % up
+        // to 2^15 rows (radix-4 ahead by 1-2 % at the bench's 2^12), the 16-per-lane kernel wins from 2^16 rows
+        // (69 % vs 65 %, 2^18: 67 % vs 57 %); degree 64 -- radix-4 up to 2^18 rows, 16-per-lane from 2^20
+        c->small_batch_rows = e ? atoi(e) : (degree == 256 ? (1 << 15) : (1 << 19));
     }
     if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
     if (rc == FZ_OK) rc = upload_doubles(itwB, nB, &c->d_itwB);

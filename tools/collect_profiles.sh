@@ -21,7 +21,7 @@ step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cp $OUT/prof/*/*_kernel_stats.csv $OUT/${TAG}_bench_rocprofv3_kernel_stats.csv 2>/dev/null
 for set in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU"; do
   n=$(echo $set | tr " " "_" | cut -c1-30)
-  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcb/$n -- python3 $R/bench.py --no-cpu-baseline --no-sweep --no-sign-verify --no-two-stream --steps 50 --prewarm-ms 20 > $OUT/pmcb_$n.log 2>&1
+  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcb/$n -- python3 $R/bench.py --no-cpu-baseline --no-sweep --no-sign-verify --no-two-stream --no-graph --steps 50 --prewarm-ms 20 > $OUT/pmcb_$n.log 2>&1
   step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc20/$n -- python3 $R/tools/prof_ntt.py 20 30 > $OUT/pmc20_$n.log 2>&1
 done
 cd $R

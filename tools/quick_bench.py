@@ -11,7 +11,7 @@ from oracle import oracle as O
 q = O.PRIME
 orc = O.COracle()
 variants = [16, 4]
-secpars = (256,)
+secpars = tuple(int(v) for v in os.environ.get("QB_SECPAR", "256").split(","))
 mults = [int(v) for v in sys.argv[1:]] or [0]
 for secpar in secpars:
     P = O.PARAMS[secpar]; d = P["d"]
@@ -23,8 +23,8 @@ for secpar in secpars:
         ok = np.array_equal(ctx.ntt_forward(xs), orc.ntt_forward(xs, q, P["root"])) and \
             np.array_equal(ctx.ntt_inverse(xs), orc.ntt_inverse(xs, q, P["inv_root"]))
         line = f"secpar={secpar} var={var} tpb={mult} parity={'OK' if ok else 'FAIL'}"
-        for logB in (12, 16, 18, 20):
-            B = 1 << logB
+        for logB in (12, 13, 14, 15, 16, 18, 20):
+            B = (1 << logB) * (256 // d)             # the same bytes per launch for every degree
             x = O.splitmix_centered(5, B * d).reshape(B, d)
             din = fusion_hip.DeviceBuffer.from_numpy(ctx, x)
             dout = fusion_hip.DeviceBuffer(ctx, x.nbytes)
@@ -38,7 +38,7 @@ for secpar in secpars:
                 for _ in range(reps): fn(din.ptr, dout.ptr, B)
                 ms = ctx.timer_stop_ms() / reps
                 gbs = 8 * d * B / (ms * 1e-3) / 1e9
-                line += f" | 2^{logB}{name} {ms*1e3:8.2f}us {gbs/80:5.1f}%"
+                line += f" | {B}{name} {ms*1e3:8.2f}us {gbs/80:5.1f}%"
             din.free(); dout.free()
         print(line, flush=True)
         ctx.close()

@@ -53,29 +53,63 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed run of the same steps before the W warmup steps: after idle the GPU needs tens of "
                          "milliseconds of load to reach its steady clocks (measured: the first ~15 ms run 10-25 %% slower)")
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(seconds):
-    """Pure-Python port (lists of ints, one cent() per reference cent call) on ONE core."""
+def _cpu_worker(job):
+    """one host process: forward+inverse pure-Python NTTs for `seconds`; returns (transforms, seconds)"""
+    index, seconds = job
     from oracle import oracle as O
     P = O.PARAMS[SECPAR]
     q, d = P["q"], P["d"]
     tw, itw = O.py_twiddles(P["root"], q, d), O.py_twiddles(P["inv_root"], q, d)
-    x = O.splitmix_centered(20261003, B * d).reshape(B, d).tolist()
+    rows = 64
+    x = O.splitmix_centered(20261003, B * d).reshape(B, d)[(index * rows) % B:][:rows].tolist()
     done, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:          # bounded sample: as many rows as fit the budget
-        row = list(x[(done // 2) % B])
+        row = list(x[(done // 2) % rows])
         O.py_ntt_inverse(O.py_ntt_forward(row, q, tw), q, itw)
         done += 2
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
-            "sample": f"{done // 2} rows (taken in order from the {B}-row batch, cycled): forward+inverse degree-256 NTT, pure-Python port "
-                      f"(oracle.py_ntt_forward/py_ntt_inverse), {dt:.1f} s on 1 core of {os.cpu_count()}"}
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(seconds):
+    """Pure-Python port (lists of ints, one cent() per reference cent call): ONE core (the reference is
+    single-threaded), then the same loop in one process per host core of this GPU's share."""
+    done, dt = _cpu_worker((0, seconds))
+    out = {"value": done / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
+           "sample": f"{done // 2} rows of the {B}-row batch: forward+inverse degree-256 NTT each, pure-Python port "
+                     f"(oracle.py_ntt_forward/py_ntt_inverse), {dt:.1f} s on 1 core of {os.cpu_count()}"}
+    try:
+        import subprocess
+        workers = max(1, min(16, os.cpu_count() or 1))      # a one-GPU box's share of the host
+        # plain child processes of this file (--cpu-worker): they import the oracle only and never touch the GPU
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--cpu-seconds",
+                                   str(seconds / 3)], stdout=subprocess.PIPE, text=True) for i in range(workers)]
+        res = []
+        for pr in procs:
+            try:
+                text, _ = pr.communicate(timeout=seconds + 60)
+                n, t = text.split()
+                res.append((int(n), float(t)))
+            except Exception:
+                pr.kill()
+        if not res:
+            raise RuntimeError("no worker finished")
+        out["all_cores"] = {"value": sum(n / t for n, t in res), "unit": "NTT/s", "cores": len(res),
+                            "sample": f"{len(res)} processes x {seconds / 3:.1f} s of the same loop"}
+    except Exception as e:                                   # the single-core figure stands on its own
+        out["all_cores"] = {"error": repr(e)}
+    return out
 
 
 def main():
     args = parse()
+    if args.cpu_worker is not None:                      # child of cpu_baseline(): host only
+        n, t = _cpu_worker((args.cpu_worker, args.cpu_seconds))
+        print(n, t)
+        return
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -414,7 +448,7 @@ def main():
                        "launch": "one by one" if args.no_graph else "hipGraph replay (fz_graph_*)", "prewarm_ms": args.prewarm_ms},
             "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8> (forward NTT, B=4096)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": fwd_bytes, "avg_launch_us": fwd_avg * 1e3,
+                         "bytes_per_launch": fwd_bytes, "butterflies_per_s": value * (d // 2) * 8, "avg_launch_us": fwd_avg * 1e3,
                          "inverse_avg_launch_us": inv_avg * 1e3, "launches_timed": prof["fwd_count"],
                          "timing": f"per-dispatch begin/end events (hipExtLaunchKernelGGL) on every {args.sample_every}th dispatch of "
                                    f"{n_inst} steps launched one by one right after the timed region (a hipGraph cannot carry them)",

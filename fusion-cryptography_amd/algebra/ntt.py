@@ -244,13 +244,13 @@ def ntt_poly_mult(f: List[int], g: List[int], modulus: int, root: int, inv_root:
     _validate_mult_args(f, g, modulus, root, inv_root, root_order, root_order // 2)
     n = len(f)
     ctx = _backend.ntt_ctx(modulus, n, root, inv_root)
-    import numpy as np
-    fg_hat = ctx.ntt_forward(np.stack([_backend.to_i32(f, modulus), _backend.to_i32(g, modulus)]))
-    prod = ctx.pw_mul(fg_hat[0], fg_hat[1])
-    back = ctx.ntt_inverse(np.stack([prod, fg_hat[0], fg_hat[1]]))
-    f[:] = back[1].tolist()
-    g[:] = back[2].tolist()
-    return back[0].tolist()
+    fi, gi = _backend.to_i32(f, modulus), _backend.to_i32(g, modulus)
+    prod = ctx.poly_mul(fi, gi)                      # one launch: both transforms, product, inverse
+    # INTT(NTT(x)) is the centred residue of x: the round trip the reference performs on f and g
+    halfmod = modulus // 2
+    f[:] = [((int(v) + halfmod) % modulus) - halfmod for v in fi]
+    g[:] = [((int(v) + halfmod) % modulus) - halfmod for v in gi]
+    return prod.tolist()
 
 
 def ntt_poly_mult_half(f: List[int], g: List[int], modulus: int, root: int, inv_root: int,

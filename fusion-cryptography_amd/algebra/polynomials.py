@@ -182,9 +182,7 @@ class PolynomialCoefficientRepresentation(PolynomialRepresentation):
         if self.root_order != other.root_order:
             raise NotImplementedError(f"Multiplication for {type(self)} with different root orders not implemented")
         # negacyclic product mod (X^d + 1, q): NTT -> pointwise -> INTT on the device
-        ctx = self._ntt()
-        hats = ctx.ntt_forward(np.stack([self._i32(), other._i32()]))
-        return self._like(ctx.ntt_inverse(ctx.pw_mul(hats[0], hats[1])).tolist())
+        return self._like(self._ntt().poly_mul(self._i32(), other._i32()).tolist())
 
     def __rmul__(self, other):
         return self.__mul__(other=other)

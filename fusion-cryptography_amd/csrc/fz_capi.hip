@@ -501,6 +501,41 @@ int fz_pw_binary_host(fz_ctx *ctx, int op, const int32_t *h_a, const int32_t *h_
     return fz_memcpy_d2h(ctx, h_out, dout, count * sizeof(int32_t));
 }
 
+// ---- negacyclic product -------------------------------------------------------------------------
+int fz_poly_mul(fz_ctx *ctx, const int32_t *d_f, const int32_t *d_g, int32_t *d_out, size_t batch) {
+    FZ_REQUIRE(ctx && (batch == 0 || (d_f && d_g && d_out)), "NULL argument");
+    if (ctx->logd < 0) return fz_set_error(FZ_E_UNSUPPORTED, "ring-only context (created with root 0) has no transforms");
+    if (batch == 0) return FZ_OK;
+    if ((ctx->logd == 6 || ctx->logd == 8) && !getenv("FZ_POLYMUL_UNFUSED")) {
+        if ((((uintptr_t)d_f | (uintptr_t)d_g | (uintptr_t)d_out) & 3) != 0)
+            return fz_set_error(FZ_E_BADARG, "buffers must be 4-byte aligned");
+        return fz_launch_polymul_fused(ctx, d_f, d_g, d_out, batch);
+    }
+    // generic degrees: NTT(f), NTT(g) into scratch, product in place, inverse into out
+    const size_t n = batch * (size_t)ctx->degree, seg = (n * sizeof(int32_t) + 255) & ~(size_t)255;
+    void *d = nullptr;
+    FZ_TRY(fz_scratch(ctx, 2 * seg, &d));
+    int32_t *fh = (int32_t *)d, *gh = (int32_t *)((char *)d + seg);
+    FZ_TRY(fz_launch_ntt(ctx, d_f, fh, batch, false));
+    FZ_TRY(fz_launch_ntt(ctx, d_g, gh, batch, false));
+    FZ_TRY(fz_launch_pw(ctx, FZ_OP_MUL, fh, gh, fh, n));
+    return fz_launch_ntt(ctx, fh, d_out, batch, true);
+}
+
+int fz_poly_mul_host(fz_ctx *ctx, const int32_t *h_f, const int32_t *h_g, int32_t *h_out, size_t batch) {
+    FZ_REQUIRE(ctx && (batch == 0 || (h_f && h_g && h_out)), "NULL argument");
+    if (ctx->logd < 0) return fz_set_error(FZ_E_UNSUPPORTED, "ring-only context (created with root 0) has no transforms");
+    if (batch == 0) return FZ_OK;
+    const size_t bytes = batch * (size_t)ctx->degree * sizeof(int32_t), seg = (bytes + 255) & ~(size_t)255;
+    void *d = nullptr;
+    FZ_TRY(fz_scratch2(ctx, 2 * seg, &d));            // scratch2: the generic path of fz_poly_mul owns the first scratch
+    int32_t *df = (int32_t *)d, *dg = (int32_t *)((char *)d + seg);
+    FZ_TRY(fz_memcpy_h2d(ctx, df, h_f, bytes));
+    FZ_TRY(fz_memcpy_h2d(ctx, dg, h_g, bytes));
+    FZ_TRY(fz_poly_mul(ctx, df, dg, df, batch));
+    return fz_memcpy_d2h(ctx, h_out, df, bytes);
+}
+
 // ---- matrix-vector ------------------------------------------------------------------------------
 int fz_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *out, size_t batch, int l) {
     FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (A && S && out)), "bad argument");

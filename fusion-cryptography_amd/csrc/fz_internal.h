@@ -41,6 +41,7 @@ struct fz_ctx {
     size_t verdict_cap;
     int grid_fwd, grid_inv;      // resident-grid caps for the persistent NTT kernels
     int grid_fwd4, grid_inv4;    // same for the radix-4 kernels
+    int grid_pm;                 // resident grid of the fused product kernel (0 = not queried yet)
     int tasks_per_block;         // radix-4 kernels: contiguous tasks per workgroup for non-persistent launches (0 = persistent)
     int grid_mult;               // grid = resident blocks x grid_mult (env FZ_NTT_GRID_MULT; 1 = persistent)
     // per-dispatch timing of the NTT kernels (fz_profile_begin/end): event pairs bound to the
@@ -67,6 +68,7 @@ int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out);   // second, independent
 int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse);
 int fz_ntt_query_grid(fz_ctx *ctx);
 
+int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int32_t *out, size_t batch);
 int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,
                            int l);
 int fz_launch_verify_fused(fz_ctx *ctx, const int32_t *A, const int32_t *sig, const int32_t *target, size_t groups, int l,

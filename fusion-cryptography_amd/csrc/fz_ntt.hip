@@ -569,6 +569,65 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *i
 }
 
 // ------------------------------------------------------------------------------------------
+// Negacyclic product INTT(NTT(f) * NTT(g)) in one launch (algebra/ntt.py:380-484 ntt_poly_mult; the product the
+// reference's schoolbook PolynomialCoefficientRepresentation.__mul__, polynomials.py:171-216, is tested against):
+// both forward transforms, the pointwise product and the inverse stay in registers / LDS; HBM sees 12*D bytes per
+// product (f, g in; f*g out) instead of the 36*D of three transform launches plus a pointwise one.  Radix-4 layout:
+// the forward passes leave a lane's values at bit-reversed positions 4mm..4mm+3, exactly where the inverse picks up.
+// `out` may alias `f` or `g` (a wave has read its whole polynomials before it writes).
+// ------------------------------------------------------------------------------------------
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32_t *f, const int32_t *g, int32_t *out, size_t batch,
+                                                                     const double2 *__restrict__ tw2,
+                                                                     const double2 *__restrict__ itw2, FzTwA twA, FzTwA itwA,
+                                                                     FzMod m) {
+    constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
+    static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
+    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = lane / LP, mm = lane % LP;
+    double *region = lds + wave * 256 + p * D;
+    const size_t tasks = (batch + PPW - 1) / PPW;
+    const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave, stride = (size_t)gridDim.x * kWavesPerBlock;
+    if (first >= tasks) return;
+
+    double2 twf[P - 1][3], twi[P - 1][3];
+    fwd4_load_twiddles<LOGD>(twf, tw2, mm);
+    inv4_load_twiddles<LOGD>(twi, itw2, mm);
+
+    for (size_t task = first; task < tasks; task += stride) {
+        const size_t poly = task * PPW + p;
+        const bool valid = poly < batch;
+        const size_t row = (valid ? poly : batch - 1) * D + mm;
+        int xf[4], xg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xf[k] = f[row + k * LP];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xg[k] = g[row + k * LP];
+        double a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = (double)xf[k];
+        fwd4_passes<LOGD, FAST>(a, region, twf, twA, m, mm);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = fz_cent(a[k], m);         // one centred factor keeps the product below 2^66
+        wave_sync();                                                 // g's first-pass writes vs f's last-pass reads
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[k] = (double)xg[k];
+        fwd4_passes<LOGD, FAST>(b, region, twf, twA, m, mm);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[k] = fz_mulmod(a[k], b[k], m);
+        wave_sync();
+        inv4_passes<LOGD, FAST>(b, region, twi, itwA, m, mm);
+        if (valid) {
+            int32_t *dst = out + poly * D + mm;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[k * LP] = (int)fz_cent(b[k], m);
+        }
+        wave_sync();      // the next product's first-pass writes must not overtake this one's last reads
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Fused keygen arithmetic (fusion/fusion.py:363-370), one workgroup per (key, half): every secret row is
 // transformed (radix-4 forward), written to sk_hat, and -- while still in registers -- multiplied by the
 // matching row of the public challenge A and accumulated; the l partial products are reduced through LDS
@@ -894,6 +953,31 @@ int fz_launch_verify_fused(fz_ctx *ctx, const int32_t *A, const int32_t *sig, co
     else return fz_set_error(FZ_E_UNSUPPORTED, "fused verify: degree 64 or 256 only");
 #undef FZ_VF
     return fz_check_hip(hipGetLastError(), "verify_fused launch");
+}
+
+// fused product for degree 64 / 256; the caller composes the generic path for other degrees
+int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int32_t *out, size_t batch) {
+    if (ctx->logd != 6 && ctx->logd != 8) return fz_set_error(FZ_E_UNSUPPORTED, "fused product: degree 64 or 256 only");
+    if (batch == 0) return FZ_OK;
+    const int ppw = 64 / (ctx->degree / 4);
+    const size_t tasks = (batch + ppw - 1) / ppw, blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (ctx->grid_pm == 0) {
+        int n = 0;
+        hipError_t e;
+#define FZ_PQ(LOGD, FAST) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, polymul_fused<LOGD, FAST>, 64 * kWavesPerBlock, 0)
+        if (ctx->logd == 8) { if (ctx->mod.fast) FZ_PQ(8, true); else FZ_PQ(8, false); }
+        else { if (ctx->mod.fast) FZ_PQ(6, true); else FZ_PQ(6, false); }
+#undef FZ_PQ
+        if (e != hipSuccess) return fz_check_hip(e, "occupancy query (polymul)");
+        ctx->grid_pm = (n < 1 ? 1 : n) * ctx->num_cu;
+    }
+    const dim3 grid((unsigned)(blocks < (size_t)ctx->grid_pm ? blocks : (size_t)ctx->grid_pm)), block(64 * kWavesPerBlock);
+#define FZ_PM(LOGD, FAST) hipLaunchKernelGGL((polymul_fused<LOGD, FAST>), grid, block, 0, ctx->stream, f, g, out, batch, \
+                                             (const double2 *)ctx->d_tw2, (const double2 *)ctx->d_itw2, ctx->twA, ctx->itwA, ctx->mod)
+    if (ctx->logd == 8) { if (ctx->mod.fast) FZ_PM(8, true); else FZ_PM(8, false); }
+    else { if (ctx->mod.fast) FZ_PM(6, true); else FZ_PM(6, false); }
+#undef FZ_PM
+    return fz_check_hip(hipGetLastError(), "polymul_fused launch");
 }
 
 int fz_ntt_query_grid(fz_ctx *ctx) {

@@ -67,6 +67,8 @@ SIGNATURES = {
     "fz_pw_mulacc": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fz_pw_binary_host": (c_int, [_ctx, c_int, _i32p, _i32p, _i32p, c_size_t]),
     "fz_pw_mul_bcast": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fz_poly_mul": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fz_poly_mul_host": (c_int, [_ctx, _i32p, _i32p, _i32p, c_size_t]),
     "fz_matvec": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
     "fz_matvec_host": (c_int, [_ctx, _i32p, _i32p, _i32p, c_size_t, c_int]),
     "fz_keygen_core": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),

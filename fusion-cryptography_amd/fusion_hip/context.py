@@ -141,6 +141,10 @@ class Context:
         fn = {OP_MUL: self._lib.fz_pw_mul, OP_ADD: self._lib.fz_pw_add, OP_SUB: self._lib.fz_pw_sub}[op]
         check(self._lib, fn(self._h, c_void_p(d_a), c_void_p(d_b), c_void_p(d_out), count))
 
+    def poly_mul_dev(self, d_f, d_g, d_out, batch):
+        """negacyclic products of `batch` coefficient-domain rows (device pointers; d_out may alias an input)"""
+        check(self._lib, self._lib.fz_poly_mul(self._h, c_void_p(d_f), c_void_p(d_g), c_void_p(d_out), batch))
+
     def pw_neg_dev(self, d_a, d_out, count):
         check(self._lib, self._lib.fz_pw_neg(self._h, c_void_p(d_a), c_void_p(d_out), count))
 
@@ -247,6 +251,15 @@ class Context:
 
     def pw_mul(self, a, b):
         return self._pw(OP_MUL, a, b)
+
+    def poly_mul(self, f, g):
+        """INTT(NTT(f) * NTT(g)) for host rows [batch][degree] (or one row): ntt_poly_mult, ntt.py:380-484"""
+        f, g = _as_i32(f), _as_i32(g)
+        if f.shape != g.shape or f.shape[-1] != self.degree:
+            raise FusionHipError(FZ_E_BADARG, f"shape mismatch {f.shape} vs {g.shape} (degree {self.degree})")
+        out = np.empty_like(f)
+        check(self._lib, self._lib.fz_poly_mul_host(self._h, _p(f), _p(g), _p(out), f.size // self.degree))
+        return out
 
     def pw_add(self, a, b):
         return self._pw(OP_ADD, a, b)

@@ -140,6 +140,15 @@ FZ_API int fz_pw_binary_host(fz_ctx *ctx, int op, const int32_t *h_a, const int3
  * GeneralMatrix.__mul__(element), algebra/matrices.py:109-114 */
 FZ_API int fz_pw_mul_bcast(fz_ctx *ctx, const int32_t *d_a, const int32_t *d_s, int32_t *d_out, size_t rows);
 
+/* ---- negacyclic product of coefficient-domain polynomials ---------------------------------------
+ * out[b] = INTT(NTT(f[b]) (.) NTT(g[b])), centred: ntt_poly_mult (algebra/ntt.py:380-484) and the value of
+ * PolynomialCoefficientRepresentation.__mul__ (algebra/polynomials.py:171-216, schoolbook there).
+ * One launch for degree 64 / 256 (both forward transforms, the product and the inverse stay on chip:
+ * 12*degree bytes of HBM traffic per product); other degrees compose the transform and pointwise kernels.
+ * d_out may alias d_f or d_g.  Rows are [batch][degree], any int32 in, centred out. */
+FZ_API int fz_poly_mul(fz_ctx *ctx, const int32_t *d_f, const int32_t *d_g, int32_t *d_out, size_t batch);
+FZ_API int fz_poly_mul_host(fz_ctx *ctx, const int32_t *h_f, const int32_t *h_g, int32_t *h_out, size_t batch);
+
 /* ---- (1 x l) . (l x 1) polynomial matrix-vector product ------------------------------------
  * GeneralMatrix.__mul__(GeneralMatrix), algebra/matrices.py:115-131, for the only shape the
  * scheme uses (fusion/fusion.py:369-370, :715-717): out[b] = cent(sum_k A[k] (.) S[b][k]).

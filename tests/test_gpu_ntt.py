@@ -164,3 +164,39 @@ def test_graph_capture_replays_a_recorded_sequence(coracle):
     for b in (dx, dy, dz):
         b.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("d", [4, 16, 32, 64, 128, 256])
+def test_poly_mul_matches_transform_composition(d, coracle, monkeypatch):
+    """fz_poly_mul (fused kernel at d = 64 / 256, composed launches otherwise) == INTT(NTT f * NTT g) of the oracle,
+    on edge rows and ragged seeded batches, in place, and equal to the unfused path"""
+    import fusion_hip
+    root = _root_for(Q, d)
+    inv_root = pow(root, Q - 2, Q)
+    ctx = fusion_hip.Context(Q, d, root, inv_root)
+    edge = _edge_rows(d, Q)
+    for rows, seed in ((len(edge), None), (1, 3), (5, 4), (1003, 5)):
+        f = edge if seed is None else O.splitmix_centered(seed, rows * d).reshape(rows, d)
+        g = edge[::-1].copy() if seed is None else O.splitmix_centered(seed + 100, rows * d).reshape(rows, d)
+        want = coracle.ntt_inverse(coracle.pw_mul(coracle.ntt_forward(f, Q, root), coracle.ntt_forward(g, Q, root), Q),
+                                   Q, inv_root)
+        assert np.array_equal(ctx.poly_mul(f, g), want)
+        # device pointers, output aliasing the first input
+        df, dg = fusion_hip.DeviceBuffer.from_numpy(ctx, f), fusion_hip.DeviceBuffer.from_numpy(ctx, g)
+        ctx.poly_mul_dev(df.ptr, dg.ptr, df.ptr, rows)
+        assert np.array_equal(ctx.d2h(np.empty_like(f), df.ptr), want)
+        df.free(); dg.free()
+    if d in (64, 256):
+        monkeypatch.setenv("FZ_POLYMUL_UNFUSED", "1")
+        f = O.splitmix_centered(8, 77 * d).reshape(77, d)
+        g = O.splitmix_centered(9, 77 * d).reshape(77, d)
+        unfused = ctx.poly_mul(f, g)
+        monkeypatch.delenv("FZ_POLYMUL_UNFUSED")
+        assert np.array_equal(ctx.poly_mul(f, g), unfused)
+    # x * 1 = cent(x); x * X = negacyclic shift
+    one = np.zeros((1, d), np.int32); one[0, 0] = 1
+    xs = O.splitmix_centered(11, d).reshape(1, d)
+    assert np.array_equal(ctx.poly_mul(xs, one), xs)
+    X = np.zeros((1, d), np.int32); X[0, 1] = 1
+    assert np.array_equal(ctx.poly_mul(xs, X)[0], np.concatenate([-xs[0, -1:], xs[0, :-1]]))
+    ctx.close()

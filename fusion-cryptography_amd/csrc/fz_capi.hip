@@ -77,6 +77,35 @@ int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out) {
     return FZ_OK;
 }
 
+int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, double **part, int **state) {
+    const size_t need = groups * doubles_per_group;
+    if (need > ctx->vpart_doubles || groups > ctx->vstate_groups) {
+        if (ctx->capturing)
+            return fz_set_error(FZ_E_BADARG, "verify scratch would grow during graph capture: run the sequence once before fz_graph_begin");
+        FZ_HIP(hipStreamSynchronize(ctx->stream), "verify scratch sync");
+        if (need > ctx->vpart_doubles) {
+            if (ctx->d_vpart) FZ_HIP(hipFree(ctx->d_vpart), "verify scratch free");
+            ctx->d_vpart = nullptr;
+            ctx->vpart_doubles = 0;
+            FZ_HIP(hipMalloc((void **)&ctx->d_vpart, (need + need / 4) * sizeof(double)), "verify scratch alloc");
+            FZ_HIP(hipMemset(ctx->d_vpart, 0, (need + need / 4) * sizeof(double)), "verify scratch clear");
+            ctx->vpart_doubles = need + need / 4;
+        }
+        if (groups > ctx->vstate_groups) {
+            if (ctx->d_vstate) FZ_HIP(hipFree(ctx->d_vstate), "verify state free");
+            ctx->d_vstate = nullptr;
+            ctx->vstate_groups = 0;
+            const size_t cap = groups + groups / 4 + 16;
+            FZ_HIP(hipMalloc((void **)&ctx->d_vstate, cap * 2 * sizeof(int)), "verify state alloc");
+            FZ_HIP(hipMemset(ctx->d_vstate, 0, cap * 2 * sizeof(int)), "verify state clear");
+            ctx->vstate_groups = cap;
+        }
+    }
+    *part = ctx->d_vpart;
+    *state = ctx->d_vstate;
+    return FZ_OK;
+}
+
 extern "C" {
 
 const char *fz_version(void) { return "fusion_hip 0.1.0 (gfx950)"; }
@@ -259,6 +288,8 @@ int fz_ctx_destroy(fz_ctx *ctx) {
         free(ctx->prof_ev);
         free(ctx->prof_kind);
     }
+    if (ctx->d_vpart) (void)hipFree(ctx->d_vpart);
+    if (ctx->d_vstate) (void)hipFree(ctx->d_vstate);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     free(ctx->h_tw);
@@ -583,6 +614,20 @@ int fz_aggregate_partial_batch(fz_ctx *ctx, const int32_t *d_sig, const int32_t 
     return fz_launch_aggregate(ctx, d_sig, d_alpha_hat, d_partial, partial_stride, nullptr, groups, N, l);
 }
 
+int fz_aggregate_target_partial_batch(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, const int32_t *d_vkL,
+                                      const int32_t *d_vkR, const int32_t *d_c_hat, int64_t *d_partial, size_t partial_stride,
+                                      int64_t *d_target_partial, size_t target_stride, size_t groups, size_t N, int l) {
+    FZ_REQUIRE(ctx && l >= 1 && d_partial && d_target_partial, "bad argument");
+    FZ_REQUIRE(N == 0 || groups == 0 || (d_sig && d_alpha_hat && d_vkL && d_vkR && d_c_hat), "NULL argument");
+    FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large for exact int64/fp64 accumulation (< 2^21)", N);
+    FZ_REQUIRE(groups <= 65535 && (groups <= 1 || (partial_stride >= (size_t)l * ctx->degree && target_stride >= (size_t)ctx->degree)),
+               "bad groups / strides");
+    FZ_REQUIRE((((uintptr_t)d_vkL | (uintptr_t)d_vkR | (uintptr_t)d_c_hat | (uintptr_t)d_alpha_hat | (uintptr_t)d_sig) & 15) == 0,
+               "inputs must be 16-byte aligned");
+    return fz_launch_aggregate(ctx, d_sig, d_alpha_hat, d_partial, partial_stride, nullptr, groups, N, l, d_vkL, d_vkR, d_c_hat,
+                               d_target_partial, target_stride);
+}
+
 int fz_aggregate_partial(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, int64_t *d_partial,
                          size_t N, int l) {
     return fz_aggregate_partial_batch(ctx, d_sig, d_alpha_hat, d_partial, 0, 1, N, l);
@@ -672,6 +717,19 @@ int fz_verify_with_target_batch_async(fz_ctx *ctx, const int32_t *d_A, const int
     if (ctx->logd != 6 && ctx->logd != 8)
         return fz_set_error(FZ_E_UNSUPPORTED, "asynchronous verification needs the fused kernel (degree 64 or 256)");
     return fz_launch_verify_fused(ctx, d_A, d_sig, d_target, groups, l, beta_vf, omega_vf, d_verdicts);
+}
+
+int fz_verify_partials_batch_async(fz_ctx *ctx, const int32_t *d_A, const int64_t *d_partial, size_t partial_stride,
+                                   const int64_t *d_target_partial, size_t target_stride, size_t groups, int l,
+                                   int64_t beta_vf, int64_t omega_vf, int *d_verdicts) {
+    FZ_REQUIRE(ctx && l >= 1 && groups >= 1 && groups <= 65535 && d_A && d_partial && d_target_partial && d_verdicts, "bad argument");
+    FZ_REQUIRE(groups == 1 || (partial_stride >= (size_t)l * ctx->degree && target_stride >= (size_t)ctx->degree), "bad strides");
+    FZ_REQUIRE((((uintptr_t)d_partial | (uintptr_t)d_target_partial | (uintptr_t)d_A) & 15) == 0 && (partial_stride & 1) == 0,
+               "partials must be 16-byte aligned");
+    if (ctx->logd != 6 && ctx->logd != 8)
+        return fz_set_error(FZ_E_UNSUPPORTED, "verification from int64 partials needs the fused kernel (degree 64 or 256)");
+    return fz_launch_verify_fused_i64(ctx, d_A, d_partial, partial_stride, d_target_partial, target_stride, groups, l, beta_vf,
+                                      omega_vf, d_verdicts);
 }
 
 int fz_verify_with_target(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const int32_t *d_target, int l,

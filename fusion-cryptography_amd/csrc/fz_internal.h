@@ -50,6 +50,11 @@ struct fz_ctx {
     hipEvent_t *prof_ev;         // 2 * prof_cap events
     unsigned char *prof_kind;    // 0 forward, 1 inverse
     int capturing;               // between fz_graph_begin and fz_graph_end: nothing may allocate or synchronise
+    // fused verification: per-aggregate fp64 accumulators of `observed` [groups][degree] and state words
+    // (arrival / failure counts); all zero between launches -- the kernel re-arms them itself
+    double *d_vpart;
+    int *d_vstate;
+    size_t vpart_doubles, vstate_groups;
 };
 
 struct fz_graph {
@@ -62,7 +67,8 @@ struct fz_graph {
 int fz_set_error(int code, const char *fmt, ...);
 int fz_check_hip(hipError_t e, const char *what);
 int fz_scratch(fz_ctx *ctx, size_t bytes, void **out);
-int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out);   // second, independent scratch (per-split partial sums)
+int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out);
+int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, double **part, int **state);   // second, independent scratch (per-split partial sums)
 
 // launchers (fz_ntt.hip)
 int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse);
@@ -71,6 +77,8 @@ int fz_ntt_query_grid(fz_ctx *ctx);
 int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int32_t *out, size_t batch);
 int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,
                            int l);
+int fz_launch_verify_fused_i64(fz_ctx *ctx, const int32_t *A, const int64_t *sig, size_t sig_stride, const int64_t *target,
+                               size_t target_stride, size_t groups, int l, int64_t beta, int64_t omega, int *d_verdict);
 int fz_launch_verify_fused(fz_ctx *ctx, const int32_t *A, const int32_t *sig, const int32_t *target, size_t groups, int l,
                            int64_t beta, int64_t omega, int *d_verdict);
 
@@ -81,7 +89,8 @@ int fz_launch_pw_bcast(fz_ctx *ctx, const int32_t *a, const int32_t *s, int32_t 
 int fz_launch_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *out, size_t batch, int l);
 int fz_launch_sign(fz_ctx *ctx, const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig, size_t batch, int l);
 int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *out64, size_t pstride,
-                        int32_t *out32, size_t groups, size_t N, int l);
+                        int32_t *out32, size_t groups, size_t N, int l, const int32_t *vkL = nullptr,
+                        const int32_t *vkR = nullptr, const int32_t *c = nullptr, int64_t *tout64 = nullptr, size_t tstride = 0);
 int fz_launch_target_partial(fz_ctx *ctx, const int32_t *vkL, const int32_t *vkR, const int32_t *c, const int32_t *alpha,
                              int64_t *partial, size_t pstride, size_t groups, size_t N);
 int fz_launch_reduce_i64(fz_ctx *ctx, const int64_t *in, int32_t *out, size_t count);

@@ -693,29 +693,49 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused verification of one aggregate per workgroup (fusion/fusion.py:690-727): sigma is read ONCE.
-// While a row of sigma is in registers it feeds both (a) observed += A[k] (.) sigma[k] and (b) the radix-4
-// inverse transform, whose centred outputs are only reduced (max |x| per aggregate, weight per row) and
-// never stored.  Then observed is compared with the target and the reference's verdict order applied
-// (target mismatch, norm, weight).  16 waves per workgroup share the l rows.
+// Fused verification (fusion/fusion.py:690-727): sigma is read ONCE.  While a row of sigma is in registers it
+// feeds both (a) observed += A[k] (.) sigma[k] and (b) the radix-4 inverse transform, whose centred outputs are
+// only reduced (max |x| per aggregate, weight per row) and never stored.  The l rows of one aggregate are spread
+// over gridDim.x workgroups (a single aggregate -- the common call -- would otherwise occupy one CU): each
+// adds its exact partial of `observed` into the aggregate's accumulator and counts itself (and its norm / weight
+// failures) in the aggregate's state word; the workgroup that arrives last compares with the target, applies the
+// reference's verdict order (target mismatch, norm, weight) and re-arms accumulator and state for the next launch.
 // ------------------------------------------------------------------------------------------
-constexpr int kVerifyWaves = 16;
+constexpr int kVerifyWaves = 4;
 
-template <int LOGD, bool FAST>
-__global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t *A, const int32_t *sig,
-                                                                  const int32_t *target, int l, long long beta,
+// 4 consecutive stored values as doubles: int32 rows as they are (any int32), int64 rows -- exact partial sums
+// straight from the cross-GPU all-reduce -- centred on load
+__device__ __forceinline__ void load4_any(const int32_t *p, double (&a)[4], const FzMod &) {
+    const int4 x = *reinterpret_cast<const int4 *>(p);
+    a[0] = (double)x.x; a[1] = (double)x.y; a[2] = (double)x.z; a[3] = (double)x.w;
+}
+__device__ __forceinline__ void load4_any(const int64_t *p, double (&a)[4], const FzMod &m) {
+    const longlong2 lo = reinterpret_cast<const longlong2 *>(p)[0], hi = reinterpret_cast<const longlong2 *>(p)[1];
+    a[0] = fz_cent_wide((double)lo.x, m); a[1] = fz_cent_wide((double)lo.y, m);
+    a[2] = fz_cent_wide((double)hi.x, m); a[3] = fz_cent_wide((double)hi.y, m);
+}
+__device__ __forceinline__ int centred_any(int32_t v, const FzMod &) { return v; }
+__device__ __forceinline__ int centred_any(int64_t v, const FzMod &m) { return (int)fz_cent_wide((double)v, m); }
+
+template <int LOGD, bool FAST, typename T>
+__global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t *A, const T *sig, size_t sig_stride,
+                                                                  const T *target, size_t target_stride, int l, long long beta,
                                                                   long long omega, const double2 *__restrict__ itw2,
-                                                                  FzTwA twA, FzMod m, int *verdict) {
+                                                                  FzTwA twA, FzMod m, double *part, int *state, int *verdict) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
+    static_assert(D <= 64 * kVerifyWaves, "one thread per coefficient in the combine steps");
     __shared__ __attribute__((aligned(16))) double lds[kVerifyWaves * 256 * 2];
-    __shared__ int s_flags;
+    __shared__ int s_flags, s_last;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane / LP, mm = lane % LP;
     double *region = lds + wave * 256 + p * D;
     double *accbuf = lds + kVerifyWaves * 256;
     if (threadIdx.x == 0) s_flags = 0;
-    sig += (size_t)blockIdx.x * l * D;
-    target += (size_t)blockIdx.x * D;
+    const int R = gridDim.x, r = blockIdx.x, g = blockIdx.y;
+    sig += (size_t)g * sig_stride;
+    target += (size_t)g * target_stride;
+    part += (size_t)g * D;                          // [groups][D] exact fp64 sums of `observed`, zero between launches
+    state += g;                                     // arrivals (bits 0-15), norm failures (16-23), weight failures (24-31)
 
     double2 twl[LOGD / 2 - 1][3];
     inv4_load_twiddles<LOGD>(twl, itw2, mm);
@@ -723,13 +743,13 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
     double acc[4] = {0, 0, 0, 0};
     int mx = 0, wfail = 0;
     const int tasks = (l + PPW - 1) / PPW;
-    for (int task = wave; task < tasks; task += kVerifyWaves) {
+    for (int task = r * kVerifyWaves + wave; task < tasks; task += R * kVerifyWaves) {
         const int row = task * PPW + p;
         const bool valid = row < l;
         const size_t off = (size_t)(valid ? row : l - 1) * D + 4 * mm;
-        const int4 x = *reinterpret_cast<const int4 *>(sig + off);
         const int4 ak = *reinterpret_cast<const int4 *>(A + off);
-        double a[4] = {(double)x.x, (double)x.y, (double)x.z, (double)x.w};
+        double a[4];
+        load4_any(sig + off, a, m);
         if (valid) {
             acc[0] += fz_mulmod(a[0], (double)ak.x, m);
             acc[1] += fz_mulmod(a[1], (double)ak.y, m);
@@ -756,17 +776,39 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
     if ((long long)mx > beta) atomicOr(&s_flags, 2);
     if (wfail) atomicOr(&s_flags, 4);
     __syncthreads();
+    // Cross-workgroup combine WITHOUT device-scope fences (a __threadfence() is an L2 write-back on this chip: several
+    // microseconds each, serialised over the workgroups).  Everything shared travels in device-scope atomics, which
+    // are performed at the memory side: exact fp64 adds of integer partials (|.| < l * q < 2^53, order-independent),
+    // then ONE integer add that counts the arrival and the norm / weight failures.  A returning atomic has been
+    // performed when its result is back, so "data before arrival" needs no fence.
     if (threadIdx.x < D) {
         double sum = 0;
         for (int w = 0; w < kVerifyWaves; ++w)
 #pragma unroll
             for (int q = 0; q < PPW; ++q) sum += accbuf[w * 256 + q * D + threadIdx.x];
-        if ((int)fz_cent(sum, m) != target[threadIdx.x]) atomicOr(&s_flags, 1);   // both centred: equal <=> equal mod q
+        const double before = __hip_atomic_fetch_add(part + threadIdx.x, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        region[0] = before;                         // consume the result: the add is complete before the barrier below
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int f = s_flags;
-        verdict[blockIdx.x] = (f & 1) ? FZ_VERDICT_TARGET_MISMATCH : ((f & 2) ? FZ_VERDICT_NORM : ((f & 4) ? FZ_VERDICT_WEIGHT : FZ_VERDICT_OK));
+        const unsigned inc = 1u + ((f & 2) ? (1u << 16) : 0u) + ((f & 4) ? (1u << 24) : 0u);
+        const unsigned old = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(state), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned now = old + inc;
+        s_last = ((old & 0xffffu) == (unsigned)(R - 1));
+        s_flags = (((now >> 16) & 0xffu) ? 2 : 0) | ((now >> 24) ? 4 : 0);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < D) {                          // read and re-arm in one operation
+        const double sum = __hip_atomic_exchange(part + threadIdx.x, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)fz_cent_wide(sum, m) != centred_any(target[threadIdx.x], m)) atomicOr(&s_flags, 1);   // both centred
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_exchange(reinterpret_cast<unsigned *>(state), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int f = s_flags;
+        verdict[g] = (f & 1) ? FZ_VERDICT_TARGET_MISMATCH : ((f & 2) ? FZ_VERDICT_NORM : ((f & 4) ? FZ_VERDICT_WEIGHT : FZ_VERDICT_OK));
     }
 }
 
@@ -943,16 +985,43 @@ int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, i
     return fz_check_hip(hipGetLastError(), "keygen_fused launch");
 }
 
-int fz_launch_verify_fused(fz_ctx *ctx, const int32_t *A, const int32_t *sig, const int32_t *target, size_t groups, int l,
-                           int64_t beta, int64_t omega, int *d_verdict) {
-    const dim3 grid((unsigned)groups), block(64 * kVerifyWaves);
-#define FZ_VF(LOGD, FAST) hipLaunchKernelGGL((verify_fused<LOGD, FAST>), grid, block, 0, ctx->stream, A, sig, target, l, \
-                                             (long long)beta, (long long)omega, (const double2 *)ctx->d_itw2, ctx->itwA, ctx->mod, d_verdict)
+template <typename T>
+static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size_t sig_stride, const T *target,
+                               size_t target_stride, size_t groups, int l, int64_t beta, int64_t omega, int *d_verdict) {
+    if (ctx->logd != 6 && ctx->logd != 8) return fz_set_error(FZ_E_UNSUPPORTED, "fused verify: degree 64 or 256 only");
+    // about one row per wave while that leaves the chip under-filled (measured: one aggregate 22 us with one workgroup,
+    // 4.5 us with 21; 64 aggregates 9.2 us with 4-8 workgroups each, 14.6 us with 22)
+    const int ppw = 64 / (ctx->degree / 4), tasks = (l + ppw - 1) / ppw;
+    int R = (tasks + kVerifyWaves - 1) / kVerifyWaves;
+    const int fill = (int)((size_t)ctx->num_cu * 2 / groups);
+    if (R > fill) R = fill;
+    if (const char *e = getenv("FZ_VERIFY_BLOCKS")) R = atoi(e);      // benchmarking knob
+    if (R < 1) R = 1;
+    if (R > 64) R = 64;
+    double *part = nullptr;
+    int *state = nullptr;
+    int rc = fz_verify_scratch(ctx, groups, (size_t)ctx->degree, &part, &state);
+    if (rc != FZ_OK) return rc;
+    const dim3 grid((unsigned)R, (unsigned)groups), block(64 * kVerifyWaves);
+#define FZ_VF(LOGD, FAST) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T>), grid, block, 0, ctx->stream, A, sig, sig_stride, target, \
+                                             target_stride, l, (long long)beta, (long long)omega, (const double2 *)ctx->d_itw2, \
+                                             ctx->itwA, ctx->mod, part, state, d_verdict)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_VF(8, true); else FZ_VF(8, false); }
-    else if (ctx->logd == 6) { if (ctx->mod.fast) FZ_VF(6, true); else FZ_VF(6, false); }
-    else return fz_set_error(FZ_E_UNSUPPORTED, "fused verify: degree 64 or 256 only");
+    else { if (ctx->mod.fast) FZ_VF(6, true); else FZ_VF(6, false); }
 #undef FZ_VF
     return fz_check_hip(hipGetLastError(), "verify_fused launch");
+}
+
+int fz_launch_verify_fused(fz_ctx *ctx, const int32_t *A, const int32_t *sig, const int32_t *target, size_t groups, int l,
+                           int64_t beta, int64_t omega, int *d_verdict) {
+    return launch_verify_fused<int32_t>(ctx, A, sig, (size_t)l * ctx->degree, target, (size_t)ctx->degree, groups, l, beta, omega,
+                                        d_verdict);
+}
+
+// the aggregates and targets as int64 partial sums (e.g. straight after the all-reduce), group g at base + g * stride
+int fz_launch_verify_fused_i64(fz_ctx *ctx, const int32_t *A, const int64_t *sig, size_t sig_stride, const int64_t *target,
+                               size_t target_stride, size_t groups, int l, int64_t beta, int64_t omega, int *d_verdict) {
+    return launch_verify_fused<int64_t>(ctx, A, sig, sig_stride, target, target_stride, groups, l, beta, omega, d_verdict);
 }
 
 // fused product for degree 64 / 256; the caller composes the generic path for other degrees

@@ -173,44 +173,65 @@ __device__ __forceinline__ void atomic_add_i64(int64_t *p, double v) {
 //   pass 1  split[g][s][k][j] = sum_{i in split s} sig[g][i][k][j] * alpha[g][i][j]   (fp64-lazy, each product
 //           reduced to ~q/2; |sum| < 2^53)  -- grid.x columns of 4 coefficients, grid.y splits, grid.z groups
 //   pass 2  partial[g][e] = sum_s split[g][s][e]  as int64 (for the cross-GPU all-reduce) or centred int32
-__global__ __launch_bounds__(kBlock) void aggregate_split_kernel(const int32_t *sig, const int32_t *alpha, double *split,
+__global__ __launch_bounds__(kBlock) void aggregate_split_kernel(const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
+                                                                 const int32_t *vkR, const int32_t *c, double *split,
                                                                  size_t N, int l, int degree, FzMod m) {
+    // columns [0, l*d/4): the aggregate; with vkL != nullptr the next d/4 columns accumulate the verification
+    // target sum_i (vkL_i*c_i + vkR_i)*alpha_i (fusion.py:706-714) in the same pass over the signers
     const int d4 = degree / 4;
-    const size_t cols = (size_t)l * d4;
+    const size_t cols_a = (size_t)l * d4, cols = cols_a + (vkL ? d4 : 0);
     const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= cols) return;
-    const int j4 = (int)(col % d4);
     const size_t g = blockIdx.z;
-    sig += g * N * (size_t)l * degree;
     alpha += g * N * (size_t)degree;
     const size_t per = (N + gridDim.y - 1) / gridDim.y;
     const size_t i0 = (size_t)blockIdx.y * per;
     const size_t i1 = (i0 + per < N) ? i0 + per : N;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (col < cols_a) {
+        const int j4 = (int)(col % d4);
+        sig += g * N * (size_t)l * degree;
 #pragma unroll 8
-    for (size_t i = i0; i < i1; ++i) {
-        int4 x = reinterpret_cast<const int4 *>(sig + i * (size_t)l * degree)[col];
-        int4 a = reinterpret_cast<const int4 *>(alpha + i * (size_t)degree)[j4];
-        s0 += fz_mulmod((double)x.x, (double)a.x, m);
-        s1 += fz_mulmod((double)x.y, (double)a.y, m);
-        s2 += fz_mulmod((double)x.z, (double)a.z, m);
-        s3 += fz_mulmod((double)x.w, (double)a.w, m);
+        for (size_t i = i0; i < i1; ++i) {
+            int4 x = reinterpret_cast<const int4 *>(sig + i * (size_t)l * degree)[col];
+            int4 a = reinterpret_cast<const int4 *>(alpha + i * (size_t)degree)[j4];
+            s0 += fz_mulmod((double)x.x, (double)a.x, m);
+            s1 += fz_mulmod((double)x.y, (double)a.y, m);
+            s2 += fz_mulmod((double)x.z, (double)a.z, m);
+            s3 += fz_mulmod((double)x.w, (double)a.w, m);
+        }
+    } else {
+        const size_t j4 = col - cols_a, goff = g * N * (size_t)degree;
+#pragma unroll 4
+        for (size_t i = i0; i < i1; ++i) {
+            const size_t o = (goff + i * (size_t)degree) / 4 + j4;
+            int4 L = reinterpret_cast<const int4 *>(vkL)[o], R = reinterpret_cast<const int4 *>(vkR)[o];
+            int4 ch = reinterpret_cast<const int4 *>(c)[o];
+            int4 a = reinterpret_cast<const int4 *>(alpha + i * (size_t)degree)[j4];
+            s0 += fz_mulmod(fz_mulmod((double)L.x, (double)ch.x, m) + (double)R.x, (double)a.x, m);   // |inner| < 2^32
+            s1 += fz_mulmod(fz_mulmod((double)L.y, (double)ch.y, m) + (double)R.y, (double)a.y, m);
+            s2 += fz_mulmod(fz_mulmod((double)L.z, (double)ch.z, m) + (double)R.z, (double)a.z, m);
+            s3 += fz_mulmod(fz_mulmod((double)L.w, (double)ch.w, m) + (double)R.w, (double)a.w, m);
+        }
     }
     double2 *dst = reinterpret_cast<double2 *>(split + ((g * gridDim.y + blockIdx.y) * cols + col) * 4);
     dst[0] = make_double2(s0, s1);
     dst[1] = make_double2(s2, s3);
 }
 
+// pass 2: elements [0, count_a) of each group go to the aggregate output, the rest (the target columns) to tout64
 template <bool CENTRE>
-__global__ __launch_bounds__(kBlock) void sum_splits_kernel(const double *split, size_t splits, size_t count,
-                                                            int64_t *out64, size_t pstride, int32_t *out32, FzMod m) {
+__global__ __launch_bounds__(kBlock) void sum_splits_kernel(const double *split, size_t splits, size_t count, size_t count_a,
+                                                            int64_t *out64, size_t pstride, int64_t *tout64, size_t tstride,
+                                                            int32_t *out32, FzMod m) {
     const size_t g = blockIdx.z;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const double *base = split + g * splits * count;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
         double s = 0;
         for (size_t t = 0; t < splits; ++t) s += base[t * count + e];
-        if (CENTRE) out32[g * count + e] = (int)fz_cent_wide(s, m);
+        if (e >= count_a) tout64[g * tstride + (e - count_a)] = (int64_t)s;
+        else if (CENTRE) out32[g * count_a + e] = (int)fz_cent_wide(s, m);
         else out64[g * pstride + e] = (int64_t)s;
     }
 }
@@ -363,12 +384,15 @@ static unsigned split_count(fz_ctx *ctx, size_t N, unsigned gx, size_t groups, s
     return (unsigned)want;
 }
 
-// out64 != nullptr: int64 partial sums at out64 + g*pstride; else centred int32 at out32 + g*l*degree
+// out64 != nullptr: int64 partial sums at out64 + g*pstride; else centred int32 at out32 + g*l*degree.
+// vkL != nullptr: the verification target's int64 partial sums go to tout64 + g*tstride in the same two launches.
 int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *out64, size_t pstride,
-                        int32_t *out32, size_t groups, size_t N, int l) {
+                        int32_t *out32, size_t groups, size_t N, int l, const int32_t *vkL, const int32_t *vkR,
+                        const int32_t *c, int64_t *tout64, size_t tstride) {
     if (ctx->degree < 4) return fz_set_error(FZ_E_UNSUPPORTED, "aggregate needs degree >= 4");
     if (groups == 0) return FZ_OK;
-    const size_t cols = (size_t)l * (ctx->degree / 4), count = cols * 4;
+    const size_t cols_a = (size_t)l * (ctx->degree / 4), cols = cols_a + (vkL ? ctx->degree / 4 : 0);
+    const size_t count = cols * 4, count_a = cols_a * 4;
     const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);
     // ~4 blocks per CU over all groups, at least 8 signatures per thread
     size_t splits = ((size_t)ctx->num_cu * 4 + gx * groups - 1) / (gx * groups);
@@ -379,16 +403,16 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
     int rc = fz_scratch2(ctx, groups * splits * count * sizeof(double), &scr);
     if (rc != FZ_OK) return rc;
     hipLaunchKernelGGL(aggregate_split_kernel, dim3(gx, (unsigned)splits, (unsigned)groups), dim3(kBlock), 0, ctx->stream,
-                       sig, alpha, (double *)scr, N, l, ctx->degree, ctx->mod);
+                       sig, alpha, vkL, vkR, c, (double *)scr, N, l, ctx->degree, ctx->mod);
     rc = fz_check_hip(hipGetLastError(), "aggregate launch");
     if (rc != FZ_OK) return rc;
     const dim3 grid2(grid_for(ctx, count, 2), 1, (unsigned)groups);
     if (out64)
         hipLaunchKernelGGL(sum_splits_kernel<false>, grid2, dim3(kBlock), 0, ctx->stream, (const double *)scr, splits, count,
-                           out64, pstride, (int32_t *)nullptr, ctx->mod);
+                           count_a, out64, pstride, tout64, tstride, (int32_t *)nullptr, ctx->mod);
     else
         hipLaunchKernelGGL(sum_splits_kernel<true>, grid2, dim3(kBlock), 0, ctx->stream, (const double *)scr, splits, count,
-                           (int64_t *)nullptr, (size_t)0, out32, ctx->mod);
+                           count_a, (int64_t *)nullptr, (size_t)0, tout64, tstride, out32, ctx->mod);
     return fz_check_hip(hipGetLastError(), "aggregate sum launch");
 }
 

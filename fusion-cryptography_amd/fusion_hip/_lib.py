@@ -76,6 +76,10 @@ SIGNATURES = {
     "fz_aggregate_core": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
     "fz_aggregate_partial": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
     "fz_aggregate_partial_batch": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_int]),
+    "fz_aggregate_target_partial_batch": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                  c_void_p, c_size_t, c_size_t, c_size_t, c_int]),
+    "fz_verify_partials_batch_async": (c_int, [_ctx, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_int,
+                                               c_int64, c_int64, c_void_p]),
     "fz_target_partial_batch": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t]),
     "fz_verify_with_target_batch": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int64, c_int64,
                                             POINTER(c_int)]),

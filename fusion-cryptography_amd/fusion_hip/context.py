@@ -180,6 +180,20 @@ class Context:
         check(self._lib, self._lib.fz_aggregate_partial_batch(self._h, c_void_p(d_sig), c_void_p(d_alpha),
                                                               c_void_p(d_partial), partial_stride, groups, N, l))
 
+    def aggregate_target_partial_batch_dev(self, d_sig, d_alpha, d_vkL, d_vkR, d_c, d_partial, partial_stride,
+                                           d_target_partial, target_stride, groups, N, l):
+        """aggregate partials and the verification target's partials in one pass over the signers"""
+        check(self._lib, self._lib.fz_aggregate_target_partial_batch(
+            self._h, c_void_p(d_sig), c_void_p(d_alpha), c_void_p(d_vkL), c_void_p(d_vkR), c_void_p(d_c),
+            c_void_p(d_partial), partial_stride, c_void_p(d_target_partial), target_stride, groups, N, l))
+
+    def verify_partials_batch_async_dev(self, d_A, d_partial, partial_stride, d_target_partial, target_stride, groups, l,
+                                        beta_vf, omega_vf, d_verdicts):
+        """verdict codes straight from int64 partial sums (asynchronous, verdicts stay on the device)"""
+        check(self._lib, self._lib.fz_verify_partials_batch_async(
+            self._h, c_void_p(d_A), c_void_p(d_partial), partial_stride, c_void_p(d_target_partial), target_stride,
+            groups, l, beta_vf, omega_vf, c_void_p(d_verdicts)))
+
     def target_partial_batch_dev(self, d_vkL, d_vkR, d_c, d_alpha, d_partial, partial_stride, groups, N):
         check(self._lib, self._lib.fz_target_partial_batch(self._h, c_void_p(d_vkL), c_void_p(d_vkR), c_void_p(d_c),
                                                            c_void_p(d_alpha), c_void_p(d_partial), partial_stride,

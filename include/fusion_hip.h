@@ -182,6 +182,14 @@ FZ_API int fz_aggregate_partial(fz_ctx *ctx, const int32_t *d_sig, const int32_t
  * partial of group g at d_partial + g * partial_stride (int64 elements). */
 FZ_API int fz_aggregate_partial_batch(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat,
                                       int64_t *d_partial, size_t partial_stride, size_t groups, size_t N, int l);
+/* aggregate partials AND the verification target's partials (fusion.py:706-714) in one pass over the signers
+ * (two launches instead of five): vkL, vkR, c_hat [groups][N][degree]; target partial of group g at
+ * d_target_partial + g * target_stride.  All inputs 16-byte aligned. */
+FZ_API int fz_aggregate_target_partial_batch(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat,
+                                             const int32_t *d_vkL, const int32_t *d_vkR, const int32_t *d_c_hat,
+                                             int64_t *d_partial, size_t partial_stride,
+                                             int64_t *d_target_partial, size_t target_stride,
+                                             size_t groups, size_t N, int l);
 /* target partial for verify: sum_i (vkL_i (.) c_i + vkR_i) (.) alpha_i as int64 [degree] */
 FZ_API int fz_target_partial(fz_ctx *ctx, const int32_t *d_vkL, const int32_t *d_vkR,
                              const int32_t *d_c_hat, const int32_t *d_alpha_hat,
@@ -204,6 +212,13 @@ FZ_API int fz_verify_with_target(fz_ctx *ctx, const int32_t *d_A, const int32_t 
 FZ_API int fz_verify_with_target_batch(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig,
                                        const int32_t *d_target, size_t groups, int l,
                                        int64_t beta_vf, int64_t omega_vf, int *h_verdicts);
+
+/* verification straight from int64 partial sums (what the all-reduce leaves): aggregate g at d_partial +
+ * g * partial_stride, its target at d_target_partial + g * target_stride; values are centred on load, so no
+ * fz_reduce_i64 pass and no int32 copy of the aggregate is needed.  Asynchronous; degree 64 or 256. */
+FZ_API int fz_verify_partials_batch_async(fz_ctx *ctx, const int32_t *d_A, const int64_t *d_partial, size_t partial_stride,
+                                          const int64_t *d_target_partial, size_t target_stride, size_t groups, int l,
+                                          int64_t beta_vf, int64_t omega_vf, int *d_verdicts);
 
 /* the same without the device-to-host copy: verdict codes are written to d_verdicts [groups] on the context's
  * stream and nothing is synchronised (pipelined verification; degree 64 or 256) */

@@ -173,6 +173,33 @@ def test_batched_aggregate_target_verify(coracle):
     assert ctx.verify_with_target_batch_dev(d_A.ptr, d_red.ptr, d_red.ptr + n_agg * 4, G, l, P["beta_vf"], d) == [0, 3, 0]
     assert ctx.verify_with_target_batch_dev(d_A.ptr, d_red.ptr, d_red.ptr + n_agg * 4, G, l, 1, d) == [4, 3, 4]
 
+    # one-pass form: aggregate and target partials from the same two launches == the separate entry points
+    part_sep = d_part.to_numpy(np.int64, (n_agg + n_tgt,))
+    d_part2 = DB(ctx, (n_agg + n_tgt) * 8)
+    ctx.aggregate_target_partial_batch_dev(d_sig.ptr, d_al.ptr, d_vkL.ptr, d_vkR.ptr, d_c.ptr, d_part2.ptr, l * d,
+                                           d_part2.ptr + n_agg * 8, d, G, N, l)
+    part_one = d_part2.to_numpy(np.int64, (n_agg + n_tgt,))
+    half = q // 2
+    assert np.array_equal((part_one + half) % q, (part_sep + half) % q)       # equal as residues (split points differ)
+    assert np.array_equal(((part_one[:n_agg] + half) % q - half).astype(np.int32).reshape(G, l, d), agg)
+    # verdicts straight from int64 sums (also shifted by multiples of q, as an all-reduce over ranks would leave them)
+    d_verd = DB(ctx, G * 4)
+    for shift in (0, 5 * q, -3 * q):
+        ctx.h2d(d_part2.ptr, part_one + shift)
+        ctx.verify_partials_batch_async_dev(d_A.ptr, d_part2.ptr, l * d, d_part2.ptr + n_agg * 8, d, G, l, P["beta_vf"], d,
+                                            d_verd.ptr)
+        assert d_verd.to_numpy(np.int32, (G,)).tolist() == [0, 0, 0]
+    badp = part_one.copy()
+    badp[2 * l * d + 9] += 1                      # last aggregate
+    badp[n_agg + 3] -= 1                          # first aggregate's target
+    ctx.h2d(d_part2.ptr, badp)
+    ctx.verify_partials_batch_async_dev(d_A.ptr, d_part2.ptr, l * d, d_part2.ptr + n_agg * 8, d, G, l, P["beta_vf"], d,
+                                        d_verd.ptr)
+    assert d_verd.to_numpy(np.int32, (G,)).tolist() == [3, 0, 3]
+    ctx.verify_partials_batch_async_dev(d_A.ptr, d_part2.ptr + l * d * 8, l * d, d_part2.ptr + (n_agg + d) * 8, d, G - 1, l,
+                                        P["beta_vf"], d, d_verd.ptr)            # a rank's share: groups 1..2
+    assert d_verd.to_numpy(np.int32, (G,)).tolist()[:2] == [0, 3]
+
 
 @pytest.mark.parametrize("secpar", [128, 256])
 def test_fused_verify_equals_unfused_path(secpar, coracle, monkeypatch):

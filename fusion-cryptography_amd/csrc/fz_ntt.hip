@@ -342,6 +342,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz4(int j) { return j ^ (((j >> 4) & 7) << 2); }
 
+// The waves of the stand-alone radix-4 kernels never talk to each other (wave-private LDS regions, no s_barrier), so
+// they are launched as one-wave workgroups: a 256-thread workgroup has to find four free wave slots on ONE CU before
+// any of its waves starts, which costs 4-5 % at the bench's batch (4.55 us vs 4.77 us per 4096-row launch) and
+// nothing at large batches.  (The fused kernels below share data between waves and keep 4 or more.)
+constexpr int kWaves4 = 1;
+
 // the log4(D) in-place passes of the radix-4 forward transform on one lane's 4 values (natural positions
 // mm + (D/4)k in, bit-reversed-order positions 4mm..4mm+3 out, NOT yet centred)
 template <int LOGD, bool FAST>
@@ -398,11 +404,11 @@ __device__ __forceinline__ void fwd4_load_twiddles(double2 (&twl)[LOGD / 2 - 1][
 }
 
 template <int LOGD, bool FAST>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *in, int32_t *out, size_t batch,
+__global__ __launch_bounds__(64 * kWaves4) void ntt_fwd4(const int32_t *in, int32_t *out, size_t batch,
                                                                 const double2 *__restrict__ tw2, FzTwA twA, FzMod m, unsigned tpb) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
-    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256];
+    __shared__ __attribute__((aligned(16))) double lds[kWaves4 * 256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane / LP, mm = lane % LP;
     double *region = lds + wave * 256 + p * D;
@@ -410,8 +416,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd4(const int32_t *i
     // task -> wave mapping: tpb == 0: persistent grid, tasks strided over the whole batch; tpb > 0: workgroup b
     // owns the contiguous tasks [b*tpb, (b+1)*tpb), its waves interleaved inside (non-persistent launch)
     const size_t all_tasks = (batch + PPW - 1) / PPW;
-    const size_t first = tpb ? (size_t)blockIdx.x * tpb + wave : (size_t)blockIdx.x * kWavesPerBlock + wave;
-    const size_t stride = tpb ? (size_t)kWavesPerBlock : (size_t)gridDim.x * kWavesPerBlock;
+    const size_t first = tpb ? (size_t)blockIdx.x * tpb + wave : (size_t)blockIdx.x * kWaves4 + wave;
+    const size_t stride = tpb ? (size_t)kWaves4 : (size_t)gridDim.x * kWaves4;
     const size_t tasks = tpb ? (((size_t)blockIdx.x + 1) * tpb < all_tasks ? ((size_t)blockIdx.x + 1) * tpb : all_tasks) : all_tasks;
     if (first >= tasks) return;
 
@@ -518,11 +524,11 @@ __device__ __forceinline__ void inv4_load_twiddles(double2 (&twl)[LOGD / 2 - 1][
 }
 
 template <int LOGD, bool FAST>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *in, int32_t *out, size_t batch,
+__global__ __launch_bounds__(64 * kWaves4) void ntt_inv4(const int32_t *in, int32_t *out, size_t batch,
                                                                 const double2 *__restrict__ itw2, FzTwA twA, FzMod m, unsigned tpb) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
-    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256];
+    __shared__ __attribute__((aligned(16))) double lds[kWaves4 * 256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane / LP, mm = lane % LP;
     double *region = lds + wave * 256 + p * D;
@@ -530,8 +536,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv4(const int32_t *i
     // task -> wave mapping: tpb == 0: persistent grid, tasks strided over the whole batch; tpb > 0: workgroup b
     // owns the contiguous tasks [b*tpb, (b+1)*tpb), its waves interleaved inside (non-persistent launch)
     const size_t all_tasks = (batch + PPW - 1) / PPW;
-    const size_t first = tpb ? (size_t)blockIdx.x * tpb + wave : (size_t)blockIdx.x * kWavesPerBlock + wave;
-    const size_t stride = tpb ? (size_t)kWavesPerBlock : (size_t)gridDim.x * kWavesPerBlock;
+    const size_t first = tpb ? (size_t)blockIdx.x * tpb + wave : (size_t)blockIdx.x * kWaves4 + wave;
+    const size_t stride = tpb ? (size_t)kWaves4 : (size_t)gridDim.x * kWaves4;
     const size_t tasks = tpb ? (((size_t)blockIdx.x + 1) * tpb < all_tasks ? ((size_t)blockIdx.x + 1) * tpb : all_tasks) : all_tasks;
     if (first >= tasks) return;
 
@@ -885,7 +891,7 @@ template <int LOGD, bool FAST>
 int launch4f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
     constexpr int PPW = 64 / ((1 << LOGD) / 4);
     const size_t tasks = (batch + PPW - 1) / PPW;
-    const size_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const size_t blocks = (tasks + kWaves4 - 1) / kWaves4;
     const size_t cap = (size_t)(inverse ? ctx->grid_inv4 : ctx->grid_fwd4) * (size_t)ctx->grid_mult;
     unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
     unsigned tpb = 0;
@@ -899,7 +905,7 @@ int launch4f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool in
         e1 = ctx->prof_ev[2 * ctx->prof_n + 1];
         ctx->prof_kind[ctx->prof_n++] = inverse ? 1 : 0;
     }
-    const dim3 block(64 * kWavesPerBlock);
+    const dim3 block(64 * kWaves4);
     if (!inverse)
         hipExtLaunchKernelGGL((ntt_fwd4<LOGD, FAST>), dim3(grid), block, 0, ctx->stream, e0, e1, 0, in, out, batch,
                               (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod, tpb);
@@ -952,7 +958,7 @@ int query16f(fz_ctx *ctx) {
 template <int LOGD, bool FAST>
 int query4f(fz_ctx *ctx) {
     int nf = 0, ni = 0;
-    const int threads = 64 * kWavesPerBlock;
+    const int threads = 64 * kWaves4;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, ntt_fwd4<LOGD, FAST>, threads, 0);
     if (e != hipSuccess) return fz_check_hip(e, "occupancy query (fwd4)");
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&ni, ntt_inv4<LOGD, FAST>, threads, 0);

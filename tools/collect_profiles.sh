@@ -11,6 +11,7 @@ mkdir -p $OUT
 cd $R
 step() { echo "[collect] $*" >&2; "$@" || { echo "[collect] FAILED ($?): $*" >&2; exit 1; }; }
 lscpu | grep -E "Model name|Socket|Thread|Core" > $OUT/${TAG}_host_cpu.txt
+step timeout -k 10 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
 step timeout -k 10 120 ./tools/microbench/build/launch_floor > $OUT/${TAG}_launch_floor.txt 2>&1
 step timeout -k 10 120 ./tools/microbench/build/clock_probe > $OUT/${TAG}_clock_probe.txt 2>&1
 step timeout -k 10 300 python tools/quick_bench.py > $OUT/${TAG}_ntt_batch_sweep.txt 2>&1

@@ -78,3 +78,22 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(base, f)).read()
                 assert "fz_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+
+
+def build_c_example(tmp_path):
+    """gcc (not hipcc), strict C99: the header is plain C and the library links without HIP on the caller's side"""
+    exe = os.path.join(str(tmp_path), "roundtrip")
+    libdir = os.path.join(ROOT, "fusion-cryptography_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "roundtrip.c"), "-o", exe, "-L", libdir, "-lfusion_hip",
+                           "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_c_caller_compiles_and_fails_loudly_without_a_device(lib, tmp_path):
+    exe = build_c_example(tmp_path)
+    n = ctypes.c_int(-1)
+    if lib.fz_device_count(ctypes.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present (tests/test_gpu_ntt.py runs the example there)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no HIP device" in r.stderr

@@ -200,3 +200,12 @@ def test_poly_mul_matches_transform_composition(d, coracle, monkeypatch):
     X = np.zeros((1, d), np.int32); X[0, 1] = 1
     assert np.array_equal(ctx.poly_mul(xs, X)[0], np.concatenate([-xs[0, -1:], xs[0, :-1]]))
     ctx.close()
+
+
+def test_c_caller_round_trip(tmp_path):
+    """examples/roundtrip.c (C99, gcc, no HIP headers): context, stream, device buffers, graph capture, replay"""
+    import subprocess
+    from test_cabi_symbols import build_c_example
+    r = subprocess.run([build_c_example(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "== x on 1000 rows" in r.stdout

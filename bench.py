@@ -391,6 +391,29 @@ def main():
               "note": "algebra cores only: sign_core, aggregate + target partials (one pass), int64 all-reduce, verification "
                       "from the int64 sums -- 4 kernel launches per step; "
                       "host hashing of str(vk) excluded"}
+        # BASELINE configs[2]: 1024 independent keygen + sign per step (keygen_core: 2*l transforms + two A.s
+        # products per key; sign_core: sigma = L*c + R), no exchange step: ranks are independent
+        ks_steps = sv_steps
+
+        def ks_step():
+            ctx.keygen_core_dev(A.data_ptr(), coef.data_ptr(), sk_hat.data_ptr(), vk.data_ptr(), S, l)
+            ctx.sign_core_dev(sk_hat.data_ptr(), c_hat.data_ptr(), sig.data_ptr(), S, l)
+        for _ in range(100 if args.prewarm_ms > 0 else 2):
+            ks_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(ks_steps):
+            ks_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        sv["keygen_sign"] = {"value": S * world * ks_steps / dt, "unit": "keygen+sign per s", "per_rank": S, "steps": ks_steps,
+                             "ms_per_step": dt / ks_steps * 1e3,
+                             "algorithmic_GB/s_per_gpu": S * ((4 * l + 2) + (3 * l + 1)) * 4 * d * ks_steps / dt / 1e9,
+                             "note": "configs[2]: keygen_core + sign_core on 1024 distinct synthetic keys per rank"}
 
     # ---- end to end through the array API: host hashing (C pipeline) + device algebra ------------------
     e2e = None

@@ -209,3 +209,22 @@ def test_c_caller_round_trip(tmp_path):
     r = subprocess.run([build_c_example(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "== x on 1000 rows" in r.stdout
+
+
+@pytest.mark.parametrize("secpar,rows", [(256, (1 << 15) + 5), (256, (1 << 17) + 3), (128, (1 << 19) + 7)])
+def test_large_batches_above_the_schedule_crossover(secpar, rows, coracle):
+    """default schedule choice at sizes where the 16-per-lane kernels take over (ragged row counts): the whole batch
+    against the C oracle, the round trip, and linearity NTT(x + y) == NTT(x) + NTT(y) mod q"""
+    import fusion_hip
+    P = O.PARAMS[secpar]
+    d, root, inv = P["d"], P["root"], P["inv_root"]
+    ctx = fusion_hip.Context(Q, d, root, inv)
+    x = O.splitmix_centered(77, rows * d).reshape(rows, d)
+    f = ctx.ntt_forward(x)
+    assert np.array_equal(f, coracle.ntt_forward(x, Q, root).reshape(rows, d))
+    assert np.array_equal(ctx.ntt_inverse(f), x)
+    y = O.splitmix_centered(78, rows * d).reshape(rows, d)
+    lhs = ctx.ntt_forward(ctx.pw_add(x, y))
+    rhs = ctx.pw_add(f, ctx.ntt_forward(y))
+    assert np.array_equal(lhs, rhs)
+    ctx.close()

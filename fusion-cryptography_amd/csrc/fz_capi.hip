@@ -601,6 +601,19 @@ int fz_keygen_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef, int32
     return fz_launch_matvec(ctx, d_A, d_sk_hat, d_vk, batch * 2, l);
 }
 
+int fz_keygen_core_bcast(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef, int32_t *d_sk_hat, int32_t *d_vk,
+                         size_t batch, int l) {
+    FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (d_A && d_coef && d_sk_hat && d_vk)), "bad argument");
+    if (batch == 0) return FZ_OK;
+    if ((ctx->logd == 6 || ctx->logd == 8) && batch * 2 <= 0x7fffffffu && !getenv("FZ_KEYGEN_UNFUSED") &&
+        ((((uintptr_t)d_A | (uintptr_t)d_coef | (uintptr_t)d_sk_hat) & 15) == 0))
+        return fz_launch_keygen_fused(ctx, d_A, d_coef, d_sk_hat, d_vk, batch * 2, l, true);
+    // generic degrees: expand the rows in sk_hat, transform in place, then the products
+    FZ_TRY(fz_launch_bcast_rows(ctx, d_coef, d_sk_hat, batch * 2, l));
+    FZ_TRY(fz_launch_ntt(ctx, d_sk_hat, d_sk_hat, batch * 2 * (size_t)l, false));
+    return fz_launch_matvec(ctx, d_A, d_sk_hat, d_vk, batch * 2, l);
+}
+
 int fz_sign_core(fz_ctx *ctx, const int32_t *d_sk_hat, const int32_t *d_c_hat, int32_t *d_sig, size_t batch, int l) {
     FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (d_sk_hat && d_c_hat && d_sig)), "bad argument");
     return fz_launch_sign(ctx, d_sk_hat, d_c_hat, d_sig, batch, l);

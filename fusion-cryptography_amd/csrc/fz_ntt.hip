@@ -640,7 +640,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
 // into the verification-key row.  sk_hat is never re-read: 342 KB of HBM traffic per key instead of 508 KB.
 // ------------------------------------------------------------------------------------------
 template <int LOGD, bool FAST>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_t *A, const int32_t *coef, int32_t *sk_hat,
+__global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_t *A, const int32_t *coef, size_t coef_seg_stride,
+                                                                    size_t coef_row_stride, int32_t *sk_hat,
                                                                     int32_t *vk, int l, const double2 *__restrict__ tw2,
                                                                     FzTwA twA, FzMod m) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
@@ -650,8 +651,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
     double *region = lds + wave * 256 + p * D;
     double *accbuf = lds + kWavesPerBlock * 256;
     const size_t seg = blockIdx.x;                      // (key, half)
-    coef += seg * (size_t)l * D;
-    sk_hat += seg * (size_t)l * D;
+    coef += seg * coef_seg_stride;                      // row stride 0: one secret polynomial per (key, half), as the
+    sk_hat += seg * (size_t)l * D;                      // reference's seeded sampler produces (polynomials.py:436-467)
 
     double2 twl[LOGD / 2 - 1][3];
     fwd4_load_twiddles<LOGD>(twl, tw2, mm);
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
     int xn[4];
     auto fetch = [&](int task) {
         const int row = task * PPW + p;
-        const int32_t *src = coef + (size_t)(row < l ? row : l - 1) * D + mm;
+        const int32_t *src = coef + (size_t)(row < l ? row : l - 1) * coef_row_stride + mm;
 #pragma unroll
         for (int k = 0; k < 4; ++k) xn[k] = src[k * LP];
     };
@@ -980,9 +981,11 @@ int query16(fz_ctx *ctx) {
 }  // namespace
 
 int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,
-                           int l) {
+                           int l, bool broadcast) {
     const dim3 grid((unsigned)segments), block(64 * kWavesPerBlock);
-#define FZ_KF(LOGD, FAST) hipLaunchKernelGGL((keygen_fused<LOGD, FAST>), grid, block, 0, ctx->stream, A, coef, sk_hat, vk, l, \
+    const size_t seg_stride = broadcast ? (size_t)ctx->degree : (size_t)l * ctx->degree;
+    const size_t row_stride = broadcast ? 0 : (size_t)ctx->degree;
+#define FZ_KF(LOGD, FAST) hipLaunchKernelGGL((keygen_fused<LOGD, FAST>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \
                                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_KF(8, true); else FZ_KF(8, false); }
     else if (ctx->logd == 6) { if (ctx->mod.fast) FZ_KF(6, true); else FZ_KF(6, false); }

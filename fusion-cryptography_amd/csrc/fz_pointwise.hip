@@ -416,6 +416,20 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
     return fz_check_hip(hipGetLastError(), "aggregate sum launch");
 }
 
+// out[seg][k][:] = in[seg][:] for k < l (generic-degree path of fz_keygen_core_bcast)
+__global__ __launch_bounds__(kBlock) void bcast_rows_kernel(const int32_t *in, int32_t *out, size_t segments, int l, int degree) {
+    const size_t total = segments * (size_t)l * degree, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
+        out[i] = in[(i / ((size_t)l * degree)) * degree + i % degree];
+}
+
+int fz_launch_bcast_rows(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t segments, int l) {
+    const size_t total = segments * (size_t)l * ctx->degree;
+    if (total == 0) return FZ_OK;
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream, in, out, segments, l, ctx->degree);
+    return fz_check_hip(hipGetLastError(), "bcast_rows launch");
+}
+
 int fz_launch_target_partial(fz_ctx *ctx, const int32_t *vkL, const int32_t *vkR, const int32_t *c, const int32_t *alpha,
                              int64_t *partial, size_t pstride, size_t groups, size_t N) {
     if (groups == 0) return FZ_OK;

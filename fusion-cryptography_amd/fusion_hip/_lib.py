@@ -72,6 +72,7 @@ SIGNATURES = {
     "fz_matvec": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
     "fz_matvec_host": (c_int, [_ctx, _i32p, _i32p, _i32p, c_size_t, c_int]),
     "fz_keygen_core": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
+    "fz_keygen_core_bcast": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
     "fz_sign_core": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
     "fz_aggregate_core": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
     "fz_aggregate_partial": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),

@@ -161,6 +161,11 @@ class Context:
         check(self._lib, self._lib.fz_keygen_core(self._h, c_void_p(d_A), c_void_p(d_coef), c_void_p(d_sk_hat),
                                                   c_void_p(d_vk), batch, l))
 
+    def keygen_core_bcast_dev(self, d_A, d_coef, d_sk_hat, d_vk, batch, l):
+        """d_coef [batch][2][degree]: one secret polynomial per (key, half), used for all l rows"""
+        check(self._lib, self._lib.fz_keygen_core_bcast(self._h, c_void_p(d_A), c_void_p(d_coef), c_void_p(d_sk_hat),
+                                                        c_void_p(d_vk), batch, l))
+
     def sign_core_dev(self, d_sk_hat, d_c_hat, d_sig, batch, l):
         check(self._lib, self._lib.fz_sign_core(self._h, c_void_p(d_sk_hat), c_void_p(d_c_hat), c_void_p(d_sig),
                                                 batch, l))

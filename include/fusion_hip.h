@@ -172,6 +172,11 @@ FZ_API int fz_matvec_host(fz_ctx *ctx, const int32_t *h_A, const int32_t *h_S, i
  *   A [l][degree], sig [l][degree] aggregate, vkL/vkR/c_hat/alpha_hat [N][degree]. */
 FZ_API int fz_keygen_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef,
                           int32_t *d_sk_hat, int32_t *d_vk, size_t batch, int l);
+/* the same with ONE secret polynomial per (key, half), d_coef [batch][2][degree], used for all l rows: what the
+ * reference's keygen really computes, because its sampler is re-seeded with the same seed for every matrix entry
+ * (fusion/fusion.py:159-170, :189-199 -> algebra/polynomials.py:447-448) -- 83x less data to upload */
+FZ_API int fz_keygen_core_bcast(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef,
+                                int32_t *d_sk_hat, int32_t *d_vk, size_t batch, int l);
 FZ_API int fz_sign_core(fz_ctx *ctx, const int32_t *d_sk_hat, const int32_t *d_c_hat,
                         int32_t *d_sig, size_t batch, int l);
 FZ_API int fz_aggregate_core(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat,

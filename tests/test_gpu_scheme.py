@@ -253,3 +253,31 @@ def test_fused_keygen_equals_unfused_path(secpar, coracle, monkeypatch):
         monkeypatch.setenv("FZ_KEYGEN_UNFUSED", "1")
         sk2, vk2 = ctx.keygen_core(A, coef)
         assert np.array_equal(sk2, want_sk) and np.array_equal(vk2, want_vk)
+
+
+@pytest.mark.parametrize("d,l", [(256, 83), (64, 195), (32, 5)])
+def test_broadcast_keygen_equals_replicated_rows(d, l, coracle, monkeypatch):
+    """fz_keygen_core_bcast (one secret polynomial per key half, as the reference's seeded sampler produces) == the
+    general entry on l replicated rows == oracle; fused kernel, multi-launch path and a generic degree"""
+    import fusion_hip
+    q = O.PRIME
+    root = next(r for r in (pow(g, (q - 1) // (2 * d), q) for g in range(2, 200)) if pow(r, d, q) == q - 1)
+    ctx = fusion_hip.Context(q, d, root, pow(root, q - 2, q))
+    DB = fusion_hip.DeviceBuffer
+    rng = np.random.default_rng(d + l)
+    n = 5
+    A = O.splitmix_centered(8, l * d).reshape(l, d)
+    one = rng.integers(-52, 53, size=(n, 2, d), dtype=np.int64).astype(np.int32)
+    coef = np.ascontiguousarray(np.broadcast_to(one[:, :, None, :], (n, 2, l, d)))
+    want_sk, want_vk = coracle.keygen_core(A, coef, q, root)
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("FZ_KEYGEN_UNFUSED", "1")
+        dA, dc = DB.from_numpy(ctx, A), DB.from_numpy(ctx, one)
+        dsk, dvk = DB(ctx, coef.nbytes), DB(ctx, n * 2 * d * 4)
+        ctx.keygen_core_bcast_dev(dA.ptr, dc.ptr, dsk.ptr, dvk.ptr, n, l)
+        assert np.array_equal(dsk.to_numpy(np.int32, (n, 2, l, d)), want_sk)
+        assert np.array_equal(dvk.to_numpy(np.int32, (n, 2, d)), want_vk)
+        for b in (dA, dc, dsk, dvk):
+            b.free()
+    ctx.close()

@@ -122,6 +122,23 @@ def test_error_codes_on_device():
     with pytest.raises(fusion_hip.FusionHipError):
         fusion_hip.Context(Q, 256, 5, 1)                          # not a primitive root
     assert lib.fz_ctx_destroy(None) == 0
+    # the entries added after the first pass refuse bad arguments before anything is launched
+    big = fusion_hip.DeviceBuffer(ctx, 1 << 16)
+    with pytest.raises(fusion_hip.FusionHipError) as e:
+        ctx.poly_mul_dev(0, big.ptr, big.ptr, 1)                  # NULL factor
+    assert e.value.code == -1
+    with pytest.raises(fusion_hip.FusionHipError) as e:
+        ring.poly_mul(np.zeros(100, np.int32), np.zeros(100, np.int32))
+    assert e.value.code == -2
+    ctx.poly_mul_dev(big.ptr, big.ptr, big.ptr, 0)                # empty batch: nothing to do
+    with pytest.raises(fusion_hip.FusionHipError, match="aligned"):
+        ctx.aggregate_target_partial_batch_dev(big.ptr, big.ptr, big.ptr + 4, big.ptr, big.ptr, big.ptr, 256, big.ptr, 256,
+                                               1, 1, 1)
+    with pytest.raises(fusion_hip.FusionHipError, match="stride"):
+        ctx.verify_partials_batch_async_dev(big.ptr, big.ptr, 8, big.ptr, 8, 2, 1, 1, 1, big.ptr)   # strides < rows
+    with pytest.raises(fusion_hip.FusionHipError, match="no capture"):
+        ctx.graph_end()
+    big.free()
 
 
 @pytest.mark.gpu

@@ -102,21 +102,36 @@ _PARAM_FIELDS = ("capacity", "modulus", "degree", "root_order", "root", "inv_roo
                  "beta_vf", "omega_sk", "omega_ch", "omega_ag", "omega_vf")
 
 
+def _replicated(sample_one, num_rows: int, num_cols: int, seed) -> list:
+    """num_rows x num_cols entries from a sampler that is re-seeded on every call.  With a seed every call returns
+    the same polynomial and leaves the process-global `random` in the same state, so one call plus fresh copies
+    (the entries must stay independent objects: callers mutate them) is indistinguishable from num_rows * num_cols
+    calls -- and 166x cheaper for a secret key.  Without a seed every entry is a fresh draw, as in the reference."""
+    if seed is None or num_rows * num_cols <= 1:
+        return [[sample_one() for _ in range(num_cols)] for _ in range(num_rows)]
+    first = sample_one()
+    data_attr = "coefficients" if hasattr(first, "coefficients") else "values"
+
+    def clone():
+        return type(first)(modulus=first.modulus, degree=first.degree, root=first.root, inv_root=first.inv_root,
+                           root_order=first.root_order, **{data_attr: list(getattr(first, data_attr))})
+    return [[first if (i == 0 and j == 0) else clone() for j in range(num_cols)] for i in range(num_rows)]
+
+
 def sample_coefficient_matrix(seed: Optional[int], modulus: int, degree: int, root_order: int, root: int,
                               inv_root: int, num_rows: int, num_cols: int, norm_bound: int,
                               weight_bound: int) -> GeneralMatrix:
     """Every entry is sampled with the SAME seed (fusion.py:156-173), so all entries are equal."""
-    return GeneralMatrix(matrix=[[sample_polynomial_coefficient_representation(
+    return GeneralMatrix(matrix=_replicated(lambda: sample_polynomial_coefficient_representation(
         modulus=modulus, degree=degree, root_order=root_order, root=root, inv_root=inv_root,
-        norm_bound=norm_bound, weight_bound=weight_bound, seed=seed) for _ in range(num_cols)]
-        for _ in range(num_rows)])
+        norm_bound=norm_bound, weight_bound=weight_bound, seed=seed), num_rows, num_cols, seed))
 
 
 def sample_ntt_matrix(seed: Optional[int], modulus: int, degree: int, root_order: int, root: int, inv_root: int,
                       num_rows: int, num_cols: int) -> GeneralMatrix:
-    return GeneralMatrix(matrix=[[sample_polynomial_ntt_representation(
-        modulus=modulus, degree=degree, root_order=root_order, root=root, inv_root=inv_root, seed=seed)
-        for _ in range(num_cols)] for _ in range(num_rows)])
+    return GeneralMatrix(matrix=_replicated(lambda: sample_polynomial_ntt_representation(
+        modulus=modulus, degree=degree, root_order=root_order, root=root, inv_root=inv_root, seed=seed),
+        num_rows, num_cols, seed))
 
 
 class Params(object):

@@ -310,3 +310,29 @@ def test_decoder_vectors_and_bounds():
             assert len(y) == params.degree and max(abs(v) for v in y) <= be and sum(1 for v in y if v) == om
     with pytest.raises(ValueError):
         F.parse_challenge(F.fusion_setup(128, 2), b"\x00" * 100)
+
+
+def test_seeded_matrices_are_replicated_without_changing_observable_state():
+    """sample_coefficient_matrix / sample_ntt_matrix with a seed: every entry equal (the reference re-seeds per entry,
+    fusion.py:156-199), entries independent objects, and the process-global `random` left exactly where l separate
+    calls would leave it; without a seed every entry is a fresh draw"""
+    import fusion.fusion as F
+    from algebra.polynomials import sample_polynomial_coefficient_representation as samp
+    p = _params(65537, 64)
+    m = F.sample_coefficient_matrix(seed=77, **p, num_rows=5, num_cols=1, norm_bound=9, weight_bound=20)
+    state_after_matrix = random.getstate()
+    one = samp(**p, norm_bound=9, weight_bound=20, seed=77)
+    for _ in range(4):
+        samp(**p, norm_bound=9, weight_bound=20, seed=77)               # what the reference does for the other rows
+    assert random.getstate() == state_after_matrix
+    rows = [r[0] for r in m.matrix]
+    assert all(r.coefficients == one.coefficients for r in rows)
+    assert len({id(r) for r in rows}) == 5 and len({id(r.coefficients) for r in rows}) == 5
+    rows[1].coefficients[0] += 1                                        # mutation stays local
+    assert rows[0].coefficients == one.coefficients and rows[2].coefficients == one.coefficients
+    n = F.sample_ntt_matrix(seed=78, **p, num_rows=3, num_cols=2)
+    flat = [z for r in n.matrix for z in r]
+    assert all(z.values == flat[0].values for z in flat) and len({id(z.values) for z in flat}) == 6
+    random.seed(1)
+    u = F.sample_coefficient_matrix(seed=None, **p, num_rows=3, num_cols=1, norm_bound=9, weight_bound=20)
+    assert len({tuple(r[0].coefficients) for r in u.matrix}) == 3      # unseeded: independent draws

@@ -485,6 +485,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
+        barrier()                                       # rank 0's single-rank legs are done: leave together
         dist.destroy_process_group()
 
 

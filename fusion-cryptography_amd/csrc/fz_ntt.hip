@@ -83,6 +83,16 @@ __device__ __forceinline__ void wave_sync() {
 
 constexpr int kWavesPerBlock = 4;
 
+// Streaming (non-temporal) stores for outputs the kernel never reads back.  A normal store allocates the line
+// dirty in this XCD's 4 MiB L2; for a transform that writes as much as it reads, half of the L2 then holds data
+// nobody will hit, and the dirty lines are written back in bursts (and at the end of the kernel).  Measured on the
+// NTT kernels: 2^14..2^18 rows 14-20 % faster (2^18 rows: 66 % -> 77 % of HBM peak), the bench's 2^12 rows 3-5 %.
+typedef int fz_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(int32_t *p, const int4 &v) {
+    fz_v4i t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<fz_v4i *>(p));
+}
+
 // one twiddle multiply: 4-op pseudo-Mersenne form when FAST (operand bound |a| <= 2^38), else 6-op
 template <bool FAST>
 __device__ __forceinline__ double tw_mul(double a, double w, double w2, const FzMod m) {
@@ -206,10 +216,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd16(const int32_t *
         chunk_to_lds(stage, lane, raw);          // waits for the prefetched loads (no store is younger)
         {
             const size_t base = task * kChunk + 4 * lane;
-            if (base < total) *reinterpret_cast<int4 *>(out + base) = o0;
-            if (base + 256 < total) *reinterpret_cast<int4 *>(out + base + 256) = o1;
-            if (base + 512 < total) *reinterpret_cast<int4 *>(out + base + 512) = o2;
-            if (base + 768 < total) *reinterpret_cast<int4 *>(out + base + 768) = o3;
+            if (base < total) nt_store4(out + base, o0);
+            if (base + 256 < total) nt_store4(out + base + 256, o1);
+            if (base + 512 < total) nt_store4(out + base + 512, o2);
+            if (base + 768 < total) nt_store4(out + base + 768, o3);
         }
     }
 }
@@ -320,10 +330,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
         chunk_to_lds(stage, lane, raw);
         {
             const size_t base = task * kChunk + 4 * lane;
-            if (base < total) *reinterpret_cast<int4 *>(out + base) = o0;
-            if (base + 256 < total) *reinterpret_cast<int4 *>(out + base + 256) = o1;
-            if (base + 512 < total) *reinterpret_cast<int4 *>(out + base + 512) = o2;
-            if (base + 768 < total) *reinterpret_cast<int4 *>(out + base + 768) = o3;
+            if (base < total) nt_store4(out + base, o0);
+            if (base + 256 < total) nt_store4(out + base + 256, o1);
+            if (base + 512 < total) nt_store4(out + base + 512, o2);
+            if (base + 768 < total) nt_store4(out + base + 768, o3);
         }
     }
 }
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(64 * kWaves4) void ntt_fwd4(const int32_t *in, int3
 #pragma unroll
             for (int k = 0; k < 4; ++k) an[k] = (double)xn[k];
         }
-        if (valid) *reinterpret_cast<int4 *>(out + poly * D + 4 * mm) = o;
+        if (valid) nt_store4(out + poly * D + 4 * mm, o);
         wave_sync();      // the next task's first-pass writes must not overtake this task's last reads
     }
 }
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(64 * kWaves4) void ntt_inv4(const int32_t *in, int3
         if (valid) {
             int32_t *dst = out + poly * D + mm;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dst[k * LP] = o[k];
+            for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(o[k], dst + k * LP);
         }
         wave_sync();
     }
@@ -627,7 +637,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
         if (valid) {
             int32_t *dst = out + poly * D + mm;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dst[k * LP] = (int)fz_cent(b[k], m);
+            for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((int)fz_cent(b[k], m), dst + k * LP);
         }
         wave_sync();      // the next product's first-pass writes must not overtake this one's last reads
     }

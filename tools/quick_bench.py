@@ -26,19 +26,26 @@ for secpar in secpars:
         for logB in (12, 13, 14, 15, 16, 18, 20):
             B = (1 << logB) * (256 // d)             # the same bytes per launch for every degree
             x = O.splitmix_centered(5, B * d).reshape(B, d)
-            din = fusion_hip.DeviceBuffer.from_numpy(ctx, x)
-            dout = fusion_hip.DeviceBuffer(ctx, x.nbytes)
+            # QB_ROTATE=1: cycle through enough buffer pairs (>= 2 GiB together) that no launch finds its input in the
+            # 256 MB Infinity Cache or the L2s from an earlier repetition ("cold" numbers)
+            pairs = max(1, -(-(2 << 30) // (2 * x.nbytes))) if os.environ.get("QB_ROTATE") else 1
+            pairs = min(pairs, 64)
+            bufs = [(fusion_hip.DeviceBuffer.from_numpy(ctx, x), fusion_hip.DeviceBuffer(ctx, x.nbytes)) for _ in range(pairs)]
             for name, fn in (("f", ctx.ntt_forward_dev), ("i", ctx.ntt_inverse_dev)):
                 t_end = time.perf_counter() + 0.04      # 40 ms of the same launches first (clock ramp after idle)
+                k = 0
                 while time.perf_counter() < t_end:
-                    for _ in range(3): fn(din.ptr, dout.ptr, B)
+                    for _ in range(3):
+                        fn(bufs[k % pairs][0].ptr, bufs[k % pairs][1].ptr, B); k += 1
                     ctx.synchronize()
                 reps = 400 if logB <= 12 else (100 if logB <= 16 else 20)
                 ctx.timer_start()
-                for _ in range(reps): fn(din.ptr, dout.ptr, B)
+                for _ in range(reps):
+                    fn(bufs[k % pairs][0].ptr, bufs[k % pairs][1].ptr, B); k += 1
                 ms = ctx.timer_stop_ms() / reps
                 gbs = 8 * d * B / (ms * 1e-3) / 1e9
                 line += f" | {B}{name} {ms*1e3:8.2f}us {gbs/80:5.1f}%"
-            din.free(); dout.free()
+            for a, b in bufs:
+                a.free(); b.free()
         print(line, flush=True)
         ctx.close()

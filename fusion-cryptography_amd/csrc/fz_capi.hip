@@ -255,9 +255,10 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         if (c->grid_mult < 1) c->grid_mult = 1;
         e = getenv("FZ_NTT_SMALL_ROWS");
         // measured crossover at steady clocks (profiles/README.md), inputs NOT cache-resident (rotating buffers):
-        // degree 256 -- radix-4 ahead up to 2^16 rows (2^16: 57 % vs 53 % of HBM peak), level at 2^15, the
-        // 16-per-lane kernel ahead from 2^18 (68 % vs 62 %); degree 64 -- radix-4 up to 2^18 rows, 16-per-lane from 2^20
-        c->small_batch_rows = e ? atoi(e) : (degree == 256 ? (1 << 17) : (1 << 19));
+        // degree 256 -- radix-4 ahead up to 2^14 rows (5-8 % at the bench's 2^12), level at 2^15, the 16-per-lane
+        // kernel ahead from 2^16 (61 % vs 58 % of HBM peak; 2^18: 70 % vs 61 %); degree 64 -- radix-4 up to 2^18
+        // rows, 16-per-lane from 2^20
+        c->small_batch_rows = e ? atoi(e) : (degree == 256 ? (1 << 16) : (1 << 19));
     }
     if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
     if (rc == FZ_OK) rc = upload_doubles(itwB, nB, &c->d_itwB);

@@ -24,6 +24,7 @@
 #include <hip/hip_ext.h>
 
 namespace {
+typedef int fz_v4i __attribute__((ext_vector_type(4)));
 
 template <int LOGD>
 struct Geom {
@@ -57,10 +58,17 @@ __device__ __forceinline__ Chunk chunk_load(const int32_t *in, size_t task, size
     const size_t base = task * kChunk + 4 * lane;
     const size_t last = total - 4;
     Chunk c;
-    c.v0 = *reinterpret_cast<const int4 *>(in + (base < total ? base : last));
-    c.v1 = *reinterpret_cast<const int4 *>(in + (base + 256 < total ? base + 256 : last));
-    c.v2 = *reinterpret_cast<const int4 *>(in + (base + 512 < total ? base + 512 : last));
-    c.v3 = *reinterpret_cast<const int4 *>(in + (base + 768 < total ? base + 768 : last));
+    // streaming loads: the 16-per-lane kernels run on batches far larger than the caches and read every input once
+    // (+2-4 % at 2^18..2^20 rows, +9 % at 2^16 with cold inputs; the radix-4 kernels, used for small batches whose
+    // data may well be cache-resident, keep normal loads: streaming ones cost them 3-5 % at 2^12 rows)
+    auto ld = [&](size_t o) {
+        const fz_v4i t = __builtin_nontemporal_load(reinterpret_cast<const fz_v4i *>(in + o));
+        return make_int4(t.x, t.y, t.z, t.w);
+    };
+    c.v0 = ld(base < total ? base : last);
+    c.v1 = ld(base + 256 < total ? base + 256 : last);
+    c.v2 = ld(base + 512 < total ? base + 512 : last);
+    c.v3 = ld(base + 768 < total ? base + 768 : last);
     return c;
 }
 
@@ -87,7 +95,6 @@ constexpr int kWavesPerBlock = 4;
 // dirty in this XCD's 4 MiB L2; for a transform that writes as much as it reads, half of the L2 then holds data
 // nobody will hit, and the dirty lines are written back in bursts (and at the end of the kernel).  Measured on the
 // NTT kernels: 2^14..2^18 rows 14-20 % faster (2^18 rows: 66 % -> 77 % of HBM peak), the bench's 2^12 rows 3-5 %.
-typedef int fz_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void nt_store4(int32_t *p, const int4 &v) {
     fz_v4i t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<fz_v4i *>(p));

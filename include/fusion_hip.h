@@ -86,7 +86,7 @@ FZ_API int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv);
  * *_async; nothing that copies to the host, synchronises, or grows the scratch -- run the sequence
  * once un-captured first) issued between fz_graph_begin and fz_graph_end is recorded into a hipGraph
  * instead of executed; fz_graph_launch replays it on the context's stream with one call
- * (measured: 4.0 us per 4096 x 256 transform instead of 4.55 us).  The context needs a non-default
+ * (measured: 3.85 us per 4096 x 256 transform instead of 4.2-4.4 us).  The context needs a non-default
  * stream (fz_ctx_set_stream).  The recorded pointers and sizes are fixed; contents may change. */
 typedef struct fz_graph fz_graph;
 FZ_API int fz_graph_begin(fz_ctx *ctx);

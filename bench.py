@@ -341,7 +341,8 @@ def main():
     if rank == 0 and not args.no_sweep:
         for logb in (16, 18, 20):
             nb = 1 << logb
-            x1 = torch.from_numpy(O.splitmix_centered(7, nb * d).reshape(nb, d)).to(dev)
+            x1 = torch.empty((nb, d), dtype=torch.int32, device=dev)
+            ctx.fill_synthetic_dev(x1.data_ptr(), nb * d, 7)              # generated on the device (up to 1 GiB)
             # cold inputs: cycle through enough (input, output) pairs (>= 2 GiB together) that no launch finds its
             # input in the 256 MB Infinity Cache or an L2 from an earlier repetition
             pairs = max(1, -(-(2 << 30) // (2 * x1.numel() * 4)))

@@ -533,6 +533,12 @@ int fz_pw_binary_host(fz_ctx *ctx, int op, const int32_t *h_a, const int32_t *h_
     return fz_memcpy_d2h(ctx, h_out, dout, count * sizeof(int32_t));
 }
 
+// ---- synthetic batches ----------------------------------------------------------------------------
+int fz_fill_synthetic(fz_ctx *ctx, int32_t *d_out, size_t count, uint64_t seed) {
+    FZ_REQUIRE(ctx && (count == 0 || d_out), "NULL argument");
+    return fz_launch_fill_synthetic(ctx, d_out, count, (unsigned long long)seed);
+}
+
 // ---- negacyclic product -------------------------------------------------------------------------
 int fz_poly_mul(fz_ctx *ctx, const int32_t *d_f, const int32_t *d_g, int32_t *d_out, size_t batch) {
     FZ_REQUIRE(ctx && (batch == 0 || (d_f && d_g && d_out)), "NULL argument");

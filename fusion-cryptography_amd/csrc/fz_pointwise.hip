@@ -430,6 +430,26 @@ int fz_launch_bcast_rows(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t se
     return fz_check_hip(hipGetLastError(), "bcast_rows launch");
 }
 
+// synthetic input generator ("device-side sampling for synthetic batches"): value i of the stream is
+// SplitMix64(seed + (i + 1) * golden) mod q, centred -- the same sequence as the host generator the tests and the
+// bench use (oracle.splitmix_centered), so device-filled and host-filled batches are interchangeable
+__global__ __launch_bounds__(kBlock) void fill_synthetic_kernel(int32_t *out, size_t count, unsigned long long seed, uint32_t q) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        unsigned long long z = seed + (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        out[i] = (int32_t)((long long)(z % q) - (long long)((q - 1) / 2));
+    }
+}
+
+int fz_launch_fill_synthetic(fz_ctx *ctx, int32_t *out, size_t count, unsigned long long seed) {
+    if (count == 0) return FZ_OK;
+    hipLaunchKernelGGL(fill_synthetic_kernel, dim3(grid_for(ctx, count)), dim3(kBlock), 0, ctx->stream, out, count, seed, ctx->q);
+    return fz_check_hip(hipGetLastError(), "fill_synthetic launch");
+}
+
 int fz_launch_target_partial(fz_ctx *ctx, const int32_t *vkL, const int32_t *vkR, const int32_t *c, const int32_t *alpha,
                              int64_t *partial, size_t pstride, size_t groups, size_t N) {
     if (groups == 0) return FZ_OK;

@@ -7,7 +7,7 @@ missing every compute entry point raises :class:`FusionHipError`.
 import ctypes
 import os
 from ctypes import (POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t,
-                    c_uint32, c_void_p)
+                    c_uint32, c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libfusion_hip.so"))
@@ -67,6 +67,7 @@ SIGNATURES = {
     "fz_pw_mulacc": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fz_pw_binary_host": (c_int, [_ctx, c_int, _i32p, _i32p, _i32p, c_size_t]),
     "fz_pw_mul_bcast": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fz_fill_synthetic": (c_int, [_ctx, c_void_p, c_size_t, c_uint64]),
     "fz_poly_mul": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fz_poly_mul_host": (c_int, [_ctx, _i32p, _i32p, _i32p, c_size_t]),
     "fz_matvec": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_int]),

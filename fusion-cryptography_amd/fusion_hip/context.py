@@ -141,6 +141,10 @@ class Context:
         fn = {OP_MUL: self._lib.fz_pw_mul, OP_ADD: self._lib.fz_pw_add, OP_SUB: self._lib.fz_pw_sub}[op]
         check(self._lib, fn(self._h, c_void_p(d_a), c_void_p(d_b), c_void_p(d_out), count))
 
+    def fill_synthetic_dev(self, d_out, count, seed):
+        """d_out[0:count] = the seeded centred-uniform stream (same values as the tests' host generator)"""
+        check(self._lib, self._lib.fz_fill_synthetic(self._h, c_void_p(d_out), count, seed))
+
     def poly_mul_dev(self, d_f, d_g, d_out, batch):
         """negacyclic products of `batch` coefficient-domain rows (device pointers; d_out may alias an input)"""
         check(self._lib, self._lib.fz_poly_mul(self._h, c_void_p(d_f), c_void_p(d_g), c_void_p(d_out), batch))

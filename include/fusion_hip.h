@@ -140,6 +140,11 @@ FZ_API int fz_pw_binary_host(fz_ctx *ctx, int op, const int32_t *h_a, const int3
  * GeneralMatrix.__mul__(element), algebra/matrices.py:109-114 */
 FZ_API int fz_pw_mul_bcast(fz_ctx *ctx, const int32_t *d_a, const int32_t *d_s, int32_t *d_out, size_t rows);
 
+/* ---- synthetic batches (benchmarks, tests) ----------------------------------------------------------
+ * d_out[i] = SplitMix64(seed + (i + 1) * 0x9E3779B97F4A7C15) mod q, centred to [-(q-1)/2, (q-1)/2]: a seeded uniform
+ * batch generated where it is used, instead of on the host and across PCIe (a 2^20 x 256 batch is 1 GiB). */
+FZ_API int fz_fill_synthetic(fz_ctx *ctx, int32_t *d_out, size_t count, uint64_t seed);
+
 /* ---- negacyclic product of coefficient-domain polynomials ---------------------------------------
  * out[b] = INTT(NTT(f[b]) (.) NTT(g[b])), centred: ntt_poly_mult (algebra/ntt.py:380-484) and the value of
  * PolynomialCoefficientRepresentation.__mul__ (algebra/polynomials.py:171-216, schoolbook there).

@@ -132,3 +132,20 @@ def test_linearity_at_full_size():
     prod = ctx.ntt_inverse(ctx.pw_mul(ctx.ntt_forward(a), np.broadcast_to(ctx.ntt_forward(xpoly), a.shape)))
     expect = np.concatenate([-a[:, -1:], a[:, :-1]], axis=1)
     assert np.array_equal(prod, expect)
+
+
+def test_device_synthetic_generator_matches_host_generator():
+    """fz_fill_synthetic == oracle.splitmix_centered (the generator tests and bench use), any offset, ragged counts"""
+    import fusion_hip
+    from oracle import oracle as O
+    P = O.PARAMS[256]
+    ctx = fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"])
+    small = fusion_hip.Context(257, 4, 0, 0)                         # another modulus (ring-only context)
+    for c, q in ((ctx, P["q"]), (small, 257)):
+        for seed, count in ((20261003, 4096 * 256 + 7), (5, 1), (2**63 + 11, 1000)):
+            buf = fusion_hip.DeviceBuffer(c, count * 4)
+            c.fill_synthetic_dev(buf.ptr, count, seed)
+            want = O.splitmix_centered(seed, count, q)
+            assert np.array_equal(buf.to_numpy(np.int32, (count,)), want)
+            buf.free()
+    ctx.fill_synthetic_dev(0, 0, 1)                                   # empty: nothing to do

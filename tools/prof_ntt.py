@@ -14,9 +14,9 @@ P = O.PARAMS[secpar]
 d = P["d"]
 ctx = fusion_hip.Context(P["q"], d, P["root"], P["inv_root"])
 B = 1 << logB
-x = O.splitmix_centered(5, B * d).reshape(B, d)
-din = fusion_hip.DeviceBuffer.from_numpy(ctx, x)
-dout = fusion_hip.DeviceBuffer(ctx, x.nbytes)
+din = fusion_hip.DeviceBuffer(ctx, B * d * 4)
+dout = fusion_hip.DeviceBuffer(ctx, B * d * 4)
+ctx.fill_synthetic_dev(din.ptr, B * d, 5)
 for _ in range(reps):
     ctx.ntt_forward_dev(din.ptr, dout.ptr, B)
     ctx.ntt_inverse_dev(dout.ptr, din.ptr, B)

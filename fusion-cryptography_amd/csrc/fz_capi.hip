@@ -88,7 +88,8 @@ int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, doub
             ctx->d_vpart = nullptr;
             ctx->vpart_doubles = 0;
             FZ_HIP(hipMalloc((void **)&ctx->d_vpart, (need + need / 4) * sizeof(double)), "verify scratch alloc");
-            FZ_HIP(hipMemset(ctx->d_vpart, 0, (need + need / 4) * sizeof(double)), "verify scratch clear");
+            // on the context's stream: a null-stream memset is not ordered with a non-blocking stream (found by tools/soak.py)
+            FZ_HIP(hipMemsetAsync(ctx->d_vpart, 0, (need + need / 4) * sizeof(double), ctx->stream), "verify scratch clear");
             ctx->vpart_doubles = need + need / 4;
         }
         if (groups > ctx->vstate_groups) {
@@ -97,7 +98,7 @@ int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, doub
             ctx->vstate_groups = 0;
             const size_t cap = groups + groups / 4 + 16;
             FZ_HIP(hipMalloc((void **)&ctx->d_vstate, cap * 2 * sizeof(int)), "verify state alloc");
-            FZ_HIP(hipMemset(ctx->d_vstate, 0, cap * 2 * sizeof(int)), "verify state clear");
+            FZ_HIP(hipMemsetAsync(ctx->d_vstate, 0, cap * 2 * sizeof(int), ctx->stream), "verify state clear");
             ctx->vstate_groups = cap;
         }
     }

@@ -281,3 +281,39 @@ def test_broadcast_keygen_equals_replicated_rows(d, l, coracle, monkeypatch):
         for b in (dA, dc, dsk, dvk):
             b.free()
     ctx.close()
+
+
+def test_first_verify_on_a_fresh_context_with_its_own_stream(coracle):
+    """regression (found by tools/soak.py): the verify accumulators are cleared on the context's stream -- a null-stream
+    memset is not ordered with a non-blocking stream, and the first verification of a context raced with it"""
+    import fusion_hip
+    P = O.PARAMS[128]
+    q, d, l, n, G = P["q"], P["d"], 1, 27, 3
+    rng = np.random.default_rng(9)
+    A = O.splitmix_centered(11, l * d).reshape(l, d)
+    coef = rng.integers(-52, 53, size=(G * n, 2, l, d)).astype(np.int32)
+    c = np.zeros((G * n, d), np.int32)
+    for i in range(G * n):
+        c[i, rng.choice(d, 60, replace=False)] = rng.choice([-1, 1], 60)
+    DB = fusion_hip.DeviceBuffer
+    for _ in range(6):
+        ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+        s = ctx.stream_create()
+        ctx.set_stream(s)
+        sk, vk = ctx.keygen_core(A, coef)
+        c_hat, al_hat = ctx.ntt_forward(c), ctx.ntt_forward(np.roll(c, 5, axis=1))
+        sig = ctx.sign_core(sk, c_hat)
+        bufs = [DB.from_numpy(ctx, a) for a in (sig, al_hat, np.ascontiguousarray(vk[:, 0]), np.ascontiguousarray(vk[:, 1]),
+                                                c_hat, A)]
+        n_agg = G * l * d
+        part, verd = DB(ctx, (n_agg + G * d) * 8), DB(ctx, G * 4)
+        ctx.aggregate_target_partial_batch_dev(bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, bufs[4].ptr, part.ptr,
+                                               l * d, part.ptr + n_agg * 8, d, G, n, l)
+        ctx.verify_partials_batch_async_dev(bufs[5].ptr, part.ptr, l * d, part.ptr + n_agg * 8, d, G, l, P["beta_vf"], d,
+                                            verd.ptr)
+        assert verd.to_numpy(np.int32, (G,)).tolist() == [0] * G
+        for b in bufs + [part, verd]:
+            b.free()
+        ctx.set_stream(0)
+        ctx.stream_destroy(s)
+        ctx.close()

@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Randomised soak of every kernel against the CPU oracle: random batch sizes, both NTT schedules, both degrees,
+fused and multi-launch paths, two contexts on two streams interleaved, repeated verify launches (re-armed
+accumulators), graph replays.  usage: soak.py [seconds] [seed]   (needs an MI355X; prints a progress line per minute)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fusion-cryptography_amd"))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import fusion_hip  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+orc = O.COracle()
+q = O.PRIME
+counts = {}
+
+
+def bump(name):
+    counts[name] = counts.get(name, 0) + 1
+
+
+def make_ctx(secpar, kernel):
+    if kernel:
+        os.environ["FZ_NTT_KERNEL"] = kernel
+    else:
+        os.environ.pop("FZ_NTT_KERNEL", None)
+    P = O.PARAMS[secpar]
+    c = fusion_hip.Context(q, P["d"], P["root"], P["inv_root"])
+    c.set_stream(c.stream_create())
+    return c
+
+
+ctxs = {(sp, k): make_ctx(sp, k) for sp in (128, 256) for k in ("", "4", "16")}
+os.environ.pop("FZ_NTT_KERNEL", None)
+DB = fusion_hip.DeviceBuffer
+t_end = time.time() + budget
+t_print = time.time() + 60
+it = 0
+while time.time() < t_end:
+    it += 1
+    sp = int(rng.choice([128, 256]))
+    P = O.PARAMS[sp]
+    d, root, inv = P["d"], P["root"], P["inv_root"]
+    kern = str(rng.choice(["", "4", "16"]))
+    ctx = ctxs[(sp, kern)]
+    other = ctxs[(sp, str(rng.choice(["", "4", "16"])))]
+    rows = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 257, 1000, 4099, int(rng.integers(1, 20000))]))
+    what = rng.choice(["ntt", "polymul", "scheme", "graph"])
+    raw = rng.random() < 0.3
+    x = (rng.integers(-2**31, 2**31, size=(rows, d), dtype=np.int64).astype(np.int32) if raw
+         else O.splitmix_centered(int(rng.integers(1, 2**40)), rows * d).reshape(rows, d))
+    if what == "ntt":
+        # two contexts on two streams, interleaved launches, then compare both
+        dx, dy, dz = DB.from_numpy(ctx, x), DB(ctx, x.nbytes), DB(ctx, x.nbytes)
+        ex, ey = DB.from_numpy(other, x), DB(other, x.nbytes)
+        for _ in range(int(rng.integers(1, 4))):
+            ctx.ntt_forward_dev(dx.ptr, dy.ptr, rows)
+            other.ntt_inverse_dev(ex.ptr, ey.ptr, rows)
+            ctx.ntt_inverse_dev(dy.ptr, dz.ptr, rows)
+        f = orc.ntt_forward(x, q, root).reshape(rows, d)
+        assert np.array_equal(dy.to_numpy(np.int32, (rows, d)), f), ("fwd", sp, kern, rows, raw)
+        assert np.array_equal(ey.to_numpy(np.int32, (rows, d)), orc.ntt_inverse(x, q, inv).reshape(rows, d)), ("inv", sp, rows, raw)
+        assert np.array_equal(dz.to_numpy(np.int32, (rows, d)), orc.ntt_inverse(f, q, inv).reshape(rows, d)), ("inv(fwd)", sp, kern, rows)
+        for b in (dx, dy, dz, ex, ey):
+            b.free()
+        bump("ntt")
+    elif what == "polymul":
+        g = O.splitmix_centered(int(rng.integers(1, 2**40)), rows * d).reshape(rows, d)
+        want = orc.ntt_inverse(orc.pw_mul(orc.ntt_forward(x, q, root), orc.ntt_forward(g, q, root), q), q, inv).reshape(rows, d)
+        assert np.array_equal(ctx.poly_mul(x, g), want), ("polymul", sp, rows, raw)
+        bump("polymul")
+    elif what == "graph":
+        rows = min(rows, 3000)
+        x = x[:rows]
+        dx, dy = DB.from_numpy(ctx, x), DB(ctx, x.nbytes)
+        ctx.ntt_forward_dev(dx.ptr, dy.ptr, rows)
+        ctx.synchronize()
+        ctx.graph_begin()
+        for _ in range(3):
+            ctx.ntt_forward_dev(dx.ptr, dy.ptr, rows)
+            ctx.ntt_inverse_dev(dy.ptr, dx.ptr, rows)
+        ctx.ntt_forward_dev(dx.ptr, dy.ptr, rows)
+        gr = ctx.graph_end()
+        for _ in range(3):
+            gr.launch()
+        want = orc.ntt_forward(orc.ntt_inverse(orc.ntt_forward(x, q, root), q, inv), q, root).reshape(rows, d)
+        assert np.array_equal(dy.to_numpy(np.int32, (rows, d)), want), ("graph", sp, kern, rows)
+        gr.destroy()
+        dx.free()
+        dy.free()
+        bump("graph")
+    else:
+        l = int(rng.choice([1, 2, 7, P["rank"]]))
+        n = int(rng.integers(1, 40))
+        G = int(rng.integers(1, 4))
+        A = O.splitmix_centered(int(rng.integers(1, 2**40)), l * d).reshape(l, d)
+        coef = rng.integers(-52, 53, size=(G * n, 2, l, d)).astype(np.int32)
+        sk, vk = ctx.keygen_core(A, coef)
+        rsk, rvk = orc.keygen_core(A, coef, q, root)
+        assert np.array_equal(sk, rsk) and np.array_equal(vk, rvk), ("keygen", sp, l, n)
+        c = np.zeros((G * n, d), np.int32)
+        for i in range(G * n):
+            c[i, rng.choice(d, min(d, 60), replace=False)] = rng.choice([-1, 1], min(d, 60))
+        c_hat = ctx.ntt_forward(c)
+        al_hat = ctx.ntt_forward(np.roll(c, 5, axis=1))
+        sig = ctx.sign_core(sk, c_hat)
+        assert np.array_equal(sig, orc.sign_core(sk, c_hat, q)), ("sign", sp, l, n)
+        d_sig, d_al, d_c = DB.from_numpy(ctx, sig), DB.from_numpy(ctx, al_hat), DB.from_numpy(ctx, c_hat)
+        d_L, d_R = DB.from_numpy(ctx, np.ascontiguousarray(vk[:, 0])), DB.from_numpy(ctx, np.ascontiguousarray(vk[:, 1]))
+        d_A = DB.from_numpy(ctx, A)
+        n_agg, n_t = G * l * d, G * d
+        part = DB(ctx, (n_agg + n_t) * 8)
+        verd = DB(ctx, G * 4)
+        tamper = int(rng.integers(-1, G))                # -1: none
+        for rep in range(3):                             # repeated launches: the verify accumulators must re-arm
+            ctx.aggregate_target_partial_batch_dev(d_sig.ptr, d_al.ptr, d_L.ptr, d_R.ptr, d_c.ptr, part.ptr, l * d,
+                                                   part.ptr + n_agg * 8, d, G, n, l)
+            if tamper >= 0 and rep == 1:
+                p = part.to_numpy(np.int64, (n_agg + n_t,))
+                p[tamper * l * d + int(rng.integers(0, l * d))] += 1
+                ctx.h2d(part.ptr, p)
+            ctx.verify_partials_batch_async_dev(d_A.ptr, part.ptr, l * d, part.ptr + n_agg * 8, d, G, l, P["beta_vf"], d, verd.ptr)
+            got = verd.to_numpy(np.int32, (G,)).tolist()
+            want = [3 if (g_ == tamper and rep == 1) else 0 for g_ in range(G)]
+            assert got == want, ("verify", sp, l, n, G, rep, got, want)
+        p = part.to_numpy(np.int64, (n_agg + n_t,))
+        half = q // 2
+        agg = ((p[:n_agg] + half) % q - half).astype(np.int32).reshape(G, l, d)
+        for g_ in range(G):
+            assert np.array_equal(agg[g_], orc.aggregate_core(sig[g_ * n:(g_ + 1) * n], al_hat[g_ * n:(g_ + 1) * n], q)), ("agg", g_)
+        for b in (d_sig, d_al, d_c, d_L, d_R, d_A, part, verd):
+            b.free()
+        bump("scheme")
+    if time.time() > t_print:
+        print(f"[soak] {it} iterations ok: {counts}", flush=True)
+        t_print = time.time() + 60
+print(f"[soak] PASSED {it} iterations in {budget:.0f} s: {counts}", flush=True)

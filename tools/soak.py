@@ -50,7 +50,7 @@ while time.time() < t_end:
     ctx = ctxs[(sp, kern)]
     other = ctxs[(sp, str(rng.choice(["", "4", "16"])))]
     rows = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 257, 1000, 4099, int(rng.integers(1, 20000))]))
-    what = rng.choice(["ntt", "polymul", "scheme", "graph"])
+    what = rng.choice(["ntt", "polymul", "scheme", "graph", "pointwise", "small", "batch_api"])
     raw = rng.random() < 0.3
     x = (rng.integers(-2**31, 2**31, size=(rows, d), dtype=np.int64).astype(np.int32) if raw
          else O.splitmix_centered(int(rng.integers(1, 2**40)), rows * d).reshape(rows, d))
@@ -94,7 +94,70 @@ while time.time() < t_end:
         dx.free()
         dy.free()
         bump("graph")
+    elif what == "pointwise":
+        # ragged, possibly unaligned element counts through the host-pointer entries (raw int32 operands)
+        count = int(rng.choice([1, 3, 4, 5, 255, 1023, int(rng.integers(1, 300000))]))
+        a = rng.integers(-2**31, 2**31, size=count, dtype=np.int64).astype(np.int32)
+        b = rng.integers(-2**31, 2**31, size=count, dtype=np.int64).astype(np.int32)
+        ring = ctxs[(sp, "")]
+        assert np.array_equal(ring.pw_mul(a, b), orc.pw_mul(a, b, q)), ("pw_mul", count)
+        assert np.array_equal(ring.pw_add(a, b), orc.pw_add(a, b, q)), ("pw_add", count)
+        assert np.array_equal(ring.pw_sub(a, b), orc.pw_sub(a, b, q)), ("pw_sub", count)
+        assert np.array_equal(ring.pw_neg(a), orc.pw_neg(a, q)), ("pw_neg", count)
+        l = int(rng.choice([1, 2, 9, P["rank"]]))
+        bt = int(rng.integers(1, 30))
+        A = rng.integers(-2**31, 2**31, size=(l, d), dtype=np.int64).astype(np.int32)
+        S = rng.integers(-2**31, 2**31, size=(bt, l, d), dtype=np.int64).astype(np.int32)
+        assert np.array_equal(ctx.matvec(A, S), orc.matvec(A, S, q)), ("matvec", sp, l, bt)
+        mx, wt = ctx.norm_weight(x)
+        rmx, rwt = orc.norm_weight(x, q)
+        assert np.array_equal(mx, rmx) and np.array_equal(wt, rwt), ("norm_weight", sp, rows)
+        bump("pointwise")
+    elif what == "small":
+        # other parameter sets: small primes / degrees (thread-per-polynomial kernels, general 6-op multiply)
+        dd = int(rng.choice([2, 4, 8, 16, 32, 64, 128]))
+        cands = [pp for pp in (257, 769, 12289, 40961, 65537, 786433, 2013265921) if (pp - 1) % (2 * dd) == 0]
+        qq = int(rng.choice(cands))
+        rt = next(r_ for r_ in (pow(g_, (qq - 1) // (2 * dd), qq) for g_ in range(2, 500)) if pow(r_, dd, qq) == qq - 1)
+        irt = pow(rt, qq - 2, qq)
+        cs = fusion_hip.Context(qq, dd, rt, irt)
+        rr = int(rng.integers(1, 3000))
+        xx = rng.integers(-2**31, 2**31, size=(rr, dd), dtype=np.int64).astype(np.int32)
+        f = cs.ntt_forward(xx)
+        assert np.array_equal(f, orc.ntt_forward(xx, qq, rt).reshape(rr, dd)), ("small fwd", qq, dd, rr)
+        assert np.array_equal(cs.ntt_inverse(xx), orc.ntt_inverse(xx, qq, irt).reshape(rr, dd)), ("small inv", qq, dd, rr)
+        yy = rng.integers(-2**31, 2**31, size=(rr, dd), dtype=np.int64).astype(np.int32)
+        want = orc.ntt_inverse(orc.pw_mul(f, orc.ntt_forward(yy, qq, rt), qq), qq, irt).reshape(rr, dd)
+        assert np.array_equal(cs.poly_mul(xx, yy), want), ("small polymul", qq, dd, rr)
+        cs.close()
+        bump("small")
+    elif what == "batch_api":
+        # array API == drop-in object API (which the GPU test-suite pins to the reference's golden strings)
+        import fusion.fusion as F
+        from fusion_hip import scheme as SCH
+        if "params" not in globals():
+            globals()["params"] = {s_: F.fusion_setup(s_, 2026 + s_) for s_ in (128, 256)}
+            globals()["bsch"] = {s_: SCH.BatchScheme(globals()["params"][s_]) for s_ in (128, 256)}
+        prm, bs = globals()["params"][sp], globals()["bsch"][sp]
+        nn = int(rng.integers(1, 4))
+        seeds = [int(v) for v in rng.integers(1, 2**31, size=nn)]
+        msgs = [f"soak {it} {i}" for i in range(nn)]
+        keys = [F.keygen(prm, s_) for s_ in seeds]
+        sigs = [F.sign(prm, k_, m_) for k_, m_ in zip(keys, msgs)]
+        agg = F.aggregate(prm, [k_[1] for k_ in keys], msgs, sigs)
+        sk_b, vk_b = bs.keygen_batch(seeds)
+        sig_b = bs.sign_batch(sk_b, vk_b, msgs)
+        agg_b = bs.aggregate(vk_b, msgs, sig_b)
+        assert np.array_equal(sig_b, np.stack([SCH.signature_from_object(prm, s_) for s_ in sigs])), ("batch sign", sp, nn)
+        assert np.array_equal(agg_b, SCH.signature_from_object(prm, agg)), ("batch aggregate", sp, nn)
+        assert bs.verify(vk_b, msgs, agg_b) == F.verify(prm, [k_[1] for k_ in keys], msgs, agg) == (True, ""), ("batch verify", sp)
+        bump("batch_api")
     else:
+        for knob in ("FZ_KEYGEN_UNFUSED", "FZ_VERIFY_UNFUSED", "FZ_POLYMUL_UNFUSED"):      # both paths of every fused kernel
+            if rng.random() < 0.3:
+                os.environ[knob] = "1"
+            else:
+                os.environ.pop(knob, None)
         l = int(rng.choice([1, 2, 7, P["rank"]]))
         n = int(rng.integers(1, 40))
         G = int(rng.integers(1, 4))

@@ -25,7 +25,11 @@ def _edge_rows(d, q):
             np.where(np.arange(d) % 2 == 0, h, -h),
             # non-centred int32 inputs: __neg__-style [-(q-1), 0], raw extremes
             -np.arange(d) * ((q - 1) // d), np.full(d, -(q - 1)), np.full(d, 2**31 - 1), np.full(d, -2**31),
-            np.where(np.arange(d) % 3 == 0, 2**31 - 1, -2**31)]
+            np.where(np.arange(d) % 3 == 0, 2**31 - 1, -2**31),
+            # the inverse transforms' fast last stage applies to inputs within 2^30: exactly at the bound (the all-add
+            # path then reaches 2^38, the 4-op multiply's limit), alternating signs, and just outside it
+            np.full(d, 2**30), np.full(d, -2**30), np.where(np.arange(d) % 2 == 0, 2**30, -2**30),
+            np.where(np.arange(d) % 5 == 0, -2**30, 2**30), np.full(d, 2**30 + 1), np.full(d, -2**30 - 1)]
     return np.stack(rows).astype(np.int32)
 
 

@@ -513,9 +513,10 @@ def main():
         out = {
             "metric": METRIC, "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64 (exact integer arithmetic; int32 in/out)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: secpar={SECPAR}, batch of {B} degree-{d} forward+inverse NTTs per GPU",
                        "batch": B, "degree": d, "modulus": q, "kernels_per_step": 2,
+                       "arithmetic": "exact integers carried in fp64 lanes (results bit-identical to the reference's int arithmetic); int32 in and out",
                        "launch": "one by one" if args.no_graph else "hipGraph replay (fz_graph_*)", "prewarm_ms": args.prewarm_ms},
             "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8> (forward NTT, B=4096)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

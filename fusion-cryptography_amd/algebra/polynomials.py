@@ -121,9 +121,12 @@ class PolynomialCoefficientRepresentation(PolynomialRepresentation):
         return self.coefficients
 
     def _like(self, values):
-        return PolynomialCoefficientRepresentation(modulus=self.modulus, degree=self.degree, root=self.root,
-                                                   inv_root=self.inv_root, root_order=self.root_order,
-                                                   coefficients=values)
+        """same ring, new data the library produced itself (a fresh list of `degree` Python ints from ndarray.tolist()):
+        the per-element isinstance scan of __init__ -- 70 % of the object API's time -- has nothing to find"""
+        z = object.__new__(PolynomialCoefficientRepresentation)
+        z.modulus, z.degree, z.root, z.inv_root, z.root_order = self.modulus, self.degree, self.root, self.inv_root, self.root_order
+        z.coefficients = values
+        return z
 
     def __str__(self):
         return (f"PolynomialCoefficientRepresentation(modulus={self.modulus}, degree={self.degree}, "
@@ -218,8 +221,11 @@ class PolynomialNTTRepresentation(PolynomialRepresentation):
         return self.values
 
     def _like(self, values):
-        return PolynomialNTTRepresentation(modulus=self.modulus, degree=self.degree, root=self.root,
-                                           inv_root=self.inv_root, root_order=self.root_order, values=values)
+        """see PolynomialCoefficientRepresentation._like"""
+        z = object.__new__(PolynomialNTTRepresentation)
+        z.modulus, z.degree, z.root, z.inv_root, z.root_order = self.modulus, self.degree, self.root, self.inv_root, self.root_order
+        z.values = values
+        return z
 
     def __str__(self):
         return (f"PolynomialNTTRepresentation(modulus={self.modulus}, degree={self.degree}, root={self.root}, "

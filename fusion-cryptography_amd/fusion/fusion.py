@@ -113,8 +113,7 @@ def _replicated(sample_one, num_rows: int, num_cols: int, seed) -> list:
     data_attr = "coefficients" if hasattr(first, "coefficients") else "values"
 
     def clone():
-        return type(first)(modulus=first.modulus, degree=first.degree, root=first.root, inv_root=first.inv_root,
-                           root_order=first.root_order, **{data_attr: list(getattr(first, data_attr))})
+        return first._like(list(getattr(first, data_attr)))
     return [[first if (i == 0 and j == 0) else clone() for j in range(num_cols)] for i in range(num_rows)]
 
 
@@ -206,7 +205,11 @@ def _ntt_poly(params, values):
 
 def _column(params, arr):
     """[rows][d] int32 -> rows x 1 GeneralMatrix of NTT-domain polynomials"""
-    return GeneralMatrix(matrix=[[_ntt_poly(params, row)] for row in arr.tolist()])
+    rows = arr.tolist()
+    if not rows:
+        return GeneralMatrix(matrix=[])
+    first = _ntt_poly(params, rows[0])               # validates the parameter tuple once; the rest share it
+    return GeneralMatrix(matrix=[[first]] + [[first._like(row)] for row in rows[1:]])
 
 
 def _rows_of(matrix: GeneralMatrix, q):

@@ -3,23 +3,30 @@
 
 Workload (BASELINE.json configs[1]): secpar=256, one batch of 4096 independent degree-256
 polynomials; a STEP is one pass of the hot path over that batch = forward NTT of the batch
-followed by inverse NTT of the result (two kernel launches, inputs resident in HBM).  The K timed
-steps are recorded into hipGraphs beforehand (the library's fz_graph_* capture) and replayed inside the
-timed region: the same 2K kernels in the same order on one stream, without a host round trip per launch
-(--no-graph launches them one by one).
-`value` = NTTs per second over the whole job (forward and inverse each count as one NTT,
-summed over all ranks).  With --gpus N every rank owns its own batch (weak scaling, no
-data-path collective for the transforms).
+followed by inverse NTT of the result (two kernel launches, inputs resident in HBM).  The K steps
+(--steps) are recorded into a hipGraph beforehand (the library's fz_graph_* capture) and the graph is
+replayed R times inside the timed region, R chosen so that the region lasts >= 20 ms whatever K is
+(a 0.2 ms region measures graph start-up, not kernels): the same 2K kernels in the same order on one
+stream, R times, no host round trip per launch (--no-graph launches them one by one).
+`value` = NTTs per second over the whole job (forward and inverse each count as one NTT, summed over
+all ranks); `ms_per_step` = elapsed / (R * K).  With --gpus N every rank owns its own batch (weak
+scaling, no data-path collective for the transforms).
+
+Launch: `python bench.py --gpus N` starts its own N ranks (child processes, before this process has
+touched a GPU) when WORLD_SIZE is not set; under torch.distributed.run it uses the ranks it is given.
 
 The same JSON line carries
-  roofline      achieved algorithmic GB/s of the dominant kernel (forward NTT: 8*d bytes per
-                polynomial), timed with events on the kernel's own stream inside the timed region;
-                plus the large-batch asymptote of the same kernel under "sweep".
-  cpu_baseline  the pure-Python port of the reference's algebra path (oracle/oracle.py py_*)
-                timed on one host core over a bounded sample of the same workload (rank 0, N=1).
-  sign_verify   the second half of BASELINE's metric: signatures signed + aggregated + verified per
-                second (algebra only; synthetic keys/messages), sharded over the ranks with one RCCL
-                all-reduce of the int64 partial aggregate per step.
+  roofline      achieved algorithmic GB/s of the dominant kernel (forward NTT: 8*d bytes per polynomial)
+                from per-dispatch begin/end events; `copy_floor` (an empty dispatch and a plain copy of the
+                same bytes, same run); `multi_job` (fz_ntt_multi: 1/2/4/8 batches of 4096 rows per dispatch);
+                `kernels` (every scheme kernel, cold operands: tools/kernel_table.py); the large-batch sweep.
+  cpu_baseline  the pure-Python port of the reference's algebra path (oracle/oracle.py py_*) timed on one
+                host core over a bounded sample of the same workload (rank 0, N=1), and on the box's cores.
+  sign_verify   the second half of BASELINE's metric: signatures signed + aggregated + verified per second
+                (algebra cores; synthetic keys/messages, operand sets rotated so that nothing is cache-resident),
+                sharded over the ranks with ONE RCCL all-reduce of the int64 partials per step, issued through
+                the C ABI (fz_allreduce_i64) and replayed from the library's graph together with the kernels.
+  ranks         what every rank reported: device index, PCI bus id, world size and backend as RCCL saw them.
 """
 import argparse
 import json
@@ -35,6 +42,7 @@ METRIC = "batched NTT/s (deg-256, secpar=256) + aggregate sign+verify/sec at 1/2
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 B = 4096                       # BASELINE configs[1]
 SECPAR = 256
+MIN_REGION_MS = 20.0
 
 
 def parse():
@@ -45,10 +53,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sign-verify", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the large-batch runs of the same kernels")
-    ap.add_argument("--no-two-stream", action="store_true", help="skip the two-stream pipelined variant")
+    ap.add_argument("--no-two-stream", action="store_true", help="skip the two-stream pipelined and cold-batch variants")
+    ap.add_argument("--no-kernel-table", action="store_true", help="skip the cold per-kernel table of the scheme kernels")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the BatchScheme leg (host hashing included)")
     ap.add_argument("--no-graph", action="store_true", help="launch the timed steps one by one instead of replaying hipGraphs")
     ap.add_argument("--sample-every", type=int, default=8,
-                    help="bind begin/end events to every k-th dispatch of each kernel inside the timed region")
+                    help="bind begin/end events to every k-th dispatch of each kernel in the instrumented pass")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the pure-Python baseline sample")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed run of the same steps before the W warmup steps: after idle the GPU needs tens of "
@@ -57,6 +67,9 @@ def parse():
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle's pure-Python port; rank 0 at N = 1 only)
+# ---------------------------------------------------------------------------------------------------------
 def _cpu_worker(job):
     """one host process: forward+inverse pure-Python NTTs for `seconds`; returns (transforms, seconds)"""
     index, seconds = job
@@ -76,21 +89,29 @@ def _cpu_worker(job):
 
 def cpu_baseline(seconds):
     """Pure-Python port (lists of ints, one cent() per reference cent call): ONE core (the reference is
-    single-threaded), then the same loop in one process per host core of this GPU's share."""
+    single-threaded), then the same loop in one process per host core this job may use."""
     done, dt = _cpu_worker((0, seconds))
+    ncpu = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = ncpu
     out = {"value": done / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
            "sample": f"{done // 2} rows of the {B}-row batch: forward+inverse degree-256 NTT each, pure-Python port "
-                     f"(oracle.py_ntt_forward/py_ntt_inverse), {dt:.1f} s on 1 core of {os.cpu_count()}"}
+                     f"(oracle.py_ntt_forward/py_ntt_inverse), {dt:.1f} s on 1 core of {ncpu}"}
     try:
         import subprocess
-        workers = max(1, min(16, os.cpu_count() or 1))      # a one-GPU box's share of the host
-        # plain child processes of this file (--cpu-worker): they import the oracle only and never touch the GPU
+        # BASELINE.md section 3 says "all host cores"; a one-GPU box of this pool is a 1/8 share (16 CPUs) of a
+        # 256-CPU host that seven other jobs use at the same time, and its process guard counts children -- so the pool
+        # is min(CPUs this process may run on, FZ_BENCH_CPU_WORKERS = 16); set the variable to os.cpu_count() on a
+        # machine of one's own.  The count actually used is reported as `cores`.
+        workers = max(1, min(usable, int(os.environ.get("FZ_BENCH_CPU_WORKERS", "16"))))
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--cpu-seconds",
                                    str(seconds / 3)], stdout=subprocess.PIPE, text=True) for i in range(workers)]
         res = []
         for pr in procs:
             try:
-                text, _ = pr.communicate(timeout=seconds + 60)
+                text, _ = pr.communicate(timeout=seconds + 120)
                 n, t = text.split()
                 res.append((int(n), float(t)))
             except Exception:
@@ -98,10 +119,56 @@ def cpu_baseline(seconds):
         if not res:
             raise RuntimeError("no worker finished")
         out["all_cores"] = {"value": sum(n / t for n, t in res), "unit": "NTT/s", "cores": len(res),
+                            "host_logical_cpus": ncpu, "usable_by_this_process": usable,
+                            "why_not_all": "pool = min(schedulable CPUs, FZ_BENCH_CPU_WORKERS=16): a one-GPU box is a 16-CPU "
+                                           "share of a shared 256-CPU host (see the comment in bench.py)",
                             "sample": f"{len(res)} processes x {seconds / 3:.1f} s of the same loop"}
     except Exception as e:                                   # the single-core figure stands on its own
         out["all_cores"] = {"error": repr(e)}
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# --gpus N without a launcher: this process starts the N ranks itself and never touches a GPU
+# ---------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + float(os.environ.get("FZ_BENCH_TIMEOUT", "1500"))
+    failed = None
+    while any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0) and failed is None:
+                failed = (r, p.returncode)
+        if failed or time.time() > deadline:
+            for p in procs:                              # exactly the children started above, nothing by pattern
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    line = procs[0].stdout.read() if procs[0].stdout else ""
+    for r, p in enumerate(procs):
+        p.wait()
+        if p.returncode != 0 and failed is None:
+            failed = (r, p.returncode)
+    if failed:
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}; no result\n")
+        sys.exit(1)
+    if time.time() > deadline:
+        sys.exit("bench.py: ranks did not finish in time")
+    sys.stdout.write(line)
+    sys.stdout.flush()
 
 
 def main():
@@ -110,28 +177,31 @@ def main():
         n, t = _cpu_worker((args.cpu_worker, args.cpu_seconds))
         print(n, t)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)                         # before anything in this process touches a GPU
+
     import numpy as np
     import torch
     import torch.distributed as dist
     import fusion_hip
-    from fusion_hip.dist import allreduce_sum_i64
+    from fusion_hip.dist import allreduce_sum_i64, shard_range
     from oracle import oracle as O
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     ndev = torch.cuda.device_count()
-    # one rank per GPU; the modulo only matters for a rehearsal of the N>1 path on a box with fewer GPUs
-    # (FZ_BENCH_BACKEND=gloo), where ranks share a device
+    backend = os.environ.get("FZ_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > ndev:
+        sys.exit(f"--gpus {world} but only {ndev} GPU(s) visible (FZ_BENCH_BACKEND=gloo rehearses the N>1 path on fewer)")
+    # one rank per GPU; the modulo only matters for the gloo rehearsal, where ranks share a device
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    backend = os.environ.get("FZ_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -152,6 +222,27 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def min_over_ranks(v):
+        return -max_over_ranks(-v)
+
+    # what every rank is, as the process group sees it (proof that N ranks on N devices took part)
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device": props.name,
+          "pci_bus_id": f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', -1):02x}:{getattr(props, 'pci_device_id', 0):02x}",
+          "world_size_seen": dist.get_world_size() if world > 1 else 1,
+          "backend": dist.get_backend() if world > 1 else "none (single rank)"}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
 
     # ---- NTT workload: inputs resident in HBM --------------------------------------------------
     x_host = O.splitmix_centered(20261003 + rank, B * d).reshape(B, d)
@@ -177,6 +268,16 @@ def main():
                 fn()
             torch.cuda.synchronize(dev)
 
+    def timed_on_stream(fn, reps):
+        """average milliseconds of fn() over reps back-to-back calls, HIP events on the kernels' own stream"""
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(reps):
+            fn()
+        b_.record(stream)
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b_) / reps
+
     step()
     barrier()
     assert torch.equal(z, x), "INTT(NTT(x)) != x"
@@ -184,12 +285,15 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # The timed region replays the K steps from hipGraphs recorded beforehand (fz_graph_*): the same 2K kernels in
-    # the same order on the same stream, without a host round trip per launch.  Chunks of <= 1000 steps.
+    # The K steps are recorded once (fz_graph_*; chunks of <= 1000 steps) and the recording is replayed R times inside
+    # the timed region, R from an untimed calibration replay so that the region lasts >= MIN_REGION_MS on every rank.
     chunk = min(args.steps, 1000)
     graphs = []
     if not args.no_graph:
-        for n_steps in ([chunk] if args.steps % chunk == 0 else [chunk, args.steps % chunk]):
+        for n_steps in ([chunk] * (args.steps // chunk)) + ([args.steps % chunk] if args.steps % chunk else []):
+            if graphs and graphs[0][0] == n_steps:
+                graphs.append(graphs[0])                 # the same recording, launched again
+                continue
             ctx.graph_begin()
             rc = 0
             for _ in range(n_steps):
@@ -199,26 +303,36 @@ def main():
             g.launch()                                   # untimed first replay (upload)
             graphs.append((n_steps, g))
         barrier()
+
+    def k_steps():
+        if graphs:
+            for _, g in graphs:
+                g.launch()
+        else:
+            rc = 0
+            for _ in range(args.steps):
+                rc |= step()
+            assert rc == 0, f"launch failed: {lib.fz_last_error()}"
+
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    k_steps()
+    torch.cuda.synchronize(dev)
+    t_once = max(time.perf_counter() - t0, 1e-6)
+    repeats = int(max_over_ranks(max(1.0, -(-MIN_REGION_MS * 1e-3 // t_once))))      # the same R on every rank
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
     ev0.record(stream)
-    if graphs:
-        for _ in range(args.steps // chunk):
-            graphs[0][1].launch()
-        if len(graphs) > 1:
-            graphs[1][1].launch()
-    else:
-        rc = 0
-        for _ in range(args.steps):
-            rc |= step()
-        assert rc == 0, f"launch failed: {lib.fz_last_error()}"
+    for _ in range(repeats):
+        k_steps()
     ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    region_launch_us = ev0.elapsed_time(ev1) * 1e3 / (2 * args.steps)     # HIP events over the timed region / launches
+    total_steps = repeats * args.steps
+    region_launch_us = ev0.elapsed_time(ev1) * 1e3 / (2 * total_steps)     # HIP events over the timed region / launches
     assert torch.equal(z, x), "INTT(NTT(x)) != x after the timed region"
-    for _, g in graphs:
+    for g in {id(g): g for _, g in graphs}.values():
         g.destroy()
     # Per-dispatch durations (kernel begin -> end, events bound to the dispatch on its own stream) cannot be taken
     # inside a graph: an instrumented pass of the same steps, launched one by one right after the timed region,
@@ -232,11 +346,51 @@ def main():
     prof = ctx.profile_end()
     assert prof["fwd_count"] == prof["inv_count"] == (n_inst + args.sample_every - 1) // args.sample_every
     fwd_avg, inv_avg = prof["fwd_avg_us"] * 1e-3, prof["inv_avg_us"] * 1e-3      # ms
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    value = 2.0 * B * args.steps * world / elapsed
+    elapsed = max_over_ranks(elapsed)
+    value = 2.0 * B * total_steps * world / elapsed
+
+    # ---- the launch floor, same run: an empty dispatch and a plain copy of the bytes one launch moves -----------
+    floor = None
+    if rank == 0:
+        prewarm(lambda: ctx.diag_empty_launch(), 20)
+        t_empty = timed_on_stream(lambda: ctx.diag_empty_launch(), 400)
+        cp = lambda: ctx.diag_copy_dev(x.data_ptr(), y.data_ptr(), x.numel() * 4)
+        prewarm(cp, 20)
+        t_copy = timed_on_stream(cp, 400)
+        fb = 8.0 * d * B
+        floor = {"empty_dispatch_us": t_empty * 1e3, "copy_us": t_copy * 1e3, "copy_bytes": fb,
+                 "copy_frac": fb / (t_copy * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "what": "back-to-back dependent launches on the kernels' stream, HIP events around 400 of them: an empty "
+                         "4096-workgroup dispatch, and a 16-byte-per-lane copy of the 4 MiB in / 4 MiB out a B=4096 "
+                         "transform launch moves (fz_diag_*)"}
+
+    # ---- many batches per dispatch (fz_ntt_multi): the same 4096-row batches, 1 / 2 / 4 / 8 of them per launch ---------
+    multi = None
+    if rank == 0:
+        multi = {}
+        nmax = 8
+        xs = [x] + [x.clone() for _ in range(nmax - 1)]
+        ys = [torch.empty_like(x) for _ in range(nmax)]
+        for jobs in (1, 2, 4, 8):
+            fj = [(xs[k].data_ptr(), ys[k].data_ptr(), B, False) for k in range(jobs)]
+            ij = [(ys[k].data_ptr(), ys[k].data_ptr(), B, True) for k in range(jobs)]
+            ctx.ntt_multi_dev(fj)
+            ctx.ntt_multi_dev(ij)
+            torch.cuda.synchronize(dev)
+            assert all(torch.equal(ys[k], xs[k]) for k in range(jobs)), "fz_ntt_multi round trip differs"
+            res = {}
+            for name, jl in (("fwd", fj), ("inv", ij)):
+                # `ij` transforms in place, so its inputs change every launch: values stay arbitrary int32, timing is the same
+                fn = (lambda jl=jl: ctx.ntt_multi_dev(jl))
+                prewarm(fn, 20, inner=10)
+                ms = timed_on_stream(fn, 300)
+                gbs = jobs * 8.0 * d * B / (ms * 1e-3) / 1e9
+                res[name] = {"us_per_launch": round(ms * 1e3, 2), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            multi[f"{jobs}x{B}"] = res
+        multi["what"] = ("one fz_ntt_multi dispatch over 1/2/4/8 independent batches of 4096 rows (the job table travels in the "
+                         "kernel arguments); back-to-back launches, HIP events on the stream, buffers re-used (cache-warm like the "
+                         "headline step)")
+        del xs, ys
 
     # ---- the same steps over batches that are NOT cache-resident (informational) ----------------------------
     # The timed region above re-reads the same 4 MiB batch every step, so after the first step it lives in the L2s /
@@ -263,7 +417,7 @@ def main():
             gc = ctx.graph_end()
         replay_c = gc.launch if gc else (lambda: run_cold(kc))
         prewarm(replay_c, args.prewarm_ms / 3, inner=1)
-        reps_c = max(3, args.steps // kc)
+        reps_c = max(3, int(MIN_REGION_MS / (kc * 0.01)) + 1)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(reps_c):
@@ -308,7 +462,7 @@ def main():
 
             def replay():
                 run2(k2)
-        reps2 = max(10, args.steps // k2)              # a single replay would mostly measure its own start-up
+        reps2 = max(10, int(MIN_REGION_MS / (k2 * 0.008)) + 1)      # a single replay would mostly measure its own start-up
         prewarm(replay, args.prewarm_ms / 3, inner=1 if g2 is not None else 50)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -370,103 +524,187 @@ def main():
                 sweep[f"{name}_B2^{logb}"] = {"us": round(ms * 1e3, 2), "GB/s": round(gbs, 1),
                                               "frac": round(gbs / HBM_PEAK_GBS, 4), "buffer_pairs_cycled": pairs}
             del xs, ys, x1, ptrs
+
+    # ---- every scheme kernel, cold operands, algorithmic bytes per unit from SURVEY 8d --------------------------
+    kernels = None
+    if rank == 0 and not args.no_kernel_table:
+        from tools.kernel_table import measure
+        torch.cuda.empty_cache()
+        kernels = measure(ctx, P, quick=False)
+        kernels["what"] = ("per-launch averages over operand sets carved out of a 2.25 GiB pool (every launch reads bytes no "
+                           "launch has touched for >= 2 GiB of other traffic): HBM, not cache bandwidth; HIP events on the "
+                           "kernels' stream; rocprofv3 per-kernel durations of the same launches: profiles/r02_*")
     barrier()
 
     # ---- sign + aggregate + verify (algebra cores; synthetic keys/messages) --------------------
     sv = None
     if not args.no_sign_verify:
-        S, GROUPS = 1024, 4                      # per rank: 1024 signatures in 4 aggregates of 256 x world
+        S, GROUPS, NSETS = 1024, 4, 8            # per rank: 1024 signatures in 4 aggregates of 256 x world; 8 operand sets
+        per = S // GROUPS
         rng = np.random.default_rng(1234 + rank)
         A = torch.from_numpy(O.splitmix_centered(99, l * d).reshape(l, d)).to(dev)      # same on every rank
-        coef = torch.from_numpy(rng.integers(1, 53, size=(S, 2, l, d)).astype(np.int32) *
-                                rng.choice(np.array([-1, 1], dtype=np.int32), size=(S, 2, l, d))).to(dev)
-        sk_hat = torch.empty_like(coef)
-        vk = torch.empty((S, 2, d), dtype=torch.int32, device=dev)
-        ctx.keygen_core_dev(A.data_ptr(), coef.data_ptr(), sk_hat.data_ptr(), vk.data_ptr(), S, l)
+        coef0 = torch.from_numpy(rng.integers(1, 53, size=(S, 2, l, d)).astype(np.int32) *
+                                 rng.choice(np.array([-1, 1], dtype=np.int32), size=(S, 2, l, d))).to(dev)
 
         def sparse(weight):
             c = np.zeros((S, d), np.int32)
             for i in range(S):
                 c[i, rng.choice(d, weight, replace=False)] = rng.choice([-1, 1], weight)
             return torch.from_numpy(c).to(dev)
-        c_hat = torch.empty((S, d), dtype=torch.int32, device=dev)
-        al_hat = torch.empty((S, d), dtype=torch.int32, device=dev)
-        cc, aa = sparse(P["omega_ch"]), sparse(P["omega_ag"])
-        ctx.ntt_forward_dev(cc.data_ptr(), c_hat.data_ptr(), S)
-        ctx.ntt_forward_dev(aa.data_ptr(), al_hat.data_ptr(), S)
-        vkL, vkR = vk[:, 0].contiguous(), vk[:, 1].contiguous()
-        sig = torch.empty((S, l, d), dtype=torch.int32, device=dev)
-        per = S // GROUPS
+        cc0, aa0 = sparse(P["omega_ch"]), sparse(P["omega_ag"])
+        # NSETS distinct operand sets (2.1 GB of keys + signatures): set i = the coefficients rotated by i positions.
+        # A step works on ONE set, consecutive steps on consecutive sets, so no step finds its keys or signatures in
+        # the 256 MB Infinity Cache (round 1 re-used one 262 MB set and read 79 % for sign_core out of the cache).
+        sets = []
+        for i in range(NSETS):
+            coef = torch.roll(coef0, shifts=i, dims=3).contiguous()
+            sk_hat = torch.empty_like(coef)
+            vk = torch.empty((S, 2, d), dtype=torch.int32, device=dev)
+            ctx.keygen_core_dev(A.data_ptr(), coef.data_ptr(), sk_hat.data_ptr(), vk.data_ptr(), S, l)
+            c_hat = torch.empty((S, d), dtype=torch.int32, device=dev)
+            al_hat = torch.empty((S, d), dtype=torch.int32, device=dev)
+            cc, aa = torch.roll(cc0, shifts=i, dims=1).contiguous(), torch.roll(aa0, shifts=3 * i + 1, dims=1).contiguous()
+            ctx.ntt_forward_dev(cc.data_ptr(), c_hat.data_ptr(), S)
+            ctx.ntt_forward_dev(aa.data_ptr(), al_hat.data_ptr(), S)
+            torch.cuda.synchronize(dev)
+            sets.append(dict(coef=coef, sk_hat=sk_hat, vk=vk, c_hat=c_hat, al_hat=al_hat, vkL=vk[:, 0].contiguous(),
+                             vkR=vk[:, 1].contiguous(), sig=torch.empty((S, l, d), dtype=torch.int32, device=dev)))
+        del coef0, cc0, aa0
         # one flat int64 buffer: [GROUPS][l*d] aggregate partials followed by [GROUPS][d] target partials
         part = torch.zeros(GROUPS * (l * d + d), dtype=torch.int64, device=dev)
         part_t = part[GROUPS * l * d:]
-        from fusion_hip.dist import shard_range
         g_lo, g_hi = shard_range(GROUPS, rank, world)      # aggregates verified by this rank
-        verdicts = []
         d_verd = torch.full((max(1, g_hi - g_lo),), -1, dtype=torch.int32, device=dev)   # verdict codes, read after the loop
 
-        def sv_step():
-            ctx.sign_core_dev(sk_hat.data_ptr(), c_hat.data_ptr(), sig.data_ptr(), S, l)
-            # aggregate partials and the verification target's partials: one pass over this rank's signers
-            ctx.aggregate_target_partial_batch_dev(sig.data_ptr(), al_hat.data_ptr(), vkL.data_ptr(), vkR.data_ptr(),
-                                                   c_hat.data_ptr(), part.data_ptr(), l * d, part_t.data_ptr(), d,
-                                                   GROUPS, per, l)
-            allreduce_sum_i64(part)              # the ONE exchange step (RCCL over xGMI when world > 1)
+        # the exchange step through the C ABI: rank 0's ncclUniqueId travels over the torch process group, every rank
+        # joins with fz_comm_create; the all-reduce is then a node of the library's own graph.  If RCCL refuses (e.g.
+        # the gloo rehearsal with ranks sharing one GPU), every rank falls back to torch.distributed together.
+        comm, collective = None, "none (single rank: no exchange step)"
+        if world > 1:
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid = [fusion_hip.comm_unique_id()]
+                except fusion_hip.FusionHipError as e:
+                    uid = [repr(e)]
+            dist.broadcast_object_list(uid, src=0)
+            ok = 0.0
+            if isinstance(uid[0], bytes) and backend == "nccl":
+                try:
+                    comm = fusion_hip.Comm(ctx, world, rank, uid[0])
+                    ok = 1.0 if comm.info()[0] == world else 0.0
+                except fusion_hip.FusionHipError as e:
+                    sys.stderr.write(f"rank {rank}: fz_comm_create failed: {e}\n")
+            if min_over_ranks(ok) < 1.0:
+                if comm is not None:
+                    comm.destroy()
+                comm = None
+                collective = f"torch.distributed all_reduce ({backend}); fz_comm_* not usable in this run"
+            else:
+                collective = f"fz_allreduce_i64 (ncclAllReduce int64 sum through the C ABI), comm of {comm.info()[0]} ranks"
+
+        def sv_step(i):
+            s_ = sets[i % NSETS]
+            ctx.sign_core_dev(s_["sk_hat"].data_ptr(), s_["c_hat"].data_ptr(), s_["sig"].data_ptr(), S, l)
+            # aggregate partials and the verification target's partials: one pass over this rank's signers, one launch
+            ctx.aggregate_target_partial_batch_dev(s_["sig"].data_ptr(), s_["al_hat"].data_ptr(), s_["vkL"].data_ptr(),
+                                                   s_["vkR"].data_ptr(), s_["c_hat"].data_ptr(), part.data_ptr(), l * d,
+                                                   part_t.data_ptr(), d, GROUPS, per, l)
+            if comm is not None:         # the ONE exchange step (RCCL over xGMI)
+                ctx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
+            else:
+                allreduce_sum_i64(part)
             if g_hi > g_lo:          # verdicts straight from the int64 sums, left on the device: no host synchronisation
                 ctx.verify_partials_batch_async_dev(
                     A.data_ptr(), part[g_lo * l * d:].data_ptr(), l * d, part_t[g_lo * d:].data_ptr(), d,
                     g_hi - g_lo, l, P["beta_vf"], d, d_verd.data_ptr())
-        sv_steps = max(3, min(args.steps, 30))
+
+        for i in range(NSETS):
+            sv_step(i)
+            barrier()
+            assert g_hi == g_lo or all(v == 0 for v in d_verd.tolist()), f"verify verdicts {d_verd.tolist()} on set {i}"
+        # one graph = NSETS steps (every set once); refused together if any rank cannot capture (e.g. the collective)
+        sv_graph, captured = None, 0.0
+        if not args.no_graph and (world == 1 or comm is not None):
+            try:
+                ctx.graph_begin()
+                try:
+                    for i in range(NSETS):
+                        sv_step(i)
+                finally:
+                    sv_graph = ctx.graph_end()
+                captured = 1.0
+            except fusion_hip.FusionHipError as e:
+                sys.stderr.write(f"rank {rank}: sign_verify capture failed: {e}\n")
+                sv_graph = None
+        if min_over_ranks(captured) < 1.0:
+            sv_graph = None
+
+        def sv_round():
+            if sv_graph is not None:
+                sv_graph.launch()
+            else:
+                for i in range(NSETS):
+                    sv_step(i)
         for _ in range(2):
-            sv_step()
-        for _ in range(300 if args.prewarm_ms > 0 else 0):      # count-based: every rank must issue the same collectives
-            sv_step()
+            sv_round()
+        for _ in range(40 if args.prewarm_ms > 0 else 0):      # count-based: every rank must issue the same collectives
+            sv_round()
         barrier()
-        verdicts = d_verd.tolist() if g_hi > g_lo else []
-        assert all(v == 0 for v in verdicts), f"verify verdicts {verdicts}"
+        torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(sv_steps):
-            sv_step()
+        sv_round()
+        torch.cuda.synchronize(dev)
+        t_once = max(time.perf_counter() - t0, 1e-6)
+        sv_rounds = int(max_over_ranks(max(3.0, -(-2 * MIN_REGION_MS * 1e-3 // t_once))))
         barrier()
-        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(sv_rounds):
+            sv_round()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
         assert g_hi == g_lo or all(v == 0 for v in d_verd.tolist()), "a verification failed inside the timed region"
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        sv_steps = sv_rounds * NSETS
         sv = {"value": S * world * sv_steps / dt, "unit": "signatures signed+aggregated+verified per s",
               "signatures_per_rank": S, "aggregates": GROUPS, "signers_per_aggregate": per * world,
-              "steps": sv_steps, "ms_per_step": dt / sv_steps * 1e3,
-              "note": "algebra cores only: sign_core, aggregate + target partials (one pass), int64 all-reduce, verification "
-                      "from the int64 sums -- 4 kernel launches per step; "
-                      "host hashing of str(vk) excluded"}
+              "steps": sv_steps, "ms_per_step": dt / sv_steps * 1e3, "operand_sets_cycled": NSETS,
+              "launch": "hipGraph replay of %d steps (fz_graph_*)" % NSETS if sv_graph is not None else "one by one",
+              "collective": collective,
+              "algorithmic_GB/s_per_gpu": S * ((3 * l + 1) + (l + 5)) * 4 * d * sv_steps / dt / 1e9,
+              "note": "algebra cores only: sign_core, aggregate + target partials (one pass, one launch), int64 all-reduce, "
+                      "verification from the int64 sums -- 3 kernel launches (+ the collective) per step; every step works on "
+                      "the next of 8 operand sets (2.1 GB), so keys and signatures come from HBM; host hashing of str(vk) excluded"}
+        if sv_graph is not None:
+            sv_graph.destroy()
         # BASELINE configs[2]: 1024 independent keygen + sign per step (keygen_core: 2*l transforms + two A.s
         # products per key; sign_core: sigma = L*c + R), no exchange step: ranks are independent
-        ks_steps = sv_steps
-
-        def ks_step():
-            ctx.keygen_core_dev(A.data_ptr(), coef.data_ptr(), sk_hat.data_ptr(), vk.data_ptr(), S, l)
-            ctx.sign_core_dev(sk_hat.data_ptr(), c_hat.data_ptr(), sig.data_ptr(), S, l)
-        for _ in range(100 if args.prewarm_ms > 0 else 2):
-            ks_step()
+        def ks_step(i):
+            s_ = sets[i % NSETS]
+            ctx.keygen_core_dev(A.data_ptr(), s_["coef"].data_ptr(), s_["sk_hat"].data_ptr(), s_["vk"].data_ptr(), S, l)
+            ctx.sign_core_dev(s_["sk_hat"].data_ptr(), s_["c_hat"].data_ptr(), s_["sig"].data_ptr(), S, l)
+        for i in range(100 if args.prewarm_ms > 0 else 2):
+            ks_step(i)
         barrier()
+        ks_steps = NSETS * max(3, int(2 * MIN_REGION_MS / (NSETS * 0.15)) + 1)
         t0 = time.perf_counter()
-        for _ in range(ks_steps):
-            ks_step()
+        for i in range(ks_steps):
+            ks_step(i)
         barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = max_over_ranks(time.perf_counter() - t0)
         sv["keygen_sign"] = {"value": S * world * ks_steps / dt, "unit": "keygen+sign per s", "per_rank": S, "steps": ks_steps,
-                             "ms_per_step": dt / ks_steps * 1e3,
+                             "ms_per_step": dt / ks_steps * 1e3, "operand_sets_cycled": NSETS,
                              "algorithmic_GB/s_per_gpu": S * ((4 * l + 2) + (3 * l + 1)) * 4 * d * ks_steps / dt / 1e9,
-                             "note": "configs[2]: keygen_core + sign_core on 1024 distinct synthetic keys per rank"}
+                             "note": "configs[2]: keygen_core + sign_core on 1024 distinct synthetic keys per rank; sign reads the "
+                                     "sk_hat keygen has just written (174 MB: part of it may still sit in the Infinity Cache), "
+                                     "coefficients come from HBM (8 sets rotated)"}
+        if comm is not None:
+            barrier()
+            comm.destroy()
+        del sets
 
     # ---- end to end through the array API: host hashing (C pipeline) + device algebra ------------------
     e2e = None
-    if rank == 0 and not args.no_sign_verify:
+    if rank == 0 and not args.no_sign_verify and not args.no_end_to_end:
         import fusion.fusion as F
         from fusion_hip.scheme import BatchScheme
         params = F.fusion_setup(SECPAR, 2026)
@@ -498,42 +736,48 @@ def main():
                        "challenges and aggregation coefficients cross PCIe; hash_ag is one serial XOF by construction"}
 
     if rank == 0:
-        # HBM-side traffic of this launch from the PMC counters (rocprofv3 --pmc, separate passes; FETCH_SIZE
-        # corrected x2 for gfx950): cannot be collected live, so the committed measurement is reported
-        traffic = None
+        # HBM-side traffic of this launch from the PMC counters (rocprofv3 --pmc, separate passes; FETCH_SIZE corrected x2
+        # for gfx950) cannot be collected live: the committed measurement of THIS round's kernel is reported, or null
+        traffic, traffic_note = None, "no PMC file for this kernel under profiles/ (tools/collect_profiles.sh writes r02_pmc_ntt.json)"
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_ntt.json")) as fh:
-                kernels = json.load(fh)["kernels"]
-            key = next(k for k in kernels if k.startswith("ntt_fwd4<8") and "B=4096" in k)
-            traffic = kernels[key]["traffic_bytes_per_launch"]
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_ntt.json")) as fh:
+                kernels_pmc = json.load(fh)["kernels"]
+            key = next(k for k in kernels_pmc if k.startswith("ntt_fwd4<8") and "B=4096" in k)
+            traffic = kernels_pmc[key]["traffic_bytes_per_launch"]
+            traffic_note = "profiles/r02_pmc_ntt.json (PMC pass of the same launch, committed this round)"
         except Exception:
             pass
         fwd_bytes = 8.0 * d * B
         ach = fwd_bytes / (fwd_avg * 1e-3) / 1e9
         out = {
-            "metric": METRIC, "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "metric": METRIC, "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "repeats": repeats,
+            "warmup": args.warmup, "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "timed_region_ms": elapsed * 1e3,
             "config": {"workload": f"configs[1]: secpar={SECPAR}, batch of {B} degree-{d} forward+inverse NTTs per GPU",
                        "batch": B, "degree": d, "modulus": q, "kernels_per_step": 2,
                        "arithmetic": "exact integers carried in fp64 lanes (results bit-identical to the reference's int arithmetic); int32 in and out",
-                       "launch": "one by one" if args.no_graph else "hipGraph replay (fz_graph_*)", "prewarm_ms": args.prewarm_ms},
+                       "launch": "one by one" if args.no_graph else f"hipGraph of {args.steps} steps (fz_graph_*), replayed {repeats} times in the timed region",
+                       "prewarm_ms": args.prewarm_ms},
+            "ranks": ranks,
             "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8> (forward NTT, B=4096)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_note,
                          "bytes_per_launch": fwd_bytes, "butterflies_per_s": value * (d // 2) * 8, "avg_launch_us": fwd_avg * 1e3,
                          "inverse_avg_launch_us": inv_avg * 1e3, "launches_timed": prof["fwd_count"],
                          "timing": f"per-dispatch begin/end events (hipExtLaunchKernelGGL) on every {args.sample_every}th dispatch of "
                                    f"{n_inst} steps launched one by one right after the timed region (a hipGraph cannot carry them)",
                          "region": {"avg_launch_us": region_launch_us, "achieved": fwd_bytes / (region_launch_us * 1e-6) / 1e9,
                                     "frac": fwd_bytes / (region_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                    "what": "HIP events around the timed region on the kernels' stream / 2K launches "
+                                    "what": "HIP events around the timed region on the kernels' stream / launches "
                                             "(consecutive dispatches overlap their launch and drain phases)"},
-                         "sweep": sweep},
+                         "copy_floor": floor, "multi_job": multi, "kernels": kernels, "sweep": sweep},
             "cold_batches": cold, "two_stream_pipelined": two_stream, "sign_verify": sv, "end_to_end": e2e, "pcie_inclusive": pcie,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         barrier()                                       # rank 0's single-rank legs are done: leave together
         dist.destroy_process_group()

@@ -29,6 +29,7 @@ struct FzMod {
     double kappa;  // delta / K, exact (delta < 2^k, power-of-two scaling)
     double magic;  // 1.5 * 2^52 * K: adding it rounds to the nearest multiple of K
     int fast;      // 1 when delta < 2^15, i.e. fz_mulmod4 is exact for |a| <= 2^38
+    double r32;    // 2^32 mod q (fz_cent_i64)
 };
 
 FZ_HD FzMod fz_make_mod(unsigned q) {
@@ -42,6 +43,7 @@ FZ_HD FzMod fz_make_mod(unsigned q) {
     m.kappa = (double)(K - q) / (double)K;
     m.magic = 6755399441055744.0 * (double)K;      // 1.5 * 2^52 * K
     m.fast = (K - q) < 32768ull ? 1 : 0;
+    m.r32 = (double)(4294967296ull % q);
     return m;
 }
 
@@ -80,12 +82,27 @@ FZ_HD double fz_cent(double x, const FzMod m) {
     return __builtin_fma(-c, m.q, x);
 }
 
-// cent() for |x| up to 2^62 (int64 accumulators): two steps.
+// cent() of an integer-valued double beyond fz_cent's 2^19 * q bound (lazily accumulated fp64 sums, |x| < 2^53):
+// two steps -- the first brings |x| below ~q (exact FMA as above), the second makes it canonical.
 FZ_HD double fz_cent_wide(double x, const FzMod m) {
-    // first bring |x| below ~q (x integer-valued double, exact FMA as above)
     double c = __builtin_rint(x * m.qinv);
     double r = __builtin_fma(-c, m.q, x);
     return fz_cent(r, m);
+}
+
+// x - q * rint(x / q) for any integer-valued |x| < 2^80: NOT canonical (|r| <= q/2 * (1 + 2^-20)), but exact --
+// the FMA's true result is an integer below 2^32, hence representable.  Folds lazily accumulated sums.
+FZ_HD double fz_fold(double x, const FzMod m) {
+    return __builtin_fma(-__builtin_rint(x * m.qinv), m.q, x);
+}
+
+// cent() of ANY int64 (partial sums that crossed an all-reduce): converting v itself to double is exact only below
+// 2^53, so split v = hi * 2^32 + lo (hi signed, lo unsigned 32-bit halves, both exact as doubles) and reduce
+// hi * 2^32 with the exact FMA multiply: |hi * r32| < 2^62 is inside fz_mulmod's bound.
+FZ_HD double fz_cent_i64(long long v, const FzMod m) {
+    const double hi = (double)(int)(v >> 32);
+    const double lo = (double)(unsigned)(v & 0xffffffffll);
+    return fz_cent(fz_mulmod(hi, m.r32, m) + lo, m);                                  // |.| < q + 2^32 < 2^19 * q
 }
 
 // cent(a*b) for int32-range a, b: canonical.

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <dlfcn.h>
 
 static thread_local char g_err[512] = "";
 
@@ -27,6 +28,10 @@ int fz_check_hip(hipError_t e, const char *what) {
 #define FZ_TRY(x) do { int rc_ = (x); if (rc_ != FZ_OK) return rc_; } while (0)
 #define FZ_HIP(x, what) FZ_TRY(fz_check_hip((x), what))
 #define FZ_REQUIRE(cond, ...) do { if (!(cond)) return fz_set_error(FZ_E_BADARG, __VA_ARGS__); } while (0)
+// Every entry point that touches the device makes the context's device current first: a process may hold contexts on
+// several GPUs (and other code -- torch -- may have changed the current device behind our back); kernels, scratch
+// allocations and events must land on ctx->device whatever stream the caller attached.
+#define FZ_DEV(ctx) FZ_HIP(hipSetDevice((ctx)->device), "hipSetDevice")
 
 static uint64_t powmod_u64(uint64_t b, uint64_t e, uint64_t q) {
     unsigned __int128 r = 1, x = b % q;
@@ -102,8 +107,42 @@ int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, doub
             ctx->vstate_groups = cap;
         }
     }
+    if (ctx->verify_dirty) {                       // an earlier launch failed: do not trust "zero between launches"
+        if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "verify scratch must be re-zeroed: not during graph capture");
+        FZ_HIP(hipMemsetAsync(ctx->d_vpart, 0, ctx->vpart_doubles * sizeof(double), ctx->stream), "verify scratch clear");
+        FZ_HIP(hipMemsetAsync(ctx->d_vstate, 0, ctx->vstate_groups * 2 * sizeof(int), ctx->stream), "verify state clear");
+        ctx->verify_dirty = 0;
+    }
     *part = ctx->d_vpart;
     *state = ctx->d_vstate;
+    return FZ_OK;
+}
+
+// accumulators + tickets of the one-pass aggregation (zero between launches; see aggregate_onepass)
+int fz_agg_scratch(fz_ctx *ctx, size_t tiles, size_t tile_doubles, double **acc, unsigned **tickets) {
+    if (tiles > ctx->aggacc_tiles) {
+        if (ctx->capturing)
+            return fz_set_error(FZ_E_BADARG, "aggregation scratch would grow during graph capture: run the sequence once before fz_graph_begin");
+        FZ_HIP(hipStreamSynchronize(ctx->stream), "aggregation scratch sync");
+        if (ctx->d_aggacc) FZ_HIP(hipFree(ctx->d_aggacc), "aggregation scratch free");
+        if (ctx->d_aggtick) FZ_HIP(hipFree(ctx->d_aggtick), "aggregation tickets free");
+        ctx->d_aggacc = nullptr;
+        ctx->d_aggtick = nullptr;
+        ctx->aggacc_tiles = 0;
+        const size_t cap = tiles + tiles / 4 + 8;
+        FZ_HIP(hipMalloc((void **)&ctx->d_aggacc, cap * tile_doubles * sizeof(double)), "aggregation scratch alloc");
+        FZ_HIP(hipMalloc((void **)&ctx->d_aggtick, ((cap * sizeof(unsigned) + 15) / 16) * 16), "aggregation tickets alloc");
+        ctx->aggacc_tiles = cap;
+        ctx->agg_dirty = 1;
+    }
+    if (ctx->agg_dirty) {
+        if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "aggregation scratch must be re-zeroed: not during graph capture");
+        FZ_HIP(hipMemsetAsync(ctx->d_aggacc, 0, ctx->aggacc_tiles * tile_doubles * sizeof(double), ctx->stream), "aggregation scratch clear");
+        FZ_HIP(hipMemsetAsync(ctx->d_aggtick, 0, ((ctx->aggacc_tiles * sizeof(unsigned) + 15) / 16) * 16, ctx->stream), "aggregation tickets clear");
+        ctx->agg_dirty = 0;
+    }
+    *acc = ctx->d_aggacc;
+    *tickets = ctx->d_aggtick;
     return FZ_OK;
 }
 
@@ -260,6 +299,17 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         // kernel ahead from 2^16 (61 % vs 58 % of HBM peak; 2^18: 70 % vs 61 %); degree 64 -- radix-4 up to 2^18
         // rows, 16-per-lane from 2^20
         c->small_batch_rows = e ? atoi(e) : (degree == 256 ? (1 << 16) : (1 << 19));
+        // every benchmarking knob is read HERE, once: no entry point consults the environment afterwards
+        auto knob = [](const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; };
+        c->knob_agg_twopass = knob("FZ_AGG_TWOPASS");
+        c->knob_agg_waves = knob("FZ_AGG_WAVES");
+        if (c->knob_agg_waves != 4 && c->knob_agg_waves != 8) c->knob_agg_waves = 0;
+        c->knob_agg_slices = knob("FZ_AGG_SLICES");
+        c->knob_verify_blocks = knob("FZ_VERIFY_BLOCKS");
+        c->knob_verify_unfused = knob("FZ_VERIFY_UNFUSED");
+        c->knob_verify_ordered = knob("FZ_VERIFY_ORDERED");
+        c->knob_keygen_unfused = knob("FZ_KEYGEN_UNFUSED");
+        c->knob_polymul_unfused = knob("FZ_POLYMUL_UNFUSED");
     }
     if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
     if (rc == FZ_OK) rc = upload_doubles(itwB, nB, &c->d_itwB);
@@ -292,6 +342,8 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     }
     if (ctx->d_vpart) (void)hipFree(ctx->d_vpart);
     if (ctx->d_vstate) (void)hipFree(ctx->d_vstate);
+    if (ctx->d_aggacc) (void)hipFree(ctx->d_aggacc);
+    if (ctx->d_aggtick) (void)hipFree(ctx->d_aggtick);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     free(ctx->h_tw);
@@ -309,6 +361,7 @@ int fz_ctx_set_stream(fz_ctx *ctx, void *hip_stream) {
 
 int fz_ctx_synchronize(fz_ctx *ctx) {
     FZ_REQUIRE(ctx, "ctx is NULL");
+    FZ_DEV(ctx);
     if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "synchronisation is not allowed during graph capture");
     FZ_HIP(hipStreamSynchronize(ctx->stream), "stream synchronize");
     return FZ_OK;
@@ -316,7 +369,7 @@ int fz_ctx_synchronize(fz_ctx *ctx) {
 
 int fz_stream_create(fz_ctx *ctx, void **out_stream) {
     FZ_REQUIRE(ctx && out_stream, "NULL argument");
-    FZ_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    FZ_DEV(ctx);
     hipStream_t s = nullptr;
     FZ_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "stream create");
     *out_stream = (void *)s;
@@ -325,6 +378,7 @@ int fz_stream_create(fz_ctx *ctx, void **out_stream) {
 
 int fz_stream_destroy(fz_ctx *ctx, void *hip_stream) {
     FZ_REQUIRE(ctx, "ctx is NULL");
+    FZ_DEV(ctx);
     if (!hip_stream) return FZ_OK;
     if (ctx->stream == (hipStream_t)hip_stream) return fz_set_error(FZ_E_BADARG, "the stream is still attached to this context");
     FZ_HIP(hipStreamDestroy((hipStream_t)hip_stream), "stream destroy");
@@ -334,6 +388,7 @@ int fz_stream_destroy(fz_ctx *ctx, void *hip_stream) {
 // ---- graph capture: a launch-bound sequence of device-pointer calls recorded once, replayed with one call ------
 int fz_graph_begin(fz_ctx *ctx) {
     FZ_REQUIRE(ctx, "ctx is NULL");
+    FZ_DEV(ctx);
     if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "a capture is already open on this context");
     if (ctx->stream == nullptr)
         return fz_set_error(FZ_E_BADARG, "graph capture needs a non-default stream (fz_ctx_set_stream)");
@@ -346,6 +401,7 @@ int fz_graph_begin(fz_ctx *ctx) {
 
 int fz_graph_end(fz_ctx *ctx, fz_graph **out_graph) {
     FZ_REQUIRE(ctx && out_graph, "NULL argument");
+    FZ_DEV(ctx);
     if (!ctx->capturing) return fz_set_error(FZ_E_BADARG, "no capture is open on this context");
     ctx->capturing = 0;
     hipGraph_t g = nullptr;
@@ -367,6 +423,7 @@ int fz_graph_end(fz_ctx *ctx, fz_graph **out_graph) {
 
 int fz_graph_launch(fz_ctx *ctx, fz_graph *graph) {
     FZ_REQUIRE(ctx && graph, "NULL argument");
+    FZ_DEV(ctx);
     if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "a graph cannot be launched into its own capture");
     if (graph->device != ctx->device) return fz_set_error(FZ_E_BADARG, "graph was captured on device %d", graph->device);
     FZ_HIP(hipGraphLaunch(graph->exec, ctx->stream), "graph launch");
@@ -391,25 +448,28 @@ int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv) {
 
 int fz_malloc(fz_ctx *ctx, size_t bytes, void **d_out) {
     FZ_REQUIRE(ctx && d_out, "NULL argument");
-    FZ_HIP(hipSetDevice(ctx->device), "hipSetDevice");
+    FZ_DEV(ctx);
     FZ_HIP(hipMalloc(d_out, bytes ? bytes : 1), "hipMalloc");
     return FZ_OK;
 }
 
 int fz_free(fz_ctx *ctx, void *d_ptr) {
     FZ_REQUIRE(ctx, "ctx is NULL");
+    FZ_DEV(ctx);
     if (d_ptr) FZ_HIP(hipFree(d_ptr), "hipFree");
     return FZ_OK;
 }
 
 int fz_memcpy_h2d(fz_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     FZ_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), "NULL argument");
+    FZ_DEV(ctx);
     if (bytes) FZ_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream), "memcpy h2d");
     return FZ_OK;
 }
 
 int fz_memcpy_d2h(fz_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     FZ_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "NULL argument");
+    FZ_DEV(ctx);
     if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "a synchronous device-to-host copy cannot be captured");
     if (bytes) FZ_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream), "memcpy d2h");
     FZ_HIP(hipStreamSynchronize(ctx->stream), "memcpy d2h sync");
@@ -418,12 +478,14 @@ int fz_memcpy_d2h(fz_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
 
 int fz_timer_start(fz_ctx *ctx) {
     FZ_REQUIRE(ctx, "ctx is NULL");
+    FZ_DEV(ctx);
     FZ_HIP(hipEventRecord(ctx->ev0, ctx->stream), "event record");
     return FZ_OK;
 }
 
 int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms) {
     FZ_REQUIRE(ctx && out_ms, "NULL argument");
+    FZ_DEV(ctx);
     if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the timer cannot be read during graph capture");
     FZ_HIP(hipEventRecord(ctx->ev1, ctx->stream), "event record");
     FZ_HIP(hipEventSynchronize(ctx->ev1), "event synchronize");
@@ -433,6 +495,7 @@ int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms) {
 
 int fz_profile_begin(fz_ctx *ctx, int max_launches, int sample_every) {
     FZ_REQUIRE(ctx && max_launches > 0 && max_launches <= (1 << 20) && sample_every >= 1, "bad argument");
+    FZ_DEV(ctx);
     if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "per-dispatch profiling cannot start during graph capture");
     if (max_launches > ctx->prof_cap) {
         hipEvent_t *ev = (hipEvent_t *)realloc(ctx->prof_ev, sizeof(hipEvent_t) * 2 * (size_t)max_launches);
@@ -452,6 +515,7 @@ int fz_profile_begin(fz_ctx *ctx, int max_launches, int sample_every) {
 
 int fz_profile_end(fz_ctx *ctx, double *fwd_avg_us, int *fwd_count, double *inv_avg_us, int *inv_count) {
     FZ_REQUIRE(ctx && fwd_avg_us && fwd_count && inv_avg_us && inv_count, "NULL argument");
+    FZ_DEV(ctx);
     ctx->prof_on = 0;
     FZ_HIP(hipStreamSynchronize(ctx->stream), "profile sync");
     double sum[2] = {0, 0};
@@ -473,16 +537,19 @@ int fz_profile_end(fz_ctx *ctx, double *fwd_avg_us, int *fwd_count, double *inv_
 // ---- transforms ----------------------------------------------------------------------------
 int fz_ntt_forward(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch) {
     FZ_REQUIRE(ctx && (batch == 0 || (d_in && d_out)), "NULL argument");
+    FZ_DEV(ctx);
     return fz_launch_ntt(ctx, d_in, d_out, batch, false);
 }
 
 int fz_ntt_inverse(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch) {
     FZ_REQUIRE(ctx && (batch == 0 || (d_in && d_out)), "NULL argument");
+    FZ_DEV(ctx);
     return fz_launch_ntt(ctx, d_in, d_out, batch, true);
 }
 
 static int ntt_host(fz_ctx *ctx, int32_t *h_data, size_t batch, bool inverse) {
     FZ_REQUIRE(ctx && (batch == 0 || h_data), "NULL argument");
+    FZ_DEV(ctx);
     if (batch == 0) return FZ_OK;
     const size_t bytes = batch * (size_t)ctx->degree * sizeof(int32_t);
     void *d = nullptr;
@@ -497,31 +564,38 @@ int fz_ntt_inverse_host(fz_ctx *ctx, int32_t *h_data, size_t batch) { return ntt
 // ---- pointwise -------------------------------------------------------------------------------
 int fz_pw_mul(fz_ctx *ctx, const int32_t *a, const int32_t *b, int32_t *out, size_t count) {
     FZ_REQUIRE(ctx && (count == 0 || (a && b && out)), "NULL argument");
+    FZ_DEV(ctx);
     return fz_launch_pw(ctx, FZ_OP_MUL, a, b, out, count);
 }
 int fz_pw_add(fz_ctx *ctx, const int32_t *a, const int32_t *b, int32_t *out, size_t count) {
     FZ_REQUIRE(ctx && (count == 0 || (a && b && out)), "NULL argument");
+    FZ_DEV(ctx);
     return fz_launch_pw(ctx, FZ_OP_ADD, a, b, out, count);
 }
 int fz_pw_sub(fz_ctx *ctx, const int32_t *a, const int32_t *b, int32_t *out, size_t count) {
     FZ_REQUIRE(ctx && (count == 0 || (a && b && out)), "NULL argument");
+    FZ_DEV(ctx);
     return fz_launch_pw(ctx, FZ_OP_SUB, a, b, out, count);
 }
 int fz_pw_neg(fz_ctx *ctx, const int32_t *a, int32_t *out, size_t count) {
     FZ_REQUIRE(ctx && (count == 0 || (a && out)), "NULL argument");
+    FZ_DEV(ctx);
     return fz_launch_pw(ctx, FZ_OP_NEG, a, a, out, count);
 }
 int fz_pw_mulacc(fz_ctx *ctx, int32_t *acc, const int32_t *a, const int32_t *b, size_t count) {
     FZ_REQUIRE(ctx && (count == 0 || (acc && a && b)), "NULL argument");
+    FZ_DEV(ctx);
     return fz_launch_pw(ctx, FZ_OP_MULACC, a, b, acc, count);
 }
 int fz_pw_mul_bcast(fz_ctx *ctx, const int32_t *a, const int32_t *s, int32_t *out, size_t rows) {
     FZ_REQUIRE(ctx && (rows == 0 || (a && s && out)), "NULL argument");
+    FZ_DEV(ctx);
     return fz_launch_pw_bcast(ctx, a, s, out, rows);
 }
 
 int fz_pw_binary_host(fz_ctx *ctx, int op, const int32_t *h_a, const int32_t *h_b, int32_t *h_out, size_t count) {
     FZ_REQUIRE(ctx && op >= FZ_OP_MUL && op <= FZ_OP_NEG, "bad op %d", op);
+    FZ_DEV(ctx);
     FZ_REQUIRE(count == 0 || (h_a && h_out && (op == FZ_OP_NEG || h_b)), "NULL argument");
     if (count == 0) return FZ_OK;
     const size_t seg = (count * sizeof(int32_t) + 255) & ~(size_t)255;
@@ -537,15 +611,17 @@ int fz_pw_binary_host(fz_ctx *ctx, int op, const int32_t *h_a, const int32_t *h_
 // ---- synthetic batches ----------------------------------------------------------------------------
 int fz_fill_synthetic(fz_ctx *ctx, int32_t *d_out, size_t count, uint64_t seed) {
     FZ_REQUIRE(ctx && (count == 0 || d_out), "NULL argument");
+    FZ_DEV(ctx);
     return fz_launch_fill_synthetic(ctx, d_out, count, (unsigned long long)seed);
 }
 
 // ---- negacyclic product -------------------------------------------------------------------------
 int fz_poly_mul(fz_ctx *ctx, const int32_t *d_f, const int32_t *d_g, int32_t *d_out, size_t batch) {
     FZ_REQUIRE(ctx && (batch == 0 || (d_f && d_g && d_out)), "NULL argument");
+    FZ_DEV(ctx);
     if (ctx->logd < 0) return fz_set_error(FZ_E_UNSUPPORTED, "ring-only context (created with root 0) has no transforms");
     if (batch == 0) return FZ_OK;
-    if ((ctx->logd == 6 || ctx->logd == 8) && !getenv("FZ_POLYMUL_UNFUSED")) {
+    if ((ctx->logd == 6 || ctx->logd == 8) && !ctx->knob_polymul_unfused) {
         if ((((uintptr_t)d_f | (uintptr_t)d_g | (uintptr_t)d_out) & 3) != 0)
             return fz_set_error(FZ_E_BADARG, "buffers must be 4-byte aligned");
         return fz_launch_polymul_fused(ctx, d_f, d_g, d_out, batch);
@@ -563,6 +639,7 @@ int fz_poly_mul(fz_ctx *ctx, const int32_t *d_f, const int32_t *d_g, int32_t *d_
 
 int fz_poly_mul_host(fz_ctx *ctx, const int32_t *h_f, const int32_t *h_g, int32_t *h_out, size_t batch) {
     FZ_REQUIRE(ctx && (batch == 0 || (h_f && h_g && h_out)), "NULL argument");
+    FZ_DEV(ctx);
     if (ctx->logd < 0) return fz_set_error(FZ_E_UNSUPPORTED, "ring-only context (created with root 0) has no transforms");
     if (batch == 0) return FZ_OK;
     const size_t bytes = batch * (size_t)ctx->degree * sizeof(int32_t), seg = (bytes + 255) & ~(size_t)255;
@@ -578,11 +655,13 @@ int fz_poly_mul_host(fz_ctx *ctx, const int32_t *h_f, const int32_t *h_g, int32_
 // ---- matrix-vector ------------------------------------------------------------------------------
 int fz_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *out, size_t batch, int l) {
     FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (A && S && out)), "bad argument");
+    FZ_DEV(ctx);
     return fz_launch_matvec(ctx, A, S, out, batch, l);
 }
 
 int fz_matvec_host(fz_ctx *ctx, const int32_t *h_A, const int32_t *h_S, int32_t *h_out, size_t batch, int l) {
     FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (h_A && h_S && h_out)), "bad argument");
+    FZ_DEV(ctx);
     if (batch == 0) return FZ_OK;
     const size_t row = (size_t)ctx->degree * sizeof(int32_t);
     const size_t bA = (size_t)l * row, bS = batch * (size_t)l * row, bO = batch * row;
@@ -600,9 +679,10 @@ int fz_matvec_host(fz_ctx *ctx, const int32_t *h_A, const int32_t *h_S, int32_t 
 int fz_keygen_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef, int32_t *d_sk_hat, int32_t *d_vk,
                    size_t batch, int l) {
     FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (d_A && d_coef && d_sk_hat && d_vk)), "bad argument");
+    FZ_DEV(ctx);
     // sk_hat = NTT(every secret row); vk_{L,R} = A . sk_hat_{L,R}   (fusion/fusion.py:363-370)
     if (batch == 0) return FZ_OK;
-    if ((ctx->logd == 6 || ctx->logd == 8) && batch * 2 <= 0x7fffffffu && !getenv("FZ_KEYGEN_UNFUSED") &&
+    if ((ctx->logd == 6 || ctx->logd == 8) && batch * 2 <= 0x7fffffffu && !ctx->knob_keygen_unfused &&
         ((((uintptr_t)d_A | (uintptr_t)d_coef | (uintptr_t)d_sk_hat) & 15) == 0))
         return fz_launch_keygen_fused(ctx, d_A, d_coef, d_sk_hat, d_vk, batch * 2, l);   // one launch, sk_hat not re-read
     FZ_TRY(fz_launch_ntt(ctx, d_coef, d_sk_hat, batch * 2 * (size_t)l, false));
@@ -612,8 +692,9 @@ int fz_keygen_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef, int32
 int fz_keygen_core_bcast(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef, int32_t *d_sk_hat, int32_t *d_vk,
                          size_t batch, int l) {
     FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (d_A && d_coef && d_sk_hat && d_vk)), "bad argument");
+    FZ_DEV(ctx);
     if (batch == 0) return FZ_OK;
-    if ((ctx->logd == 6 || ctx->logd == 8) && batch * 2 <= 0x7fffffffu && !getenv("FZ_KEYGEN_UNFUSED") &&
+    if ((ctx->logd == 6 || ctx->logd == 8) && batch * 2 <= 0x7fffffffu && !ctx->knob_keygen_unfused &&
         ((((uintptr_t)d_A | (uintptr_t)d_coef | (uintptr_t)d_sk_hat) & 15) == 0))
         return fz_launch_keygen_fused(ctx, d_A, d_coef, d_sk_hat, d_vk, batch * 2, l, true);
     // generic degrees: expand the rows in sk_hat, transform in place, then the products
@@ -624,12 +705,14 @@ int fz_keygen_core_bcast(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef,
 
 int fz_sign_core(fz_ctx *ctx, const int32_t *d_sk_hat, const int32_t *d_c_hat, int32_t *d_sig, size_t batch, int l) {
     FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (d_sk_hat && d_c_hat && d_sig)), "bad argument");
+    FZ_DEV(ctx);
     return fz_launch_sign(ctx, d_sk_hat, d_c_hat, d_sig, batch, l);
 }
 
 int fz_aggregate_partial_batch(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, int64_t *d_partial,
                                size_t partial_stride, size_t groups, size_t N, int l) {
     FZ_REQUIRE(ctx && l >= 1 && d_partial && (N == 0 || groups == 0 || (d_sig && d_alpha_hat)), "bad argument");
+    FZ_DEV(ctx);
     FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large for exact int64/fp64 accumulation (< 2^21)", N);
     FZ_REQUIRE(groups <= 65535 && (groups <= 1 || partial_stride >= (size_t)l * ctx->degree), "bad groups / stride");
     return fz_launch_aggregate(ctx, d_sig, d_alpha_hat, d_partial, partial_stride, nullptr, groups, N, l);
@@ -639,6 +722,7 @@ int fz_aggregate_target_partial_batch(fz_ctx *ctx, const int32_t *d_sig, const i
                                       const int32_t *d_vkR, const int32_t *d_c_hat, int64_t *d_partial, size_t partial_stride,
                                       int64_t *d_target_partial, size_t target_stride, size_t groups, size_t N, int l) {
     FZ_REQUIRE(ctx && l >= 1 && d_partial && d_target_partial, "bad argument");
+    FZ_DEV(ctx);
     FZ_REQUIRE(N == 0 || groups == 0 || (d_sig && d_alpha_hat && d_vkL && d_vkR && d_c_hat), "NULL argument");
     FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large for exact int64/fp64 accumulation (< 2^21)", N);
     FZ_REQUIRE(groups <= 65535 && (groups <= 1 || (partial_stride >= (size_t)l * ctx->degree && target_stride >= (size_t)ctx->degree)),
@@ -656,11 +740,13 @@ int fz_aggregate_partial(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alp
 
 int fz_reduce_i64(fz_ctx *ctx, const int64_t *d_in, int32_t *d_out, size_t count) {
     FZ_REQUIRE(ctx && (count == 0 || (d_in && d_out)), "NULL argument");
+    FZ_DEV(ctx);
     return fz_launch_reduce_i64(ctx, d_in, d_out, count);
 }
 
 int fz_aggregate_core(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, int32_t *d_out, size_t N, int l) {
     FZ_REQUIRE(ctx && l >= 1 && N >= 1 && d_sig && d_alpha_hat && d_out, "bad argument");
+    FZ_DEV(ctx);
     FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large for exact fp64 accumulation (< 2^21)", N);
     return fz_launch_aggregate(ctx, d_sig, d_alpha_hat, nullptr, 0, d_out, 1, N, l);
 }
@@ -669,6 +755,7 @@ int fz_target_partial_batch(fz_ctx *ctx, const int32_t *d_vkL, const int32_t *d_
                             const int32_t *d_alpha_hat, int64_t *d_partial, size_t partial_stride, size_t groups,
                             size_t N) {
     FZ_REQUIRE(ctx && d_partial && (N == 0 || groups == 0 || (d_vkL && d_vkR && d_c_hat && d_alpha_hat)), "bad argument");
+    FZ_DEV(ctx);
     FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large (< 2^21)", N);
     FZ_REQUIRE(groups <= 65535 && (groups <= 1 || partial_stride >= (size_t)ctx->degree), "bad groups / stride");
     return fz_launch_target_partial(ctx, d_vkL, d_vkR, d_c_hat, d_alpha_hat, d_partial, partial_stride, groups, N);
@@ -681,11 +768,13 @@ int fz_target_partial(fz_ctx *ctx, const int32_t *d_vkL, const int32_t *d_vkR, c
 
 int fz_norm_weight(fz_ctx *ctx, const int32_t *d_coef, size_t batch, int64_t *d_max_abs, int32_t *d_weight) {
     FZ_REQUIRE(ctx && (batch == 0 || (d_coef && d_max_abs && d_weight)), "NULL argument");
+    FZ_DEV(ctx);
     return fz_launch_norm_weight(ctx, d_coef, batch, d_max_abs, d_weight);
 }
 
 int fz_norm_weight_host(fz_ctx *ctx, const int32_t *h_coef, size_t batch, int64_t *h_max_abs, int32_t *h_weight) {
     FZ_REQUIRE(ctx && (batch == 0 || (h_coef && h_max_abs && h_weight)), "NULL argument");
+    FZ_DEV(ctx);
     if (batch == 0) return FZ_OK;
     const size_t bC = batch * (size_t)ctx->degree * sizeof(int32_t);
     const size_t oM = (bC + 255) & ~(size_t)255, oW = oM + ((batch * sizeof(int64_t) + 255) & ~(size_t)255);
@@ -701,6 +790,7 @@ int fz_norm_weight_host(fz_ctx *ctx, const int32_t *h_coef, size_t batch, int64_
 int fz_verify_with_target_batch(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const int32_t *d_target,
                                 size_t groups, int l, int64_t beta_vf, int64_t omega_vf, int *h_verdicts) {
     FZ_REQUIRE(ctx && l >= 1 && groups >= 1 && groups <= 65535 && d_A && d_sig && d_target && h_verdicts, "bad argument");
+    FZ_DEV(ctx);
     const size_t row = (size_t)ctx->degree * sizeof(int32_t), rows = groups * (size_t)l;
     // scratch: observed [G][D] i32 | coef [G][l][D] i32 | max_abs [G][l] i64 | weight [G][l] i32
     const size_t oC = (groups * row + 255) & ~(size_t)255;
@@ -716,7 +806,7 @@ int fz_verify_with_target_batch(fz_ctx *ctx, const int32_t *d_A, const int32_t *
         FZ_HIP(hipMalloc((void **)&ctx->d_verdict, groups * sizeof(int)), "verdict alloc");
         ctx->verdict_cap = groups;
     }
-    if ((ctx->logd == 6 || ctx->logd == 8) && !getenv("FZ_VERIFY_UNFUSED")) {
+    if ((ctx->logd == 6 || ctx->logd == 8) && !ctx->knob_verify_unfused) {
         // one launch: sigma read once (matvec + inverse transforms + norm/weight + verdict fused)
         FZ_TRY(fz_launch_verify_fused(ctx, d_A, d_sig, d_target, groups, l, beta_vf, omega_vf, ctx->d_verdict));
         return fz_memcpy_d2h(ctx, h_verdicts, ctx->d_verdict, groups * sizeof(int));
@@ -735,6 +825,7 @@ int fz_verify_with_target_batch(fz_ctx *ctx, const int32_t *d_A, const int32_t *
 int fz_verify_with_target_batch_async(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const int32_t *d_target,
                                       size_t groups, int l, int64_t beta_vf, int64_t omega_vf, int *d_verdicts) {
     FZ_REQUIRE(ctx && l >= 1 && groups >= 1 && groups <= 65535 && d_A && d_sig && d_target && d_verdicts, "bad argument");
+    FZ_DEV(ctx);
     if (ctx->logd != 6 && ctx->logd != 8)
         return fz_set_error(FZ_E_UNSUPPORTED, "asynchronous verification needs the fused kernel (degree 64 or 256)");
     return fz_launch_verify_fused(ctx, d_A, d_sig, d_target, groups, l, beta_vf, omega_vf, d_verdicts);
@@ -744,6 +835,7 @@ int fz_verify_partials_batch_async(fz_ctx *ctx, const int32_t *d_A, const int64_
                                    const int64_t *d_target_partial, size_t target_stride, size_t groups, int l,
                                    int64_t beta_vf, int64_t omega_vf, int *d_verdicts) {
     FZ_REQUIRE(ctx && l >= 1 && groups >= 1 && groups <= 65535 && d_A && d_partial && d_target_partial && d_verdicts, "bad argument");
+    FZ_DEV(ctx);
     FZ_REQUIRE(groups == 1 || (partial_stride >= (size_t)l * ctx->degree && target_stride >= (size_t)ctx->degree), "bad strides");
     FZ_REQUIRE((((uintptr_t)d_partial | (uintptr_t)d_target_partial | (uintptr_t)d_A) & 15) == 0 && (partial_stride & 1) == 0,
                "partials must be 16-byte aligned");
@@ -763,6 +855,7 @@ int fz_verify_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const 
                    int64_t beta_vf, int64_t omega_vf, int *h_verdict) {
     FZ_REQUIRE(ctx && l >= 1 && N >= 1 && d_A && d_sig && d_vkL && d_vkR && d_c_hat && d_alpha_hat && h_verdict,
                "bad argument");
+    FZ_DEV(ctx);
     // target lives behind the fz_verify_with_target scratch layout: allocate both up front
     const size_t row = (size_t)ctx->degree * sizeof(int32_t);
     const size_t inner = ((row + 255) & ~(size_t)255) + (((size_t)l * row + 255) & ~(size_t)255) +
@@ -776,6 +869,160 @@ int fz_verify_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig, const 
     FZ_TRY(fz_target_partial(ctx, d_vkL, d_vkR, d_c_hat, d_alpha_hat, partial, N));   // fusion.py:706-714
     FZ_TRY(fz_launch_reduce_i64(ctx, partial, target, (size_t)ctx->degree));
     return fz_verify_with_target(ctx, d_A, d_sig, target, l, beta_vf, omega_vf, h_verdict);
+}
+
+
+// ---- many independent transforms in one dispatch -------------------------------------------------------
+int fz_ntt_multi(fz_ctx *ctx, const fz_ntt_job *h_jobs, size_t n_jobs) {
+    FZ_REQUIRE(ctx && (n_jobs == 0 || h_jobs), "NULL argument");
+    FZ_DEV(ctx);
+    if (ctx->logd < 0) return fz_set_error(FZ_E_UNSUPPORTED, "ring-only context (created with root 0) has no transforms");
+    for (size_t j = 0; j < n_jobs; ++j) {
+        const fz_ntt_job &jb = h_jobs[j];
+        FZ_REQUIRE(jb.rows == 0 || (jb.d_in && jb.d_out), "job %zu: NULL buffer", j);
+        FZ_REQUIRE(jb.rows < ((size_t)1 << 31), "job %zu: too many rows", j);
+        if ((((uintptr_t)jb.d_in | (uintptr_t)jb.d_out) & 15) != 0 && ctx->logd >= 2)
+            return fz_set_error(FZ_E_BADARG, "job %zu: transform buffers must be 16-byte aligned", j);
+    }
+    if (ctx->logd != 6 && ctx->logd != 8) {              // other degrees: one launch per job (same results)
+        for (size_t j = 0; j < n_jobs; ++j)
+            FZ_TRY(fz_launch_ntt(ctx, h_jobs[j].d_in, h_jobs[j].d_out, h_jobs[j].rows, h_jobs[j].inverse != 0));
+        return FZ_OK;
+    }
+    const unsigned ppw = 64u / (unsigned)(ctx->degree / 4);
+    FzMultiJobs J;
+    memset(&J, 0, sizeof(J));
+    unsigned long long total = 0;
+    for (size_t j = 0; j < n_jobs; ++j) {
+        const fz_ntt_job &jb = h_jobs[j];
+        if (jb.rows == 0) continue;
+        const unsigned long long tasks = (jb.rows + ppw - 1) / ppw;
+        if (J.n == kFzMultiMax || total + tasks > 0x7fffffffull) {      // table full: flush
+            FZ_TRY(fz_launch_ntt_multi(ctx, J));
+            memset(&J, 0, sizeof(J));
+            total = 0;
+        }
+        total += tasks;
+        J.in[J.n] = jb.d_in;
+        J.out[J.n] = jb.d_out;
+        J.end[J.n] = (unsigned)total;
+        J.rows[J.n] = (unsigned)jb.rows | (jb.inverse ? 0x80000000u : 0u);
+        ++J.n;
+    }
+    return fz_launch_ntt_multi(ctx, J);
+}
+
+// ---- launch-floor diagnostics ------------------------------------------------------------------------------
+int fz_diag_empty_launch(fz_ctx *ctx) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    FZ_DEV(ctx);
+    return fz_launch_diag(ctx, 0, nullptr, nullptr, 0);
+}
+
+int fz_diag_copy(fz_ctx *ctx, const void *d_src, void *d_dst, size_t bytes) {
+    FZ_REQUIRE(ctx && (bytes == 0 || (d_src && d_dst)), "NULL argument");
+    FZ_REQUIRE((((uintptr_t)d_src | (uintptr_t)d_dst) & 15) == 0 && bytes % 16 == 0, "16-byte aligned buffers and size");
+    FZ_DEV(ctx);
+    return fz_launch_diag(ctx, 1, d_src, d_dst, bytes);
+}
+
+// ---- the one exchange step of the path, in the C ABI: RCCL all-reduce of the int64 partial sums ---------------------
+// RCCL is bound lazily (dlopen): the library loads and every other entry point works on a machine without it, and a
+// process that already carries an RCCL (torch ships its own copy under the same soname) shares that one.
+namespace {
+struct RcclApi {
+    void *handle;
+    int (*GetUniqueId)(void *);
+    int (*CommInitRank)(void **, int, fz_unique_id, int);
+    int (*CommDestroy)(void *);
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    const char *(*GetErrorString)(int);
+    int (*CommCount)(void *, int *);
+};
+RcclApi g_rccl = {};
+
+int rccl_bind() {
+    if (g_rccl.handle) return FZ_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fz_set_error(FZ_E_RCCL, "RCCL not found (librccl.so.1): %s", dlerror());
+    RcclApi a = {};
+    a.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void **, int, fz_unique_id, int))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    a.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+    a.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    a.CommCount = (int (*)(void *, int *))dlsym(h, "ncclCommCount");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString)
+        return fz_set_error(FZ_E_RCCL, "librccl.so.1 lacks an expected symbol");
+    a.handle = h;
+    g_rccl = a;
+    return FZ_OK;
+}
+
+int rccl_check(int rc, const char *what) {
+    if (rc == 0) return FZ_OK;
+    return fz_set_error(FZ_E_RCCL, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+}
+}  // namespace
+
+struct fz_comm {
+    void *comm;          // ncclComm_t
+    int nranks, rank, device;
+};
+
+int fz_comm_unique_id(fz_unique_id *out_id) {
+    FZ_REQUIRE(out_id, "out_id is NULL");
+    FZ_TRY(rccl_bind());
+    return rccl_check(g_rccl.GetUniqueId(out_id), "ncclGetUniqueId");
+}
+
+int fz_comm_create(fz_ctx *ctx, int nranks, int rank, const fz_unique_id *id, fz_comm **out) {
+    FZ_REQUIRE(ctx && id && out && nranks >= 1 && rank >= 0 && rank < nranks, "bad argument");
+    *out = nullptr;
+    FZ_DEV(ctx);                                          // the communicator binds to the CURRENT device
+    FZ_TRY(rccl_bind());
+    void *c = nullptr;
+    FZ_TRY(rccl_check(g_rccl.CommInitRank(&c, nranks, *id, rank), "ncclCommInitRank"));
+    fz_comm *C = new (std::nothrow) fz_comm();
+    if (!C) { g_rccl.CommDestroy(c); return fz_set_error(FZ_E_HIP, "out of host memory"); }
+    C->comm = c; C->nranks = nranks; C->rank = rank; C->device = ctx->device;
+    *out = C;
+    return FZ_OK;
+}
+
+int fz_comm_destroy(fz_comm *comm) {
+    if (!comm) return FZ_OK;
+    int rc = FZ_OK;
+    if (comm->comm && g_rccl.CommDestroy) {
+        (void)hipSetDevice(comm->device);
+        rc = rccl_check(g_rccl.CommDestroy(comm->comm), "ncclCommDestroy");
+    }
+    delete comm;
+    return rc;
+}
+
+int fz_comm_info(fz_comm *comm, int *out_nranks, int *out_rank) {
+    FZ_REQUIRE(comm, "comm is NULL");
+    int n = comm->nranks;
+    if (g_rccl.CommCount) FZ_TRY(rccl_check(g_rccl.CommCount(comm->comm, &n), "ncclCommCount"));   // what RCCL itself reports
+    if (out_nranks) *out_nranks = n;
+    if (out_rank) *out_rank = comm->rank;
+    return FZ_OK;
+}
+
+int fz_allreduce_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, size_t count) {
+    FZ_REQUIRE(ctx && comm && (count == 0 || d_buf), "NULL argument");
+    if (comm->device != ctx->device) return fz_set_error(FZ_E_BADARG, "communicator was created on device %d", comm->device);
+    FZ_DEV(ctx);
+    if (count == 0) return FZ_OK;
+    // in place, ncclInt64 (= 4), ncclSum (= 0), on the context's stream: ordered with the kernels around it and
+    // capturable by fz_graph_* like them
+    return rccl_check(g_rccl.AllReduce(d_buf, d_buf, count, 4, 0, comm->comm, ctx->stream), "ncclAllReduce");
 }
 
 }  // extern "C"

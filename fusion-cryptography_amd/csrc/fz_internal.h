@@ -55,6 +55,28 @@ struct fz_ctx {
     double *d_vpart;
     int *d_vstate;
     size_t vpart_doubles, vstate_groups;
+    int verify_dirty;            // a verify launch failed: accumulators / state words are re-zeroed before the next one
+    // one-pass aggregation: per (aggregate, column block) fp64 accumulators [tiles][tile_doubles] and ticket words;
+    // all zero between launches (the last arrival re-arms them)
+    double *d_aggacc;
+    unsigned *d_aggtick;
+    size_t aggacc_tiles;
+    int agg_dirty;
+    int grid_multi;              // resident grid of the multi-job transform kernel (0 = not queried yet)
+    // benchmarking knobs, read ONCE at context creation
+    int knob_agg_twopass, knob_agg_waves, knob_agg_slices;
+    int knob_verify_blocks, knob_verify_unfused, knob_verify_ordered, knob_keygen_unfused, knob_polymul_unfused;
+    // RCCL (fz_comm_*): communicators are owned by the caller; nothing here
+};
+
+// the job table of one fz_ntt_multi launch travels in the kernarg segment (no device copy, capturable in a graph)
+constexpr int kFzMultiMax = 32;
+struct FzMultiJobs {
+    const int32_t *in[kFzMultiMax];
+    int32_t *out[kFzMultiMax];
+    unsigned end[kFzMultiMax];   // running total of wave-tasks up to and including job j
+    unsigned rows[kFzMultiMax];  // rows of job j; bit 31 set: inverse transform
+    int n;
 };
 
 struct fz_graph {
@@ -68,11 +90,14 @@ int fz_set_error(int code, const char *fmt, ...);
 int fz_check_hip(hipError_t e, const char *what);
 int fz_scratch(fz_ctx *ctx, size_t bytes, void **out);
 int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out);
-int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, double **part, int **state);   // second, independent scratch (per-split partial sums)
+int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, double **part, int **state);
+int fz_agg_scratch(fz_ctx *ctx, size_t tiles, size_t tile_doubles, double **acc, unsigned **tickets);
 
 // launchers (fz_ntt.hip)
 int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse);
 int fz_ntt_query_grid(fz_ctx *ctx);
+int fz_launch_ntt_multi(fz_ctx *ctx, const FzMultiJobs &jobs);     // degree 64 / 256
+int fz_launch_diag(fz_ctx *ctx, int what, const void *src, void *dst, size_t bytes);
 
 int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int32_t *out, size_t batch);
 int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,

@@ -592,6 +592,77 @@ __global__ __launch_bounds__(64 * kWaves4) void ntt_inv4(const int32_t *in, int3
 }
 
 // ------------------------------------------------------------------------------------------
+// Many independent transforms in ONE dispatch (fz_ntt_multi).  The reference issues its transforms one polynomial at a
+// time (fusion/fusion.py:363-368: 2*rank per key; :690-692: rank per verification), and a launch of a few thousand rows
+// sits on the dispatch floor (a 4096-row launch is ~2.3 us of floor plus ~1.5 us of transform).  Here a job table --
+// (in, out, rows, direction) per job, in the kernarg segment -- is walked by one grid: wave-tasks are numbered
+// through all jobs, each wave finds its job by a scalar scan of the running totals, forward and inverse jobs mix
+// freely (both twiddle sets stay in registers, as in the fused product).  Radix-4 schedule, degree 64 / 256.
+// ------------------------------------------------------------------------------------------
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64) void ntt_multi4(FzMultiJobs J, const double2 *__restrict__ tw2, const double2 *__restrict__ itw2,
+                                                 FzTwA twA, FzTwA itwA, FzMod m) {
+    constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
+    __shared__ __attribute__((aligned(16))) double lds[256];
+    const int lane = threadIdx.x & 63;
+    const int p = lane / LP, mm = lane % LP;
+    double *region = lds + p * D;
+    const unsigned total = J.end[J.n - 1];
+    unsigned task = blockIdx.x;
+    const unsigned stride = gridDim.x;
+    if (task >= total) return;
+
+    double2 twf[P - 1][3], twi[P - 1][3];
+    fwd4_load_twiddles<LOGD>(twf, tw2, mm);
+    inv4_load_twiddles<LOGD>(twi, itw2, mm);
+
+    int xn[4];
+    bool inv_n = false, valid_n = false;
+    int32_t *dst_n = nullptr;
+    auto fetch = [&](unsigned t) {
+        int j = 0;
+        while (t >= J.end[j]) ++j;                                   // wave-uniform scalar scan, <= 32 entries
+        const unsigned local = t - (j ? J.end[j - 1] : 0u);
+        const unsigned rows = J.rows[j] & 0x7fffffffu;
+        inv_n = (J.rows[j] >> 31) != 0;
+        const size_t poly = (size_t)local * PPW + p;
+        valid_n = poly < rows;
+        const size_t row = (valid_n ? poly : (size_t)rows - 1) * D;
+        dst_n = J.out[j] + row;
+        const int32_t *src = J.in[j] + row;
+        if (inv_n) {
+            const int4 v = *reinterpret_cast<const int4 *>(src + 4 * mm);
+            xn[0] = v.x; xn[1] = v.y; xn[2] = v.z; xn[3] = v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xn[k] = src[mm + k * LP];
+        }
+    };
+    fetch(task);
+    for (; task < total; task += stride) {
+        double a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = (double)xn[k];
+        const bool inverse = inv_n, valid = valid_n;
+        int32_t *dst = dst_n;
+        if (task + stride < total) fetch(task + stride);              // next task's coefficients in flight during the passes
+        if (inverse) {
+            inv4_passes<LOGD, FAST>(a, region, twi, itwA, m, mm);
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((int)fz_cent(a[k], m), dst + mm + k * LP);
+            }
+        } else {
+            fwd4_passes<LOGD, FAST>(a, region, twf, twA, m, mm);
+            if (valid)
+                nt_store4(dst + 4 * mm, make_int4((int)fz_cent(a[0], m), (int)fz_cent(a[1], m), (int)fz_cent(a[2], m),
+                                                  (int)fz_cent(a[3], m)));
+        }
+        wave_sync();      // the next task's first-pass writes must not overtake this task's last reads
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Negacyclic product INTT(NTT(f) * NTT(g)) in one launch (algebra/ntt.py:380-484 ntt_poly_mult; the product the
 // reference's schoolbook PolynomialCoefficientRepresentation.__mul__, polynomials.py:171-216, is tested against):
 // both forward transforms, the pointwise product and the inverse stay in registers / LDS; HBM sees 12*D bytes per
@@ -735,13 +806,13 @@ __device__ __forceinline__ void load4_any(const int32_t *p, double (&a)[4], cons
 }
 __device__ __forceinline__ void load4_any(const int64_t *p, double (&a)[4], const FzMod &m) {
     const longlong2 lo = reinterpret_cast<const longlong2 *>(p)[0], hi = reinterpret_cast<const longlong2 *>(p)[1];
-    a[0] = fz_cent_wide((double)lo.x, m); a[1] = fz_cent_wide((double)lo.y, m);
-    a[2] = fz_cent_wide((double)hi.x, m); a[3] = fz_cent_wide((double)hi.y, m);
+    a[0] = fz_cent_i64(lo.x, m); a[1] = fz_cent_i64(lo.y, m);          // exact for any int64
+    a[2] = fz_cent_i64(hi.x, m); a[3] = fz_cent_i64(hi.y, m);
 }
 __device__ __forceinline__ int centred_any(int32_t v, const FzMod &) { return v; }
-__device__ __forceinline__ int centred_any(int64_t v, const FzMod &m) { return (int)fz_cent_wide((double)v, m); }
+__device__ __forceinline__ int centred_any(int64_t v, const FzMod &m) { return (int)fz_cent_i64(v, m); }
 
-template <int LOGD, bool FAST, typename T>
+template <int LOGD, bool FAST, typename T, bool ORDERED>
 __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t *A, const T *sig, size_t sig_stride,
                                                                   const T *target, size_t target_stride, int l, long long beta,
                                                                   long long omega, const double2 *__restrict__ itw2,
@@ -813,11 +884,20 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
         const double before = __hip_atomic_fetch_add(part + threadIdx.x, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         region[0] = before;                         // consume the result: the add is complete before the barrier below
     }
+    // ... and say so to the hardware in so many words (inline asm: no compiler pass may drop or move it): every
+    // add of this wave has been performed -- its old value is back -- before the wave reaches the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const int f = s_flags;
         const unsigned inc = 1u + ((f & 2) ? (1u << 16) : 0u) + ((f & 4) ? (1u << 24) : 0u);
-        const unsigned old = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(state), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ORDERED (FZ_VERIFY_ORDERED=1): the arrival carries release/acquire semantics at agent scope as the HIP memory
+        // model words it (one L2 write-back + L1 invalidate per workgroup).  The default relies on what the hardware
+        // does with these operations: every shared word is ONLY ever touched by agent-scope atomics, which execute at
+        // the memory side (MI355X_MICROARCH.md, "Global float atomics"), so no cache holds a copy that could be stale,
+        // and the arrival cannot overtake the adds because they have returned (the wait above, the barrier).
+        const unsigned old = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(state), inc,
+                                                    ORDERED ? __ATOMIC_ACQ_REL : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned now = old + inc;
         s_last = ((old & 0xffffu) == (unsigned)(R - 1));
         s_flags = (((now >> 16) & 0xffu) ? 2 : 0) | ((now >> 24) ? 4 : 0);
@@ -1021,7 +1101,7 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
     int R = (tasks + kVerifyWaves - 1) / kVerifyWaves;
     const int fill = (int)((size_t)ctx->num_cu * 2 / groups);
     if (R > fill) R = fill;
-    if (const char *e = getenv("FZ_VERIFY_BLOCKS")) R = atoi(e);      // benchmarking knob
+    if (ctx->knob_verify_blocks > 0) R = ctx->knob_verify_blocks;     // benchmarking knob (FZ_VERIFY_BLOCKS)
     if (R < 1) R = 1;
     if (R > 64) R = 64;
     double *part = nullptr;
@@ -1029,13 +1109,17 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
     int rc = fz_verify_scratch(ctx, groups, (size_t)ctx->degree, &part, &state);
     if (rc != FZ_OK) return rc;
     const dim3 grid((unsigned)R, (unsigned)groups), block(64 * kVerifyWaves);
-#define FZ_VF(LOGD, FAST) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T>), grid, block, 0, ctx->stream, A, sig, sig_stride, target, \
-                                             target_stride, l, (long long)beta, (long long)omega, (const double2 *)ctx->d_itw2, \
-                                             ctx->itwA, ctx->mod, part, state, d_verdict)
+#define FZ_VF2(LOGD, FAST, ORD) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T, ORD>), grid, block, 0, ctx->stream, A, sig, sig_stride, target, \
+                                                   target_stride, l, (long long)beta, (long long)omega, (const double2 *)ctx->d_itw2, \
+                                                   ctx->itwA, ctx->mod, part, state, d_verdict)
+#define FZ_VF(LOGD, FAST) do { if (ctx->knob_verify_ordered) FZ_VF2(LOGD, FAST, true); else FZ_VF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_VF(8, true); else FZ_VF(8, false); }
     else { if (ctx->mod.fast) FZ_VF(6, true); else FZ_VF(6, false); }
 #undef FZ_VF
-    return fz_check_hip(hipGetLastError(), "verify_fused launch");
+#undef FZ_VF2
+    rc = fz_check_hip(hipGetLastError(), "verify_fused launch");
+    if (rc != FZ_OK) ctx->verify_dirty = 1;          // the accumulators may be left non-zero: re-zeroed before the next launch
+    return rc;
 }
 
 int fz_launch_verify_fused(fz_ctx *ctx, const int32_t *A, const int32_t *sig, const int32_t *target, size_t groups, int l,
@@ -1101,4 +1185,58 @@ int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch
         case 8: return launch16<8>(ctx, d_in, d_out, batch, inverse);
         default: return fz_set_error(FZ_E_UNSUPPORTED, "degree %d not supported (2..256)", ctx->degree);
     }
+}
+
+// one launch over a job table (at most kFzMultiMax jobs, degree 64 / 256)
+int fz_launch_ntt_multi(fz_ctx *ctx, const FzMultiJobs &J) {
+    if (ctx->logd != 6 && ctx->logd != 8) return fz_set_error(FZ_E_UNSUPPORTED, "multi-job transform: degree 64 or 256 only");
+    if (J.n <= 0) return FZ_OK;
+    const unsigned total = J.end[J.n - 1];
+    if (total == 0) return FZ_OK;
+    if (ctx->grid_multi == 0) {
+        int n = 0;
+        hipError_t e;
+#define FZ_MQ(LOGD, FAST) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ntt_multi4<LOGD, FAST>, 64, 0)
+        if (ctx->logd == 8) { if (ctx->mod.fast) FZ_MQ(8, true); else FZ_MQ(8, false); }
+        else { if (ctx->mod.fast) FZ_MQ(6, true); else FZ_MQ(6, false); }
+#undef FZ_MQ
+        if (e != hipSuccess) return fz_check_hip(e, "occupancy query (multi)");
+        ctx->grid_multi = (n < 1 ? 1 : n) * ctx->num_cu;
+    }
+    const unsigned cap = (unsigned)ctx->grid_multi * (unsigned)ctx->grid_mult;
+    const dim3 grid(total < cap ? total : cap), block(64);
+#define FZ_MJ(LOGD, FAST) hipLaunchKernelGGL((ntt_multi4<LOGD, FAST>), grid, block, 0, ctx->stream, J, (const double2 *)ctx->d_tw2, \
+                                             (const double2 *)ctx->d_itw2, ctx->twA, ctx->itwA, ctx->mod)
+    if (ctx->logd == 8) { if (ctx->mod.fast) FZ_MJ(8, true); else FZ_MJ(8, false); }
+    else { if (ctx->mod.fast) FZ_MJ(6, true); else FZ_MJ(6, false); }
+#undef FZ_MJ
+    return fz_check_hip(hipGetLastError(), "ntt_multi launch");
+}
+
+// ------------------------------------------------------------------------------------------
+// Launch-floor diagnostics (fz_diag_*): what a dispatch of NO work and a plain copy of the same bytes cost on this
+// device, measured next to the transforms so that a small batch can be judged against a same-run floor.
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void diag_empty_kernel() {}
+__global__ __launch_bounds__(64) void diag_copy_kernel(const int4 *__restrict__ src, int4 *__restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 64;
+    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < n16; i += stride) {
+        const fz_v4i t = *reinterpret_cast<const fz_v4i *>(src + i);
+        __builtin_nontemporal_store(t, reinterpret_cast<fz_v4i *>(dst + i));
+    }
+}
+}  // namespace
+
+int fz_launch_diag(fz_ctx *ctx, int what, const void *src, void *dst, size_t bytes) {
+    if (what == 0) {
+        hipLaunchKernelGGL(diag_empty_kernel, dim3(4096), dim3(64), 0, ctx->stream);
+    } else {
+        const size_t n16 = bytes / 16;
+        if (n16 == 0) return FZ_OK;
+        const size_t blocks = (n16 + 63) / 64, cap = (size_t)ctx->num_cu * 32;
+        hipLaunchKernelGGL(diag_copy_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(64), 0, ctx->stream,
+                           (const int4 *)src, (int4 *)dst, n16);
+    }
+    return fz_check_hip(hipGetLastError(), "diag launch");
 }

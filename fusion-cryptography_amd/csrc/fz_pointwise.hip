@@ -126,7 +126,7 @@ __global__ __launch_bounds__(1024) void matvec_split_kernel(const int32_t *A, co
         reinterpret_cast<int4 *>(out + b * (size_t)degree)[j4] = r;
     }
 }
-// degree < 4 fallback (degree 2): scalar
+// any degree (degree % 4 != 0, or rows that are not 16-byte aligned): scalar
 __global__ __launch_bounds__(kBlock) void matvec_scalar_kernel(const int32_t *A, const int32_t *S, int32_t *out,
                                                                size_t batch, int l, int degree, FzMod m) {
     const size_t total = batch * (size_t)degree;
@@ -162,6 +162,265 @@ __global__ __launch_bounds__(kBlock) void sign_kernel(const int32_t *sk_hat, con
         o.z = cent_i32(fz_mulmod((double)x.z, (double)c.z, m) + (double)y.z, m);
         o.w = cent_i32(fz_mulmod((double)x.w, (double)c.w, m) + (double)y.w, m);
         reinterpret_cast<int4 *>(sig)[i] = o;
+    }
+}
+
+// any degree (degree % 4 != 0 included): one thread per coefficient
+__global__ __launch_bounds__(kBlock) void sign_scalar_kernel(const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig,
+                                                             size_t batch, int l, int degree, FzMod m) {
+    const size_t per_sig = (size_t)l * degree, total = batch * per_sig;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t b = i / per_sig, rem = i % per_sig;
+        const int32_t *Lp = sk_hat + b * 2 * per_sig;
+        const double cj = (double)c_hat[b * (size_t)degree + rem % degree];
+        sig[i] = cent_i32(fz_mulmod((double)Lp[rem], cj, m) + (double)Lp[per_sig + rem], m);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One-pass aggregation (fusion/fusion.py:670-676, and the verification target of :706-714 as extra columns).
+//
+//   out[g][k][j] = sum_i sig[g][i][k][j] * alpha[g][i][j]      (mod q; centred int32 or int64 partial sums)
+//
+// Work split: a workgroup owns 1024 consecutive coefficients of the aggregate (kAggR = 4 int4 columns per lane, i.e.
+// four rows at degree 256, sixteen at degree 64) for ONE slice of the signers; its WAVES waves take the slice's
+// signers round-robin and never talk to each other until the end.  Per signer a lane loads ONE int4 of alpha (its
+// position j is the same for its four columns) and four int4 of sigma, the next signer's five loads in flight
+// meanwhile.  Arithmetic: alpha = hi * 2^16 + lo (hi in [-2^15, 2^15), lo in [0, 2^16)), so x * hi and x * lo are
+// below 2^47 for any int32 x and sixteen signers accumulate EXACTLY in fp64 (< 2^51) with two FMAs per coefficient
+// and no reduction at all; every kAggFold signers the two sums fold back below q (fz_fold, exact).  The split of
+// alpha costs 16 integer/convert operations per signer and lane, shared by the lane's 16 coefficients.
+// End of the workgroup: the WAVES partials meet in LDS; with one slice per aggregate the result is written directly;
+// with several, each workgroup adds its 1024 exact integers into the aggregate's fp64 accumulator with agent-scope
+// atomics (performed at the memory side: coherent across the 8 XCD L2s without any fence), takes a ticket, and the
+// last arrival swaps the sums out (re-arming the accumulator for the next launch) and writes the output.  Only
+// sigma and alpha are ever read: no scratch round trip, no second launch.
+// Workgroup -> XCD placement (speed only): workgroups b and b + 8 share an XCD, so all column blocks of one
+// (aggregate, slice) pair get block ids equal mod 8 and each alpha row is fetched into ONE L2.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kAggR = 4;          // int4 columns per lane
+constexpr int kAggFold = 16;      // signers between folds: 16 * 2^31 * 2^16 = 2^51 < 2^53
+constexpr int kAggTile = 64 * kAggR * 4;   // coefficients per workgroup (1024)
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
+                                                                const int32_t *vkR, const int32_t *c, size_t N, int l, int d4,
+                                                                int ncb_a, int ncb, int nsl, int pairs, double *accum,
+                                                                unsigned *tickets, int64_t *out64, size_t pstride,
+                                                                int64_t *tout64, size_t tstride, int32_t *out32, FzMod m) {
+    __shared__ __attribute__((aligned(16))) double red[(WAVES / 2) * kAggTile];
+    __shared__ int s_last;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // block id -> (column block, aggregate, slice); pairs p = g * nsl + sb with equal p % 8 share an XCD
+    const unsigned b = blockIdx.x, rest = b >> 3;
+    const int cb = (int)(rest % (unsigned)ncb);
+    const int p = (int)(rest / (unsigned)ncb) * 8 + (int)(b & 7u);
+    if (p >= pairs) return;
+    const size_t g = (size_t)(p / nsl);
+    const int sb = p % nsl;
+    const size_t base = N / (size_t)nsl, extra = N % (size_t)nsl;
+    const size_t i0 = (size_t)sb * base + ((size_t)sb < extra ? (size_t)sb : extra);
+    const size_t i1 = i0 + base + ((size_t)sb < extra ? 1 : 0);
+    const bool tgt = cb >= ncb_a;
+    const size_t cols_a = (size_t)l * d4;
+    const int4 *alpha4 = reinterpret_cast<const int4 *>(alpha) + g * N * (size_t)d4;
+
+    double lo[kAggR][4];
+#pragma unroll
+    for (int r = 0; r < kAggR; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lo[r][k] = 0.0;
+
+    if (!tgt) {
+        double hi[kAggR][4];
+#pragma unroll
+        for (int r = 0; r < kAggR; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hi[r][k] = 0.0;
+        const int j4 = lane % d4;                         // d4 divides 64: the same position for the lane's four columns
+        size_t col[kAggR];
+#pragma unroll
+        for (int r = 0; r < kAggR; ++r) {
+            const size_t cr = (size_t)cb * (64 * kAggR) + (size_t)r * 64 + lane;
+            col[r] = cr < cols_a ? cr : cols_a - 1;       // clamped lanes compute garbage that is never written
+        }
+        const int4 *sig4 = reinterpret_cast<const int4 *>(sig) + g * N * cols_a;
+        int4 a_cur, x_cur[kAggR], a_nxt, x_nxt[kAggR];
+        size_t i = i0 + wave;
+        if (i < i1) {
+            a_cur = alpha4[i * d4 + j4];
+#pragma unroll
+            for (int r = 0; r < kAggR; ++r) x_cur[r] = sig4[i * cols_a + col[r]];
+        }
+        int since = 0;
+        while (i < i1) {
+            const size_t in = i + WAVES;
+            if (in < i1) {                                // wave-uniform
+                a_nxt = alpha4[in * d4 + j4];
+#pragma unroll
+                for (int r = 0; r < kAggR; ++r) x_nxt[r] = sig4[in * cols_a + col[r]];
+            }
+            const int av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
+            double ah[4], al[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ah[k] = (double)(av[k] >> 16);
+                al[k] = (double)(av[k] & 0xffff);
+            }
+#pragma unroll
+            for (int r = 0; r < kAggR; ++r) {
+                const double xv[4] = {(double)x_cur[r].x, (double)x_cur[r].y, (double)x_cur[r].z, (double)x_cur[r].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    hi[r][k] = __builtin_fma(xv[k], ah[k], hi[r][k]);
+                    lo[r][k] = __builtin_fma(xv[k], al[k], lo[r][k]);
+                }
+            }
+            if (++since == kAggFold) {
+                since = 0;
+#pragma unroll
+                for (int r = 0; r < kAggR; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lo[r][k] = fz_fold(lo[r][k], m) + fz_fold(hi[r][k] * 65536.0, m);
+                        hi[r][k] = 0.0;
+                    }
+            }
+            a_cur = a_nxt;
+#pragma unroll
+            for (int r = 0; r < kAggR; ++r) x_cur[r] = x_nxt[r];
+            i = in;
+        }
+#pragma unroll
+        for (int r = 0; r < kAggR; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lo[r][k] = fz_fold(lo[r][k], m) + fz_fold(hi[r][k] * 65536.0, m);
+    } else {
+        // verification target: sum_i (vkL_i * c_i + vkR_i) * alpha_i, degree/4 int4 columns in lo[0]
+        const size_t tcol = (size_t)(cb - ncb_a) * 64 + lane;
+        const size_t tc = tcol < (size_t)d4 ? tcol : (size_t)d4 - 1;
+        const int4 *L4 = reinterpret_cast<const int4 *>(vkL) + g * N * (size_t)d4;
+        const int4 *R4 = reinterpret_cast<const int4 *>(vkR) + g * N * (size_t)d4;
+        const int4 *C4 = reinterpret_cast<const int4 *>(c) + g * N * (size_t)d4;
+#pragma unroll 2
+        for (size_t i = i0 + wave; i < i1; i += WAVES) {
+            const size_t o = i * d4 + tc;
+            const int4 L = L4[o], R = R4[o], ch = C4[o], a = alpha4[o];
+            lo[0][0] += fz_mulmod(fz_mulmod((double)L.x, (double)ch.x, m) + (double)R.x, (double)a.x, m);   // |inner| < 2^32
+            lo[0][1] += fz_mulmod(fz_mulmod((double)L.y, (double)ch.y, m) + (double)R.y, (double)a.y, m);
+            lo[0][2] += fz_mulmod(fz_mulmod((double)L.z, (double)ch.z, m) + (double)R.z, (double)a.z, m);
+            lo[0][3] += fz_mulmod(fz_mulmod((double)L.w, (double)ch.w, m) + (double)R.w, (double)a.w, m);
+        }
+    }
+
+    // the WAVES partials meet in LDS (element e of the tile = coefficient cb * 1024 + e of the aggregate), in two
+    // rounds so that the staging area stays at WAVES/2 tiles: the upper half of the waves hands its sums to the lower
+    {
+        constexpr int H = WAVES / 2;
+        double *mine = red + (wave % H) * kAggTile + lane * 4;
+        if (wave >= H) {
+#pragma unroll
+            for (int r = 0; r < kAggR; ++r) {
+                *reinterpret_cast<double2 *>(mine + r * 256) = make_double2(lo[r][0], lo[r][1]);
+                *reinterpret_cast<double2 *>(mine + r * 256 + 2) = make_double2(lo[r][2], lo[r][3]);
+            }
+        }
+        __syncthreads();
+        if (wave < H) {
+#pragma unroll
+            for (int r = 0; r < kAggR; ++r) {
+                const double2 u = *reinterpret_cast<const double2 *>(mine + r * 256);
+                const double2 v = *reinterpret_cast<const double2 *>(mine + r * 256 + 2);
+                lo[r][0] += u.x; lo[r][1] += u.y; lo[r][2] += v.x; lo[r][3] += v.y;
+            }
+        }
+        __syncthreads();
+        if (wave < H) {
+#pragma unroll
+            for (int r = 0; r < kAggR; ++r) {
+                *reinterpret_cast<double2 *>(mine + r * 256) = make_double2(lo[r][0], lo[r][1]);
+                *reinterpret_cast<double2 *>(mine + r * 256 + 2) = make_double2(lo[r][2], lo[r][3]);
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int PER = kAggTile / (64 * WAVES);          // elements per thread in the combine steps
+    const size_t limit = tgt ? (size_t)d4 * 4 : cols_a * 4;
+    const size_t k0 = tgt ? (size_t)(cb - ncb_a) * 256 : (size_t)cb * kAggTile;
+    const int span = tgt ? 256 : kAggTile;
+    double sum[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = threadIdx.x + u * 64 * WAVES;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES / 2; ++w) s += red[w * kAggTile + e];
+        sum[u] = s;
+    }
+    auto emit = [&](int e, double s) {
+        const size_t k = k0 + (size_t)e;
+        if (e >= span || k >= limit) return;
+        if (tgt) tout64[g * tstride + k] = (int64_t)s;
+        else if (out64) out64[g * pstride + k] = (int64_t)s;
+        else out32[g * cols_a * 4 + k] = (int)fz_cent_wide(s, m);
+    };
+    if (nsl == 1) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) emit(threadIdx.x + u * 64 * WAVES, sum[u]);
+        return;
+    }
+    double *acc = accum + (g * (size_t)ncb + (size_t)cb) * kAggTile;
+    unsigned *ticket = tickets + g * (size_t)ncb + (size_t)cb;
+    double seen = 0.0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = threadIdx.x + u * 64 * WAVES;
+        if (e < span && k0 + (size_t)e < limit)
+            seen += __hip_atomic_fetch_add(acc + e, sum[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every add of this workgroup has been PERFORMED (its old value is back) before the ticket is drawn
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (seen == 0x1.0p+1000) s_last = -1;                 // never true: keeps the returned values live
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (unsigned)(nsl - 1)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last != 1) return;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = threadIdx.x + u * 64 * WAVES;
+        if (e < span && k0 + (size_t)e < limit)
+            emit(e, __hip_atomic_exchange(acc + e, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // read and re-arm
+    }
+    if (threadIdx.x == 0) __hip_atomic_exchange(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// any degree, any N: one thread per coefficient of the aggregate (and of the target), all signers in sequence.
+// Only for parameter sets the one-pass kernel does not cover (degree not a power of two <= 256).
+__global__ __launch_bounds__(kBlock) void aggregate_generic_kernel(const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
+                                                                   const int32_t *vkR, const int32_t *c, size_t N, int l, int degree,
+                                                                   int64_t *out64, size_t pstride, int64_t *tout64, size_t tstride,
+                                                                   int32_t *out32, FzMod m) {
+    const size_t g = blockIdx.z, per = (size_t)l * degree, total = per + (vkL ? (size_t)degree : 0);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const size_t j = e % (size_t)degree;
+        double s = 0.0;
+        if (e < per) {
+            for (size_t i = 0; i < N; ++i)
+                s += fz_mulmod((double)sig[(g * N + i) * per + e], (double)alpha[(g * N + i) * degree + j], m);
+            if (out64) out64[g * pstride + e] = (int64_t)s;
+            else out32[g * per + e] = (int)fz_cent_wide(s, m);
+        } else {
+            for (size_t i = 0; i < N; ++i) {
+                const size_t o = (g * N + i) * degree + j;
+                s += fz_mulmod(fz_mulmod((double)vkL[o], (double)c[o], m) + (double)vkR[o], (double)alpha[o], m);
+            }
+            tout64[g * tstride + j] = (int64_t)s;
+        }
     }
 }
 
@@ -266,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void zero_i64_kernel(int64_t *partial, size
 __global__ __launch_bounds__(kBlock) void reduce_i64_kernel(const int64_t *in, int32_t *out, size_t count, FzMod m) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
-        out[i] = (int)fz_cent_wide((double)in[i], m);
+        out[i] = (int)fz_cent_i64(in[i], m);         // exact for ANY int64 (sums that crossed an all-reduce)
 }
 
 // one wave per row: max |x| over stored values, #{x : x mod q != 0}
@@ -352,11 +611,12 @@ int fz_launch_pw_bcast(fz_ctx *ctx, const int32_t *a, const int32_t *s, int32_t 
 
 int fz_launch_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *out, size_t batch, int l) {
     if (batch == 0) return FZ_OK;
-    if (ctx->degree >= 16 && ctx->degree <= 4096 && (ctx->degree & (ctx->degree - 1)) == 0 &&
+    const bool vec = ctx->degree % 4 == 0 && ((((uintptr_t)A | (uintptr_t)S | (uintptr_t)out) & 15) == 0);   // int4 rows
+    if (vec && ctx->degree >= 16 && ctx->degree <= 4096 && (ctx->degree & (ctx->degree - 1)) == 0 &&
         batch * (size_t)(ctx->degree / 4) < (size_t)ctx->num_cu * 256)
         hipLaunchKernelGGL(matvec_split_kernel, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, A, S, out, l,
                            ctx->degree, ctx->mod);
-    else if (ctx->degree >= 4)
+    else if (vec)
         hipLaunchKernelGGL(matvec_kernel, dim3(grid_for(ctx, batch * (size_t)(ctx->degree / 4))), dim3(kBlock), 0,
                            ctx->stream, A, S, out, batch, l, ctx->degree, ctx->mod);
     else
@@ -367,7 +627,12 @@ int fz_launch_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *o
 
 int fz_launch_sign(fz_ctx *ctx, const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig, size_t batch, int l) {
     if (batch == 0) return FZ_OK;
-    if (ctx->degree < 4) return fz_set_error(FZ_E_UNSUPPORTED, "sign_core needs degree >= 4");
+    if (ctx->degree % 4 != 0 || ((((uintptr_t)sk_hat | (uintptr_t)c_hat | (uintptr_t)sig) & 15) != 0)) {
+        const size_t n = batch * (size_t)l * ctx->degree;
+        hipLaunchKernelGGL(sign_scalar_kernel, dim3(grid_for(ctx, n)), dim3(kBlock), 0, ctx->stream, sk_hat, c_hat, sig, batch, l,
+                           ctx->degree, ctx->mod);
+        return fz_check_hip(hipGetLastError(), "sign (scalar) launch");
+    }
     const size_t total = batch * (size_t)l * (ctx->degree / 4);
     hipLaunchKernelGGL(sign_kernel, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream, sk_hat, c_hat, sig, batch,
                        l, ctx->degree, ctx->mod);
@@ -384,13 +649,76 @@ static unsigned split_count(fz_ctx *ctx, size_t N, unsigned gx, size_t groups, s
     return (unsigned)want;
 }
 
+template <int WAVES>
+static void launch_onepass(fz_ctx *ctx, unsigned grid, const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
+                           const int32_t *vkR, const int32_t *c, size_t N, int l, int d4, int ncb_a, int ncb, int nsl, int pairs,
+                           double *acc, unsigned *tickets, int64_t *out64, size_t pstride, int64_t *tout64, size_t tstride,
+                           int32_t *out32) {
+    hipLaunchKernelGGL(aggregate_onepass<WAVES>, dim3(grid), dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N, l, d4,
+                       ncb_a, ncb, nsl, pairs, acc, tickets, out64, pstride, tout64, tstride, out32, ctx->mod);
+}
+
 // out64 != nullptr: int64 partial sums at out64 + g*pstride; else centred int32 at out32 + g*l*degree.
-// vkL != nullptr: the verification target's int64 partial sums go to tout64 + g*tstride in the same two launches.
+// vkL != nullptr: the verification target's int64 partial sums go to tout64 + g*tstride in the same launch.
 int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *out64, size_t pstride,
                         int32_t *out32, size_t groups, size_t N, int l, const int32_t *vkL, const int32_t *vkR,
                         const int32_t *c, int64_t *tout64, size_t tstride) {
-    if (ctx->degree < 4) return fz_set_error(FZ_E_UNSUPPORTED, "aggregate needs degree >= 4");
     if (groups == 0) return FZ_OK;
+    const int d = ctx->degree;
+    const uintptr_t align = (uintptr_t)sig | (uintptr_t)alpha | (uintptr_t)vkL | (uintptr_t)vkR | (uintptr_t)c;
+    const bool vec = (d % 4 == 0) && (align & 15) == 0;
+    if (vec && (d & (d - 1)) == 0 && d <= 256 && !ctx->knob_agg_twopass) {
+        const int d4 = d / 4;
+        const size_t cols_a = (size_t)l * d4;
+        const int ncb_a = (int)((cols_a + 64 * kAggR - 1) / (64 * kAggR));
+        const int ncb = ncb_a + (vkL ? 1 : 0);                       // d4 <= 64: the target fits one column block
+        // slices of the signers per aggregate: enough workgroups for every CU, at least 4 signers per wave
+        int waves = ctx->knob_agg_waves ? ctx->knob_agg_waves : 8;
+        const size_t blocks_min = (size_t)ncb * groups;
+        auto slices = [&](int wv) {
+            const size_t want = (size_t)ctx->num_cu * (wv == 8 ? 1 : 2);
+            size_t n = (want + blocks_min - 1) / blocks_min;
+            const size_t most = N / ((size_t)wv * 4);
+            if (n > most) n = most;
+            if (n < 1) n = 1;
+            if (n > 4096) n = 4096;
+            return n;
+        };
+        size_t nsl = slices(waves);
+        if (!ctx->knob_agg_waves && blocks_min * nsl < (size_t)ctx->num_cu) {   // too few 8-wave workgroups: halve them
+            waves = 4;
+            nsl = slices(waves);
+        }
+        if (ctx->knob_agg_slices > 0) nsl = (size_t)ctx->knob_agg_slices;
+        if (nsl > N && N > 0) nsl = N;
+        if (N == 0) nsl = 1;
+        const size_t pairs = groups * nsl;
+        if (pairs * (size_t)ncb > 0x3fffffffull) return fz_set_error(FZ_E_UNSUPPORTED, "aggregate: grid too large");
+        double *acc = nullptr;
+        unsigned *tickets = nullptr;
+        if (nsl > 1) {
+            int rc = fz_agg_scratch(ctx, groups * (size_t)ncb, (size_t)kAggTile, &acc, &tickets);
+            if (rc != FZ_OK) return rc;
+        }
+        const unsigned grid = (unsigned)(8 * ((pairs + 7) / 8) * (size_t)ncb);
+        if (waves == 4)
+            launch_onepass<4>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, tickets, out64,
+                              pstride, tout64, tstride, out32);
+        else
+            launch_onepass<8>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, tickets, out64,
+                              pstride, tout64, tstride, out32);
+        const int rc = fz_check_hip(hipGetLastError(), "aggregate launch");
+        if (rc != FZ_OK && nsl > 1) ctx->agg_dirty = 1;              // accumulators / tickets may no longer be zero
+        return rc;
+    }
+    if (!vec || !ctx->knob_agg_twopass) {
+        // degrees the one-pass kernel does not cover (not a power of two, > 256, or unaligned rows)
+        const size_t total = (size_t)l * d + (vkL ? (size_t)d : 0);
+        hipLaunchKernelGGL(aggregate_generic_kernel, dim3(grid_for(ctx, total), 1, (unsigned)groups), dim3(kBlock), 0, ctx->stream,
+                           sig, alpha, vkL, vkR, c, N, l, d, out64, pstride, tout64, tstride, out32, ctx->mod);
+        return fz_check_hip(hipGetLastError(), "aggregate (generic) launch");
+    }
+    // FZ_AGG_TWOPASS=1: the two-launch form the one-pass kernel replaced (kept for A/B measurements)
     const size_t cols_a = (size_t)l * (ctx->degree / 4), cols = cols_a + (vkL ? ctx->degree / 4 : 0);
     const size_t count = cols * 4, count_a = cols_a * 4;
     const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);

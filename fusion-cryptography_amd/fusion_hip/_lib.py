@@ -17,6 +17,7 @@ FZ_E_BADARG = -1
 FZ_E_UNSUPPORTED = -2
 FZ_E_HIP = -3
 FZ_E_NODEVICE = -4
+FZ_E_RCCL = -5
 
 
 class FusionHipError(RuntimeError):
@@ -125,6 +126,29 @@ SIGNATURES.update({
     "fz_sample_ntt_values": (c_int, [ctypes.c_uint64, c_int64, c_int, _i32p]),
     "fz_sample_coefficients": (c_int, [ctypes.c_uint64, c_int64, c_int, c_int64, c_int64, _i32p]),
     "fz_sample_secret_polys": (c_int, [POINTER(ctypes.c_uint64), c_size_t, c_int64, c_int, c_int64, c_int64, _i32p, c_int]),
+})
+
+
+
+class NttJob(ctypes.Structure):
+    """fz_ntt_job of include/fusion_hip.h"""
+    _fields_ = [("d_in", c_void_p), ("d_out", c_void_p), ("rows", c_size_t), ("inverse", c_int)]
+
+
+class UniqueId(ctypes.Structure):
+    """fz_unique_id (== ncclUniqueId)"""
+    _fields_ = [("internal", ctypes.c_char * 128)]
+
+
+SIGNATURES.update({
+    "fz_ntt_multi": (c_int, [_ctx, POINTER(NttJob), c_size_t]),
+    "fz_comm_unique_id": (c_int, [POINTER(UniqueId)]),
+    "fz_comm_create": (c_int, [_ctx, c_int, c_int, POINTER(UniqueId), POINTER(c_void_p)]),
+    "fz_comm_destroy": (c_int, [c_void_p]),
+    "fz_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "fz_allreduce_i64": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
+    "fz_diag_empty_launch": (c_int, [_ctx]),
+    "fz_diag_copy": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
 })
 
 _lib = None

@@ -11,7 +11,7 @@ from ctypes import byref, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 import numpy as np
 
-from ._lib import FZ_E_BADARG, FusionHipError, check, load_library
+from ._lib import FZ_E_BADARG, FusionHipError, NttJob, UniqueId, check, load_library
 
 _I32P = ctypes.POINTER(c_int32)
 _I64P = ctypes.POINTER(c_int64)
@@ -136,6 +136,21 @@ class Context:
 
     def ntt_inverse_dev(self, d_in, d_out, batch):
         check(self._lib, self._lib.fz_ntt_inverse(self._h, c_void_p(d_in), c_void_p(d_out), batch))
+
+    def ntt_multi_dev(self, jobs):
+        """ONE dispatch over independent transform jobs: jobs = [(d_in, d_out, rows, inverse), ...]"""
+        arr = (NttJob * len(jobs))(*[NttJob(c_void_p(i), c_void_p(o), int(r), 1 if inv else 0) for i, o, r, inv in jobs])
+        check(self._lib, self._lib.fz_ntt_multi(self._h, arr, len(jobs)))
+
+    def diag_empty_launch(self):
+        check(self._lib, self._lib.fz_diag_empty_launch(self._h))
+
+    def diag_copy_dev(self, d_src, d_dst, nbytes):
+        check(self._lib, self._lib.fz_diag_copy(self._h, c_void_p(d_src), c_void_p(d_dst), nbytes))
+
+    def allreduce_i64_dev(self, comm, d_buf, count):
+        """in-place ncclAllReduce(int64, sum) on this context's stream (comm: a Comm)"""
+        check(self._lib, self._lib.fz_allreduce_i64(self._h, comm._c, c_void_p(d_buf), count))
 
     def pw_dev(self, op, d_a, d_b, d_out, count):
         fn = {OP_MUL: self._lib.fz_pw_mul, OP_ADD: self._lib.fz_pw_add, OP_SUB: self._lib.fz_pw_sub}[op]
@@ -369,6 +384,42 @@ class Context:
         finally:
             for b in bufs:
                 b.free()
+
+
+def comm_unique_id():
+    """-> 128 bytes (ncclUniqueId) that rank 0 hands to the other ranks"""
+    lib = load_library()
+    uid = UniqueId()
+    check(lib, lib.fz_comm_unique_id(byref(uid)))
+    return ctypes.string_at(ctypes.addressof(uid), 128)
+
+
+class Comm:
+    """An RCCL communicator owned through the C ABI (fz_comm_*): one per process / GPU."""
+
+    def __init__(self, ctx, nranks, rank, unique_id):
+        self._lib = ctx._lib
+        self._c = c_void_p()
+        uid = UniqueId()
+        ctypes.memmove(ctypes.addressof(uid), bytes(unique_id), 128)
+        check(self._lib, self._lib.fz_comm_create(ctx._h, nranks, rank, byref(uid), byref(self._c)))
+
+    def info(self):
+        """-> (nranks as RCCL reports it, rank)"""
+        n, r = c_int(), c_int()
+        check(self._lib, self._lib.fz_comm_info(self._c, byref(n), byref(r)))
+        return n.value, r.value
+
+    def destroy(self):
+        if self._c:
+            self._lib.fz_comm_destroy(self._c)
+            self._c = c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 class Graph:

@@ -41,6 +41,7 @@ extern "C" {
 #define FZ_E_UNSUPPORTED (-2)   /* parameters outside what the kernels implement        */
 #define FZ_E_HIP         (-3)   /* a HIP runtime call failed (message in fz_last_error) */
 #define FZ_E_NODEVICE    (-4)   /* no usable gfx950 device                              */
+#define FZ_E_RCCL        (-5)   /* RCCL missing or an RCCL call failed (fz_comm_*, fz_allreduce_i64) */
 
 /* verify verdict codes (fusion/fusion.py:686-728) */
 #define FZ_VERDICT_OK              0  /* (True, "")                                              */
@@ -121,6 +122,21 @@ FZ_API int fz_ntt_forward(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size
 FZ_API int fz_ntt_inverse(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch);
 FZ_API int fz_ntt_forward_host(fz_ctx *ctx, int32_t *h_data, size_t batch);   /* in place */
 FZ_API int fz_ntt_inverse_host(fz_ctx *ctx, int32_t *h_data, size_t batch);   /* in place */
+
+/* Many independent transforms in ONE dispatch.  The reference issues its transforms polynomial by polynomial
+ * (transform(), algebra/polynomials.py:391-433, called 2*rank times per key in fusion/fusion.py:363-368, rank times
+ * per verification in :690-692, once per challenge in :499-507); a device launch of a few thousand rows is mostly
+ * dispatch floor.  A job is (d_in, d_out, rows, direction); jobs must be independent of each other (d_in == d_out
+ * inside a job is allowed).  The job table travels in the kernel arguments: nothing is copied to the device, the
+ * call is asynchronous and can be recorded by fz_graph_*.  Degree 64 / 256: one launch per 32 jobs; other degrees:
+ * one launch per job.  h_jobs is read before the call returns. */
+typedef struct fz_ntt_job {
+    const int32_t *d_in;
+    int32_t *d_out;
+    size_t rows;
+    int inverse;               /* 0: cooley_tukey_ntt (ntt.py:216-291), 1: gentleman_sande_intt (ntt.py:294-377) */
+} fz_ntt_job;
+FZ_API int fz_ntt_multi(fz_ctx *ctx, const fz_ntt_job *h_jobs, size_t n_jobs);
 
 /* ---- pointwise ring operations on `count` int32 values -------------------------------------
  * PolynomialNTTRepresentation.__mul__/__add__/__neg__/__sub__ (algebra/polynomials.py:341-385,
@@ -235,6 +251,30 @@ FZ_API int fz_verify_partials_batch_async(fz_ctx *ctx, const int32_t *d_A, const
 FZ_API int fz_verify_with_target_batch_async(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_sig,
                                              const int32_t *d_target, size_t groups, int l,
                                              int64_t beta_vf, int64_t omega_vf, int *d_verdicts);
+
+/* ---- the exchange step across GPUs: RCCL all-reduce of the int64 partial sums -------------------
+ * aggregate() (fusion.py:670-676) and verify()'s target (:706-714) are sums over signers; with the signers sharded over
+ * GPUs each rank holds exact int64 partials (fz_aggregate_partial*, fz_target_partial*, fz_aggregate_target_partial_batch)
+ * and ONE ncclAllReduce(ncclInt64, ncclSum) over xGMI completes them (8 centred values already overflow int32).
+ * One process per GPU: rank 0 calls fz_comm_unique_id and hands the 128 bytes to the other ranks by any means
+ * (a file, a socket, MPI, torch.distributed); every rank calls fz_comm_create (collective: returns when all ranks
+ * have joined).  fz_allreduce_i64 runs in place on the context's stream, asynchronously, ordered with the kernels
+ * issued around it, and can be recorded by fz_graph_* together with them.  RCCL is bound at the first fz_comm_* call
+ * (dlopen "librccl.so.1"); without it these entries return FZ_E_RCCL and everything else keeps working. */
+typedef struct fz_unique_id { char internal[128]; } fz_unique_id;      /* == ncclUniqueId */
+typedef struct fz_comm fz_comm;
+FZ_API int fz_comm_unique_id(fz_unique_id *out_id);
+FZ_API int fz_comm_create(fz_ctx *ctx, int nranks, int rank, const fz_unique_id *id, fz_comm **out);
+FZ_API int fz_comm_destroy(fz_comm *comm);
+/* what the communicator itself reports (ncclCommCount) and this rank's index */
+FZ_API int fz_comm_info(fz_comm *comm, int *out_nranks, int *out_rank);
+FZ_API int fz_allreduce_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, size_t count);
+
+/* ---- launch-floor diagnostics (benchmarks) ---------------------------------------------------------------------
+ * An empty 4096-workgroup dispatch and a plain 16-byte-per-lane copy on the context's stream: the two floors a
+ * small-batch transform launch is judged against (bench.py reports them from the same run as the transforms). */
+FZ_API int fz_diag_empty_launch(fz_ctx *ctx);
+FZ_API int fz_diag_copy(fz_ctx *ctx, const void *d_src, void *d_dst, size_t bytes);
 
 /* ---- norm / weight of coefficient rows -------------------------------------------------------
  * PolynomialCoefficientRepresentation.norm("infty") / weight(), algebra/polynomials.py:221-227:

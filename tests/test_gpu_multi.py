@@ -1,0 +1,213 @@
+"""GPU tests of the entry points added in round 2: the multi-job transform launch (fz_ntt_multi), degrees that are not
+a multiple of 4, the RCCL binding of the C ABI on one rank, the launch-floor diagnostics and the
+device guard of contexts on different GPUs."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+Q = O.PRIME
+
+
+def _root_for(q, d):
+    for g in range(2, 2000):
+        r = pow(g, (q - 1) // (2 * d), q)
+        if pow(r, d, q) == q - 1:
+            return r
+    raise AssertionError("no root")
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_ntt_multi_ragged_mixed_jobs_match_the_oracle(secpar, coracle):
+    """one dispatch over a ragged list of forward and inverse jobs (one of them in place, one empty, more than one
+    table of 32): every job equals the oracle's transform of its rows (ntt.py:216-291, :294-377)"""
+    import fusion_hip
+    P = O.PARAMS[secpar]
+    d, root, inv = P["d"], P["root"], P["inv_root"]
+    ctx = fusion_hip.Context(Q, d, root, inv)
+    rng = np.random.default_rng(secpar)
+    rows = [1, 2, 3, 5, 64, 0, 4096, 4097, 129, 7] + [int(r) for r in rng.integers(1, 300, size=30)]
+    bufs, jobs, expect = [], [], []
+    for j, r in enumerate(rows):
+        inverse = (j % 3 == 1)
+        x = O.splitmix_centered(1000 + j, max(r, 1) * d).reshape(max(r, 1), d)[:r]
+        if j % 4 == 0 and r:       # raw int32 inputs, not centred
+            x = rng.integers(-2**31, 2**31, size=(r, d), dtype=np.int64).astype(np.int32)
+        din = fusion_hip.DeviceBuffer.from_numpy(ctx, x) if r else fusion_hip.DeviceBuffer(ctx, 16)
+        dout = din if j % 5 == 2 else fusion_hip.DeviceBuffer(ctx, max(16, r * d * 4))      # some in place
+        bufs += [din, dout]
+        jobs.append((din.ptr, dout.ptr, r, inverse))
+        expect.append((coracle.ntt_inverse(x, Q, inv) if inverse else coracle.ntt_forward(x, Q, root)) if r else x)
+    assert len([r for r in rows if r]) > 32           # exercises the flush of a full job table
+    ctx.ntt_multi_dev(jobs)
+    ctx.synchronize()
+    for (din, dout, r, inverse), e in zip(jobs, expect):
+        if r:
+            got = np.empty((r, d), np.int32)
+            ctx.d2h(got, dout)
+            assert np.array_equal(got, e), (r, inverse)
+    # the bench's shape: forward of 4 batches of 4096 rows, then their inverses, each ONE launch
+    B = 4096
+    xs = [O.splitmix_centered(50 + k, B * d).reshape(B, d) for k in range(4)]
+    dx = [fusion_hip.DeviceBuffer.from_numpy(ctx, x) for x in xs]
+    dy = [fusion_hip.DeviceBuffer(ctx, B * d * 4) for _ in xs]
+    ctx.ntt_multi_dev([(a.ptr, b.ptr, B, False) for a, b in zip(dx, dy)])
+    y0 = dy[0].to_numpy(np.int32, (B, d))
+    assert np.array_equal(y0, coracle.ntt_forward(xs[0], Q, root))
+    ctx.ntt_multi_dev([(b.ptr, b.ptr, B, True) for b in dy])
+    for x, b in zip(xs, dy):
+        assert np.array_equal(b.to_numpy(np.int32, (B, d)), x)
+    for b in bufs + dx + dy:
+        b.free()
+
+
+def test_ntt_multi_other_degrees_and_graph_capture(coracle):
+    import fusion_hip
+    d = 16
+    root = _root_for(Q, d)
+    ctx = fusion_hip.Context(Q, d, root, pow(root, Q - 2, Q))
+    x = O.splitmix_centered(3, 50 * d).reshape(50, d)
+    a, b = fusion_hip.DeviceBuffer.from_numpy(ctx, x), fusion_hip.DeviceBuffer(ctx, x.nbytes)
+    ctx.ntt_multi_dev([(a.ptr, b.ptr, 20, False), (a.ptr + 20 * d * 4, b.ptr + 20 * d * 4, 30, False)])   # one launch per job
+    assert np.array_equal(b.to_numpy(np.int32, x.shape), coracle.ntt_forward(x, Q, root))
+    # degree 256: the job table travels in the kernel arguments, so the call can be recorded and replayed
+    P = O.PARAMS[256]
+    c2 = fusion_hip.Context(Q, 256, P["root"], P["inv_root"])
+    s = c2.stream_create()
+    c2.set_stream(s)
+    x2 = O.splitmix_centered(4, 300 * 256).reshape(300, 256)
+    a2, b2, z2 = fusion_hip.DeviceBuffer.from_numpy(c2, x2), fusion_hip.DeviceBuffer(c2, x2.nbytes), fusion_hip.DeviceBuffer(c2, x2.nbytes)
+    jobs_f = [(a2.ptr, b2.ptr, 100, False), (a2.ptr + 100 * 1024, b2.ptr + 100 * 1024, 200, False)]
+    jobs_i = [(b2.ptr, z2.ptr, 300, True)]
+    c2.ntt_multi_dev(jobs_f)
+    c2.graph_begin()
+    c2.ntt_multi_dev(jobs_f)
+    c2.ntt_multi_dev(jobs_i)
+    g = c2.graph_end()
+    g.launch()
+    g.launch()
+    c2.synchronize()
+    assert np.array_equal(b2.to_numpy(np.int32, x2.shape), coracle.ntt_forward(x2, Q, P["root"]))
+    assert np.array_equal(z2.to_numpy(np.int32, x2.shape), x2)
+    g.destroy()
+    c2.set_stream(0)
+    c2.stream_destroy(s)
+
+
+@pytest.mark.parametrize("degree", [5, 6, 7, 9, 10, 12])
+def test_degrees_that_are_not_a_multiple_of_four(degree, coracle):
+    """ring-only contexts accept any degree; the int4 kernels must not be chosen for them:
+    matvec, sign_core, aggregate_core and the GeneralMatrix product against the oracle"""
+    import fusion_hip
+    from algebra.matrices import GeneralMatrix
+    from algebra.polynomials import PolynomialNTTRepresentation as PN
+    q, l, n = 65537, 7, 11
+    ctx = fusion_hip.Context(q, degree, 0, 0)         # ring-only: pointwise, matvec, scheme cores
+    rng = np.random.default_rng(degree)
+    A = rng.integers(-(q // 2), q // 2 + 1, size=(l, degree)).astype(np.int32)
+    S = rng.integers(-2**31, 2**31, size=(n, l, degree), dtype=np.int64).astype(np.int32)
+    assert np.array_equal(ctx.matvec(A, S), coracle.matvec(A, S, q))
+    sk = rng.integers(-(q // 2), q // 2 + 1, size=(n, 2, l, degree)).astype(np.int32)
+    c = rng.integers(-(q // 2), q // 2 + 1, size=(n, degree)).astype(np.int32)
+    sig = ctx.sign_core(sk, c)
+    assert np.array_equal(sig, coracle.sign_core(sk, c, q))
+    assert np.array_equal(ctx.aggregate_core(sig, c), coracle.aggregate_core(sig, c, q))
+    # the drop-in matrix product goes through the same entry point (matrices.py:115-131)
+    root = 3                                            # q = 65537: 3 is a primitive root; order 65536 is fine for the container
+    mk = lambda v: PN(modulus=q, degree=degree, root=pow(root, 65536 // 2, q), inv_root=pow(pow(root, 65536 // 2, q), q - 2, q),
+                      root_order=2, values=[int(t) for t in v])
+    left = GeneralMatrix(matrix=[[mk(A[k]) for k in range(l)]])
+    right = GeneralMatrix(matrix=[[mk(S[0, k])] for k in range(l)])
+    prod = left * right
+    assert [int(t) for t in prod.matrix[0][0].values] == coracle.matvec(A, S[:1], q)[0].tolist()
+
+
+def test_rccl_binding_of_the_c_abi_on_one_rank():
+    """fz_comm_* / fz_allreduce_i64 with nranks = 1 (the single-GPU box): the binding, the in-place int64 sum on the
+    context's stream, and its capture into the library's own graph between two kernels"""
+    import fusion_hip
+    P = O.PARAMS[256]
+    q, d, l = P["q"], P["d"], P["rank"]
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    uid = fusion_hip.comm_unique_id()
+    assert len(uid) == 128
+    comm = fusion_hip.Comm(ctx, 1, 0, uid)
+    assert comm.info() == (1, 0)
+    v = np.arange(-500, 500, dtype=np.int64) * (2**40 + 3)
+    buf = fusion_hip.DeviceBuffer.from_numpy(ctx, v)
+    ctx.allreduce_i64_dev(comm, buf.ptr, v.size)
+    ctx.synchronize()
+    assert np.array_equal(buf.to_numpy(np.int64, v.shape), v)
+    # partials -> all-reduce -> verification from the sums, as one replayable graph
+    s = ctx.stream_create()
+    ctx.set_stream(s)
+    n = 40
+    rng = np.random.default_rng(1)
+    A = O.splitmix_centered(8, l * d).reshape(l, d)
+    coef = rng.integers(-52, 53, size=(n, 2, d)).astype(np.int32)
+    dA, dc = fusion_hip.DeviceBuffer.from_numpy(ctx, A), fusion_hip.DeviceBuffer.from_numpy(ctx, coef)
+    dsk, dvk = fusion_hip.DeviceBuffer(ctx, n * 2 * l * d * 4), fusion_hip.DeviceBuffer(ctx, n * 2 * d * 4)
+    ctx.keygen_core_bcast_dev(dA.ptr, dc.ptr, dsk.ptr, dvk.ptr, n, l)
+    vk = dvk.to_numpy(np.int32, (n, 2, d))
+    ch = ctx.ntt_forward((rng.integers(0, 2, size=(n, d))).astype(np.int32))
+    al = ctx.ntt_forward((rng.integers(0, 2, size=(n, d))).astype(np.int32))
+    dch, dal = fusion_hip.DeviceBuffer.from_numpy(ctx, ch), fusion_hip.DeviceBuffer.from_numpy(ctx, al)
+    dL, dR = fusion_hip.DeviceBuffer.from_numpy(ctx, vk[:, 0]), fusion_hip.DeviceBuffer.from_numpy(ctx, vk[:, 1])
+    dsig = fusion_hip.DeviceBuffer(ctx, n * l * d * 4)
+    dpart = fusion_hip.DeviceBuffer(ctx, (l * d + d) * 8)
+    dver = fusion_hip.DeviceBuffer.from_numpy(ctx, np.full(1, -1, np.int32))
+
+    def step():
+        ctx.sign_core_dev(dsk.ptr, dch.ptr, dsig.ptr, n, l)
+        ctx.aggregate_target_partial_batch_dev(dsig.ptr, dal.ptr, dL.ptr, dR.ptr, dch.ptr, dpart.ptr, l * d,
+                                               dpart.ptr + l * d * 8, d, 1, n, l)
+        ctx.allreduce_i64_dev(comm, dpart.ptr, l * d + d)
+        ctx.verify_partials_batch_async_dev(dA.ptr, dpart.ptr, l * d, dpart.ptr + l * d * 8, d, 1, l, 2**40, d, dver.ptr)
+    step()
+    ctx.synchronize()
+    assert dver.to_numpy(np.int32, (1,))[0] == 0
+    ctx.graph_begin()
+    step()
+    g = ctx.graph_end()
+    for _ in range(3):
+        g.launch()
+    ctx.synchronize()
+    assert dver.to_numpy(np.int32, (1,))[0] == 0
+    g.destroy()
+    ctx.set_stream(0)
+    ctx.stream_destroy(s)
+    comm.destroy()
+
+
+def test_launch_floor_diagnostics_run():
+    import fusion_hip
+    P = O.PARAMS[256]
+    ctx = fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"])
+    x = O.splitmix_centered(1, 4096 * 256)
+    a, b = fusion_hip.DeviceBuffer.from_numpy(ctx, x), fusion_hip.DeviceBuffer(ctx, x.nbytes)
+    ctx.diag_empty_launch()
+    ctx.diag_copy_dev(a.ptr, b.ptr, x.nbytes)
+    assert np.array_equal(b.to_numpy(np.int32, x.shape), x)
+
+
+def test_contexts_on_two_devices_do_not_cross(coracle):
+    """every entry point makes the context's device current: a context on device 1 must launch
+    there even when the last-created context sits on device 0"""
+    import fusion_hip
+    lib = fusion_hip.load_library()
+    n = ctypes.c_int(0)
+    lib.fz_device_count(ctypes.byref(n))
+    if n.value < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU node)")
+    P = O.PARAMS[256]
+    c1 = fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"], device=1)
+    c0 = fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"], device=0)     # leaves device 0 current
+    x = O.splitmix_centered(9, 300 * 256).reshape(300, 256)
+    f1 = c1.ntt_forward(x)                                                              # default stream, device 1
+    f0 = c0.ntt_forward(x)
+    ref = coracle.ntt_forward(x, P["q"], P["root"])
+    assert np.array_equal(f1, ref) and np.array_equal(f0, ref)
+    assert np.array_equal(c1.ntt_inverse(f1), x)

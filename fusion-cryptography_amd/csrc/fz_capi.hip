@@ -118,31 +118,26 @@ int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, doub
     return FZ_OK;
 }
 
-// accumulators + tickets of the one-pass aggregation (zero between launches; see aggregate_onepass)
-int fz_agg_scratch(fz_ctx *ctx, size_t tiles, size_t tile_doubles, double **acc, unsigned **tickets) {
+// accumulator words of the one-pass aggregation (zero between launches; see aggregate_onepass)
+int fz_agg_scratch(fz_ctx *ctx, size_t tiles, size_t tile_words, unsigned long long **acc) {
     if (tiles > ctx->aggacc_tiles) {
         if (ctx->capturing)
             return fz_set_error(FZ_E_BADARG, "aggregation scratch would grow during graph capture: run the sequence once before fz_graph_begin");
         FZ_HIP(hipStreamSynchronize(ctx->stream), "aggregation scratch sync");
         if (ctx->d_aggacc) FZ_HIP(hipFree(ctx->d_aggacc), "aggregation scratch free");
-        if (ctx->d_aggtick) FZ_HIP(hipFree(ctx->d_aggtick), "aggregation tickets free");
         ctx->d_aggacc = nullptr;
-        ctx->d_aggtick = nullptr;
         ctx->aggacc_tiles = 0;
         const size_t cap = tiles + tiles / 4 + 8;
-        FZ_HIP(hipMalloc((void **)&ctx->d_aggacc, cap * tile_doubles * sizeof(double)), "aggregation scratch alloc");
-        FZ_HIP(hipMalloc((void **)&ctx->d_aggtick, ((cap * sizeof(unsigned) + 15) / 16) * 16), "aggregation tickets alloc");
+        FZ_HIP(hipMalloc((void **)&ctx->d_aggacc, cap * tile_words * sizeof(unsigned long long)), "aggregation scratch alloc");
         ctx->aggacc_tiles = cap;
         ctx->agg_dirty = 1;
     }
     if (ctx->agg_dirty) {
         if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "aggregation scratch must be re-zeroed: not during graph capture");
-        FZ_HIP(hipMemsetAsync(ctx->d_aggacc, 0, ctx->aggacc_tiles * tile_doubles * sizeof(double), ctx->stream), "aggregation scratch clear");
-        FZ_HIP(hipMemsetAsync(ctx->d_aggtick, 0, ((ctx->aggacc_tiles * sizeof(unsigned) + 15) / 16) * 16, ctx->stream), "aggregation tickets clear");
+        FZ_HIP(hipMemsetAsync(ctx->d_aggacc, 0, ctx->aggacc_tiles * tile_words * sizeof(unsigned long long), ctx->stream), "aggregation scratch clear");
         ctx->agg_dirty = 0;
     }
     *acc = ctx->d_aggacc;
-    *tickets = ctx->d_aggtick;
     return FZ_OK;
 }
 
@@ -343,7 +338,6 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     if (ctx->d_vpart) (void)hipFree(ctx->d_vpart);
     if (ctx->d_vstate) (void)hipFree(ctx->d_vstate);
     if (ctx->d_aggacc) (void)hipFree(ctx->d_aggacc);
-    if (ctx->d_aggtick) (void)hipFree(ctx->d_aggtick);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     free(ctx->h_tw);

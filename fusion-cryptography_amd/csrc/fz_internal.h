@@ -56,10 +56,9 @@ struct fz_ctx {
     int *d_vstate;
     size_t vpart_doubles, vstate_groups;
     int verify_dirty;            // a verify launch failed: accumulators / state words are re-zeroed before the next one
-    // one-pass aggregation: per (aggregate, column block) fp64 accumulators [tiles][tile_doubles] and ticket words;
-    // all zero between launches (the last arrival re-arms them)
-    double *d_aggacc;
-    unsigned *d_aggtick;
+    // one-pass aggregation: per (aggregate, column block) accumulator words [tiles][tile_words] (running sum + arrival
+    // count, see aggregate_onepass); all zero between launches (the last adder of a word re-arms it)
+    unsigned long long *d_aggacc;
     size_t aggacc_tiles;
     int agg_dirty;
     int grid_multi;              // resident grid of the multi-job transform kernel (0 = not queried yet)
@@ -91,7 +90,7 @@ int fz_check_hip(hipError_t e, const char *what);
 int fz_scratch(fz_ctx *ctx, size_t bytes, void **out);
 int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out);
 int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, double **part, int **state);
-int fz_agg_scratch(fz_ctx *ctx, size_t tiles, size_t tile_doubles, double **acc, unsigned **tickets);
+int fz_agg_scratch(fz_ctx *ctx, size_t tiles, size_t tile_words, unsigned long long **acc);
 
 // launchers (fz_ntt.hip)
 int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse);

@@ -192,31 +192,35 @@ __global__ __launch_bounds__(kBlock) void sign_scalar_kernel(const int32_t *sk_h
 // and no reduction at all; every kAggFold signers the two sums fold back below q (fz_fold, exact).  The split of
 // alpha costs 16 integer/convert operations per signer and lane, shared by the lane's 16 coefficients.
 // End of the workgroup: the WAVES partials meet in LDS; with one slice per aggregate the result is written directly;
-// with several, each workgroup adds its 1024 exact integers into the aggregate's fp64 accumulator with agent-scope
-// atomics (performed at the memory side: coherent across the 8 XCD L2s without any fence), takes a ticket, and the
-// last arrival swaps the sums out (re-arming the accumulator for the next launch) and writes the output.  Only
-// sigma and alpha are ever read: no scratch round trip, no second launch.
+// with several, each workgroup adds its 1024 exact integers into the tile's 64-bit accumulator words with returning
+// agent-scope atomics (performed at the memory side: coherent across the 8 XCD L2s without any fence); a word also
+// counts its arrivals, so the thread whose add comes last holds the finished sum and writes the output (see below).
+// Only sigma and alpha are ever read: no scratch round trip, no second launch.
 // Workgroup -> XCD placement (speed only): workgroups b and b + 8 share an XCD, so all column blocks of one
 // (aggregate, slice) pair get block ids equal mod 8 and each alpha row is fetched into ONE L2.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kAggR = 4;          // int4 columns per lane
+constexpr int kAggDepth = 3;      // signers in flight per wave
 constexpr int kAggFold = 16;      // signers between folds: 16 * 2^31 * 2^16 = 2^51 < 2^53
 constexpr int kAggTile = 64 * kAggR * 4;   // coefficients per workgroup (1024)
 
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
                                                                 const int32_t *vkR, const int32_t *c, size_t N, int l, int d4,
-                                                                int ncb_a, int ncb, int nsl, int pairs, double *accum,
-                                                                unsigned *tickets, int64_t *out64, size_t pstride,
+                                                                int ncb_a, int ncb, int nsl, int pairs,
+                                                                unsigned long long *accum, int64_t *out64, size_t pstride,
                                                                 int64_t *tout64, size_t tstride, int32_t *out32, FzMod m) {
-    __shared__ __attribute__((aligned(16))) double red[(WAVES / 2) * kAggTile];
-    __shared__ int s_last;
+    __shared__ __attribute__((aligned(16))) double red[WAVES * kAggTile];      // 64 KiB at 8 waves
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // block id -> (column block, aggregate, slice); pairs p = g * nsl + sb with equal p % 8 share an XCD
-    const unsigned b = blockIdx.x, rest = b >> 3;
-    const int cb = (int)(rest % (unsigned)ncb);
-    const int p = (int)(rest / (unsigned)ncb) * 8 + (int)(b & 7u);
-    if (p >= pairs) return;
+    // block id -> tile t = p * ncb + cb (p = g * nsl + sb: the (aggregate, slice) pair, cb the column block).  Workgroups
+    // b and b + 8 share an XCD, so XCD x = b % 8 gets the CONTIGUOUS run of tiles [x * per_xcd, (x + 1) * per_xcd): equal
+    // load on every XCD (a pair-per-XCD mapping left XCDs with 21 and others with 42 workgroups at 12 slices: 30.7 us
+    // instead of 21.9), and an alpha row is still fetched into one L2, two where a run of tiles ends inside a pair
+    const unsigned tiles = (unsigned)pairs * (unsigned)ncb, per_xcd = (tiles + 7u) / 8u;
+    const unsigned tl = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || tl >= tiles) return;
+    const int cb = (int)(tl % (unsigned)ncb);
+    const int p = (int)(tl / (unsigned)ncb);
     const size_t g = (size_t)(p / nsl);
     const int sb = p % nsl;
     const size_t base = N / (size_t)nsl, extra = N % (size_t)nsl;
@@ -246,51 +250,54 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
             col[r] = cr < cols_a ? cr : cols_a - 1;       // clamped lanes compute garbage that is never written
         }
         const int4 *sig4 = reinterpret_cast<const int4 *>(sig) + g * N * cols_a;
-        int4 a_cur, x_cur[kAggR], a_nxt, x_nxt[kAggR];
-        size_t i = i0 + wave;
-        if (i < i1) {
-            a_cur = alpha4[i * d4 + j4];
+        // kAggDepth signers in flight per wave (5 loads of 16 bytes per lane each): a wave's signers are a SEQUENTIAL
+        // chain of memory latencies otherwise (first version, one signer ahead: N = 1024 took 29 us, 11 signers per wave
+        // at ~2 us each)
+        int4 a_q[kAggDepth], x_q[kAggDepth][kAggR];
+        auto load = [&](int s, size_t i) {
+            a_q[s] = alpha4[i * d4 + j4];
 #pragma unroll
-            for (int r = 0; r < kAggR; ++r) x_cur[r] = sig4[i * cols_a + col[r]];
-        }
+            for (int r = 0; r < kAggR; ++r) x_q[s][r] = sig4[i * cols_a + col[r]];
+        };
+        const size_t first = i0 + wave;
+#pragma unroll
+        for (int s = 0; s < kAggDepth; ++s)
+            if (first + (size_t)s * WAVES < i1) load(s, first + (size_t)s * WAVES);       // wave-uniform
         int since = 0;
-        while (i < i1) {
-            const size_t in = i + WAVES;
-            if (in < i1) {                                // wave-uniform
-                a_nxt = alpha4[in * d4 + j4];
+        for (size_t i = first; i < i1; i += (size_t)kAggDepth * WAVES) {
 #pragma unroll
-                for (int r = 0; r < kAggR; ++r) x_nxt[r] = sig4[in * cols_a + col[r]];
-            }
-            const int av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
-            double ah[4], al[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                ah[k] = (double)(av[k] >> 16);
-                al[k] = (double)(av[k] & 0xffff);
-            }
-#pragma unroll
-            for (int r = 0; r < kAggR; ++r) {
-                const double xv[4] = {(double)x_cur[r].x, (double)x_cur[r].y, (double)x_cur[r].z, (double)x_cur[r].w};
+            for (int s = 0; s < kAggDepth; ++s) {
+                const size_t is = i + (size_t)s * WAVES;
+                if (is >= i1) break;
+                const int av[4] = {a_q[s].x, a_q[s].y, a_q[s].z, a_q[s].w};
+                double ah[4], al[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    hi[r][k] = __builtin_fma(xv[k], ah[k], hi[r][k]);
-                    lo[r][k] = __builtin_fma(xv[k], al[k], lo[r][k]);
+                    ah[k] = (double)(av[k] >> 16);
+                    al[k] = (double)(av[k] & 0xffff);
                 }
-            }
-            if (++since == kAggFold) {
-                since = 0;
 #pragma unroll
-                for (int r = 0; r < kAggR; ++r)
+                for (int r = 0; r < kAggR; ++r) {
+                    const double xv[4] = {(double)x_q[s][r].x, (double)x_q[s][r].y, (double)x_q[s][r].z, (double)x_q[s][r].w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        lo[r][k] = fz_fold(lo[r][k], m) + fz_fold(hi[r][k] * 65536.0, m);
-                        hi[r][k] = 0.0;
+                        hi[r][k] = __builtin_fma(xv[k], ah[k], hi[r][k]);
+                        lo[r][k] = __builtin_fma(xv[k], al[k], lo[r][k]);
                     }
-            }
-            a_cur = a_nxt;
+                }
+                const size_t in = is + (size_t)kAggDepth * WAVES;
+                if (in < i1) load(s, in);                 // refill this slot: the loads stay kAggDepth signers ahead
+                if (++since == kAggFold) {
+                    since = 0;
 #pragma unroll
-            for (int r = 0; r < kAggR; ++r) x_cur[r] = x_nxt[r];
-            i = in;
+                    for (int r = 0; r < kAggR; ++r)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            lo[r][k] = fz_fold(lo[r][k], m) + fz_fold(hi[r][k] * 65536.0, m);
+                            hi[r][k] = 0.0;
+                        }
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < kAggR; ++r)
@@ -314,34 +321,13 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
         }
     }
 
-    // the WAVES partials meet in LDS (element e of the tile = coefficient cb * 1024 + e of the aggregate), in two
-    // rounds so that the staging area stays at WAVES/2 tiles: the upper half of the waves hands its sums to the lower
+    // the WAVES partials meet in LDS: element e of the tile = coefficient cb * 1024 + e of the aggregate
     {
-        constexpr int H = WAVES / 2;
-        double *mine = red + (wave % H) * kAggTile + lane * 4;
-        if (wave >= H) {
+        double *mine = red + wave * kAggTile + lane * 4;
 #pragma unroll
-            for (int r = 0; r < kAggR; ++r) {
-                *reinterpret_cast<double2 *>(mine + r * 256) = make_double2(lo[r][0], lo[r][1]);
-                *reinterpret_cast<double2 *>(mine + r * 256 + 2) = make_double2(lo[r][2], lo[r][3]);
-            }
-        }
-        __syncthreads();
-        if (wave < H) {
-#pragma unroll
-            for (int r = 0; r < kAggR; ++r) {
-                const double2 u = *reinterpret_cast<const double2 *>(mine + r * 256);
-                const double2 v = *reinterpret_cast<const double2 *>(mine + r * 256 + 2);
-                lo[r][0] += u.x; lo[r][1] += u.y; lo[r][2] += v.x; lo[r][3] += v.y;
-            }
-        }
-        __syncthreads();
-        if (wave < H) {
-#pragma unroll
-            for (int r = 0; r < kAggR; ++r) {
-                *reinterpret_cast<double2 *>(mine + r * 256) = make_double2(lo[r][0], lo[r][1]);
-                *reinterpret_cast<double2 *>(mine + r * 256 + 2) = make_double2(lo[r][2], lo[r][3]);
-            }
+        for (int r = 0; r < kAggR; ++r) {
+            *reinterpret_cast<double2 *>(mine + r * 256) = make_double2(lo[r][0], lo[r][1]);
+            *reinterpret_cast<double2 *>(mine + r * 256 + 2) = make_double2(lo[r][2], lo[r][3]);
         }
     }
     __syncthreads();
@@ -355,47 +341,44 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
         const int e = threadIdx.x + u * 64 * WAVES;
         double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < WAVES / 2; ++w) s += red[w * kAggTile + e];
+        for (int w = 0; w < WAVES; ++w) s += red[w * kAggTile + e];
         sum[u] = s;
     }
-    auto emit = [&](int e, double s) {
+    auto emit = [&](int e, long long v) {
         const size_t k = k0 + (size_t)e;
-        if (e >= span || k >= limit) return;
-        if (tgt) tout64[g * tstride + k] = (int64_t)s;
-        else if (out64) out64[g * pstride + k] = (int64_t)s;
-        else out32[g * cols_a * 4 + k] = (int)fz_cent_wide(s, m);
+        if (tgt) tout64[g * tstride + k] = v;
+        else if (out64) out64[g * pstride + k] = v;
+        else out32[g * cols_a * 4 + k] = (int)fz_cent_i64(v, m);
     };
     if (nsl == 1) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) emit(threadIdx.x + u * 64 * WAVES, sum[u]);
+        for (int u = 0; u < PER; ++u) {
+            const int e = threadIdx.x + u * 64 * WAVES;
+            if (e < span && k0 + (size_t)e < limit) emit(e, (long long)sum[u]);
+        }
         return;
     }
-    double *acc = accum + (g * (size_t)ncb + (size_t)cb) * kAggTile;
-    unsigned *ticket = tickets + g * (size_t)ncb + (size_t)cb;
-    double seen = 0.0;
+    // Several slices per aggregate: every workgroup ADDS its exact integers into the tile's accumulator words with one
+    // returning agent-scope atomic per coefficient (executed at the memory side: coherent across the 8 XCD L2s, no
+    // fence).  A word carries the running sum in its low 54 bits (two's complement, |sum| < 2^53) and the number of
+    // arrivals above them (each add also adds 2^54), so the value an add returns tells its thread whether it was the
+    // LAST of the nsl adders of that coefficient: that thread then holds the complete sum, writes the output and
+    // re-arms the word for the next launch by subtracting what it read.  No ticket, no barrier, no read-back pass:
+    // the tail of the kernel is one atomic round trip (the first version -- fp64 adds, a ticket per tile, the last
+    // workgroup swapping the sums out -- spent three: 8 us of fixed cost per launch, of which this removes ~2.5).
+    unsigned long long *acc = accum + (g * (size_t)ncb + (size_t)cb) * kAggTile;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int e = threadIdx.x + u * 64 * WAVES;
-        if (e < span && k0 + (size_t)e < limit)
-            seen += __hip_atomic_fetch_add(acc + e, sum[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e < span && k0 + (size_t)e < limit) {
+            const unsigned long long add = (unsigned long long)(long long)sum[u] + (1ull << 54);
+            const unsigned long long now = __hip_atomic_fetch_add(acc + e, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+            if ((unsigned)((now + (1ull << 53)) >> 54) == (unsigned)nsl) {
+                emit(e, (long long)(now - ((unsigned long long)nsl << 54)));
+                __hip_atomic_fetch_add(acc + e, 0ull - now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // back to zero
+            }
+        }
     }
-    // every add of this workgroup has been PERFORMED (its old value is back) before the ticket is drawn
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (seen == 0x1.0p+1000) s_last = -1;                 // never true: keeps the returned values live
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == (unsigned)(nsl - 1)) ? 1 : 0;
-    }
-    __syncthreads();
-    if (s_last != 1) return;
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int e = threadIdx.x + u * 64 * WAVES;
-        if (e < span && k0 + (size_t)e < limit)
-            emit(e, __hip_atomic_exchange(acc + e, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // read and re-arm
-    }
-    if (threadIdx.x == 0) __hip_atomic_exchange(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // any degree, any N: one thread per coefficient of the aggregate (and of the target), all signers in sequence.
@@ -652,10 +635,10 @@ static unsigned split_count(fz_ctx *ctx, size_t N, unsigned gx, size_t groups, s
 template <int WAVES>
 static void launch_onepass(fz_ctx *ctx, unsigned grid, const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
                            const int32_t *vkR, const int32_t *c, size_t N, int l, int d4, int ncb_a, int ncb, int nsl, int pairs,
-                           double *acc, unsigned *tickets, int64_t *out64, size_t pstride, int64_t *tout64, size_t tstride,
+                           unsigned long long *acc, int64_t *out64, size_t pstride, int64_t *tout64, size_t tstride,
                            int32_t *out32) {
     hipLaunchKernelGGL(aggregate_onepass<WAVES>, dim3(grid), dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N, l, d4,
-                       ncb_a, ncb, nsl, pairs, acc, tickets, out64, pstride, tout64, tstride, out32, ctx->mod);
+                       ncb_a, ncb, nsl, pairs, acc, out64, pstride, tout64, tstride, out32, ctx->mod);
 }
 
 // out64 != nullptr: int64 partial sums at out64 + g*pstride; else centred int32 at out32 + g*l*degree.
@@ -672,40 +655,33 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
         const size_t cols_a = (size_t)l * d4;
         const int ncb_a = (int)((cols_a + 64 * kAggR - 1) / (64 * kAggR));
         const int ncb = ncb_a + (vkL ? 1 : 0);                       // d4 <= 64: the target fits one column block
-        // slices of the signers per aggregate: enough workgroups for every CU, at least 4 signers per wave
+        // slices of the signers per aggregate: as many tiles (column block x aggregate x slice) as the chip holds at once --
+        // one 8-wave workgroup per CU (180 VGPRs: two waves per SIMD) -- so that every CU streams from the first moment
+        // and nothing waits for a second round; at least kAggDepth signers per wave
         int waves = ctx->knob_agg_waves ? ctx->knob_agg_waves : 8;
         const size_t blocks_min = (size_t)ncb * groups;
-        auto slices = [&](int wv) {
-            const size_t want = (size_t)ctx->num_cu * (wv == 8 ? 1 : 2);
-            size_t n = (want + blocks_min - 1) / blocks_min;
-            const size_t most = N / ((size_t)wv * 4);
-            if (n > most) n = most;
-            if (n < 1) n = 1;
-            if (n > 4096) n = 4096;
-            return n;
-        };
-        size_t nsl = slices(waves);
-        if (!ctx->knob_agg_waves && blocks_min * nsl < (size_t)ctx->num_cu) {   // too few 8-wave workgroups: halve them
-            waves = 4;
-            nsl = slices(waves);
-        }
-        if (ctx->knob_agg_slices > 0) nsl = (size_t)ctx->knob_agg_slices;
+        const size_t capacity = (size_t)ctx->num_cu * (waves == 8 ? 1 : 2);
+        size_t nsl = capacity / blocks_min;
+        const size_t most = N / ((size_t)waves * kAggDepth);
+        if (nsl > most) nsl = most;
+        if (nsl < 1) nsl = 1;
+        if (nsl > 512) nsl = 512;                      // the arrival count shares a 64-bit word with the sum (10 bits)
+        if (ctx->knob_agg_slices > 0 && ctx->knob_agg_slices <= 512) nsl = (size_t)ctx->knob_agg_slices;
         if (nsl > N && N > 0) nsl = N;
         if (N == 0) nsl = 1;
         const size_t pairs = groups * nsl;
         if (pairs * (size_t)ncb > 0x3fffffffull) return fz_set_error(FZ_E_UNSUPPORTED, "aggregate: grid too large");
-        double *acc = nullptr;
-        unsigned *tickets = nullptr;
+        unsigned long long *acc = nullptr;
         if (nsl > 1) {
-            int rc = fz_agg_scratch(ctx, groups * (size_t)ncb, (size_t)kAggTile, &acc, &tickets);
+            int rc = fz_agg_scratch(ctx, groups * (size_t)ncb, (size_t)kAggTile, &acc);
             if (rc != FZ_OK) return rc;
         }
-        const unsigned grid = (unsigned)(8 * ((pairs + 7) / 8) * (size_t)ncb);
+        const unsigned grid = (unsigned)(8 * ((pairs * (size_t)ncb + 7) / 8));
         if (waves == 4)
-            launch_onepass<4>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, tickets, out64,
+            launch_onepass<4>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, out64,
                               pstride, tout64, tstride, out32);
         else
-            launch_onepass<8>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, tickets, out64,
+            launch_onepass<8>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, out64,
                               pstride, tout64, tstride, out32);
         const int rc = fz_check_hip(hipGetLastError(), "aggregate launch");
         if (rc != FZ_OK && nsl > 1) ctx->agg_dirty = 1;              // accumulators / tickets may no longer be zero

@@ -710,16 +710,28 @@ def main():
         params = F.fusion_setup(SECPAR, 2026)
         bs = BatchScheme(params, device=dev_index)
         bs.ctx.set_stream(stream.cuda_stream)
-        n_e2e = 256
+        n_e2e = 1024
         seeds = [10_000 + 2 * i for i in range(n_e2e)]
         msgs = [f"synthetic message {i:06d}" for i in range(n_e2e)]
         bs.keygen_batch(seeds[:4])
         t0 = time.perf_counter()
         sk_e, vk_e = bs.keygen_batch(seeds, device=True)               # secret keys stay in HBM
         t_keygen = time.perf_counter() - t0
+        bs.sign_batch(sk_e, vk_e, msgs, device=True).free()           # scratch growth outside the timing
         t0 = time.perf_counter()
         sig_e = bs.sign_batch(sk_e, vk_e, msgs, device=True)           # signatures stay in HBM
         t_sign = time.perf_counter() - t0
+        # the same signatures with the challenge pipeline on the HOST threads (round 1's path), for the split
+        bs.device_hash = False
+        t0 = time.perf_counter()
+        bs.sign_batch(sk_e, vk_e, msgs, device=True).free()
+        t_sign_host = time.perf_counter() - t0
+        bs.device_hash = True
+        t0 = time.perf_counter()
+        pre_only = bs.challenges_dev(vk_e, msgs)[0]
+        torch.cuda.synchronize(dev)
+        t_chal = time.perf_counter() - t0
+        pre_only.free()
         t0 = time.perf_counter()
         agg_e = bs.aggregate(vk_e, msgs, sig_e)
         t_agg = time.perf_counter() - t0
@@ -727,13 +739,33 @@ def main():
         ok, why = bs.verify(vk_e, msgs, agg_e)
         t_ver = time.perf_counter() - t0
         assert ok, why
+        sig_e.free()
+        sk_e.free()
+        # a larger batch of signatures: the device pipeline is a latency chain of ~108 Keccak permutations per signer,
+        # the same ~0.7 ms for any batch up to 32 768 signers (two lanes per signer, one wave per SIMD)
+        n_big = 16384
+        seeds_b = [50_000 + 2 * i for i in range(n_big)]
+        msgs_b = [f"synthetic message {i:06d}" for i in range(n_big)]
+        sk_b, vk_b = bs.keygen_batch(seeds_b, device=True)
+        bs.sign_batch(sk_b, vk_b, msgs_b[:n_big], device=True).free()
+        t0 = time.perf_counter()
+        bs.sign_batch(sk_b, vk_b, msgs_b, device=True).free()
+        t_sign_big = time.perf_counter() - t0
+        sk_b.free()
         e2e = {"signatures": n_e2e, "host_threads": bs.threads, "keygen_per_s": n_e2e / t_keygen,
                "sign_per_s": n_e2e / t_sign,
+               "sign_split": {"device_challenge_pipeline_ms": t_chal * 1e3, "whole_sign_batch_ms": t_sign * 1e3,
+                              "sign_per_s_with_host_challenge_pipeline": n_e2e / t_sign_host,
+                              "what": "sign_batch = SHA3 of the messages on the host + upload of 32 B per message + device: text of "
+                                      "str(vk), SHAKE-256, decoder, NTT (fz_challenge_hat_dev) + sign_core; the host-pipeline figure "
+                                      "runs serialiser + SHAKE + decoder on the host threads instead (round 1)"},
+               "sign_per_s_at_16384_signatures": n_big / t_sign_big,
                "aggregate_per_s": n_e2e / t_agg, "verify_per_s": n_e2e / t_ver,
                "sign_plus_verify_per_s": n_e2e / (t_sign + t_agg + t_ver),
-               "note": "BatchScheme with device-resident keys and signatures: C host pipeline (reference-exact MT19937 "
-                       "sampling, str(vk) serialisation, SHA3/SHAKE, decoder) + device cores; verification keys, "
-                       "challenges and aggregation coefficients cross PCIe; hash_ag is one serial XOF by construction"}
+               "note": "BatchScheme with device-resident keys and signatures: reference-exact MT19937 sampling and message "
+                       "pre-hash on the host, the per-signer challenge pipeline and all algebra on the device; aggregate and "
+                       "verify are bounded by hash_ag, ONE serial SHAKE-256 over ~13.5 KB per signer on the host by construction "
+                       "(fusion.py:632-652)"}
 
     if rank == 0:
         # HBM-side traffic of this launch from the PMC counters (rocprofv3 --pmc, separate passes; FETCH_SIZE corrected x2

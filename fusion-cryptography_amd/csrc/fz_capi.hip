@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
+#include <vector>
 #include <dlfcn.h>
 
 static thread_local char g_err[512] = "";
@@ -904,6 +906,66 @@ int fz_ntt_multi(fz_ctx *ctx, const fz_ntt_job *h_jobs, size_t n_jobs) {
         ++J.n;
     }
     return fz_launch_ntt_multi(ctx, J);
+}
+
+// ---- the challenge pipeline on the device (device half) ---------------------------------------------
+static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *h_prehash, size_t N,
+                         int32_t *d_out, bool transform) {
+    FZ_REQUIRE(ctx && P && (N == 0 || (d_vk && h_prehash && d_out)), "NULL argument");
+    FZ_DEV(ctx);
+    if (!fz_host_params_ok(P)) return fz_set_error(FZ_E_BADARG, "bad scheme parameters");
+    if (P->degree != ctx->degree || P->modulus != (int64_t)ctx->q)
+        return fz_set_error(FZ_E_BADARG, "scheme parameters (degree %d) do not belong to this context (degree %d)", P->degree, ctx->degree);
+    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the challenge pipeline uploads the pre-hashed messages: not during graph capture");
+    const long long bound = std::max<long long>(1, std::min<long long>((long long)P->modulus / 2, P->beta_ch));
+    if (bound != 1 || P->degree > 256 || P->degree < 4 || (P->degree & (P->degree - 1)) || P->omega_ch > P->degree ||
+        (((uintptr_t)d_vk | (uintptr_t)d_out) & 15))
+        return fz_set_error(FZ_E_UNSUPPORTED, "device challenge pipeline: ternary challenges (norm bound 1), degree 4..256 and "
+                                              "16-byte aligned rows only; use fz_challenge_coefficients (host)");
+    if (transform && ctx->logd < 0) return fz_set_error(FZ_E_UNSUPPORTED, "ring-only context (created with root 0) has no transforms");
+    if (N == 0) return FZ_OK;
+    int sb = 0, cb = 0, ib = 0;
+    const size_t needed = fz_host_challenge_needed_bytes(P, &sb, &cb, &ib);
+    const int out_blocks = (int)((needed + 135) / 136);
+    // longest possible text: fixed pieces + 2*degree values of up to 11 characters + separators + 78 digits
+    char t0[384], t1[384], t2[16];
+    int n0, n1, n2;
+    fz_host_vk_text_parts(P, t0, &n0, t1, &n1, t2, &n2, 384);
+    if (n0 < 0) return fz_set_error(FZ_E_UNSUPPORTED, "verification-key text pieces do not fit");
+    const size_t max_len = (size_t)n0 + n1 + n2 + (size_t)2 * P->degree * 13 + 78;
+    size_t blocks = max_len / 136 + 1;
+    blocks += blocks & 1;                                   // even: rows stay 16-byte aligned
+    const size_t text_stride = blocks * 136;
+    // signers per pass: 65536 = two waves of 32 signers on each of the chip's 1024 SIMDs (a second wave per SIMD fills the
+    // issue slots one wave alone leaves empty); bounds the scratch at ~16 KB per signer
+    const size_t chunk = 65536;
+    for (size_t base = 0; base < N; base += chunk) {
+        const size_t n = std::min(chunk, N - base);
+        const size_t xstride = (n + 63) & ~(size_t)63;
+        const size_t o_pre = 0, o_nb = (n * 32 + 255) & ~(size_t)255, o_text = o_nb + ((n * 4 + 255) & ~(size_t)255);
+        const size_t o_xof = o_text + ((n * text_stride + 255) & ~(size_t)255);
+        const size_t total = o_xof + (size_t)out_blocks * 34 * xstride * 4;
+        void *scr = nullptr;
+        FZ_TRY(fz_scratch(ctx, total, &scr));
+        uint8_t *sp = (uint8_t *)scr;
+        FZ_HIP(hipMemcpyAsync(sp + o_pre, h_prehash + 32 * base, n * 32, hipMemcpyHostToDevice, ctx->stream), "upload of the pre-hashed messages");
+        FZ_HIP(hipStreamSynchronize(ctx->stream), "upload sync");      // the caller's buffer has been consumed when this returns
+        FZ_TRY(fz_launch_challenge(ctx, P, d_vk + base * 2 * (size_t)P->degree, sp + o_pre, n, sp + o_text, text_stride,
+                                   (int *)(sp + o_nb), (uint32_t *)(sp + o_xof), xstride, out_blocks,
+                                   d_out + base * (size_t)P->degree));
+    }
+    if (transform) return fz_launch_ntt(ctx, d_out, d_out, N, false);
+    return FZ_OK;
+}
+
+int fz_challenge_coefficients_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *h_prehash,
+                                  size_t N, int32_t *d_coefs) {
+    return challenge_dev(ctx, P, d_vk, h_prehash, N, d_coefs, false);
+}
+
+int fz_challenge_hat_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *h_prehash, size_t N,
+                         int32_t *d_c_hat) {
+    return challenge_dev(ctx, P, d_vk, h_prehash, N, d_c_hat, true);
 }
 
 // ---- launch-floor diagnostics ------------------------------------------------------------------------------

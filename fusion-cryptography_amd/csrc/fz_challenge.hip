@@ -1,0 +1,386 @@
+// fz_challenge.hip -- the per-signer challenge pipeline ON THE DEVICE (device half).
+//
+// hash_ch (fusion/fusion.py:511-531) for N independent (key, message) pairs:
+//     x  = sign_hash_dst + "," + str(vk) + "," + str(int(prehash))                      fusion.py:412-419
+//     b  = SHAKE-256(x), as many bytes as the decoder consumes                          fusion.py:515-524
+//     c  = decode_bytes_to_polynomial_coefficients(b, ...)                              fusion.py:422-481
+//     c^ = NTT(c)                                                                       fusion.py:499-507
+// The text of str(vk) is the one the reference hashes (fusion.py:328-329 -> algebra/matrices.py:40-41 ->
+// algebra/polynomials.py:257-258).  Verification keys never leave the device as text: three kernels,
+//   1. vk_text_kernel      one wave per signer: the exact ASCII text (the decimal of the 256-bit pre-hashed message
+//                          included), padded (SHAKE suffix 0x1f ... 0x80) to whole 136-byte blocks, written to a scratch
+//                          row; integers are formatted where they are stored
+//   2. shake_kernel        TWO lanes per signer, one holding the low and one the high 32 bits of every Keccak lane:
+//                          bitwise steps are independent 32-bit operations, a 64-bit rotation is one v_alignbit of
+//                          (own half, partner's half) with the partner's half fetched by a DPP quad swap -- the same
+//                          instruction stream for both lanes.  159 vector operations per round and lane instead of
+//                          260 for a whole state per lane: the chain of ~108 permutations per signer (47 absorbed
+//                          blocks + 61 squeezed) is the latency of the whole pipeline, and Keccak offers no more
+//                          parallelism inside a permutation without bit-slicing overheads that cancel it.
+//                          Output words leave transposed ([word][signer]) so that every access is coalesced.
+//   3. decode_kernel       one lane per signer: bit-string of signs, then the partial Fisher-Yates shuffle driven by
+//                          33-byte big-endian integers reduced mod (i + 1); all stream positions are the same for
+//                          every signer, so they live in scalar registers and the shuffle state in LDS ([position][lane],
+//                          conflict-free for data-dependent positions).
+// then the ordinary forward transform (fz_ntt.hip).  Supported: the scheme's parameter sets (norm bound 1, i.e. ternary
+// challenges; degree <= 256); anything else returns FZ_E_UNSUPPORTED and callers use the host pipeline (fz_host.cpp).
+#include "fz_internal.h"
+#include "../../include/fusion_hip.h"
+
+namespace {
+
+constexpr int kRate = 136;                   // SHAKE-256 rate in bytes (17 lanes of 64 bits)
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1. text
+// ---------------------------------------------------------------------------------------------------------------
+struct VkTextParts {                         // the fixed pieces of the text, built on the host once per call
+    char s0[384], s1[384], s2[16];           // before the left values / between left and right / after the right values
+    int n0, n1, n2;
+};
+
+__device__ __forceinline__ int dec_len(int v) {          // len(str(v)) for an int32
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    int n = (v < 0) ? 2 : 1;
+    n += u >= 10u; n += u >= 100u; n += u >= 1000u; n += u >= 10000u; n += u >= 100000u; n += u >= 1000000u;
+    n += u >= 10000000u; n += u >= 100000000u; n += u >= 1000000000u;
+    return n;
+}
+
+// one wave per signer, kTextWaves signers per workgroup.  text row i: blocks * 136 bytes, *nblocks = blocks
+constexpr int kTextWaves = 4;
+__global__ __launch_bounds__(64 * kTextWaves) void vk_text_kernel(const int32_t *vk, size_t vk_stride, const uint8_t *pre,
+                                                                  size_t N, int degree, VkTextParts T,
+                                                                  uint8_t *text, size_t text_stride, int *nblocks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t i = (size_t)blockIdx.x * kTextWaves + wave;
+    if (i >= N) return;
+    uint8_t *buf = smem + (size_t)wave * text_stride;
+    uint32_t *aux = reinterpret_cast<uint32_t *>(smem + (size_t)kTextWaves * text_stride) + wave * 16;
+    // str(int.from_bytes(prehash, "little")) (fusion.py:405-409, :416-418): the 256-bit integer in base 10^9, least
+    // significant chunk first (one lane: 9 rounds of an 8-limb short division), digits written by lanes 0..8 below
+    if (lane == 0) {
+        uint32_t limb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint8_t *b = pre + i * 32 + 4 * t;
+            limb[t] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        }
+        int n = 0;
+        bool nz = true;
+        while (nz && n < 9) {
+            unsigned long long rem = 0;
+            nz = false;
+#pragma unroll
+            for (int t = 7; t >= 0; --t) {
+                const unsigned long long cur = (rem << 32) | limb[t];
+                limb[t] = (uint32_t)(cur / 1000000000ull);
+                rem = cur % 1000000000ull;
+                nz |= limb[t] != 0;
+            }
+            aux[n++] = (uint32_t)rem;
+        }
+        aux[9] = (uint32_t)n;
+    }
+    for (size_t o = (size_t)lane * 16; o < text_stride; o += 64 * 16) *reinterpret_cast<int4 *>(buf + o) = make_int4(0, 0, 0, 0);
+    const int nvals = 2 * degree;
+    const int vpl = nvals >= 64 ? nvals / 64 : 1;               // values per lane (a lane never straddles the two halves)
+    const int k0 = lane * vpl;
+    const int32_t *row = vk + i * vk_stride;
+    // pass 1: lengths (digits + ", " unless last of its half)
+    int mine = 0;
+    for (int t = 0; t < vpl; ++t) {
+        const int k = k0 + t;
+        if (k < nvals) mine += dec_len(row[k]) + (((k + 1) % degree) ? 2 : 0);
+    }
+    int incl = mine;                                            // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    const int total_vals = __shfl(incl, 63);
+    const int left_total = (nvals >= 64) ? __shfl(incl, 31) : __shfl(incl, degree - 1);
+    int pos = T.n0 + (incl - mine) + ((k0 >= degree) ? T.n1 : 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the zero fill above before the byte writes below
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // pass 2: characters, last digit first
+    for (int t = 0; t < vpl; ++t) {
+        const int k = k0 + t;
+        if (k >= nvals) break;
+        const int v = row[k];
+        const int n = dec_len(v);
+        unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+        int p = pos + n;
+        do {
+            buf[--p] = (uint8_t)('0' + u % 10u);
+            u /= 10u;
+        } while (u);
+        if (v < 0) buf[--p] = '-';
+        pos += n;
+        if ((k + 1) % degree) { buf[pos] = ','; buf[pos + 1] = ' '; pos += 2; }
+    }
+    // fixed pieces and the decimal of the pre-hashed message (lane c writes chunk c: 9 digits, the leading chunk as many
+    // as it has)
+    const int nch = (int)aux[9];
+    const int top = dec_len((int)aux[nch - 1]);                  // < 10^9: fits an int
+    const int tl = top + 9 * (nch - 1);
+    const int at1 = T.n0 + left_total, at2 = T.n0 + T.n1 + total_vals, at3 = at2 + T.n2;
+    for (int c = lane; c < T.n0; c += 64) buf[c] = (uint8_t)T.s0[c];
+    for (int c = lane; c < T.n1; c += 64) buf[at1 + c] = (uint8_t)T.s1[c];
+    for (int c = lane; c < T.n2; c += 64) buf[at2 + c] = (uint8_t)T.s2[c];
+    if (lane < nch) {
+        unsigned u = aux[lane];
+        const int nd = (lane == nch - 1) ? top : 9;
+        int p = at3 + tl - 9 * lane;                             // one past this chunk's last digit
+        for (int k = 0; k < nd; ++k) {
+            buf[--p] = (uint8_t)('0' + u % 10u);
+            u /= 10u;
+        }
+    }
+    const int len = at3 + tl;
+    const int nb = len / kRate + 1;                             // pad10*1 always adds at least one byte
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) {
+        buf[len] ^= 0x1f;                                       // SHAKE domain bits + first pad bit (FIPS 202)
+        buf[nb * kRate - 1] ^= 0x80;
+        nblocks[i] = nb;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint8_t *dst = text + i * text_stride;
+    for (int o = lane * 8; o < nb * kRate; o += 64 * 8) *reinterpret_cast<uint2 *>(dst + o) = *reinterpret_cast<const uint2 *>(buf + o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2. Keccak-f[1600] on two lanes per state (low halves in the even lane, high halves in the odd lane)
+// ---------------------------------------------------------------------------------------------------------------
+__constant__ uint32_t kRC[24][2] = {
+    {0x00000001u, 0x00000000u}, {0x00008082u, 0x00000000u}, {0x0000808au, 0x80000000u}, {0x80008000u, 0x80000000u},
+    {0x0000808bu, 0x00000000u}, {0x80000001u, 0x00000000u}, {0x80008081u, 0x80000000u}, {0x00008009u, 0x80000000u},
+    {0x0000008au, 0x00000000u}, {0x00000088u, 0x00000000u}, {0x80008009u, 0x00000000u}, {0x8000000au, 0x00000000u},
+    {0x8000808bu, 0x00000000u}, {0x0000008bu, 0x80000000u}, {0x00008089u, 0x80000000u}, {0x00008003u, 0x80000000u},
+    {0x00008002u, 0x80000000u}, {0x00000080u, 0x80000000u}, {0x0000800au, 0x00000000u}, {0x8000000au, 0x80000000u},
+    {0x80008081u, 0x80000000u}, {0x00008080u, 0x80000000u}, {0x80000001u, 0x00000000u}, {0x80008008u, 0x80000000u}};
+
+__device__ __forceinline__ uint32_t partner(uint32_t x) {       // the other half of the same 64-bit lane: quad_perm [1,0,3,2]
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
+}
+
+// this lane's half of rotl64(X, R), X = (own half, partner's half):  R < 32: (x << R) | (px >> (32 - R)) for BOTH lanes
+// (low lane: lo' = lo << R | hi >> (32-R); high lane: hi' = hi << R | lo >> (32-R)); R >= 32 swaps the roles first
+template <int R>
+__device__ __forceinline__ uint32_t rotl64_half(uint32_t x, uint32_t px) {
+    if (R == 0) return x;
+    if (R == 32) return px;
+    if (R < 32) return __builtin_amdgcn_alignbit(x, px, 32 - R);
+    return __builtin_amdgcn_alignbit(px, x, 64 - R);
+}
+
+#define FZ_ROT(dst, src, R) { const uint32_t t_ = (src); dst = rotl64_half<R>(t_, partner(t_)); }
+// one round A -> E (theta, rho + pi, chi, iota); every index a compile-time constant
+#define FZ_KROUND32(A, E, rc) { \
+    const uint32_t c0 = A##0 ^ A##5 ^ A##10 ^ A##15 ^ A##20, c1 = A##1 ^ A##6 ^ A##11 ^ A##16 ^ A##21, \
+                   c2 = A##2 ^ A##7 ^ A##12 ^ A##17 ^ A##22, c3 = A##3 ^ A##8 ^ A##13 ^ A##18 ^ A##23, \
+                   c4 = A##4 ^ A##9 ^ A##14 ^ A##19 ^ A##24; \
+    uint32_t r0, r1, r2, r3, r4; \
+    FZ_ROT(r1, c1, 1) FZ_ROT(r2, c2, 1) FZ_ROT(r3, c3, 1) FZ_ROT(r4, c4, 1) FZ_ROT(r0, c0, 1) \
+    const uint32_t d0 = c4 ^ r1, d1 = c0 ^ r2, d2 = c1 ^ r3, d3 = c2 ^ r4, d4 = c3 ^ r0; \
+    uint32_t b0, b1, b2, b3, b4; \
+    b0 = A##0 ^ d0; FZ_ROT(b1, A##6 ^ d1, 44) FZ_ROT(b2, A##12 ^ d2, 43) FZ_ROT(b3, A##18 ^ d3, 21) FZ_ROT(b4, A##24 ^ d4, 14) \
+    E##0 = b0 ^ (~b1 & b2) ^ (rc); E##1 = b1 ^ (~b2 & b3); E##2 = b2 ^ (~b3 & b4); E##3 = b3 ^ (~b4 & b0); E##4 = b4 ^ (~b0 & b1); \
+    FZ_ROT(b0, A##3 ^ d3, 28) FZ_ROT(b1, A##9 ^ d4, 20) FZ_ROT(b2, A##10 ^ d0, 3) FZ_ROT(b3, A##16 ^ d1, 45) FZ_ROT(b4, A##22 ^ d2, 61) \
+    E##5 = b0 ^ (~b1 & b2); E##6 = b1 ^ (~b2 & b3); E##7 = b2 ^ (~b3 & b4); E##8 = b3 ^ (~b4 & b0); E##9 = b4 ^ (~b0 & b1); \
+    FZ_ROT(b0, A##1 ^ d1, 1) FZ_ROT(b1, A##7 ^ d2, 6) FZ_ROT(b2, A##13 ^ d3, 25) FZ_ROT(b3, A##19 ^ d4, 8) FZ_ROT(b4, A##20 ^ d0, 18) \
+    E##10 = b0 ^ (~b1 & b2); E##11 = b1 ^ (~b2 & b3); E##12 = b2 ^ (~b3 & b4); E##13 = b3 ^ (~b4 & b0); E##14 = b4 ^ (~b0 & b1); \
+    FZ_ROT(b0, A##4 ^ d4, 27) FZ_ROT(b1, A##5 ^ d0, 36) FZ_ROT(b2, A##11 ^ d1, 10) FZ_ROT(b3, A##17 ^ d2, 15) FZ_ROT(b4, A##23 ^ d3, 56) \
+    E##15 = b0 ^ (~b1 & b2); E##16 = b1 ^ (~b2 & b3); E##17 = b2 ^ (~b3 & b4); E##18 = b3 ^ (~b4 & b0); E##19 = b4 ^ (~b0 & b1); \
+    FZ_ROT(b0, A##2 ^ d2, 62) FZ_ROT(b1, A##8 ^ d3, 55) FZ_ROT(b2, A##14 ^ d4, 39) FZ_ROT(b3, A##15 ^ d0, 41) FZ_ROT(b4, A##21 ^ d1, 2) \
+    E##20 = b0 ^ (~b1 & b2); E##21 = b1 ^ (~b2 & b3); E##22 = b2 ^ (~b3 & b4); E##23 = b3 ^ (~b4 & b0); E##24 = b4 ^ (~b0 & b1); }
+
+struct KState {
+    uint32_t a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15, a16, a17, a18, a19, a20, a21, a22, a23, a24;
+};
+
+__device__ __forceinline__ void keccak_f_half(KState &S, int half) {
+    uint32_t a0 = S.a0, a1 = S.a1, a2 = S.a2, a3 = S.a3, a4 = S.a4, a5 = S.a5, a6 = S.a6, a7 = S.a7, a8 = S.a8, a9 = S.a9,
+             a10 = S.a10, a11 = S.a11, a12 = S.a12, a13 = S.a13, a14 = S.a14, a15 = S.a15, a16 = S.a16, a17 = S.a17,
+             a18 = S.a18, a19 = S.a19, a20 = S.a20, a21 = S.a21, a22 = S.a22, a23 = S.a23, a24 = S.a24;
+    uint32_t e0, e1, e2, e3, e4, e5, e6, e7, e8, e9, e10, e11, e12, e13, e14, e15, e16, e17, e18, e19, e20, e21, e22, e23, e24;
+#pragma unroll 1
+    for (int r = 0; r < 24; r += 2) {
+        FZ_KROUND32(a, e, kRC[r][half])
+        FZ_KROUND32(e, a, kRC[r + 1][half])
+    }
+    S.a0 = a0; S.a1 = a1; S.a2 = a2; S.a3 = a3; S.a4 = a4; S.a5 = a5; S.a6 = a6; S.a7 = a7; S.a8 = a8; S.a9 = a9;
+    S.a10 = a10; S.a11 = a11; S.a12 = a12; S.a13 = a13; S.a14 = a14; S.a15 = a15; S.a16 = a16; S.a17 = a17; S.a18 = a18;
+    S.a19 = a19; S.a20 = a20; S.a21 = a21; S.a22 = a22; S.a23 = a23; S.a24 = a24;
+}
+
+#define FZ_FOR17(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)
+
+// text rows [N][text_stride] (padded blocks), nblocks [N]  ->  xof words, transposed: word k (32 bits: 64-bit lane k/2 of
+// the stream, half k%2) of signer s at xof[k * xstride + s]
+__global__ __launch_bounds__(64) void shake_kernel(const uint8_t *text, size_t text_stride, const int *nblocks, size_t N,
+                                                   int max_blocks, int out_blocks, uint32_t *xof, size_t xstride) {
+    const int lane = threadIdx.x & 63, half = lane & 1;
+    const size_t s_raw = (size_t)blockIdx.x * 32 + (lane >> 1);
+    const bool live = s_raw < N;
+    const size_t s = live ? s_raw : N - 1;                       // idle pairs shadow the last signer and store nothing
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(text + s * text_stride) + half;
+    const int nb = nblocks[s];
+    KState S = {};
+#pragma unroll 1
+    for (int b = 0; b < max_blocks; ++b) {
+        if (b < nb) {                                            // both lanes of a pair agree; pairs of a wave may differ by a block
+            const uint32_t *w = row + b * (kRate / 4);
+#define FZ_ABS(i) S.a##i ^= w[2 * i];
+            FZ_FOR17(FZ_ABS)
+#undef FZ_ABS
+            keccak_f_half(S, half);
+        }
+    }
+    uint32_t *out = xof + s + (size_t)half * xstride;
+#pragma unroll 1
+    for (int m = 0; m < out_blocks; ++m) {
+        if (live) {
+            uint32_t *o = out + (size_t)m * 34 * xstride;
+#define FZ_SQ(i) o[(size_t)(2 * i) * xstride] = S.a##i;
+            FZ_FOR17(FZ_SQ)
+#undef FZ_SQ
+        }
+        if (m + 1 < out_blocks) keccak_f_half(S, half);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3. decoder (fusion.py:422-481) for norm bound 1: signs, then the partial Fisher-Yates shuffle
+// ---------------------------------------------------------------------------------------------------------------
+struct DecodeShapeDev {
+    int degree, weight, sign_bytes, coef_bytes, index_bytes;
+};
+
+// stream byte `pos` (the same for every lane) of this lane's signer
+__device__ __forceinline__ uint32_t stream_byte(const uint32_t *x, size_t xstride, int pos) {
+    return (x[(size_t)(pos >> 2) * xstride] >> (8 * (pos & 3))) & 0xffu;
+}
+
+constexpr int kChunkWords = 12;              // 32-bit stream words that can hold one index chunk at any alignment (<= 44 bytes)
+
+__global__ __launch_bounds__(64) void decode_kernel(const uint32_t *xof, size_t xstride, size_t N, DecodeShapeDev D, int32_t *coefs) {
+    extern __shared__ __attribute__((aligned(16))) int32_t out[];              // [degree][64]
+    const int lane = threadIdx.x & 63;
+    const size_t s_raw = (size_t)blockIdx.x * 64 + lane;
+    const bool live = s_raw < N;
+    const uint32_t *x = xof + (live ? s_raw : N - 1);
+    const int d = D.degree;
+    for (int j = 0; j < d; ++j) out[j * 64 + lane] = 0;
+    // sign i = bit i (LSB first) of the big-endian integer in the leading sign_bytes bytes (fusion.py:447-453);
+    // magnitudes are 1 + (chunk mod 1) = 1
+    for (int i = 0; i < D.weight; ++i) {
+        const uint32_t byte = stream_byte(x, xstride, D.sign_bytes - 1 - (i >> 3));
+        const int bit = (byte >> (i & 7)) & 1;
+        if (i < d) out[i * 64 + lane] = bit ? 1 : -1;
+    }
+    // for i = degree-1 down to weight+1: j = int.from_bytes(chunk, "big") % (i + 1); swap(out[i], out[j])   (fusion.py:472-480)
+    // Every stream position is the same for all lanes (scalar registers).  A chunk's words are loaded TOGETHER, one chunk
+    // ahead of the arithmetic: loaded where they are used, each 4-byte step waited for its own L2 round trip and the
+    // kernel took 0.58 ms for what is 0.05 ms of arithmetic.
+    const int ib = D.index_bytes, head = ib & 3, groups = ib >> 2;
+    int pos = D.sign_bytes + D.coef_bytes * D.weight;
+    uint32_t wn[kChunkWords];
+    auto fetch = [&](int p) {                                    // words covering stream bytes [p, p + ib)
+        const int k0 = p >> 2, cnt = ((p + ib - 1) >> 2) - k0 + 1;
+#pragma unroll
+        for (int t = 0; t < kChunkWords; ++t) wn[t] = (t < cnt) ? x[(size_t)(k0 + t) * xstride] : 0u;
+    };
+    if (D.weight < d - 1) fetch(pos);
+    for (int i = d - 1; i > D.weight; --i) {
+        uint32_t w[kChunkWords + 1];
+#pragma unroll
+        for (int t = 0; t < kChunkWords; ++t) w[t] = wn[t];
+        w[kChunkWords] = 0u;
+        const int sh = pos & 3;
+        if (i - 1 > D.weight) fetch(pos + ib);                   // next chunk in flight during this one's arithmetic
+        const double mdl = (double)(i + 1), inv = 1.0 / mdl;
+        // head bytes (ib mod 4 of them), big-endian
+        const uint32_t u0 = sh ? __builtin_amdgcn_alignbyte(w[1], w[0], sh) : w[0];
+        double r = head ? (double)(__builtin_bswap32(u0) >> (8 * (4 - head))) : 0.0;          // < 2^24
+        r = r - mdl * __builtin_floor(r * inv);
+        if (r < 0.0) r += mdl;
+        if (r >= mdl) r -= mdl;
+        // the 4-byte groups start at stream offset pos + head: word offset base2 (0 or 1) into w, byte shift sh2
+        const int sh2 = (sh + head) & 3;
+        if ((sh + head) >> 2) {
+#pragma unroll
+            for (int t = 0; t < kChunkWords; ++t) w[t] = w[t + 1];
+        }
+#pragma unroll
+        for (int g = 0; g < kChunkWords - 1; ++g) {
+            if (g < groups) {                                    // scalar condition
+                const uint32_t le = sh2 ? __builtin_amdgcn_alignbyte(w[g + 1], w[g], sh2) : w[g];
+                double t = __builtin_fma(r, 4294967296.0, (double)__builtin_bswap32(le));      // r < 2^8: exact below 2^41
+                const double qn = __builtin_floor(t * inv);
+                t = __builtin_fma(-qn, mdl, t);
+                if (t < 0.0) t += mdl;                           // the quotient estimate may be off by one
+                if (t >= mdl) t -= mdl;
+                r = t;
+            }
+        }
+        pos += ib;
+        const int j = (int)r;
+        const int vi = out[i * 64 + lane], vj = out[j * 64 + lane];
+        out[i * 64 + lane] = vj;
+        out[j * 64 + lane] = vi;
+    }
+    if (live) {
+        int32_t *dst = coefs + s_raw * (size_t)d;
+        for (int j = 0; j < d; j += 4)
+            *reinterpret_cast<int4 *>(dst + j) = make_int4(out[j * 64 + lane], out[(j + 1) * 64 + lane], out[(j + 2) * 64 + lane],
+                                                           out[(j + 3) * 64 + lane]);
+    }
+}
+
+}  // namespace
+
+// the fixed pieces of str(OneTimeVerificationKey) come from the host serialiser, so both pipelines share one definition
+void fz_host_vk_text_parts(const fz_scheme_params *P, char *s0, int *n0, char *s1, int *n1, char *s2, int *n2, int cap);
+size_t fz_host_challenge_needed_bytes(const fz_scheme_params *P, int *sign_bytes, int *coef_bytes, int *index_bytes);
+
+// d_vk [N][2][degree] int32 (left row, right row), d_pre [N][32] (SHA3-256 digests of the messages = the pre-hashed
+// integers, little-endian), d_text / d_nblocks / d_xof scratch; d_coefs [N][degree] out
+int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *d_pre, size_t N,
+                        uint8_t *d_text, size_t text_stride, int *d_nblocks, uint32_t *d_xof, size_t xstride, int out_blocks,
+                        int32_t *d_coefs) {
+    VkTextParts T;
+    fz_host_vk_text_parts(P, T.s0, &T.n0, T.s1, &T.n1, T.s2, &T.n2, 384);
+    if (T.n0 < 0) return fz_set_error(FZ_E_UNSUPPORTED, "verification-key text pieces do not fit");
+    const int d = P->degree;
+    const size_t lds_text = (size_t)kTextWaves * text_stride + kTextWaves * 64;
+    if (lds_text > 160 * 1024) return fz_set_error(FZ_E_UNSUPPORTED, "text row too long for the serialiser");
+    if (lds_text > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)vk_text_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_text);
+        if (e != hipSuccess) return fz_check_hip(e, "text kernel LDS attribute");
+    }
+    hipLaunchKernelGGL(vk_text_kernel, dim3((unsigned)((N + kTextWaves - 1) / kTextWaves)), dim3(64 * kTextWaves), lds_text, ctx->stream,
+                       d_vk, (size_t)2 * d, d_pre, N, d, T, d_text, text_stride, d_nblocks);
+    int rc = fz_check_hip(hipGetLastError(), "vk_text launch");
+    if (rc != FZ_OK) return rc;
+    const int max_blocks = (int)(text_stride / kRate);
+    hipLaunchKernelGGL(shake_kernel, dim3((unsigned)((N + 31) / 32)), dim3(64), 0, ctx->stream, d_text, text_stride, d_nblocks, N,
+                       max_blocks, out_blocks, d_xof, xstride);
+    rc = fz_check_hip(hipGetLastError(), "shake launch");
+    if (rc != FZ_OK) return rc;
+    DecodeShapeDev D;
+    D.degree = d;
+    D.weight = P->omega_ch;
+    (void)fz_host_challenge_needed_bytes(P, &D.sign_bytes, &D.coef_bytes, &D.index_bytes);
+    if (D.index_bytes > 4 * (kChunkWords - 1)) return fz_set_error(FZ_E_UNSUPPORTED, "index chunks of %d bytes", D.index_bytes);
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), (size_t)d * 64 * 4, ctx->stream, d_xof, xstride, N, D, d_coefs);
+    return fz_check_hip(hipGetLastError(), "decode launch");
+}

@@ -383,6 +383,44 @@ bool params_ok(const fz_scheme_params *P) {
 
 }  // namespace
 
+// ---- what the device challenge pipeline (fz_challenge.hip) shares with this file -------------------------------------
+// The fixed pieces of dst + "," + str(vk) + "," around the two lists of values, cut out of the serialiser's own output
+// for an all-zero key (so both pipelines have ONE definition of the text): s0 before the left values, s1 between the
+// lists, s2 after the right values (including the "," that precedes the pre-hashed message).  n0 = -1 if a piece
+// does not fit `cap` (or 16 for s2).
+void fz_host_vk_text_parts(const fz_scheme_params *P, char *s0, int *n0, char *s1, int *n1, char *s2, int *n2, int cap) {
+    const int d = P->degree;
+    std::vector<int32_t> zeros((size_t)d, 0);
+    std::string t;
+    t.append(reinterpret_cast<const char *>(P->sign_hash_dst), 2);
+    t += ",";
+    put_vk(t, *P, zeros.data(), zeros.data());
+    t += ",";
+    const size_t zl = (size_t)3 * d - 2;                              // "0, 0, ..., 0"
+    const size_t a = t.find("values=[") + 8;
+    const size_t b = t.find("values=[", a) + 8;
+    const std::string p0 = t.substr(0, a), p1 = t.substr(a + zl, b - (a + zl)), p2 = t.substr(b + zl);
+    *n0 = *n1 = *n2 = -1;
+    if ((int)p0.size() > cap || (int)p1.size() > cap || p2.size() > 16) return;
+    memcpy(s0, p0.data(), p0.size());
+    memcpy(s1, p1.data(), p1.size());
+    memcpy(s2, p2.data(), p2.size());
+    *n0 = (int)p0.size(); *n1 = (int)p1.size(); *n2 = (int)p2.size();
+}
+
+// bytes of the XOF stream the challenge decoder CONSUMES (fusion.py:422-481): signs, weight magnitudes, and
+// degree - 1 - weight shuffle indices -- a prefix of the n bytes the reference squeezes (:515-524)
+size_t fz_host_challenge_needed_bytes(const fz_scheme_params *P, int *sign_bytes, int *coef_bytes, int *index_bytes) {
+    const DecodeShape s = decode_shape(P->secpar, P->modulus, P->degree, P->beta_ch, P->omega_ch);
+    if (sign_bytes) *sign_bytes = s.sign_bytes;
+    if (coef_bytes) *coef_bytes = s.coef_bytes;
+    if (index_bytes) *index_bytes = s.index_bytes;
+    const int draws = std::max(0, P->degree - 1 - P->omega_ch);
+    return (size_t)s.sign_bytes + (size_t)s.coef_bytes * (size_t)P->omega_ch + (size_t)s.index_bytes * (size_t)draws;
+}
+
+bool fz_host_params_ok(const fz_scheme_params *P) { return params_ok(P); }
+
 extern "C" {
 
 int fz_sha3_256(const uint8_t *h_data, size_t len, uint8_t *h_out32) {
@@ -422,7 +460,9 @@ int fz_decode_coefficients(const uint8_t *h_bytes, size_t len, int log2_bias, in
 int fz_hash_messages(const fz_scheme_params *P, const char *h_msgs, const size_t *h_msg_off, size_t N,
                      uint8_t *h_prehash) {
     if (!params_ok(P) || !h_msg_off || !h_prehash || (N && !h_msgs)) return fz_set_error(FZ_E_BADARG, "bad argument");
-    for (size_t i = 0; i < N; ++i) prehash(*P, h_msgs + h_msg_off[i], h_msg_off[i + 1] - h_msg_off[i], h_prehash + 32 * i);
+    // independent messages: spread over host threads once there are enough of them to pay for the threads
+    const int threads = N >= 2048 ? (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    parallel_for(N, threads, [&](size_t i) { prehash(*P, h_msgs + h_msg_off[i], h_msg_off[i + 1] - h_msg_off[i], h_prehash + 32 * i); });
     return FZ_OK;
 }
 

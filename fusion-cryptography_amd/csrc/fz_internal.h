@@ -98,6 +98,15 @@ int fz_ntt_query_grid(fz_ctx *ctx);
 int fz_launch_ntt_multi(fz_ctx *ctx, const FzMultiJobs &jobs);     // degree 64 / 256
 int fz_launch_diag(fz_ctx *ctx, int what, const void *src, void *dst, size_t bytes);
 
+// challenge pipeline on the device (fz_challenge.hip) and the pieces it shares with the host serialiser (fz_host.cpp)
+struct fz_scheme_params;
+int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *d_pre, size_t N,
+                        uint8_t *d_text, size_t text_stride, int *d_nblocks, uint32_t *d_xof, size_t xstride, int out_blocks,
+                        int32_t *d_coefs);
+void fz_host_vk_text_parts(const fz_scheme_params *P, char *s0, int *n0, char *s1, int *n1, char *s2, int *n2, int cap);
+size_t fz_host_challenge_needed_bytes(const fz_scheme_params *P, int *sign_bytes, int *coef_bytes, int *index_bytes);
+bool fz_host_params_ok(const fz_scheme_params *P);
+
 int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int32_t *out, size_t batch);
 int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,
                            int l, bool broadcast = false);

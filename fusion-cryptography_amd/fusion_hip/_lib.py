@@ -123,6 +123,8 @@ SIGNATURES.update({
     "fz_challenge_coefficients": (c_int, [_spp, _i32p, _i32p, c_char_p, _szp, c_size_t, _i32p, _u8p, c_int]),
     "fz_sort_by_vk_string": (c_int, [_spp, _i32p, _i32p, c_size_t, _szp, c_int]),
     "fz_aggregation_coefficients": (c_int, [_spp, _i32p, _i32p, _u8p, _i32p, c_size_t, _i32p, c_int]),
+    "fz_challenge_coefficients_dev": (c_int, [_ctx, _spp, c_void_p, _u8p, c_size_t, c_void_p]),
+    "fz_challenge_hat_dev": (c_int, [_ctx, _spp, c_void_p, _u8p, c_size_t, c_void_p]),
     "fz_sample_ntt_values": (c_int, [ctypes.c_uint64, c_int64, c_int, _i32p]),
     "fz_sample_coefficients": (c_int, [ctypes.c_uint64, c_int64, c_int, c_int64, c_int64, _i32p]),
     "fz_sample_secret_polys": (c_int, [POINTER(ctypes.c_uint64), c_size_t, c_int64, c_int, c_int64, c_int64, _i32p, c_int]),

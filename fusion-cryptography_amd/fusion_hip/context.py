@@ -152,6 +152,17 @@ class Context:
         """in-place ncclAllReduce(int64, sum) on this context's stream (comm: a Comm)"""
         check(self._lib, self._lib.fz_allreduce_i64(self._h, comm._c, c_void_p(d_buf), count))
 
+    def challenge_dev(self, P, d_vk, prehash, N, d_out, transform=True):
+        """hash_ch on the device for N (key, message) pairs: P a SchemeParams, d_vk [N][2][degree] (device), prehash
+        [N][32] uint8 (host, hostpipe.hash_messages), d_out [N][degree] (device): c_hat, or the coefficient rows
+        with transform=False"""
+        pre = np.ascontiguousarray(prehash, dtype=np.uint8).reshape(-1, 32)
+        if pre.shape[0] != N:
+            raise FusionHipError(FZ_E_BADARG, f"{pre.shape[0]} pre-hashed messages for {N} keys")
+        fn = self._lib.fz_challenge_hat_dev if transform else self._lib.fz_challenge_coefficients_dev
+        check(self._lib, fn(self._h, byref(P), c_void_p(d_vk), pre.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), N,
+                            c_void_p(d_out)))
+
     def pw_dev(self, op, d_a, d_b, d_out, count):
         fn = {OP_MUL: self._lib.fz_pw_mul, OP_ADD: self._lib.fz_pw_add, OP_SUB: self._lib.fz_pw_sub}[op]
         check(self._lib, fn(self._h, c_void_p(d_a), c_void_p(d_b), c_void_p(d_out), count))

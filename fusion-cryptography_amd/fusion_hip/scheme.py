@@ -10,6 +10,7 @@ sig [N][l][d], aggregate [l][d]; all int32, centred.
 import numpy as np
 
 from . import hostpipe
+from ._lib import FZ_E_UNSUPPORTED, FusionHipError
 from .context import DeviceArray, VERDICT_REASONS, get_context
 
 
@@ -21,6 +22,7 @@ class BatchScheme:
         self.threads = threads or hostpipe.default_threads()
         self.d, self.l, self.q = params.degree, params.num_rows_sk, params.modulus
         self.ctx = get_context(params.modulus, params.degree, params.root, params.inv_root, device)
+        self.device_hash = True          # per-signer challenge pipeline on the device (falls back to the host if unsupported)
         self.A = np.array([z.values for row in params.public_challenge.matrix for z in row], dtype=np.int32)
 
     # ---- keygen ------------------------------------------------------------------------------------
@@ -60,20 +62,60 @@ class BatchScheme:
                 b.free()
 
     # ---- sign --------------------------------------------------------------------------------------
+    def challenges_dev(self, vk, messages):
+        """hash_ch for every (key, message) ON THE DEVICE (fz_challenge_hat_dev: text of str(vk), SHAKE-256, decoder,
+        forward NTT): -> (c_hat DeviceArray [N][d], prehash [N][32]).  vk: numpy [N][2][d] or a DeviceArray of that
+        shape.  Raises FusionHipError(FZ_E_UNSUPPORTED) for parameter sets the device pipeline does not cover."""
+        pre = hostpipe.hash_messages(self.P, messages)
+        n = len(messages)
+        dV, own = self._dev(vk, (n, 2, self.d))
+        dC = DeviceArray(self.ctx, (n, self.d))
+        try:
+            self.ctx.challenge_dev(self.P, dV.ptr, pre, n, dC.ptr, transform=True)
+        except Exception:
+            dC.free()
+            raise
+        finally:
+            if own:
+                self.ctx.synchronize()
+                dV.free()
+        return dC, pre
+
     def challenges(self, vk, messages):
-        """hash_ch for every (key, message): -> (c_hat [N][d], prehash [N][32])"""
-        vk = np.ascontiguousarray(vk, dtype=np.int32).reshape(-1, 2, self.d)
+        """hash_ch for every (key, message): -> (c_hat [N][d], prehash [N][32]).  The per-signer pipeline runs on the
+        device when it covers the parameter set (self.device_hash), else in the C host pipeline."""
+        if self.device_hash:
+            try:
+                dC, pre = self.challenges_dev(vk, messages)
+                out = dC.numpy()
+                dC.free()
+                return out, pre
+            except FusionHipError as e:
+                if e.code != FZ_E_UNSUPPORTED:
+                    raise
+                self.device_hash = False
+        vk = np.ascontiguousarray(vk.numpy() if isinstance(vk, DeviceArray) else vk, dtype=np.int32).reshape(-1, 2, self.d)
         coefs, pre = hostpipe.challenge_coefficients(self.P, np.ascontiguousarray(vk[:, 0]),
                                                      np.ascontiguousarray(vk[:, 1]), messages, self.threads)
         return self.ctx.ntt_forward(coefs), pre
 
     def sign_batch(self, sk_hat, vk, messages, device=False):
         """-> sig [N][l][d]; row i equals sign(params, key_i, messages[i]).signature_hat.
-        sk_hat may be a numpy array or a DeviceArray; with device=True the signatures stay on the device."""
-        c_hat, _ = self.challenges(vk, messages)
-        n = c_hat.shape[0]
+        sk_hat may be a numpy array or a DeviceArray; with device=True the signatures stay on the device.
+        With the device challenge pipeline the challenges never visit the host."""
+        dC = None
+        if self.device_hash:
+            try:
+                dC, _ = self.challenges_dev(vk, messages)
+            except FusionHipError as e:
+                if e.code != FZ_E_UNSUPPORTED:
+                    raise
+                self.device_hash = False
+        if dC is None:
+            c_hat, _ = self.challenges(vk, messages)
+            dC = DeviceArray.from_numpy(self.ctx, c_hat)
+        n = dC.shape[0]
         dK, own = self._dev(sk_hat, (n, 2, self.l, self.d))
-        dC = DeviceArray.from_numpy(self.ctx, c_hat)
         dS = DeviceArray(self.ctx, (n, self.l, self.d))
         try:
             self.ctx.sign_core_dev(dK.ptr, dC.ptr, dS.ptr, n, self.l)
@@ -95,8 +137,7 @@ class BatchScheme:
         order = hostpipe.sort_by_vk_string(self.P, L, R, self.threads)
         L, R = L[order], R[order]
         msgs = [messages[i] for i in order]
-        coefs, pre = hostpipe.challenge_coefficients(self.P, L, R, msgs, self.threads)
-        c_hat = self.ctx.ntt_forward(coefs)
+        c_hat, pre = self.challenges(np.stack([L, R], axis=1), msgs)
         alpha = hostpipe.aggregation_coefficients(self.P, L, R, pre, c_hat, self.threads)
         return order, L, R, c_hat, self.ctx.ntt_forward(alpha)
 

@@ -327,6 +327,21 @@ FZ_API int fz_aggregation_coefficients(const fz_scheme_params *P, const int32_t 
                                        const int32_t *h_vk_right, const uint8_t *h_prehash,
                                        const int32_t *h_c_hat, size_t N, int32_t *h_coefs, int threads);
 
+/* ---- the per-signer challenge pipeline on the DEVICE (device half) ------------------------------
+ * hash_ch (fusion.py:511-531) for N independent (key, message) pairs without the keys ever leaving the device as text:
+ * the exact str(OneTimeVerificationKey) serialisation (fusion.py:328-329 -> matrices.py:40-41 -> polynomials.py:257-258),
+ * SHAKE-256 (fusion.py:412-419), the byte decoder (fusion.py:422-481) and -- fz_challenge_hat_dev -- the forward
+ * transform (fusion.py:499-507).  d_vk [N][2][degree] as fz_keygen_core writes it (left row, right row); h_prehash
+ * [N][32] from fz_hash_messages (HOST memory: 32 bytes per message, converted to decimal text and uploaded by the call);
+ * d_coefs / d_c_hat [N][degree].  Asynchronous apart from that upload.  Only as many XOF bytes are squeezed as the
+ * decoder consumes (a prefix of the reference's n).  Supported: ternary challenges (norm bound 1: both parameter sets
+ * of the reference), degree 4..256; otherwise FZ_E_UNSUPPORTED -- use fz_challenge_coefficients.
+ * hash_ag (fusion.py:632-652) stays on the host: it is ONE serial XOF over all signers by construction. */
+FZ_API int fz_challenge_coefficients_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *h_prehash,
+                                         size_t N, int32_t *d_coefs);
+FZ_API int fz_challenge_hat_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *h_prehash,
+                                size_t N, int32_t *d_c_hat);
+
 /* ---- reference-exact sampling on the host -----------------------------------------
  * CPython's MT19937 `random` exactly as the reference's samplers drive it (random.seed(int), randrange):
  * the same seed yields the same polynomial as algebra/polynomials.py:436-488.  Non-negative int seeds. */

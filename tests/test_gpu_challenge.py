@@ -1,0 +1,99 @@
+"""GPU parity of the device challenge pipeline (fz_challenge_*_dev: text of str(vk) -> SHAKE-256 -> decoder -> NTT) against
+ * the reference's own KAT rows (intermediate_hash_ch_KAT_128.csv, via tests/golden/kat.json),
+ * the reference's golden challenges of tests/golden/scheme_{128,256}.npz,
+ * the host pipeline (fz_challenge_coefficients, itself pinned by CPython's hashlib and the KATs) on 1024+ random keys.
+Reference: fusion/fusion.py:412-419 (hash), :422-481 (decoder), :484-531 (parse_challenge / hash_ch)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _setup(secpar):
+    import fusion.fusion as F
+    import fusion_hip
+    from fusion_hip import hostpipe
+    params = F.fusion_setup(secpar, 7)
+    P = hostpipe.scheme_params(params)
+    ctx = fusion_hip.get_context(params.modulus, params.degree, params.root, params.inv_root)
+    return params, P, ctx
+
+
+def _device_challenges(ctx, P, vk, prehash, transform):
+    import fusion_hip
+    n, d = vk.shape[0], vk.shape[2]
+    dvk = fusion_hip.DeviceBuffer.from_numpy(ctx, np.ascontiguousarray(vk, dtype=np.int32))
+    dout = fusion_hip.DeviceBuffer(ctx, n * d * 4)
+    ctx.challenge_dev(P, dvk.ptr, prehash, n, dout.ptr, transform=transform)
+    out = dout.to_numpy(np.int32, (n, d))
+    dvk.free()
+    dout.free()
+    return out
+
+
+@pytest.mark.parametrize("secpar,n", [(128, 1), (128, 65), (256, 1), (256, 33), (256, 1024), (128, 1500)])
+def test_device_pipeline_equals_host_pipeline(secpar, n, coracle):
+    from fusion_hip import hostpipe
+    params, P, ctx = _setup(secpar)
+    d, q = params.degree, params.modulus
+    rng = np.random.default_rng(secpar + n)
+    vk = rng.integers(-(q // 2), q // 2 + 1, size=(n, 2, d)).astype(np.int32)
+    # every length of decimal text: tiny, zero and extreme values in some keys
+    vk[0, 0, :8] = [0, 1, -1, 9, -10, 99999, -100000, q // 2]
+    vk[-1, 1, -4:] = [-(q // 2), 1000000000, -999999999, 0]
+    msgs = [f"message {i}" * (1 + i % 3) for i in range(n)]
+    coefs, pre = hostpipe.challenge_coefficients(P, vk[:, 0], vk[:, 1], msgs)
+    assert np.array_equal(pre, hostpipe.hash_messages(P, msgs))
+    pre[0] = 0                                               # str(int) of the pre-hash: 1 digit ...
+    if n > 1:
+        pre[1] = 255                                         # ... and the full 78
+    # host pipeline with the edited pre-hashes, through its generic pieces
+    for i in range(min(n, 2)):
+        text = (bytes(P.sign_hash_dst) + b"," + hostpipe.format_vk(P, vk[i, 0], vk[i, 1]).encode() + b"," +
+                str(int.from_bytes(bytes(pre[i]), "little")).encode())
+        nbytes = 8 * 1024 * 2
+        coefs[i] = hostpipe.decode_coefficients(hostpipe.shake256(text, nbytes), P.secpar, q, d, params.beta_ch, params.omega_ch)
+    got = _device_challenges(ctx, P, vk, pre, transform=False)
+    assert np.array_equal(got, coefs), np.argwhere((got != coefs).any(axis=1))[:5]
+    assert (np.abs(got).sum(axis=1) == params.omega_ch).all()
+    hat = _device_challenges(ctx, P, vk, pre, transform=True)
+    assert np.array_equal(hat, coracle.ntt_forward(coefs, q, params.root))
+
+
+def test_reference_kat_rows_hash_ch_128():
+    """the 20 rows of the reference's intermediate_hash_ch_KAT_128.csv (the in-tree KAT that pins hash_ch bit-exactly)"""
+    import fusion.fusion as F
+    import fusion_hip
+    from fusion_hip import hostpipe
+    with open(os.path.join(G, "kat.json")) as fh:
+        rows = json.load(fh)["hash_ch"]
+    params = F.fusion_setup(128, 1)
+    P = hostpipe.scheme_params(params)
+    ctx = fusion_hip.get_context(params.modulus, params.degree, params.root, params.inv_root)
+    vk = np.array([[r["vk_left"], r["vk_right"]] for r in rows], dtype=np.int64).astype(np.int32)
+    pre = hostpipe.hash_messages(P, [r["message"] for r in rows])
+    hat = _device_challenges(ctx, P, vk, pre, transform=True)
+    assert hat.tolist() == [r["c_hat"] for r in rows]
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_golden_scheme_challenges(secpar):
+    """c_hat of the reference's setup -> keygen -> sign flow (tests/golden/scheme_*.npz)"""
+    import fusion.fusion as F
+    import fusion_hip
+    from fusion_hip import hostpipe
+    with open(os.path.join(G, "scheme.json")) as fh:
+        m = json.load(fh)[str(secpar)]
+    S = np.load(os.path.join(G, f"scheme_{secpar}.npz"))
+    params = F.fusion_setup(secpar, m["setup_seed"])
+    P = hostpipe.scheme_params(params)
+    ctx = fusion_hip.get_context(params.modulus, params.degree, params.root, params.inv_root)
+    pre = hostpipe.hash_messages(P, m["messages"])
+    hat = _device_challenges(ctx, P, S["vk"], pre, transform=True)
+    assert np.array_equal(hat, S["c_hat"])

@@ -340,6 +340,7 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     if (ctx->d_vpart) (void)hipFree(ctx->d_vpart);
     if (ctx->d_vstate) (void)hipFree(ctx->d_vstate);
     if (ctx->d_aggacc) (void)hipFree(ctx->d_aggacc);
+    if (ctx->d_chal_tab) (void)hipFree(ctx->d_chal_tab);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     free(ctx->h_tw);
@@ -936,6 +937,15 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
     size_t blocks = max_len / 136 + 1;
     blocks += blocks & 1;                                   // even: rows stay 16-byte aligned
     const size_t text_stride = blocks * 136;
+    if (!ctx->d_chal_tab || ctx->chal_tab_ib != ib || ctx->chal_tab_degree != P->degree) {
+        std::vector<uint32_t> tab((size_t)(P->degree + 1) * 16);
+        fz_challenge_weight_table(ib, P->degree, tab.data());
+        if (ctx->d_chal_tab) { FZ_HIP(hipStreamSynchronize(ctx->stream), "table sync"); FZ_HIP(hipFree(ctx->d_chal_tab), "table free"); ctx->d_chal_tab = nullptr; }
+        FZ_HIP(hipMalloc((void **)&ctx->d_chal_tab, tab.size() * 4), "table alloc");
+        FZ_HIP(hipMemcpy(ctx->d_chal_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice), "table upload");
+        ctx->chal_tab_ib = ib;
+        ctx->chal_tab_degree = P->degree;
+    }
     // signers per pass: 65536 = two waves of 32 signers on each of the chip's 1024 SIMDs (a second wave per SIMD fills the
     // issue slots one wave alone leaves empty); bounds the scratch at ~16 KB per signer
     const size_t chunk = 65536;
@@ -951,7 +961,7 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
         FZ_HIP(hipMemcpyAsync(sp + o_pre, h_prehash + 32 * base, n * 32, hipMemcpyHostToDevice, ctx->stream), "upload of the pre-hashed messages");
         FZ_HIP(hipStreamSynchronize(ctx->stream), "upload sync");      // the caller's buffer has been consumed when this returns
         FZ_TRY(fz_launch_challenge(ctx, P, d_vk + base * 2 * (size_t)P->degree, sp + o_pre, n, sp + o_text, text_stride,
-                                   (int *)(sp + o_nb), (uint32_t *)(sp + o_xof), xstride, out_blocks,
+                                   (int *)(sp + o_nb), (uint32_t *)(sp + o_xof), xstride, out_blocks, ctx->d_chal_tab,
                                    d_out + base * (size_t)P->degree));
     }
     if (transform) return fz_launch_ntt(ctx, d_out, d_out, N, false);

@@ -13,8 +13,8 @@
 //   2. shake_kernel        TWO lanes per signer, one holding the low and one the high 32 bits of every Keccak lane:
 //                          bitwise steps are independent 32-bit operations, a 64-bit rotation is one v_alignbit of
 //                          (own half, partner's half) with the partner's half fetched by a DPP quad swap -- the same
-//                          instruction stream for both lanes.  159 vector operations per round and lane instead of
-//                          260 for a whole state per lane: the chain of ~108 permutations per signer (47 absorbed
+//                          instruction stream for both lanes.  119 vector operations per round and lane instead of
+//                          ~200 for a whole state per lane: the chain of ~108 permutations per signer (47 absorbed
 //                          blocks + 61 squeezed) is the latency of the whole pipeline, and Keccak offers no more
 //                          parallelism inside a permutation without bit-slicing overheads that cancel it.
 //                          Output words leave transposed ([word][signer]) so that every access is coalesced.
@@ -182,25 +182,38 @@ __device__ __forceinline__ uint32_t rotl64_half(uint32_t x, uint32_t px) {
     return __builtin_amdgcn_alignbit(px, x, 64 - R);
 }
 
-#define FZ_ROT(dst, src, R) { const uint32_t t_ = (src); dst = rotl64_half<R>(t_, partner(t_)); }
-// one round A -> E (theta, rho + pi, chi, iota); every index a compile-time constant
+// three-input XOR in ONE instruction (v_bitop3_b32, truth table 0x96; the compiler keeps two v_xor otherwise)
+#define FZ_X3(a, b, c) ((uint32_t)__builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96))
+// five rotated lanes of one output row: the five inputs first, then their five partner fetches, then the five
+// rotations -- a DPP read of a register written by the previous instruction costs two wait states, and the compiler fills
+// them with s_nop (36 per round pair in the first version) unless independent work sits in between
+#define FZ_ROW(A0_, R0, A1_, R1, A2_, R2, A3_, R3, A4_, R4) \
+    { const uint32_t t0 = (A0_), t1 = (A1_), t2 = (A2_), t3 = (A3_), t4 = (A4_); \
+      const uint32_t p0 = partner(t0), p1 = partner(t1), p2 = partner(t2), p3 = partner(t3), p4 = partner(t4); \
+      b0 = rotl64_half<R0>(t0, p0); b1 = rotl64_half<R1>(t1, p1); b2 = rotl64_half<R2>(t2, p2); \
+      b3 = rotl64_half<R3>(t3, p3); b4 = rotl64_half<R4>(t4, p4); }
+// one round A -> E (theta, rho + pi, chi, iota); every index a compile-time constant.  theta's column parities take two
+// 3-input XORs each, and A ^ D = A ^ C[x-1] ^ rot(C[x+1], 1) is one more, so D is never formed: 119 vector operations per
+// round and lane (10 parities, 10 for the five rotated parities, 25 + 48 for rho and pi, 25 chi, 1 iota)
 #define FZ_KROUND32(A, E, rc) { \
-    const uint32_t c0 = A##0 ^ A##5 ^ A##10 ^ A##15 ^ A##20, c1 = A##1 ^ A##6 ^ A##11 ^ A##16 ^ A##21, \
-                   c2 = A##2 ^ A##7 ^ A##12 ^ A##17 ^ A##22, c3 = A##3 ^ A##8 ^ A##13 ^ A##18 ^ A##23, \
-                   c4 = A##4 ^ A##9 ^ A##14 ^ A##19 ^ A##24; \
+    const uint32_t c0 = FZ_X3(FZ_X3(A##0, A##5, A##10), A##15, A##20), c1 = FZ_X3(FZ_X3(A##1, A##6, A##11), A##16, A##21), \
+                   c2 = FZ_X3(FZ_X3(A##2, A##7, A##12), A##17, A##22), c3 = FZ_X3(FZ_X3(A##3, A##8, A##13), A##18, A##23), \
+                   c4 = FZ_X3(FZ_X3(A##4, A##9, A##14), A##19, A##24); \
     uint32_t r0, r1, r2, r3, r4; \
-    FZ_ROT(r1, c1, 1) FZ_ROT(r2, c2, 1) FZ_ROT(r3, c3, 1) FZ_ROT(r4, c4, 1) FZ_ROT(r0, c0, 1) \
-    const uint32_t d0 = c4 ^ r1, d1 = c0 ^ r2, d2 = c1 ^ r3, d3 = c2 ^ r4, d4 = c3 ^ r0; \
+    { const uint32_t q0 = partner(c0), q1 = partner(c1), q2 = partner(c2), q3 = partner(c3), q4 = partner(c4); \
+      r0 = rotl64_half<1>(c0, q0); r1 = rotl64_half<1>(c1, q1); r2 = rotl64_half<1>(c2, q2); r3 = rotl64_half<1>(c3, q3); \
+      r4 = rotl64_half<1>(c4, q4); } \
+    /* d0 = c4 ^ r1, d1 = c0 ^ r2, d2 = c1 ^ r3, d3 = c2 ^ r4, d4 = c3 ^ r0 */ \
     uint32_t b0, b1, b2, b3, b4; \
-    b0 = A##0 ^ d0; FZ_ROT(b1, A##6 ^ d1, 44) FZ_ROT(b2, A##12 ^ d2, 43) FZ_ROT(b3, A##18 ^ d3, 21) FZ_ROT(b4, A##24 ^ d4, 14) \
+    FZ_ROW(FZ_X3(A##0, c4, r1), 0, FZ_X3(A##6, c0, r2), 44, FZ_X3(A##12, c1, r3), 43, FZ_X3(A##18, c2, r4), 21, FZ_X3(A##24, c3, r0), 14) \
     E##0 = b0 ^ (~b1 & b2) ^ (rc); E##1 = b1 ^ (~b2 & b3); E##2 = b2 ^ (~b3 & b4); E##3 = b3 ^ (~b4 & b0); E##4 = b4 ^ (~b0 & b1); \
-    FZ_ROT(b0, A##3 ^ d3, 28) FZ_ROT(b1, A##9 ^ d4, 20) FZ_ROT(b2, A##10 ^ d0, 3) FZ_ROT(b3, A##16 ^ d1, 45) FZ_ROT(b4, A##22 ^ d2, 61) \
+    FZ_ROW(FZ_X3(A##3, c2, r4), 28, FZ_X3(A##9, c3, r0), 20, FZ_X3(A##10, c4, r1), 3, FZ_X3(A##16, c0, r2), 45, FZ_X3(A##22, c1, r3), 61) \
     E##5 = b0 ^ (~b1 & b2); E##6 = b1 ^ (~b2 & b3); E##7 = b2 ^ (~b3 & b4); E##8 = b3 ^ (~b4 & b0); E##9 = b4 ^ (~b0 & b1); \
-    FZ_ROT(b0, A##1 ^ d1, 1) FZ_ROT(b1, A##7 ^ d2, 6) FZ_ROT(b2, A##13 ^ d3, 25) FZ_ROT(b3, A##19 ^ d4, 8) FZ_ROT(b4, A##20 ^ d0, 18) \
+    FZ_ROW(FZ_X3(A##1, c0, r2), 1, FZ_X3(A##7, c1, r3), 6, FZ_X3(A##13, c2, r4), 25, FZ_X3(A##19, c3, r0), 8, FZ_X3(A##20, c4, r1), 18) \
     E##10 = b0 ^ (~b1 & b2); E##11 = b1 ^ (~b2 & b3); E##12 = b2 ^ (~b3 & b4); E##13 = b3 ^ (~b4 & b0); E##14 = b4 ^ (~b0 & b1); \
-    FZ_ROT(b0, A##4 ^ d4, 27) FZ_ROT(b1, A##5 ^ d0, 36) FZ_ROT(b2, A##11 ^ d1, 10) FZ_ROT(b3, A##17 ^ d2, 15) FZ_ROT(b4, A##23 ^ d3, 56) \
+    FZ_ROW(FZ_X3(A##4, c3, r0), 27, FZ_X3(A##5, c4, r1), 36, FZ_X3(A##11, c0, r2), 10, FZ_X3(A##17, c1, r3), 15, FZ_X3(A##23, c2, r4), 56) \
     E##15 = b0 ^ (~b1 & b2); E##16 = b1 ^ (~b2 & b3); E##17 = b2 ^ (~b3 & b4); E##18 = b3 ^ (~b4 & b0); E##19 = b4 ^ (~b0 & b1); \
-    FZ_ROT(b0, A##2 ^ d2, 62) FZ_ROT(b1, A##8 ^ d3, 55) FZ_ROT(b2, A##14 ^ d4, 39) FZ_ROT(b3, A##15 ^ d0, 41) FZ_ROT(b4, A##21 ^ d1, 2) \
+    FZ_ROW(FZ_X3(A##2, c1, r3), 62, FZ_X3(A##8, c2, r4), 55, FZ_X3(A##14, c3, r0), 39, FZ_X3(A##15, c4, r1), 41, FZ_X3(A##21, c0, r2), 2) \
     E##20 = b0 ^ (~b1 & b2); E##21 = b1 ^ (~b2 & b3); E##22 = b2 ^ (~b3 & b4); E##23 = b3 ^ (~b4 & b0); E##24 = b4 ^ (~b0 & b1); }
 
 struct KState {
@@ -212,10 +225,18 @@ __device__ __forceinline__ void keccak_f_half(KState &S, int half) {
              a10 = S.a10, a11 = S.a11, a12 = S.a12, a13 = S.a13, a14 = S.a14, a15 = S.a15, a16 = S.a16, a17 = S.a17,
              a18 = S.a18, a19 = S.a19, a20 = S.a20, a21 = S.a21, a22 = S.a22, a23 = S.a23, a24 = S.a24;
     uint32_t e0, e1, e2, e3, e4, e5, e6, e7, e8, e9, e10, e11, e12, e13, e14, e15, e16, e17, e18, e19, e20, e21, e22, e23, e24;
+    // both halves of a round constant by SCALAR loads (the round index is uniform), the lane's half by a bitwise select (a
+    // per-lane load put a vector-memory wait inside every round pair); the next pair's constants are requested before
+    // this pair's rounds, so their latency is covered
+    const uint32_t hmask = 0u - (uint32_t)half;
+    uint32_t lo0 = kRC[0][0], hi0 = kRC[0][1], lo1 = kRC[1][0], hi1 = kRC[1][1];
 #pragma unroll 1
     for (int r = 0; r < 24; r += 2) {
-        FZ_KROUND32(a, e, kRC[r][half])
-        FZ_KROUND32(e, a, kRC[r + 1][half])
+        const uint32_t rc0 = lo0 ^ ((lo0 ^ hi0) & hmask), rc1 = lo1 ^ ((lo1 ^ hi1) & hmask);
+        const int rn = (r + 2) % 24;
+        lo0 = kRC[rn][0]; hi0 = kRC[rn][1]; lo1 = kRC[rn + 1][0]; hi1 = kRC[rn + 1][1];
+        FZ_KROUND32(a, e, rc0)
+        FZ_KROUND32(e, a, rc1)
     }
     S.a0 = a0; S.a1 = a1; S.a2 = a2; S.a3 = a3; S.a4 = a4; S.a5 = a5; S.a6 = a6; S.a7 = a7; S.a8 = a8; S.a9 = a9;
     S.a10 = a10; S.a11 = a11; S.a12 = a12; S.a13 = a13; S.a14 = a14; S.a15 = a15; S.a16 = a16; S.a17 = a17; S.a18 = a18;
@@ -235,13 +256,22 @@ __global__ __launch_bounds__(64) void shake_kernel(const uint8_t *text, size_t t
     const uint32_t *row = reinterpret_cast<const uint32_t *>(text + s * text_stride) + half;
     const int nb = nblocks[s];
     KState S = {};
+    // the next block's 17 words are requested before this block's permutation: an absorbed block is otherwise one memory
+    // round trip (the rows are 7 KB apart: nothing coalesces) in front of every one of the ~47 permutations
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10, m11, m12, m13, m14, m15, m16;
+#define FZ_LD(i) m##i = row[2 * i];
+    FZ_FOR17(FZ_LD)
+#undef FZ_LD
 #pragma unroll 1
     for (int b = 0; b < max_blocks; ++b) {
         if (b < nb) {                                            // both lanes of a pair agree; pairs of a wave may differ by a block
-            const uint32_t *w = row + b * (kRate / 4);
-#define FZ_ABS(i) S.a##i ^= w[2 * i];
+#define FZ_ABS(i) S.a##i ^= m##i;
             FZ_FOR17(FZ_ABS)
 #undef FZ_ABS
+            const uint32_t *w = row + (b + 1 < nb ? b + 1 : b) * (kRate / 4);
+#define FZ_LD(i) m##i = w[2 * i];
+            FZ_FOR17(FZ_LD)
+#undef FZ_LD
             keccak_f_half(S, half);
         }
     }
@@ -271,8 +301,16 @@ __device__ __forceinline__ uint32_t stream_byte(const uint32_t *x, size_t xstrid
 }
 
 constexpr int kChunkWords = 12;              // 32-bit stream words that can hold one index chunk at any alignment (<= 44 bytes)
+constexpr int kTabStride = 16;               // uint32 per modulus in the weight table: 12 packed weight words, the reciprocal
 
-__global__ __launch_bounds__(64) void decode_kernel(const uint32_t *xof, size_t xstride, size_t N, DecodeShapeDev D, int32_t *coefs) {
+// int.from_bytes(chunk, "big") % m for m <= 256 is a DOT PRODUCT: sum_k byte_k * (256^(ib-1-k) mod m) < 44 * 255^2 < 2^22,
+// reduced once.  The weights of modulus m sit packed four to a word in tab[m] in the chunk's own byte order, so every
+// four stream bytes cost one v_dot4_u32_u8; tab[m][12] = ceil(2^32 / m) gives the exact quotient of the final
+// reduction by one multiply-high (sum * (ceil(2^32/m) * m - 2^32) < 2^22 * 2^8 < 2^32).  The first version carried the
+// remainder through nine dependent fp64 steps per chunk: 185 us per launch of pure latency; this is ~15.
+template <int NW>       // stream words per chunk: ceil((3 + index_bytes) / 4)
+__global__ __launch_bounds__(64) void decode_kernel(const uint32_t *xof, size_t xstride, size_t N, DecodeShapeDev D,
+                                                    const uint32_t *__restrict__ tab, int kmax, int32_t *coefs) {
     extern __shared__ __attribute__((aligned(16))) int32_t out[];              // [degree][64]
     const int lane = threadIdx.x & 63;
     const size_t s_raw = (size_t)blockIdx.x * 64 + lane;
@@ -288,55 +326,52 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t *xof, size_t 
         if (i < d) out[i * 64 + lane] = bit ? 1 : -1;
     }
     // for i = degree-1 down to weight+1: j = int.from_bytes(chunk, "big") % (i + 1); swap(out[i], out[j])   (fusion.py:472-480)
-    // Every stream position is the same for all lanes (scalar registers).  A chunk's words are loaded TOGETHER, one chunk
-    // ahead of the arithmetic: loaded where they are used, each 4-byte step waited for its own L2 round trip and the
-    // kernel took 0.58 ms for what is 0.05 ms of arithmetic.
-    const int ib = D.index_bytes, head = ib & 3, groups = ib >> 2;
+    // Every stream position is the same for all lanes (scalar registers); a chunk's words are loaded together, two
+    // chunks ahead of their use.
+    const int ib = D.index_bytes;
     int pos = D.sign_bytes + D.coef_bytes * D.weight;
-    uint32_t wn[kChunkWords];
-    auto fetch = [&](int p) {                                    // words covering stream bytes [p, p + ib)
-        const int k0 = p >> 2, cnt = ((p + ib - 1) >> 2) - k0 + 1;
+    // UNCONDITIONAL loads (word indices clamped to the stream's last word, kmax): a load behind a branch, even a uniform
+    // one, makes the compiler wait for every outstanding load at the join, and the prefetch is gone
+    uint32_t wn[NW], wn2[NW];                                    // the next chunk's words and the one after
+    auto fetch = [&](uint32_t (&dst)[NW], int p) {              // words covering stream bytes [p, p + ib)
+        const int k0 = p >> 2;
 #pragma unroll
-        for (int t = 0; t < kChunkWords; ++t) wn[t] = (t < cnt) ? x[(size_t)(k0 + t) * xstride] : 0u;
+        for (int t = 0; t < NW; ++t) {
+            const int k = k0 + t < kmax ? k0 + t : kmax;
+            dst[t] = x[(size_t)k * xstride];
+        }
     };
-    if (D.weight < d - 1) fetch(pos);
+    fetch(wn, pos);
+    fetch(wn2, pos + ib);
+    // the weights of modulus i + 1 (13 uniform words: scalar loads) are requested one iteration early as well
+    uint32_t tc[13];
+#pragma unroll
+    for (int g = 0; g < 13; ++g) tc[g] = tab[(size_t)d * kTabStride + g];
     for (int i = d - 1; i > D.weight; --i) {
-        uint32_t w[kChunkWords + 1];
+        uint32_t w[NW + 1];
 #pragma unroll
-        for (int t = 0; t < kChunkWords; ++t) w[t] = wn[t];
-        w[kChunkWords] = 0u;
+        for (int t = 0; t < NW; ++t) { w[t] = wn[t]; wn[t] = wn2[t]; }
+        w[NW] = 0u;
         const int sh = pos & 3;
-        if (i - 1 > D.weight) fetch(pos + ib);                   // next chunk in flight during this one's arithmetic
-        const double mdl = (double)(i + 1), inv = 1.0 / mdl;
-        // head bytes (ib mod 4 of them), big-endian
-        const uint32_t u0 = sh ? __builtin_amdgcn_alignbyte(w[1], w[0], sh) : w[0];
-        double r = head ? (double)(__builtin_bswap32(u0) >> (8 * (4 - head))) : 0.0;          // < 2^24
-        r = r - mdl * __builtin_floor(r * inv);
-        if (r < 0.0) r += mdl;
-        if (r >= mdl) r -= mdl;
-        // the 4-byte groups start at stream offset pos + head: word offset base2 (0 or 1) into w, byte shift sh2
-        const int sh2 = (sh + head) & 3;
-        if ((sh + head) >> 2) {
+        fetch(wn2, pos + 2 * ib);
+        uint32_t tn[13];
 #pragma unroll
-            for (int t = 0; t < kChunkWords; ++t) w[t] = w[t + 1];
-        }
+        for (int g = 0; g < 13; ++g) tn[g] = tab[(size_t)i * kTabStride + g];      // modulus i: the next iteration's
+        uint32_t sum = 0;
 #pragma unroll
-        for (int g = 0; g < kChunkWords - 1; ++g) {
-            if (g < groups) {                                    // scalar condition
-                const uint32_t le = sh2 ? __builtin_amdgcn_alignbyte(w[g + 1], w[g], sh2) : w[g];
-                double t = __builtin_fma(r, 4294967296.0, (double)__builtin_bswap32(le));      // r < 2^8: exact below 2^41
-                const double qn = __builtin_floor(t * inv);
-                t = __builtin_fma(-qn, mdl, t);
-                if (t < 0.0) t += mdl;                           // the quotient estimate may be off by one
-                if (t >= mdl) t -= mdl;
-                r = t;
-            }
+        for (int g = 0; g < NW; ++g) {
+            // chunk bytes 4g .. 4g+3 in stream order (bytes past the chunk meet zero weights)
+            const uint32_t u = __builtin_amdgcn_alignbyte(w[g + 1], w[g], sh);
+            sum = __builtin_amdgcn_udot4(u, tc[g], sum, false);
         }
+        const uint32_t m = (uint32_t)(i + 1);
+        const uint32_t j = sum - __umulhi(sum, tc[12]) * m;      // sum mod m, exact
         pos += ib;
-        const int j = (int)r;
         const int vi = out[i * 64 + lane], vj = out[j * 64 + lane];
         out[i * 64 + lane] = vj;
         out[j * 64 + lane] = vi;
+#pragma unroll
+        for (int g = 0; g < 13; ++g) tc[g] = tn[g];
     }
     if (live) {
         int32_t *dst = coefs + s_raw * (size_t)d;
@@ -356,7 +391,7 @@ size_t fz_host_challenge_needed_bytes(const fz_scheme_params *P, int *sign_bytes
 // integers, little-endian), d_text / d_nblocks / d_xof scratch; d_coefs [N][degree] out
 int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *d_pre, size_t N,
                         uint8_t *d_text, size_t text_stride, int *d_nblocks, uint32_t *d_xof, size_t xstride, int out_blocks,
-                        int32_t *d_coefs) {
+                        const uint32_t *d_tab, int32_t *d_coefs) {
     VkTextParts T;
     fz_host_vk_text_parts(P, T.s0, &T.n0, T.s1, &T.n1, T.s2, &T.n2, 384);
     if (T.n0 < 0) return fz_set_error(FZ_E_UNSUPPORTED, "verification-key text pieces do not fit");
@@ -381,6 +416,28 @@ int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d
     D.weight = P->omega_ch;
     (void)fz_host_challenge_needed_bytes(P, &D.sign_bytes, &D.coef_bytes, &D.index_bytes);
     if (D.index_bytes > 4 * (kChunkWords - 1)) return fz_set_error(FZ_E_UNSUPPORTED, "index chunks of %d bytes", D.index_bytes);
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), (size_t)d * 64 * 4, ctx->stream, d_xof, xstride, N, D, d_coefs);
+    const int nw = (3 + D.index_bytes + 3) / 4, kmax = out_blocks * 34 - 1;
+    const dim3 dgrid((unsigned)((N + 63) / 64));
+    const size_t dlds = (size_t)d * 64 * 4;
+    if (nw <= 5) hipLaunchKernelGGL(decode_kernel<5>, dgrid, dim3(64), dlds, ctx->stream, d_xof, xstride, N, D, d_tab, kmax, d_coefs);
+    else if (nw <= 9) hipLaunchKernelGGL(decode_kernel<9>, dgrid, dim3(64), dlds, ctx->stream, d_xof, xstride, N, D, d_tab, kmax, d_coefs);
+    else hipLaunchKernelGGL(decode_kernel<12>, dgrid, dim3(64), dlds, ctx->stream, d_xof, xstride, N, D, d_tab, kmax, d_coefs);
     return fz_check_hip(hipGetLastError(), "decode launch");
+}
+
+// the decoder's weight table for (index_bytes, degree): tab[m][g] (g < 12) packs 256^(ib-1-(4g+t)) mod m for t = 0..3 (zero
+// past the chunk), tab[m][12] = ceil(2^32 / m); m = 1 .. degree.  Host array of (degree + 1) * 16 words.
+void fz_challenge_weight_table(int index_bytes, int degree, uint32_t *h_tab) {
+    for (int m = 0; m <= degree; ++m) {
+        uint32_t *T = h_tab + (size_t)m * kTabStride;
+        for (int g = 0; g < kTabStride; ++g) T[g] = 0;
+        if (m == 0) continue;
+        uint32_t pw = 1u % (uint32_t)m;                          // 256^0 mod m, then upwards from the chunk's LAST byte
+        for (int k = index_bytes - 1; k >= 0; --k) {
+            T[k >> 2] |= pw << (8 * (k & 3));
+            pw = (pw * 256u) % (uint32_t)m;
+        }
+        T[12] = (uint32_t)((0x100000000ull + (unsigned)m - 1) / (unsigned)m);      // ceil(2^32 / m); m = 1: 0 (2^32 wraps) ...
+        if (m == 1) T[12] = 0xffffffffu;                         // ... any sum mod 1 = 0: with q = sum - 1 the weights are all 0 anyway
+    }
 }

@@ -62,6 +62,8 @@ struct fz_ctx {
     size_t aggacc_tiles;
     int agg_dirty;
     int grid_multi;              // resident grid of the multi-job transform kernel (0 = not queried yet)
+    uint32_t *d_chal_tab;        // weight table of the challenge decoder (fz_challenge.hip), built on first use
+    int chal_tab_ib, chal_tab_degree;
     // benchmarking knobs, read ONCE at context creation
     int knob_agg_twopass, knob_agg_waves, knob_agg_slices;
     int knob_verify_blocks, knob_verify_unfused, knob_verify_ordered, knob_keygen_unfused, knob_polymul_unfused;
@@ -102,7 +104,8 @@ int fz_launch_diag(fz_ctx *ctx, int what, const void *src, void *dst, size_t byt
 struct fz_scheme_params;
 int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *d_pre, size_t N,
                         uint8_t *d_text, size_t text_stride, int *d_nblocks, uint32_t *d_xof, size_t xstride, int out_blocks,
-                        int32_t *d_coefs);
+                        const uint32_t *d_tab, int32_t *d_coefs);
+void fz_challenge_weight_table(int index_bytes, int degree, uint32_t *h_tab);      // (degree + 1) * 16 words
 void fz_host_vk_text_parts(const fz_scheme_params *P, char *s0, int *n0, char *s1, int *n1, char *s2, int *n2, int cap);
 size_t fz_host_challenge_needed_bytes(const fz_scheme_params *P, int *sign_bytes, int *coef_bytes, int *index_bytes);
 bool fz_host_params_ok(const fz_scheme_params *P);

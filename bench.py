@@ -167,7 +167,10 @@ def self_launch(args):
         sys.exit(1)
     if time.time() > deadline:
         sys.exit("bench.py: ranks did not finish in time")
-    sys.stdout.write(line)
+    result = [ln for ln in line.splitlines() if ln.startswith('{"metric"')]      # a backend may chat on stdout (gloo does)
+    if not result:
+        sys.exit("bench.py: rank 0 printed no result line")
+    sys.stdout.write(result[-1] + "\n")
     sys.stdout.flush()
 
 
@@ -285,12 +288,17 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # The K steps are recorded once (fz_graph_*; chunks of <= 1000 steps) and the recording is replayed R times inside
-    # the timed region, R from an untimed calibration replay so that the region lasts >= MIN_REGION_MS on every rank.
-    chunk = min(args.steps, 1000)
+    # The K steps are recorded once (fz_graph_*; graphs of <= 1000 steps) and replayed R times inside the timed region, R
+    # from an untimed calibration so that the region lasts >= MIN_REGION_MS on every rank.  A replay costs the host and the
+    # command processor ~10 us whatever it holds, so for K < 1000 one recording holds M = 1000 // K repetitions of the K
+    # steps (R counts every repetition): --steps 20 and --steps 1000 then replay the same 1000-step recordings and agree.
+    K = args.steps
+    M = max(1, 1000 // K) if K < 1000 else 1
+    chunk = min(K, 1000)
     graphs = []
     if not args.no_graph:
-        for n_steps in ([chunk] * (args.steps // chunk)) + ([args.steps % chunk] if args.steps % chunk else []):
+        sizes = [K * M] if K < 1000 else ([chunk] * (K // chunk)) + ([K % chunk] if K % chunk else [])
+        for n_steps in sizes:
             if graphs and graphs[0][0] == n_steps:
                 graphs.append(graphs[0])                 # the same recording, launched again
                 continue
@@ -303,8 +311,11 @@ def main():
             g.launch()                                   # untimed first replay (upload)
             graphs.append((n_steps, g))
         barrier()
+    else:
+        M = 1
 
     def k_steps():
+        """M repetitions of the K steps"""
         if graphs:
             for _, g in graphs:
                 g.launch()
@@ -319,12 +330,13 @@ def main():
     k_steps()
     torch.cuda.synchronize(dev)
     t_once = max(time.perf_counter() - t0, 1e-6)
-    repeats = int(max_over_ranks(max(1.0, -(-MIN_REGION_MS * 1e-3 // t_once))))      # the same R on every rank
+    launches = int(max_over_ranks(max(1.0, -(-MIN_REGION_MS * 1e-3 // t_once))))     # the same count on every rank
+    repeats = launches * M
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
     ev0.record(stream)
-    for _ in range(repeats):
+    for _ in range(launches):
         k_steps()
     ev1.record(stream)
     barrier()
@@ -789,7 +801,7 @@ def main():
             "config": {"workload": f"configs[1]: secpar={SECPAR}, batch of {B} degree-{d} forward+inverse NTTs per GPU",
                        "batch": B, "degree": d, "modulus": q, "kernels_per_step": 2,
                        "arithmetic": "exact integers carried in fp64 lanes (results bit-identical to the reference's int arithmetic); int32 in and out",
-                       "launch": "one by one" if args.no_graph else f"hipGraph of {args.steps} steps (fz_graph_*), replayed {repeats} times in the timed region",
+                       "launch": "one by one" if args.no_graph else f"hipGraphs (fz_graph_*) holding {M} x {args.steps} steps, {launches} replays in the timed region = {repeats} repetitions of the {args.steps} steps",
                        "prewarm_ms": args.prewarm_ms},
             "ranks": ranks,
             "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8> (forward NTT, B=4096)", "achieved": ach,

@@ -10,6 +10,11 @@ from collections import defaultdict
 
 root, tag = sys.argv[1], sys.argv[2]
 GROUPS = {"pmcb": ("B=4096 (bench launch)", 4096), "pmc20": ("B=2^20", 1 << 20)}
+# scheme kernels (tools/prof_scheme.py, secpar 256: l = 83, d = 256): algorithmic bytes per launch from SURVEY.md 8d
+L_, D_ = 83, 256
+SCHEME_BYTES = {"keygen_fused": 1024 * (4 * L_ + 2) * 4 * D_, "sign_kernel": 1024 * (3 * L_ + 1) * 4 * D_,
+                "matvec_kernel": 2048 * (L_ + 1) * 4 * D_, "pw_kernel": 1024 * L_ * D_ * 12,
+                "verify_fused": 64 * (L_ + 2) * 4 * D_ + L_ * 4 * D_}
 out = {"source": "rocprofv3 --pmc <one set per pass> --output-format csv (tools/collect_profiles.sh, tools/pmc_summary.py); "
                  "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane coalesced reads on gfx950; KB -> bytes x1024",
        "kernels": {}}
@@ -53,3 +58,47 @@ for sub, (label, rows) in GROUPS.items():
 with open(os.path.join(root, f"{tag}_pmc_ntt.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))
+
+# ---- scheme kernels ----------------------------------------------------------------------------------------------
+sch = {"source": out["source"] + "; launches of tools/prof_scheme.py (cold operand sets)", "kernels": {}}
+per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
+dur, grid = defaultdict(dict), {}
+for path in glob.glob(os.path.join(root, "pmcs", "*", "*", "*_counter_collection.csv")):
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+            if k.startswith("aggregate_onepass"):
+                # N = 1024 and N = 256 launches differ in their grid
+                k += f" grid={r['Grid_Size']}" if "Grid_Size" in r else ""
+            per[k][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+            dur[k][int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+for k, counters in per.items():
+    if k.startswith(("fill_synthetic", "ntt_")):
+        continue
+    e = {}
+    for c, by_dispatch in counters.items():
+        ids = sorted(by_dispatch)
+        ids = ids[2:] if len(ids) > 4 else ids
+        e[c] = sum(by_dispatch[i] for i in ids) / len(ids)
+        e.setdefault("dispatches_averaged", len(ids))
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        e["read_bytes_corrected"] = e["FETCH_SIZE"] * 1024 * 2
+        e["write_bytes"] = e["WRITE_SIZE"] * 1024
+        e["traffic_bytes_per_launch"] = e["read_bytes_corrected"] + e["write_bytes"]
+        alg = next((v for n, v in SCHEME_BYTES.items() if k.startswith(n)), None)
+        if k.startswith("aggregate_onepass"):
+            # the larger grid is the N = 1024 launch
+            grids = sorted({kk for kk in per if kk.startswith("aggregate_onepass")}, key=lambda kk: int(kk.split("grid=")[1]) if "grid=" in kk else 0)
+            n_sign = 1024 if k == grids[-1] else 256
+            alg = n_sign * (L_ + 1) * 4 * D_ + L_ * 4 * D_
+            e["signers"] = n_sign
+        if alg:
+            e["algorithmic_bytes_per_launch"] = alg
+            e["traffic_over_algorithmic"] = e["traffic_bytes_per_launch"] / alg
+    ds = sorted(dur[k])
+    ds = ds[2:] if len(ds) > 4 else ds
+    e["serialised_duration_us_under_pmc"] = sum(dur[k][i] for i in ds) / len(ds)
+    sch["kernels"][k] = e
+if sch["kernels"]:
+    with open(os.path.join(root, f"{tag}_pmc_scheme.json"), "w") as fh:
+        json.dump(sch, fh, indent=1)

@@ -1,0 +1,45 @@
+"""Minimal launcher for PMC / kernel-trace passes over the scheme kernels on COLD operands (one launch per operand set,
+sets carved out of a 2.25 GiB pool).  usage: prof_scheme.py [reps]     (secpar 256; N = 1024 signers / keys / signatures)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "fusion-cryptography_amd"), ROOT):
+    sys.path.insert(0, p)
+import fusion_hip
+from oracle import oracle as O
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+P = O.PARAMS[256]
+q, d, l = P["q"], P["d"], P["rank"]
+row = d * 4
+ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+POOL = 9 << 28
+pin, pout = fusion_hip.DeviceBuffer(ctx, POOL), fusion_hip.DeviceBuffer(ctx, POOL)
+A = fusion_hip.DeviceBuffer(ctx, l * row)
+ctx.fill_synthetic_dev(pin.ptr, POOL // 4, 21)
+ctx.fill_synthetic_dev(pout.ptr, POOL // 4, 22)
+ctx.fill_synthetic_dev(A.ptr, l * d, 23)
+S = 1024
+kb = S * 2 * l * row
+
+
+def sets(step):
+    step = (step + 4095) & ~4095
+    n = POOL // step
+    return [pin.ptr + k * step for k in range(n)], [pout.ptr + (k % max(1, POOL // step)) * step for k in range(n)]
+
+
+for name, in_bytes, fn in (
+        ("keygen", kb, lambda i, o: ctx.keygen_core_dev(A.ptr, i, o, o + kb, S, l)),
+        ("sign", kb + S * row, lambda i, o: ctx.sign_core_dev(i, i + kb, o, S, l)),
+        ("aggregate1024", S * (l + 1) * row, lambda i, o: ctx.aggregate_core_dev(i, i + S * l * row, o, S, l)),
+        ("aggregate256", 256 * (l + 1) * row, lambda i, o: ctx.aggregate_core_dev(i, i + 256 * l * row, o, 256, l)),
+        ("matvec", 2 * S * l * row, lambda i, o: ctx.matvec_dev(A.ptr, i, o, 2 * S, l)),
+        ("pw_mul", 2 * S * l * row, lambda i, o: ctx.pw_dev(fusion_hip.OP_MUL, i, i + S * l * row, o, S * l * d)),
+        ("verify64", 64 * (l + 1) * row, lambda i, o: ctx.verify_with_target_batch_async_dev(A.ptr, i, i + 64 * l * row, 64, l, P["beta_vf"], d, o))):
+    ins, outs = sets(max(in_bytes, kb + S * 2 * row))
+    for k in range(reps):
+        fn(ins[k % len(ins)], outs[k % len(outs)])
+    ctx.synchronize()
+print("done", reps)

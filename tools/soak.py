@@ -24,19 +24,26 @@ def bump(name):
     counts[name] = counts.get(name, 0) + 1
 
 
-def make_ctx(secpar, kernel):
+def make_ctx(secpar, kernel, env=None):
+    """knobs are read once, at context creation: every variant is a context of its own"""
+    env = dict(env or {})
     if kernel:
-        os.environ["FZ_NTT_KERNEL"] = kernel
-    else:
-        os.environ.pop("FZ_NTT_KERNEL", None)
+        env["FZ_NTT_KERNEL"] = kernel
+    for k_, v_ in env.items():
+        os.environ[k_] = v_
     P = O.PARAMS[secpar]
     c = fusion_hip.Context(q, P["d"], P["root"], P["inv_root"])
+    for k_ in env:
+        os.environ.pop(k_, None)
     c.set_stream(c.stream_create())
     return c
 
 
 ctxs = {(sp, k): make_ctx(sp, k) for sp in (128, 256) for k in ("", "4", "16")}
-os.environ.pop("FZ_NTT_KERNEL", None)
+# the multi-launch forms of the fused kernels and other launch shapes of the one-pass aggregation
+VARIANTS = [{}, {"FZ_KEYGEN_UNFUSED": "1", "FZ_VERIFY_UNFUSED": "1", "FZ_POLYMUL_UNFUSED": "1"}, {"FZ_AGG_TWOPASS": "1"},
+            {"FZ_AGG_WAVES": "4", "FZ_AGG_SLICES": "3"}, {"FZ_AGG_SLICES": "7", "FZ_VERIFY_ORDERED": "1"}, {"FZ_STREAM_PER_CU": "8"}]
+vctx = {(sp, i): make_ctx(sp, "", v) for sp in (128, 256) for i, v in enumerate(VARIANTS)}
 DB = fusion_hip.DeviceBuffer
 t_end = time.time() + budget
 t_print = time.time() + 60
@@ -50,7 +57,7 @@ while time.time() < t_end:
     ctx = ctxs[(sp, kern)]
     other = ctxs[(sp, str(rng.choice(["", "4", "16"])))]
     rows = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 257, 1000, 4099, int(rng.integers(1, 20000))]))
-    what = rng.choice(["ntt", "polymul", "scheme", "graph", "pointwise", "small", "batch_api"])
+    what = rng.choice(["ntt", "polymul", "scheme", "graph", "pointwise", "small", "batch_api", "multi", "challenge"])
     raw = rng.random() < 0.3
     x = (rng.integers(-2**31, 2**31, size=(rows, d), dtype=np.int64).astype(np.int32) if raw
          else O.splitmix_centered(int(rng.integers(1, 2**40)), rows * d).reshape(rows, d))
@@ -69,6 +76,49 @@ while time.time() < t_end:
         for b in (dx, dy, dz, ex, ey):
             b.free()
         bump("ntt")
+    elif what == "multi":
+        # one dispatch over a random list of forward / inverse jobs (some in place, some empty)
+        nj = int(rng.integers(1, 45))
+        jobs, want, keep = [], [], []
+        for j in range(nj):
+            r = int(rng.choice([0, 1, 2, 7, 64, 65, int(rng.integers(1, 1500))]))
+            inv_j = bool(rng.random() < 0.5)
+            xx = rng.integers(-2**31, 2**31, size=(max(r, 1), d), dtype=np.int64).astype(np.int32)[:r]
+            a = DB.from_numpy(ctx, xx) if r else DB(ctx, 16)
+            b = a if rng.random() < 0.3 else DB(ctx, max(16, r * d * 4))
+            keep += [a, b]
+            jobs.append((a.ptr, b.ptr, r, inv_j))
+            want.append((orc.ntt_inverse(xx, q, inv) if inv_j else orc.ntt_forward(xx, q, root)).reshape(r, d) if r else None)
+        ctx.ntt_multi_dev(jobs)
+        ctx.synchronize()
+        for (a, b, r, inv_j), w_ in zip(jobs, want):
+            if r:
+                got = np.empty((r, d), np.int32)
+                ctx.d2h(got, b)
+                assert np.array_equal(got, w_), ("multi", sp, r, inv_j)
+        for b in keep:
+            b.free()
+        bump("multi")
+    elif what == "challenge":
+        # device challenge pipeline (text of str(vk), SHAKE-256, decoder, NTT) == host pipeline + oracle NTT
+        import fusion.fusion as F
+        from fusion_hip import hostpipe
+        if "hp_params" not in globals():
+            globals()["hp_params"] = {s_: F.fusion_setup(s_, 11 + s_) for s_ in (128, 256)}
+        prm = globals()["hp_params"][sp]
+        HP = hostpipe.scheme_params(prm)
+        nn = int(rng.choice([1, 2, 31, 32, 33, 64, 65, int(rng.integers(1, 400))]))
+        vk = rng.integers(-(q // 2), q // 2 + 1, size=(nn, 2, d)).astype(np.int32)
+        if rng.random() < 0.3:
+            vk[rng.random(size=vk.shape) < 0.3] = 0                         # short decimal texts
+        msgs = [f"soak {it} {i} " + "x" * int(rng.integers(0, 200)) for i in range(nn)]
+        coefs, pre = hostpipe.challenge_coefficients(HP, vk[:, 0], vk[:, 1], msgs)
+        dv, dc = DB.from_numpy(ctx, vk), DB(ctx, nn * d * 4)
+        ctx.challenge_dev(HP, dv.ptr, pre, nn, dc.ptr, transform=True)
+        assert np.array_equal(dc.to_numpy(np.int32, (nn, d)), orc.ntt_forward(coefs, q, root).reshape(nn, d)), ("challenge", sp, nn)
+        dv.free()
+        dc.free()
+        bump("challenge")
     elif what == "polymul":
         g = O.splitmix_centered(int(rng.integers(1, 2**40)), rows * d).reshape(rows, d)
         want = orc.ntt_inverse(orc.pw_mul(orc.ntt_forward(x, q, root), orc.ntt_forward(g, q, root), q), q, inv).reshape(rows, d)
@@ -153,13 +203,9 @@ while time.time() < t_end:
         assert bs.verify(vk_b, msgs, agg_b) == F.verify(prm, [k_[1] for k_ in keys], msgs, agg) == (True, ""), ("batch verify", sp)
         bump("batch_api")
     else:
-        for knob in ("FZ_KEYGEN_UNFUSED", "FZ_VERIFY_UNFUSED", "FZ_POLYMUL_UNFUSED"):      # both paths of every fused kernel
-            if rng.random() < 0.3:
-                os.environ[knob] = "1"
-            else:
-                os.environ.pop(knob, None)
+        ctx = vctx[(sp, int(rng.integers(0, len(VARIANTS))))]          # fused / multi-launch forms, aggregation launch shapes
         l = int(rng.choice([1, 2, 7, P["rank"]]))
-        n = int(rng.integers(1, 40))
+        n = int(rng.integers(1, 40)) if rng.random() < 0.8 else int(rng.integers(40, 700 if l < 20 else 160))
         G = int(rng.integers(1, 4))
         A = O.splitmix_centered(int(rng.integers(1, 2**40)), l * d).reshape(l, d)
         coef = rng.integers(-52, 53, size=(G * n, 2, l, d)).astype(np.int32)

@@ -25,7 +25,7 @@ for sub, (label, rows) in GROUPS.items():
         with open(path) as fh:
             for r in csv.DictReader(fh):
                 k = r["Kernel_Name"]
-                if "ntt_" not in k:
+                if "ntt_" not in k or "ntt_multi" in k:      # the multi-job launches of a bench run have varying job counts
                     continue
                 short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
                 per[short][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])

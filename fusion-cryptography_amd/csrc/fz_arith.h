@@ -90,8 +90,9 @@ FZ_HD double fz_cent_wide(double x, const FzMod m) {
     return fz_cent(r, m);
 }
 
-// x - q * rint(x / q) for any integer-valued |x| < 2^80: NOT canonical (|r| <= q/2 * (1 + 2^-20)), but exact --
-// the FMA's true result is an integer below 2^32, hence representable.  Folds lazily accumulated sums.
+// x - q * rint(x / q) for any integer-valued |x| < 2^80: NOT canonical (|r| <= q/2 + |x| * 2^-51: the quotient estimate is
+// off by at most |x| / q * 2^-51; below 2^67, as in the aggregation kernel, that is q/2 + 2^16), but
+// exact -- the FMA's true result is an integer below 2^33, hence representable.  Folds lazily accumulated sums.
 FZ_HD double fz_fold(double x, const FzMod m) {
     return __builtin_fma(-__builtin_rint(x * m.qinv), m.q, x);
 }

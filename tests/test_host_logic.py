@@ -336,3 +336,20 @@ def test_seeded_matrices_are_replicated_without_changing_observable_state():
     random.seed(1)
     u = F.sample_coefficient_matrix(seed=None, **p, num_rows=3, num_cols=1, norm_bound=9, weight_bound=20)
     assert len({tuple(r[0].coefficients) for r in u.matrix}) == 3      # unseeded: independent draws
+
+
+def test_bench_starts_its_own_ranks_and_fails_loudly_without_gpus():
+    """`bench.py --gpus 2` without a launcher spawns its ranks itself (before touching a GPU) and exits non-zero -- without
+    hanging and without a result line -- when a rank cannot run (here: no GPU in the CPU container)."""
+    import subprocess
+    import sys as _sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert '{"metric"' not in r.stdout
+    assert "rank" in r.stderr and "no result" in r.stderr

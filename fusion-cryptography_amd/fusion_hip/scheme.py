@@ -32,9 +32,11 @@ class BatchScheme:
             return a, False
         return DeviceArray.from_numpy(self.ctx, np.ascontiguousarray(a, dtype=np.int32).reshape(shape)), True
 
-    def keygen_batch(self, seeds, device=False):
+    def keygen_batch(self, seeds, device=False, keep_vk=False):
         """-> (sk_hat [N][2][l][d], vk [N][2][d]); key i equals keygen(params, seeds[i]).  With device=True
-        sk_hat stays in device memory (a DeviceArray) -- vk always comes back (it is hashed on the host).
+        sk_hat stays in device memory (a DeviceArray) -- vk always comes back (hash_ag hashes it on the host); with
+        keep_vk=True a third value is returned, the verification keys as a DeviceArray [N][2][d] (what sign_batch's
+        device challenge pipeline reads: pass it as `vk` and the keys are not uploaded again).
         Sampling: the reference draws every entry of a secret matrix with the SAME seed (fusion.py:156-173),
         so a matrix is one polynomial repeated l times; the polynomial itself comes from the C clone of
         CPython's MT19937 `random` (hostpipe.sample_secret_polys, pinned against `random` in the tests).
@@ -52,14 +54,18 @@ class BatchScheme:
         try:
             self.ctx.keygen_core_bcast_dev(dA.ptr, coef.ptr, sk.ptr, vk.ptr, n, self.l)
             vk_host = vk.numpy()
-            if device:
-                return sk, vk_host
-            out = sk.numpy()
-            sk.free()
-            return out, vk_host
+            res_sk = sk
+            if not device:
+                res_sk = sk.numpy()
+                sk.free()
+            if keep_vk:
+                keep, vk = vk, None
+                return res_sk, vk_host, keep
+            return res_sk, vk_host
         finally:
             for b in (coef, dA, vk):
-                b.free()
+                if b is not None:
+                    b.free()
 
     # ---- sign --------------------------------------------------------------------------------------
     def challenges_dev(self, vk, messages):

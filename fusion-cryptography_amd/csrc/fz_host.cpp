@@ -460,8 +460,9 @@ int fz_decode_coefficients(const uint8_t *h_bytes, size_t len, int log2_bias, in
 int fz_hash_messages(const fz_scheme_params *P, const char *h_msgs, const size_t *h_msg_off, size_t N,
                      uint8_t *h_prehash) {
     if (!params_ok(P) || !h_msg_off || !h_prehash || (N && !h_msgs)) return fz_set_error(FZ_E_BADARG, "bad argument");
-    // independent messages: spread over host threads once there are enough of them to pay for the threads
-    const int threads = N >= 256 ? (int)std::min<size_t>(std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency())), N / 64) : 1;
+    // independent messages: spread over host threads once there are enough of them to pay for starting the threads
+    // (0.3 us per message on one core; 16 threads cost more than 1024 messages do)
+    const int threads = N >= 8192 ? (int)std::min<size_t>(std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency())), N / 2048) : 1;
     parallel_for(N, threads, [&](size_t i) { prehash(*P, h_msgs + h_msg_off[i], h_msg_off[i + 1] - h_msg_off[i], h_prehash + 32 * i); });
     return FZ_OK;
 }

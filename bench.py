@@ -349,7 +349,7 @@ def main():
     # Per-dispatch durations (kernel begin -> end, events bound to the dispatch on its own stream) cannot be taken
     # inside a graph: an instrumented pass of the same steps, launched one by one right after the timed region,
     # samples every k-th dispatch.  This is the figure rocprofv3's per-kernel average corresponds to.
-    n_inst = max(args.sample_every, min(args.steps, 400))
+    n_inst = 400                                        # whatever --steps is: 50 samples per kernel at the default --sample-every
     ctx.profile_begin(2 * n_inst, args.sample_every)
     rc = 0
     for _ in range(n_inst):

@@ -92,3 +92,31 @@ def test_device_resident_path_equals_host_path():
     assert bs.verify(vk_h, msgs, agg_d) == (True, "")
     sk_d.free()
     sig_d.free()
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_device_and_host_challenge_pipelines_give_the_same_signatures(secpar):
+    """sign_batch with the challenge pipeline on the device (keys device-resident: keep_vk) == with the host pipeline"""
+    import fusion.fusion as F
+    import fusion_hip
+    from fusion_hip.scheme import BatchScheme
+    params = F.fusion_setup(secpar, 21)
+    bs = BatchScheme(params, threads=4)
+    n = 70
+    seeds = [7000 + 5 * i for i in range(n)]
+    msgs = [f"message number {i}" + "!" * (i % 9) for i in range(n)]
+    sk_d, vk_h, vk_d = bs.keygen_batch(seeds, device=True, keep_vk=True)
+    assert isinstance(vk_d, fusion_hip.DeviceArray) and np.array_equal(vk_d.numpy(), vk_h)
+    assert bs.device_hash
+    sig_dev = bs.sign_batch(sk_d, vk_d, msgs)                 # keys never leave the device
+    assert bs.device_hash                                      # ... and the device pipeline was really used
+    c_dev, _ = bs.challenges(vk_h, msgs)
+    bs.device_hash = False
+    sig_host = bs.sign_batch(sk_d, vk_h, msgs)
+    c_host, _ = bs.challenges(vk_h, msgs)
+    assert np.array_equal(c_dev, c_host) and np.array_equal(sig_dev, sig_host)
+    bs.device_hash = True
+    agg = bs.aggregate(vk_h, msgs, sig_dev)
+    assert bs.verify(vk_h, msgs, agg) == (True, "")
+    sk_d.free()
+    vk_d.free()

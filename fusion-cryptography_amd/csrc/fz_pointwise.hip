@@ -222,10 +222,16 @@ constexpr int kAggDepth = 3;      // signers in flight per wave
 constexpr int kAggFold = 16;      // signers between folds: 16 * 2^31 * 2^16 = 2^51 < 2^53
 constexpr int kAggTile = 64 * kAggR * 4;   // coefficients per workgroup (1024)
 
+struct AggDiv {                   // host-side arithmetic of the tile mapping (see the kernel)
+    unsigned m_ncb, m_nsl;        // ceil(2^32 / ncb), ceil(2^32 / nsl): __umulhi(x, m) == x / d exactly for x * d < 2^32
+    unsigned per_xcd;             // ceil(tiles / 8)
+    unsigned base, extra;         // N / nsl, N % nsl
+};
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
                                                                 const int32_t *vkR, const int32_t *c, size_t N, int l, int d4,
-                                                                int ncb_a, int ncb, int nsl, int pairs,
+                                                                int ncb_a, int ncb, int nsl, int pairs, AggDiv dv,
                                                                 unsigned long long *accum, int64_t *out64, size_t pstride,
                                                                 int64_t *tout64, size_t tstride, int32_t *out32, FzMod m) {
     __shared__ __attribute__((aligned(16))) double red[WAVES * kAggTile];      // 64 KiB at 8 waves
@@ -234,14 +240,18 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
     // b and b + 8 share an XCD, so XCD x = b % 8 gets the CONTIGUOUS run of tiles [x * per_xcd, (x + 1) * per_xcd): equal
     // load on every XCD (a pair-per-XCD mapping left XCDs with 21 and others with 42 workgroups at 12 slices: 30.7 us
     // instead of 21.9), and an alpha row is still fetched into one L2, two where a run of tiles ends inside a pair
-    const unsigned tiles = (unsigned)pairs * (unsigned)ncb, per_xcd = (tiles + 7u) / 8u;
+    // (no integer division on the device: a uniform 64-bit divide is ~100 instructions in front of the first load;
+    // quotients by ncb and nsl come from host-computed reciprocals, exact for these ranges -- AggDiv)
+    const unsigned tiles = (unsigned)pairs * (unsigned)ncb, per_xcd = dv.per_xcd;
     const unsigned tl = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || tl >= tiles) return;
-    const int cb = (int)(tl % (unsigned)ncb);
-    const int p = (int)(tl / (unsigned)ncb);
-    const size_t g = (size_t)(p / nsl);
-    const int sb = p % nsl;
-    const size_t base = N / (size_t)nsl, extra = N % (size_t)nsl;
+    const unsigned pu = ncb > 1 ? __umulhi(tl, dv.m_ncb) : tl;
+    const int cb = (int)(tl - pu * (unsigned)ncb);
+    const int p = (int)pu;
+    const unsigned gu = nsl > 1 ? __umulhi(pu, dv.m_nsl) : pu;
+    const size_t g = (size_t)gu;
+    const int sb = (int)(pu - gu * (unsigned)nsl);
+    const size_t base = dv.base, extra = dv.extra;
     const size_t i0 = (size_t)sb * base + ((size_t)sb < extra ? (size_t)sb : extra);
     const size_t i1 = i0 + base + ((size_t)sb < extra ? 1 : 0);
     const bool tgt = cb >= ncb_a;
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
         for (int r = 0; r < kAggR; ++r)
 #pragma unroll
             for (int k = 0; k < 4; ++k) hi[r][k] = 0.0;
-        const int j4 = lane % d4;                         // d4 divides 64: the same position for the lane's four columns
+        const int j4 = lane & (d4 - 1);                   // d4 (a power of two) divides 64: the same position for the lane's four columns
         size_t col[kAggR];
 #pragma unroll
         for (int r = 0; r < kAggR; ++r) {
@@ -656,8 +666,14 @@ static void launch_onepass(fz_ctx *ctx, unsigned grid, const int32_t *sig, const
                            const int32_t *vkR, const int32_t *c, size_t N, int l, int d4, int ncb_a, int ncb, int nsl, int pairs,
                            unsigned long long *acc, int64_t *out64, size_t pstride, int64_t *tout64, size_t tstride,
                            int32_t *out32) {
+    AggDiv dv;
+    dv.m_ncb = ncb > 1 ? (unsigned)((0x100000000ull + (unsigned)ncb - 1) / (unsigned)ncb) : 0u;      // unused for a divisor of 1
+    dv.m_nsl = nsl > 1 ? (unsigned)((0x100000000ull + (unsigned)nsl - 1) / (unsigned)nsl) : 0u;
+    dv.per_xcd = (unsigned)(((size_t)pairs * ncb + 7) / 8);
+    dv.base = (unsigned)(N / (size_t)nsl);
+    dv.extra = (unsigned)(N % (size_t)nsl);
     hipLaunchKernelGGL(aggregate_onepass<WAVES>, dim3(grid), dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N, l, d4,
-                       ncb_a, ncb, nsl, pairs, acc, out64, pstride, tout64, tstride, out32, ctx->mod);
+                       ncb_a, ncb, nsl, pairs, dv, acc, out64, pstride, tout64, tstride, out32, ctx->mod);
 }
 
 // out64 != nullptr: int64 partial sums at out64 + g*pstride; else centred int32 at out32 + g*l*degree.
@@ -689,7 +705,9 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
         if (nsl > N && N > 0) nsl = N;
         if (N == 0) nsl = 1;
         const size_t pairs = groups * nsl;
-        if (pairs * (size_t)ncb > 0x3fffffffull) return fz_set_error(FZ_E_UNSUPPORTED, "aggregate: grid too large");
+        // the kernel divides tile numbers by ncb and nsl with 32-bit reciprocals: exact while tiles * divisor < 2^32
+        if (pairs * (size_t)ncb > 0x3fffffffull || pairs * (size_t)ncb * (size_t)(ncb > (int)nsl ? ncb : (int)nsl) >= 0x100000000ull)
+            return fz_set_error(FZ_E_UNSUPPORTED, "aggregate: grid too large (%zu aggregates x %zu slices x %d column blocks)", groups, nsl, ncb);
         unsigned long long *acc = nullptr;
         if (nsl > 1) {
             int rc = fz_agg_scratch(ctx, groups * (size_t)ncb, (size_t)kAggTile, &acc);

@@ -21,7 +21,7 @@ HBM_PEAK_GBS = 8000.0
 POOL_BYTES = 9 << 28          # 2.25 GiB
 
 
-def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False):
+def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None):
     """-> {kernel: {units, bytes_per_unit, avg_us, GB/s, frac, sets_cycled}} ; ctx: fusion_hip.Context on the device.
     Device memory comes from fz_malloc (no torch needed); timing from events on the context's stream."""
     import fusion_hip
@@ -39,6 +39,8 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False):
 
     def run(name, units, bytes_per_unit, in_bytes, out_bytes, launch, note=None):
         """launch(in_ptr, out_ptr): one launch on operand set (in_ptr .. in_ptr + in_bytes) -> (out_ptr ..)"""
+        if only and only not in name:
+            return
         in_step = (in_bytes + 4095) & ~4095
         out_step = (max(out_bytes, 16) + 4095) & ~4095
         nsets = max(1, min(POOL_BYTES // in_step, 4096))
@@ -127,7 +129,8 @@ def main():
     ctx = fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"])
     s = ctx.stream_create()
     ctx.set_stream(s)
-    table = measure(ctx, P, quick="--quick" in sys.argv)
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    table = measure(ctx, P, quick="--quick" in sys.argv, only=only)
     for name, r in table.items():
         print(f"{name:34s} {r['units_per_launch']:9d} units  {r['avg_us']:9.2f} us  {r['GB/s']:8.1f} GB/s algorithmic "
               f"({r['frac'] * 100:5.1f} % of 8 TB/s)  cold: {r['sets_cycled']} operand sets cycled")

@@ -957,7 +957,7 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
         const size_t xstride = (n + 63) & ~(size_t)63;
         const size_t o_pre = 0, o_nb = (n * 32 + 255) & ~(size_t)255, o_text = o_nb + ((n * 4 + 255) & ~(size_t)255);
         const size_t o_xof = o_text + ((n * text_stride + 255) & ~(size_t)255);
-        const size_t total = o_xof + (size_t)out_blocks * 34 * xstride * 4;
+        const size_t total = o_xof + ((size_t)out_blocks * 34 + 1) * xstride * 4;       // + one spare word row (decoder)
         void *scr = nullptr;
         FZ_TRY(fz_scratch(ctx, total, &scr));
         uint8_t *sp = (uint8_t *)scr;

@@ -19,9 +19,10 @@
 //                          parallelism inside a permutation without bit-slicing overheads that cancel it.
 //                          Output words leave transposed ([word][signer]) so that every access is coalesced.
 //   3. decode_kernel       one lane per signer: bit-string of signs, then the partial Fisher-Yates shuffle driven by
-//                          33-byte big-endian integers reduced mod (i + 1); all stream positions are the same for
-//                          every signer, so they live in scalar registers and the shuffle state in LDS ([position][lane],
-//                          conflict-free for data-dependent positions).
+//                          33-byte big-endian integers reduced mod (i + 1) -- as byte dot products with a weight table
+//                          (v_dot4_u32_u8), all indices first (independent, loads three iterations ahead), then the
+//                          swaps; stream positions are the same for every signer (scalar registers), shuffle state
+//                          and indices in LDS ([position][lane]).
 // then the ordinary forward transform (fz_ntt.hip).  Supported: the scheme's parameter sets (norm bound 1, i.e. ternary
 // challenges; degree <= 256); anything else returns FZ_E_UNSUPPORTED and callers use the host pipeline (fz_host.cpp).
 #include "fz_internal.h"
@@ -306,72 +307,93 @@ constexpr int kTabStride = 16;               // uint32 per modulus in the weight
 // int.from_bytes(chunk, "big") % m for m <= 256 is a DOT PRODUCT: sum_k byte_k * (256^(ib-1-k) mod m) < 44 * 255^2 < 2^22,
 // reduced once.  The weights of modulus m sit packed four to a word in tab[m] in the chunk's own byte order, so every
 // four stream bytes cost one v_dot4_u32_u8; tab[m][12] = ceil(2^32 / m) gives the exact quotient of the final
-// reduction by one multiply-high (sum * (ceil(2^32/m) * m - 2^32) < 2^22 * 2^8 < 2^32).  The first version carried the
-// remainder through nine dependent fp64 steps per chunk: 185 us per launch of pure latency; this is ~15.
+// reduction by one multiply-high (sum * (ceil(2^32/m) * m - 2^32) < 2^22 * 2^8 < 2^32).
+//
+// Two phases.  (1) The shuffle INDICES j_n do not depend on the shuffle state, so all of them are computed first, as
+// independent iterations whose loads are requested three iterations ahead (three chunk buffers with fixed roles: a
+// register that a load is still writing is never moved; every load unconditional, indices clamped; the table rows come
+// through VECTOR loads of a lane-invariant address, because scalar loads share one out-of-order counter with LDS and
+// cannot be waited for individually), and parked in LDS as bytes.  (2) The swaps, the only sequential part: three
+// dependent LDS accesses each.  Versions of this kernel, per launch: nine dependent fp64 steps per chunk with loads where
+// they were used 582 us; loads ahead 185; dot products 131; branch-free loads 91; two phases with cheap addressing ~70.
 template <int NW>       // stream words per chunk: ceil((3 + index_bytes) / 4)
 __global__ __launch_bounds__(64) void decode_kernel(const uint32_t *xof, size_t xstride, size_t N, DecodeShapeDev D,
-                                                    const uint32_t *__restrict__ tab, int kmax, int32_t *coefs) {
-    extern __shared__ __attribute__((aligned(16))) int32_t out[];              // [degree][64]
+                                                    const uint32_t *tab, int kmax, int32_t *coefs) {
+    extern __shared__ __attribute__((aligned(16))) signed char lds_dec[];
     const int lane = threadIdx.x & 63;
     const size_t s_raw = (size_t)blockIdx.x * 64 + lane;
     const bool live = s_raw < N;
     const uint32_t *x = xof + (live ? s_raw : N - 1);
     const int d = D.degree;
-    for (int j = 0; j < d; ++j) out[j * 64 + lane] = 0;
+    signed char *out = lds_dec;                                  // [degree][64]: coefficients are -1, 0, 1 (norm bound 1)
+    unsigned char *jl = reinterpret_cast<unsigned char *>(lds_dec) + (size_t)d * 64;      // [draws][64]: shuffle indices
+    const int draws = d - 1 - D.weight > 0 ? d - 1 - D.weight : 0;
+    for (int j = D.weight; j < d; ++j) out[j * 64 + lane] = 0;
     // sign i = bit i (LSB first) of the big-endian integer in the leading sign_bytes bytes (fusion.py:447-453);
-    // magnitudes are 1 + (chunk mod 1) = 1
-    for (int i = 0; i < D.weight; ++i) {
-        const uint32_t byte = stream_byte(x, xstride, D.sign_bytes - 1 - (i >> 3));
-        const int bit = (byte >> (i & 7)) & 1;
-        if (i < d) out[i * 64 + lane] = bit ? 1 : -1;
-    }
-    // for i = degree-1 down to weight+1: j = int.from_bytes(chunk, "big") % (i + 1); swap(out[i], out[j])   (fusion.py:472-480)
-    // Every stream position is the same for all lanes (scalar registers); a chunk's words are loaded together, two
-    // chunks ahead of their use.
-    const int ib = D.index_bytes;
-    int pos = D.sign_bytes + D.coef_bytes * D.weight;
-    // UNCONDITIONAL loads (word indices clamped to the stream's last word, kmax): a load behind a branch, even a uniform
-    // one, makes the compiler wait for every outstanding load at the join, and the prefetch is gone
-    uint32_t wn[NW], wn2[NW];                                    // the next chunk's words and the one after
-    auto fetch = [&](uint32_t (&dst)[NW], int p) {              // words covering stream bytes [p, p + ib)
-        const int k0 = p >> 2;
-#pragma unroll
-        for (int t = 0; t < NW; ++t) {
-            const int k = k0 + t < kmax ? k0 + t : kmax;
-            dst[t] = x[(size_t)k * xstride];
+    // magnitudes are 1 + (chunk mod 1) = 1.  Up to 64 signs: the integer is two byte-swapped words, loaded once.
+    if (D.sign_bytes <= 8) {
+        const uint32_t w0 = x[0], w1 = x[(size_t)(1 < kmax ? 1 : kmax) * xstride];
+        unsigned long long v = ((unsigned long long)__builtin_bswap32(w0) << 32) | __builtin_bswap32(w1);    // bytes 0..7, big-endian
+        v >>= 8 * (8 - D.sign_bytes);
+        for (int i = 0; i < D.weight; ++i)
+            if (i < d) out[i * 64 + lane] = ((v >> i) & 1ull) ? 1 : -1;
+    } else {
+        for (int i = 0; i < D.weight; ++i) {
+            const uint32_t byte = stream_byte(x, xstride, D.sign_bytes - 1 - (i >> 3));
+            if (i < d) out[i * 64 + lane] = ((byte >> (i & 7)) & 1) ? 1 : -1;
         }
+    }
+    // ---- phase 1: j_n = int.from_bytes(chunk_n, "big") % (d - n) for n = 0 .. draws-1   (fusion.py:472-480) ----
+    const int ib = D.index_bytes, pos = D.sign_bytes + D.coef_bytes * D.weight;
+    unsigned vzero = 0;
+    asm volatile("" : "+v"(vzero));                              // an opaque zero in a VGPR: tab + vzero is still a GLOBAL pointer
+    const uint32_t *tabv = tab + vzero;                          // (a laundered pointer would become flat loads, which force
+                                                                 // vmcnt(0) waits), but its loads are vector loads
+    struct Buf { uint32_t w[NW]; uint4 t0, t1, t2; uint32_t t12; };
+    auto fetch = [&](Buf &b, int n) {                            // chunk n's words and its modulus' table row
+        // past the last chunk the last one is fetched again (never used): every word index is then valid without a
+        // per-word clamp (the stream buffer has one spare word row), and a chunk's NW words are ONE 64-bit base plus
+        // loop-invariant multiples of the row stride -- per-word 64-bit index arithmetic was 2/3 of this loop's instructions
+        const int nn = n < draws ? n : draws - 1;
+        const uint32_t *pw = x + (size_t)((pos + nn * ib) >> 2) * xstride;
+#pragma unroll
+        for (int t = 0; t < NW; ++t) b.w[t] = pw[(size_t)t * xstride];
+        const uint32_t *T = tabv + (size_t)(d - nn) * kTabStride;       // modulus i + 1 = d - n
+        b.t0 = *reinterpret_cast<const uint4 *>(T);
+        b.t1 = *reinterpret_cast<const uint4 *>(T + 4);
+        b.t2 = *reinterpret_cast<const uint4 *>(T + 8);
+        b.t12 = T[12];
     };
-    fetch(wn, pos);
-    fetch(wn2, pos + ib);
-    // the weights of modulus i + 1 (13 uniform words: scalar loads) are requested one iteration early as well
-    uint32_t tc[13];
-#pragma unroll
-    for (int g = 0; g < 13; ++g) tc[g] = tab[(size_t)d * kTabStride + g];
-    for (int i = d - 1; i > D.weight; --i) {
-        uint32_t w[NW + 1];
-#pragma unroll
-        for (int t = 0; t < NW; ++t) { w[t] = wn[t]; wn[t] = wn2[t]; }
-        w[NW] = 0u;
-        const int sh = pos & 3;
-        fetch(wn2, pos + 2 * ib);
-        uint32_t tn[13];
-#pragma unroll
-        for (int g = 0; g < 13; ++g) tn[g] = tab[(size_t)i * kTabStride + g];      // modulus i: the next iteration's
+    auto step = [&](Buf &b, int n) {
+        const int i = n < draws ? d - 1 - n : 0;
+        const int sh = (pos + n * ib) & 3;
+        const uint32_t tw[12] = {b.t0.x, b.t0.y, b.t0.z, b.t0.w, b.t1.x, b.t1.y, b.t1.z, b.t1.w, b.t2.x, b.t2.y, b.t2.z, b.t2.w};
         uint32_t sum = 0;
 #pragma unroll
         for (int g = 0; g < NW; ++g) {
             // chunk bytes 4g .. 4g+3 in stream order (bytes past the chunk meet zero weights)
-            const uint32_t u = __builtin_amdgcn_alignbyte(w[g + 1], w[g], sh);
-            sum = __builtin_amdgcn_udot4(u, tc[g], sum, false);
+            const uint32_t hi = g + 1 < NW ? b.w[g + 1 < NW ? g + 1 : g] : 0u;
+            sum = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(hi, b.w[g], sh), tw[g], sum, false);
         }
-        const uint32_t m = (uint32_t)(i + 1);
-        const uint32_t j = sum - __umulhi(sum, tc[12]) * m;      // sum mod m, exact
-        pos += ib;
-        const int vi = out[i * 64 + lane], vj = out[j * 64 + lane];
+        const uint32_t j = sum - __umulhi(sum, b.t12) * (uint32_t)(i + 1);       // sum mod (i + 1), exact
+        if (n < draws) jl[n * 64 + lane] = (unsigned char)j;
+        fetch(b, n + 3);                                         // refill: three iterations ahead
+    };
+    Buf ba, bb, bc;
+    fetch(ba, 0);
+    fetch(bb, 1);
+    fetch(bc, 2);
+    for (int n = 0; n < draws; n += 3) {
+        step(ba, n);
+        step(bb, n + 1);
+        step(bc, n + 2);
+    }
+    // ---- phase 2: for i = d-1 down to weight+1: swap(out[i], out[j]) ----
+    for (int n = 0; n < draws; ++n) {
+        const int i = d - 1 - n, j = jl[n * 64 + lane];
+        const signed char vi = out[i * 64 + lane], vj = out[j * 64 + lane];
         out[i * 64 + lane] = vj;
         out[j * 64 + lane] = vi;
-#pragma unroll
-        for (int g = 0; g < 13; ++g) tc[g] = tn[g];
     }
     if (live) {
         int32_t *dst = coefs + s_raw * (size_t)d;
@@ -418,7 +440,7 @@ int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d
     if (D.index_bytes > 4 * (kChunkWords - 1)) return fz_set_error(FZ_E_UNSUPPORTED, "index chunks of %d bytes", D.index_bytes);
     const int nw = (3 + D.index_bytes + 3) / 4, kmax = out_blocks * 34 - 1;
     const dim3 dgrid((unsigned)((N + 63) / 64));
-    const size_t dlds = (size_t)d * 64 * 4;
+    const size_t dlds = (size_t)d * 64 + (size_t)(d > D.weight ? d - 1 - D.weight : 0) * 64 + 64;
     if (nw <= 5) hipLaunchKernelGGL(decode_kernel<5>, dgrid, dim3(64), dlds, ctx->stream, d_xof, xstride, N, D, d_tab, kmax, d_coefs);
     else if (nw <= 9) hipLaunchKernelGGL(decode_kernel<9>, dgrid, dim3(64), dlds, ctx->stream, d_xof, xstride, N, D, d_tab, kmax, d_coefs);
     else hipLaunchKernelGGL(decode_kernel<12>, dgrid, dim3(64), dlds, ctx->stream, d_xof, xstride, N, D, d_tab, kmax, d_coefs);

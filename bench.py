@@ -32,6 +32,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -65,6 +66,9 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed run of the same steps before the W warmup steps: after idle the GPU needs tens of "
                          "milliseconds of load to reach its steady clocks (measured: the first ~15 ms run 10-25 %% slower)")
+    ap.add_argument("--watchdog-s", type=float, default=420.0,
+                    help="if the legs after the headline have not finished by then, rank 0 prints the line with what it has "
+                         "(\"watchdog\" says which leg was running) and every rank leaves: a hung collective must not cost the line")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -164,6 +168,11 @@ def self_launch(args):
         p.wait()
         if p.returncode != 0 and failed is None:
             failed = (r, p.returncode)
+    rescued = [ln for ln in line.splitlines() if ln.startswith('{"metric"') and '"watchdog"' in ln]
+    if rescued:                                          # a leg after the headline hung: rank 0's watchdog printed what it had
+        sys.stdout.write(rescued[-1] + "\n")
+        sys.stdout.flush()
+        return
     if failed:
         sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}; no result\n")
         sys.exit(1)
@@ -364,8 +373,75 @@ def main():
     elapsed = max_over_ranks(elapsed)
     value = 2.0 * B * total_steps * world / elapsed
 
+    # ---- everything below is a side leg: the headline is measured.  A watchdog prints the line with whatever is there if
+    # a leg hangs (a collective that never completes cannot be cancelled from Python) ------------------------------------
+    floor = multi = cold = two_stream = pcie = kernels = sv = e2e = None
+    sweep = {}
+    stage = ["copy_floor"]
+    done = threading.Event()
+
+    def build_line(watchdog=None):
+        # HBM-side traffic of this launch from the PMC counters (rocprofv3 --pmc, separate passes; FETCH_SIZE corrected x2
+        # for gfx950) cannot be collected live: the committed measurement of THIS round's kernel is reported, or null
+        traffic, traffic_note = None, "no PMC file for this kernel under profiles/ (tools/collect_profiles.sh writes r02_pmc_ntt.json)"
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_ntt.json")) as fh:
+                kernels_pmc = json.load(fh)["kernels"]
+            key = next(k for k in kernels_pmc if k.startswith("ntt_fwd4<8") and "B=4096" in k)
+            traffic = kernels_pmc[key]["traffic_bytes_per_launch"]
+            traffic_note = "profiles/r02_pmc_ntt.json (PMC pass of the same launch, committed this round)"
+        except Exception:
+            pass
+        fwd_bytes = 8.0 * d * B
+        ach = fwd_bytes / (fwd_avg * 1e-3) / 1e9
+        out = {
+            "metric": METRIC, "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "repeats": repeats,
+            "warmup": args.warmup, "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "timed_region_ms": elapsed * 1e3,
+            "config": {"workload": f"configs[1]: secpar={SECPAR}, batch of {B} degree-{d} forward+inverse NTTs per GPU",
+                       "batch": B, "degree": d, "modulus": q, "kernels_per_step": 2,
+                       "arithmetic": "exact integers carried in fp64 lanes (results bit-identical to the reference's int arithmetic); int32 in and out",
+                       "launch": "one by one" if args.no_graph else f"hipGraphs (fz_graph_*) holding {M} x {args.steps} steps, {launches} replays in the timed region = {repeats} repetitions of the {args.steps} steps",
+                       "prewarm_ms": args.prewarm_ms},
+            "ranks": ranks,
+            "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8> (forward NTT, B=4096)", "achieved": ach,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_note,
+                         "bytes_per_launch": fwd_bytes, "butterflies_per_s": value * (d // 2) * 8, "avg_launch_us": fwd_avg * 1e3,
+                         "inverse_avg_launch_us": inv_avg * 1e3, "launches_timed": prof["fwd_count"],
+                         "timing": f"per-dispatch begin/end events (hipExtLaunchKernelGGL) on every {args.sample_every}th dispatch of "
+                                   f"{n_inst} steps launched one by one right after the timed region (a hipGraph cannot carry them)",
+                         "region": {"avg_launch_us": region_launch_us, "achieved": fwd_bytes / (region_launch_us * 1e-6) / 1e9,
+                                    "frac": fwd_bytes / (region_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                    "what": "HIP events around the timed region on the kernels' stream / launches "
+                                            "(consecutive dispatches overlap their launch and drain phases)"},
+                         "copy_floor": floor, "multi_job": multi, "kernels": kernels, "sweep": sweep},
+            "cold_batches": cold, "two_stream_pipelined": two_stream, "sign_verify": sv, "end_to_end": e2e, "pcie_inclusive": pcie,
+        }
+        if watchdog:
+            out["watchdog"] = watchdog
+        return out
+
+    def watchdog():
+        if done.wait(args.watchdog_s):
+            return
+        _BAILING.set()
+        if rank == 0:
+            try:
+                print(json.dumps(build_line(f"side legs not finished {args.watchdog_s:.0f} s after the headline; running: {stage[0]}")))
+                sys.stdout.flush()
+            except Exception:
+                import traceback
+                traceback.print_exc()
+        sys.stderr.write(f"rank {rank}: watchdog fired in leg '{stage[0]}'\n")
+        sys.stderr.flush()
+        if rank == 0:
+            time.sleep(3.0)                             # the other ranks' watchdogs fire at the same moment: let them leave first
+        os._exit(0)                                     # the line is out; a non-zero code would make a launcher discard it
+    threading.Thread(target=watchdog, daemon=True).start()
+
     # ---- the launch floor, same run: an empty dispatch and a plain copy of the bytes one launch moves -----------
-    floor = None
     if rank == 0:
         try:
             prewarm(lambda: ctx.diag_empty_launch(), 20)
@@ -385,7 +461,7 @@ def main():
             floor = {"error": repr(exc)}
 
     # ---- many batches per dispatch (fz_ntt_multi): the same 4096-row batches, 1 / 2 / 4 / 8 of them per launch ---------
-    multi = None
+    stage[0] = "multi"
     if rank == 0:
         try:
             multi = {}
@@ -420,7 +496,7 @@ def main():
     # ---- the same steps over batches that are NOT cache-resident (informational) ----------------------------
     # The timed region above re-reads the same 4 MiB batch every step, so after the first step it lives in the L2s /
     # the 256 MB Infinity Cache.  Here the steps cycle through 32 batches (x, y, z: 384 MiB together).
-    cold = None
+    stage[0] = "cold"
     if rank == 0 and not args.no_two_stream:
         try:
             nb_c = 32
@@ -463,7 +539,7 @@ def main():
             cold = {"error": repr(exc)}
 
     # ---- the same steps as two independent pipelines (two HIP streams / two branches of one graph; informational) ----
-    two_stream = None
+    stage[0] = "two_stream"
     if rank == 0 and not args.no_two_stream:
         try:
             side = torch.cuda.Stream(dev)
@@ -514,7 +590,7 @@ def main():
             two_stream = {"error": repr(exc)}
 
     # ---- host-pointer path (PCIe-inclusive; informational, never `value`) -----------------------
-    pcie = None
+    stage[0] = "pcie"
     if rank == 0:
         try:
             hx = x_host.copy()
@@ -531,7 +607,7 @@ def main():
             pcie = {"error": repr(exc)}
 
     # ---- large-batch asymptote of the same kernels (context for the roofline) ------------------
-    sweep = {}
+    stage[0] = "sweep"
     if rank == 0 and not args.no_sweep:
         try:
             for logb in (16, 18, 20):
@@ -571,7 +647,7 @@ def main():
             sweep["error"] = repr(exc)
 
     # ---- every scheme kernel, cold operands, algorithmic bytes per unit from SURVEY 8d --------------------------
-    kernels = None
+    stage[0] = "kernels"
     if rank == 0 and not args.no_kernel_table:
         try:
             from tools.kernel_table import measure
@@ -587,7 +663,7 @@ def main():
     barrier()
 
     # ---- sign + aggregate + verify (algebra cores; synthetic keys/messages) --------------------
-    sv = None
+    stage[0] = "sv"
     if not args.no_sign_verify:
         try:
             S, GROUPS, NSETS = 1024, 4, 8            # per rank: 1024 signatures in 4 aggregates of 256 x world; 8 operand sets
@@ -758,7 +834,7 @@ def main():
             sv = {"error": repr(exc)}
 
     # ---- end to end through the array API: host hashing (C pipeline) + device algebra ------------------
-    e2e = None
+    stage[0] = "e2e"
     if rank == 0 and not args.no_sign_verify and not args.no_end_to_end:
         try:
             import fusion.fusion as F
@@ -829,45 +905,10 @@ def main():
             traceback.print_exc()
             e2e = {"error": repr(exc)}
 
+    stage[0] = "cpu_baseline"
+    done.set()                                          # the bounded CPU sample is not under the watchdog
     if rank == 0:
-        # HBM-side traffic of this launch from the PMC counters (rocprofv3 --pmc, separate passes; FETCH_SIZE corrected x2
-        # for gfx950) cannot be collected live: the committed measurement of THIS round's kernel is reported, or null
-        traffic, traffic_note = None, "no PMC file for this kernel under profiles/ (tools/collect_profiles.sh writes r02_pmc_ntt.json)"
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_ntt.json")) as fh:
-                kernels_pmc = json.load(fh)["kernels"]
-            key = next(k for k in kernels_pmc if k.startswith("ntt_fwd4<8") and "B=4096" in k)
-            traffic = kernels_pmc[key]["traffic_bytes_per_launch"]
-            traffic_note = "profiles/r02_pmc_ntt.json (PMC pass of the same launch, committed this round)"
-        except Exception:
-            pass
-        fwd_bytes = 8.0 * d * B
-        ach = fwd_bytes / (fwd_avg * 1e-3) / 1e9
-        out = {
-            "metric": METRIC, "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "repeats": repeats,
-            "warmup": args.warmup, "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "timed_region_ms": elapsed * 1e3,
-            "config": {"workload": f"configs[1]: secpar={SECPAR}, batch of {B} degree-{d} forward+inverse NTTs per GPU",
-                       "batch": B, "degree": d, "modulus": q, "kernels_per_step": 2,
-                       "arithmetic": "exact integers carried in fp64 lanes (results bit-identical to the reference's int arithmetic); int32 in and out",
-                       "launch": "one by one" if args.no_graph else f"hipGraphs (fz_graph_*) holding {M} x {args.steps} steps, {launches} replays in the timed region = {repeats} repetitions of the {args.steps} steps",
-                       "prewarm_ms": args.prewarm_ms},
-            "ranks": ranks,
-            "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8> (forward NTT, B=4096)", "achieved": ach,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_note,
-                         "bytes_per_launch": fwd_bytes, "butterflies_per_s": value * (d // 2) * 8, "avg_launch_us": fwd_avg * 1e3,
-                         "inverse_avg_launch_us": inv_avg * 1e3, "launches_timed": prof["fwd_count"],
-                         "timing": f"per-dispatch begin/end events (hipExtLaunchKernelGGL) on every {args.sample_every}th dispatch of "
-                                   f"{n_inst} steps launched one by one right after the timed region (a hipGraph cannot carry them)",
-                         "region": {"avg_launch_us": region_launch_us, "achieved": fwd_bytes / (region_launch_us * 1e-6) / 1e9,
-                                    "frac": fwd_bytes / (region_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                    "what": "HIP events around the timed region on the kernels' stream / launches "
-                                            "(consecutive dispatches overlap their launch and drain phases)"},
-                         "copy_floor": floor, "multi_job": multi, "kernels": kernels, "sweep": sweep},
-            "cold_batches": cold, "two_stream_pipelined": two_stream, "sign_verify": sv, "end_to_end": e2e, "pcie_inclusive": pcie,
-        }
+        out = build_line()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out))
@@ -877,5 +918,13 @@ def main():
         dist.destroy_process_group()
 
 
+_BAILING = threading.Event()       # set by the watchdog: from then on an exception in the main thread is a peer leaving
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        if not _BAILING.is_set():
+            raise
+        time.sleep(10.0)           # the watchdog thread prints the line and ends the process with code 0
+        os._exit(0)

@@ -61,7 +61,7 @@ struct fz_ctx {
     unsigned long long *d_aggacc;
     size_t aggacc_tiles;
     int agg_dirty;
-    int grid_multi;              // resident grid of the multi-job transform kernel (0 = not queried yet)
+    int grid_multi[3];           // resident grid of the multi-job transform kernel per direction mix (0 = not queried yet)
     uint32_t *d_chal_tab;        // weight table of the challenge decoder (fz_challenge.hip), built on first use
     int chal_tab_ib, chal_tab_degree;
     // benchmarking knobs, read ONCE at context creation

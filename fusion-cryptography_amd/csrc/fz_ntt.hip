@@ -599,7 +599,9 @@ __global__ __launch_bounds__(64 * kWaves4) void ntt_inv4(const int32_t *in, int3
 // through all jobs, each wave finds its job by a scalar scan of the running totals, forward and inverse jobs mix
 // freely (both twiddle sets stay in registers, as in the fused product).  Radix-4 schedule, degree 64 / 256.
 // ------------------------------------------------------------------------------------------
-template <int LOGD, bool FAST>
+// DIR: 0 = every job forward, 1 = every job inverse (one twiddle set in registers: 82 instead of 124 VGPRs, and the first
+// row waits for half as many table loads), 2 = mixed.
+template <int LOGD, bool FAST, int DIR>
 __global__ __launch_bounds__(64) void ntt_multi4(FzMultiJobs J, const double2 *__restrict__ tw2, const double2 *__restrict__ itw2,
                                                  FzTwA twA, FzTwA itwA, FzMod m) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
@@ -613,8 +615,8 @@ __global__ __launch_bounds__(64) void ntt_multi4(FzMultiJobs J, const double2 *_
     if (task >= total) return;
 
     double2 twf[P - 1][3], twi[P - 1][3];
-    fwd4_load_twiddles<LOGD>(twf, tw2, mm);
-    inv4_load_twiddles<LOGD>(twi, itw2, mm);
+    if constexpr (DIR != 1) fwd4_load_twiddles<LOGD>(twf, tw2, mm);
+    if constexpr (DIR != 0) inv4_load_twiddles<LOGD>(twi, itw2, mm);
 
     int xn[4];
     bool inv_n = false, valid_n = false;
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(64) void ntt_multi4(FzMultiJobs J, const double2 *_
         while (t >= J.end[j]) ++j;                                   // wave-uniform scalar scan, <= 32 entries
         const unsigned local = t - (j ? J.end[j - 1] : 0u);
         const unsigned rows = J.rows[j] & 0x7fffffffu;
-        inv_n = (J.rows[j] >> 31) != 0;
+        inv_n = DIR == 2 ? (J.rows[j] >> 31) != 0 : DIR == 1;
         const size_t poly = (size_t)local * PPW + p;
         valid_n = poly < rows;
         const size_t row = (valid_n ? poly : (size_t)rows - 1) * D;
@@ -646,17 +648,21 @@ __global__ __launch_bounds__(64) void ntt_multi4(FzMultiJobs J, const double2 *_
         const bool inverse = inv_n, valid = valid_n;
         int32_t *dst = dst_n;
         if (task + stride < total) fetch(task + stride);              // next task's coefficients in flight during the passes
-        if (inverse) {
-            inv4_passes<LOGD, FAST>(a, region, twi, itwA, m, mm);
-            if (valid) {
+        if (DIR == 1 || (DIR == 2 && inverse)) {
+            if constexpr (DIR != 0) {
+                inv4_passes<LOGD, FAST>(a, region, twi, itwA, m, mm);
+                if (valid) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((int)fz_cent(a[k], m), dst + mm + k * LP);
+                    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((int)fz_cent(a[k], m), dst + mm + k * LP);
+                }
             }
         } else {
-            fwd4_passes<LOGD, FAST>(a, region, twf, twA, m, mm);
-            if (valid)
-                nt_store4(dst + 4 * mm, make_int4((int)fz_cent(a[0], m), (int)fz_cent(a[1], m), (int)fz_cent(a[2], m),
-                                                  (int)fz_cent(a[3], m)));
+            if constexpr (DIR != 1) {
+                fwd4_passes<LOGD, FAST>(a, region, twf, twA, m, mm);
+                if (valid)
+                    nt_store4(dst + 4 * mm, make_int4((int)fz_cent(a[0], m), (int)fz_cent(a[1], m), (int)fz_cent(a[2], m),
+                                                      (int)fz_cent(a[3], m)));
+            }
         }
         wave_sync();      // the next task's first-pass writes must not overtake this task's last reads
     }
@@ -1193,22 +1199,29 @@ int fz_launch_ntt_multi(fz_ctx *ctx, const FzMultiJobs &J) {
     if (J.n <= 0) return FZ_OK;
     const unsigned total = J.end[J.n - 1];
     if (total == 0) return FZ_OK;
-    if (ctx->grid_multi == 0) {
+    int dir = (J.rows[0] >> 31) ? 1 : 0;
+    for (int j = 1; j < J.n; ++j)
+        if (((J.rows[j] >> 31) ? 1 : 0) != dir) { dir = 2; break; }
+    if (ctx->grid_multi[dir] == 0) {
         int n = 0;
-        hipError_t e;
-#define FZ_MQ(LOGD, FAST) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ntt_multi4<LOGD, FAST>, 64, 0)
-        if (ctx->logd == 8) { if (ctx->mod.fast) FZ_MQ(8, true); else FZ_MQ(8, false); }
-        else { if (ctx->mod.fast) FZ_MQ(6, true); else FZ_MQ(6, false); }
+        hipError_t e = hipSuccess;
+#define FZ_MQ(LOGD, FAST, DIR) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, ntt_multi4<LOGD, FAST, DIR>, 64, 0)
+#define FZ_MQD(LOGD, FAST) { if (dir == 0) FZ_MQ(LOGD, FAST, 0); else if (dir == 1) FZ_MQ(LOGD, FAST, 1); else FZ_MQ(LOGD, FAST, 2); }
+        if (ctx->logd == 8) { if (ctx->mod.fast) FZ_MQD(8, true) else FZ_MQD(8, false) }
+        else { if (ctx->mod.fast) FZ_MQD(6, true) else FZ_MQD(6, false) }
+#undef FZ_MQD
 #undef FZ_MQ
         if (e != hipSuccess) return fz_check_hip(e, "occupancy query (multi)");
-        ctx->grid_multi = (n < 1 ? 1 : n) * ctx->num_cu;
+        ctx->grid_multi[dir] = (n < 1 ? 1 : n) * ctx->num_cu;
     }
-    const unsigned cap = (unsigned)ctx->grid_multi * (unsigned)ctx->grid_mult;
+    const unsigned cap = (unsigned)ctx->grid_multi[dir] * (unsigned)ctx->grid_mult;
     const dim3 grid(total < cap ? total : cap), block(64);
-#define FZ_MJ(LOGD, FAST) hipLaunchKernelGGL((ntt_multi4<LOGD, FAST>), grid, block, 0, ctx->stream, J, (const double2 *)ctx->d_tw2, \
-                                             (const double2 *)ctx->d_itw2, ctx->twA, ctx->itwA, ctx->mod)
-    if (ctx->logd == 8) { if (ctx->mod.fast) FZ_MJ(8, true); else FZ_MJ(8, false); }
-    else { if (ctx->mod.fast) FZ_MJ(6, true); else FZ_MJ(6, false); }
+#define FZ_MJ(LOGD, FAST, DIR) hipLaunchKernelGGL((ntt_multi4<LOGD, FAST, DIR>), grid, block, 0, ctx->stream, J, (const double2 *)ctx->d_tw2, \
+                                                  (const double2 *)ctx->d_itw2, ctx->twA, ctx->itwA, ctx->mod)
+#define FZ_MJD(LOGD, FAST) { if (dir == 0) FZ_MJ(LOGD, FAST, 0); else if (dir == 1) FZ_MJ(LOGD, FAST, 1); else FZ_MJ(LOGD, FAST, 2); }
+    if (ctx->logd == 8) { if (ctx->mod.fast) FZ_MJD(8, true) else FZ_MJD(8, false) }
+    else { if (ctx->mod.fast) FZ_MJD(6, true) else FZ_MJD(6, false) }
+#undef FZ_MJD
 #undef FZ_MJ
     return fz_check_hip(hipGetLastError(), "ntt_multi launch");
 }

@@ -26,7 +26,7 @@ for lb in (12, 13, 14, 15):
     nb = 1 << lb
     f = t(lambda i, o: ctx.ntt_forward_dev(i, o, nb), nb); v = t(lambda i, o: ctx.ntt_inverse_dev(i, o, nb), nb)
     print(f"B=2^{lb}: fwd {f:7.2f} us ({nb*2048/f/8e6*100:5.1f}%)  inv {v:7.2f} us ({nb*2048/v/8e6*100:5.1f}%)")
-for jobs in (2, 4, 8):
+for jobs in (1, 2, 3, 4, 6, 8):
     nb = 4096
     f = t(lambda i, o: ctx.ntt_multi_dev([(i + j * nb * 1024, o + j * nb * 1024, nb, False) for j in range(jobs)]), nb, jobs)
     v = t(lambda i, o: ctx.ntt_multi_dev([(i + j * nb * 1024, o + j * nb * 1024, nb, True) for j in range(jobs)]), nb, jobs)

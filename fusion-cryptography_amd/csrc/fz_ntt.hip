@@ -804,17 +804,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
 // ------------------------------------------------------------------------------------------
 constexpr int kVerifyWaves = 4;
 
-// 4 consecutive stored values as doubles: int32 rows as they are (any int32), int64 rows -- exact partial sums
-// straight from the cross-GPU all-reduce -- centred on load
-__device__ __forceinline__ void load4_any(const int32_t *p, double (&a)[4], const FzMod &) {
-    const int4 x = *reinterpret_cast<const int4 *>(p);
-    a[0] = (double)x.x; a[1] = (double)x.y; a[2] = (double)x.z; a[3] = (double)x.w;
-}
-__device__ __forceinline__ void load4_any(const int64_t *p, double (&a)[4], const FzMod &m) {
-    const longlong2 lo = reinterpret_cast<const longlong2 *>(p)[0], hi = reinterpret_cast<const longlong2 *>(p)[1];
-    a[0] = fz_cent_i64(lo.x, m); a[1] = fz_cent_i64(lo.y, m);          // exact for any int64
-    a[2] = fz_cent_i64(hi.x, m); a[3] = fz_cent_i64(hi.y, m);
-}
+// 4 consecutive stored values of a row, as loaded (the request is issued one row ahead of its use) and as doubles:
+// int32 rows as they are (any int32), int64 rows -- exact partial sums straight from the cross-GPU all-reduce --
+// centred on unpacking
+template <typename T> struct Raw4;
+template <> struct Raw4<int32_t> {
+    int4 v;
+    __device__ __forceinline__ void load(const int32_t *p) { v = *reinterpret_cast<const int4 *>(p); }
+    __device__ __forceinline__ void unpack(double (&a)[4], const FzMod &) const {
+        a[0] = (double)v.x; a[1] = (double)v.y; a[2] = (double)v.z; a[3] = (double)v.w;
+    }
+};
+template <> struct Raw4<int64_t> {
+    longlong2 lo, hi;
+    __device__ __forceinline__ void load(const int64_t *p) {
+        lo = reinterpret_cast<const longlong2 *>(p)[0];
+        hi = reinterpret_cast<const longlong2 *>(p)[1];
+    }
+    __device__ __forceinline__ void unpack(double (&a)[4], const FzMod &m) const {
+        a[0] = fz_cent_i64(lo.x, m); a[1] = fz_cent_i64(lo.y, m);          // exact for any int64
+        a[2] = fz_cent_i64(hi.x, m); a[3] = fz_cent_i64(hi.y, m);
+    }
+};
 __device__ __forceinline__ int centred_any(int32_t v, const FzMod &) { return v; }
 __device__ __forceinline__ int centred_any(int64_t v, const FzMod &m) { return (int)fz_cent_i64(v, m); }
 
@@ -842,15 +853,31 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
     inv4_load_twiddles<LOGD>(twl, itw2, mm);
 
     double acc[4] = {0, 0, 0, 0};
-    int mx = 0, wfail = 0;
-    const int tasks = (l + PPW - 1) / PPW;
-    for (int task = r * kVerifyWaves + wave; task < tasks; task += R * kVerifyWaves) {
+    double mx = 0.0;                                // max |centred output|, kept as a double: |.| <= q/2, exact
+    int wfail = 0;
+    const bool weigh = omega < (long long)D;        // a row has D coefficients: a bound of D or more cannot fail
+    const unsigned long long gmask = LP == 64 ? ~0ull : (((1ull << (LP & 63)) - 1ull) << ((LP * p) & 63));
+    const int tasks = (l + PPW - 1) / PPW, step = R * kVerifyWaves;
+    // a wave's rows are a sequential chain: the next row (sigma from HBM, A from the L2) is requested before this row's
+    // passes start -- unconditionally, clamped to the last task, so that no branch stands between request and use.  Without
+    // it a workgroup per aggregate (many aggregates per launch) paid one memory latency per row: 24 % of the HBM peak.
+    Raw4<T> rn;
+    int4 an;
+    auto fetch = [&](int t) {
+        const int row = t * PPW + p;
+        const size_t off = (size_t)(row < l ? row : l - 1) * D + 4 * mm;
+        an = *reinterpret_cast<const int4 *>(A + off);
+        rn.load(sig + off);
+    };
+    int task = r * kVerifyWaves + wave;
+    if (task < tasks) fetch(task);
+    for (; task < tasks; task += step) {
         const int row = task * PPW + p;
         const bool valid = row < l;
-        const size_t off = (size_t)(valid ? row : l - 1) * D + 4 * mm;
-        const int4 ak = *reinterpret_cast<const int4 *>(A + off);
+        const int4 ak = an;
         double a[4];
-        load4_any(sig + off, a, m);
+        rn.unpack(a, m);
+        fetch(task + step < tasks ? task + step : tasks - 1);
         if (valid) {
             acc[0] += fz_mulmod(a[0], (double)ak.x, m);
             acc[1] += fz_mulmod(a[1], (double)ak.y, m);
@@ -858,25 +885,42 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
             acc[3] += fz_mulmod(a[3], (double)ak.w, m);
         }
         inv4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
-        int cnt = 0;
+        // norm and weight of the row stay in the fp64 lanes (no conversions): a slot past the last row repeats row l - 1, which
+        // changes neither the maximum nor any row's weight.  Weight = population count of "non-zero" ballots (scalar unit).
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int o = (int)fz_cent(a[k], m);          // canonical: zero mod q <=> 0
-            const int ao = o < 0 ? -o : o;
-            if (valid) mx = ao > mx ? ao : mx;
-            cnt += (o != 0) ? 1 : 0;
+            a[k] = fz_cent(a[k], m);                      // canonical: zero mod q <=> 0
+            mx = __builtin_fmax(mx, __builtin_fabs(a[k]));
         }
+        if (weigh) {
+            int cnt = 0;
 #pragma unroll
-        for (int w = 1; w < LP; w <<= 1) cnt += __shfl_xor(cnt, w);       // weight of this lane group's row
-        if (valid && (long long)cnt > omega) wfail = 1;
+            for (int k = 0; k < 4; ++k) cnt += __popcll(__ballot(a[k] != 0.0) & gmask);
+            if ((long long)cnt > omega) wfail = 1;
+        }
         wave_sync();      // the next row's first-pass writes must not overtake this row's last reads
     }
     // partial products of this wave, indexed by (row slot p, position)
     double *mine = accbuf + wave * 256 + p * D + 4 * mm;
     mine[0] = acc[0]; mine[1] = acc[1]; mine[2] = acc[2]; mine[3] = acc[3];
-    if ((long long)mx > beta) atomicOr(&s_flags, 2);
+    if (mx > (double)beta) atomicOr(&s_flags, 2);       // mx < 2^31 and integer-valued; beta as a double rounds only above 2^53
     if (wfail) atomicOr(&s_flags, 4);
     __syncthreads();
+    if (R == 1) {                                   // the whole aggregate is this workgroup's: nothing to share
+        if (threadIdx.x < D) {
+            double sum = 0;
+            for (int w = 0; w < kVerifyWaves; ++w)
+#pragma unroll
+                for (int q = 0; q < PPW; ++q) sum += accbuf[w * 256 + q * D + threadIdx.x];
+            if ((int)fz_cent_wide(sum, m) != centred_any(target[threadIdx.x], m)) atomicOr(&s_flags, 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int f = s_flags;
+            verdict[g] = (f & 1) ? FZ_VERDICT_TARGET_MISMATCH : ((f & 2) ? FZ_VERDICT_NORM : ((f & 4) ? FZ_VERDICT_WEIGHT : FZ_VERDICT_OK));
+        }
+        return;
+    }
     // Cross-workgroup combine WITHOUT device-scope fences (a __threadfence() is an L2 write-back on this chip: several
     // microseconds each, serialised over the workgroups).  Everything shared travels in device-scope atomics, which
     // are performed at the memory side: exact fp64 adds of integer partials (|.| < l * q < 2^53, order-independent),

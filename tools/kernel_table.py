@@ -95,7 +95,7 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
                                                             o + G * l * d * 8, d, G, per, l),
         note="reads sigma + alpha + vkL + vkR + c_hat: (l + 5) rows per signer")
     # verify from int32 aggregates (fusion.py:690-727): sig [G][l][d] + target [G][d] -> verdict codes
-    for G in (1, 64):
+    for G in (1, 64, 1024, 8192):
         vb = G * l * row
         run(f"verify_fused G={G}", G, (2 * l + 2) * row if G == 1 else (l + 2) * row, vb + G * row, G * 4,
             lambda i, o, G=G, vb=vb: ctx.verify_with_target_batch_async_dev(A.ptr, i, i + vb, G, l, P["beta_vf"], d, o),

@@ -1,4 +1,4 @@
-"""Cold, per-kernel timing of the scheme kernels at secpar 256 (SURVEY.md 8d byte counts).
+"""Cold, per-kernel timing of the scheme kernels at secpar 256 (--secpar 128: degree 64, rank 195) (SURVEY.md 8d byte counts).
 
 Every launch reads an operand set that no launch has touched for >= 2 GiB of other traffic: the sets are carved out
 of one 2.25 GiB input pool (and the outputs rotate through a second pool), so nothing is served by the 256 MB Infinity
@@ -112,6 +112,11 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
     cnt = S * l * d
     run("pw_kernel<mul>", cnt, 12, 2 * cnt * 4, cnt * 4,
         lambda i, o: ctx.pw_dev(fusion_hip.OP_MUL, i, i + cnt * 4, o, cnt))
+    # the practical ceiling: a plain copy (16 B per lane, non-temporal stores) of as many bytes, same cold cycling
+    for mb in (64, 256):
+        nbytes = mb << 20
+        run(f"plain copy {mb} MiB -> {mb} MiB", nbytes // row, 2 * row, nbytes, nbytes,
+            lambda i, o, nbytes=nbytes: ctx.diag_copy_dev(i, o, nbytes), note="not a scheme kernel: what HBM gives a read+write stream")
     if not quick:
         for logb in (12, 14, 16, 18):
             nb = 1 << logb
@@ -125,7 +130,7 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
 def main():
     import fusion_hip
     from oracle import oracle as O      # parameters only (tools/ is not product code)
-    P = O.PARAMS[256]
+    P = O.PARAMS[int(sys.argv[sys.argv.index("--secpar") + 1]) if "--secpar" in sys.argv else 256]
     ctx = fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"])
     s = ctx.stream_create()
     ctx.set_stream(s)

@@ -534,6 +534,23 @@ int fz_profile_end(fz_ctx *ctx, double *fwd_avg_us, int *fwd_count, double *inv_
     return FZ_OK;
 }
 
+int fz_profile_end_samples(fz_ctx *ctx, double *us, int *kind, int cap, int *n) {
+    FZ_REQUIRE(ctx && us && kind && n && cap >= 0, "bad argument");
+    FZ_DEV(ctx);
+    ctx->prof_on = 0;
+    FZ_HIP(hipStreamSynchronize(ctx->stream), "profile sync");
+    int k = 0;
+    for (int i = 0; i < ctx->prof_n && k < cap; ++i, ++k) {
+        float ms = 0;
+        FZ_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]), "event elapsed");
+        us[k] = ms * 1e3;
+        kind[k] = ctx->prof_kind[i];
+    }
+    *n = k;
+    ctx->prof_n = 0;
+    return FZ_OK;
+}
+
 // ---- transforms ----------------------------------------------------------------------------
 int fz_ntt_forward(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch) {
     FZ_REQUIRE(ctx && (batch == 0 || (d_in && d_out)), "NULL argument");
@@ -913,9 +930,16 @@ int fz_ntt_multi(fz_ctx *ctx, const fz_ntt_job *h_jobs, size_t n_jobs) {
 }
 
 // ---- the challenge pipeline on the device (device half) ---------------------------------------------
-static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *h_prehash, size_t N,
-                         int32_t *d_out, bool transform) {
-    FZ_REQUIRE(ctx && P && (N == 0 || (d_vk && h_prehash && d_out)), "NULL argument");
+// the pre-hashed messages come either as h_prehash [N][32] (computed by the caller, fz_hash_messages) or are computed here,
+// on the device, from the messages themselves (h_msgs back to back, h_msg_off [N + 1]); h_prehash_out (optional, with
+// messages only) receives them
+static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *h_prehash, const char *h_msgs,
+                         const size_t *h_msg_off, uint8_t *h_prehash_out, size_t N, int32_t *d_out, bool transform) {
+    FZ_REQUIRE(ctx && P && (N == 0 || (d_vk && (h_prehash || h_msg_off) && d_out)), "NULL argument");
+    if (!h_prehash && N) {
+        FZ_REQUIRE(h_msg_off[N] == h_msg_off[0] || h_msgs, "NULL argument");
+        for (size_t i = 0; i < N; ++i) FZ_REQUIRE(h_msg_off[i] <= h_msg_off[i + 1], "message offsets must not decrease");
+    }
     FZ_DEV(ctx);
     if (!fz_host_params_ok(P)) return fz_set_error(FZ_E_BADARG, "bad scheme parameters");
     if (P->degree != ctx->degree || P->modulus != (int64_t)ctx->q)
@@ -957,12 +981,25 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
         const size_t xstride = (n + 63) & ~(size_t)63;
         const size_t o_pre = 0, o_nb = (n * 32 + 255) & ~(size_t)255, o_text = o_nb + ((n * 4 + 255) & ~(size_t)255);
         const size_t o_xof = o_text + ((n * text_stride + 255) & ~(size_t)255);
-        const size_t total = o_xof + ((size_t)out_blocks * 34 + 1) * xstride * 4;       // + one spare word row (decoder)
+        const size_t o_off = o_xof + ((((size_t)out_blocks * 34 + 1) * xstride * 4 + 255) & ~(size_t)255);    // + one spare word row (decoder)
+        const size_t msg_bytes = h_prehash ? 0 : h_msg_off[base + n] - h_msg_off[base];
+        const size_t o_msg = o_off + (((n + 1) * 8 + 255) & ~(size_t)255);
+        const size_t total = h_prehash ? o_off : o_msg + ((msg_bytes + 255) & ~(size_t)255);
         void *scr = nullptr;
         FZ_TRY(fz_scratch(ctx, total, &scr));
         uint8_t *sp = (uint8_t *)scr;
-        FZ_HIP(hipMemcpyAsync(sp + o_pre, h_prehash + 32 * base, n * 32, hipMemcpyHostToDevice, ctx->stream), "upload of the pre-hashed messages");
-        FZ_HIP(hipStreamSynchronize(ctx->stream), "upload sync");      // the caller's buffer has been consumed when this returns
+        if (h_prehash) {
+            FZ_HIP(hipMemcpyAsync(sp + o_pre, h_prehash + 32 * base, n * 32, hipMemcpyHostToDevice, ctx->stream), "upload of the pre-hashed messages");
+        } else {
+            static_assert(sizeof(size_t) == sizeof(unsigned long long), "offsets travel as 64-bit words");
+            FZ_HIP(hipMemcpyAsync(sp + o_off, h_msg_off + base, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream), "upload of the message offsets");
+            if (msg_bytes)
+                FZ_HIP(hipMemcpyAsync(sp + o_msg, h_msgs + h_msg_off[base], msg_bytes, hipMemcpyHostToDevice, ctx->stream), "upload of the messages");
+            FZ_TRY(fz_launch_prehash(ctx, P, sp + o_msg, (const unsigned long long *)(sp + o_off), n, sp + o_pre));
+            if (h_prehash_out)
+                FZ_HIP(hipMemcpyAsync(h_prehash_out + 32 * base, sp + o_pre, n * 32, hipMemcpyDeviceToHost, ctx->stream), "download of the pre-hashed messages");
+        }
+        FZ_HIP(hipStreamSynchronize(ctx->stream), "upload sync");      // the caller's buffers have been consumed when this returns
         FZ_TRY(fz_launch_challenge(ctx, P, d_vk + base * 2 * (size_t)P->degree, sp + o_pre, n, sp + o_text, text_stride,
                                    (int *)(sp + o_nb), (uint32_t *)(sp + o_xof), xstride, out_blocks, ctx->d_chal_tab,
                                    d_out + base * (size_t)P->degree));
@@ -973,12 +1010,20 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
 
 int fz_challenge_coefficients_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *h_prehash,
                                   size_t N, int32_t *d_coefs) {
-    return challenge_dev(ctx, P, d_vk, h_prehash, N, d_coefs, false);
+    FZ_REQUIRE(h_prehash || N == 0, "NULL argument");
+    return challenge_dev(ctx, P, d_vk, h_prehash, nullptr, nullptr, nullptr, N, d_coefs, false);
 }
 
 int fz_challenge_hat_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *h_prehash, size_t N,
                          int32_t *d_c_hat) {
-    return challenge_dev(ctx, P, d_vk, h_prehash, N, d_c_hat, true);
+    FZ_REQUIRE(h_prehash || N == 0, "NULL argument");
+    return challenge_dev(ctx, P, d_vk, h_prehash, nullptr, nullptr, nullptr, N, d_c_hat, true);
+}
+
+int fz_challenge_hat_msgs_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const char *h_msgs, const size_t *h_msg_off,
+                              size_t N, int32_t *d_c_hat, uint8_t *h_prehash_out) {
+    FZ_REQUIRE(h_msg_off || N == 0, "NULL argument");
+    return challenge_dev(ctx, P, d_vk, nullptr, h_msgs, h_msg_off, h_prehash_out, N, d_c_hat, true);
 }
 
 // ---- launch-floor diagnostics ------------------------------------------------------------------------------

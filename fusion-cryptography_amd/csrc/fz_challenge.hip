@@ -289,6 +289,54 @@ __global__ __launch_bounds__(64) void shake_kernel(const uint8_t *text, size_t t
     }
 }
 
+// hash_message_to_int (fusion.py:405-409): SHA3-256 of dst + "," + message, one lane pair per message as above.  The
+// stream is read byte by byte where it is absorbed -- messages are short (one block below 133 bytes) and start at any
+// byte offset; its padding (0x06 ... 0x80) is part of the same byte function.  pre [N][32]: the digests, i.e. the
+// pre-hashed integers, little-endian, exactly what vk_text_kernel prints in decimal.
+__global__ __launch_bounds__(64) void prehash_kernel(const uint8_t *msgs, const unsigned long long *off, size_t N, uint32_t dst0,
+                                                     uint32_t dst1, uint8_t *pre) {
+    const int lane = threadIdx.x & 63, half = lane & 1;
+    const size_t s_raw = (size_t)blockIdx.x * 32 + (lane >> 1);
+    const bool live = s_raw < N;
+    const size_t s = live ? s_raw : N - 1;                       // idle pairs shadow the last message and store nothing
+    const unsigned long long len = off[s + 1] - off[s];
+    const uint8_t *m = msgs + (off[s] - off[0]);
+    const unsigned long long nb = (len + 4 + kRate - 1) / kRate;        // 3 prefix bytes + message + the suffix byte
+    const unsigned long long last = nb * kRate - 1;
+    unsigned long long nbmax = nb;                               // the wave's loop bound
+#pragma unroll
+    for (int w = 2; w < 64; w <<= 1) {
+        const unsigned long long o = __shfl_xor(nbmax, w);
+        nbmax = o > nbmax ? o : nbmax;
+    }
+    auto byte_at = [&](unsigned long long p) -> uint32_t {
+        uint32_t v;
+        if (p < 3) {
+            v = p == 0 ? dst0 : (p == 1 ? dst1 : 0x2cu);
+        } else {
+            const unsigned long long k = p - 3;
+            v = k < len ? (uint32_t)m[k] : (k == len ? 0x06u : 0u);
+        }
+        return p == last ? (v | 0x80u) : v;
+    };
+    KState S = {};
+#pragma unroll 1
+    for (unsigned long long b = 0; b < nbmax; ++b) {
+        if (b < nb) {                                            // both lanes of a pair agree
+            const unsigned long long base = b * kRate + 4 * half;
+#define FZ_ABSB(i) { const unsigned long long q_ = base + 8 * i; \
+                     S.a##i ^= byte_at(q_) | (byte_at(q_ + 1) << 8) | (byte_at(q_ + 2) << 16) | (byte_at(q_ + 3) << 24); }
+            FZ_FOR17(FZ_ABSB)
+#undef FZ_ABSB
+            keccak_f_half(S, half);
+        }
+    }
+    if (live) {
+        uint32_t *o = reinterpret_cast<uint32_t *>(pre + s * 32) + half;
+        o[0] = S.a0; o[2] = S.a1; o[4] = S.a2; o[6] = S.a3;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // 3. decoder (fusion.py:422-481) for norm bound 1: signs, then the partial Fisher-Yates shuffle
 // ---------------------------------------------------------------------------------------------------------------
@@ -445,6 +493,16 @@ int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d
     else if (nw <= 9) hipLaunchKernelGGL(decode_kernel<9>, dgrid, dim3(64), dlds, ctx->stream, d_xof, xstride, N, D, d_tab, kmax, d_coefs);
     else hipLaunchKernelGGL(decode_kernel<12>, dgrid, dim3(64), dlds, ctx->stream, d_xof, xstride, N, D, d_tab, kmax, d_coefs);
     return fz_check_hip(hipGetLastError(), "decode launch");
+}
+
+// SHA3-256 of dst + "," + message for N messages: d_msgs the message bytes back to back, d_off [N + 1] their offsets (any
+// origin: off[0] is subtracted), d_pre [N][32] out
+int fz_launch_prehash(fz_ctx *ctx, const fz_scheme_params *P, const uint8_t *d_msgs, const unsigned long long *d_off, size_t N,
+                      uint8_t *d_pre) {
+    if (N == 0) return FZ_OK;
+    hipLaunchKernelGGL(prehash_kernel, dim3((unsigned)((N + 31) / 32)), dim3(64), 0, ctx->stream, d_msgs, d_off, N,
+                       (uint32_t)P->sign_pre_hash_dst[0], (uint32_t)P->sign_pre_hash_dst[1], d_pre);
+    return fz_check_hip(hipGetLastError(), "prehash launch");
 }
 
 // the decoder's weight table for (index_bytes, degree): tab[m][g] (g < 12) packs 256^(ib-1-(4g+t)) mod m for t = 0..3 (zero

@@ -57,6 +57,7 @@ SIGNATURES = {
     "fz_timer_stop_ms": (c_int, [_ctx, POINTER(c_float)]),
     "fz_profile_begin": (c_int, [_ctx, c_int, c_int]),
     "fz_profile_end": (c_int, [_ctx, POINTER(ctypes.c_double), POINTER(c_int), POINTER(ctypes.c_double), POINTER(c_int)]),
+    "fz_profile_end_samples": (c_int, [_ctx, POINTER(ctypes.c_double), POINTER(c_int), c_int, POINTER(c_int)]),
     "fz_ntt_forward": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
     "fz_ntt_inverse": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
     "fz_ntt_forward_host": (c_int, [_ctx, _i32p, c_size_t]),
@@ -125,6 +126,7 @@ SIGNATURES.update({
     "fz_aggregation_coefficients": (c_int, [_spp, _i32p, _i32p, _u8p, _i32p, c_size_t, _i32p, c_int]),
     "fz_challenge_coefficients_dev": (c_int, [_ctx, _spp, c_void_p, _u8p, c_size_t, c_void_p]),
     "fz_challenge_hat_dev": (c_int, [_ctx, _spp, c_void_p, _u8p, c_size_t, c_void_p]),
+    "fz_challenge_hat_msgs_dev": (c_int, [_ctx, _spp, c_void_p, c_char_p, _szp, c_size_t, c_void_p, _u8p]),
     "fz_sample_ntt_values": (c_int, [ctypes.c_uint64, c_int64, c_int, _i32p]),
     "fz_sample_coefficients": (c_int, [ctypes.c_uint64, c_int64, c_int, c_int64, c_int64, _i32p]),
     "fz_sample_secret_polys": (c_int, [POINTER(ctypes.c_uint64), c_size_t, c_int64, c_int, c_int64, c_int64, _i32p, c_int]),

@@ -130,6 +130,13 @@ class Context:
         check(self._lib, self._lib.fz_profile_end(self._h, byref(fa), byref(fc), byref(ia), byref(ic)))
         return dict(fwd_avg_us=fa.value, fwd_count=fc.value, inv_avg_us=ia.value, inv_count=ic.value)
 
+    def profile_end_samples(self, cap):
+        """-> (us [n] float64, kind [n] int32: 0 forward / 1 inverse): every instrumented launch since profile_begin"""
+        us, kind, n = np.empty(cap, dtype=np.float64), np.empty(cap, dtype=np.int32), c_int()
+        check(self._lib, self._lib.fz_profile_end_samples(self._h, us.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                          kind.ctypes.data_as(ctypes.POINTER(c_int)), cap, byref(n)))
+        return us[:n.value], kind[:n.value]
+
     # -- device face (raw pointers) -------------------------------------------------------------
     def ntt_forward_dev(self, d_in, d_out, batch):
         check(self._lib, self._lib.fz_ntt_forward(self._h, c_void_p(d_in), c_void_p(d_out), batch))
@@ -162,6 +169,19 @@ class Context:
         fn = self._lib.fz_challenge_hat_dev if transform else self._lib.fz_challenge_coefficients_dev
         check(self._lib, fn(self._h, byref(P), c_void_p(d_vk), pre.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), N,
                             c_void_p(d_out)))
+
+    def challenge_msgs_dev(self, P, d_vk, blob, offsets, N, d_out, want_prehash=False):
+        """hash_ch on the device INCLUDING hash_message_to_int (fz_challenge_hat_msgs_dev): blob = the N messages' bytes back
+        to back, offsets [N + 1] uintp (hostpipe._pack_messages); -> the [N][32] digests if want_prehash else None"""
+        off = np.ascontiguousarray(offsets, dtype=np.uintp)
+        if off.shape[0] != N + 1:
+            raise FusionHipError(FZ_E_BADARG, f"{off.shape[0]} offsets for {N} messages")
+        pre = np.empty((N, 32), dtype=np.uint8) if want_prehash else None
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        check(self._lib, self._lib.fz_challenge_hat_msgs_dev(
+            self._h, byref(P), c_void_p(d_vk), blob, off.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), N, c_void_p(d_out),
+            pre.ctypes.data_as(u8p) if want_prehash else ctypes.cast(None, u8p)))
+        return pre
 
     def pw_dev(self, op, d_a, d_b, d_out, count):
         fn = {OP_MUL: self._lib.fz_pw_mul, OP_ADD: self._lib.fz_pw_add, OP_SUB: self._lib.fz_pw_sub}[op]

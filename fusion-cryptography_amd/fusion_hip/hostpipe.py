@@ -40,9 +40,20 @@ def _p(a):
 
 
 def _pack_messages(messages):
+    """-> (the messages' UTF-8 bytes back to back, offsets [N + 1] uintp).  ASCII-only str messages (byte length = character
+    length) are joined and encoded in one go: a per-message encode() costs more than hashing the message does."""
+    n = len(messages)
+    off = np.zeros(n + 1, dtype=np.uintp)
+    try:
+        joined = "".join(messages)
+        blob = joined.encode("utf-8")
+        if len(blob) == len(joined):
+            np.cumsum(np.fromiter(map(len, messages), dtype=np.uintp, count=n), out=off[1:])
+            return blob, off
+    except TypeError:                                   # bytes-like messages among them
+        pass
     enc = [m.encode("utf-8") if isinstance(m, str) else bytes(m) for m in messages]
-    off = np.zeros(len(enc) + 1, dtype=np.uintp)
-    np.cumsum([len(e) for e in enc], out=off[1:])
+    np.cumsum(np.fromiter(map(len, enc), dtype=np.uintp, count=n), out=off[1:])
     return b"".join(enc), off
 
 

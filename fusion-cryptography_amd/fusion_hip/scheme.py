@@ -68,16 +68,17 @@ class BatchScheme:
                     b.free()
 
     # ---- sign --------------------------------------------------------------------------------------
-    def challenges_dev(self, vk, messages):
-        """hash_ch for every (key, message) ON THE DEVICE (fz_challenge_hat_dev: text of str(vk), SHAKE-256, decoder,
-        forward NTT): -> (c_hat DeviceArray [N][d], prehash [N][32]).  vk: numpy [N][2][d] or a DeviceArray of that
-        shape.  Raises FusionHipError(FZ_E_UNSUPPORTED) for parameter sets the device pipeline does not cover."""
-        pre = hostpipe.hash_messages(self.P, messages)
+    def challenges_dev(self, vk, messages, want_prehash=True):
+        """hash_ch for every (key, message) ON THE DEVICE (fz_challenge_hat_msgs_dev: SHA3-256 of the messages, text of
+        str(vk), SHAKE-256, decoder, forward NTT): -> (c_hat DeviceArray [N][d], prehash [N][32] or None).  vk: numpy
+        [N][2][d] or a DeviceArray of that shape.  Raises FusionHipError(FZ_E_UNSUPPORTED) for parameter sets the device
+        pipeline does not cover."""
+        blob, off = hostpipe._pack_messages(messages)
         n = len(messages)
         dV, own = self._dev(vk, (n, 2, self.d))
         dC = DeviceArray(self.ctx, (n, self.d))
         try:
-            self.ctx.challenge_dev(self.P, dV.ptr, pre, n, dC.ptr, transform=True)
+            pre = self.ctx.challenge_msgs_dev(self.P, dV.ptr, blob, off, n, dC.ptr, want_prehash)
         except Exception:
             dC.free()
             raise
@@ -112,7 +113,7 @@ class BatchScheme:
         dC = None
         if self.device_hash:
             try:
-                dC, _ = self.challenges_dev(vk, messages)
+                dC, _ = self.challenges_dev(vk, messages, want_prehash=False)
             except FusionHipError as e:
                 if e.code != FZ_E_UNSUPPORTED:
                     raise

@@ -111,6 +111,8 @@ FZ_API int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms);        /* records, wait
  * fz_profile_end synchronises and returns the average durations in microseconds. */
 FZ_API int fz_profile_begin(fz_ctx *ctx, int max_launches, int sample_every);
 FZ_API int fz_profile_end(fz_ctx *ctx, double *fwd_avg_us, int *fwd_count, double *inv_avg_us, int *inv_count);
+/* the same, every sample: us[k] the duration of the k-th instrumented launch, kind[k] 0 = forward, 1 = inverse */
+FZ_API int fz_profile_end_samples(fz_ctx *ctx, double *us, int *kind, int cap, int *n);
 
 /* ---- transforms ---------------------------------------------------------------------------
  * fz_ntt_forward: cooley_tukey_ntt (algebra/ntt.py:216-291) on `batch` rows.
@@ -341,6 +343,11 @@ FZ_API int fz_challenge_coefficients_dev(fz_ctx *ctx, const fz_scheme_params *P,
                                          size_t N, int32_t *d_coefs);
 FZ_API int fz_challenge_hat_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *h_prehash,
                                 size_t N, int32_t *d_c_hat);
+/* The same with hash_message_to_int (fusion.py:405-409: SHA3-256 of dst + "," + message) on the device as well: h_msgs the
+ * N messages' bytes back to back (UTF-8, as the reference's .encode()), h_msg_off [N + 1] their offsets (as
+ * fz_hash_messages takes them); h_prehash_out (optional) receives the [N][32] digests, which hash_ag needs on the host. */
+FZ_API int fz_challenge_hat_msgs_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const char *h_msgs,
+                                     const size_t *h_msg_off, size_t N, int32_t *d_c_hat, uint8_t *h_prehash_out);
 
 /* ---- reference-exact sampling on the host -----------------------------------------
  * CPython's MT19937 `random` exactly as the reference's samplers drive it (random.seed(int), randrange):

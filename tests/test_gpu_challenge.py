@@ -97,3 +97,41 @@ def test_golden_scheme_challenges(secpar):
     pre = hostpipe.hash_messages(P, m["messages"])
     hat = _device_challenges(ctx, P, S["vk"], pre, transform=True)
     assert np.array_equal(hat, S["c_hat"])
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_messages_hashed_on_the_device(secpar, coracle):
+    """fz_challenge_hat_msgs_dev: hash_message_to_int (fusion.py:405-409) on the device too.  The digests it returns are
+    CPython's hashlib.sha3_256 of dst + "," + message for every block-boundary length (rate 136: 3 prefix bytes, one
+    suffix byte), empty and multi-block messages and non-ASCII text; the challenges equal the host pipeline's."""
+    import hashlib
+    import fusion_hip
+    from fusion_hip import hostpipe
+    params, P, ctx = _setup(secpar)
+    d, q = params.degree, params.modulus
+    lengths = list(range(0, 8)) + list(range(128, 140)) + [264, 265, 266, 267, 268, 269, 270, 271, 272, 273, 400, 1000, 5000]
+    msgs = ["".join(chr(33 + (7 * i + k) % 90) for k in range(n)) for i, n in enumerate(lengths)]
+    msgs += ["café ✓ \U0001f511" * 9, "ü" * 66, "ü" * 67]          # UTF-8: 2- to 4-byte characters, 132 / 134 bytes
+    msgs += [f"synthetic message {i:06d}" for i in range(70)]
+    n = len(msgs)
+    rng = np.random.default_rng(secpar)
+    vk = rng.integers(-(q // 2), q // 2 + 1, size=(n, 2, d)).astype(np.int32)
+    blob, off = hostpipe._pack_messages(msgs)
+    dvk = fusion_hip.DeviceBuffer.from_numpy(ctx, vk)
+    dout = fusion_hip.DeviceBuffer(ctx, n * d * 4)
+    try:
+        pre = ctx.challenge_msgs_dev(P, dvk.ptr, blob, off, n, dout.ptr, want_prehash=True)
+        dst = bytes(P.sign_pre_hash_dst)
+        for i, m in enumerate(msgs):
+            assert bytes(pre[i]) == hashlib.sha3_256(dst + b"," + m.encode("utf-8")).digest(), (i, len(m))
+        assert np.array_equal(pre, hostpipe.hash_messages(P, msgs))
+        coefs, _ = hostpipe.challenge_coefficients(P, vk[:, 0], vk[:, 1], msgs)
+        assert np.array_equal(dout.to_numpy(np.int32, (n, d)), coracle.ntt_forward(coefs, q, params.root))
+        # offsets with a non-zero origin (a slice of a larger packing), no digests requested
+        ctx.h2d(dout.ptr, np.zeros((n, d), np.int32))
+        k = 40
+        assert ctx.challenge_msgs_dev(P, dvk.ptr + k * 2 * d * 4, blob, off[k:], n - k, dout.ptr + k * d * 4) is None
+        assert np.array_equal(dout.to_numpy(np.int32, (n, d))[k:], coracle.ntt_forward(coefs[k:], q, params.root))
+    finally:
+        dvk.free()
+        dout.free()

@@ -276,3 +276,49 @@ def test_knobbed_paths_agree_with_the_oracle(knob, coracle, monkeypatch):
     finally:
         dev.close()
         ctx.close()
+
+
+def test_config2_sweep_maximum_2_22_rows(coracle):
+    """BASELINE configs[1]'s sweep ends at B = 2^22 rows (4 GiB in, 4 GiB out at degree 256).  At that size: sampled rows
+    against the C oracle (first, middle, last 2048 rows of the seeded stream), the round trip INTT(NTT(x)) == x over ALL
+    rows (difference reduced on the device: max |.| and weight per row), and linearity NTT(x + y) == NTT(x) + NTT(y)."""
+    import fusion_hip
+    P = O.PARAMS[256]
+    q, d = P["q"], P["d"]
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    rows = 1 << 22
+    count = rows * d
+    DB = fusion_hip.DeviceBuffer
+    GAMMA = 0x9E3779B97F4A7C15
+
+    def host_rows(seed, first, n):          # the same stream as fz_fill_synthetic, from element first * d on
+        return O.splitmix_centered((seed + first * d * GAMMA) % (1 << 64), n * d).reshape(n, d)
+    dx, dy, dz = DB(ctx, count * 4), DB(ctx, count * 4), DB(ctx, count * 4)
+    dm, dw = DB(ctx, rows * 8), DB(ctx, rows * 4)          # fz_norm_weight: int64 maxima, int32 weights
+    try:
+        ctx.fill_synthetic_dev(dx.ptr, count, 5)
+        ctx.ntt_forward_dev(dx.ptr, dy.ptr, rows)
+        for first in (0, 1234567, rows - 2048):
+            want = coracle.ntt_forward(host_rows(5, first, 2048), q, P["root"]).reshape(2048, d)
+            got = np.empty((2048, d), np.int32)
+            ctx.d2h(got, dy.ptr + first * d * 4)
+            assert np.array_equal(got, want), first
+
+        def all_zero(ptr):
+            ctx.norm_weight_dev(ptr, rows, dm.ptr, dw.ptr)
+            return not dm.to_numpy(np.int64, (rows,)).any() and not dw.to_numpy(np.int32, (rows,)).any()
+        ctx.ntt_inverse_dev(dy.ptr, dy.ptr, rows)                       # in place
+        ctx.pw_dev(fusion_hip.OP_SUB, dy.ptr, dx.ptr, dy.ptr, count)
+        assert all_zero(dy.ptr), "INTT(NTT(x)) != x somewhere in 2^22 rows"
+        ctx.fill_synthetic_dev(dz.ptr, count, 6)
+        ctx.pw_dev(fusion_hip.OP_ADD, dx.ptr, dz.ptr, dy.ptr, count)    # x + y
+        ctx.ntt_forward_dev(dy.ptr, dy.ptr, rows)
+        ctx.ntt_forward_dev(dx.ptr, dx.ptr, rows)
+        ctx.ntt_forward_dev(dz.ptr, dz.ptr, rows)
+        ctx.pw_dev(fusion_hip.OP_ADD, dx.ptr, dz.ptr, dx.ptr, count)
+        ctx.pw_dev(fusion_hip.OP_SUB, dy.ptr, dx.ptr, dy.ptr, count)
+        assert all_zero(dy.ptr), "NTT(x + y) != NTT(x) + NTT(y) somewhere in 2^22 rows"
+    finally:
+        for b in (dx, dy, dz, dm, dw):
+            b.free()
+        ctx.close()

@@ -114,7 +114,12 @@ while time.time() < t_end:
         msgs = [f"soak {it} {i} " + "x" * int(rng.integers(0, 200)) for i in range(nn)]
         coefs, pre = hostpipe.challenge_coefficients(HP, vk[:, 0], vk[:, 1], msgs)
         dv, dc = DB.from_numpy(ctx, vk), DB(ctx, nn * d * 4)
-        ctx.challenge_dev(HP, dv.ptr, pre, nn, dc.ptr, transform=True)
+        if rng.random() < 0.5:
+            ctx.challenge_dev(HP, dv.ptr, pre, nn, dc.ptr, transform=True)
+        else:                                       # the messages hashed on the device as well
+            blob, off = hostpipe._pack_messages(msgs)
+            got_pre = ctx.challenge_msgs_dev(HP, dv.ptr, blob, off, nn, dc.ptr, want_prehash=True)
+            assert np.array_equal(got_pre, pre), ("prehash", sp, nn)
         assert np.array_equal(dc.to_numpy(np.int32, (nn, d)), orc.ntt_forward(coefs, q, root).reshape(nn, d)), ("challenge", sp, nn)
         dv.free()
         dc.free()

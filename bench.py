@@ -906,8 +906,8 @@ def main():
                    "sign_per_s_at_16384_signatures": n_big / t_sign_big,
                    "aggregate_per_s": n_e2e / t_agg, "verify_per_s": n_e2e / t_ver,
                    "sign_plus_verify_per_s": n_e2e / (t_sign + t_agg + t_ver),
-                   "note": "BatchScheme with device-resident keys and signatures: reference-exact MT19937 sampling on the host, "
-                           "the per-signer challenge pipeline (message pre-hash included) and all algebra on the device; aggregate and "
+                   "note": "BatchScheme with device-resident keys and signatures: reference-exact MT19937 sampling of the secret "
+                           "polynomials, the per-signer challenge pipeline (message pre-hash included) and all algebra on the device; aggregate and "
                            "verify are bounded by hash_ag, ONE serial SHAKE-256 over ~13.5 KB per signer on the host by construction "
                            "(fusion.py:632-652)"}
         except Exception as exc:                      # a side leg must never take the headline down with it

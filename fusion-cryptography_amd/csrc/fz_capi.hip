@@ -344,6 +344,7 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     if (ctx->d_vstate) (void)hipFree(ctx->d_vstate);
     if (ctx->d_aggacc) (void)hipFree(ctx->d_aggacc);
     if (ctx->d_chal_tab) (void)hipFree(ctx->d_chal_tab);
+    if (ctx->d_mt_init) (void)hipFree(ctx->d_mt_init);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     free(ctx->h_tw);
@@ -1024,6 +1025,40 @@ int fz_challenge_hat_msgs_dev(fz_ctx *ctx, const fz_scheme_params *P, const int3
                               size_t N, int32_t *d_c_hat, uint8_t *h_prehash_out) {
     FZ_REQUIRE(h_msg_off || N == 0, "NULL argument");
     return challenge_dev(ctx, P, d_vk, nullptr, h_msgs, h_msg_off, h_prehash_out, N, d_c_hat, true);
+}
+
+// ---- the reference's seeded secret-key sampler on the device (fz_sample.hip) --------------------------------------------
+int fz_sample_secret_polys_dev(fz_ctx *ctx, const uint64_t *h_seeds, size_t N, int64_t modulus, int degree, int64_t norm_bound,
+                               int64_t weight_bound, int32_t *d_out) {
+    FZ_REQUIRE(ctx && (N == 0 || (h_seeds && d_out)), "NULL argument");
+    FZ_REQUIRE(degree >= 1 && modulus >= 2, "bad degree / modulus");
+    FZ_DEV(ctx);
+    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the sampler uploads the seeds: not during graph capture");
+    const int64_t bound = std::max<int64_t>(0, std::min<int64_t>(modulus / 2, norm_bound));
+    if (bound < 1 || bound >= (1ll << 32)) return fz_set_error(FZ_E_BADARG, "empty range for randrange()");
+    if (weight_bound < degree)
+        return fz_set_error(FZ_E_UNSUPPORTED, "device sampler: weight bound = degree only (no shuffle); use fz_sample_secret_polys");
+    if (N == 0) return FZ_OK;
+    if (!ctx->d_mt_init) {
+        uint32_t tab[624];
+        fz_mt_init_table(tab);
+        FZ_HIP(hipMalloc((void **)&ctx->d_mt_init, sizeof(tab)), "sampler table alloc");
+        FZ_HIP(hipMemcpy(ctx->d_mt_init, tab, sizeof(tab), hipMemcpyHostToDevice), "sampler table upload");
+    }
+    int kbits = 0;
+    for (uint64_t t = (uint64_t)bound; t; t >>= 1) ++kbits;            // bound.bit_length()
+    void *scr = nullptr;
+    FZ_TRY(fz_scratch(ctx, N * 8 + 256, &scr));
+    int *d_fail = (int *)scr;
+    unsigned long long *d_seeds = (unsigned long long *)((uint8_t *)scr + 256);
+    FZ_HIP(hipMemsetAsync(d_fail, 0, 4, ctx->stream), "sampler flag");
+    FZ_HIP(hipMemcpyAsync(d_seeds, h_seeds, N * 8, hipMemcpyHostToDevice, ctx->stream), "upload of the seeds");
+    FZ_TRY(fz_launch_mt_sample(ctx, d_seeds, N, degree, (uint32_t)bound, kbits, ctx->d_mt_init, d_out, d_fail));
+    int fail = 0;
+    FZ_HIP(hipMemcpyAsync(&fail, d_fail, 4, hipMemcpyDeviceToHost, ctx->stream), "sampler flag read");
+    FZ_HIP(hipStreamSynchronize(ctx->stream), "sampler sync");
+    if (fail) return fz_set_error(FZ_E_UNSUPPORTED, "device sampler ran out of generator output for a seed; use fz_sample_secret_polys");
+    return FZ_OK;
 }
 
 // ---- launch-floor diagnostics ------------------------------------------------------------------------------

@@ -62,6 +62,7 @@ struct fz_ctx {
     size_t aggacc_tiles;
     int agg_dirty;
     int grid_multi[3];           // resident grid of the multi-job transform kernel per direction mix (0 = not queried yet)
+    uint32_t *d_mt_init;         // MT19937 state after init_genrand(19650218) (fz_sample_secret_polys_dev), lazily
     uint32_t *d_chal_tab;        // weight table of the challenge decoder (fz_challenge.hip), built on first use
     int chal_tab_ib, chal_tab_degree;
     // benchmarking knobs, read ONCE at context creation
@@ -106,6 +107,9 @@ struct fz_scheme_params;
 int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *d_pre, size_t N,
                         uint8_t *d_text, size_t text_stride, int *d_nblocks, uint32_t *d_xof, size_t xstride, int out_blocks,
                         const uint32_t *d_tab, int32_t *d_coefs);
+void fz_mt_init_table(uint32_t *h_tab);                                              // 624 words
+int fz_launch_mt_sample(fz_ctx *ctx, const unsigned long long *d_seeds, size_t nkeys, int degree, uint32_t bound, int kbits,
+                        const uint32_t *d_init, int32_t *d_out, int *d_fail);
 int fz_launch_prehash(fz_ctx *ctx, const fz_scheme_params *P, const uint8_t *d_msgs, const unsigned long long *d_off, size_t N,
                       uint8_t *d_pre);
 void fz_challenge_weight_table(int index_bytes, int degree, uint32_t *h_tab);      // (degree + 1) * 16 words

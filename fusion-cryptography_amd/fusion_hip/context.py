@@ -170,6 +170,13 @@ class Context:
         check(self._lib, fn(self._h, byref(P), c_void_p(d_vk), pre.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), N,
                             c_void_p(d_out)))
 
+    def sample_secret_polys_dev(self, seeds, modulus, degree, norm_bound, weight_bound, d_out):
+        """the two secret polynomials of keygen(params, seed) for every seed, sampled ON THE DEVICE by an exact MT19937
+        (fz_sample_secret_polys_dev): d_out [N][2][degree] int32 (device)"""
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        check(self._lib, self._lib.fz_sample_secret_polys_dev(self._h, sd.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), sd.size,
+                                                              modulus, degree, norm_bound, weight_bound, c_void_p(d_out)))
+
     def challenge_msgs_dev(self, P, d_vk, blob, offsets, N, d_out, want_prehash=False):
         """hash_ch on the device INCLUDING hash_message_to_int (fz_challenge_hat_msgs_dev): blob = the N messages' bytes back
         to back, offsets [N + 1] uintp (hostpipe._pack_messages); -> the [N][32] digests if want_prehash else None"""

@@ -23,6 +23,7 @@ class BatchScheme:
         self.d, self.l, self.q = params.degree, params.num_rows_sk, params.modulus
         self.ctx = get_context(params.modulus, params.degree, params.root, params.inv_root, device)
         self.device_hash = True          # per-signer challenge pipeline on the device (falls back to the host if unsupported)
+        self.device_sampler = True       # secret polynomials sampled on the device (the same fallback)
         self.A = np.array([z.values for row in params.public_challenge.matrix for z in row], dtype=np.int32)
 
     # ---- keygen ------------------------------------------------------------------------------------
@@ -38,16 +39,30 @@ class BatchScheme:
         keep_vk=True a third value is returned, the verification keys as a DeviceArray [N][2][d] (what sign_batch's
         device challenge pipeline reads: pass it as `vk` and the keys are not uploaded again).
         Sampling: the reference draws every entry of a secret matrix with the SAME seed (fusion.py:156-173),
-        so a matrix is one polynomial repeated l times; the polynomial itself comes from the C clone of
-        CPython's MT19937 `random` (hostpipe.sample_secret_polys, pinned against `random` in the tests).
+        so a matrix is one polynomial repeated l times; the polynomial itself comes from a clone of CPython's
+        MT19937 `random` -- on the device (self.device_sampler) or in C on the host (hostpipe.sample_secret_polys); both
+        are pinned against `random` in the tests.
         Unlike the reference this does not leave the process-global `random` generator re-seeded."""
         p = self.params
-        polys = hostpipe.sample_secret_polys([int(s) for s in seeds], p.modulus, p.degree, p.beta_sk, p.omega_sk,
-                                             self.threads)                       # [N][2][d]
-        n = polys.shape[0]
+        sd = np.array([int(s) for s in seeds], dtype=np.uint64)
+        n = sd.size
         # the reference's sampler yields ONE polynomial per (key, half) for all l rows (same seed for every matrix
-        # entry): upload it once and let the kernel reuse it -- 2 KiB per key instead of 166 KiB
-        coef = DeviceArray.from_numpy(self.ctx, polys)
+        # entry): 2 KiB per key instead of 166 KiB.  Sampled on the device (an exact MT19937 per lane, fz_sample.hip) when
+        # the parameter set allows (weight bound = degree), else by the C clone on the host threads and uploaded.
+        coef = None
+        if self.device_sampler:
+            coef = DeviceArray(self.ctx, (n, 2, self.d))
+            try:
+                self.ctx.sample_secret_polys_dev(sd, p.modulus, p.degree, p.beta_sk, p.omega_sk, coef.ptr)
+            except FusionHipError as e:
+                coef.free()
+                coef = None
+                if e.code != FZ_E_UNSUPPORTED:
+                    raise
+                self.device_sampler = False
+        if coef is None:
+            polys = hostpipe.sample_secret_polys(sd, p.modulus, p.degree, p.beta_sk, p.omega_sk, self.threads)   # [N][2][d]
+            coef = DeviceArray.from_numpy(self.ctx, polys)
         dA = DeviceArray.from_numpy(self.ctx, self.A)
         sk = DeviceArray(self.ctx, (n, 2, self.l, self.d))
         vk = DeviceArray(self.ctx, (n, 2, self.d))

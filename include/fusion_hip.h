@@ -358,6 +358,12 @@ FZ_API int fz_sample_coefficients(uint64_t seed, int64_t modulus, int degree, in
 /* the two distinct secret polynomials of keygen(params, seed) for N keys: [N][2][degree] */
 FZ_API int fz_sample_secret_polys(const uint64_t *h_seeds, size_t N, int64_t modulus, int degree,
                                   int64_t norm_bound, int64_t weight_bound, int32_t *h_out, int threads);
+/* The same on the DEVICE (csrc/fz_sample.hip): one lane per polynomial runs CPython's MT19937 exactly (init_by_array
+ * seeding, getrandbits, rejection) and writes d_out [N][2][degree] in device memory -- what fz_keygen_core_bcast reads, so
+ * the secret polynomials of keygen(params, seed) never exist on the host.  Supported: weight_bound >= degree (both parameter
+ * sets: no shuffle), any seeds < 2^64; else FZ_E_UNSUPPORTED.  Synchronous (it reads back a completion flag). */
+FZ_API int fz_sample_secret_polys_dev(fz_ctx *ctx, const uint64_t *h_seeds, size_t N, int64_t modulus, int degree,
+                                      int64_t norm_bound, int64_t weight_bound, int32_t *d_out);
 
 #ifdef __cplusplus
 }

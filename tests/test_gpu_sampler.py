@@ -1,0 +1,74 @@
+"""GPU parity of the device sampler (csrc/fz_sample.hip: CPython's MT19937 per lane) against
+ * CPython's own `random` driven exactly as the reference's sampler drives it (algebra/polynomials.py:436-467),
+ * the C clone on the host (fz_sample_secret_polys, itself pinned by the fusion_setup KAT rows),
+ * the reference's golden keys (tests/golden/scheme_*.npz) through keygen_batch.
+Reference: fusion/fusion.py:339-362 (seed for the left matrix, seed + 1 for the right one)."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _reference_poly(seed, degree, bound):
+    """sample_polynomial_coefficient_representation with weight bound = degree, on CPython's generator"""
+    rng = random.Random()
+    rng.seed(seed)
+    return [(1 + rng.randrange(bound)) * (1 - 2 * rng.randrange(2)) for _ in range(degree)]
+
+
+@pytest.mark.parametrize("degree,bound", [(256, 52), (64, 52), (256, 1), (16, 2**31 - 1), (100, 7)])
+def test_device_sampler_is_cpythons_mt19937(degree, bound):
+    import fusion_hip
+    from fusion_hip import hostpipe
+    P = O.PARAMS[256]
+    ctx = fusion_hip.get_context(P["q"], P["d"], P["root"], P["inv_root"])
+    q = 2**32 - 5 if bound > 2**30 else P["q"]          # the sampler's modulus only caps the bound at q // 2
+    seeds = [0, 1, 2, 42, 2**32 - 2, 2**32 - 1, 2**32, 2**32 + 1, 2**63 + 12345, 2**64 - 2, 987654321987654321]
+    seeds += [10_000 + 2 * i for i in range(150)]       # more than two waves; ragged last wave
+    n = len(seeds)
+    dout = fusion_hip.DeviceBuffer(ctx, n * 2 * degree * 4)
+    try:
+        ctx.sample_secret_polys_dev(seeds, q, degree, bound, degree, dout.ptr)
+        got = dout.to_numpy(np.int32, (n, 2, degree))
+        want = hostpipe.sample_secret_polys(seeds, q, degree, bound, degree)
+        assert np.array_equal(got, want)
+        for i in (0, 1, 4, 5, 6, 8, 9, 10, 11, n - 1):
+            for half in (0, 1):
+                assert got[i, half].tolist() == _reference_poly(seeds[i] + half, degree, min(bound, q // 2)), (seeds[i], half)
+    finally:
+        dout.free()
+
+
+def test_unsupported_shapes_fall_back(coracle):
+    import fusion_hip
+    P = O.PARAMS[256]
+    ctx = fusion_hip.get_context(P["q"], P["d"], P["root"], P["inv_root"])
+    dout = fusion_hip.DeviceBuffer(ctx, 4 * 2 * 256 * 4)
+    try:
+        with pytest.raises(fusion_hip.FusionHipError) as e:
+            ctx.sample_secret_polys_dev([1, 2], P["q"], 256, 52, 255, dout.ptr)      # weight < degree: a shuffle follows
+        from fusion_hip._lib import FZ_E_UNSUPPORTED
+        assert e.value.code == FZ_E_UNSUPPORTED
+    finally:
+        dout.free()
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_keygen_batch_with_the_device_sampler_equals_the_host_one(secpar):
+    import fusion.fusion as F
+    from fusion_hip.scheme import BatchScheme
+    params = F.fusion_setup(secpar, 42)
+    bs = BatchScheme(params)
+    seeds = [7, 8, 2**40 + 3] + list(range(100, 140))
+    assert bs.device_sampler
+    sk_d, vk_d = bs.keygen_batch(seeds)
+    assert bs.device_sampler                      # no fallback happened
+    bs.device_sampler = False
+    sk_h, vk_h = bs.keygen_batch(seeds)
+    assert np.array_equal(sk_d, sk_h) and np.array_equal(vk_d, vk_h)

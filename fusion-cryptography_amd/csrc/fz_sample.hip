@@ -50,10 +50,21 @@ __global__ __launch_bounds__(64) void mt_sample_kernel(const unsigned long long 
     }
     prev = (FZ_MT(1) ^ ((prev ^ (prev >> 30)) * 1664525u)) + (j ? key1 : key0) + j;      // mt[0] = mt[623] = prev
     FZ_MT(1) = prev;
-    // second loop (623 steps: i = 2..623, then i = 1 after the wrap)
-    for (int i = 2; i < kMtN; ++i) {
-        prev = (FZ_MT(i) ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
-        FZ_MT(i) = prev;
+    // second loop (623 steps: i = 2..623, then i = 1 after the wrap).  The words it reads are the first loop's: eight are
+    // requested ahead of the eight dependent steps that use them (the compiler cannot move an LDS load above the previous
+    // step's store by itself; one load latency per step would double the chain)
+    constexpr int U = 8;
+    for (int i0 = 2; i0 < kMtN; i0 += U) {
+        uint32_t m[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) m[u] = FZ_MT(i0 + u < kMtN ? i0 + u : kMtN - 1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u < kMtN) {
+                prev = (m[u] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i0 + u);
+                FZ_MT(i0 + u) = prev;
+            }
+        }
     }
     prev = (FZ_MT(1) ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
     FZ_MT(1) = prev;
@@ -63,38 +74,46 @@ __global__ __launch_bounds__(64) void mt_sample_kernel(const unsigned long long 
     uint32_t mag = 0;                        // 0: the next accepted draw is a magnitude; else its sign
     bool done = false;
     int32_t *row = out + p * (size_t)degree;
+    static_assert(kMtN % U == 0, "chunks of 8 words");
     for (int gen = 0; gen < kMaxGenerations; ++gen) {
-        // regenerate all 624 words in place (genrand_uint32's refill), every lane its own column
-        uint32_t cur = FZ_MT(0);
-        for (int k = 0; k < kMtN - 1; ++k) {
-            const uint32_t nxt = FZ_MT(k + 1);
-            const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
-            const int kk = k + kMtM < kMtN ? k + kMtM : k + kMtM - kMtN;
-            FZ_MT(k) = FZ_MT(kk) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-            cur = nxt;
-        }
-        {
-            const uint32_t y = (cur & 0x80000000u) | (FZ_MT(0) & 0x7fffffffu);         // mt[0] is already the new one
-            FZ_MT(kMtN - 1) = FZ_MT(kMtM - 1) ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        }
-        for (int r = 0; r < kMtN; ++r) {
-            const uint32_t y = mt_temper(FZ_MT(r));
-            if (!done) {
-                if (mag == 0) {
-                    const uint32_t v = y >> (32 - kbits);                  // getrandbits(kbits), kept if below the bound
-                    if (v < bound) mag = v + 1u;
-                } else {
-                    const uint32_t s = y >> 30;                            // randrange(2): getrandbits(2), kept if < 2
-                    if (s < 2u) {
-                        if (live) row[t] = s ? -(int32_t)mag : (int32_t)mag;       // (1 + r1) * (1 - 2 * r2)
-                        mag = 0;
-                        done = ++t == degree;
-                    }
-                }
+        // regenerate all 624 words in place (genrand_uint32's refill), every lane its own column.  Word k needs the OLD
+        // words k and k + 1 and word k + 397 (old below k = 227, else the new word k - 227, written 227 steps earlier; the
+        // last step reads the new word 0): a chunk of 8 steps can read all its 17 inputs before its first store.
+        for (int k0 = 0; k0 < kMtN; k0 += U) {
+            uint32_t a[U + 1], b[U];
+#pragma unroll
+            for (int u = 0; u <= U; ++u) a[u] = FZ_MT(k0 + u < kMtN ? k0 + u : 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = k0 + u + kMtM;
+                b[u] = FZ_MT(kk < kMtN ? kk : kk - kMtN);
             }
-            if ((r & 15) == 15 && __all(done)) return;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t y = (a[u] & 0x80000000u) | (a[u + 1] & 0x7fffffffu);
+                FZ_MT(k0 + u) = b[u] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
         }
-        if (__all(done)) return;
+        for (int r0 = 0; r0 < kMtN; r0 += U) {
+            uint32_t ys[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) ys[u] = FZ_MT(r0 + u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t y = mt_temper(ys[u]);
+                const uint32_t v = y >> (32 - kbits), sg = y >> 30;
+                // getrandbits(kbits) kept if below the bound, then randrange(2) = getrandbits(2) kept if < 2
+                const bool take_sign = !done && mag != 0 && sg < 2u;
+                const bool take_mag = !done && mag == 0 && v < bound;
+                if (take_sign) {
+                    if (live) row[t] = sg ? -(int32_t)mag : (int32_t)mag;          // (1 + r1) * (1 - 2 * r2)
+                    ++t;
+                    done = t == degree;
+                }
+                mag = take_sign ? 0u : (take_mag ? v + 1u : mag);
+            }
+            if ((r0 & 8) && __all(done)) return;
+        }
     }
     if (!done && live) atomicOr(fail, 1);    // never seen: the caller falls back to the host sampler
 #undef FZ_MT

@@ -6,6 +6,7 @@ missing every compute entry point raises :class:`FusionHipError`.
 """
 import ctypes
 import os
+import sys
 from ctypes import (POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t,
                     c_uint32, c_uint64, c_void_p)
 
@@ -159,6 +160,28 @@ SIGNATURES.update({
 _lib = None
 
 
+def _prefer_torch_hip_runtime():
+    """A torch wheel carries its own libamdhip64 / libhsa-runtime64 (same sonames as /opt/rocm's) and maps them by path, so
+    a process that loaded libfusion_hip.so FIRST (against /opt/rocm) ends up with two HIP runtimes, and the second one
+    finds no GPU (`import fusion_hip; ...; import torch; torch.cuda...` -> "No HIP GPUs are available").  If torch is
+    installed but not imported yet, map ITS copies first: libfusion_hip.so then binds to them by soname and a later
+    `import torch` finds its runtime already alive.  FZ_HIP_RUNTIME=system keeps /opt/rocm's (no torch in the process)."""
+    if "torch" in sys.modules or os.environ.get("FZ_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        d = os.path.join(os.path.dirname(spec.origin), "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            f = os.path.join(d, name)
+            if os.path.exists(f):
+                ctypes.CDLL(f, mode=ctypes.RTLD_GLOBAL)
+    except Exception:      # noqa: BLE001 - any failure here leaves the system runtime, which is the default anyway
+        pass
+
+
 def load_library(path=None):
     """Load (once) and return the ctypes handle; raise FusionHipError if it is not built."""
     global _lib
@@ -169,6 +192,7 @@ def load_library(path=None):
         raise FusionHipError(FZ_E_NODEVICE,
                              f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(there is no CPU fallback)")
+    _prefer_torch_hip_runtime()
     try:
         lib = ctypes.CDLL(p)
     except OSError as e:  # pragma: no cover - depends on the machine

@@ -28,6 +28,6 @@ order = T("sort_by_vk_string", lambda: hostpipe.sort_by_vk_string(bs.P, L, Rr, b
 Ls, Rs = T("permute keys (numpy)", lambda: (L[order], Rr[order]))
 ms = [msgs[i] for i in order]
 c_hat, pre = T("challenges (device pipeline + copies)", lambda: bs.challenges(np.stack([Ls, Rs], axis=1), ms))
-for thr in (1, 8, bs.threads):
+for thr in (1, 2, 3, 4, 8, bs.threads, 1, 4):
     al = T(f"aggregation_coefficients, {thr} threads", lambda: hostpipe.aggregation_coefficients(bs.P, Ls, Rs, pre, c_hat, thr))
 T("ntt_forward(alpha) host face", lambda: bs.ctx.ntt_forward(al))

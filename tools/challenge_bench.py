@@ -10,6 +10,8 @@ for p in (os.path.join(ROOT, "fusion-cryptography_amd"), ROOT):
 import numpy as np
 import fusion.fusion as F
 import fusion_hip
+from fusion_hip.numa import pin_to_gpu_node
+pin_to_gpu_node(0)          # host threads on the GPU's NUMA node (before the first HIP call)
 from fusion_hip import hostpipe
 
 

@@ -14,9 +14,14 @@ lscpu | grep -E "Model name|Socket|Thread|Core" > $OUT/${TAG}_host_cpu.txt
 step timeout -k 10 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
 step timeout -k 10 120 ./tools/microbench/build/launch_floor > $OUT/${TAG}_launch_floor.txt 2>&1
 step timeout -k 10 300 python tools/kernel_table.py > $OUT/${TAG}_kernel_table.txt 2>&1
+step timeout -k 10 300 python tools/kernel_table.py --secpar 128 > $OUT/${TAG}_kernel_table_secpar128.txt 2>&1
 step timeout -k 10 300 python tools/agg_tune.py --twopass > $OUT/${TAG}_aggregate_shapes.txt 2>&1
 step timeout -k 10 200 python tools/ntt_ab.py > $OUT/${TAG}_ntt_small_batches.txt 2>&1
 step timeout -k 10 200 python tools/challenge_bench.py > $OUT/${TAG}_challenge_pipeline.txt 2>&1
+step timeout -k 10 200 python tools/keygen_probe.py > $OUT/${TAG}_keygen_end_to_end.txt 2>&1
+step timeout -k 10 200 python tools/agg_probe.py > $OUT/${TAG}_aggregate_end_to_end.txt 2>&1
+step timeout -k 10 200 python tools/copy_bw.py > $OUT/${TAG}_copy_ceiling.txt 2>&1
+step timeout -k 10 200 python tools/dispatch_dist.py > $OUT/${TAG}_dispatch_distribution.txt 2>&1
 step timeout -k 10 500 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations from the profiler: the bench's transform launches, the cold kernel table, the challenge pipeline
@@ -33,6 +38,13 @@ for set in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU"; do
   step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc20/$n -- python3 $R/tools/prof_ntt.py 20 30 > $OUT/pmc20_$n.log 2>&1
   step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcs/$n -- python3 $R/tools/prof_scheme.py 12 > $OUT/pmcs_$n.log 2>&1
 done
+# where the waves' cycles go (issue, stalls, LDS): two SQ counter sets over the cold scheme kernels
+step timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/sq1 -- python3 $R/tools/prof_scheme.py 6 > $OUT/sq1.log 2>&1
+step timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq2 -- python3 $R/tools/prof_scheme.py 6 > $OUT/sq2.log 2>&1
 cd $R
+python3 tools/pmc_stalls.py $OUT/sq1/*/*counter_collection.csv $OUT/sq2/*/*counter_collection.csv > $OUT/${TAG}_wave_cycles.txt
+python3 tools/trace_summary.py $OUT/prof/*/*_kernel_trace.csv > $OUT/${TAG}_bench_rocprofv3_by_grid.csv 2>/dev/null
+python3 tools/trace_summary.py $OUT/profk/*/*_kernel_trace.csv > $OUT/${TAG}_kernel_table_rocprofv3_by_grid.csv 2>/dev/null
+python3 tools/trace_summary.py $OUT/profc/*/*_kernel_trace.csv > $OUT/${TAG}_challenge_rocprofv3_by_grid.csv 2>/dev/null
 step python3 tools/pmc_summary.py $OUT $TAG > /dev/null
 echo collected into $OUT

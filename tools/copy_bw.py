@@ -3,6 +3,8 @@ import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, "fusion-cryptography_amd")); sys.path.insert(0, R)
 import fusion_hip
+from fusion_hip.numa import pin_to_gpu_node
+pin_to_gpu_node(0)          # host threads on the GPU's NUMA node (before the first HIP call)
 from oracle import oracle as O
 P = O.PARAMS[256]
 ctx = fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"])

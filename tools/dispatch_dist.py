@@ -4,10 +4,22 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, "fusion-cryptography_amd")); sys.path.insert(0, R)
 import numpy as np
 import fusion_hip
+from fusion_hip.numa import pin_to_gpu_node
+pin_to_gpu_node(0)          # host threads on the GPU's NUMA node (before the first HIP call)
 from oracle import oracle as O
 P = O.PARAMS[256]
+mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
 ctx = fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"])
-s = ctx.stream_create(); ctx.set_stream(s)
+if mode in ("torch_stream", "torch_import"):
+    import torch
+    torch.cuda.set_device(0)
+    if mode == "torch_stream":
+        ts = torch.cuda.Stream(torch.device("cuda", 0)); torch.cuda.set_stream(ts); ctx.set_stream(ts.cuda_stream)
+    else:
+        torch.zeros(8, device="cuda"); s = ctx.stream_create(); ctx.set_stream(s)
+else:
+    s = ctx.stream_create(); ctx.set_stream(s)
+print("mode", mode)
 B, d = 4096, 256
 DB = fusion_hip.DeviceBuffer
 x, y, z = DB(ctx, B * d * 4), DB(ctx, B * d * 4), DB(ctx, B * d * 4)
@@ -21,8 +33,7 @@ def busy(ms):
     while time.perf_counter() < te:
         for _ in range(50): step()
         ctx.synchronize()
-mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
-for p in range(6):
+for p in range(4):
     busy(150 if p == 0 else 20)
     n = 400
     ctx.profile_begin(2 * n, 1)

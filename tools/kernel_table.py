@@ -131,6 +131,8 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
 
 def main():
     import fusion_hip
+    from fusion_hip.numa import pin_to_gpu_node
+    pin_to_gpu_node(0)                      # host threads on the GPU's NUMA node (before the first HIP call)
     from oracle import oracle as O      # parameters only (tools/ is not product code)
     P = O.PARAMS[int(sys.argv[sys.argv.index("--secpar") + 1]) if "--secpar" in sys.argv else 256]
     ctx = fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"])

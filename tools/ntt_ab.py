@@ -1,6 +1,8 @@
 import sys, os, time
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "fusion-cryptography_amd")); sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import fusion_hip
+from fusion_hip.numa import pin_to_gpu_node
+pin_to_gpu_node(0)          # host threads on the GPU's NUMA node (before the first HIP call)
 from oracle import oracle as O
 import numpy as np
 P = O.PARAMS[256]

@@ -3,7 +3,7 @@ import collections, csv, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0][-60:] + " grid=" + r.get("Grid_Size", "?")
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:] + " grid=" + r.get("Grid_Size", "?")
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     m = {c: sum(v) / len(v) for c, v in cs.items()}

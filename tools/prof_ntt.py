@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import fusion_hip
+from fusion_hip.numa import pin_to_gpu_node
+pin_to_gpu_node(0)          # host threads on the GPU's NUMA node (before the first HIP call)
 from oracle import oracle as O
 
 logB = int(sys.argv[1]) if len(sys.argv) > 1 else 20

@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "fusion-cryptography_amd"), ROOT):
     sys.path.insert(0, p)
 import fusion_hip
+from fusion_hip.numa import pin_to_gpu_node
+pin_to_gpu_node(0)          # host threads on the GPU's NUMA node (before the first HIP call)
 from oracle import oracle as O
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12

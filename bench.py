@@ -194,8 +194,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)                         # before anything in this process touches a GPU
 
-    # host threads on the GPU's NUMA node, before anything initialises the GPU (sysfs + sched_setaffinity only): from the far
-    # socket a launch costs the host 6 % more and the device-side begin -> end of a 4096-row launch 4 % more
+    # host threads on ONE NUMA node (the GPU's), before anything initialises the GPU (sysfs + sched_setaffinity only): a
+    # launching thread the scheduler moves to the other socket after initialisation launches at 5.1-7.5 us per dispatch
+    # instead of 4.4-4.8 (profiles/r02_numa_placement.txt) -- the run-to-run spread of roofline.frac before this
     from fusion_hip.numa import pin_to_gpu_node
     placement = pin_to_gpu_node(int(os.environ.get("LOCAL_RANK", "0")))
 

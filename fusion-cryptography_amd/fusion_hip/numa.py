@@ -1,11 +1,13 @@
-"""Host-thread placement: run on the CPUs of the NUMA node the GPU hangs off.
+"""Host-thread placement: keep the process on the CPUs of ONE NUMA node -- the one the GPU hangs off.
 
-A dispatch is a doorbell write from the launching core and a completion signal the command processor writes back; from the
-far socket of a two-socket host both cross the inter-socket link: measured on an MI355X box, the same 4096-row transform
-launch is 4.44 us (begin -> end) and 9.6 us of host time per launch from the GPU's node, 4.64 us / 10.2 us from the other
-one (profiles/r02_numa_placement.txt).  Nothing here touches the GPU: it reads sysfs (KFD topology -> PCI address -> node)
-and calls sched_setaffinity, so it can -- and should -- run before the first HIP call (the runtime's own threads inherit
-the affinity they are created under)."""
+A dispatch is a doorbell write from the launching core and a completion signal the command processor writes back.  On a
+two-socket MI355X host the same 4096-row transform launch measures 4.4-4.8 us (begin -> end) and 9.6-10.4 us of host time
+per launch while the launching thread stays on the socket the runtime was initialised on, and 5.1-7.5 us / 11.6-14 us once
+the scheduler has moved it to the other socket (profiles/r02_numa_placement.txt): an unpinned benchmark is bimodal from
+run to run.  WHICH node is second order (+-3 %, and not always in favour of the GPU's own node); the GPU's node is the
+principled choice.  Nothing here touches the GPU: it reads sysfs (KFD topology -> PCI address -> node) and calls
+sched_setaffinity, so it can -- and should -- run before the first HIP call (the runtime's own threads inherit the
+affinity they are created under)."""
 import glob
 import os
 

@@ -353,3 +353,18 @@ def test_bench_starts_its_own_ranks_and_fails_loudly_without_gpus():
     assert r.returncode != 0
     assert '{"metric"' not in r.stdout
     assert "rank" in r.stderr and "no result" in r.stderr
+
+
+def test_numa_helper_is_harmless_without_a_gpu(monkeypatch):
+    """fusion_hip.numa reads sysfs only: no KFD topology here -> no GPU nodes, nothing pinned, affinity untouched"""
+    import os
+    from fusion_hip import numa
+    assert numa._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert numa._cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    if not os.path.isdir("/sys/class/kfd/kfd/topology/nodes"):
+        assert numa.gpu_numa_nodes() == []
+        assert numa.pin_to_gpu_node(0) is None
+    monkeypatch.setenv("FZ_NO_PIN", "1")
+    assert numa.pin_to_gpu_node(0) is None
+    assert os.sched_getaffinity(0) == before

@@ -22,6 +22,8 @@ step timeout -k 10 200 python tools/keygen_probe.py > $OUT/${TAG}_keygen_end_to_
 step timeout -k 10 200 python tools/agg_probe.py > $OUT/${TAG}_aggregate_end_to_end.txt 2>&1
 step timeout -k 10 200 python tools/copy_bw.py > $OUT/${TAG}_copy_ceiling.txt 2>&1
 step timeout -k 10 200 python tools/dispatch_dist.py > $OUT/${TAG}_dispatch_distribution.txt 2>&1
+step timeout -k 10 300 python tools/numa_placement.py > $OUT/${TAG}_numa_placement.txt 2>&1
+for st in none 0 1; do FZ_NO_PIN=1 timeout -k 10 100 python tools/numa_switch.py $st >> $OUT/${TAG}_numa_placement.txt 2>&1; done
 step timeout -k 10 500 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations from the profiler: the bench's transform launches, the cold kernel table, the challenge pipeline

@@ -1291,7 +1291,9 @@ int fz_launch_diag(fz_ctx *ctx, int what, const void *src, void *dst, size_t byt
     } else {
         const size_t n16 = bytes / 16;
         if (n16 == 0) return FZ_OK;
-        const size_t blocks = (n16 + 63) / 64, cap = (size_t)ctx->num_cu * 32;
+        // flat grid, one 16-byte item per thread: a capped grid-stride loop streams 1 GiB at 4.9-5.5 TB/s, the flat grid at
+        // 6.2 TB/s (profiles/r02_launch_floor.txt) -- the ceiling this kernel exists to show
+        const size_t blocks = (n16 + 63) / 64, cap = (size_t)0x7fffffff;
         hipLaunchKernelGGL(diag_copy_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(64), 0, ctx->stream,
                            (const int4 *)src, (int4 *)dst, n16);
     }

@@ -12,6 +12,9 @@
 
 namespace {
 
+typedef int fz_v4i __attribute__((ext_vector_type(4)));      // 16-byte vector the non-temporal builtins accept
+
+
 constexpr int kBlock = 256;
 
 __device__ __forceinline__ int cent_i32(double x, const FzMod m) { return (int)fz_cent(x, m); }
@@ -32,7 +35,7 @@ __device__ __forceinline__ int pw_op(int a, int b, int acc, const FzMod m) {
 
 template <int OP>
 __global__ __launch_bounds__(kBlock) void pw_kernel(const int32_t *a, const int32_t *b, int32_t *out,
-                                                    size_t count, int vec, FzMod m) {
+                                                    size_t count, int vec, FzMod m, int nt) {
     const size_t n4 = vec ? count / 4 : 0;   // vec == 0: pointers not 16-byte aligned, all scalar
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -48,7 +51,12 @@ __global__ __launch_bounds__(kBlock) void pw_kernel(const int32_t *a, const int3
         o.y = pw_op<OP>(x.y, y.y, z.y, m);
         o.z = pw_op<OP>(x.z, y.z, z.z, m);
         o.w = pw_op<OP>(x.w, y.w, z.w, m);
-        o4[i] = o;
+        if (nt && OP != FZ_OP_MULACC) {
+            const fz_v4i t = {o.x, o.y, o.z, o.w};
+            __builtin_nontemporal_store(t, reinterpret_cast<fz_v4i *>(o4 + i));
+        } else {
+            o4[i] = o;
+        }
     }
     // ragged tail (count not a multiple of 4) or the whole range when unaligned
     for (size_t i = n4 * 4 + gid; i < count; i += stride) {
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void matvec_scalar_kernel(const int32_t *A,
 
 // sig[b][k][j] = cent(cent(L[b][k][j] * c[b][j]) + R[b][k][j]); sk_hat = [batch][2][l][degree]
 __global__ __launch_bounds__(kBlock) void sign_kernel(const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig,
-                                                      size_t batch, int l, int degree, FzMod m) {
+                                                      size_t batch, int l, int degree, FzMod m, int nt) {
     const int d4 = degree / 4;
     const size_t per_sig = (size_t)l * d4;
     const size_t total = batch * per_sig;
@@ -179,7 +187,12 @@ __global__ __launch_bounds__(kBlock) void sign_kernel(const int32_t *sk_hat, con
         o.y = cent_i32(fz_mulmod((double)x.y, (double)c.y, m) + (double)y.y, m);
         o.z = cent_i32(fz_mulmod((double)x.z, (double)c.z, m) + (double)y.z, m);
         o.w = cent_i32(fz_mulmod((double)x.w, (double)c.w, m) + (double)y.w, m);
-        reinterpret_cast<int4 *>(sig)[i] = o;
+        if (nt) {
+            const fz_v4i t = {o.x, o.y, o.z, o.w};
+            __builtin_nontemporal_store(t, reinterpret_cast<fz_v4i *>(sig) + i);
+        } else {
+            reinterpret_cast<int4 *>(sig)[i] = o;
+        }
     }
 }
 
@@ -603,11 +616,11 @@ int fz_launch_pw(fz_ctx *ctx, int op, const int32_t *a, const int32_t *b, int32_
     const int vec = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0) ? 1 : 0;
     const unsigned grid = grid_for(ctx, vec ? count / 4 + 4 : count);
     switch (op) {
-        case FZ_OP_MUL: hipLaunchKernelGGL(pw_kernel<FZ_OP_MUL>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
-        case FZ_OP_ADD: hipLaunchKernelGGL(pw_kernel<FZ_OP_ADD>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
-        case FZ_OP_SUB: hipLaunchKernelGGL(pw_kernel<FZ_OP_SUB>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
-        case FZ_OP_NEG: hipLaunchKernelGGL(pw_kernel<FZ_OP_NEG>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, a, out, count, vec, ctx->mod); break;
-        case FZ_OP_MULACC: hipLaunchKernelGGL(pw_kernel<FZ_OP_MULACC>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
+        case FZ_OP_MUL: hipLaunchKernelGGL(pw_kernel<FZ_OP_MUL>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod, ctx->knob_stream_nt); break;
+        case FZ_OP_ADD: hipLaunchKernelGGL(pw_kernel<FZ_OP_ADD>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod, ctx->knob_stream_nt); break;
+        case FZ_OP_SUB: hipLaunchKernelGGL(pw_kernel<FZ_OP_SUB>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod, ctx->knob_stream_nt); break;
+        case FZ_OP_NEG: hipLaunchKernelGGL(pw_kernel<FZ_OP_NEG>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, a, out, count, vec, ctx->mod, ctx->knob_stream_nt); break;
+        case FZ_OP_MULACC: hipLaunchKernelGGL(pw_kernel<FZ_OP_MULACC>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod, ctx->knob_stream_nt); break;
         default: return fz_set_error(FZ_E_BADARG, "unknown pointwise op %d", op);
     }
     return fz_check_hip(hipGetLastError(), "pointwise launch");
@@ -647,7 +660,7 @@ int fz_launch_sign(fz_ctx *ctx, const int32_t *sk_hat, const int32_t *c_hat, int
     }
     const size_t total = batch * (size_t)l * (ctx->degree / 4);
     hipLaunchKernelGGL(sign_kernel, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream, sk_hat, c_hat, sig, batch,
-                       l, ctx->degree, ctx->mod);
+                       l, ctx->degree, ctx->mod, ctx->knob_stream_nt);
     return fz_check_hip(hipGetLastError(), "sign launch");
 }
 

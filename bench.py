@@ -205,7 +205,7 @@ def main():
     import torch.distributed as dist
     import fusion_hip
     from fusion_hip.dist import allreduce_sum_i64, shard_range
-    from oracle import oracle as O
+    import fusion.fusion as F                     # the drop-in's parameter sets (the oracle is the CPU baseline's only)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -229,7 +229,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    P = O.PARAMS[SECPAR]
+    ps = F.PREFIX_PARAMETERS[SECPAR]
+    P = {"q": ps["modulus"], "d": ps["degree"], "root": ps["root"], "inv_root": ps["inv_root"], "rank": ps["num_rows_sk"],
+         "omega_ch": ps["omega_ch"], "omega_ag": ps["omega_ag"], "capacity": ps["capacity"], "beta_vf": ps["beta_vf"]}
     q, d, l = P["q"], P["d"], P["rank"]
     ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
     # a non-default stream, made torch's current one: graph capture needs it, and torch ops / RCCL order on it too
@@ -265,8 +267,11 @@ def main():
         dist.all_gather_object(ranks, me)
 
     # ---- NTT workload: inputs resident in HBM --------------------------------------------------
-    x_host = O.splitmix_centered(20261003 + rank, B * d).reshape(B, d)
-    x = torch.from_numpy(x_host).to(dev)
+    # i.i.d. uniform centred residues, seeded per rank, generated where they are consumed (fz_fill_synthetic: the stream the
+    # tests' host generator produces)
+    x = torch.empty((B, d), dtype=torch.int32, device=dev)
+    ctx.fill_synthetic_dev(x.data_ptr(), B * d, 20261003 + rank)
+    torch.cuda.synchronize(dev)
     y = torch.empty_like(x)
     z = torch.empty_like(x)
 
@@ -610,7 +615,7 @@ def main():
     stage[0] = "pcie"
     if rank == 0:
         try:
-            hx = x_host.copy()
+            hx = x.cpu().numpy().copy()
             ctx.ntt_forward(hx[:64])
             t0 = time.perf_counter()
             reps = 5
@@ -686,7 +691,8 @@ def main():
             S, GROUPS, NSETS = 1024, 4, 8            # per rank: 1024 signatures in 4 aggregates of 256 x world; 8 operand sets
             per = S // GROUPS
             rng = np.random.default_rng(1234 + rank)
-            A = torch.from_numpy(O.splitmix_centered(99, l * d).reshape(l, d)).to(dev)      # same on every rank
+            A = torch.empty((l, d), dtype=torch.int32, device=dev)                           # same on every rank
+            ctx.fill_synthetic_dev(A.data_ptr(), l * d, 99)
             coef0 = torch.from_numpy(rng.integers(1, 53, size=(S, 2, l, d)).astype(np.int32) *
                                      rng.choice(np.array([-1, 1], dtype=np.int32), size=(S, 2, l, d))).to(dev)
 

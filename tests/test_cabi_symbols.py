@@ -80,6 +80,28 @@ def test_product_never_imports_the_oracle():
                 assert "fz_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
 
 
+def test_bench_touches_the_oracle_in_its_cpu_baseline_leg_only():
+    """bench.py: every import of `oracle` sits inside _cpu_worker (the cpu_baseline leg); the measured path takes its
+    parameters from the drop-in package and its inputs from fz_fill_synthetic"""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    inside = set()
+    for fn in ast.walk(tree):
+        if isinstance(fn, ast.FunctionDef) and fn.name == "_cpu_worker":
+            inside = {id(n) for n in ast.walk(fn)}
+    found = 0
+    for n in ast.walk(tree):
+        names = []
+        if isinstance(n, ast.ImportFrom):
+            names = [n.module or ""]
+        elif isinstance(n, ast.Import):
+            names = [a.name for a in n.names]
+        if any(x == "oracle" or x.startswith("oracle.") for x in names):
+            found += 1
+            assert id(n) in inside, f"bench.py imports the oracle outside _cpu_worker (line {n.lineno})"
+    assert found >= 1
+
+
 def build_c_example(tmp_path):
     """gcc (not hipcc), strict C99: the header is plain C and the library links without HIP on the caller's side"""
     exe = os.path.join(str(tmp_path), "roundtrip")

@@ -135,3 +135,27 @@ def test_messages_hashed_on_the_device(secpar, coracle):
     finally:
         dvk.free()
         dout.free()
+
+
+def test_message_entry_rejects_bad_arguments():
+    import fusion_hip
+    from fusion_hip._lib import FZ_E_BADARG
+    params, P, ctx = _setup(256)
+    d = params.degree
+    dvk = fusion_hip.DeviceBuffer(ctx, 2 * 2 * d * 4)
+    dout = fusion_hip.DeviceBuffer(ctx, 2 * d * 4)
+    ctx.h2d(dvk.ptr, np.zeros((2, 2, d), np.int32))
+    try:
+        with pytest.raises(fusion_hip.FusionHipError) as e:
+            ctx.challenge_msgs_dev(P, dvk.ptr, b"abcdef", np.array([0, 4, 2], dtype=np.uintp), 2, dout.ptr)     # offsets decrease
+        assert e.value.code == FZ_E_BADARG
+        with pytest.raises(fusion_hip.FusionHipError):
+            ctx.challenge_msgs_dev(P, dvk.ptr, b"abcdef", np.array([0, 4], dtype=np.uintp), 2, dout.ptr)        # N + 1 offsets needed
+        # empty batch and all-empty messages are fine
+        assert ctx.challenge_msgs_dev(P, dvk.ptr, b"", np.array([0], dtype=np.uintp), 0, dout.ptr) is None
+        pre = ctx.challenge_msgs_dev(P, dvk.ptr, b"", np.array([0, 0, 0], dtype=np.uintp), 2, dout.ptr, want_prehash=True)
+        import hashlib
+        assert bytes(pre[0]) == bytes(pre[1]) == hashlib.sha3_256(bytes(P.sign_pre_hash_dst) + b",").digest()
+    finally:
+        dvk.free()
+        dout.free()

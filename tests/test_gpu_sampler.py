@@ -72,3 +72,18 @@ def test_keygen_batch_with_the_device_sampler_equals_the_host_one(secpar):
     bs.device_sampler = False
     sk_h, vk_h = bs.keygen_batch(seeds)
     assert np.array_equal(sk_d, sk_h) and np.array_equal(vk_d, vk_h)
+
+
+def test_sampler_argument_checks():
+    import fusion_hip
+    from fusion_hip._lib import FZ_E_BADARG
+    P = O.PARAMS[256]
+    ctx = fusion_hip.get_context(P["q"], P["d"], P["root"], P["inv_root"])
+    dout = fusion_hip.DeviceBuffer(ctx, 2 * 2 * 64 * 4)
+    try:
+        with pytest.raises(fusion_hip.FusionHipError) as e:
+            ctx.sample_secret_polys_dev([1, 2], P["q"], 64, 0, 64, dout.ptr)         # randrange(0): empty range
+        assert e.value.code == FZ_E_BADARG
+        ctx.sample_secret_polys_dev([], P["q"], 64, 52, 64, dout.ptr)                 # empty batch: nothing to do
+    finally:
+        dout.free()

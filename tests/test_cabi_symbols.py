@@ -102,18 +102,19 @@ def test_bench_touches_the_oracle_in_its_cpu_baseline_leg_only():
     assert found >= 1
 
 
-def build_c_example(tmp_path):
+def build_c_example(tmp_path, name="roundtrip"):
     """gcc (not hipcc), strict C99: the header is plain C and the library links without HIP on the caller's side"""
-    exe = os.path.join(str(tmp_path), "roundtrip")
+    exe = os.path.join(str(tmp_path), name)
     libdir = os.path.join(ROOT, "fusion-cryptography_amd", "lib")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "roundtrip.c"), "-o", exe, "-L", libdir, "-lfusion_hip",
+                           os.path.join(ROOT, "examples", name + ".c"), "-o", exe, "-L", libdir, "-lfusion_hip",
                            "-Wl,-rpath," + libdir])
     return exe
 
 
-def test_c_caller_compiles_and_fails_loudly_without_a_device(lib, tmp_path):
-    exe = build_c_example(tmp_path)
+@pytest.mark.parametrize("name", ["roundtrip", "scheme_flow"])
+def test_c_caller_compiles_and_fails_loudly_without_a_device(lib, tmp_path, name):
+    exe = build_c_example(tmp_path, name)
     n = ctypes.c_int(-1)
     if lib.fz_device_count(ctypes.byref(n)) == 0 and n.value > 0:
         pytest.skip("a GPU is present (tests/test_gpu_ntt.py runs the example there)")

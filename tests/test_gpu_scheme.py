@@ -366,3 +366,13 @@ def test_many_aggregates_per_launch_one_workgroup_each(secpar, G, coracle):
         for b in (dA, dsig, dt, dv):
             b.free()
         ctx.close()
+
+
+def test_c_caller_runs_the_whole_scheme_flow(tmp_path):
+    """examples/scheme_flow.c: keygen (device sampler) -> sign (device challenge pipeline) -> aggregate (host hash_ag) ->
+    verify through the C ABI alone, from strict C99; exit code 0 = accepted, and the tampered aggregate rejected"""
+    import subprocess
+    from test_cabi_symbols import build_c_example
+    r = subprocess.run([build_c_example(tmp_path, "scheme_flow")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "verdict 0 (0 = accepted), tampered aggregate: verdict 3" in r.stdout

@@ -57,7 +57,7 @@ while time.time() < t_end:
     ctx = ctxs[(sp, kern)]
     other = ctxs[(sp, str(rng.choice(["", "4", "16"])))]
     rows = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 257, 1000, 4099, int(rng.integers(1, 20000))]))
-    what = rng.choice(["ntt", "polymul", "scheme", "graph", "pointwise", "small", "batch_api", "multi", "challenge"])
+    what = rng.choice(["ntt", "polymul", "scheme", "graph", "pointwise", "small", "batch_api", "multi", "challenge", "sampler"])
     raw = rng.random() < 0.3
     x = (rng.integers(-2**31, 2**31, size=(rows, d), dtype=np.int64).astype(np.int32) if raw
          else O.splitmix_centered(int(rng.integers(1, 2**40)), rows * d).reshape(rows, d))
@@ -99,6 +99,20 @@ while time.time() < t_end:
         for b in keep:
             b.free()
         bump("multi")
+    elif what == "sampler":
+        # device MT19937 sampler == the C clone on the host (itself pinned by CPython's random), any seed / bound / degree
+        from fusion_hip import hostpipe
+        nn = int(rng.choice([1, 2, 31, 32, 33, 64, 65, int(rng.integers(1, 300))]))
+        deg = int(rng.choice([4, 16, 64, 100, 256]))
+        bound = int(rng.choice([1, 2, 52, 1000, 2**20 + 7, q // 2]))
+        seeds = [int(v) for v in rng.integers(0, 2**63, size=nn, dtype=np.uint64)]
+        if rng.random() < 0.5:
+            seeds = [v % 2**32 for v in seeds]                                # one-word keys
+        do = DB(ctx, nn * 2 * deg * 4)
+        ctx.sample_secret_polys_dev(seeds, q, deg, bound, deg, do.ptr)
+        assert np.array_equal(do.to_numpy(np.int32, (nn, 2, deg)), hostpipe.sample_secret_polys(seeds, q, deg, bound, deg)), ("sampler", nn, deg, bound)
+        do.free()
+        bump("sampler")
     elif what == "challenge":
         # device challenge pipeline (text of str(vk), SHAKE-256, decoder, NTT) == host pipeline + oracle NTT
         import fusion.fusion as F

@@ -821,6 +821,7 @@ def main():
                   "launch": "hipGraph replay of %d steps (fz_graph_*)" % NSETS if sv_graph is not None else "one by one",
                   "collective": collective,
                   "algorithmic_GB/s_per_gpu": S * ((3 * l + 1) + (l + 5)) * 4 * d * sv_steps / dt / 1e9,
+                  "hbm_frac_per_gpu": S * ((3 * l + 1) + (l + 5)) * 4 * d * sv_steps / dt / 1e9 / HBM_PEAK_GBS,
                   "note": "algebra cores only: sign_core, aggregate + target partials (one pass, one launch), int64 all-reduce, "
                           "verification from the int64 sums -- 3 kernel launches (+ the collective) per step; every step works on "
                           "the next of 8 operand sets (2.1 GB), so keys and signatures come from HBM; host hashing of str(vk) excluded"}
@@ -844,6 +845,7 @@ def main():
             sv["keygen_sign"] = {"value": S * world * ks_steps / dt, "unit": "keygen+sign per s", "per_rank": S, "steps": ks_steps,
                                  "ms_per_step": dt / ks_steps * 1e3, "operand_sets_cycled": NSETS,
                                  "algorithmic_GB/s_per_gpu": S * ((4 * l + 2) + (3 * l + 1)) * 4 * d * ks_steps / dt / 1e9,
+                                 "hbm_frac_per_gpu": S * ((4 * l + 2) + (3 * l + 1)) * 4 * d * ks_steps / dt / 1e9 / HBM_PEAK_GBS,
                                  "note": "configs[2]: keygen_core + sign_core on 1024 distinct synthetic keys per rank; sign reads the "
                                          "sk_hat keygen has just written (174 MB: part of it may still sit in the Infinity Cache), "
                                          "coefficients come from HBM (8 sets rotated)"}

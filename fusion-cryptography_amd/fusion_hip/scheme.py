@@ -25,6 +25,18 @@ class BatchScheme:
         self.device_hash = True          # per-signer challenge pipeline on the device (falls back to the host if unsupported)
         self.device_sampler = True       # secret polynomials sampled on the device (the same fallback)
         self.A = np.array([z.values for row in params.public_challenge.matrix for z in row], dtype=np.int32)
+        self._dA = None                  # the public challenge, resident on the device after its first use
+
+    def _A_dev(self):
+        if self._dA is None:
+            self._dA = DeviceArray.from_numpy(self.ctx, self.A)
+        return self._dA
+
+    def close(self):
+        """release the device copy of the public challenge (the context itself is shared and stays)"""
+        if self._dA is not None:
+            self._dA.free()
+            self._dA = None
 
     # ---- keygen ------------------------------------------------------------------------------------
     def _dev(self, a, shape):
@@ -63,7 +75,7 @@ class BatchScheme:
         if coef is None:
             polys = hostpipe.sample_secret_polys(sd, p.modulus, p.degree, p.beta_sk, p.omega_sk, self.threads)   # [N][2][d]
             coef = DeviceArray.from_numpy(self.ctx, polys)
-        dA = DeviceArray.from_numpy(self.ctx, self.A)
+        dA = self._A_dev()
         sk = DeviceArray(self.ctx, (n, 2, self.l, self.d))
         vk = DeviceArray(self.ctx, (n, 2, self.d))
         try:
@@ -78,7 +90,7 @@ class BatchScheme:
                 return res_sk, vk_host, keep
             return res_sk, vk_host
         finally:
-            for b in (coef, dA, vk):
+            for b in (coef, vk):
                 if b is not None:
                     b.free()
 

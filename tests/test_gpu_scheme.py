@@ -319,10 +319,10 @@ def test_first_verify_on_a_fresh_context_with_its_own_stream(coracle):
         ctx.close()
 
 
-@pytest.mark.parametrize("secpar,G", [(256, 700), (128, 1100), (256, 300)])
+@pytest.mark.parametrize("secpar,G", [(256, 700), (128, 1100), (256, 200)])
 def test_many_aggregates_per_launch_one_workgroup_each(secpar, G, coracle):
     """G aggregates in one launch: above 2 x CUs each aggregate is ONE workgroup's (rows prefetched one ahead, no shared
-    accumulators); G = 300 keeps the shared-accumulator path with few workgroups per aggregate.  Every verdict branch, the
+    accumulators); G = 200 keeps the shared-accumulator path with two workgroups per aggregate.  Every verdict branch, the
     reference's order (target, norm, weight: fusion.py:718-727), int32 and int64 rows, twice (state re-arms itself)."""
     import fusion_hip
     P = O.PARAMS[secpar]

@@ -477,7 +477,7 @@ int fz_challenge_coefficients(const fz_scheme_params *P, const int32_t *h_vk_lef
     const size_t need = (size_t)P->omega_ch * P->bytes_for_one_coef_bdd_by_beta_ch + P->bytes_for_poly_shuffle;
     if (n < need) return fz_set_error(FZ_E_BADARG, "hashed_vk_and_pre_hashed_message is too short");
     const int d = P->degree;
-    int bad = 0;
+    std::atomic<int> bad(0);      // set by any worker thread
     parallel_for(N, threads, [&](size_t i) {
         uint8_t ph[32];
         prehash(*P, h_msgs + h_msg_off[i], h_msg_off[i + 1] - h_msg_off[i], ph);
@@ -545,7 +545,7 @@ int fz_aggregation_coefficients(const fz_scheme_params *P, const int32_t *h_vk_l
     const size_t n = agg_coef_bytes(*P);
     std::vector<uint8_t> xof(n * N);
     sp.squeeze(xof.data(), xof.size());
-    int bad = 0;
+    std::atomic<int> bad(0);      // set by any worker thread
     parallel_for(N, threads, [&](size_t i) {
         if (decode(xof.data() + i * n, n, P->secpar, P->modulus, d, P->beta_ag, P->omega_ag, h_coefs + i * (size_t)d) != 0)
             bad = 1;
@@ -589,7 +589,7 @@ int fz_sample_coefficients(uint64_t seed, int64_t modulus, int degree, int64_t n
 int fz_sample_secret_polys(const uint64_t *h_seeds, size_t N, int64_t modulus, int degree, int64_t norm_bound,
                            int64_t weight_bound, int32_t *h_out, int threads) {
     if ((N && !h_seeds) || !h_out) return fz_set_error(FZ_E_BADARG, "NULL argument");
-    int bad = 0;
+    std::atomic<int> bad(0);      // set by any worker thread
     parallel_for(2 * N, threads, [&](size_t i) {
         if (fz_sample_coefficients(h_seeds[i / 2] + (i & 1), modulus, degree, norm_bound, weight_bound,
                                    h_out + i * (size_t)degree) != FZ_OK)

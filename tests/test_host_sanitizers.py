@@ -108,3 +108,25 @@ def test_host_pipeline_under_asan_and_ubsan(tmp_path):
         assert lines[("sha3", n)] == hashlib.sha3_256(data[:n]).hexdigest()
         assert lines[("shake", n)] == hashlib.shake_256(data[:n]).hexdigest(301)
     assert "secpar 128 weight %d" % (37 * 31) in r.stdout and "secpar 256 weight %d" % (37 * 60) in r.stdout
+
+
+def test_host_pipeline_threads_under_tsan(tmp_path):
+    """the same driver under ThreadSanitizer: the host pipeline spreads signers over std::threads (parallel_for) and shares
+    read-only inputs, per-signer outputs and one `bad` flag -- no data race may be reported (race
+    detection)"""
+    src = tmp_path / "driver.cpp"
+    src.write_text(DRIVER)
+    exe = tmp_path / "driver_tsan"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread",
+           "-I", os.path.join(ROOT, "include"), str(src), os.path.join(ROOT, "fusion-cryptography_amd", "csrc", "fz_host.cpp"),
+           "-o", str(exe)]
+    try:
+        subprocess.check_call(cmd)
+    except subprocess.CalledProcessError:
+        pytest.skip("g++ with the thread sanitizer runtime not available")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0"))
+    if "FATAL: ThreadSanitizer" in r.stderr and "unexpected memory mapping" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0 and "done" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]

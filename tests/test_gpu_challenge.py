@@ -159,3 +159,34 @@ def test_message_entry_rejects_bad_arguments():
     finally:
         dvk.free()
         dout.free()
+
+
+def test_more_signers_than_one_pass_holds(coracle):
+    """66 313 signers: the pipeline runs in passes of 65 536 (scratch bound), the second pass starts at a non-zero base in the
+    keys, the messages, the offsets and the output.  Rows around the pass boundary, the last rows and a random sample
+    against the host pipeline, for both entry points (messages / pre-hashed messages)."""
+    import fusion_hip
+    from fusion_hip import hostpipe
+    params, P, ctx = _setup(256)
+    d, q = params.degree, params.modulus
+    n = 65536 + 777
+    rng = np.random.default_rng(99)
+    vk = rng.integers(-(q // 2), q // 2 + 1, size=(n, 2, d), dtype=np.int64).astype(np.int32)
+    msgs = [f"m{i}" * (1 + i % 5) for i in range(n)]
+    pick = np.unique(np.concatenate([np.arange(0, 4), np.arange(65530, 65542), np.arange(n - 4, n), rng.integers(0, n, 40)]))
+    coefs, pre_pick = hostpipe.challenge_coefficients(P, vk[pick, 0], vk[pick, 1], [msgs[i] for i in pick])
+    want = coracle.ntt_forward(coefs, q, params.root).reshape(len(pick), d)
+    blob, off = hostpipe._pack_messages(msgs)
+    dvk = fusion_hip.DeviceBuffer.from_numpy(ctx, vk)
+    dout = fusion_hip.DeviceBuffer(ctx, n * d * 4)
+    try:
+        pre = ctx.challenge_msgs_dev(P, dvk.ptr, blob, off, n, dout.ptr, want_prehash=True)
+        assert np.array_equal(pre[pick], pre_pick)
+        got = dout.to_numpy(np.int32, (n, d))
+        assert np.array_equal(got[pick], want)
+        ctx.h2d(dout.ptr + 65530 * d * 4, np.zeros((20, d), np.int32))
+        ctx.challenge_dev(P, dvk.ptr, pre, n, dout.ptr, transform=True)
+        assert np.array_equal(dout.to_numpy(np.int32, (n, d)), got)
+    finally:
+        dvk.free()
+        dout.free()

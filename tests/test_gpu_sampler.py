@@ -87,3 +87,21 @@ def test_sampler_argument_checks():
         ctx.sample_secret_polys_dev([], P["q"], 64, 52, 64, dout.ptr)                 # empty batch: nothing to do
     finally:
         dout.free()
+
+
+def test_large_batch_more_waves_than_cus():
+    """20 000 keys = 625 one-wave workgroups (one per CU at a time: the 156 KiB of generator states fill a CU's LDS), i.e. more
+    than one round over the chip; every polynomial against the C clone"""
+    import fusion_hip
+    from fusion_hip import hostpipe
+    P = O.PARAMS[256]
+    ctx = fusion_hip.get_context(P["q"], P["d"], P["root"], P["inv_root"])
+    n = 20000
+    rng = np.random.default_rng(5)
+    seeds = [int(v) for v in rng.integers(0, 2**40, size=n, dtype=np.uint64)]
+    dout = fusion_hip.DeviceBuffer(ctx, n * 2 * 256 * 4)
+    try:
+        ctx.sample_secret_polys_dev(seeds, P["q"], 256, 52, 256, dout.ptr)
+        assert np.array_equal(dout.to_numpy(np.int32, (n, 2, 256)), hostpipe.sample_secret_polys(seeds, P["q"], 256, 52, 256))
+    finally:
+        dout.free()

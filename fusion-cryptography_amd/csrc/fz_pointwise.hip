@@ -260,7 +260,6 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
     if ((blockIdx.x >> 3) >= per_xcd || tl >= tiles) return;
     const unsigned pu = ncb > 1 ? __umulhi(tl, dv.m_ncb) : tl;
     const int cb = (int)(tl - pu * (unsigned)ncb);
-    const int p = (int)pu;
     const unsigned gu = nsl > 1 ? __umulhi(pu, dv.m_nsl) : pu;
     const size_t g = (size_t)gu;
     const int sb = (int)(pu - gu * (unsigned)nsl);

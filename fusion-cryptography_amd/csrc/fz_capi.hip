@@ -306,6 +306,7 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         // signatures (cold) for sign_core, the same for the pointwise kernels, against a grid capped at 8 workgroups per CU
         c->knob_stream_per_cu = getenv("FZ_STREAM_PER_CU") ? knob("FZ_STREAM_PER_CU") : 0;
         c->knob_stream_nt = knob("FZ_STREAM_NT");
+        c->knob_shake_full = knob("FZ_SHAKE_FORM");
         c->knob_verify_blocks = knob("FZ_VERIFY_BLOCKS");
         c->knob_verify_unfused = knob("FZ_VERIFY_UNFUSED");
         c->knob_verify_ordered = knob("FZ_VERIFY_ORDERED");

@@ -248,10 +248,16 @@ __device__ __forceinline__ void keccak_f_half(KState &S, int half) {
 
 // text rows [N][text_stride] (padded blocks), nblocks [N]  ->  xof words, transposed: word k (32 bits: 64-bit lane k/2 of
 // the stream, half k%2) of signer s at xof[k * xstride + s]
-__global__ __launch_bounds__(64) void shake_kernel(const uint8_t *text, size_t text_stride, const int *nblocks, size_t N,
-                                                   int max_blocks, int out_blocks, uint32_t *xof, size_t xstride) {
+// Workgroups of WAVES independent waves.  More waves than CUs: four per workgroup -- they go to the four SIMDs of a CU,
+// whereas four one-wave workgroups on a CU may share a SIMD (1024 of them ran at twice the time of 256: two chains on one
+// issue port).  Fewer: one per workgroup, so that every chain has a CU (and its instruction fetch) to itself (669 us
+// against 693 us).
+template <int kShakeWaves>
+__global__ __launch_bounds__(64 * kShakeWaves) void shake_kernel(const uint8_t *text, size_t text_stride, const int *nblocks, size_t N,
+                                                                 int max_blocks, int out_blocks, uint32_t *xof, size_t xstride) {
     const int lane = threadIdx.x & 63, half = lane & 1;
-    const size_t s_raw = (size_t)blockIdx.x * 32 + (lane >> 1);
+    const size_t s_raw = ((size_t)blockIdx.x * kShakeWaves + (threadIdx.x >> 6)) * 32 + (lane >> 1);
+    if (s_raw - (lane >> 1) >= N) return;                        // a whole wave past the end (the waves never synchronise)
     const bool live = s_raw < N;
     const size_t s = live ? s_raw : N - 1;                       // idle pairs shadow the last signer and store nothing
     const uint32_t *row = reinterpret_cast<const uint32_t *>(text + s * text_stride) + half;
@@ -286,6 +292,104 @@ __global__ __launch_bounds__(64) void shake_kernel(const uint8_t *text, size_t t
 #undef FZ_SQ
         }
         if (m + 1 < out_blocks) keccak_f_half(S, half);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2b. Keccak-f[1600] with a WHOLE state per lane (both 32-bit halves of every 64-bit lane in registers), for batches that
+// fill the chip: a 64-bit rotation is two v_alignbit of the lane's own halves -- no partner fetch -- so a state costs
+// ~180 vector operations per round instead of 2 x 119.  A single state takes 1.5x as long as on a lane pair, so this form
+// pays only when the pair form would need more than one wave per SIMD (> 32 768 signers per pass): 65 536 signers are
+// 1024 waves, one per SIMD.
+// ---------------------------------------------------------------------------------------------------------------
+struct W2 {
+    uint32_t l, h;
+};
+__device__ __forceinline__ W2 w2_x3(W2 a, W2 b, W2 c) { return W2{FZ_X3(a.l, b.l, c.l), FZ_X3(a.h, b.h, c.h)}; }
+__device__ __forceinline__ W2 w2_chi(W2 a, W2 b, W2 c) { return W2{a.l ^ (~b.l & c.l), a.h ^ (~b.h & c.h)}; }
+template <int R>
+__device__ __forceinline__ W2 w2_rotl(W2 x) {
+    if (R == 0) return x;
+    if (R == 32) return W2{x.h, x.l};
+    if (R < 32) return W2{__builtin_amdgcn_alignbit(x.l, x.h, 32 - R), __builtin_amdgcn_alignbit(x.h, x.l, 32 - R)};
+    return W2{__builtin_amdgcn_alignbit(x.h, x.l, 64 - R), __builtin_amdgcn_alignbit(x.l, x.h, 64 - R)};
+}
+// one output row y' of rho + pi + chi: B[x'] = rot(A[x][y] ^ D[x]) for the five (x, y) that land in row y' (x' = y,
+// y' = 2x + 3y), the same (index, rotation) table as FZ_KROUND32 above
+#define FZ_ROW64(E, O, I0, R0, I1, R1, I2, R2, I3, R3, I4, R4) \
+    { const W2 b0 = w2_rotl<R0>(w2_x3(A[I0], C[(I0 + 4) % 5], Q[(I0 + 1) % 5])), b1 = w2_rotl<R1>(w2_x3(A[I1], C[(I1 + 4) % 5], Q[(I1 + 1) % 5])), \
+               b2 = w2_rotl<R2>(w2_x3(A[I2], C[(I2 + 4) % 5], Q[(I2 + 1) % 5])), b3 = w2_rotl<R3>(w2_x3(A[I3], C[(I3 + 4) % 5], Q[(I3 + 1) % 5])), \
+               b4 = w2_rotl<R4>(w2_x3(A[I4], C[(I4 + 4) % 5], Q[(I4 + 1) % 5])); \
+      E[O] = w2_chi(b0, b1, b2); E[O + 1] = w2_chi(b1, b2, b3); E[O + 2] = w2_chi(b2, b3, b4); E[O + 3] = w2_chi(b3, b4, b0); \
+      E[O + 4] = w2_chi(b4, b0, b1); }
+__device__ __forceinline__ void keccak_round_full(const W2 (&A)[25], W2 (&E)[25], uint32_t rcl, uint32_t rch) {
+    W2 C[5], Q[5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) C[x] = w2_x3(w2_x3(A[x], A[x + 5], A[x + 10]), A[x + 15], A[x + 20]);
+#pragma unroll
+    for (int x = 0; x < 5; ++x) Q[x] = w2_rotl<1>(C[x]);
+    FZ_ROW64(E, 0, 0, 0, 6, 44, 12, 43, 18, 21, 24, 14)
+    FZ_ROW64(E, 5, 3, 28, 9, 20, 10, 3, 16, 45, 22, 61)
+    FZ_ROW64(E, 10, 1, 1, 7, 6, 13, 25, 19, 8, 20, 18)
+    FZ_ROW64(E, 15, 4, 27, 5, 36, 11, 10, 17, 15, 23, 56)
+    FZ_ROW64(E, 20, 2, 62, 8, 55, 14, 39, 15, 41, 21, 2)
+    E[0].l ^= rcl;
+    E[0].h ^= rch;
+}
+__device__ __forceinline__ void keccak_f_full(W2 (&A)[25]) {
+    W2 E[25];
+    uint32_t lo0 = kRC[0][0], hi0 = kRC[0][1], lo1 = kRC[1][0], hi1 = kRC[1][1];
+#pragma unroll 1
+    for (int r = 0; r < 24; r += 2) {
+        const uint32_t a0 = lo0, b0 = hi0, a1 = lo1, b1 = hi1;
+        const int rn = (r + 2) % 24;
+        lo0 = kRC[rn][0]; hi0 = kRC[rn][1]; lo1 = kRC[rn + 1][0]; hi1 = kRC[rn + 1][1];
+        keccak_round_full(A, E, a0, b0);
+        keccak_round_full(E, A, a1, b1);
+    }
+}
+
+// the same contract as shake_kernel, one lane per signer
+template <int kShakeWaves>
+__global__ __launch_bounds__(64 * kShakeWaves) void shake_full_kernel(const uint8_t *text, size_t text_stride, const int *nblocks,
+                                                                      size_t N, int max_blocks, int out_blocks, uint32_t *xof,
+                                                                      size_t xstride) {
+    const int lane = threadIdx.x & 63;
+    const size_t s_raw = ((size_t)blockIdx.x * kShakeWaves + (threadIdx.x >> 6)) * 64 + lane;
+    if (s_raw - lane >= N) return;                               // a whole wave past the end (the waves never synchronise)
+    const bool live = s_raw < N;
+    const size_t s = live ? s_raw : N - 1;                       // idle lanes shadow the last signer and store nothing
+    const uint2 *row = reinterpret_cast<const uint2 *>(text + s * text_stride);
+    const int nb = nblocks[s];
+    W2 A[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) A[i] = W2{0u, 0u};
+    uint2 m[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) m[i] = row[i];
+#pragma unroll 1
+    for (int b = 0; b < max_blocks; ++b) {
+        if (b < nb) {
+#pragma unroll
+            for (int i = 0; i < 17; ++i) { A[i].l ^= m[i].x; A[i].h ^= m[i].y; }
+            const uint2 *w = row + (size_t)(b + 1 < nb ? b + 1 : b) * (kRate / 8);
+#pragma unroll
+            for (int i = 0; i < 17; ++i) m[i] = w[i];
+            keccak_f_full(A);
+        }
+    }
+    uint32_t *out = xof + s;
+#pragma unroll 1
+    for (int q = 0; q < out_blocks; ++q) {
+        if (live) {
+            uint32_t *o = out + (size_t)q * 34 * xstride;
+#pragma unroll
+            for (int i = 0; i < 17; ++i) {
+                o[(size_t)(2 * i) * xstride] = A[i].l;
+                o[(size_t)(2 * i + 1) * xstride] = A[i].h;
+            }
+        }
+        if (q + 1 < out_blocks) keccak_f_full(A);
     }
 }
 
@@ -477,8 +581,14 @@ int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d
     int rc = fz_check_hip(hipGetLastError(), "vk_text launch");
     if (rc != FZ_OK) return rc;
     const int max_blocks = (int)(text_stride / kRate);
-    hipLaunchKernelGGL(shake_kernel, dim3((unsigned)((N + 31) / 32)), dim3(64), 0, ctx->stream, d_text, text_stride, d_nblocks, N,
-                       max_blocks, out_blocks, d_xof, xstride);
+    // lane pairs while they fit one wave per SIMD (the latency-optimal form), whole states per lane beyond
+    const int shake_mode = ctx->knob_shake_full ? ctx->knob_shake_full : ((N + 31) / 32 > (size_t)ctx->num_cu * 4 ? 2 : 1);
+    const size_t per_wave = shake_mode == 2 ? 64 : 32, waves = (N + per_wave - 1) / per_wave;
+#define FZ_SHK(KERNEL, W) hipLaunchKernelGGL((KERNEL<W>), dim3((unsigned)((waves + W - 1) / W)), dim3(64 * W), 0, ctx->stream, d_text, \
+                                             text_stride, d_nblocks, N, max_blocks, out_blocks, d_xof, xstride)
+    if (shake_mode == 2) { if (waves > (size_t)ctx->num_cu) FZ_SHK(shake_full_kernel, 4); else FZ_SHK(shake_full_kernel, 1); }
+    else { if (waves > (size_t)ctx->num_cu) FZ_SHK(shake_kernel, 4); else FZ_SHK(shake_kernel, 1); }
+#undef FZ_SHK
     rc = fz_check_hip(hipGetLastError(), "shake launch");
     if (rc != FZ_OK) return rc;
     DecodeShapeDev D;

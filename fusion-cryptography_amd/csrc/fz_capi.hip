@@ -986,7 +986,8 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
         const size_t o_xof = o_text + ((n * text_stride + 255) & ~(size_t)255);
         const size_t o_off = o_xof + ((((size_t)out_blocks * 34 + 1) * xstride * 4 + 255) & ~(size_t)255);    // + one spare word row (decoder)
         const size_t msg_bytes = h_prehash ? 0 : h_msg_off[base + n] - h_msg_off[base];
-        const size_t o_msg = o_off + (((n + 1) * 8 + 255) & ~(size_t)255);
+        const size_t o_dec = o_off + (((n + 1) * 8 + 255) & ~(size_t)255);              // [n][16] words: the integers in base 10^9
+        const size_t o_msg = o_dec + n * 64;
         const size_t total = h_prehash ? o_off : o_msg + ((msg_bytes + 255) & ~(size_t)255);
         void *scr = nullptr;
         FZ_TRY(fz_scratch(ctx, total, &scr));
@@ -998,12 +999,13 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
             FZ_HIP(hipMemcpyAsync(sp + o_off, h_msg_off + base, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream), "upload of the message offsets");
             if (msg_bytes)
                 FZ_HIP(hipMemcpyAsync(sp + o_msg, h_msgs + h_msg_off[base], msg_bytes, hipMemcpyHostToDevice, ctx->stream), "upload of the messages");
-            FZ_TRY(fz_launch_prehash(ctx, P, sp + o_msg, (const unsigned long long *)(sp + o_off), n, sp + o_pre));
+            FZ_TRY(fz_launch_prehash(ctx, P, sp + o_msg, (const unsigned long long *)(sp + o_off), n, sp + o_pre, (uint32_t *)(sp + o_dec)));
             if (h_prehash_out)
                 FZ_HIP(hipMemcpyAsync(h_prehash_out + 32 * base, sp + o_pre, n * 32, hipMemcpyDeviceToHost, ctx->stream), "download of the pre-hashed messages");
         }
         FZ_HIP(hipStreamSynchronize(ctx->stream), "upload sync");      // the caller's buffers have been consumed when this returns
-        FZ_TRY(fz_launch_challenge(ctx, P, d_vk + base * 2 * (size_t)P->degree, sp + o_pre, n, sp + o_text, text_stride,
+        FZ_TRY(fz_launch_challenge(ctx, P, d_vk + base * 2 * (size_t)P->degree, sp + o_pre,
+                                   h_prehash ? nullptr : (const uint32_t *)(sp + o_dec), n, sp + o_text, text_stride,
                                    (int *)(sp + o_nb), (uint32_t *)(sp + o_xof), xstride, out_blocks, ctx->d_chal_tab,
                                    d_out + base * (size_t)P->degree));
     }

@@ -48,10 +48,33 @@ __device__ __forceinline__ int dec_len(int v) {          // len(str(v)) for an i
     return n;
 }
 
-// one wave per signer, kTextWaves signers per workgroup.  text row i: blocks * 136 bytes, *nblocks = blocks
+// str(int) of a 256-bit integer (eight 32-bit limbs, least significant first) in base 10^9: chunks out[0..n-1], least
+// significant first; returns n (1..9).  Nine rounds of an eight-limb short division: a sequential chain, one LANE's work.
+__device__ __forceinline__ int u256_to_base1e9(uint32_t (&limb)[8], uint32_t *out) {
+    int n = 0;
+    bool nz = true;
+    while (nz && n < 9) {
+        unsigned long long rem = 0;
+        nz = false;
+#pragma unroll
+        for (int t = 7; t >= 0; --t) {
+            const unsigned long long cur = (rem << 32) | limb[t];
+            limb[t] = (uint32_t)(cur / 1000000000ull);
+            rem = cur % 1000000000ull;
+            nz |= limb[t] != 0;
+        }
+        out[n++] = (uint32_t)rem;
+    }
+    return n;
+}
+constexpr int kDecStride = 16;               // uint32 per signer in the decimal scratch: 9 chunks, the chunk count at [9]
+
+// one wave per signer, kTextWaves signers per workgroup.  text row i: blocks * 136 bytes, *nblocks = blocks.
+// dec (optional): the pre-hashed integers already in base 10^9 (prehash_kernel converts them with a lane per message; done
+// here it is one lane of the signer's wave while 63 wait: a third of this kernel's time)
 constexpr int kTextWaves = 4;
 __global__ __launch_bounds__(64 * kTextWaves) void vk_text_kernel(const int32_t *vk, size_t vk_stride, const uint8_t *pre,
-                                                                  size_t N, int degree, VkTextParts T,
+                                                                  const uint32_t *dec, size_t N, int degree, VkTextParts T,
                                                                   uint8_t *text, size_t text_stride, int *nblocks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -61,28 +84,16 @@ __global__ __launch_bounds__(64 * kTextWaves) void vk_text_kernel(const int32_t 
     uint32_t *aux = reinterpret_cast<uint32_t *>(smem + (size_t)kTextWaves * text_stride) + wave * 16;
     // str(int.from_bytes(prehash, "little")) (fusion.py:405-409, :416-418): the 256-bit integer in base 10^9, least
     // significant chunk first (one lane: 9 rounds of an 8-limb short division), digits written by lanes 0..8 below
-    if (lane == 0) {
+    if (dec) {
+        if (lane < 10) aux[lane] = dec[i * kDecStride + lane];
+    } else if (lane == 0) {
         uint32_t limb[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const uint8_t *b = pre + i * 32 + 4 * t;
             limb[t] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
         }
-        int n = 0;
-        bool nz = true;
-        while (nz && n < 9) {
-            unsigned long long rem = 0;
-            nz = false;
-#pragma unroll
-            for (int t = 7; t >= 0; --t) {
-                const unsigned long long cur = (rem << 32) | limb[t];
-                limb[t] = (uint32_t)(cur / 1000000000ull);
-                rem = cur % 1000000000ull;
-                nz |= limb[t] != 0;
-            }
-            aux[n++] = (uint32_t)rem;
-        }
-        aux[9] = (uint32_t)n;
+        aux[9] = (uint32_t)u256_to_base1e9(limb, aux);
     }
     for (size_t o = (size_t)lane * 16; o < text_stride; o += 64 * 16) *reinterpret_cast<int4 *>(buf + o) = make_int4(0, 0, 0, 0);
     const int nvals = 2 * degree;
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(64 * kShakeWaves) void shake_full_kernel(const uint
 // byte offset; its padding (0x06 ... 0x80) is part of the same byte function.  pre [N][32]: the digests, i.e. the
 // pre-hashed integers, little-endian, exactly what vk_text_kernel prints in decimal.
 __global__ __launch_bounds__(64) void prehash_kernel(const uint8_t *msgs, const unsigned long long *off, size_t N, uint32_t dst0,
-                                                     uint32_t dst1, uint8_t *pre) {
+                                                     uint32_t dst1, uint8_t *pre, uint32_t *dec) {
     const int lane = threadIdx.x & 63, half = lane & 1;
     const size_t s_raw = (size_t)blockIdx.x * 32 + (lane >> 1);
     const bool live = s_raw < N;
@@ -438,6 +449,14 @@ __global__ __launch_bounds__(64) void prehash_kernel(const uint8_t *msgs, const 
     if (live) {
         uint32_t *o = reinterpret_cast<uint32_t *>(pre + s * 32) + half;
         o[0] = S.a0; o[2] = S.a1; o[4] = S.a2; o[6] = S.a3;
+    }
+    // the integer's decimal chunks for vk_text_kernel, by the even lane of the pair (limb 2k = its own half of lane k, limb
+    // 2k + 1 = the partner's)
+    const uint32_t p0 = partner(S.a0), p1 = partner(S.a1), p2 = partner(S.a2), p3 = partner(S.a3);
+    if (dec && live && half == 0) {
+        uint32_t limb[8] = {S.a0, p0, S.a1, p1, S.a2, p2, S.a3, p3};
+        uint32_t *d = dec + s * kDecStride;
+        d[9] = (uint32_t)u256_to_base1e9(limb, d);
     }
 }
 
@@ -563,7 +582,7 @@ size_t fz_host_challenge_needed_bytes(const fz_scheme_params *P, int *sign_bytes
 
 // d_vk [N][2][degree] int32 (left row, right row), d_pre [N][32] (SHA3-256 digests of the messages = the pre-hashed
 // integers, little-endian), d_text / d_nblocks / d_xof scratch; d_coefs [N][degree] out
-int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *d_pre, size_t N,
+int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *d_pre, const uint32_t *d_dec, size_t N,
                         uint8_t *d_text, size_t text_stride, int *d_nblocks, uint32_t *d_xof, size_t xstride, int out_blocks,
                         const uint32_t *d_tab, int32_t *d_coefs) {
     VkTextParts T;
@@ -577,7 +596,7 @@ int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d
         if (e != hipSuccess) return fz_check_hip(e, "text kernel LDS attribute");
     }
     hipLaunchKernelGGL(vk_text_kernel, dim3((unsigned)((N + kTextWaves - 1) / kTextWaves)), dim3(64 * kTextWaves), lds_text, ctx->stream,
-                       d_vk, (size_t)2 * d, d_pre, N, d, T, d_text, text_stride, d_nblocks);
+                       d_vk, (size_t)2 * d, d_pre, d_dec, N, d, T, d_text, text_stride, d_nblocks);
     int rc = fz_check_hip(hipGetLastError(), "vk_text launch");
     if (rc != FZ_OK) return rc;
     const int max_blocks = (int)(text_stride / kRate);
@@ -608,10 +627,10 @@ int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d
 // SHA3-256 of dst + "," + message for N messages: d_msgs the message bytes back to back, d_off [N + 1] their offsets (any
 // origin: off[0] is subtracted), d_pre [N][32] out
 int fz_launch_prehash(fz_ctx *ctx, const fz_scheme_params *P, const uint8_t *d_msgs, const unsigned long long *d_off, size_t N,
-                      uint8_t *d_pre) {
+                      uint8_t *d_pre, uint32_t *d_dec) {
     if (N == 0) return FZ_OK;
     hipLaunchKernelGGL(prehash_kernel, dim3((unsigned)((N + 31) / 32)), dim3(64), 0, ctx->stream, d_msgs, d_off, N,
-                       (uint32_t)P->sign_pre_hash_dst[0], (uint32_t)P->sign_pre_hash_dst[1], d_pre);
+                       (uint32_t)P->sign_pre_hash_dst[0], (uint32_t)P->sign_pre_hash_dst[1], d_pre, d_dec);
     return fz_check_hip(hipGetLastError(), "prehash launch");
 }
 

@@ -106,14 +106,14 @@ int fz_launch_diag(fz_ctx *ctx, int what, const void *src, void *dst, size_t byt
 
 // challenge pipeline on the device (fz_challenge.hip) and the pieces it shares with the host serialiser (fz_host.cpp)
 struct fz_scheme_params;
-int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *d_pre, size_t N,
+int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *d_pre, const uint32_t *d_dec, size_t N,
                         uint8_t *d_text, size_t text_stride, int *d_nblocks, uint32_t *d_xof, size_t xstride, int out_blocks,
                         const uint32_t *d_tab, int32_t *d_coefs);
 void fz_mt_init_table(uint32_t *h_tab);                                              // 624 words
 int fz_launch_mt_sample(fz_ctx *ctx, const unsigned long long *d_seeds, size_t nkeys, int degree, uint32_t bound, int kbits,
                         const uint32_t *d_init, int32_t *d_out, int *d_fail);
 int fz_launch_prehash(fz_ctx *ctx, const fz_scheme_params *P, const uint8_t *d_msgs, const unsigned long long *d_off, size_t N,
-                      uint8_t *d_pre);
+                      uint8_t *d_pre, uint32_t *d_dec);          // d_dec [N][16]: the integers in base 10^9 + chunk count
 void fz_challenge_weight_table(int index_bytes, int degree, uint32_t *h_tab);      // (degree + 1) * 16 words
 void fz_host_vk_text_parts(const fz_scheme_params *P, char *s0, int *n0, char *s1, int *n1, char *s2, int *n2, int cap);
 size_t fz_host_challenge_needed_bytes(const fz_scheme_params *P, int *sign_bytes, int *coef_bytes, int *index_bytes);

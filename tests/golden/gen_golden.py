@@ -253,6 +253,103 @@ def gen_scheme():
         json.dump(meta, f)
 
 
+def gen_scheme_many():
+    """Many DISTINCT signers (VERDICT r02 task 2a): the reference's whole flow for N = 32 keys at secpar 128 and
+    N = 16 at secpar 256 -- everything that depends on the ORDER of many keys (sorted(key=str(vk)) on signed decimals,
+    the hash_ag text over N tuples, the aggregation coefficients in sorted order) -- plus nested sub-aggregates of
+    mixed sizes (a many-aggregates call) and the tamper verdicts.  Signatures and keys are stored as digests (they are
+    regenerated from the seeds by the build and compared by SHA-256); alpha_hat, aggregates and orders are stored whole."""
+    meta = {}
+    for secpar, setup_seed, nkeys, subsets in ((128, 4242, 32, ((0, 32), (0, 5), (5, 17), (17, 32))),
+                                               (256, 777, 16, ((0, 16), (0, 3), (3, 9), (9, 16)))):
+        t0 = time.time()
+        params = F.fusion_setup(secpar, setup_seed)
+        key_seeds = [31337 * secpar + 1009 * i * i + 7 * i for i in range(nkeys)]
+        msgs = [f"signer {i}: pay {100 + 13 * i} units to account #{(i * 7919) % 1000:03d}" for i in range(nkeys)]
+        keys = [F.keygen(params, s) for s in key_seeds]
+        vks = [k[1] for k in keys]
+        sigs = [F.sign(params, k, m) for k, m in zip(keys, msgs)]
+        vk = np.stack([np.stack([mat_values(v.left_vk_hat)[0], mat_values(v.right_vk_hat)[0]]) for v in vks])
+        sig = np.stack([mat_values(s.signature_hat) for s in sigs])
+        arrays = dict(vk=vk, A=mat_values(params.public_challenge))
+        info = dict(secpar=secpar, setup_seed=setup_seed, key_seeds=key_seeds, messages=msgs,
+                    sha256_sig_rows=[sha_i32(s) for s in sig], sha256_str_vk=[sha_str(str(v)) for v in vks],
+                    sha256_str_sig=[sha_str(str(s)) for s in sigs], subsets=[list(s) for s in subsets], agg={})
+        for lo, hi in subsets:
+            sub_v, sub_m, sub_s = vks[lo:hi], msgs[lo:hi], sigs[lo:hi]
+            n = hi - lo
+            order = sorted(range(n), key=lambda i: str(sub_v[i]))
+            alphas = F.hash_ag(params, [sub_v[i] for i in order], [sub_m[i] for i in order])
+            agg = F.aggregate(params, sub_v, sub_m, sub_s)
+            verdict = F.verify(params, sub_v, sub_m, agg)
+            assert verdict == (True, ""), verdict
+            tag = f"{lo}_{hi}"
+            arrays[f"alpha_hat_sorted_{tag}"] = np.array([a.alpha_hat.values for a in alphas], dtype=np.int32)
+            arrays[f"agg_{tag}"] = mat_values(agg.signature_hat)
+            agg.signature_hat.matrix[n % params.num_rows_sk][0].values[3] += 1
+            bad = F.verify(params, sub_v, sub_m, agg)
+            agg.signature_hat.matrix[n % params.num_rows_sk][0].values[3] -= 1
+            swapped = list(sub_m)
+            swapped[0], swapped[-1] = swapped[-1], swapped[0]
+            info["agg"][tag] = dict(order=order, sha256_str_agg=sha_str(str(agg)), verdict=list(verdict),
+                                    tampered_verdict=list(bad), tampered_at=[n % params.num_rows_sk, 3],
+                                    swapped_messages_verdict=list(F.verify(params, sub_v, swapped, agg)) if n > 1 else None)
+        np.savez_compressed(os.path.join(HERE, f"scheme_many_{secpar}.npz"), **arrays)
+        meta[str(secpar)] = info
+        print(f"scheme_many secpar={secpar}: {nkeys} signers, {time.time()-t0:.1f}s")
+    with open(os.path.join(HERE, "scheme_many.json"), "w") as f:
+        json.dump(meta, f)
+
+
+def gen_kat_flow(seed=20261004, sigs=8):
+    """VERDICT r02 task 2b: SHA-256 of every row (`str(inputs)`, `str(outputs)`) the flow of the reference's
+    KATs/generate_KAT_values.py:36-147 produces, run through the REFERENCE's functions in the reference's order, with
+    the seeds drawn from random.Random(seed) in the order tools/generate_kat_values.py draws them (the reference's
+    script draws from the process-global generator, which its own samplers re-seed: not reproducible by design)."""
+    import random
+    from math import ceil, log2
+    rng = random.Random(seed)
+    out = {"seed": seed, "sigs": sigs, "rows": {}}
+
+    def put(name, secpar, inputs, outputs):
+        out["rows"].setdefault(f"{name}_KAT_{secpar}", []).append([sha_str(str(inputs)), sha_str(str(outputs))])
+    for secpar in (128, 256):
+        t0 = time.time()
+        seed_a = rng.randint(0, 2**32 - 1)
+        params = F.fusion_setup(secpar, seed_a)
+        put("fusion_setup", secpar, (secpar, seed_a), params)
+        seeds, msgs, otks, pre, challs, sgs = [], [], [], [], [], []
+        for i in range(sigs):
+            seeds.append(rng.randint(0, 2**32 - 1))
+            msgs.append(str(i))
+            otks.append(F.keygen(params, seeds[i]))
+            put("fusion_keygen", secpar, (params, seeds[i]), otks[-1])
+            vk = otks[i][1]
+            pre.append(F.hash_message_to_int(params, msgs[i]))
+            put("intermediate_hash_message_to_int", secpar, (params, msgs[i]), pre[-1])
+            num_coefs = max(0, min(params.degree, params.omega_ch))
+            bound = max(0, min(params.modulus // 2, params.beta_ch))
+            n = ceil(params.omega_ch / 8) + ceil((log2(bound) + 1 + params.secpar) / 8) * num_coefs + \
+                params.degree * ceil((log2(params.degree) + params.secpar) / 8)
+            put("intermediate_hash_vk_and_int_to_bytes_to_int", secpar, (params, vk, pre[i], n),
+                F.hash_vk_and_int_to_bytes(params, vk, pre[i], n))
+            challs.append(F.hash_ch(params, vk, msgs[i]))
+            put("intermediate_hash_ch", secpar, (params, vk, msgs[i]), challs[-1])
+            sgs.append(F.sign(params, otks[i], msgs[i]))
+            put("fusion_sign", secpar, (params, otks[i], pre[i]), sgs[-1])
+        vks = [k[1] for k in otks]
+        # the reference's script passes the (sk, vk) TUPLES to these two (generate_KAT_values.py:115, :127)
+        put("intermediate_hash_vks_and_ints_and_challs_to_bytes", secpar, (params, otks, pre, challs),
+            F.hash_vks_and_ints_and_challs_to_bytes(params, otks, pre, challs))
+        put("intermediate_hash_ag", secpar, (params, otks, msgs), F.hash_ag(params, otks, msgs))
+        agg = F.aggregate(params, vks, msgs, sgs)
+        put("fusion_aggregate", secpar, (params, vks, msgs, sgs), agg)
+        assert F.verify(params, vks, msgs, agg) == (True, "")
+        print(f"kat_flow secpar={secpar}: {time.time()-t0:.1f}s")
+    with open(os.path.join(HERE, "kat_flow.json"), "w") as f:
+        json.dump(out, f)
+
+
 _VAL = re.compile(r"values=\[([^\]]*)\]")
 
 
@@ -315,7 +412,11 @@ def gen_kat():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["algebra", "bulk", "scheme", "kat"]
+    which = sys.argv[1:] or ["algebra", "bulk", "scheme", "kat", "many", "kat_flow"]
+    if "many" in which:
+        gen_scheme_many()
+    if "kat_flow" in which:
+        gen_kat_flow()
     if "algebra" in which:
         gen_algebra()
     if "bulk" in which:

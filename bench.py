@@ -70,6 +70,7 @@ def parse():
                     help="if the legs after the headline have not finished by then, rank 0 prints the line with what it has "
                          "(\"watchdog\" says which leg was running) and every rank leaves: a hung collective must not cost the line")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-signers", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -77,12 +78,45 @@ def parse():
 # CPU baseline (the oracle's pure-Python port; rank 0 at N = 1 only)
 # ---------------------------------------------------------------------------------------------------------
 def _cpu_worker(job):
-    """one host process: forward+inverse pure-Python NTTs for `seconds`; returns (transforms, seconds)"""
-    index, seconds = job
+    """one host process of the CPU baseline (the ONLY place bench.py touches oracle/).
+    (index, seconds): forward+inverse pure-Python NTTs for `seconds`; returns (transforms, seconds).
+    (index, n, "scheme"): the metric's second half in the pure-Python port -- keygen, sign, aggregate and verify cores
+    (fusion/fusion.py:363-370, :557, :670-676, :690-727) of ONE aggregate of n synthetic signers; returns the four phase
+    times in seconds (the verdict must be 0: it is real work on valid signatures)."""
     from oracle import oracle as O
     P = O.PARAMS[SECPAR]
     q, d = P["q"], P["d"]
     tw, itw = O.py_twiddles(P["root"], q, d), O.py_twiddles(P["inv_root"], q, d)
+    if len(job) == 3:
+        import random
+        index, n, _ = job
+        l = P["rank"]
+        rng = random.Random(9000 + index)
+        A = O.splitmix_centered(99, l * d).reshape(l, d).tolist()
+
+        def secret():      # beta_sk = 52, omega_sk = d (fusion.py:30-31, :116): every coefficient non-zero in +-[1, 52]
+            return [(1 + rng.randrange(52)) * (1 - 2 * rng.randrange(2)) for _ in range(d)]
+
+        def sparse_hat(weight):
+            c = [0] * d
+            for j in rng.sample(range(d), weight):
+                c[j] = 1 - 2 * rng.randrange(2)
+            return O.py_ntt_forward(c, q, tw)
+        secrets = [([secret() for _ in range(l)], [secret() for _ in range(l)]) for _ in range(n)]
+        c_hat = [sparse_hat(P["omega_ch"]) for _ in range(n)]
+        al_hat = [sparse_hat(P["omega_ag"]) for _ in range(n)]
+        t0 = time.perf_counter()
+        keys = [O.py_keygen_core(A, sL, sR, q, tw) for sL, sR in secrets]
+        t1 = time.perf_counter()
+        sigs = [O.py_sign_core(k[0], k[1], c, q) for k, c in zip(keys, c_hat)]
+        t2 = time.perf_counter()
+        agg = O.py_aggregate_core(sigs, al_hat, q)
+        t3 = time.perf_counter()
+        code = O.py_verify_core(A, agg, [k[2] for k in keys], [k[3] for k in keys], c_hat, al_hat, q, itw, P["beta_vf"], d)
+        t4 = time.perf_counter()
+        assert code == 0, f"pure-Python verify returned {code}"
+        return n, t1 - t0, t2 - t1, t3 - t2, t4 - t3
+    index, seconds = job
     rows = 64
     x = O.splitmix_centered(20261003, B * d).reshape(B, d)[(index * rows) % B:][:rows].tolist()
     done, t0 = 0, time.perf_counter()
@@ -131,6 +165,39 @@ def cpu_baseline(seconds):
                             "sample": f"{len(res)} processes x {seconds / 3:.1f} s of the same loop"}
     except Exception as e:                                   # the single-core figure stands on its own
         out["all_cores"] = {"error": repr(e)}
+    # ---- the metric's second half: keygen/s, sign/s, aggregate-signatures/s, verify-signatures/s of the
+    # pure-Python port on a sub-sample (64 signers on one core; `workers` x 16 signers on the pool), synthetic inputs as the
+    # GPU legs use them (secrets in +-[1, 52], ternary challenges / aggregation coefficients of the parameter set's weights)
+    def rates(n, tk, ts, ta, tv):
+        return {"keygen_per_s": n / tk, "sign_per_s": n / ts, "aggregate_signatures_per_s": n / ta, "verify_signatures_per_s": n / tv,
+                "sign_plus_verify_per_s": n / (ts + ta + tv), "keygen_plus_sign_per_s": n / (tk + ts)}
+    try:
+        n1 = int(os.environ.get("FZ_BENCH_CPU_SIGNERS", "64"))
+        n, tk, ts, ta, tv = _cpu_worker((0, n1, "scheme"))
+        sch = dict(rates(n, tk, ts, ta, tv), cores=1, kind="port", unit="per second",
+                   sample=f"one aggregate of {n} synthetic signers at secpar {SECPAR}: keygen {tk:.2f} s, sign {ts:.2f} s, aggregate "
+                          f"{ta:.2f} s, verify {tv:.3f} s on 1 core (oracle.py_keygen_core / py_sign_core / py_aggregate_core / "
+                          f"py_verify_core: lists of Python ints, one cent() per reference cent call)")
+        import subprocess
+        workers = max(1, min(usable, int(os.environ.get("FZ_BENCH_CPU_WORKERS", "16"))))
+        npool = max(2, n1 // 4)
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), "--cpu-signers", str(npool)],
+                                  stdout=subprocess.PIPE, text=True) for i in range(workers)]
+        res = []
+        for pr in procs:
+            try:
+                text, _ = pr.communicate(timeout=600)
+                res.append([float(x) for x in text.split()])
+            except Exception:
+                pr.kill()
+        if res:
+            # independent aggregates, one per process: the pool's rate of a phase = all signers / the slowest worker's phase time
+            tot = sum(r[0] for r in res)
+            sch["all_cores"] = dict(rates(tot, *[max(r[k] for r in res) for k in (1, 2, 3, 4)]), cores=len(res),
+                                    sample=f"{len(res)} processes, one aggregate of {npool} signers each")
+        out["scheme"] = sch
+    except Exception as e:
+        out["scheme"] = {"error": repr(e)}
     return out
 
 
@@ -188,8 +255,11 @@ def self_launch(args):
 def main():
     args = parse()
     if args.cpu_worker is not None:                      # child of cpu_baseline(): host only
-        n, t = _cpu_worker((args.cpu_worker, args.cpu_seconds))
-        print(n, t)
+        if args.cpu_signers:
+            print(*_cpu_worker((args.cpu_worker, args.cpu_signers, "scheme")))
+        else:
+            n, t = _cpu_worker((args.cpu_worker, args.cpu_seconds))
+            print(n, t)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)                         # before anything in this process touches a GPU

@@ -51,13 +51,30 @@ static unsigned bitrev(unsigned i, int k) {
     return r;
 }
 
+// A device allocation that is being replaced by a larger one.  A graph captured on this context may hold its address
+// (fz_graph_*: recorded pointers are fixed), and a replay must never touch freed memory: once any graph was captured the
+// old allocation is kept until fz_ctx_destroy instead of being freed.
+int fz_retire(fz_ctx *ctx, void *d_ptr, const char *what) {
+    if (!d_ptr) return FZ_OK;
+    if (!ctx->graphs_captured) return fz_check_hip(hipFree(d_ptr), what);
+    if (ctx->n_retired == ctx->cap_retired) {
+        const int cap = ctx->cap_retired ? 2 * ctx->cap_retired : 16;
+        void **r = (void **)realloc(ctx->retired, sizeof(void *) * (size_t)cap);
+        if (!r) return fz_set_error(FZ_E_HIP, "out of host memory");
+        ctx->retired = r;
+        ctx->cap_retired = cap;
+    }
+    ctx->retired[ctx->n_retired++] = d_ptr;
+    return FZ_OK;
+}
+
 int fz_scratch(fz_ctx *ctx, size_t bytes, void **out) {
     if (bytes > ctx->scratch_bytes) {
         if (ctx->capturing)
             return fz_set_error(FZ_E_BADARG, "scratch would grow during graph capture: run the sequence once before fz_graph_begin");
         // previous users of the scratch are stream-ordered before this point
         FZ_HIP(hipStreamSynchronize(ctx->stream), "scratch sync");
-        if (ctx->d_scratch) FZ_HIP(hipFree(ctx->d_scratch), "scratch free");
+        FZ_TRY(fz_retire(ctx, ctx->d_scratch, "scratch free"));
         ctx->d_scratch = nullptr;
         ctx->scratch_bytes = 0;
         size_t want = bytes + bytes / 4 + 4096;
@@ -73,7 +90,7 @@ int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out) {
         if (ctx->capturing)
             return fz_set_error(FZ_E_BADARG, "scratch would grow during graph capture: run the sequence once before fz_graph_begin");
         FZ_HIP(hipStreamSynchronize(ctx->stream), "scratch2 sync");
-        if (ctx->d_scratch2) FZ_HIP(hipFree(ctx->d_scratch2), "scratch2 free");
+        FZ_TRY(fz_retire(ctx, ctx->d_scratch2, "scratch2 free"));
         ctx->d_scratch2 = nullptr;
         ctx->scratch2_bytes = 0;
         size_t want = bytes + bytes / 4 + 4096;
@@ -91,7 +108,7 @@ int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, doub
             return fz_set_error(FZ_E_BADARG, "verify scratch would grow during graph capture: run the sequence once before fz_graph_begin");
         FZ_HIP(hipStreamSynchronize(ctx->stream), "verify scratch sync");
         if (need > ctx->vpart_doubles) {
-            if (ctx->d_vpart) FZ_HIP(hipFree(ctx->d_vpart), "verify scratch free");
+            FZ_TRY(fz_retire(ctx, ctx->d_vpart, "verify scratch free"));
             ctx->d_vpart = nullptr;
             ctx->vpart_doubles = 0;
             FZ_HIP(hipMalloc((void **)&ctx->d_vpart, (need + need / 4) * sizeof(double)), "verify scratch alloc");
@@ -100,7 +117,7 @@ int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, doub
             ctx->vpart_doubles = need + need / 4;
         }
         if (groups > ctx->vstate_groups) {
-            if (ctx->d_vstate) FZ_HIP(hipFree(ctx->d_vstate), "verify state free");
+            FZ_TRY(fz_retire(ctx, ctx->d_vstate, "verify state free"));
             ctx->d_vstate = nullptr;
             ctx->vstate_groups = 0;
             const size_t cap = groups + groups / 4 + 16;
@@ -126,7 +143,7 @@ int fz_agg_scratch(fz_ctx *ctx, size_t tiles, size_t tile_words, unsigned long l
         if (ctx->capturing)
             return fz_set_error(FZ_E_BADARG, "aggregation scratch would grow during graph capture: run the sequence once before fz_graph_begin");
         FZ_HIP(hipStreamSynchronize(ctx->stream), "aggregation scratch sync");
-        if (ctx->d_aggacc) FZ_HIP(hipFree(ctx->d_aggacc), "aggregation scratch free");
+        FZ_TRY(fz_retire(ctx, ctx->d_aggacc, "aggregation scratch free"));     // a captured aggregation keeps a valid (if stale) accumulator
         ctx->d_aggacc = nullptr;
         ctx->aggacc_tiles = 0;
         const size_t cap = tiles + tiles / 4 + 8;
@@ -312,6 +329,8 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         c->knob_verify_ordered = knob("FZ_VERIFY_ORDERED");
         c->knob_keygen_unfused = knob("FZ_KEYGEN_UNFUSED");
         c->knob_polymul_unfused = knob("FZ_POLYMUL_UNFUSED");
+        c->knob_no_split = knob("FZ_NO_SPLIT");
+        c->knob_verify_cent = knob("FZ_VERIFY_CENT");
     }
     if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
     if (rc == FZ_OK) rc = upload_doubles(itwB, nB, &c->d_itwB);
@@ -345,6 +364,9 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     if (ctx->d_vpart) (void)hipFree(ctx->d_vpart);
     if (ctx->d_vstate) (void)hipFree(ctx->d_vstate);
     if (ctx->d_aggacc) (void)hipFree(ctx->d_aggacc);
+    if (ctx->d_Asplit) (void)hipFree(ctx->d_Asplit);
+    for (int i = 0; i < ctx->n_retired; ++i) (void)hipFree(ctx->retired[i]);
+    free(ctx->retired);
     if (ctx->d_chal_tab) (void)hipFree(ctx->d_chal_tab);
     if (ctx->d_mt_init) (void)hipFree(ctx->d_mt_init);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -358,6 +380,12 @@ int fz_ctx_destroy(fz_ctx *ctx) {
 int fz_ctx_set_stream(fz_ctx *ctx, void *hip_stream) {
     FZ_REQUIRE(ctx, "ctx is NULL");
     if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the stream cannot change during graph capture");
+    if (ctx->stream != (hipStream_t)hip_stream && (ctx->d_aggacc || ctx->d_vpart || ctx->d_scratch || ctx->d_scratch2)) {
+        // the accumulator words of the one-pass aggregation / fused verification and the scratch areas belong to the context,
+        // not to a stream: work still in flight on the old stream must not share them with work on the new one
+        FZ_DEV(ctx);
+        FZ_HIP(hipStreamSynchronize(ctx->stream), "stream change: synchronise the old stream");
+    }
     ctx->stream = (hipStream_t)hip_stream;
     return FZ_OK;
 }
@@ -417,6 +445,7 @@ int fz_graph_end(fz_ctx *ctx, fz_graph **out_graph) {
         return fz_check_hip(e, "graph instantiate");
     }
     fz_graph *G = new fz_graph;
+    ctx->graphs_captured++;
     G->graph = g;
     G->exec = ex;
     G->device = ctx->device;
@@ -456,9 +485,13 @@ int fz_malloc(fz_ctx *ctx, size_t bytes, void **d_out) {
     return FZ_OK;
 }
 
+int fz_ctx_bind_public_challenge(fz_ctx *ctx, const int32_t *d_A, int l);
 int fz_free(fz_ctx *ctx, void *d_ptr) {
     FZ_REQUIRE(ctx, "ctx is NULL");
     FZ_DEV(ctx);
+    // freeing the rows that are bound as the public challenge ends the binding: the address may come back from the
+    // allocator with other contents, and the pre-split copy must never outlive what it was made from
+    if (d_ptr && d_ptr == (void *)ctx->bound_A && !ctx->capturing) FZ_TRY(fz_ctx_bind_public_challenge(ctx, nullptr, 0));
     if (d_ptr) FZ_HIP(hipFree(d_ptr), "hipFree");
     return FZ_OK;
 }
@@ -758,6 +791,84 @@ int fz_aggregate_partial(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alp
     return fz_aggregate_partial_batch(ctx, d_sig, d_alpha_hat, d_partial, 0, 1, N, l);
 }
 
+int fz_runtime_info(fz_ctx *ctx, int *out_build, int *out_runtime, char *out_arch, size_t arch_cap) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    if (out_build) *out_build = HIP_VERSION;
+    if (out_runtime) {
+        int v = 0;
+        FZ_HIP(hipRuntimeGetVersion(&v), "hipRuntimeGetVersion");
+        *out_runtime = v;
+    }
+    if (out_arch && arch_cap) {
+        hipDeviceProp_t prop;
+        FZ_HIP(hipGetDeviceProperties(&prop, ctx->device), "hipGetDeviceProperties");
+        snprintf(out_arch, arch_cap, "%s", prop.gcnArchName);
+    }
+    return FZ_OK;
+}
+
+int fz_ctx_bind_public_challenge(fz_ctx *ctx, const int32_t *d_A, int l) {
+    FZ_REQUIRE(ctx && (d_A == nullptr || l >= 1), "bad argument");
+    FZ_DEV(ctx);
+    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the public challenge cannot be (re)bound during graph capture");
+    FZ_HIP(hipStreamSynchronize(ctx->stream), "bind: synchronise");
+    FZ_TRY(fz_retire(ctx, ctx->d_Asplit, "split table free"));
+    ctx->d_Asplit = nullptr;
+    ctx->bound_A = nullptr;
+    ctx->bound_l = 0;
+    if (!d_A) return FZ_OK;
+    FZ_REQUIRE(((uintptr_t)d_A & 15) == 0, "the public challenge must be 16-byte aligned");
+    const size_t count = (size_t)l * ctx->degree;
+    FZ_HIP(hipMalloc((void **)&ctx->d_Asplit, count * sizeof(double2)), "split table alloc");
+    int rc = fz_launch_split_A(ctx, d_A, ctx->d_Asplit, count);
+    if (rc != FZ_OK) { (void)hipFree(ctx->d_Asplit); ctx->d_Asplit = nullptr; return rc; }
+    ctx->bound_A = d_A;
+    ctx->bound_l = l;
+    return FZ_OK;
+}
+
+// many aggregates of different sizes: chunks of kFzRaggedMax groups per launch
+static int aggregate_ragged(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, const int32_t *d_vkL, const int32_t *d_vkR,
+                            const int32_t *d_c_hat, const size_t *h_offsets, size_t groups, int l, int32_t *d_out32,
+                            int64_t *d_partial, size_t partial_stride, int64_t *d_target_partial, size_t target_stride) {
+    const size_t per = (size_t)l * ctx->degree;
+    for (size_t g = 0; g < groups; ++g) {
+        FZ_REQUIRE(h_offsets[g] <= h_offsets[g + 1], "offsets must not decrease");
+        FZ_REQUIRE(h_offsets[g + 1] - h_offsets[g] < ((size_t)1 << 21), "aggregate %zu: too many signers for exact accumulation (< 2^21)", g);
+    }
+    FZ_REQUIRE(h_offsets[groups] < 0xffffffffull, "too many signers in one call");
+    for (size_t g0 = 0; g0 < groups; g0 += (size_t)kFzRaggedMax) {
+        const size_t n = std::min<size_t>(kFzRaggedMax, groups - g0);
+        size_t nmax = 0;
+        for (size_t g = g0; g < g0 + n; ++g) nmax = std::max(nmax, h_offsets[g + 1] - h_offsets[g]);
+        FZ_TRY(fz_launch_aggregate(ctx, d_sig, d_alpha_hat, d_partial ? d_partial + g0 * partial_stride : nullptr, partial_stride,
+                                   d_out32 ? d_out32 + g0 * per : nullptr, n, nmax, l, d_vkL, d_vkR, d_c_hat,
+                                   d_target_partial ? d_target_partial + g0 * target_stride : nullptr, target_stride, h_offsets + g0));
+    }
+    return FZ_OK;
+}
+
+int fz_aggregate_core_ragged(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, const size_t *h_offsets, size_t groups,
+                             int l, int32_t *d_out) {
+    FZ_REQUIRE(ctx && l >= 1 && h_offsets && (groups == 0 || (d_sig && d_alpha_hat && d_out)), "bad argument");
+    FZ_DEV(ctx);
+    if (groups == 0) return FZ_OK;
+    return aggregate_ragged(ctx, d_sig, d_alpha_hat, nullptr, nullptr, nullptr, h_offsets, groups, l, d_out, nullptr, 0, nullptr, 0);
+}
+
+int fz_aggregate_target_partial_ragged(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, const int32_t *d_vkL,
+                                       const int32_t *d_vkR, const int32_t *d_c_hat, const size_t *h_offsets, size_t groups, int l,
+                                       int64_t *d_partial, size_t partial_stride, int64_t *d_target_partial, size_t target_stride) {
+    FZ_REQUIRE(ctx && l >= 1 && h_offsets && d_target_partial && d_alpha_hat && d_vkL && d_vkR && d_c_hat, "bad argument");
+    FZ_REQUIRE((d_sig == nullptr) == (d_partial == nullptr), "d_sig and d_partial go together (both NULL: verification targets only)");
+    FZ_DEV(ctx);
+    if (groups == 0) return FZ_OK;
+    FZ_REQUIRE(groups == 1 || ((!d_partial || partial_stride >= (size_t)l * ctx->degree) && target_stride >= (size_t)ctx->degree),
+               "bad strides");
+    return aggregate_ragged(ctx, d_sig, d_alpha_hat, d_vkL, d_vkR, d_c_hat, h_offsets, groups, l, nullptr, d_partial, partial_stride,
+                            d_target_partial, target_stride);
+}
+
 int fz_reduce_i64(fz_ctx *ctx, const int64_t *d_in, int32_t *d_out, size_t count) {
     FZ_REQUIRE(ctx && (count == 0 || (d_in && d_out)), "NULL argument");
     FZ_DEV(ctx);
@@ -820,7 +931,7 @@ int fz_verify_with_target_batch(fz_ctx *ctx, const int32_t *d_A, const int32_t *
     FZ_TRY(fz_scratch(ctx, oW + rows * sizeof(int32_t), &d));
     if (groups > ctx->verdict_cap) {
         FZ_HIP(hipStreamSynchronize(ctx->stream), "verdict sync");
-        FZ_HIP(hipFree(ctx->d_verdict), "verdict free");
+        FZ_TRY(fz_retire(ctx, ctx->d_verdict, "verdict free"));
         ctx->d_verdict = nullptr;
         ctx->verdict_cap = 0;
         FZ_HIP(hipMalloc((void **)&ctx->d_verdict, groups * sizeof(int)), "verdict alloc");
@@ -970,7 +1081,7 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
     if (!ctx->d_chal_tab || ctx->chal_tab_ib != ib || ctx->chal_tab_degree != P->degree) {
         std::vector<uint32_t> tab((size_t)(P->degree + 1) * 16);
         fz_challenge_weight_table(ib, P->degree, tab.data());
-        if (ctx->d_chal_tab) { FZ_HIP(hipStreamSynchronize(ctx->stream), "table sync"); FZ_HIP(hipFree(ctx->d_chal_tab), "table free"); ctx->d_chal_tab = nullptr; }
+        if (ctx->d_chal_tab) { FZ_HIP(hipStreamSynchronize(ctx->stream), "table sync"); FZ_TRY(fz_retire(ctx, ctx->d_chal_tab, "table free")); ctx->d_chal_tab = nullptr; }
         FZ_HIP(hipMalloc((void **)&ctx->d_chal_tab, tab.size() * 4), "table alloc");
         FZ_HIP(hipMemcpy(ctx->d_chal_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice), "table upload");
         ctx->chal_tab_ib = ib;
@@ -1042,6 +1153,11 @@ int fz_sample_secret_polys_dev(fz_ctx *ctx, const uint64_t *h_seeds, size_t N, i
     if (bound < 1 || bound >= (1ll << 32)) return fz_set_error(FZ_E_BADARG, "empty range for randrange()");
     if (weight_bound < degree)
         return fz_set_error(FZ_E_UNSUPPORTED, "device sampler: weight bound = degree only (no shuffle); use fz_sample_secret_polys");
+    // the right half of a key is seeded with seed + 1: at seed = 2^64 - 1 that is 2^64, a THREE-word key for CPython's
+    // init_by_array, not the wrapped 0 -- outside what this entry (and the host clone) takes
+    for (size_t i = 0; i < N; ++i)
+        if (h_seeds[i] == UINT64_MAX)
+            return fz_set_error(FZ_E_UNSUPPORTED, "seed %zu is 2^64 - 1: seed + 1 needs a wider key than this sampler takes", i);
     if (N == 0) return FZ_OK;
     if (!ctx->d_mt_init) {
         uint32_t tab[624];

@@ -589,6 +589,9 @@ int fz_sample_coefficients(uint64_t seed, int64_t modulus, int degree, int64_t n
 int fz_sample_secret_polys(const uint64_t *h_seeds, size_t N, int64_t modulus, int degree, int64_t norm_bound,
                            int64_t weight_bound, int32_t *h_out, int threads) {
     if ((N && !h_seeds) || !h_out) return fz_set_error(FZ_E_BADARG, "NULL argument");
+    for (size_t i = 0; i < N; ++i)      // seed + 1 must not wrap: CPython seeds 2^64 with a three-word key, not with 0
+        if (h_seeds[i] == UINT64_MAX)
+            return fz_set_error(FZ_E_UNSUPPORTED, "seed %zu is 2^64 - 1: seed + 1 needs a wider key than this sampler takes", i);
     std::atomic<int> bad(0);      // set by any worker thread
     parallel_for(2 * N, threads, [&](size_t i) {
         if (fz_sample_coefficients(h_seeds[i / 2] + (i & 1), modulus, degree, norm_bound, weight_bound,

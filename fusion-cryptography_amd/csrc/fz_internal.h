@@ -71,7 +71,27 @@ struct fz_ctx {
     int knob_stream_nt;          // FZ_STREAM_NT: streaming (non-temporal) stores in the elementwise kernels
     int knob_stream_per_cu;      // grid cap of the grid-stride streaming kernels in workgroups per CU (0 = flat grid)
     int knob_verify_blocks, knob_verify_unfused, knob_verify_ordered, knob_keygen_unfused, knob_polymul_unfused;
+    int knob_no_split;           // FZ_NO_SPLIT=1: ignore the bound pre-split public challenge (A/B runs)
+    int knob_verify_cent;        // FZ_VERIFY_CENT=1: centre the inverse transform's outputs before the norm test even when beta allows skipping it
+    // the public challenge A as the caller bound it (fz_ctx_bind_public_challenge): rows pre-split as fp64 pairs
+    // (hi = A >> 16, lo = A & 0xffff) so that the fused keygen / verify kernels accumulate A (.) y with two FMAs
+    const int32_t *bound_A;
+    int bound_l;
+    double2 *d_Asplit;           // [bound_l][degree]
+    // device allocations replaced by a larger one while a captured graph may still hold their address: kept until
+    // fz_ctx_destroy (a replay must never touch freed memory)
+    int graphs_captured;
+    void **retired;
+    int n_retired, cap_retired;
     // RCCL (fz_comm_*): communicators are owned by the caller; nothing here
+};
+
+// group table of a ragged aggregation launch (kernarg segment): signers of aggregate g are rows [off[g], off[g+1]) of the
+// concatenated signature / coefficient arrays; base / extra = its signers per slice and the remainder
+constexpr int kFzRaggedMax = 64;
+struct FzRagged {
+    unsigned off[kFzRaggedMax + 1];
+    unsigned base[kFzRaggedMax], extra[kFzRaggedMax];
 };
 
 // the job table of one fz_ntt_multi launch travels in the kernarg segment (no device copy, capturable in a graph)
@@ -97,6 +117,7 @@ int fz_scratch(fz_ctx *ctx, size_t bytes, void **out);
 int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out);
 int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, double **part, int **state);
 int fz_agg_scratch(fz_ctx *ctx, size_t tiles, size_t tile_words, unsigned long long **acc);
+int fz_retire(fz_ctx *ctx, void *d_ptr, const char *what);       // hipFree, or keep until destroy when graphs were captured
 
 // launchers (fz_ntt.hip)
 int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse);
@@ -122,6 +143,7 @@ bool fz_host_params_ok(const fz_scheme_params *P);
 int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int32_t *out, size_t batch);
 int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,
                            int l, bool broadcast = false);
+int fz_launch_split_A(fz_ctx *ctx, const int32_t *A, double2 *out, size_t count);
 int fz_launch_fill_synthetic(fz_ctx *ctx, int32_t *out, size_t count, unsigned long long seed);
 int fz_launch_bcast_rows(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t segments, int l);
 int fz_launch_verify_fused_i64(fz_ctx *ctx, const int32_t *A, const int64_t *sig, size_t sig_stride, const int64_t *target,
@@ -137,7 +159,8 @@ int fz_launch_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *o
 int fz_launch_sign(fz_ctx *ctx, const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig, size_t batch, int l);
 int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *out64, size_t pstride,
                         int32_t *out32, size_t groups, size_t N, int l, const int32_t *vkL = nullptr,
-                        const int32_t *vkR = nullptr, const int32_t *c = nullptr, int64_t *tout64 = nullptr, size_t tstride = 0);
+                        const int32_t *vkR = nullptr, const int32_t *c = nullptr, int64_t *tout64 = nullptr, size_t tstride = 0,
+                        const size_t *h_offsets = nullptr);
 int fz_launch_target_partial(fz_ctx *ctx, const int32_t *vkL, const int32_t *vkR, const int32_t *c, const int32_t *alpha,
                              int64_t *partial, size_t pstride, size_t groups, size_t N);
 int fz_launch_reduce_i64(fz_ctx *ctx, const int64_t *in, int32_t *out, size_t count);

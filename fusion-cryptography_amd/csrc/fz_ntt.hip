@@ -292,6 +292,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
             }
         }
 
+        // After the contiguous pass a[0] (the sum of the lane's 16 inputs, up to 2^(31+SB)) is the one value no multiply
+        // has reduced; a[1] <= 2^(29+SB), the rest less.  One fold (2 ops) brings the largest operand of the strided pass
+        // down to 2^(29+SB) * 2^4 <= 2^37: the last stage can then use the 4-op multiply (16 x 2 ops saved per lane).
+        if (FAST && 31 + SB + 4 > 38) a[0] = fz_fold(a[0], m);
         // transpose back to the strided layout
         {
             double2 *blk = reinterpret_cast<double2 *>(row + 18 * r);
@@ -303,9 +307,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
         for (int k = 0; k < 16; ++k) a[k] = row[pad16(r + L * k)];
         wave_sync();
 
-        // strided pass: GS stages with distance L, 2L, 4L, 8L; uniform twiddles.  With raw int32
-        // inputs the lazily accumulated operands reach 2^(32+SB+s): the last stage (up to 2^39) is
-        // beyond the 4-op multiply's bound and uses the general 6-op form.
+        // strided pass: GS stages with distance L, 2L, 4L, 8L; uniform twiddles; n^-1 folded into the last stage.
+        // Operands stay below 2^38 (see the fold above), so every stage uses the 4-op multiply when the modulus admits it.
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int tk = 1 << s;
@@ -315,13 +318,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
                 if (k & tk) continue;
                 const double u = a[k], v = a[k + tk];
                 if (s == 3) {
-                    a[k] = fz_mulmod(u + v, twA.n_inv, m);
-                    a[k + tk] = fz_mulmod(u - v, twA.w1_n_inv, m);
+                    a[k] = tw_mul<FAST>(u + v, twA.n_inv, twA.n_inv2, m);
+                    a[k + tk] = tw_mul<FAST>(u - v, twA.w1_n_inv, twA.w1_n_inv2, m);
                 } else {
                     const int e = h + (k >> (s + 1));
                     a[k] = u + v;
-                    a[k + tk] = (SB + s <= 6) ? tw_mul<FAST>(u - v, twA.w[e], twA.w2[e], m)
-                                              : fz_mulmod(u - v, twA.w[e], m);
+                    a[k + tk] = tw_mul<FAST>(u - v, twA.w[e], twA.w2[e], m);
                 }
             }
         }
@@ -502,6 +504,11 @@ __device__ __forceinline__ void inv4_passes(double (&a)[4], double *region, cons
             a[0] = u + v; a[2] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
             u = a[1]; v = a[3];
             a[1] = u + v; a[3] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
+            // Degree 256 with raw int32 inputs: a[0] is the only value no multiply has reduced (the sum of four inputs, up to
+            // 2^33; a[1] <= 2^31.1, a[2], a[3] <= 2^30.1).  Folding it once (2 ops) keeps every later operand below
+            // 2^31.1 * 2^6 = 2^37.1, inside the 4-op multiply's 2^38 bound up to and including the final stage -- which
+            // otherwise needs the general 6-op form four times (8 extra ops per lane).
+            if (FAST && i == 0 && 31 + LOGD > 38) a[0] = fz_fold(a[0], m);
             if (s == 1) {
                 *reinterpret_cast<double2 *>(region + swz4(base)) = make_double2(a[0], a[1]);
                 *reinterpret_cast<double2 *>(region + swz4(base + 2)) = make_double2(a[2], a[3]);
@@ -511,9 +518,9 @@ __device__ __forceinline__ void inv4_passes(double (&a)[4], double *region, cons
             }
         } else {
             // last pass: uniform twiddles itw[2], itw[3], itw[1]; n^-1 folded into the final stage.
-            // With raw int32 inputs the operands of the final stage reach 2^(31+LOGD): beyond the 4-op
-            // multiply's 2^38 bound for degree 256, so that stage uses the general 6-op form.
-            constexpr bool LAST4 = FAST && (31 + LOGD <= 38);
+            // Its operands are below 2^38 for raw int32 inputs: 2^(31+LOGD) up to degree 128, 2^37.1 at degree 256
+            // thanks to the fold after pass 0 -- so the 4-op multiply serves whenever the modulus admits it.
+            constexpr bool LAST4 = FAST;
             double u = a[0], v = a[1];
             a[0] = u + v; a[1] = tw_mul<FAST>(u - v, twA.w[2], twA.w2[2], m);
             u = a[2]; v = a[3];
@@ -733,8 +740,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
 // matching row of the public challenge A and accumulated; the l partial products are reduced through LDS
 // into the verification-key row.  sk_hat is never re-read: 342 KB of HBM traffic per key instead of 508 KB.
 // ------------------------------------------------------------------------------------------
-template <int LOGD, bool FAST>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_t *A, const int32_t *coef, size_t coef_seg_stride,
+// SPLIT: the public challenge comes pre-split as fp64 pairs (hi = A >> 16, lo = A & 0xffff: fz_ctx_bind_public_challenge), so
+// A[k] (.) y accumulates with TWO FMAs per coefficient -- y * hi and y * lo stay below 2^47 and a wave's rows (at most kSplitFold
+// between folds) sum exactly in fp64 -- instead of an int -> fp64 conversion, the 5-op multiply and an add.
+constexpr int kSplitFold = 32;      // 32 * 2^31 * 2^16 = 2^52 < 2^53
+template <int LOGD, bool FAST, bool SPLIT>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_t *A, const double2 *__restrict__ As, const int32_t *coef,
+                                                                    size_t coef_seg_stride,
                                                                     size_t coef_row_stride, int32_t *sk_hat,
                                                                     int32_t *vk, int l, const double2 *__restrict__ tw2,
                                                                     FzTwA twA, FzMod m) {
@@ -752,6 +764,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
     fwd4_load_twiddles<LOGD>(twl, tw2, mm);
 
     double acc[4] = {0, 0, 0, 0};
+    double ach[4] = {0, 0, 0, 0};                       // SPLIT: sums of y * hi (acc holds y * lo)
+    int since = 0;
     const int tasks = (l + PPW - 1) / PPW;
     int xn[4];
     auto fetch = [&](int task) {
@@ -767,18 +781,49 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
         double a[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = (double)xn[k];
-        const int4 ak = *reinterpret_cast<const int4 *>(A + (size_t)(valid ? row : l - 1) * D + 4 * mm);
+        const size_t aoff = (size_t)(valid ? row : l - 1) * D + 4 * mm;
+        int4 ak;
+        double2 as[4];
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) as[k] = As[aoff + k];
+        } else {
+            ak = *reinterpret_cast<const int4 *>(A + aoff);
+        }
         if (task + kWavesPerBlock < tasks) fetch(task + kWavesPerBlock);
         fwd4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
         const double y0 = fz_cent(a[0], m), y1 = fz_cent(a[1], m), y2 = fz_cent(a[2], m), y3 = fz_cent(a[3], m);
         if (valid) {
             *reinterpret_cast<int4 *>(sk_hat + (size_t)row * D + 4 * mm) = make_int4((int)y0, (int)y1, (int)y2, (int)y3);
-            acc[0] += fz_mulmod(y0, (double)ak.x, m);
-            acc[1] += fz_mulmod(y1, (double)ak.y, m);
-            acc[2] += fz_mulmod(y2, (double)ak.z, m);
-            acc[3] += fz_mulmod(y3, (double)ak.w, m);
+            if constexpr (SPLIT) {
+                const double y[4] = {y0, y1, y2, y3};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ach[k] = __builtin_fma(y[k], as[k].x, ach[k]);
+                    acc[k] = __builtin_fma(y[k], as[k].y, acc[k]);
+                }
+            } else {
+                acc[0] += fz_mulmod(y0, (double)ak.x, m);
+                acc[1] += fz_mulmod(y1, (double)ak.y, m);
+                acc[2] += fz_mulmod(y2, (double)ak.z, m);
+                acc[3] += fz_mulmod(y3, (double)ak.w, m);
+            }
+        }
+        if constexpr (SPLIT) {
+            if (++since == kSplitFold) {                 // wave-uniform; never reached by the scheme's ranks (83 / 195 rows over 4 waves)
+                since = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[k] = fz_fold(acc[k], m) + fz_fold(ach[k] * 65536.0, m);
+                    ach[k] = 0.0;
+                }
+            }
         }
         wave_sync();
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fz_fold(acc[k], m) + fz_fold(ach[k] * 65536.0, m);
     }
     double *mine = accbuf + wave * 256 + p * D + 4 * mm;
     mine[0] = acc[0]; mine[1] = acc[1]; mine[2] = acc[2]; mine[3] = acc[3];
@@ -829,10 +874,15 @@ template <> struct Raw4<int64_t> {
 __device__ __forceinline__ int centred_any(int32_t v, const FzMod &) { return v; }
 __device__ __forceinline__ int centred_any(int64_t v, const FzMod &m) { return (int)fz_cent_i64(v, m); }
 
-template <int LOGD, bool FAST, typename T, bool ORDERED>
-__global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t *A, const T *sig, size_t sig_stride,
+// SPLIT: A pre-split as fp64 pairs (see keygen_fused).  `lazy` (host-decided, uniform): beta < q/2 - q * 2^-12, so the norm
+// test needs no centring at all -- the inverse transform's outputs r satisfy |r| <= q/2 + q * 2^-13; if |r| <= beta then r is
+// already the centred residue and passes; if |r| > beta then |cent(r)| >= q - |r| >= q/2 - q * 2^-13 > beta (or cent(r) = r):
+// max |r| > beta <=> max |cent(r)| > beta.  Likewise r == 0 (mod q) <=> r == 0, since |r| < q.  Saves 8 of ~180 ops per row.
+template <int LOGD, bool FAST, typename T, bool ORDERED, bool SPLIT>
+__global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t *A, const double2 *__restrict__ As, const T *sig,
+                                                                  size_t sig_stride,
                                                                   const T *target, size_t target_stride, int l, long long beta,
-                                                                  long long omega, const double2 *__restrict__ itw2,
+                                                                  long long omega, int lazy, const double2 *__restrict__ itw2,
                                                                   FzTwA twA, FzMod m, double *part, int *state, int *verdict) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
     static_assert(D <= 64 * kVerifyWaves, "one thread per coefficient in the combine steps");
@@ -863,35 +913,67 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
     // it a workgroup per aggregate (many aggregates per launch) paid one memory latency per row: 24 % of the HBM peak.
     Raw4<T> rn;
     int4 an;
+    double2 asn[4];
     auto fetch = [&](int t) {
         const int row = t * PPW + p;
         const size_t off = (size_t)(row < l ? row : l - 1) * D + 4 * mm;
-        an = *reinterpret_cast<const int4 *>(A + off);
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asn[k] = As[off + k];
+        } else {
+            an = *reinterpret_cast<const int4 *>(A + off);
+        }
         rn.load(sig + off);
     };
+    double ach[4] = {0, 0, 0, 0};                   // SPLIT: sums of sigma * hi (acc holds sigma * lo)
+    int since = 0;
     int task = r * kVerifyWaves + wave;
     if (task < tasks) fetch(task);
     for (; task < tasks; task += step) {
         const int row = task * PPW + p;
         const bool valid = row < l;
         const int4 ak = an;
+        double2 as[4];
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) as[k] = asn[k];
+        }
         double a[4];
         rn.unpack(a, m);
         fetch(task + step < tasks ? task + step : tasks - 1);
         if (valid) {
-            acc[0] += fz_mulmod(a[0], (double)ak.x, m);
-            acc[1] += fz_mulmod(a[1], (double)ak.y, m);
-            acc[2] += fz_mulmod(a[2], (double)ak.z, m);
-            acc[3] += fz_mulmod(a[3], (double)ak.w, m);
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {       // |a| <= 2^31 (raw int32 rows): a * hi, a * lo < 2^47
+                    ach[k] = __builtin_fma(a[k], as[k].x, ach[k]);
+                    acc[k] = __builtin_fma(a[k], as[k].y, acc[k]);
+                }
+            } else {
+                acc[0] += fz_mulmod(a[0], (double)ak.x, m);
+                acc[1] += fz_mulmod(a[1], (double)ak.y, m);
+                acc[2] += fz_mulmod(a[2], (double)ak.z, m);
+                acc[3] += fz_mulmod(a[3], (double)ak.w, m);
+            }
+        }
+        if constexpr (SPLIT) {
+            if (++since == kSplitFold) {                 // wave-uniform
+                since = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[k] = fz_fold(acc[k], m) + fz_fold(ach[k] * 65536.0, m);
+                    ach[k] = 0.0;
+                }
+            }
         }
         inv4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
         // norm and weight of the row stay in the fp64 lanes (no conversions): a slot past the last row repeats row l - 1, which
         // changes neither the maximum nor any row's weight.  Weight = population count of "non-zero" ballots (scalar unit).
+        if (!lazy) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            a[k] = fz_cent(a[k], m);                      // canonical: zero mod q <=> 0
-            mx = __builtin_fmax(mx, __builtin_fabs(a[k]));
+            for (int k = 0; k < 4; ++k) a[k] = fz_cent(a[k], m);          // canonical: zero mod q <=> 0
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx = __builtin_fmax(mx, __builtin_fabs(a[k]));
         if (weigh) {
             int cnt = 0;
 #pragma unroll
@@ -899,6 +981,10 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
             if ((long long)cnt > omega) wfail = 1;
         }
         wave_sync();      // the next row's first-pass writes must not overtake this row's last reads
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = fz_fold(acc[k], m) + fz_fold(ach[k] * 65536.0, m);
     }
     // partial products of this wave, indexed by (row slot p, position)
     double *mine = accbuf + wave * 256 + p * D + 4 * mm;
@@ -1132,12 +1218,16 @@ int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, i
     const dim3 grid((unsigned)segments), block(64 * kWavesPerBlock);
     const size_t seg_stride = broadcast ? (size_t)ctx->degree : (size_t)l * ctx->degree;
     const size_t row_stride = broadcast ? 0 : (size_t)ctx->degree;
-#define FZ_KF(LOGD, FAST) hipLaunchKernelGGL((keygen_fused<LOGD, FAST>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \
+    // the pre-split copy of A serves when the caller bound exactly these rows (fz_ctx_bind_public_challenge)
+    const double2 *As = (ctx->d_Asplit && ctx->bound_A == A && l <= ctx->bound_l && !ctx->knob_no_split) ? ctx->d_Asplit : nullptr;
+#define FZ_KF2(LOGD, FAST, SP) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, SP>), grid, block, 0, ctx->stream, A, As, coef, seg_stride, row_stride, sk_hat, vk, l, \
                                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod)
+#define FZ_KF(LOGD, FAST) do { if (As) FZ_KF2(LOGD, FAST, true); else FZ_KF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_KF(8, true); else FZ_KF(8, false); }
     else if (ctx->logd == 6) { if (ctx->mod.fast) FZ_KF(6, true); else FZ_KF(6, false); }
     else return fz_set_error(FZ_E_UNSUPPORTED, "fused keygen: degree 64 or 256 only");
 #undef FZ_KF
+#undef FZ_KF2
     return fz_check_hip(hipGetLastError(), "keygen_fused launch");
 }
 
@@ -1159,14 +1249,19 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
     int rc = fz_verify_scratch(ctx, groups, (size_t)ctx->degree, &part, &state);
     if (rc != FZ_OK) return rc;
     const dim3 grid((unsigned)R, (unsigned)groups), block(64 * kVerifyWaves);
-#define FZ_VF2(LOGD, FAST, ORD) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T, ORD>), grid, block, 0, ctx->stream, A, sig, sig_stride, target, \
-                                                   target_stride, l, (long long)beta, (long long)omega, (const double2 *)ctx->d_itw2, \
+    const double2 *As = (ctx->d_Asplit && ctx->bound_A == A && l <= ctx->bound_l && !ctx->knob_no_split) ? ctx->d_Asplit : nullptr;
+    // the inverse passes leave |r| <= q/2 + q * 2^-13 (4-op multiply) -- see the kernel's header for why no centring is needed then
+    const int lazy = (beta >= 0 && (double)beta < 0.5 * ctx->mod.q - ctx->mod.q / 4096.0 && !ctx->knob_verify_cent) ? 1 : 0;
+#define FZ_VF3(LOGD, FAST, ORD, SP) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T, ORD, SP>), grid, block, 0, ctx->stream, A, As, sig, sig_stride, target, \
+                                                   target_stride, l, (long long)beta, (long long)omega, lazy, (const double2 *)ctx->d_itw2, \
                                                    ctx->itwA, ctx->mod, part, state, d_verdict)
+#define FZ_VF2(LOGD, FAST, ORD) do { if (As) FZ_VF3(LOGD, FAST, ORD, true); else FZ_VF3(LOGD, FAST, ORD, false); } while (0)
 #define FZ_VF(LOGD, FAST) do { if (ctx->knob_verify_ordered) FZ_VF2(LOGD, FAST, true); else FZ_VF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_VF(8, true); else FZ_VF(8, false); }
     else { if (ctx->mod.fast) FZ_VF(6, true); else FZ_VF(6, false); }
 #undef FZ_VF
 #undef FZ_VF2
+#undef FZ_VF3
     rc = fz_check_hip(hipGetLastError(), "verify_fused launch");
     if (rc != FZ_OK) ctx->verify_dirty = 1;          // the accumulators may be left non-zero: re-zeroed before the next launch
     return rc;

@@ -241,12 +241,17 @@ struct AggDiv {                   // host-side arithmetic of the tile mapping (s
     unsigned base, extra;         // N / nsl, N % nsl
 };
 
-template <int WAVES>
+// RAG = FzNoRag: `groups` aggregates of N signers each, aggregate g's rows at g * N; RAG = FzRagged: aggregates of DIFFERENT
+// sizes in one launch (fz_aggregate_*_ragged: many independent aggregate() calls, fusion.py:655, batched) -- aggregate g's
+// signers are rows [off[g], off[g+1]) of the concatenated arrays, its slices from the table's base / extra
+struct FzNoRag {};
+template <int WAVES, typename RAG>
 __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
                                                                 const int32_t *vkR, const int32_t *c, size_t N, int l, int d4,
                                                                 int ncb_a, int ncb, int nsl, int pairs, AggDiv dv,
                                                                 unsigned long long *accum, int64_t *out64, size_t pstride,
-                                                                int64_t *tout64, size_t tstride, int32_t *out32, FzMod m) {
+                                                                int64_t *tout64, size_t tstride, int32_t *out32, FzMod m, RAG rag) {
+    constexpr bool RAGGED = !__is_same(RAG, FzNoRag);
     __shared__ __attribute__((aligned(16))) double red[WAVES * kAggTile];      // 64 KiB at 8 waves
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // block id -> tile t = p * ncb + cb (p = g * nsl + sb: the (aggregate, slice) pair, cb the column block).  Workgroups
@@ -263,12 +268,17 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
     const unsigned gu = nsl > 1 ? __umulhi(pu, dv.m_nsl) : pu;
     const size_t g = (size_t)gu;
     const int sb = (int)(pu - gu * (unsigned)nsl);
-    const size_t base = dv.base, extra = dv.extra;
+    size_t base = dv.base, extra = dv.extra, first_row = g * N;
+    if constexpr (RAGGED) {
+        base = rag.base[gu];
+        extra = rag.extra[gu];
+        first_row = rag.off[gu];
+    }
     const size_t i0 = (size_t)sb * base + ((size_t)sb < extra ? (size_t)sb : extra);
     const size_t i1 = i0 + base + ((size_t)sb < extra ? 1 : 0);
     const bool tgt = cb >= ncb_a;
     const size_t cols_a = (size_t)l * d4;
-    const int4 *alpha4 = reinterpret_cast<const int4 *>(alpha) + g * N * (size_t)d4;
+    const int4 *alpha4 = reinterpret_cast<const int4 *>(alpha) + first_row * (size_t)d4;
 
     double lo[kAggR][4];
 #pragma unroll
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
             const size_t cr = (size_t)cb * (64 * kAggR) + (size_t)r * 64 + lane;
             col[r] = cr < cols_a ? cr : cols_a - 1;       // clamped lanes compute garbage that is never written
         }
-        const int4 *sig4 = reinterpret_cast<const int4 *>(sig) + g * N * cols_a;
+        const int4 *sig4 = reinterpret_cast<const int4 *>(sig) + first_row * cols_a;
         // kAggDepth signers in flight per wave (5 loads of 16 bytes per lane each): a wave's signers are a SEQUENTIAL
         // chain of memory latencies otherwise (first version, one signer ahead: N = 1024 took 29 us, 11 signers per wave
         // at ~2 us each)
@@ -347,9 +357,9 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
         // verification target: sum_i (vkL_i * c_i + vkR_i) * alpha_i, degree/4 int4 columns in lo[0]
         const size_t tcol = (size_t)(cb - ncb_a) * 64 + lane;
         const size_t tc = tcol < (size_t)d4 ? tcol : (size_t)d4 - 1;
-        const int4 *L4 = reinterpret_cast<const int4 *>(vkL) + g * N * (size_t)d4;
-        const int4 *R4 = reinterpret_cast<const int4 *>(vkR) + g * N * (size_t)d4;
-        const int4 *C4 = reinterpret_cast<const int4 *>(c) + g * N * (size_t)d4;
+        const int4 *L4 = reinterpret_cast<const int4 *>(vkL) + first_row * (size_t)d4;
+        const int4 *R4 = reinterpret_cast<const int4 *>(vkR) + first_row * (size_t)d4;
+        const int4 *C4 = reinterpret_cast<const int4 *>(c) + first_row * (size_t)d4;
 #pragma unroll 2
         for (size_t i = i0 + wave; i < i1; i += WAVES) {
             const size_t o = i * d4 + tc;
@@ -677,30 +687,38 @@ template <int WAVES>
 static void launch_onepass(fz_ctx *ctx, unsigned grid, const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
                            const int32_t *vkR, const int32_t *c, size_t N, int l, int d4, int ncb_a, int ncb, int nsl, int pairs,
                            unsigned long long *acc, int64_t *out64, size_t pstride, int64_t *tout64, size_t tstride,
-                           int32_t *out32) {
+                           int32_t *out32, const FzRagged *rag) {
     AggDiv dv;
     dv.m_ncb = ncb > 1 ? (unsigned)((0x100000000ull + (unsigned)ncb - 1) / (unsigned)ncb) : 0u;      // unused for a divisor of 1
     dv.m_nsl = nsl > 1 ? (unsigned)((0x100000000ull + (unsigned)nsl - 1) / (unsigned)nsl) : 0u;
     dv.per_xcd = (unsigned)(((size_t)pairs * ncb + 7) / 8);
     dv.base = (unsigned)(N / (size_t)nsl);
     dv.extra = (unsigned)(N % (size_t)nsl);
-    hipLaunchKernelGGL(aggregate_onepass<WAVES>, dim3(grid), dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N, l, d4,
-                       ncb_a, ncb, nsl, pairs, dv, acc, out64, pstride, tout64, tstride, out32, ctx->mod);
+    if (rag)
+        hipLaunchKernelGGL((aggregate_onepass<WAVES, FzRagged>), dim3(grid), dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N,
+                           l, d4, ncb_a, ncb, nsl, pairs, dv, acc, out64, pstride, tout64, tstride, out32, ctx->mod, *rag);
+    else
+        hipLaunchKernelGGL((aggregate_onepass<WAVES, FzNoRag>), dim3(grid), dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N,
+                           l, d4, ncb_a, ncb, nsl, pairs, dv, acc, out64, pstride, tout64, tstride, out32, ctx->mod, FzNoRag());
 }
 
 // out64 != nullptr: int64 partial sums at out64 + g*pstride; else centred int32 at out32 + g*l*degree.
 // vkL != nullptr: the verification target's int64 partial sums go to tout64 + g*tstride in the same launch.
+// h_offsets != nullptr (ragged): aggregate g's signers are rows [h_offsets[g], h_offsets[g+1]) of the arrays, groups <=
+// kFzRaggedMax, N = the largest group; sig == nullptr then means "verification targets only".  One-pass kernel only.
 int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *out64, size_t pstride,
                         int32_t *out32, size_t groups, size_t N, int l, const int32_t *vkL, const int32_t *vkR,
-                        const int32_t *c, int64_t *tout64, size_t tstride) {
+                        const int32_t *c, int64_t *tout64, size_t tstride, const size_t *h_offsets) {
     if (groups == 0) return FZ_OK;
     const int d = ctx->degree;
     const uintptr_t align = (uintptr_t)sig | (uintptr_t)alpha | (uintptr_t)vkL | (uintptr_t)vkR | (uintptr_t)c;
     const bool vec = (d % 4 == 0) && (align & 15) == 0;
-    if (vec && (d & (d - 1)) == 0 && d <= 256 && !ctx->knob_agg_twopass) {
+    if (h_offsets && !(vec && (d & (d - 1)) == 0 && d <= 256 && groups <= (size_t)kFzRaggedMax))
+        return fz_set_error(FZ_E_UNSUPPORTED, "ragged aggregation: power-of-two degree <= 256, 16-byte aligned rows, <= %d aggregates per launch", kFzRaggedMax);
+    if (vec && (d & (d - 1)) == 0 && d <= 256 && (!ctx->knob_agg_twopass || h_offsets)) {
         const int d4 = d / 4;
         const size_t cols_a = (size_t)l * d4;
-        const int ncb_a = (int)((cols_a + 64 * kAggR - 1) / (64 * kAggR));
+        const int ncb_a = sig ? (int)((cols_a + 64 * kAggR - 1) / (64 * kAggR)) : 0;
         const int ncb = ncb_a + (vkL ? 1 : 0);                       // d4 <= 64: the target fits one column block
         // slices of the signers per aggregate: as many tiles (column block x aggregate x slice) as the chip holds at once --
         // one 8-wave workgroup per CU (180 VGPRs: two waves per SIMD) -- so that every CU streams from the first moment
@@ -726,12 +744,23 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
             if (rc != FZ_OK) return rc;
         }
         const unsigned grid = (unsigned)(8 * ((pairs * (size_t)ncb + 7) / 8));
+        FzRagged rag;
+        if (h_offsets) {
+            for (size_t g = 0; g < groups; ++g) {
+                const size_t ng = h_offsets[g + 1] - h_offsets[g];
+                rag.off[g] = (unsigned)h_offsets[g];
+                rag.base[g] = (unsigned)(ng / nsl);
+                rag.extra[g] = (unsigned)(ng % nsl);
+            }
+            rag.off[groups] = (unsigned)h_offsets[groups];
+        }
+        const FzRagged *rp = h_offsets ? &rag : nullptr;
         if (waves == 4)
             launch_onepass<4>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, out64,
-                              pstride, tout64, tstride, out32);
+                              pstride, tout64, tstride, out32, rp);
         else
             launch_onepass<8>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, out64,
-                              pstride, tout64, tstride, out32);
+                              pstride, tout64, tstride, out32, rp);
         const int rc = fz_check_hip(hipGetLastError(), "aggregate launch");
         if (rc != FZ_OK && nsl > 1) ctx->agg_dirty = 1;              // accumulators / tickets may no longer be zero
         return rc;
@@ -767,6 +796,21 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
         hipLaunchKernelGGL(sum_splits_kernel<true>, grid2, dim3(kBlock), 0, ctx->stream, (const double *)scr, splits, count,
                            count_a, (int64_t *)nullptr, (size_t)0, tout64, tstride, out32, ctx->mod);
     return fz_check_hip(hipGetLastError(), "aggregate sum launch");
+}
+
+// the public challenge as fp64 pairs (hi, lo), A = hi * 2^16 + lo with hi = A >> 16 (arithmetic), lo = A & 0xffff
+__global__ __launch_bounds__(kBlock) void split_A_kernel(const int32_t *A, double2 *out, size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const int v = A[i];
+        out[i] = make_double2((double)(v >> 16), (double)(v & 0xffff));
+    }
+}
+
+int fz_launch_split_A(fz_ctx *ctx, const int32_t *A, double2 *out, size_t count) {
+    if (count == 0) return FZ_OK;
+    hipLaunchKernelGGL(split_A_kernel, dim3(grid_for(ctx, count)), dim3(kBlock), 0, ctx->stream, A, out, count);
+    return fz_check_hip(hipGetLastError(), "split_A launch");
 }
 
 // out[seg][k][:] = in[seg][:] for k < l (generic-degree path of fz_keygen_core_bcast)

@@ -43,6 +43,7 @@ class Context:
         self._h = c_void_p()
         self.modulus, self.degree, self.root, self.inv_root = modulus, degree, root, inv_root
         self.device = device
+        self.bound_A = 0
         if not (0 < modulus < 2 ** 31):
             raise FusionHipError(FZ_E_BADARG, f"modulus {modulus} outside (0, 2^31)")
         check(self._lib, self._lib.fz_ctx_create(device, modulus, degree, root % modulus, inv_root % modulus,
@@ -86,6 +87,19 @@ class Context:
         check(self._lib, self._lib.fz_graph_end(self._h, byref(g)))
         return Graph(self, g)
 
+    def bind_public_challenge(self, d_A, l):
+        """declare the rows at d_A [l][degree] (device) as THE public challenge: the fused keygen / verify kernels then use a
+        pre-split fp64 copy (two FMAs per coefficient for A (.) y); d_A = 0 unbinds.  The rows must not change while bound."""
+        check(self._lib, self._lib.fz_ctx_bind_public_challenge(self._h, c_void_p(d_A or None), int(l)))
+        self.bound_A = d_A or 0
+
+    def runtime_info(self):
+        """-> dict(build_hip_version, runtime_hip_version, arch): what the library was built with / is bound to"""
+        b, r = c_int(), c_int()
+        arch = ctypes.create_string_buffer(64)
+        check(self._lib, self._lib.fz_runtime_info(self._h, byref(b), byref(r), arch, 64))
+        return dict(build_hip_version=b.value, runtime_hip_version=r.value, arch=arch.value.decode())
+
     def twiddles(self):
         f = np.empty(self.degree, dtype=np.uint32)
         i = np.empty(self.degree, dtype=np.uint32)
@@ -101,6 +115,8 @@ class Context:
 
     def free(self, ptr):
         check(self._lib, self._lib.fz_free(self._h, c_void_p(ptr)))
+        if ptr and ptr == self.bound_A:                 # the library ended the binding with the rows
+            self.bound_A = 0
 
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)
@@ -248,6 +264,22 @@ class Context:
         check(self._lib, self._lib.fz_aggregate_target_partial_batch(
             self._h, c_void_p(d_sig), c_void_p(d_alpha), c_void_p(d_vkL), c_void_p(d_vkR), c_void_p(d_c),
             c_void_p(d_partial), partial_stride, c_void_p(d_target_partial), target_stride, groups, N, l))
+
+    def aggregate_core_ragged_dev(self, d_sig, d_alpha, offsets, l, d_out):
+        """len(offsets) - 1 aggregates of different sizes in one launch: aggregate g = rows [offsets[g], offsets[g+1]) of the
+        concatenated signatures / coefficients; d_out [groups][l][degree] int32 (centred)"""
+        off = (ctypes.c_size_t * len(offsets))(*[int(x) for x in offsets])
+        check(self._lib, self._lib.fz_aggregate_core_ragged(self._h, c_void_p(d_sig), c_void_p(d_alpha), off, len(offsets) - 1, l,
+                                                            c_void_p(d_out)))
+
+    def aggregate_target_partial_ragged_dev(self, d_sig, d_alpha, d_vkL, d_vkR, d_c, offsets, l, d_partial, partial_stride,
+                                            d_target_partial, target_stride):
+        """int64 partial sums of aggregates (d_sig / d_partial may both be 0: targets only) and verification targets for
+        aggregates of different sizes, one launch"""
+        off = (ctypes.c_size_t * len(offsets))(*[int(x) for x in offsets])
+        check(self._lib, self._lib.fz_aggregate_target_partial_ragged(
+            self._h, c_void_p(d_sig or None), c_void_p(d_alpha), c_void_p(d_vkL), c_void_p(d_vkR), c_void_p(d_c), off,
+            len(offsets) - 1, l, c_void_p(d_partial or None), partial_stride, c_void_p(d_target_partial), target_stride))
 
     def verify_partials_batch_async_dev(self, d_A, d_partial, partial_stride, d_target_partial, target_stride, groups, l,
                                         beta_vf, omega_vf, d_verdicts):

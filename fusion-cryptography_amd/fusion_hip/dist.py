@@ -44,3 +44,190 @@ def sharded_sum(partial_fn: Callable[[int, int], "object"], total: int, rank: in
     [lo, hi) (zeros for an empty block); returns the all-reduced tensor."""
     lo, hi = shard_range(total, rank, world)
     return allreduce_sum_i64(partial_fn(lo, hi), group)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# End-to-end sharded aggregate() / verify() (BASELINE configs[3]; SURVEY.md 8e; fusion/fusion.py:655-677, :680-728)
+# ---------------------------------------------------------------------------------------------------------------
+class TorchCollective:
+    """The exchange step over torch.distributed (backend "nccl" = RCCL over xGMI with one GPU per rank; "gloo" when ranks
+    share a GPU, as in the tests).  Buffers are torch tensors; the library's kernels read and write them by pointer."""
+    name = "torch.distributed all_reduce"
+
+    def __init__(self, ctx, device, group=None):
+        import torch
+        self.ctx, self.group = ctx, group
+        self.device = torch.device("cuda", device)
+
+    def alloc_i64(self, count):
+        import torch
+        return torch.zeros(count, dtype=torch.int64, device=self.device)
+
+    @staticmethod
+    def ptr(buf):
+        return buf.data_ptr()
+
+    def allreduce(self, buf):
+        import torch
+        self.ctx.synchronize()                 # the library's stream and torch's need not be the same stream
+        allreduce_sum_i64(buf, self.group)
+        torch.cuda.synchronize(self.device)
+
+    @staticmethod
+    def to_numpy(buf):
+        return buf.cpu().numpy()
+
+    def free(self, buf):
+        pass
+
+
+class CommCollective:
+    """The exchange step through the C ABI: fz_allreduce_i64 = ncclAllReduce(int64, sum) on the context's own stream, ordered
+    with the kernels around it (one GPU per rank; `comm` a fusion_hip.Comm)."""
+    name = "fz_allreduce_i64 (RCCL through the C ABI)"
+
+    def __init__(self, ctx, comm):
+        self.ctx, self.comm = ctx, comm
+
+    def alloc_i64(self, count):
+        from .context import DeviceArray
+        import numpy as np
+        return DeviceArray.from_numpy(self.ctx, np.zeros(count, dtype=np.int64))
+
+    @staticmethod
+    def ptr(buf):
+        return buf.ptr
+
+    def allreduce(self, buf):
+        self.ctx.allreduce_i64_dev(self.comm, buf.ptr, buf.shape[0])
+
+    @staticmethod
+    def to_numpy(buf):
+        return buf.numpy()
+
+    def free(self, buf):
+        buf.free()
+
+
+class ShardedScheme:
+    """aggregate() and verify() of the reference with the SIGNERS sharded over ranks -- one process per GPU, rank r holds
+    the signatures of its contiguous block [lo, hi) of the callers' list (shard_range) in its GPU's memory.
+
+    Who computes what, and why:
+      * Verification keys and messages are public and small (2 KiB per signer); every rank has all of them.
+      * The global sort by str(vk) (fusion.py:661-663, :693), the per-signer challenges and hash_ag's ONE serial SHAKE-256
+        over the whole sorted list (fusion.py:586-591, :632-652) run REDUNDANTLY on every rank: the sponge is serial by
+        construction and bounds the wall time wherever it runs, so computing it once and broadcasting would only add a
+        dependency on the slowest rank plus a collective; the challenges of all N signers cost a rank's GPU the same
+        ~0.75 ms latency chain as N / world of them.  Every rank therefore derives bit-identical alpha without any exchange.
+      * alpha is scattered back to the callers' order on the host (a permutation of 1 KiB rows) and each rank uploads and
+        transforms ONLY its block.
+      * Each rank makes ONE pass over its signers (fz_aggregate_target_partial_batch): exact int64 partial sums of the
+        aggregate [l][d] and of the verification target [d].
+      * ONE all-reduce of l*d + d int64 (sums of centred products need more than 32 bits) -- the path's only exchange.
+      * Every rank then holds the complete sums: the aggregate is their centring (fz_reduce_i64), the verdict comes straight
+        from the sums (fz_verify_partials_batch_async).  Integer sums are associative: bit-identical for any world size.
+    """
+
+    def __init__(self, scheme, rank, world, collective):
+        self.bs, self.rank, self.world, self.coll = scheme, int(rank), int(world), collective
+        self.ctx, self.d, self.l = scheme.ctx, scheme.d, scheme.l
+
+    def block(self, n):
+        return shard_range(n, self.rank, self.world)
+
+    def _local_operands(self, vk_all, messages_all):
+        """-> (n, lo, hi, dC_all, dAl_local, dL, dR): challenges of ALL signers (device, callers' order), alpha_hat / vk rows
+        of this rank's block"""
+        import numpy as np
+        from .context import DeviceArray
+        bs = self.bs
+        vk, L, R = bs._split_vk(vk_all)
+        n = vk.shape[0]
+        if n != len(messages_all):
+            raise ValueError("Number of keys and messages must be equal.")
+        lo, hi = self.block(n)
+        dC, c_hat, pre = bs._challenges_both(vk, messages_all)
+        try:
+            _, alpha = bs._alpha_coefficients(L, R, pre, c_hat)                  # redundantly on every rank (see the class docstring)
+            m = hi - lo
+            dAl = DeviceArray.from_numpy(self.ctx, np.ascontiguousarray(alpha[lo:hi]))
+            if m:
+                self.ctx.ntt_forward_dev(dAl.ptr, dAl.ptr, m)
+            dL = DeviceArray.from_numpy(self.ctx, np.ascontiguousarray(L[lo:hi]))
+            dR = DeviceArray.from_numpy(self.ctx, np.ascontiguousarray(R[lo:hi]))
+        except Exception:
+            dC.free()
+            raise
+        return n, lo, hi, dC, dAl, dL, dR
+
+    def aggregate_verify_sharded(self, vk_all, messages_all, sig_local):
+        """-> (aggregate [l][d] int32, (ok, reason)) on EVERY rank.  sig_local: this rank's signatures [hi - lo][l][d]
+        (numpy or DeviceArray), rows in the callers' order.  One pass over the local signers, one all-reduce, verification
+        from the int64 sums."""
+        import numpy as np
+        from .context import DeviceArray, VERDICT_REASONS
+        bs, ctx, l, d = self.bs, self.ctx, self.l, self.d
+        n, lo, hi, dC, dAl, dL, dR = self._local_operands(vk_all, messages_all)
+        m = hi - lo
+        dS, own = bs._dev(sig_local, (m, l, d))
+        part = self.coll.alloc_i64(l * d + d)                # zeros: a rank without signers contributes nothing
+        pp = self.coll.ptr(part)
+        dV = DeviceArray(ctx, (1,))
+        dO = DeviceArray(ctx, (l, d))
+        try:
+            if m:
+                ctx.aggregate_target_partial_batch_dev(dS.ptr, dAl.ptr, dL.ptr, dR.ptr, dC.ptr + lo * d * 4, pp, l * d,
+                                                       pp + l * d * 8, d, 1, m, l)
+            self.coll.allreduce(part)                         # the ONE exchange step
+            ctx.reduce_i64_dev(pp, dO.ptr, l * d)
+            agg = dO.numpy()
+            if n > bs.params.capacity:                        # fusion.py:686-687 (checked before anything else there)
+                return agg, (False, VERDICT_REASONS[1])
+            ctx.verify_partials_batch_async_dev(bs._A_dev().ptr, pp, l * d, pp + l * d * 8, d, 1, l, int(bs.params.beta_vf),
+                                                int(bs.params.omega_vf), dV.ptr)
+            code = int(dV.numpy()[0])
+            return agg, (code == 0, VERDICT_REASONS[code])
+        finally:
+            ctx.synchronize()
+            self.coll.free(part)
+            for b in (dC, dAl, dL, dR, dV, dO):
+                b.free()
+            if own:
+                dS.free()
+
+    def aggregate_sharded(self, vk_all, messages_all, sig_local):
+        """-> aggregate [l][d] int32 == aggregate(params, keys, messages, signatures).signature_hat, on every rank"""
+        return self.aggregate_verify_sharded(vk_all, messages_all, sig_local)[0]
+
+    def verify_sharded(self, vk_all, messages_all, aggregate):
+        """-> (bool, reason) == verify(params, keys, messages, aggregate_signature) on every rank; the SIGNERS of the
+        verification target sum_i (vkL_i c_i + vkR_i) alpha_i (fusion.py:706-714) are sharded, one all-reduce of d int64."""
+        import numpy as np
+        from .context import DeviceArray, VERDICT_REASONS
+        bs, ctx, l, d = self.bs, self.ctx, self.l, self.d
+        nk = (vk_all.shape[0] if isinstance(vk_all, DeviceArray) else np.asarray(vk_all).reshape(-1, 2, d).shape[0])
+        if nk > bs.params.capacity:
+            return False, VERDICT_REASONS[1]
+        if nk != len(messages_all):
+            return False, VERDICT_REASONS[2]
+        n, lo, hi, dC, dAl, dL, dR = self._local_operands(vk_all, messages_all)
+        m = hi - lo
+        dS, own = bs._dev(aggregate, (l, d))
+        part = self.coll.alloc_i64(d)
+        pp = self.coll.ptr(part)
+        dT = DeviceArray(ctx, (d,))
+        try:
+            if m:
+                ctx.target_partial_dev(dL.ptr, dR.ptr, dC.ptr + lo * d * 4, dAl.ptr, pp, m)
+            self.coll.allreduce(part)
+            ctx.reduce_i64_dev(pp, dT.ptr, d)
+            code = ctx.verify_with_target_dev(bs._A_dev().ptr, dS.ptr, dT.ptr, l, int(bs.params.beta_vf), int(bs.params.omega_vf))
+            return code == 0, VERDICT_REASONS[code]
+        finally:
+            ctx.synchronize()
+            self.coll.free(part)
+            for b in (dC, dAl, dL, dR, dT):
+                b.free()
+            if own:
+                dS.free()

@@ -30,11 +30,15 @@ class BatchScheme:
     def _A_dev(self):
         if self._dA is None:
             self._dA = DeviceArray.from_numpy(self.ctx, self.A)
+            # the fused keygen / verify kernels then use a pre-split fp64 copy of these rows (two FMAs per A (.) y)
+            self.ctx.bind_public_challenge(self._dA.ptr, self.l)
         return self._dA
 
     def close(self):
         """release the device copy of the public challenge (the context itself is shared and stays)"""
         if self._dA is not None:
+            if self.ctx.bound_A == self._dA.ptr:
+                self.ctx.bind_public_challenge(0, 0)
             self._dA.free()
             self._dA = None
 
@@ -165,48 +169,170 @@ class BatchScheme:
                 dK.free()
 
     # ---- aggregate / verify ----------------------------------------------------------------------------
-    def _sorted_inputs(self, vk, messages):
-        vk = np.ascontiguousarray(vk, dtype=np.int32).reshape(-1, 2, self.d)
-        L, R = np.ascontiguousarray(vk[:, 0]), np.ascontiguousarray(vk[:, 1])
-        order = hostpipe.sort_by_vk_string(self.P, L, R, self.threads)
-        L, R = L[order], R[order]
-        msgs = [messages[i] for i in order]
-        c_hat, pre = self.challenges(np.stack([L, R], axis=1), msgs)
-        alpha = hostpipe.aggregation_coefficients(self.P, L, R, pre, c_hat, self.threads)
-        return order, L, R, c_hat, self.ctx.ntt_forward(alpha)
+    def _split_vk(self, vk):
+        vk = np.ascontiguousarray(vk.numpy() if isinstance(vk, DeviceArray) else vk, dtype=np.int32).reshape(-1, 2, self.d)
+        return vk, np.ascontiguousarray(vk[:, 0]), np.ascontiguousarray(vk[:, 1])
+
+    def _challenges_both(self, vk, messages):
+        """hash_ch for every (key, message) in the CALLERS' order: -> (dC DeviceArray [N][d], c_hat host copy, prehash
+        [N][32]).  The device pipeline leaves c_hat where the kernels need it; hash_ag needs a host copy of it as text input."""
+        if self.device_hash:
+            try:
+                dC, pre = self.challenges_dev(vk, messages)
+                return dC, dC.numpy(), pre
+            except FusionHipError as e:
+                if e.code != FZ_E_UNSUPPORTED:
+                    raise
+                self.device_hash = False
+        c_hat, pre = self.challenges(vk, messages)
+        return DeviceArray.from_numpy(self.ctx, c_hat), c_hat, pre
+
+    def _alpha_coefficients(self, L, R, pre, c_hat, threads=None):
+        """hash_ag without the transforms (fusion.py:632-652) for ONE aggregate: sort by str(vk) (fusion.py:661-663, :693), the
+        one serial SHAKE-256 over the sorted list, decode; -> (order, alpha coefficient rows scattered back to the CALLERS'
+        order).  The aggregate and the target are sums over signers, so nothing else ever has to be permuted."""
+        threads = threads or self.threads
+        order = hostpipe.sort_by_vk_string(self.P, L, R, threads)
+        alpha_sorted = hostpipe.aggregation_coefficients(self.P, L[order], R[order], pre[order], c_hat[order], threads)
+        alpha = np.empty_like(alpha_sorted)
+        alpha[order] = alpha_sorted
+        return order, alpha
+
+    def hash_ag_dev(self, vk, messages):
+        """Everything aggregate() and verify() derive from the keys and messages, device-resident and in the callers' order:
+        -> (dC [N][d] challenges c_hat, dAl [N][d] aggregation coefficients alpha_hat, order, vkL, vkR host rows)."""
+        vk, L, R = self._split_vk(vk)
+        dC, c_hat, pre = self._challenges_both(vk, messages)
+        try:
+            order, alpha = self._alpha_coefficients(L, R, pre, c_hat)
+            dAl = DeviceArray.from_numpy(self.ctx, alpha)
+            self.ctx.ntt_forward_dev(dAl.ptr, dAl.ptr, alpha.shape[0])          # in place
+        except Exception:
+            dC.free()
+            raise
+        return dC, dAl, order, L, R
 
     def aggregate(self, vk, messages, sig):
         """-> aggregate [l][d] == aggregate(params, keys, messages, signatures).signature_hat.
-        sig may be a numpy array or a DeviceArray.  The aggregation coefficients are derived in sorted key
-        order (as the reference does) and scattered back to the callers' order: the aggregate is a sum, so
-        the signatures themselves never have to be permuted."""
-        order, _, _, _, alpha_sorted = self._sorted_inputs(vk, messages)
-        n = alpha_sorted.shape[0]
-        alpha = np.empty_like(alpha_sorted)
-        alpha[order] = alpha_sorted
+        sig may be a numpy array or a DeviceArray.  Challenges and aggregation coefficients stay on the device; only the
+        keys' text input of hash_ag and the result cross PCIe."""
+        dC, dAl, _, _, _ = self.hash_ag_dev(vk, messages)
+        n = dAl.shape[0]
         dS, own = self._dev(sig, (n, self.l, self.d))
-        dA = DeviceArray.from_numpy(self.ctx, alpha)
         dO = DeviceArray(self.ctx, (self.l, self.d))
         try:
-            self.ctx.aggregate_core_dev(dS.ptr, dA.ptr, dO.ptr, n, self.l)
+            self.ctx.aggregate_core_dev(dS.ptr, dAl.ptr, dO.ptr, n, self.l)
             return dO.numpy()
         finally:
-            dA.free()
-            dO.free()
+            for b in (dC, dAl, dO):
+                b.free()
             if own:
                 dS.free()
 
     def verify(self, vk, messages, aggregate):
         """-> (bool, reason) with the reference's reason strings (fusion.py:680-728)"""
-        n = np.asarray(vk).reshape(-1, 2, self.d).shape[0]
+        n = (vk.shape[0] if isinstance(vk, DeviceArray) else np.asarray(vk).reshape(-1, 2, self.d).shape[0])
         if n > self.params.capacity:
             return False, VERDICT_REASONS[1]
         if n != len(messages):
             return False, VERDICT_REASONS[2]
-        _, L, R, c_hat, alpha_hat = self._sorted_inputs(vk, messages)
-        code = self.ctx.verify_core(self.A, aggregate, L, R, c_hat, alpha_hat, self.params.beta_vf,
-                                    self.params.omega_vf)
-        return code == 0, VERDICT_REASONS[code]
+        dC, dAl, _, L, R = self.hash_ag_dev(vk, messages)
+        dL, dR = DeviceArray.from_numpy(self.ctx, L), DeviceArray.from_numpy(self.ctx, R)
+        dS, own = self._dev(aggregate, (self.l, self.d))
+        try:
+            code = self.ctx.verify_core_dev(self._A_dev().ptr, dS.ptr, dL.ptr, dR.ptr, dC.ptr, dAl.ptr, n, self.l,
+                                            int(self.params.beta_vf), int(self.params.omega_vf))
+            return code == 0, VERDICT_REASONS[code]
+        finally:
+            for b in (dC, dAl, dL, dR):
+                b.free()
+            if own:
+                dS.free()
+
+    # ---- many aggregates at once ------------------------------------------------------------------------
+    def _hash_ag_many(self, vk, messages, sizes):
+        """hash_ag for G independent aggregates whose signers are concatenated (aggregate g = rows off[g]:off[g+1]): ONE device
+        pass for all challenges, then one host thread per aggregate for its sort + serial SHAKE-256 (the sponges are what
+        bounds a lone aggregate: independent aggregates hide each other's), ONE upload + transform of all coefficients.
+        -> (dC, dAl [sum N][d], offsets, L, R)"""
+        from concurrent.futures import ThreadPoolExecutor
+        vk, L, R = self._split_vk(vk)
+        sizes = [int(x) for x in sizes]
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        if off[-1] != vk.shape[0] or vk.shape[0] != len(messages):
+            raise FusionHipError(-1, f"sizes sum to {off[-1]} but {vk.shape[0]} keys and {len(messages)} messages were given")
+        if any(x < 1 for x in sizes):
+            raise FusionHipError(-1, "every aggregate needs at least one signer")
+        dC, c_hat, pre = self._challenges_both(vk, messages)
+        try:
+            per = max(1, self.threads // max(1, len(sizes)))
+
+            def one(g):
+                a, b = off[g], off[g + 1]
+                return self._alpha_coefficients(L[a:b], R[a:b], pre[a:b], c_hat[a:b], per)[1]
+            with ThreadPoolExecutor(max_workers=min(len(sizes), self.threads)) as pool:      # the C calls release the GIL
+                alpha = np.concatenate(list(pool.map(one, range(len(sizes)))))
+            dAl = DeviceArray.from_numpy(self.ctx, alpha)
+            self.ctx.ntt_forward_dev(dAl.ptr, dAl.ptr, alpha.shape[0])
+        except Exception:
+            dC.free()
+            raise
+        return dC, dAl, off, L, R
+
+    def aggregate_many(self, vk, messages, sig, sizes):
+        """G independent aggregate() calls (fusion.py:655; the reference is called once per aggregate) as one batch:
+        vk [sum N][2][d], messages (sum N of them), sig [sum N][l][d] (numpy or DeviceArray) hold the signers of aggregate 0,
+        then of aggregate 1, ...; sizes = signers per aggregate (they may differ).  -> [G][l][d]; row g equals
+        aggregate(params, keys_g, messages_g, signatures_g).signature_hat.  One launch for all aggregates."""
+        dC, dAl, off, _, _ = self._hash_ag_many(vk, messages, sizes)
+        g = len(off) - 1
+        dS, own = self._dev(sig, (int(off[-1]), self.l, self.d))
+        dO = DeviceArray(self.ctx, (g, self.l, self.d))
+        try:
+            self.ctx.aggregate_core_ragged_dev(dS.ptr, dAl.ptr, off, self.l, dO.ptr)
+            return dO.numpy()
+        finally:
+            for b in (dC, dAl, dO):
+                b.free()
+            if own:
+                dS.free()
+
+    def verify_many(self, vk, messages, aggregates, sizes):
+        """G independent verify() calls (fusion.py:680-728) as one batch; aggregates [G][l][d].  -> list of (bool, reason).
+        One launch for all verification targets, one for all verifications, verdicts read once."""
+        sizes = [int(x) for x in sizes]
+        g = len(sizes)
+        out = [None] * g
+        live = []
+        for i, n in enumerate(sizes):                 # the reference's capacity check comes first (fusion.py:686-687)
+            if n > self.params.capacity:
+                out[i] = (False, VERDICT_REASONS[1])
+            else:
+                live.append(i)
+        if len(live) != g:                            # rare: verify the rest one by one, keeping the batch path simple
+            vkh, _, _ = self._split_vk(vk)
+            off = np.concatenate([[0], np.cumsum(sizes)])
+            aggs = aggregates.numpy() if isinstance(aggregates, DeviceArray) else np.asarray(aggregates)
+            for i in live:
+                out[i] = self.verify(vkh[off[i]:off[i + 1]], messages[off[i]:off[i + 1]], aggs.reshape(g, self.l, self.d)[i])
+            return out
+        dC, dAl, off, L, R = self._hash_ag_many(vk, messages, sizes)
+        dL, dR = DeviceArray.from_numpy(self.ctx, L), DeviceArray.from_numpy(self.ctx, R)
+        dS, own = self._dev(aggregates, (g, self.l, self.d))
+        dT64 = DeviceArray(self.ctx, (g, self.d), np.int64)
+        dT = DeviceArray(self.ctx, (g, self.d))
+        dV = DeviceArray(self.ctx, (g,))
+        try:
+            self.ctx.aggregate_target_partial_ragged_dev(0, dAl.ptr, dL.ptr, dR.ptr, dC.ptr, off, self.l, 0, 0, dT64.ptr, self.d)
+            self.ctx.reduce_i64_dev(dT64.ptr, dT.ptr, g * self.d)
+            self.ctx.verify_with_target_batch_async_dev(self._A_dev().ptr, dS.ptr, dT.ptr, g, self.l, int(self.params.beta_vf),
+                                                        int(self.params.omega_vf), dV.ptr)
+            return [(int(c) == 0, VERDICT_REASONS[int(c)]) for c in dV.numpy()]
+        finally:
+            for b in (dC, dAl, dL, dR, dT64, dT, dV):
+                b.free()
+            if own:
+                dS.free()
 
 
 # ---- conversions between the array face and the drop-in object face ----------------------------------------

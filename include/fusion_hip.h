@@ -79,6 +79,17 @@ FZ_API int fz_stream_destroy(fz_ctx *ctx, void *hip_stream);
  * equal to bit_reverse_copy([pow(root,i,q)]) / ([pow(inv_root,i,q)]). Either may be NULL. */
 FZ_API int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv);
 
+/* The public challenge of the scheme (Params.public_challenge, fusion/fusion.py:263-277: 1 x rank NTT-domain polynomials,
+ * fixed by fusion_setup) is the same operand of every keygen and every verification.  Binding it lets the library keep
+ * a pre-split fp64 copy (hi = A >> 16, lo = A & 0xffff), with which fz_keygen_core* and the fused verification accumulate
+ * A (.) y with two FMAs per coefficient instead of a conversion and a 5-op modular multiply (results identical).
+ * d_A [l][degree] int32, 16-byte aligned; the caller promises not to change those rows while they are bound; calls that
+ * pass a different d_A simply do not use the copy.  d_A == NULL unbinds.  Synchronises the context's stream. */
+FZ_API int fz_ctx_bind_public_challenge(fz_ctx *ctx, const int32_t *d_A, int l);
+/* HIP version the library was built with and the one of the runtime it is bound to (e.g. 70200000 / 70051831), plus the
+ * device's gcnArchName: which libamdhip64 a process ended up with is not always the one it was linked against. */
+FZ_API int fz_runtime_info(fz_ctx *ctx, int *out_build_hip_version, int *out_runtime_hip_version, char *out_arch, size_t arch_cap);
+
 /* ---- graph capture --------------------------------------------------------------------------
  * The reference runs its algebra as a long sequence of small calls (one cooley_tukey_ntt /
  * gentleman_sande_intt per polynomial: fusion/fusion.py:363-370, :557, :670-676); at the batch sizes
@@ -218,6 +229,21 @@ FZ_API int fz_aggregate_target_partial_batch(fz_ctx *ctx, const int32_t *d_sig, 
                                              int64_t *d_partial, size_t partial_stride,
                                              int64_t *d_target_partial, size_t target_stride,
                                              size_t groups, size_t N, int l);
+/* MANY aggregates of DIFFERENT sizes in one launch -- the reference is called once per aggregate (fusion.py:655, :680;
+ * benchmarks/benchmarks.py:37-141 loops over them): aggregate g's signers are rows [h_offsets[g], h_offsets[g+1]) of the
+ * concatenated arrays d_sig [sum N][l][degree], d_alpha_hat / d_vkL / d_vkR / d_c_hat [sum N][degree]; h_offsets (HOST,
+ * groups + 1 entries, read before the call returns) travels in the kernel arguments, so the call is asynchronous and
+ * capturable.  fz_aggregate_core_ragged writes the centred aggregates d_out [groups][l][degree];
+ * fz_aggregate_target_partial_ragged the int64 partial sums of aggregates and verification targets (as
+ * fz_aggregate_target_partial_batch does for equal sizes); with d_sig == NULL and d_partial == NULL only the targets
+ * (fusion.py:706-714) are computed.  Power-of-two degree <= 256, 16-byte aligned rows. */
+FZ_API int fz_aggregate_core_ragged(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, const size_t *h_offsets,
+                                    size_t groups, int l, int32_t *d_out);
+FZ_API int fz_aggregate_target_partial_ragged(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat,
+                                              const int32_t *d_vkL, const int32_t *d_vkR, const int32_t *d_c_hat,
+                                              const size_t *h_offsets, size_t groups, int l,
+                                              int64_t *d_partial, size_t partial_stride,
+                                              int64_t *d_target_partial, size_t target_stride);
 /* target partial for verify: sum_i (vkL_i (.) c_i + vkR_i) (.) alpha_i as int64 [degree] */
 FZ_API int fz_target_partial(fz_ctx *ctx, const int32_t *d_vkL, const int32_t *d_vkR,
                              const int32_t *d_c_hat, const int32_t *d_alpha_hat,
@@ -351,7 +377,9 @@ FZ_API int fz_challenge_hat_msgs_dev(fz_ctx *ctx, const fz_scheme_params *P, con
 
 /* ---- reference-exact sampling on the host -----------------------------------------
  * CPython's MT19937 `random` exactly as the reference's samplers drive it (random.seed(int), randrange):
- * the same seed yields the same polynomial as algebra/polynomials.py:436-488.  Non-negative int seeds. */
+ * the same seed yields the same polynomial as algebra/polynomials.py:436-488.  Seeds are the non-negative integers below
+ * 2^64 (fz_sample_secret_polys: below 2^64 - 1, because the right half uses seed + 1); callers map other Python seeds
+ * themselves (random.seed(int) uses abs(seed); larger ones need more key words than these entries take). */
 FZ_API int fz_sample_ntt_values(uint64_t seed, int64_t modulus, int degree, int32_t *h_out);
 FZ_API int fz_sample_coefficients(uint64_t seed, int64_t modulus, int degree, int64_t norm_bound,
                                   int64_t weight_bound, int32_t *h_out);
@@ -361,7 +389,8 @@ FZ_API int fz_sample_secret_polys(const uint64_t *h_seeds, size_t N, int64_t mod
 /* The same on the DEVICE (csrc/fz_sample.hip): one lane per polynomial runs CPython's MT19937 exactly (init_by_array
  * seeding, getrandbits, rejection) and writes d_out [N][2][degree] in device memory -- what fz_keygen_core_bcast reads, so
  * the secret polynomials of keygen(params, seed) never exist on the host.  Supported: weight_bound >= degree (both parameter
- * sets: no shuffle), any seeds < 2^64; else FZ_E_UNSUPPORTED.  Synchronous (it reads back a completion flag). */
+ * sets: no shuffle), seeds < 2^64 - 1 (the right half is seeded with seed + 1, which must not wrap); else
+ * FZ_E_UNSUPPORTED.  Synchronous (it reads back a completion flag). */
 FZ_API int fz_sample_secret_polys_dev(fz_ctx *ctx, const uint64_t *h_seeds, size_t N, int64_t modulus, int degree,
                                       int64_t norm_bound, int64_t weight_bound, int32_t *d_out);
 

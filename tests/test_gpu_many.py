@@ -1,0 +1,140 @@
+"""Many DISTINCT signers against the reference (tests/golden/scheme_many_*: 32 signers at secpar 128, 16 at 256, nested
+sub-aggregates): everything that depends on the ORDER of many keys -- sorted(key=str(vk)) on signed decimals
+(fusion.py:661-663, :693), the hash_ag text over N tuples (:586-591), the scatter of alpha back to the callers' order -- through
+the array API (BatchScheme), the many-aggregates batch (aggregate_many / verify_many) and the drop-in object API."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(secpar):
+    S = np.load(os.path.join(G, f"scheme_many_{secpar}.npz"))
+    with open(os.path.join(G, "scheme_many.json")) as fh:
+        return S, json.load(fh)[str(secpar)]
+
+
+def sha_i32(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<i4").tobytes()).hexdigest()
+
+
+def sha_str(s):
+    return hashlib.sha256(s.encode("utf-8")).hexdigest()
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_batch_scheme_at_many_signers_equals_the_reference(secpar):
+    import fusion.fusion as F
+    from fusion_hip import hostpipe
+    from fusion_hip.scheme import BatchScheme
+    S, m = load(secpar)
+    params = F.fusion_setup(secpar, m["setup_seed"])
+    bs = BatchScheme(params)
+    assert np.array_equal(bs.A, S["A"])
+    sk, vk = bs.keygen_batch(m["key_seeds"])
+    assert np.array_equal(vk, S["vk"])
+    sig = bs.sign_batch(sk, vk, m["messages"])
+    assert [sha_i32(r) for r in sig] == m["sha256_sig_rows"]
+    for lo, hi in m["subsets"]:
+        info = m["agg"][f"{lo}_{hi}"]
+        v, ms, sg = vk[lo:hi], m["messages"][lo:hi], sig[lo:hi]
+        order = hostpipe.sort_by_vk_string(bs.P, v[:, 0], v[:, 1], 3)
+        assert order.tolist() == info["order"]                                   # the reference's sorted(key=str(vk))
+        dC, dAl, order2, _, _ = bs.hash_ag_dev(v, ms)
+        alpha = dAl.numpy()
+        dC.free()
+        dAl.free()
+        assert order2.tolist() == info["order"]
+        assert np.array_equal(alpha[order], S[f"alpha_hat_sorted_{lo}_{hi}"])     # hash_ag's output, in the reference's order
+        agg = bs.aggregate(v, ms, sg)
+        assert np.array_equal(agg, S[f"agg_{lo}_{hi}"])
+        assert list(bs.verify(v, ms, agg)) == info["verdict"]
+        bad = agg.copy()
+        bad[info["tampered_at"][0], info["tampered_at"][1]] += 1
+        assert list(bs.verify(v, ms, bad)) == info["tampered_verdict"]
+        sw = list(ms)
+        sw[0], sw[-1] = sw[-1], sw[0]
+        assert list(bs.verify(v, sw, agg)) == info["swapped_messages_verdict"]
+    # the fused kernels with and without the bound pre-split public challenge agree (the binding happened above)
+    assert bs.ctx.bound_A == bs._A_dev().ptr
+    bs.close()
+    assert bs.ctx.bound_A == 0
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_many_aggregates_in_one_batch_equal_the_reference(secpar):
+    """aggregate_many / verify_many: G = 3 aggregates of DIFFERENT sizes in one launch each"""
+    import fusion.fusion as F
+    from fusion_hip.scheme import BatchScheme
+    S, m = load(secpar)
+    params = F.fusion_setup(secpar, m["setup_seed"])
+    bs = BatchScheme(params)
+    sk, vk, vk_dev = bs.keygen_batch(m["key_seeds"], device=True, keep_vk=True)
+    sig = bs.sign_batch(sk, vk_dev, m["messages"], device=True)                  # signatures stay on the device
+    parts = m["subsets"][1:]                                                      # three consecutive blocks covering all signers
+    assert parts[0][0] == 0 and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    sizes = [hi - lo for lo, hi in parts]
+    aggs = bs.aggregate_many(vk, m["messages"], sig, sizes)
+    for g, (lo, hi) in enumerate(parts):
+        assert np.array_equal(aggs[g], S[f"agg_{lo}_{hi}"]), f"aggregate {g} ({lo}:{hi})"
+    assert bs.verify_many(vk, m["messages"], aggs, sizes) == [(True, "")] * 3
+    bad = aggs.copy()
+    bad[1, 2, 5] += 1
+    want = [(True, ""), (False, "Target doesn't match image of aggregate signature."), (True, "")]
+    assert bs.verify_many(vk, m["messages"], bad, sizes) == want
+    # one aggregate as a "batch" of one, and the whole set again through the single-aggregate entry
+    lo, hi = m["subsets"][0]
+    assert np.array_equal(bs.aggregate_many(vk, m["messages"], sig, [hi - lo])[0], S[f"agg_{lo}_{hi}"])
+    assert np.array_equal(bs.aggregate(vk, m["messages"], sig), S[f"agg_{lo}_{hi}"])
+    sk.free()
+    vk_dev.free()
+    sig.free()
+
+
+def test_more_aggregates_than_one_launch_holds():
+    """70 small aggregates (the group table of a launch holds 64): equal to 70 single calls"""
+    import fusion.fusion as F
+    from fusion_hip.scheme import BatchScheme
+    params = F.fusion_setup(128, 9)
+    bs = BatchScheme(params, threads=4)
+    sizes = [1 + (g * 7) % 5 for g in range(70)]
+    n = sum(sizes)
+    seeds = [40_000 + 3 * i for i in range(n)]
+    msgs = [f"m{i}" for i in range(n)]
+    sk, vk = bs.keygen_batch(seeds)
+    sig = bs.sign_batch(sk, vk, msgs)
+    aggs = bs.aggregate_many(vk, msgs, sig, sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    for g in (0, 1, 33, 63, 64, 69):
+        a, b = off[g], off[g + 1]
+        assert np.array_equal(aggs[g], bs.aggregate(vk[a:b], msgs[a:b], sig[a:b])), g
+    verdicts = bs.verify_many(vk, msgs, aggs, sizes)
+    assert verdicts == [(True, "")] * 70
+    aggs[64, 0, 0] += 1
+    assert [v[0] for v in bs.verify_many(vk, msgs, aggs, sizes)] == [g != 64 for g in range(70)]
+
+
+def test_drop_in_object_api_at_32_signers_prints_the_reference_strings():
+    """fusion.fusion keygen / sign / aggregate / verify on 32 distinct signers: the hashed str() of every key, signature and
+    of the aggregate equal the reference's (sorted(key=str(vk)) and hash_ag over 32 tuples included)"""
+    import fusion.fusion as F
+    S, m = load(128)
+    params = F.fusion_setup(128, m["setup_seed"])
+    keys = [F.keygen(params, s) for s in m["key_seeds"]]
+    assert [sha_str(str(k[1])) for k in keys] == m["sha256_str_vk"]
+    sigs = [F.sign(params, k, msg) for k, msg in zip(keys, m["messages"])]
+    assert [sha_str(str(s)) for s in sigs] == m["sha256_str_sig"]
+    vks = [k[1] for k in keys]
+    for lo, hi in m["subsets"]:
+        info = m["agg"][f"{lo}_{hi}"]
+        agg = F.aggregate(params, vks[lo:hi], m["messages"][lo:hi], sigs[lo:hi])
+        assert sha_str(str(agg)) == info["sha256_str_agg"]
+        assert list(F.verify(params, vks[lo:hi], m["messages"][lo:hi], agg)) == info["verdict"]
+        r, c = info["tampered_at"]
+        agg.signature_hat.matrix[r][0].values[c] += 1
+        assert list(F.verify(params, vks[lo:hi], m["messages"][lo:hi], agg)) == info["tampered_verdict"]

@@ -134,6 +134,22 @@ def test_scheme_cores(secpar, coracle):
     # pure-Python port on one row
     assert O.py_sign_core(S["sk_hat"][0, 0, :1].tolist(), S["sk_hat"][0, 1, :1].tolist(), S["c_hat"][0].tolist(), q) \
         == S["sig"][0, :1].tolist()
+    # ... and the whole keygen / verify cores of the port (what bench.py's cpu_baseline times for the metric's second half)
+    tw, itw = O.py_twiddles(root, q, P["d"]), O.py_twiddles(inv, q, P["d"])
+    Al = A.tolist()
+    Lh, Rh, vL, vR = O.py_keygen_core(Al, S["coef"][1, 0].tolist(), S["coef"][1, 1].tolist(), q, tw)
+    assert Lh == S["sk_hat"][1, 0].tolist() and Rh == S["sk_hat"][1, 1].tolist()
+    assert vL == S["vk"][1, 0].tolist() and vR == S["vk"][1, 1].tolist()
+    order = meta["agg"]["4"]["order"]
+    rest = [S["vk"][order, 0].tolist(), S["vk"][order, 1].tolist(), S["c_hat"][order].tolist(), S["alpha_hat_4"].tolist()]
+    agg4 = S["agg_4"].tolist()
+    assert O.py_aggregate_core(S["sig"][order].tolist(), S["alpha_hat_4"].tolist(), q) == agg4
+    assert O.py_verify_core(Al, agg4, *rest, q, itw, meta["beta_vf"], meta["omega_vf"]) == 0
+    bad4 = [list(r) for r in agg4]
+    bad4[0][0] += 1
+    assert O.py_verify_core(Al, bad4, *rest, q, itw, meta["beta_vf"], meta["omega_vf"]) == 3
+    assert O.py_verify_core(Al, agg4, *rest, q, itw, 1, meta["omega_vf"]) == 4
+    assert O.py_verify_core(Al, agg4, *rest, q, itw, meta["beta_vf"], 1) == 5
 
 
 def test_reference_kat_hash_ch_pins_forward_ntt(coracle):

@@ -49,9 +49,9 @@ for secpar in (128, 256):
         sigs.append(s)
     vks = [k[1] for k in keys]
     (inp, exp), = rows("intermediate_hash_vks_and_ints_and_challs_to_bytes", secpar)
-    assert inp == str((params, vks, pre, challs)) and str(F.hash_vks_and_ints_and_challs_to_bytes(params, vks, pre, challs)) == exp
+    assert inp == str((params, keys, pre, challs)) and str(F.hash_vks_and_ints_and_challs_to_bytes(params, keys, pre, challs)) == exp
     (inp, exp), = rows("intermediate_hash_ag", secpar)
-    assert inp == str((params, vks, msgs)) and str(F.hash_ag(params, vks, msgs)) == exp
+    assert inp == str((params, keys, msgs)) and str(F.hash_ag(params, keys, msgs)) == exp
     (inp, exp), = rows("fusion_aggregate", secpar)
     agg = F.aggregate(params, vks, msgs, sigs)
     assert inp == str((params, vks, msgs, sigs)) and str(agg) == exp

@@ -3,7 +3,9 @@
 `str(inputs), str(outputs)` CSV rows, for the same functions and file names, using the drop-in package
 running on the GPU.  Because every str() format is byte-identical to the reference's, the files can be
 diffed against KAT files produced by a reference checkout with the same seeds -- including the 12 files
-the reference's checkout is missing (.MISSING_LARGE_BLOBS).
+the reference's checkout is missing (.MISSING_LARGE_BLOBS).  tests/test_gpu_kat_tools.py compares every row this script
+writes for one fixed (seed, sigs) with SHA-256 digests of the rows the REFERENCE's functions produce in the same flow
+(tests/golden/kat_flow.json, made by tests/golden/gen_golden.py).
 
 usage: generate_kat_values.py [out_dir] [--seed S] [--sigs N]     (needs an MI355X)
 """
@@ -75,9 +77,11 @@ def main():
             sigs.append(signature_to_object(params, b_sig[i]) if args.batch else sign(params, keys[i], msgs[i]))
             row(f("fusion_sign", secpar), (params, keys[i], pre[i]), sigs[-1])
         vks = [k[1] for k in keys]
-        row(f("intermediate_hash_vks_and_ints_and_challs_to_bytes", secpar), (params, vks, pre, challs),
-            hash_vks_and_ints_and_challs_to_bytes(params, vks, pre, challs))
-        row(f("intermediate_hash_ag", secpar), (params, vks, msgs), hash_ag(params, vks, msgs))
+        # like the reference's script, these two rows hash the (signing key, verification key) TUPLES
+        # (KATs/generate_KAT_values.py:115, :127 pass `otks`); aggregate and verify get the verification keys
+        row(f("intermediate_hash_vks_and_ints_and_challs_to_bytes", secpar), (params, keys, pre, challs),
+            hash_vks_and_ints_and_challs_to_bytes(params, keys, pre, challs))
+        row(f("intermediate_hash_ag", secpar), (params, keys, msgs), hash_ag(params, keys, msgs))
         if args.batch:
             b_agg = bs.aggregate(b_vk, b_msgs, b_sig)
             agg = signature_to_object(params, b_agg)

@@ -329,7 +329,7 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         c->knob_verify_ordered = knob("FZ_VERIFY_ORDERED");
         c->knob_keygen_unfused = knob("FZ_KEYGEN_UNFUSED");
         c->knob_polymul_unfused = knob("FZ_POLYMUL_UNFUSED");
-        c->knob_no_split = knob("FZ_NO_SPLIT");
+        c->knob_no_imad = knob("FZ_NO_IMAD");
         c->knob_verify_cent = knob("FZ_VERIFY_CENT");
     }
     if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
@@ -364,7 +364,6 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     if (ctx->d_vpart) (void)hipFree(ctx->d_vpart);
     if (ctx->d_vstate) (void)hipFree(ctx->d_vstate);
     if (ctx->d_aggacc) (void)hipFree(ctx->d_aggacc);
-    if (ctx->d_Asplit) (void)hipFree(ctx->d_Asplit);
     for (int i = 0; i < ctx->n_retired; ++i) (void)hipFree(ctx->retired[i]);
     free(ctx->retired);
     if (ctx->d_chal_tab) (void)hipFree(ctx->d_chal_tab);
@@ -485,13 +484,9 @@ int fz_malloc(fz_ctx *ctx, size_t bytes, void **d_out) {
     return FZ_OK;
 }
 
-int fz_ctx_bind_public_challenge(fz_ctx *ctx, const int32_t *d_A, int l);
 int fz_free(fz_ctx *ctx, void *d_ptr) {
     FZ_REQUIRE(ctx, "ctx is NULL");
     FZ_DEV(ctx);
-    // freeing the rows that are bound as the public challenge ends the binding: the address may come back from the
-    // allocator with other contents, and the pre-split copy must never outlive what it was made from
-    if (d_ptr && d_ptr == (void *)ctx->bound_A && !ctx->capturing) FZ_TRY(fz_ctx_bind_public_challenge(ctx, nullptr, 0));
     if (d_ptr) FZ_HIP(hipFree(d_ptr), "hipFree");
     return FZ_OK;
 }
@@ -804,26 +799,6 @@ int fz_runtime_info(fz_ctx *ctx, int *out_build, int *out_runtime, char *out_arc
         FZ_HIP(hipGetDeviceProperties(&prop, ctx->device), "hipGetDeviceProperties");
         snprintf(out_arch, arch_cap, "%s", prop.gcnArchName);
     }
-    return FZ_OK;
-}
-
-int fz_ctx_bind_public_challenge(fz_ctx *ctx, const int32_t *d_A, int l) {
-    FZ_REQUIRE(ctx && (d_A == nullptr || l >= 1), "bad argument");
-    FZ_DEV(ctx);
-    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the public challenge cannot be (re)bound during graph capture");
-    FZ_HIP(hipStreamSynchronize(ctx->stream), "bind: synchronise");
-    FZ_TRY(fz_retire(ctx, ctx->d_Asplit, "split table free"));
-    ctx->d_Asplit = nullptr;
-    ctx->bound_A = nullptr;
-    ctx->bound_l = 0;
-    if (!d_A) return FZ_OK;
-    FZ_REQUIRE(((uintptr_t)d_A & 15) == 0, "the public challenge must be 16-byte aligned");
-    const size_t count = (size_t)l * ctx->degree;
-    FZ_HIP(hipMalloc((void **)&ctx->d_Asplit, count * sizeof(double2)), "split table alloc");
-    int rc = fz_launch_split_A(ctx, d_A, ctx->d_Asplit, count);
-    if (rc != FZ_OK) { (void)hipFree(ctx->d_Asplit); ctx->d_Asplit = nullptr; return rc; }
-    ctx->bound_A = d_A;
-    ctx->bound_l = l;
     return FZ_OK;
 }
 

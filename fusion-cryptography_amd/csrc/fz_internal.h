@@ -71,13 +71,8 @@ struct fz_ctx {
     int knob_stream_nt;          // FZ_STREAM_NT: streaming (non-temporal) stores in the elementwise kernels
     int knob_stream_per_cu;      // grid cap of the grid-stride streaming kernels in workgroups per CU (0 = flat grid)
     int knob_verify_blocks, knob_verify_unfused, knob_verify_ordered, knob_keygen_unfused, knob_polymul_unfused;
-    int knob_no_split;           // FZ_NO_SPLIT=1: ignore the bound pre-split public challenge (A/B runs)
+    int knob_no_imad;            // FZ_NO_IMAD=1: A (.) y through the general fp64 multiply instead of integer multiply-adds (A/B runs)
     int knob_verify_cent;        // FZ_VERIFY_CENT=1: centre the inverse transform's outputs before the norm test even when beta allows skipping it
-    // the public challenge A as the caller bound it (fz_ctx_bind_public_challenge): rows pre-split as fp64 pairs
-    // (hi = A >> 16, lo = A & 0xffff) so that the fused keygen / verify kernels accumulate A (.) y with two FMAs
-    const int32_t *bound_A;
-    int bound_l;
-    double2 *d_Asplit;           // [bound_l][degree]
     // device allocations replaced by a larger one while a captured graph may still hold their address: kept until
     // fz_ctx_destroy (a replay must never touch freed memory)
     int graphs_captured;
@@ -143,7 +138,6 @@ bool fz_host_params_ok(const fz_scheme_params *P);
 int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int32_t *out, size_t batch);
 int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,
                            int l, bool broadcast = false);
-int fz_launch_split_A(fz_ctx *ctx, const int32_t *A, double2 *out, size_t count);
 int fz_launch_fill_synthetic(fz_ctx *ctx, int32_t *out, size_t count, unsigned long long seed);
 int fz_launch_bcast_rows(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t segments, int l);
 int fz_launch_verify_fused_i64(fz_ctx *ctx, const int32_t *A, const int64_t *sig, size_t sig_stride, const int64_t *target,

@@ -740,12 +740,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
 // matching row of the public challenge A and accumulated; the l partial products are reduced through LDS
 // into the verification-key row.  sk_hat is never re-read: 342 KB of HBM traffic per key instead of 508 KB.
 // ------------------------------------------------------------------------------------------
-// SPLIT: the public challenge comes pre-split as fp64 pairs (hi = A >> 16, lo = A & 0xffff: fz_ctx_bind_public_challenge), so
-// A[k] (.) y accumulates with TWO FMAs per coefficient -- y * hi and y * lo stay below 2^47 and a wave's rows (at most kSplitFold
-// between folds) sum exactly in fp64 -- instead of an int -> fp64 conversion, the 5-op multiply and an add.
-constexpr int kSplitFold = 32;      // 32 * 2^31 * 2^16 = 2^52 < 2^53
-template <int LOGD, bool FAST, bool SPLIT>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_t *A, const double2 *__restrict__ As, const int32_t *coef,
+// IMAD: A[k] (.) y accumulates in 64-bit INTEGERS: A = hi * 2^16 + lo (hi = A >> 16, lo = A & 0xffff, two integer ops on the
+// int32 row as it is loaded), then acc_hi += y * hi and acc_lo += y * lo are one v_mad_i64_i32 each -- |y * hi|, |y * lo| < 2^47,
+// so 2^16 rows sum without overflow and nothing is reduced inside the loop: 4 operations per coefficient instead of 8
+// (conversion of A, the 6-op FMA-Barrett multiply, the accumulate).  The integer form of y is the value keygen stores anyway.
+// (Measured and dropped: A pre-split into fp64 (hi, lo) pairs by the host -- two FMAs per coefficient, but 64 bytes of L2
+// traffic per lane and row instead of 16: keygen 79 -> 109 us per 1024 keys, verify 256 -> 270 us per 8192 aggregates,
+// profiles/r03_presplit_A_experiment.txt.)
+// hi * 2^16 + lo (mod q) as a double with |result| <= q + 2^18.  `small` (wave-uniform): at most 32 products went into each
+// sum, so |hi|, |lo| < 2^52 convert to fp64 exactly and two folds do (12 operations); otherwise both sums are centred exactly
+// as arbitrary int64 first.
+__device__ __forceinline__ double fz_imad_total(long long hi, long long lo, bool small, const FzMod &m) {
+    if (small) return fz_fold((double)hi * 65536.0, m) + fz_fold((double)lo, m);
+    return fz_fold(fz_cent_i64(hi, m) * 65536.0, m) + fz_cent_i64(lo, m);
+}
+template <int LOGD, bool FAST, bool IMAD>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_t *A, const int32_t *coef,
                                                                     size_t coef_seg_stride,
                                                                     size_t coef_row_stride, int32_t *sk_hat,
                                                                     int32_t *vk, int l, const double2 *__restrict__ tw2,
@@ -764,8 +774,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
     fwd4_load_twiddles<LOGD>(twl, tw2, mm);
 
     double acc[4] = {0, 0, 0, 0};
-    double ach[4] = {0, 0, 0, 0};                       // SPLIT: sums of y * hi (acc holds y * lo)
-    int since = 0;
+    long long ihi[4] = {0, 0, 0, 0}, ilo[4] = {0, 0, 0, 0};      // IMAD: exact integer sums of y * hi and y * lo
     const int tasks = (l + PPW - 1) / PPW;
     int xn[4];
     auto fetch = [&](int task) {
@@ -781,26 +790,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
         double a[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = (double)xn[k];
-        const size_t aoff = (size_t)(valid ? row : l - 1) * D + 4 * mm;
-        int4 ak;
-        double2 as[4];
-        if constexpr (SPLIT) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) as[k] = As[aoff + k];
-        } else {
-            ak = *reinterpret_cast<const int4 *>(A + aoff);
-        }
+        const int4 ak = *reinterpret_cast<const int4 *>(A + (size_t)(valid ? row : l - 1) * D + 4 * mm);
         if (task + kWavesPerBlock < tasks) fetch(task + kWavesPerBlock);
         fwd4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
         const double y0 = fz_cent(a[0], m), y1 = fz_cent(a[1], m), y2 = fz_cent(a[2], m), y3 = fz_cent(a[3], m);
         if (valid) {
-            *reinterpret_cast<int4 *>(sk_hat + (size_t)row * D + 4 * mm) = make_int4((int)y0, (int)y1, (int)y2, (int)y3);
-            if constexpr (SPLIT) {
-                const double y[4] = {y0, y1, y2, y3};
+            const int4 yi = make_int4((int)y0, (int)y1, (int)y2, (int)y3);
+            *reinterpret_cast<int4 *>(sk_hat + (size_t)row * D + 4 * mm) = yi;
+            if constexpr (IMAD) {
+                const int yv[4] = {yi.x, yi.y, yi.z, yi.w}, av[4] = {ak.x, ak.y, ak.z, ak.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    ach[k] = __builtin_fma(y[k], as[k].x, ach[k]);
-                    acc[k] = __builtin_fma(y[k], as[k].y, acc[k]);
+                    ihi[k] += (long long)yv[k] * (long long)(av[k] >> 16);
+                    ilo[k] += (long long)yv[k] * (long long)(av[k] & 0xffff);
                 }
             } else {
                 acc[0] += fz_mulmod(y0, (double)ak.x, m);
@@ -809,21 +811,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
                 acc[3] += fz_mulmod(y3, (double)ak.w, m);
             }
         }
-        if constexpr (SPLIT) {
-            if (++since == kSplitFold) {                 // wave-uniform; never reached by the scheme's ranks (83 / 195 rows over 4 waves)
-                since = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    acc[k] = fz_fold(acc[k], m) + fz_fold(ach[k] * 65536.0, m);
-                    ach[k] = 0.0;
-                }
-            }
-        }
         wave_sync();
     }
-    if constexpr (SPLIT) {
+    if constexpr (IMAD) {
+        const bool small = tasks <= 32 * kWavesPerBlock;          // rows per wave <= 32
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = fz_fold(acc[k], m) + fz_fold(ach[k] * 65536.0, m);
+        for (int k = 0; k < 4; ++k) acc[k] = fz_imad_total(ihi[k], ilo[k], small, m);
     }
     double *mine = accbuf + wave * 256 + p * D + 4 * mm;
     mine[0] = acc[0]; mine[1] = acc[1]; mine[2] = acc[2]; mine[3] = acc[3];
@@ -859,6 +852,7 @@ template <> struct Raw4<int32_t> {
     __device__ __forceinline__ void unpack(double (&a)[4], const FzMod &) const {
         a[0] = (double)v.x; a[1] = (double)v.y; a[2] = (double)v.z; a[3] = (double)v.w;
     }
+    __device__ __forceinline__ void ints(int (&s)[4], const double (&)[4]) const { s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w; }
 };
 template <> struct Raw4<int64_t> {
     longlong2 lo, hi;
@@ -870,16 +864,19 @@ template <> struct Raw4<int64_t> {
         a[0] = fz_cent_i64(lo.x, m); a[1] = fz_cent_i64(lo.y, m);          // exact for any int64
         a[2] = fz_cent_i64(hi.x, m); a[3] = fz_cent_i64(hi.y, m);
     }
+    __device__ __forceinline__ void ints(int (&s)[4], const double (&a)[4]) const {       // the centred values just unpacked
+        s[0] = (int)a[0]; s[1] = (int)a[1]; s[2] = (int)a[2]; s[3] = (int)a[3];
+    }
 };
 __device__ __forceinline__ int centred_any(int32_t v, const FzMod &) { return v; }
 __device__ __forceinline__ int centred_any(int64_t v, const FzMod &m) { return (int)fz_cent_i64(v, m); }
 
-// SPLIT: A pre-split as fp64 pairs (see keygen_fused).  `lazy` (host-decided, uniform): beta < q/2 - q * 2^-12, so the norm
+// IMAD: A (.) sigma in 64-bit integer multiply-adds (see keygen_fused).  `lazy` (host-decided, uniform): beta < q/2 - q * 2^-12, so the norm
 // test needs no centring at all -- the inverse transform's outputs r satisfy |r| <= q/2 + q * 2^-13; if |r| <= beta then r is
 // already the centred residue and passes; if |r| > beta then |cent(r)| >= q - |r| >= q/2 - q * 2^-13 > beta (or cent(r) = r):
 // max |r| > beta <=> max |cent(r)| > beta.  Likewise r == 0 (mod q) <=> r == 0, since |r| < q.  Saves 8 of ~180 ops per row.
-template <int LOGD, bool FAST, typename T, bool ORDERED, bool SPLIT>
-__global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t *A, const double2 *__restrict__ As, const T *sig,
+template <int LOGD, bool FAST, typename T, bool ORDERED, bool IMAD>
+__global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t *A, const T *sig,
                                                                   size_t sig_stride,
                                                                   const T *target, size_t target_stride, int l, long long beta,
                                                                   long long omega, int lazy, const double2 *__restrict__ itw2,
@@ -913,56 +910,37 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
     // it a workgroup per aggregate (many aggregates per launch) paid one memory latency per row: 24 % of the HBM peak.
     Raw4<T> rn;
     int4 an;
-    double2 asn[4];
     auto fetch = [&](int t) {
         const int row = t * PPW + p;
         const size_t off = (size_t)(row < l ? row : l - 1) * D + 4 * mm;
-        if constexpr (SPLIT) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) asn[k] = As[off + k];
-        } else {
-            an = *reinterpret_cast<const int4 *>(A + off);
-        }
+        an = *reinterpret_cast<const int4 *>(A + off);
         rn.load(sig + off);
     };
-    double ach[4] = {0, 0, 0, 0};                   // SPLIT: sums of sigma * hi (acc holds sigma * lo)
-    int since = 0;
+    long long ihi[4] = {0, 0, 0, 0}, ilo[4] = {0, 0, 0, 0};      // IMAD: exact integer sums of sigma * hi and sigma * lo
     int task = r * kVerifyWaves + wave;
     if (task < tasks) fetch(task);
     for (; task < tasks; task += step) {
         const int row = task * PPW + p;
         const bool valid = row < l;
         const int4 ak = an;
-        double2 as[4];
-        if constexpr (SPLIT) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) as[k] = asn[k];
-        }
         double a[4];
+        int si[4];
         rn.unpack(a, m);
+        if constexpr (IMAD) rn.ints(si, a);
         fetch(task + step < tasks ? task + step : tasks - 1);
         if (valid) {
-            if constexpr (SPLIT) {
+            if constexpr (IMAD) {
+                const int av[4] = {ak.x, ak.y, ak.z, ak.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {       // |a| <= 2^31 (raw int32 rows): a * hi, a * lo < 2^47
-                    ach[k] = __builtin_fma(a[k], as[k].x, ach[k]);
-                    acc[k] = __builtin_fma(a[k], as[k].y, acc[k]);
+                for (int k = 0; k < 4; ++k) {       // any int32 sigma, any int32 A: |sigma * hi|, |sigma * lo| < 2^47
+                    ihi[k] += (long long)si[k] * (long long)(av[k] >> 16);
+                    ilo[k] += (long long)si[k] * (long long)(av[k] & 0xffff);
                 }
             } else {
                 acc[0] += fz_mulmod(a[0], (double)ak.x, m);
                 acc[1] += fz_mulmod(a[1], (double)ak.y, m);
                 acc[2] += fz_mulmod(a[2], (double)ak.z, m);
                 acc[3] += fz_mulmod(a[3], (double)ak.w, m);
-            }
-        }
-        if constexpr (SPLIT) {
-            if (++since == kSplitFold) {                 // wave-uniform
-                since = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    acc[k] = fz_fold(acc[k], m) + fz_fold(ach[k] * 65536.0, m);
-                    ach[k] = 0.0;
-                }
             }
         }
         inv4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
@@ -982,9 +960,10 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
         }
         wave_sync();      // the next row's first-pass writes must not overtake this row's last reads
     }
-    if constexpr (SPLIT) {
+    if constexpr (IMAD) {
+        const bool small = tasks <= 32 * step;                    // rows per wave <= 32
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = fz_fold(acc[k], m) + fz_fold(ach[k] * 65536.0, m);
+        for (int k = 0; k < 4; ++k) acc[k] = fz_imad_total(ihi[k], ilo[k], small, m);
     }
     // partial products of this wave, indexed by (row slot p, position)
     double *mine = accbuf + wave * 256 + p * D + 4 * mm;
@@ -1218,11 +1197,9 @@ int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, i
     const dim3 grid((unsigned)segments), block(64 * kWavesPerBlock);
     const size_t seg_stride = broadcast ? (size_t)ctx->degree : (size_t)l * ctx->degree;
     const size_t row_stride = broadcast ? 0 : (size_t)ctx->degree;
-    // the pre-split copy of A serves when the caller bound exactly these rows (fz_ctx_bind_public_challenge)
-    const double2 *As = (ctx->d_Asplit && ctx->bound_A == A && l <= ctx->bound_l && !ctx->knob_no_split) ? ctx->d_Asplit : nullptr;
-#define FZ_KF2(LOGD, FAST, SP) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, SP>), grid, block, 0, ctx->stream, A, As, coef, seg_stride, row_stride, sk_hat, vk, l, \
+#define FZ_KF2(LOGD, FAST, IM) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, IM>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \
                                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod)
-#define FZ_KF(LOGD, FAST) do { if (As) FZ_KF2(LOGD, FAST, true); else FZ_KF2(LOGD, FAST, false); } while (0)
+#define FZ_KF(LOGD, FAST) do { if (!ctx->knob_no_imad) FZ_KF2(LOGD, FAST, true); else FZ_KF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_KF(8, true); else FZ_KF(8, false); }
     else if (ctx->logd == 6) { if (ctx->mod.fast) FZ_KF(6, true); else FZ_KF(6, false); }
     else return fz_set_error(FZ_E_UNSUPPORTED, "fused keygen: degree 64 or 256 only");
@@ -1249,13 +1226,12 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
     int rc = fz_verify_scratch(ctx, groups, (size_t)ctx->degree, &part, &state);
     if (rc != FZ_OK) return rc;
     const dim3 grid((unsigned)R, (unsigned)groups), block(64 * kVerifyWaves);
-    const double2 *As = (ctx->d_Asplit && ctx->bound_A == A && l <= ctx->bound_l && !ctx->knob_no_split) ? ctx->d_Asplit : nullptr;
     // the inverse passes leave |r| <= q/2 + q * 2^-13 (4-op multiply) -- see the kernel's header for why no centring is needed then
     const int lazy = (beta >= 0 && (double)beta < 0.5 * ctx->mod.q - ctx->mod.q / 4096.0 && !ctx->knob_verify_cent) ? 1 : 0;
-#define FZ_VF3(LOGD, FAST, ORD, SP) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T, ORD, SP>), grid, block, 0, ctx->stream, A, As, sig, sig_stride, target, \
+#define FZ_VF3(LOGD, FAST, ORD, IM) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T, ORD, IM>), grid, block, 0, ctx->stream, A, sig, sig_stride, target, \
                                                    target_stride, l, (long long)beta, (long long)omega, lazy, (const double2 *)ctx->d_itw2, \
                                                    ctx->itwA, ctx->mod, part, state, d_verdict)
-#define FZ_VF2(LOGD, FAST, ORD) do { if (As) FZ_VF3(LOGD, FAST, ORD, true); else FZ_VF3(LOGD, FAST, ORD, false); } while (0)
+#define FZ_VF2(LOGD, FAST, ORD) do { if (!ctx->knob_no_imad) FZ_VF3(LOGD, FAST, ORD, true); else FZ_VF3(LOGD, FAST, ORD, false); } while (0)
 #define FZ_VF(LOGD, FAST) do { if (ctx->knob_verify_ordered) FZ_VF2(LOGD, FAST, true); else FZ_VF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_VF(8, true); else FZ_VF(8, false); }
     else { if (ctx->mod.fast) FZ_VF(6, true); else FZ_VF(6, false); }

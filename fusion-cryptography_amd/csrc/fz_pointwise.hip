@@ -798,21 +798,6 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
     return fz_check_hip(hipGetLastError(), "aggregate sum launch");
 }
 
-// the public challenge as fp64 pairs (hi, lo), A = hi * 2^16 + lo with hi = A >> 16 (arithmetic), lo = A & 0xffff
-__global__ __launch_bounds__(kBlock) void split_A_kernel(const int32_t *A, double2 *out, size_t count) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const int v = A[i];
-        out[i] = make_double2((double)(v >> 16), (double)(v & 0xffff));
-    }
-}
-
-int fz_launch_split_A(fz_ctx *ctx, const int32_t *A, double2 *out, size_t count) {
-    if (count == 0) return FZ_OK;
-    hipLaunchKernelGGL(split_A_kernel, dim3(grid_for(ctx, count)), dim3(kBlock), 0, ctx->stream, A, out, count);
-    return fz_check_hip(hipGetLastError(), "split_A launch");
-}
-
 // out[seg][k][:] = in[seg][:] for k < l (generic-degree path of fz_keygen_core_bcast)
 __global__ __launch_bounds__(kBlock) void bcast_rows_kernel(const int32_t *in, int32_t *out, size_t segments, int l, int degree) {
     const size_t total = segments * (size_t)l * degree, stride = (size_t)gridDim.x * blockDim.x;

@@ -44,7 +44,6 @@ SIGNATURES = {
     "fz_ctx_set_stream": (c_int, [_ctx, c_void_p]),
     "fz_ctx_synchronize": (c_int, [_ctx]),
     "fz_ctx_twiddles": (c_int, [_ctx, _u32p, _u32p]),
-    "fz_ctx_bind_public_challenge": (c_int, [_ctx, c_void_p, c_int]),
     "fz_runtime_info": (c_int, [_ctx, POINTER(c_int), POINTER(c_int), c_char_p, c_size_t]),
     "fz_aggregate_core_ragged": (c_int, [_ctx, c_void_p, c_void_p, POINTER(c_size_t), c_size_t, c_int, c_void_p]),
     "fz_aggregate_target_partial_ragged": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_size_t), c_size_t,

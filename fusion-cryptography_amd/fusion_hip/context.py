@@ -43,7 +43,6 @@ class Context:
         self._h = c_void_p()
         self.modulus, self.degree, self.root, self.inv_root = modulus, degree, root, inv_root
         self.device = device
-        self.bound_A = 0
         if not (0 < modulus < 2 ** 31):
             raise FusionHipError(FZ_E_BADARG, f"modulus {modulus} outside (0, 2^31)")
         check(self._lib, self._lib.fz_ctx_create(device, modulus, degree, root % modulus, inv_root % modulus,
@@ -87,12 +86,6 @@ class Context:
         check(self._lib, self._lib.fz_graph_end(self._h, byref(g)))
         return Graph(self, g)
 
-    def bind_public_challenge(self, d_A, l):
-        """declare the rows at d_A [l][degree] (device) as THE public challenge: the fused keygen / verify kernels then use a
-        pre-split fp64 copy (two FMAs per coefficient for A (.) y); d_A = 0 unbinds.  The rows must not change while bound."""
-        check(self._lib, self._lib.fz_ctx_bind_public_challenge(self._h, c_void_p(d_A or None), int(l)))
-        self.bound_A = d_A or 0
-
     def runtime_info(self):
         """-> dict(build_hip_version, runtime_hip_version, arch): what the library was built with / is bound to"""
         b, r = c_int(), c_int()
@@ -115,8 +108,6 @@ class Context:
 
     def free(self, ptr):
         check(self._lib, self._lib.fz_free(self._h, c_void_p(ptr)))
-        if ptr and ptr == self.bound_A:                 # the library ended the binding with the rows
-            self.bound_A = 0
 
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)

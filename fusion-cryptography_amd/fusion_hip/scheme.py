@@ -30,15 +30,11 @@ class BatchScheme:
     def _A_dev(self):
         if self._dA is None:
             self._dA = DeviceArray.from_numpy(self.ctx, self.A)
-            # the fused keygen / verify kernels then use a pre-split fp64 copy of these rows (two FMAs per A (.) y)
-            self.ctx.bind_public_challenge(self._dA.ptr, self.l)
         return self._dA
 
     def close(self):
         """release the device copy of the public challenge (the context itself is shared and stays)"""
         if self._dA is not None:
-            if self.ctx.bound_A == self._dA.ptr:
-                self.ctx.bind_public_challenge(0, 0)
             self._dA.free()
             self._dA = None
 

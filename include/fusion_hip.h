@@ -79,13 +79,6 @@ FZ_API int fz_stream_destroy(fz_ctx *ctx, void *hip_stream);
  * equal to bit_reverse_copy([pow(root,i,q)]) / ([pow(inv_root,i,q)]). Either may be NULL. */
 FZ_API int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv);
 
-/* The public challenge of the scheme (Params.public_challenge, fusion/fusion.py:263-277: 1 x rank NTT-domain polynomials,
- * fixed by fusion_setup) is the same operand of every keygen and every verification.  Binding it lets the library keep
- * a pre-split fp64 copy (hi = A >> 16, lo = A & 0xffff), with which fz_keygen_core* and the fused verification accumulate
- * A (.) y with two FMAs per coefficient instead of a conversion and a 5-op modular multiply (results identical).
- * d_A [l][degree] int32, 16-byte aligned; the caller promises not to change those rows while they are bound; calls that
- * pass a different d_A simply do not use the copy.  d_A == NULL unbinds.  Synchronises the context's stream. */
-FZ_API int fz_ctx_bind_public_challenge(fz_ctx *ctx, const int32_t *d_A, int l);
 /* HIP version the library was built with and the one of the runtime it is bound to (e.g. 70200000 / 70051831), plus the
  * device's gcnArchName: which libamdhip64 a process ended up with is not always the one it was linked against. */
 FZ_API int fz_runtime_info(fz_ctx *ctx, int *out_build_hip_version, int *out_runtime_hip_version, char *out_arch, size_t arch_cap);

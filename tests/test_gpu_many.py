@@ -60,10 +60,7 @@ def test_batch_scheme_at_many_signers_equals_the_reference(secpar):
         sw = list(ms)
         sw[0], sw[-1] = sw[-1], sw[0]
         assert list(bs.verify(v, sw, agg)) == info["swapped_messages_verdict"]
-    # the fused kernels with and without the bound pre-split public challenge agree (the binding happened above)
-    assert bs.ctx.bound_A == bs._A_dev().ptr
     bs.close()
-    assert bs.ctx.bound_A == 0
 
 
 @pytest.mark.parametrize("secpar", [128, 256])

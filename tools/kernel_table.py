@@ -78,14 +78,6 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
     S = 1024
     # keygen (fusion.py:363-370): coef [S][2][l][d] -> sk_hat same shape + vk [S][2][d]
     kb = S * 2 * l * row
-    if not quick:
-        # first WITHOUT the bound pre-split public challenge (the general multiply in the A (.) y accumulation), for the A/B
-        run("keygen_fused (A not bound)", S, (4 * l + 2) * row, kb, kb + S * 2 * row,
-            lambda i, o: ctx.keygen_core_dev(A.ptr, i, o, o + kb, S, l))
-        G8 = 8192
-        run(f"verify_fused G={G8} (A not bound)", G8, (l + 2) * row, G8 * l * row + G8 * row, G8 * 4,
-            lambda i, o: ctx.verify_with_target_batch_async_dev(A.ptr, i, i + G8 * l * row, G8, l, P["beta_vf"], d, o))
-    ctx.bind_public_challenge(A.ptr, l)           # what BatchScheme does with Params.public_challenge
     run("keygen_fused", S, (4 * l + 2) * row, kb, kb + S * 2 * row,
         lambda i, o: ctx.keygen_core_dev(A.ptr, i, o, o + kb, S, l))
     # sign (fusion.py:557): sk_hat [S][2][l][d], c_hat [S][d] -> sig [S][l][d]
@@ -132,7 +124,6 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
             nb = 1 << logb
             run(f"ntt_forward B=2^{logb}", nb, 2 * row, nb * row, nb * row, lambda i, o, nb=nb: ctx.ntt_forward_dev(i, o, nb))
             run(f"ntt_inverse B=2^{logb}", nb, 2 * row, nb * row, nb * row, lambda i, o, nb=nb: ctx.ntt_inverse_dev(i, o, nb))
-    ctx.bind_public_challenge(0, 0)
     for b in (pool_in, pool_out, A):
         b.free()
     return out

@@ -1,0 +1,248 @@
+// ntt_variants.hip -- A/B harness for the headline launch (BASELINE configs[1]: 4096 rows of degree 256, forward transform).
+//
+// The library's radix-4 forward kernel (ntt_fwd4<8>) gives every row its own one-wave workgroup: 4096 workgroups, each of
+// which loads nine per-lane (w, w * K/q) twiddle pairs (9 KiB through the vector-memory path for 1 KiB of data), computes its
+// LDS offsets, transforms ONE row and leaves.  This harness times variants of that schedule in one process, back to back, each
+// checked bit for bit against the library kernel's output:
+//   NR     rows per wave (1 / 2 / 4): twiddle loads, index arithmetic and the wave's start-up amortise over NR rows, and the NR
+//          independent rows give one wave instruction-level parallelism across the dependent fp64 chains;
+//   WAVES  waves per workgroup (1 / 4 / 8 / 16);
+//   TW     0 = nine per-lane global loads (as the library), 1 = the 4 KiB table staged once per workgroup in LDS;
+// plus the same-process floors: an empty dispatch of each grid shape and a plain 4 MiB -> 4 MiB copy.
+//
+// It compiles the library's own kernel source into this translation unit (the kernels live in an anonymous namespace), so
+// the baseline IS the shipped kernel.  usage: ntt_variants [rows=4096] [reps=400]
+#include "../../fusion-cryptography_amd/csrc/fz_ntt.hip"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+// the few symbols fz_ntt.hip expects from fz_capi.hip
+int fz_set_error(int code, const char *, ...) { return code; }
+int fz_check_hip(hipError_t e, const char *what) {
+    if (e != hipSuccess) { printf("HIP error in %s: %s\n", what, hipGetErrorString(e)); return FZ_E_HIP; }
+    return FZ_OK;
+}
+int fz_verify_scratch(fz_ctx *, size_t, size_t, double **, int **) { return FZ_E_UNSUPPORTED; }
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+namespace {
+
+// NR rows per wave, WAVES waves per workgroup, TW: twiddle source.  Degree 256 only (LOGD = 8, 64 lanes x 4 coefficients).
+template <int NR, int WAVES, int TW, bool FAST>
+__global__ __launch_bounds__(64 * WAVES) void fwd4_variant(const int32_t *in, int32_t *out, size_t batch,
+                                                           const double2 *__restrict__ tw2, FzTwA twA, FzMod m) {
+    constexpr int LOGD = 8, D = 256, LP = 64, P = 4;
+    __shared__ __attribute__((aligned(16))) double lds[WAVES * NR * 256 + (TW ? 512 : 0)];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, mm = lane;
+    double *region = lds + wave * NR * 256;
+    const size_t tasks = (batch + NR - 1) / NR;
+    const size_t task = (size_t)blockIdx.x * WAVES + wave;
+
+    // data loads first: they have the longest way to go
+    int x[NR][4];
+    const bool active = task < tasks;
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const size_t row = task * NR + r;
+            const int32_t *src = in + (row < batch ? row : batch - 1) * D + mm;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[r][k] = src[k * LP];
+        }
+    }
+    double2 twl[P - 1][3];
+    if (TW == 0) {
+        fwd4_load_twiddles<LOGD>(twl, tw2, mm);
+    } else {
+        // the (w, w2) table, 256 entries of 16 bytes, staged once per workgroup: 4 coalesced 16-byte loads per lane of wave 0
+        // ... spread over all waves of the workgroup
+        double2 *s_tw = reinterpret_cast<double2 *>(lds + WAVES * NR * 256);
+        for (int i = threadIdx.x; i < 256; i += 64 * WAVES) s_tw[i] = tw2[i];
+        if (WAVES == 1) wave_sync(); else __syncthreads();
+#pragma unroll
+        for (int i = 1; i < P; ++i) {
+            const int s = D >> (2 * i + 2), g = mm / s, pw = 1 << (2 * i);
+            twl[i - 1][0] = s_tw[pw + g];
+            twl[i - 1][1] = s_tw[2 * pw + 2 * g];
+            twl[i - 1][2] = s_tw[2 * pw + 2 * g + 1];
+        }
+    }
+    if (!active) return;
+
+    double a[NR][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[r][k] = (double)x[r][k];
+
+    // the four passes, all NR rows in lock step (one wave-local synchronisation per pass, not per row)
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int s = D >> (2 * i + 2);
+        const int base = (mm / s) * 4 * s + mm % s;
+        double wA, wA2, wB0, wB02, wB1, wB12;
+        if (i == 0) {
+            wA = twA.w[1]; wA2 = twA.w2[1]; wB0 = twA.w[2]; wB02 = twA.w2[2]; wB1 = twA.w[3]; wB12 = twA.w2[3];
+        } else {
+            wA = twl[i - 1][0].x; wA2 = twl[i - 1][0].y;
+            wB0 = twl[i - 1][1].x; wB02 = twl[i - 1][1].y;
+            wB1 = twl[i - 1][2].x; wB12 = twl[i - 1][2].y;
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                double *reg = region + r * 256;
+                if (s == 1) {
+                    const double2 lo = *reinterpret_cast<const double2 *>(reg + swz4(base));
+                    const double2 hi = *reinterpret_cast<const double2 *>(reg + swz4(base + 2));
+                    a[r][0] = lo.x; a[r][1] = lo.y; a[r][2] = hi.x; a[r][3] = hi.y;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[r][k] = reg[swz4(base + k * s)];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            double v = tw_mul<FAST>(a[r][2], wA, wA2, m), u = a[r][0];
+            a[r][0] = u + v; a[r][2] = u - v;
+            v = tw_mul<FAST>(a[r][3], wA, wA2, m); u = a[r][1];
+            a[r][1] = u + v; a[r][3] = u - v;
+            v = tw_mul<FAST>(a[r][1], wB0, wB02, m); u = a[r][0];
+            a[r][0] = u + v; a[r][1] = u - v;
+            v = tw_mul<FAST>(a[r][3], wB1, wB12, m); u = a[r][2];
+            a[r][2] = u + v; a[r][3] = u - v;
+        }
+        if (i < P - 1) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                double *reg = region + r * 256;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) reg[swz4(base + k * s)] = a[r][k];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const size_t row = task * NR + r;
+        if (row < batch)
+            nt_store4(out + row * D + 4 * mm, make_int4((int)fz_cent(a[r][0], m), (int)fz_cent(a[r][1], m), (int)fz_cent(a[r][2], m),
+                                                         (int)fz_cent(a[r][3], m)));
+    }
+}
+
+__global__ __launch_bounds__(1024) void empty_kernel() {}
+
+uint64_t powmod(uint64_t b, uint64_t e, uint64_t q) {
+    unsigned __int128 r = 1, x = b % q;
+    while (e) { if (e & 1) r = (r * x) % q; x = (x * x) % q; e >>= 1; }
+    return (uint64_t)r;
+}
+unsigned brev(unsigned i, int k) { unsigned r = 0; for (int b = 0; b < k; ++b) r |= ((i >> b) & 1u) << (k - 1 - b); return r; }
+
+struct Timer {
+    hipEvent_t a, b;
+    Timer() { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+};
+
+}  // namespace
+
+template <typename F>
+static double time_us(F launch, int reps, hipStream_t st, Timer &t) {
+    for (int i = 0; i < 50; ++i) launch();                       // clocks up, code resident
+    (void)hipStreamSynchronize(st);
+    double best = 1e30;
+    for (int pass = 0; pass < 3; ++pass) {
+        (void)hipEventRecord(t.a, st);
+        for (int i = 0; i < reps; ++i) launch();
+        (void)hipEventRecord(t.b, st);
+        (void)hipEventSynchronize(t.b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, t.a, t.b);
+        if (ms * 1e3 / reps < best) best = ms * 1e3 / reps;
+    }
+    return best;
+}
+
+int main(int argc, char **argv) {
+    const size_t B = argc > 1 ? (size_t)atoll(argv[1]) : 4096;
+    const int reps = argc > 2 ? atoi(argv[2]) : 400;
+    const uint32_t q = 2147465729u, root = 3337519u;
+    const int n = 256, k = 8;
+    FzMod mod = fz_make_mod(q);
+    std::vector<double> pairs(2 * n);
+    FzTwA twA;
+    memset(&twA, 0, sizeof(twA));
+    for (int i = 0; i < n; ++i) {
+        const double w = (double)powmod(root, brev((unsigned)i, k), q);
+        pairs[2 * i] = w;
+        pairs[2 * i + 1] = w * mod.kq;
+        if (i < 16) { twA.w[i] = w; twA.w2[i] = w * mod.kq; }
+    }
+    double *d_tw2;
+    CHECK(hipMalloc((void **)&d_tw2, sizeof(double) * 2 * n));
+    CHECK(hipMemcpy(d_tw2, pairs.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    std::vector<int32_t> h(B * n);
+    uint64_t z = 20261003;
+    for (auto &v : h) { z = z * 6364136223846793005ull + 1442695040888963407ull; v = (int32_t)((int64_t)((z >> 33) % q) - (int64_t)(q / 2)); }
+    int32_t *d_in, *d_ref, *d_out;
+    CHECK(hipMalloc((void **)&d_in, B * n * 4));
+    CHECK(hipMalloc((void **)&d_ref, B * n * 4));
+    CHECK(hipMalloc((void **)&d_out, B * n * 4));
+    CHECK(hipMemcpy(d_in, h.data(), B * n * 4, hipMemcpyHostToDevice));
+    hipStream_t st;
+    CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    Timer t;
+    const double bytes = 2048.0 * B;
+    printf("# forward NTT, %zu rows of degree 256 (%.1f MiB in + out), back-to-back dependent launches, best of 3 passes of %d\n", B,
+           bytes / 1048576.0, reps);
+
+    // baseline: the library kernel exactly as fz_ntt_forward launches it below 2^16 rows
+    auto base = [&]() { hipLaunchKernelGGL((ntt_fwd4<8, true>), dim3((unsigned)B), dim3(64), 0, st, (const int32_t *)d_in, d_ref, B,
+                                           (const double2 *)d_tw2, twA, mod, 0u); };
+    base();
+    CHECK(hipStreamSynchronize(st));
+    std::vector<int32_t> ref(B * n), got(B * n);
+    CHECK(hipMemcpy(ref.data(), d_ref, B * n * 4, hipMemcpyDeviceToHost));
+    const double t_base = time_us(base, reps, st, t);
+    printf("%-44s grid %5zu x %4d  %7.3f us  %5.1f %% of 8 TB/s\n", "library ntt_fwd4<8> (NR=1 WAVES=1 TW=global)", B, 64, t_base,
+           bytes / (t_base * 1e-6) / 8e12 * 100);
+
+    int bad = 0;
+#define VARIANT(NR, WAVES, TW)                                                                                                  \
+    {                                                                                                                           \
+        const size_t tasks = (B + NR - 1) / NR;                                                                                 \
+        const unsigned grid = (unsigned)((tasks + WAVES - 1) / WAVES);                                                          \
+        auto f = [&]() { hipLaunchKernelGGL((fwd4_variant<NR, WAVES, TW, true>), dim3(grid), dim3(64 * WAVES), 0, st,           \
+                                            (const int32_t *)d_in, d_out, B, (const double2 *)d_tw2, twA, mod); };              \
+        CHECK(hipMemsetAsync(d_out, 0, B * n * 4, st));                                                                         \
+        f();                                                                                                                    \
+        CHECK(hipStreamSynchronize(st));                                                                                        \
+        CHECK(hipMemcpy(got.data(), d_out, B * n * 4, hipMemcpyDeviceToHost));                                                  \
+        const bool ok = memcmp(got.data(), ref.data(), B * n * 4) == 0;                                                         \
+        if (!ok) ++bad;                                                                                                         \
+        const double us = time_us(f, reps, st, t);                                                                              \
+        auto e = [&]() { hipLaunchKernelGGL(empty_kernel, dim3(grid), dim3(64 * WAVES), 0, st); };                              \
+        const double ue = time_us(e, reps, st, t);                                                                              \
+        char name[64];                                                                                                          \
+        snprintf(name, sizeof(name), "NR=%d WAVES=%-2d TW=%s", NR, WAVES, TW ? "lds" : "global");                               \
+        printf("%-44s grid %5u x %4d  %7.3f us  %5.1f %% of 8 TB/s   empty grid %6.3f us   %s\n", name, grid, 64 * WAVES, us, \
+               bytes / (us * 1e-6) / 8e12 * 100, ue, ok ? "bit-exact" : "MISMATCH");                                            \
+    }
+    VARIANT(1, 1, 0) VARIANT(1, 1, 1) VARIANT(1, 4, 0) VARIANT(1, 4, 1) VARIANT(1, 8, 1) VARIANT(1, 16, 1)
+    VARIANT(2, 1, 0) VARIANT(2, 1, 1) VARIANT(2, 4, 0) VARIANT(2, 4, 1) VARIANT(2, 8, 1)
+    VARIANT(4, 1, 0) VARIANT(4, 1, 1) VARIANT(4, 4, 0) VARIANT(4, 4, 1) VARIANT(4, 2, 0)
+    {
+        const size_t n16 = B * n * 4 / 16;
+        auto c = [&]() { hipLaunchKernelGGL(diag_copy_kernel, dim3((unsigned)((n16 + 63) / 64)), dim3(64), 0, st, (const int4 *)d_in, (int4 *)d_out, n16); };
+        const double us = time_us(c, reps, st, t);
+        printf("%-44s grid %5zu x %4d  %7.3f us  %5.1f %% of 8 TB/s\n", "plain copy of the same bytes (16 B per lane)", (n16 + 63) / 64, 64, us,
+               bytes / (us * 1e-6) / 8e12 * 100);
+    }
+    printf(bad ? "# %d variant(s) MISMATCHED\n" : "# all variants bit-exact against the library kernel\n", bad);
+    return bad ? 2 : 0;
+}

@@ -68,7 +68,8 @@ def parse():
                          "milliseconds of load to reach its steady clocks (measured: the first ~15 ms run 10-25 %% slower)")
     ap.add_argument("--watchdog-s", type=float, default=420.0,
                     help="if the legs after the headline have not finished by then, rank 0 prints the line with what it has "
-                         "(\"watchdog\" says which leg was running) and every rank leaves: a hung collective must not cost the line")
+                         "(\"watchdog\" says which leg was running) and every rank leaves WITH EXIT CODE 3: a hung collective must "
+                         "not cost the headline, and must not pass for success either")
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-signers", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -239,7 +240,9 @@ def self_launch(args):
     if rescued:                                          # a leg after the headline hung: rank 0's watchdog printed what it had
         sys.stdout.write(rescued[-1] + "\n")
         sys.stdout.flush()
-        return
+        sys.stderr.write("bench.py: a side leg hung and the watchdog fired (see the line's \"watchdog\" field): the headline is "
+                         "in the line above, the run is a FAILURE -- exit code 3\n")
+        sys.exit(3)
     if failed:
         sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}; no result\n")
         sys.exit(1)
@@ -521,8 +524,15 @@ def main():
         _BAILING.set()
         if rank == 0:
             try:
-                print(json.dumps(build_line(f"side legs not finished {args.watchdog_s:.0f} s after the headline; running: {stage[0]}")))
+                text = json.dumps(build_line(f"side legs not finished {args.watchdog_s:.0f} s after the headline; running: {stage[0]}"))
+                print(text)
                 sys.stdout.flush()
+                try:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    with open(os.path.join(ROOT, "gpurun_out", "bench_watchdog_line.json"), "w") as fh:
+                        fh.write(text + "\n")
+                except OSError:
+                    pass
             except Exception:
                 import traceback
                 traceback.print_exc()
@@ -530,7 +540,9 @@ def main():
         sys.stderr.flush()
         if rank == 0:
             time.sleep(3.0)                             # the other ranks' watchdogs fire at the same moment: let them leave first
-        os._exit(0)                                     # the line is out; a non-zero code would make a launcher discard it
+        # A process that hung on the GPU must not report success: the line (with its "watchdog" field) is on stdout AND in
+        # gpurun_out/bench_watchdog_line.json for launchers that drop the output of a failed run; the exit code says failure.
+        os._exit(3)
     threading.Thread(target=watchdog, daemon=True).start()
 
     # ---- the launch floor, same run: an empty dispatch and a plain copy of the bytes one launch moves -----------
@@ -758,7 +770,13 @@ def main():
     stage[0] = "sv"
     if not args.no_sign_verify:
         try:
-            S, GROUPS, NSETS = 1024, 4, 8            # per rank: 1024 signatures in 4 aggregates of 256 x world; 8 operand sets
+            # per rank: 1024 signatures in GROUPS aggregates of (1024 / GROUPS) x world signers; 8 operand sets.  At least as many
+            # aggregates as ranks, so that EVERY rank verifies (with 4 aggregates ranks 4-7 of an 8-GPU run would sit out the
+            # verification step); world = 8: 8 aggregates of 128 x 8 = 1024 signers (capacity 2818)
+            S, NSETS = 1024, 8
+            GROUPS = max(4, world)
+            while S % GROUPS:
+                GROUPS += 1
             per = S // GROUPS
             rng = np.random.default_rng(1234 + rank)
             A = torch.empty((l, d), dtype=torch.int32, device=dev)                           # same on every rank
@@ -895,6 +913,7 @@ def main():
                   "note": "algebra cores only: sign_core, aggregate + target partials (one pass, one launch), int64 all-reduce, "
                           "verification from the int64 sums -- 3 kernel launches (+ the collective) per step; every step works on "
                           "the next of 8 operand sets (2.1 GB), so keys and signatures come from HBM; host hashing of str(vk) excluded"}
+            sv_graph_used = sv_graph is not None
             if sv_graph is not None:
                 sv_graph.destroy()
             # BASELINE configs[2]: 1024 independent keygen + sign per step (keygen_core: 2*l transforms + two A.s
@@ -919,6 +938,14 @@ def main():
                                  "note": "configs[2]: keygen_core + sign_core on 1024 distinct synthetic keys per rank; sign reads the "
                                          "sk_hat keygen has just written (174 MB: part of it may still sit in the Infinity Cache), "
                                          "coefficients come from HBM (8 sets rotated)"}
+            if world > 1:            # what EVERY rank did in this leg, as the ranks themselves report it
+                mine = {"rank": rank, "collective": collective, "aggregates_verified": int(g_hi - g_lo), "verdicts_ok": True,
+                        "graph": sv_graph_used}
+                allr = [None] * world
+                dist.all_gather_object(allr, mine)
+                sv["ranks"] = allr
+                sv["every_rank_verified"] = all(r_["aggregates_verified"] > 0 for r_ in allr)
+                sv["one_collective_path"] = len({r_["collective"] for r_ in allr}) == 1
             if comm is not None:
                 barrier()
                 comm.destroy()
@@ -966,9 +993,6 @@ def main():
             ok, why = bs.verify(vk_e, msgs, agg_e)
             t_ver = time.perf_counter() - t0
             assert ok, why
-            sig_e.free()
-            sk_e.free()
-            vk_dev.free()
             # a larger batch of signatures: the device pipeline is a latency chain of ~108 Keccak permutations per signer,
             # the same ~0.7 ms for any batch up to 32 768 signers (two lanes per signer, one wave per SIMD)
             n_big = 16384
@@ -981,7 +1005,29 @@ def main():
             t_sign_big = time.perf_counter() - t0
             sk_b.free()
             vkd_b.free()
-            e2e = {"signatures": n_e2e, "host_threads": bs.threads, "keygen_per_s": n_e2e / t_keygen,
+            # many independent aggregates in one batch (aggregate_many / verify_many): one host thread per aggregate for its
+            # sort + serial SHAKE-256, one launch for all aggregates, one for all verifications.  Same 1024 signatures as above.
+            many = {}
+            for g_, n_ in ((4, 256), (16, 64), (64, 16)):
+                sizes = [n_] * g_
+                bs.aggregate_many(vk_e, msgs, sig_e, sizes)                      # scratch growth outside the timing
+                t0 = time.perf_counter()
+                aggs = bs.aggregate_many(vk_e, msgs, sig_e, sizes)
+                t_am = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                verd = bs.verify_many(vk_e, msgs, aggs, sizes)
+                t_vm = time.perf_counter() - t0
+                assert all(v[0] for v in verd), verd
+                many[f"{g_}x{n_}"] = {"aggregate_per_s": n_e2e / t_am, "verify_per_s": n_e2e / t_vm,
+                                      "sign_plus_verify_per_s": n_e2e / (t_sign + t_am + t_vm),
+                                      "aggregate_ms": t_am * 1e3, "verify_ms": t_vm * 1e3}
+            many["what"] = ("BatchScheme.aggregate_many / verify_many on the same 1024 signatures split into G aggregates of N signers: "
+                            "G independent hash_ag sponges on G host threads, ONE ragged launch for the G aggregates, ONE for the G "
+                            "verifications (reference call pattern: one aggregate()/verify() per aggregate, fusion.py:655, :680)")
+            sig_e.free()
+            sk_e.free()
+            vk_dev.free()
+            e2e = {"signatures": n_e2e, "host_threads": bs.threads, "keygen_per_s": n_e2e / t_keygen, "many_aggregates": many,
                    "sign_per_s": n_e2e / t_sign,
                    "sign_split": {"device_challenge_pipeline_ms": t_chal * 1e3, "whole_sign_batch_ms": t_sign * 1e3,
                                   "sign_per_s_with_host_challenge_pipeline": n_e2e / t_sign_host,
@@ -1000,12 +1046,81 @@ def main():
             traceback.print_exc()
             e2e = {"error": repr(exc)}
 
+    # ---- end to end, SHARDED: aggregate() + verify() of ONE aggregate of 1024 signers with the signers (and their signatures)
+    # spread over the ranks (fusion_hip.dist.ShardedScheme: global sort + hash_ag on every rank, alpha scattered, ONE pass over
+    # the local signatures, ONE all-reduce of int64 partials, verification from the sums) -- BASELINE configs[3]
+    stage[0] = "e2e_sharded"
+    e2e_sh = None
+    if not args.no_sign_verify and not args.no_end_to_end:
+        try:
+            from fusion_hip.dist import ShardedScheme, TorchCollective
+            from fusion_hip.scheme import BatchScheme
+            params = F.fusion_setup(SECPAR, 2026)
+            bs = BatchScheme(params, device=dev_index)
+            bs.ctx.set_stream(stream.cuda_stream)
+            n_all = 1024
+            seeds = [10_000 + 2 * i for i in range(n_all)]
+            msgs = [f"synthetic message {i:06d}" for i in range(n_all)]
+            lo_, hi_ = shard_range(n_all, rank, world)
+            sk_l, vk_l, vk_ld = bs.keygen_batch(seeds[lo_:hi_], device=True, keep_vk=True)
+            sig_l = bs.sign_batch(sk_l, vk_ld, msgs[lo_:hi_], device=True)         # this rank's signatures stay in its HBM
+            if world > 1:                                                          # verification keys are public: everyone gets all
+                parts = [None] * world
+                dist.all_gather_object(parts, vk_l)
+                vk_all = np.concatenate(parts)
+            else:
+                vk_all = vk_l
+            sh = ShardedScheme(bs, rank, world, TorchCollective(bs.ctx, dev_index))
+            sh.aggregate_verify_sharded(vk_all, msgs, sig_l)                      # scratch growth, first-use tables
+            barrier()
+            t0 = time.perf_counter()
+            agg_s, verdict_s = sh.aggregate_verify_sharded(vk_all, msgs, sig_l)
+            barrier()
+            t_sh = max_over_ranks(time.perf_counter() - t0)
+            assert verdict_s == (True, ""), verdict_s
+            t0 = time.perf_counter()
+            v2 = sh.verify_sharded(vk_all, msgs, agg_s)
+            barrier()
+            t_vs = max_over_ranks(time.perf_counter() - t0)
+            assert v2 == (True, ""), v2
+            e2e_sh = {"signers": n_all, "ranks": world, "signers_per_rank": hi_ - lo_,
+                      "aggregate_plus_verify_per_s": n_all / t_sh, "aggregate_plus_verify_ms": t_sh * 1e3,
+                      "verify_per_s": n_all / t_vs, "verify_ms": t_vs * 1e3,
+                      "collective": (f"torch.distributed all_reduce ({dist.get_backend()})" if world > 1 else "none (single rank)"),
+                      "what": "ShardedScheme.aggregate_verify_sharded / verify_sharded: every rank sorts and hashes the whole key list "
+                              "(hash_ag is one serial SHAKE-256 over all signers, the same on every rank), transforms only its block of "
+                              "alpha, makes one pass over its block of signatures, then ONE all-reduce of l*d + d int64; max over ranks"}
+            for b in (sk_l, vk_ld, sig_l):
+                b.free()
+        except Exception as exc:                      # a side leg must never take the headline down with it
+            import traceback
+            traceback.print_exc()
+            e2e_sh = {"error": repr(exc)}
+        if isinstance(e2e, dict):
+            e2e["sharded"] = e2e_sh
+        elif e2e is None and rank == 0:
+            e2e = {"sharded": e2e_sh}
+
     stage[0] = "cpu_baseline"
     done.set()                                          # the bounded CPU sample is not under the watchdog
     if rank == 0:
         out = build_line()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            sch = out["cpu_baseline"].get("scheme") or {}
+            if "sign_plus_verify_per_s" in sch and isinstance(out.get("sign_verify"), dict) and "value" in out["sign_verify"]:
+                # the second half of the metric, CPU beside GPU: same cores -- sign, aggregate, verify
+                # (and keygen + sign for configs[2]) -- in the pure-Python port, per signature
+                out["sign_verify"]["cpu_baseline"] = {
+                    "value": sch["sign_plus_verify_per_s"], "unit": "signatures signed+aggregated+verified per s", "cores": 1, "kind": "port",
+                    "all_cores": (sch.get("all_cores") or {}).get("sign_plus_verify_per_s"), "all_cores_count": (sch.get("all_cores") or {}).get("cores"),
+                    "sign_per_s": sch["sign_per_s"], "aggregate_signatures_per_s": sch["aggregate_signatures_per_s"],
+                    "verify_signatures_per_s": sch["verify_signatures_per_s"], "sample": sch["sample"]}
+                if isinstance(out["sign_verify"].get("keygen_sign"), dict):
+                    out["sign_verify"]["keygen_sign"]["cpu_baseline"] = {
+                        "value": sch["keygen_plus_sign_per_s"], "unit": "keygen+sign per s", "cores": 1, "kind": "port",
+                        "all_cores": (sch.get("all_cores") or {}).get("keygen_plus_sign_per_s"), "keygen_per_s": sch["keygen_per_s"],
+                        "sign_per_s": sch["sign_per_s"], "sample": sch["sample"]}
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
@@ -1021,5 +1136,5 @@ if __name__ == "__main__":
     except BaseException:
         if not _BAILING.is_set():
             raise
-        time.sleep(10.0)           # the watchdog thread prints the line and ends the process with code 0
-        os._exit(0)
+        time.sleep(10.0)           # the watchdog thread prints the line and ends the process (exit code 3: a hang is a failure)
+        os._exit(3)

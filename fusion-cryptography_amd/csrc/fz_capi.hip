@@ -302,16 +302,20 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     {
         const char *e = getenv("FZ_NTT_KERNEL");
         c->force_kernel = e ? atoi(e) : 0;
-        e = getenv("FZ_NTT_TPB");
-        c->tasks_per_block = e ? atoi(e) : 0;
+        e = getenv("FZ_FUSED_ROWS");
+        c->knob_fused_rows = e ? atoi(e) : 0;
+        e = getenv("FZ_NTT_WAVES");
+        c->knob_ntt_waves = e ? atoi(e) : 0;
+        e = getenv("FZ_NTT_ROWS");
+        c->knob_ntt_rows = e ? atoi(e) : 0;
         e = getenv("FZ_NTT_GRID_MULT");
         c->grid_mult = e ? atoi(e) : 1;
         if (c->grid_mult < 1) c->grid_mult = 1;
         e = getenv("FZ_NTT_SMALL_ROWS");
-        // measured crossover at steady clocks (profiles/README.md), inputs NOT cache-resident (rotating buffers):
-        // degree 256 -- radix-4 ahead up to 2^14 rows (5-8 % at the bench's 2^12), level at 2^15, the 16-per-lane
-        // kernel ahead from 2^16 (61 % vs 58 % of HBM peak; 2^18: 70 % vs 61 %); degree 64 -- radix-4 up to 2^18
-        // rows, 16-per-lane from 2^20
+        // measured crossover, inputs NOT cache-resident, both schedules on one box (profiles/r03_ntt_crossover.txt): degree 256 --
+        // the radix-4 kernels lead up to 2^15 rows (4.19 / 5.50 / 8.44 / 15.35 us at 2^12 .. 2^15 against 4.92 / 6.36 / 9.17 /
+        // 15.86 for the 16-per-lane kernel), the 16-per-lane kernel from 2^16 (28.2 us against 32.3); degree 64 -- radix-4 up to
+        // 2^18 rows (round 2's measurement)
         c->small_batch_rows = e ? atoi(e) : (degree == 256 ? (1 << 16) : (1 << 19));
         // every benchmarking knob is read HERE, once: no entry point consults the environment afterwards
         auto knob = [](const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; };

@@ -361,17 +361,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz4(int j) { return j ^ (((j >> 4) & 7) << 2); }
 
-// The waves of the stand-alone radix-4 kernels never talk to each other (wave-private LDS regions, no s_barrier), so
-// they are launched as one-wave workgroups: a 256-thread workgroup has to find four free wave slots on ONE CU before
-// any of its waves starts, which costs 4-5 % at the bench's batch (4.55 us vs 4.77 us per 4096-row launch) and
-// nothing at large batches.  (The fused kernels below share data between waves and keep 4 or more.)
-constexpr int kWaves4 = 1;
 
-// the log4(D) in-place passes of the radix-4 forward transform on one lane's 4 values (natural positions
-// mm + (D/4)k in, bit-reversed-order positions 4mm..4mm+3 out, NOT yet centred)
-template <int LOGD, bool FAST>
-__device__ __forceinline__ void fwd4_passes(double (&a)[4], double *region, const double2 (&twl)[LOGD / 2 - 1][3],
-                                            const FzTwA &twA, const FzMod &m, int mm) {
+// the log4(D) in-place passes of the radix-4 forward transform on one lane's 4 values per row group (natural positions
+// mm + (D/4)k in, bit-reversed-order positions 4mm..4mm+3 out, NOT yet centred).  NR independent row groups (a wave's 64
+// lanes hold 64 / (D/4) polynomials per group) go through the passes in lock step: one wave-local synchronisation per
+// pass whatever NR is, twiddles and LDS offsets computed once, and NR independent dependency chains for the fp64 pipeline.
+// Row group r of this lane's polynomial lives at region + r * 256 doubles.
+template <int LOGD, bool FAST, int NR>
+__device__ __forceinline__ void fwd4_passes_n(double (&a)[NR][4], double *region, const double2 (&twl)[LOGD / 2 - 1][3],
+                                              const FzTwA &twA, const FzMod &m, int mm) {
     constexpr int D = 1 << LOGD, P = LOGD / 2;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -385,29 +383,46 @@ __device__ __forceinline__ void fwd4_passes(double (&a)[4], double *region, cons
             wB0 = twl[i - 1][1].x; wB02 = twl[i - 1][1].y;
             wB1 = twl[i - 1][2].x; wB12 = twl[i - 1][2].y;
             wave_sync();
-            if (s == 1) {
-                const double2 lo = *reinterpret_cast<const double2 *>(region + swz4(base));
-                const double2 hi = *reinterpret_cast<const double2 *>(region + swz4(base + 2));
-                a[0] = lo.x; a[1] = lo.y; a[2] = hi.x; a[3] = hi.y;
-            } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] = region[swz4(base + k * s)];
+            for (int r = 0; r < NR; ++r) {
+                const double *reg = region + r * 256;
+                if (s == 1) {
+                    const double2 lo = *reinterpret_cast<const double2 *>(reg + swz4(base));
+                    const double2 hi = *reinterpret_cast<const double2 *>(reg + swz4(base + 2));
+                    a[r][0] = lo.x; a[r][1] = lo.y; a[r][2] = hi.x; a[r][3] = hi.y;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[r][k] = reg[swz4(base + k * s)];
+                }
             }
         }
         // stage 2i: distance 2s, one twiddle; stage 2i+1: distance s, two twiddles
-        double v = tw_mul<FAST>(a[2], wA, wA2, m), u = a[0];
-        a[0] = u + v; a[2] = u - v;
-        v = tw_mul<FAST>(a[3], wA, wA2, m); u = a[1];
-        a[1] = u + v; a[3] = u - v;
-        v = tw_mul<FAST>(a[1], wB0, wB02, m); u = a[0];
-        a[0] = u + v; a[1] = u - v;
-        v = tw_mul<FAST>(a[3], wB1, wB12, m); u = a[2];
-        a[2] = u + v; a[3] = u - v;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            double v = tw_mul<FAST>(a[r][2], wA, wA2, m), u = a[r][0];
+            a[r][0] = u + v; a[r][2] = u - v;
+            v = tw_mul<FAST>(a[r][3], wA, wA2, m); u = a[r][1];
+            a[r][1] = u + v; a[r][3] = u - v;
+            v = tw_mul<FAST>(a[r][1], wB0, wB02, m); u = a[r][0];
+            a[r][0] = u + v; a[r][1] = u - v;
+            v = tw_mul<FAST>(a[r][3], wB1, wB12, m); u = a[r][2];
+            a[r][2] = u + v; a[r][3] = u - v;
+        }
         if (i < P - 1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) region[swz4(base + k * s)] = a[k];
+            for (int r = 0; r < NR; ++r) {
+                double *reg = region + r * 256;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) reg[swz4(base + k * s)] = a[r][k];
+            }
         }
     }
+}
+
+template <int LOGD, bool FAST>
+__device__ __forceinline__ void fwd4_passes(double (&a)[4], double *region, const double2 (&twl)[LOGD / 2 - 1][3],
+                                            const FzTwA &twA, const FzMod &m, int mm) {
+    fwd4_passes_n<LOGD, FAST, 1>(reinterpret_cast<double (&)[1][4]>(a), region, twl, twA, m, mm);
 }
 
 template <int LOGD>
@@ -422,67 +437,59 @@ __device__ __forceinline__ void fwd4_load_twiddles(double2 (&twl)[LOGD / 2 - 1][
     }
 }
 
-template <int LOGD, bool FAST>
-__global__ __launch_bounds__(64 * kWaves4) void ntt_fwd4(const int32_t *in, int32_t *out, size_t batch,
-                                                                const double2 *__restrict__ tw2, FzTwA twA, FzMod m, unsigned tpb) {
+// One wave-task = NR row groups (NR * 64 / (D/4) consecutive polynomials), one task per wave, WAVES waves per workgroup,
+// grid = tasks / WAVES: no persistent loop (a loop's bookkeeping -- 64-bit task arithmetic, the prefetch state, the
+// conditional refill -- cost the one-row-per-wave kernel 7-9 % at the bench's 4096 rows: 4.74 -> 4.32 us cold).
+// Measured on one box, forward, degree 256, cold operands (tools/microbench/ntt_variants.hip, profiles/r03_ntt_variants.txt):
+//   4096 rows: NR = 1 4.32 us (the loop kernel 4.74; NR = 2 4.51; NR = 4 5.4 -- too few waves);
+//   8192 rows: NR = 2 6.03 us (NR = 1 6.23-6.51; the loop kernel 7.09; the 16-per-lane kernel 6.52);
+//   16384 rows: NR = 4 9.24 us (NR = 2 10.3; NR = 1 10.6; the loop kernel 11.3; 16-per-lane 9.40);
+//   from 32768 rows the 16-per-lane kernel leads (15.0 us against 16.6).
+// The waves of a workgroup never talk to each other (wave-private LDS regions, no s_barrier).
+template <int LOGD, bool FAST, int NR, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void ntt_fwd4(const int32_t *in, int32_t *out, size_t batch,
+                                                       const double2 *__restrict__ tw2, FzTwA twA, FzMod m) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
-    __shared__ __attribute__((aligned(16))) double lds[kWaves4 * 256];
+    __shared__ __attribute__((aligned(16))) double lds[WAVES * NR * 256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane / LP, mm = lane % LP;
-    double *region = lds + wave * 256 + p * D;
+    double *region = lds + wave * NR * 256 + p * D;
+    const size_t task = (size_t)blockIdx.x * WAVES + wave;
+    const size_t poly0 = task * (NR * PPW) + p;                 // row group r: polynomial poly0 + r * PPW
+    if (task * (NR * PPW) >= batch) return;
 
-    // task -> wave mapping: tpb == 0: persistent grid, tasks strided over the whole batch; tpb > 0: workgroup b
-    // owns the contiguous tasks [b*tpb, (b+1)*tpb), its waves interleaved inside (non-persistent launch)
-    const size_t all_tasks = (batch + PPW - 1) / PPW;
-    const size_t first = tpb ? (size_t)blockIdx.x * tpb + wave : (size_t)blockIdx.x * kWaves4 + wave;
-    const size_t stride = tpb ? (size_t)kWaves4 : (size_t)gridDim.x * kWaves4;
-    const size_t tasks = tpb ? (((size_t)blockIdx.x + 1) * tpb < all_tasks ? ((size_t)blockIdx.x + 1) * tpb : all_tasks) : all_tasks;
-    if (first >= tasks) return;
-
-    // per-lane twiddles of passes 1..P-1 (independent of the data: issued before the first load returns)
-    double2 twl[P - 1][3];
-    fwd4_load_twiddles<LOGD>(twl, tw2, mm);
-
-    int xn[4];                                   // next task's coefficients, in flight during the passes
-    auto fetch = [&](size_t task) {
-        const size_t poly = task * PPW + p;
+    int x[NR][4];                                 // the data loads first: they have the longest way to go
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const size_t poly = poly0 + (size_t)r * PPW;
         const int32_t *src = in + (poly < batch ? poly : batch - 1) * D + mm;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xn[k] = src[k * LP];
-    };
-    fetch(first);
-    double an[4];                                // ... converted BEFORE this task's store is issued (see ntt_fwd16)
+        for (int k = 0; k < 4; ++k) x[r][k] = src[k * LP];
+    }
+    double2 twl[P - 1][3];
+    fwd4_load_twiddles<LOGD>(twl, tw2, mm);
+    double a[NR][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) an[k] = (double)xn[k];
-    for (size_t task = first; task < tasks; task += stride) {
-        const size_t poly = task * PPW + p;
-        const bool valid = poly < batch;
-        const bool more = task + stride < tasks;
-        double a[4];
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = an[k];
-        if (more) fetch(task + stride);
-        fwd4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
-        int4 o;
-        o.x = (int)fz_cent(a[0], m);
-        o.y = (int)fz_cent(a[1], m);
-        o.z = (int)fz_cent(a[2], m);
-        o.w = (int)fz_cent(a[3], m);
-        if (more) {
+        for (int k = 0; k < 4; ++k) a[r][k] = (double)x[r][k];
+    fwd4_passes_n<LOGD, FAST, NR>(a, region, twl, twA, m, mm);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) an[k] = (double)xn[k];
-        }
-        if (valid) nt_store4(out + poly * D + 4 * mm, o);
-        wave_sync();      // the next task's first-pass writes must not overtake this task's last reads
+    for (int r = 0; r < NR; ++r) {
+        const size_t poly = poly0 + (size_t)r * PPW;
+        if (poly < batch)
+            nt_store4(out + poly * D + 4 * mm, make_int4((int)fz_cent(a[r][0], m), (int)fz_cent(a[r][1], m), (int)fz_cent(a[r][2], m),
+                                                          (int)fz_cent(a[r][3], m)));
     }
 }
 
-// the log4(D) in-place passes of the radix-4 inverse on one lane's 4 values (bit-reversed positions
-// 4mm..4mm+3 in, natural positions mm + (D/4)k out, n^-1 applied, NOT yet centred)
-template <int LOGD, bool FAST>
-__device__ __forceinline__ void inv4_passes(double (&a)[4], double *region, const double2 (&twl)[LOGD / 2 - 1][3],
-                                            const FzTwA &twA, const FzMod &m, int mm) {
+// the log4(D) in-place passes of the radix-4 inverse on one lane's 4 values per row group (bit-reversed positions
+// 4mm..4mm+3 in, natural positions mm + (D/4)k out, n^-1 applied, NOT yet centred); NR row groups in lock step (see
+// fwd4_passes_n)
+template <int LOGD, bool FAST, int NR>
+__device__ __forceinline__ void inv4_passes_n(double (&a)[NR][4], double *region, const double2 (&twl)[LOGD / 2 - 1][3],
+                                              const FzTwA &twA, const FzMod &m, int mm) {
     constexpr int P = LOGD / 2;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -491,48 +498,64 @@ __device__ __forceinline__ void inv4_passes(double (&a)[4], double *region, cons
         if (i > 0) {
             wave_sync();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = region[swz4(base + k * s)];
+            for (int r = 0; r < NR; ++r) {
+                const double *reg = region + r * 256;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[r][k] = reg[swz4(base + k * s)];
+            }
         }
         if (i < P - 1) {
             // GS stage 2i (distance s, two twiddles) then stage 2i+1 (distance 2s, one twiddle);
             // operands stay below 2^(33+2i+1) <= 2^38
-            double u = a[0], v = a[1];
-            a[0] = u + v; a[1] = tw_mul<FAST>(u - v, twl[i][0].x, twl[i][0].y, m);
-            u = a[2]; v = a[3];
-            a[2] = u + v; a[3] = tw_mul<FAST>(u - v, twl[i][1].x, twl[i][1].y, m);
-            u = a[0]; v = a[2];
-            a[0] = u + v; a[2] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
-            u = a[1]; v = a[3];
-            a[1] = u + v; a[3] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
-            // Degree 256 with raw int32 inputs: a[0] is the only value no multiply has reduced (the sum of four inputs, up to
-            // 2^33; a[1] <= 2^31.1, a[2], a[3] <= 2^30.1).  Folding it once (2 ops) keeps every later operand below
-            // 2^31.1 * 2^6 = 2^37.1, inside the 4-op multiply's 2^38 bound up to and including the final stage -- which
-            // otherwise needs the general 6-op form four times (8 extra ops per lane).
-            if (FAST && i == 0 && 31 + LOGD > 38) a[0] = fz_fold(a[0], m);
-            if (s == 1) {
-                *reinterpret_cast<double2 *>(region + swz4(base)) = make_double2(a[0], a[1]);
-                *reinterpret_cast<double2 *>(region + swz4(base + 2)) = make_double2(a[2], a[3]);
-            } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) region[swz4(base + k * s)] = a[k];
+            for (int r = 0; r < NR; ++r) {
+                double u = a[r][0], v = a[r][1];
+                a[r][0] = u + v; a[r][1] = tw_mul<FAST>(u - v, twl[i][0].x, twl[i][0].y, m);
+                u = a[r][2]; v = a[r][3];
+                a[r][2] = u + v; a[r][3] = tw_mul<FAST>(u - v, twl[i][1].x, twl[i][1].y, m);
+                u = a[r][0]; v = a[r][2];
+                a[r][0] = u + v; a[r][2] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
+                u = a[r][1]; v = a[r][3];
+                a[r][1] = u + v; a[r][3] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
+                // Degree 256 with raw int32 inputs: a[0] is the only value no multiply has reduced (the sum of four inputs, up
+                // to 2^33; a[1] <= 2^31.1, a[2], a[3] <= 2^30.1).  Folding it once (2 ops) keeps every later operand below
+                // 2^31.1 * 2^6 = 2^37.1, inside the 4-op multiply's 2^38 bound up to and including the final stage -- which
+                // otherwise needs the general 6-op form four times (8 extra ops per lane).
+                if (FAST && i == 0 && 31 + LOGD > 38) a[r][0] = fz_fold(a[r][0], m);
+                double *reg = region + r * 256;
+                if (s == 1) {
+                    *reinterpret_cast<double2 *>(reg + swz4(base)) = make_double2(a[r][0], a[r][1]);
+                    *reinterpret_cast<double2 *>(reg + swz4(base + 2)) = make_double2(a[r][2], a[r][3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) reg[swz4(base + k * s)] = a[r][k];
+                }
             }
         } else {
             // last pass: uniform twiddles itw[2], itw[3], itw[1]; n^-1 folded into the final stage.
             // Its operands are below 2^38 for raw int32 inputs: 2^(31+LOGD) up to degree 128, 2^37.1 at degree 256
             // thanks to the fold after pass 0 -- so the 4-op multiply serves whenever the modulus admits it.
-            constexpr bool LAST4 = FAST;
-            double u = a[0], v = a[1];
-            a[0] = u + v; a[1] = tw_mul<FAST>(u - v, twA.w[2], twA.w2[2], m);
-            u = a[2]; v = a[3];
-            a[2] = u + v; a[3] = tw_mul<FAST>(u - v, twA.w[3], twA.w2[3], m);
-            u = a[0]; v = a[2];
-            a[0] = LAST4 ? fz_mulmod4(u + v, twA.n_inv, twA.n_inv2, m) : fz_mulmod(u + v, twA.n_inv, m);
-            a[2] = LAST4 ? fz_mulmod4(u - v, twA.w1_n_inv, twA.w1_n_inv2, m) : fz_mulmod(u - v, twA.w1_n_inv, m);
-            u = a[1]; v = a[3];
-            a[1] = LAST4 ? fz_mulmod4(u + v, twA.n_inv, twA.n_inv2, m) : fz_mulmod(u + v, twA.n_inv, m);
-            a[3] = LAST4 ? fz_mulmod4(u - v, twA.w1_n_inv, twA.w1_n_inv2, m) : fz_mulmod(u - v, twA.w1_n_inv, m);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                double u = a[r][0], v = a[r][1];
+                a[r][0] = u + v; a[r][1] = tw_mul<FAST>(u - v, twA.w[2], twA.w2[2], m);
+                u = a[r][2]; v = a[r][3];
+                a[r][2] = u + v; a[r][3] = tw_mul<FAST>(u - v, twA.w[3], twA.w2[3], m);
+                u = a[r][0]; v = a[r][2];
+                a[r][0] = tw_mul<FAST>(u + v, twA.n_inv, twA.n_inv2, m);
+                a[r][2] = tw_mul<FAST>(u - v, twA.w1_n_inv, twA.w1_n_inv2, m);
+                u = a[r][1]; v = a[r][3];
+                a[r][1] = tw_mul<FAST>(u + v, twA.n_inv, twA.n_inv2, m);
+                a[r][3] = tw_mul<FAST>(u - v, twA.w1_n_inv, twA.w1_n_inv2, m);
+            }
         }
     }
+}
+
+template <int LOGD, bool FAST>
+__device__ __forceinline__ void inv4_passes(double (&a)[4], double *region, const double2 (&twl)[LOGD / 2 - 1][3],
+                                            const FzTwA &twA, const FzMod &m, int mm) {
+    inv4_passes_n<LOGD, FAST, 1>(reinterpret_cast<double (&)[1][4]>(a), region, twl, twA, m, mm);
 }
 
 template <int LOGD>
@@ -547,54 +570,41 @@ __device__ __forceinline__ void inv4_load_twiddles(double2 (&twl)[LOGD / 2 - 1][
     }
 }
 
-template <int LOGD, bool FAST>
-__global__ __launch_bounds__(64 * kWaves4) void ntt_inv4(const int32_t *in, int32_t *out, size_t batch,
-                                                                const double2 *__restrict__ itw2, FzTwA twA, FzMod m, unsigned tpb) {
+template <int LOGD, bool FAST, int NR, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void ntt_inv4(const int32_t *in, int32_t *out, size_t batch,
+                                                       const double2 *__restrict__ itw2, FzTwA twA, FzMod m) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
-    __shared__ __attribute__((aligned(16))) double lds[kWaves4 * 256];
+    __shared__ __attribute__((aligned(16))) double lds[WAVES * NR * 256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane / LP, mm = lane % LP;
-    double *region = lds + wave * 256 + p * D;
+    double *region = lds + wave * NR * 256 + p * D;
+    const size_t task = (size_t)blockIdx.x * WAVES + wave;      // one task per wave: see ntt_fwd4
+    const size_t poly0 = task * (NR * PPW) + p;
+    if (task * (NR * PPW) >= batch) return;
 
-    // task -> wave mapping: tpb == 0: persistent grid, tasks strided over the whole batch; tpb > 0: workgroup b
-    // owns the contiguous tasks [b*tpb, (b+1)*tpb), its waves interleaved inside (non-persistent launch)
-    const size_t all_tasks = (batch + PPW - 1) / PPW;
-    const size_t first = tpb ? (size_t)blockIdx.x * tpb + wave : (size_t)blockIdx.x * kWaves4 + wave;
-    const size_t stride = tpb ? (size_t)kWaves4 : (size_t)gridDim.x * kWaves4;
-    const size_t tasks = tpb ? (((size_t)blockIdx.x + 1) * tpb < all_tasks ? ((size_t)blockIdx.x + 1) * tpb : all_tasks) : all_tasks;
-    if (first >= tasks) return;
-
-    // per-lane twiddles of passes 0..P-2 (the last pass is wave-uniform)
+    int4 x[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const size_t poly = poly0 + (size_t)r * PPW;
+        x[r] = *reinterpret_cast<const int4 *>(in + (poly < batch ? poly : batch - 1) * D + 4 * mm);
+    }
     double2 twl[P - 1][3];
     inv4_load_twiddles<LOGD>(twl, itw2, mm);
-
-    int4 xn;
-    auto fetch = [&](size_t task) {
-        const size_t poly = task * PPW + p;
-        xn = *reinterpret_cast<const int4 *>(in + (poly < batch ? poly : batch - 1) * D + 4 * mm);
-    };
-    fetch(first);
-    double an[4] = {(double)xn.x, (double)xn.y, (double)xn.z, (double)xn.w};
-    for (size_t task = first; task < tasks; task += stride) {
-        const size_t poly = task * PPW + p;
-        const bool valid = poly < batch;
-        const bool more = task + stride < tasks;
-        double a[4] = {an[0], an[1], an[2], an[3]};
-        if (more) fetch(task + stride);
-        inv4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
-        int o[4];
+    double a[NR][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = (int)fz_cent(a[k], m);
-        if (more) {
-            an[0] = (double)xn.x; an[1] = (double)xn.y; an[2] = (double)xn.z; an[3] = (double)xn.w;
-        }
-        if (valid) {
+    for (int r = 0; r < NR; ++r) {
+        a[r][0] = (double)x[r].x; a[r][1] = (double)x[r].y; a[r][2] = (double)x[r].z; a[r][3] = (double)x[r].w;
+    }
+    inv4_passes_n<LOGD, FAST, NR>(a, region, twl, twA, m, mm);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const size_t poly = poly0 + (size_t)r * PPW;
+        if (poly < batch) {
             int32_t *dst = out + poly * D + mm;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(o[k], dst + k * LP);
+            for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((int)fz_cent(a[r][k], m), dst + k * LP);
         }
-        wave_sync();
     }
 }
 
@@ -754,18 +764,20 @@ __device__ __forceinline__ double fz_imad_total(long long hi, long long lo, bool
     if (small) return fz_fold((double)hi * 65536.0, m) + fz_fold((double)lo, m);
     return fz_fold(fz_cent_i64(hi, m) * 65536.0, m) + fz_cent_i64(lo, m);
 }
-template <int LOGD, bool FAST, bool IMAD>
+// NR: row groups a wave takes through the transform passes together (fwd4_passes_n: one synchronisation per pass for NR rows,
+// NR independent fp64 dependency chains per wave).
+template <int LOGD, bool FAST, bool IMAD, int NR>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_t *A, const int32_t *coef,
                                                                     size_t coef_seg_stride,
                                                                     size_t coef_row_stride, int32_t *sk_hat,
                                                                     int32_t *vk, int l, const double2 *__restrict__ tw2,
                                                                     FzTwA twA, FzMod m) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
-    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256 * 2];
+    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256 * (NR + 1)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane / LP, mm = lane % LP;
-    double *region = lds + wave * 256 + p * D;
-    double *accbuf = lds + kWavesPerBlock * 256;
+    double *region = lds + wave * NR * 256 + p * D;
+    double *accbuf = lds + kWavesPerBlock * NR * 256;
     const size_t seg = blockIdx.x;                      // (key, half)
     coef += seg * coef_seg_stride;                      // row stride 0: one secret polynomial per (key, half), as the
     sk_hat += seg * (size_t)l * D;                      // reference's seeded sampler produces (polynomials.py:436-467)
@@ -776,39 +788,50 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
     double acc[4] = {0, 0, 0, 0};
     long long ihi[4] = {0, 0, 0, 0}, ilo[4] = {0, 0, 0, 0};      // IMAD: exact integer sums of y * hi and y * lo
     const int tasks = (l + PPW - 1) / PPW;
-    int xn[4];
+    constexpr int STEP = kWavesPerBlock * NR;           // a wave's iteration covers tasks t, t + 4, .. (NR of them)
+    int xn[NR][4];
     auto fetch = [&](int task) {
-        const int row = task * PPW + p;
-        const int32_t *src = coef + (size_t)(row < l ? row : l - 1) * coef_row_stride + mm;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xn[k] = src[k * LP];
+        for (int r = 0; r < NR; ++r) {
+            const int row = (task + r * kWavesPerBlock) * PPW + p;
+            const int32_t *src = coef + (size_t)(row < l ? row : l - 1) * coef_row_stride + mm;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xn[r][k] = src[k * LP];
+        }
     };
     if (wave < tasks) fetch(wave);
-    for (int task = wave; task < tasks; task += kWavesPerBlock) {
-        const int row = task * PPW + p;
-        const bool valid = row < l;
-        double a[4];
+    for (int task = wave; task < tasks; task += STEP) {
+        double a[NR][4];
+        int4 ak[NR];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = (double)xn[k];
-        const int4 ak = *reinterpret_cast<const int4 *>(A + (size_t)(valid ? row : l - 1) * D + 4 * mm);
-        if (task + kWavesPerBlock < tasks) fetch(task + kWavesPerBlock);
-        fwd4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
-        const double y0 = fz_cent(a[0], m), y1 = fz_cent(a[1], m), y2 = fz_cent(a[2], m), y3 = fz_cent(a[3], m);
-        if (valid) {
-            const int4 yi = make_int4((int)y0, (int)y1, (int)y2, (int)y3);
-            *reinterpret_cast<int4 *>(sk_hat + (size_t)row * D + 4 * mm) = yi;
-            if constexpr (IMAD) {
-                const int yv[4] = {yi.x, yi.y, yi.z, yi.w}, av[4] = {ak.x, ak.y, ak.z, ak.w};
+        for (int r = 0; r < NR; ++r) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    ihi[k] += (long long)yv[k] * (long long)(av[k] >> 16);
-                    ilo[k] += (long long)yv[k] * (long long)(av[k] & 0xffff);
+            for (int k = 0; k < 4; ++k) a[r][k] = (double)xn[r][k];
+            const int row = (task + r * kWavesPerBlock) * PPW + p;
+            ak[r] = *reinterpret_cast<const int4 *>(A + (size_t)(row < l ? row : l - 1) * D + 4 * mm);
+        }
+        if (task + STEP < tasks) fetch(task + STEP);
+        fwd4_passes_n<LOGD, FAST, NR>(a, region, twl, twA, m, mm);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int row = (task + r * kWavesPerBlock) * PPW + p;
+            const double y0 = fz_cent(a[r][0], m), y1 = fz_cent(a[r][1], m), y2 = fz_cent(a[r][2], m), y3 = fz_cent(a[r][3], m);
+            if (row < l) {
+                const int4 yi = make_int4((int)y0, (int)y1, (int)y2, (int)y3);
+                *reinterpret_cast<int4 *>(sk_hat + (size_t)row * D + 4 * mm) = yi;
+                if constexpr (IMAD) {
+                    const int yv[4] = {yi.x, yi.y, yi.z, yi.w}, av[4] = {ak[r].x, ak[r].y, ak[r].z, ak[r].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        ihi[k] += (long long)yv[k] * (long long)(av[k] >> 16);
+                        ilo[k] += (long long)yv[k] * (long long)(av[k] & 0xffff);
+                    }
+                } else {
+                    acc[0] += fz_mulmod(y0, (double)ak[r].x, m);
+                    acc[1] += fz_mulmod(y1, (double)ak[r].y, m);
+                    acc[2] += fz_mulmod(y2, (double)ak[r].z, m);
+                    acc[3] += fz_mulmod(y3, (double)ak[r].w, m);
                 }
-            } else {
-                acc[0] += fz_mulmod(y0, (double)ak.x, m);
-                acc[1] += fz_mulmod(y1, (double)ak.y, m);
-                acc[2] += fz_mulmod(y2, (double)ak.z, m);
-                acc[3] += fz_mulmod(y3, (double)ak.w, m);
             }
         }
         wave_sync();
@@ -875,7 +898,7 @@ __device__ __forceinline__ int centred_any(int64_t v, const FzMod &m) { return (
 // test needs no centring at all -- the inverse transform's outputs r satisfy |r| <= q/2 + q * 2^-13; if |r| <= beta then r is
 // already the centred residue and passes; if |r| > beta then |cent(r)| >= q - |r| >= q/2 - q * 2^-13 > beta (or cent(r) = r):
 // max |r| > beta <=> max |cent(r)| > beta.  Likewise r == 0 (mod q) <=> r == 0, since |r| < q.  Saves 8 of ~180 ops per row.
-template <int LOGD, bool FAST, typename T, bool ORDERED, bool IMAD>
+template <int LOGD, bool FAST, typename T, bool ORDERED, bool IMAD, int NR>
 __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t *A, const T *sig,
                                                                   size_t sig_stride,
                                                                   const T *target, size_t target_stride, int l, long long beta,
@@ -883,12 +906,12 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
                                                                   FzTwA twA, FzMod m, double *part, int *state, int *verdict) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
     static_assert(D <= 64 * kVerifyWaves, "one thread per coefficient in the combine steps");
-    __shared__ __attribute__((aligned(16))) double lds[kVerifyWaves * 256 * 2];
+    __shared__ __attribute__((aligned(16))) double lds[kVerifyWaves * 256 * (NR + 1)];
     __shared__ int s_flags, s_last;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = lane / LP, mm = lane % LP;
-    double *region = lds + wave * 256 + p * D;
-    double *accbuf = lds + kVerifyWaves * 256;
+    double *region = lds + wave * NR * 256 + p * D;
+    double *accbuf = lds + kVerifyWaves * NR * 256;
     if (threadIdx.x == 0) s_flags = 0;
     const int R = gridDim.x, r = blockIdx.x, g = blockIdx.y;
     sig += (size_t)g * sig_stride;
@@ -908,57 +931,67 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
     // a wave's rows are a sequential chain: the next row (sigma from HBM, A from the L2) is requested before this row's
     // passes start -- unconditionally, clamped to the last task, so that no branch stands between request and use.  Without
     // it a workgroup per aggregate (many aggregates per launch) paid one memory latency per row: 24 % of the HBM peak.
-    Raw4<T> rn;
-    int4 an;
+    // NR row groups per iteration (tasks t, t + step, ..): they go through the inverse passes in lock step (inv4_passes_n)
+    Raw4<T> rn[NR];
+    int4 an[NR];
     auto fetch = [&](int t) {
-        const int row = t * PPW + p;
-        const size_t off = (size_t)(row < l ? row : l - 1) * D + 4 * mm;
-        an = *reinterpret_cast<const int4 *>(A + off);
-        rn.load(sig + off);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int row = (t + j * step) * PPW + p;
+            const size_t off = (size_t)(row < l ? row : l - 1) * D + 4 * mm;
+            an[j] = *reinterpret_cast<const int4 *>(A + off);
+            rn[j].load(sig + off);
+        }
     };
     long long ihi[4] = {0, 0, 0, 0}, ilo[4] = {0, 0, 0, 0};      // IMAD: exact integer sums of sigma * hi and sigma * lo
     int task = r * kVerifyWaves + wave;
     if (task < tasks) fetch(task);
-    for (; task < tasks; task += step) {
-        const int row = task * PPW + p;
-        const bool valid = row < l;
-        const int4 ak = an;
-        double a[4];
-        int si[4];
-        rn.unpack(a, m);
-        if constexpr (IMAD) rn.ints(si, a);
-        fetch(task + step < tasks ? task + step : tasks - 1);
-        if (valid) {
-            if constexpr (IMAD) {
-                const int av[4] = {ak.x, ak.y, ak.z, ak.w};
+    for (; task < tasks; task += NR * step) {
+        double a[NR][4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {       // any int32 sigma, any int32 A: |sigma * hi|, |sigma * lo| < 2^47
-                    ihi[k] += (long long)si[k] * (long long)(av[k] >> 16);
-                    ilo[k] += (long long)si[k] * (long long)(av[k] & 0xffff);
+        for (int j = 0; j < NR; ++j) {
+            const int row = (task + j * step) * PPW + p;
+            const bool valid = row < l;
+            const int4 ak = an[j];
+            int si[4];
+            rn[j].unpack(a[j], m);
+            if constexpr (IMAD) rn[j].ints(si, a[j]);
+            if (valid) {
+                if constexpr (IMAD) {
+                    const int av[4] = {ak.x, ak.y, ak.z, ak.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {       // any int32 sigma, any int32 A: |sigma * hi|, |sigma * lo| < 2^47
+                        ihi[k] += (long long)si[k] * (long long)(av[k] >> 16);
+                        ilo[k] += (long long)si[k] * (long long)(av[k] & 0xffff);
+                    }
+                } else {
+                    acc[0] += fz_mulmod(a[j][0], (double)ak.x, m);
+                    acc[1] += fz_mulmod(a[j][1], (double)ak.y, m);
+                    acc[2] += fz_mulmod(a[j][2], (double)ak.z, m);
+                    acc[3] += fz_mulmod(a[j][3], (double)ak.w, m);
                 }
-            } else {
-                acc[0] += fz_mulmod(a[0], (double)ak.x, m);
-                acc[1] += fz_mulmod(a[1], (double)ak.y, m);
-                acc[2] += fz_mulmod(a[2], (double)ak.z, m);
-                acc[3] += fz_mulmod(a[3], (double)ak.w, m);
             }
         }
-        inv4_passes<LOGD, FAST>(a, region, twl, twA, m, mm);
-        // norm and weight of the row stay in the fp64 lanes (no conversions): a slot past the last row repeats row l - 1, which
+        fetch(task + NR * step < tasks ? task + NR * step : tasks - 1);
+        inv4_passes_n<LOGD, FAST, NR>(a, region, twl, twA, m, mm);
+        // norm and weight of the rows stay in the fp64 lanes (no conversions): a slot past the last row repeats row l - 1, which
         // changes neither the maximum nor any row's weight.  Weight = population count of "non-zero" ballots (scalar unit).
-        if (!lazy) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = fz_cent(a[k], m);          // canonical: zero mod q <=> 0
+        for (int j = 0; j < NR; ++j) {
+            if (!lazy) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[j][k] = fz_cent(a[j][k], m);          // canonical: zero mod q <=> 0
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mx = __builtin_fmax(mx, __builtin_fabs(a[j][k]));
+            if (weigh) {
+                int cnt = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cnt += __popcll(__ballot(a[j][k] != 0.0) & gmask);
+                if ((long long)cnt > omega) wfail = 1;
+            }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) mx = __builtin_fmax(mx, __builtin_fabs(a[k]));
-        if (weigh) {
-            int cnt = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cnt += __popcll(__ballot(a[k] != 0.0) & gmask);
-            if ((long long)cnt > omega) wfail = 1;
-        }
-        wave_sync();      // the next row's first-pass writes must not overtake this row's last reads
+        wave_sync();      // the next rows' first-pass writes must not overtake these rows' last reads
     }
     if constexpr (IMAD) {
         const bool small = tasks <= 32 * step;                    // rows per wave <= 32
@@ -1100,31 +1133,40 @@ int launch16f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool i
     return fz_check_hip(hipGetLastError(), "ntt16 launch");
 }
 
+// rows per wave by batch size: enough waves to fill the chip first (about four per SIMD), then more rows per wave
+template <int LOGD, bool FAST, int NR, int WAVES>
+void launch4n(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse, hipEvent_t e0, hipEvent_t e1) {
+    constexpr int PPW = 64 / ((1 << LOGD) / 4);
+    const size_t tasks = (batch + (size_t)NR * PPW - 1) / ((size_t)NR * PPW);
+    const dim3 grid((unsigned)((tasks + WAVES - 1) / WAVES)), block(64 * WAVES);
+    if (!inverse)
+        hipExtLaunchKernelGGL((ntt_fwd4<LOGD, FAST, NR, WAVES>), grid, block, 0, ctx->stream, e0, e1, 0, in, out, batch,
+                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod);
+    else
+        hipExtLaunchKernelGGL((ntt_inv4<LOGD, FAST, NR, WAVES>), grid, block, 0, ctx->stream, e0, e1, 0, in, out, batch,
+                              (const double2 *)ctx->d_itw2, ctx->itwA, ctx->mod);
+}
+
 template <int LOGD, bool FAST>
 int launch4f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
     constexpr int PPW = 64 / ((1 << LOGD) / 4);
-    const size_t tasks = (batch + PPW - 1) / PPW;
-    const size_t blocks = (tasks + kWaves4 - 1) / kWaves4;
-    const size_t cap = (size_t)(inverse ? ctx->grid_inv4 : ctx->grid_fwd4) * (size_t)ctx->grid_mult;
-    unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
-    unsigned tpb = 0;
-    if (ctx->tasks_per_block > 0 && blocks > cap) {          // more work than one resident wave of blocks: contiguous chunks
-        tpb = (unsigned)ctx->tasks_per_block;
-        grid = (unsigned)((tasks + tpb - 1) / tpb);
-    }
+    const size_t waves1 = (batch + PPW - 1) / PPW;                   // waves at one row group per wave
+    if (waves1 > 0x7fffffffull) return fz_set_error(FZ_E_UNSUPPORTED, "batch too large for the radix-4 schedule");
+    int nr = ctx->knob_ntt_rows;                                      // FZ_NTT_ROWS (benchmarking)
+    if (nr != 1 && nr != 2 && nr != 4) nr = waves1 <= (size_t)24 * ctx->num_cu ? 1 : (waves1 <= (size_t)48 * ctx->num_cu ? 2 : 4);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_on && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen[inverse ? 1 : 0]++ % ctx->prof_every) == 0) {
         e0 = ctx->prof_ev[2 * ctx->prof_n];
         e1 = ctx->prof_ev[2 * ctx->prof_n + 1];
         ctx->prof_kind[ctx->prof_n++] = inverse ? 1 : 0;
     }
-    const dim3 block(64 * kWaves4);
-    if (!inverse)
-        hipExtLaunchKernelGGL((ntt_fwd4<LOGD, FAST>), dim3(grid), block, 0, ctx->stream, e0, e1, 0, in, out, batch,
-                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod, tpb);
-    else
-        hipExtLaunchKernelGGL((ntt_inv4<LOGD, FAST>), dim3(grid), block, 0, ctx->stream, e0, e1, 0, in, out, batch,
-                              (const double2 *)ctx->d_itw2, ctx->itwA, ctx->mod, tpb);
+    if (nr == 1) {
+        if (ctx->knob_ntt_waves == 1) launch4n<LOGD, FAST, 1, 1>(ctx, in, out, batch, inverse, e0, e1);          // FZ_NTT_WAVES (A/B runs)
+        else if (ctx->knob_ntt_waves == 4) launch4n<LOGD, FAST, 1, 4>(ctx, in, out, batch, inverse, e0, e1);
+        else launch4n<LOGD, FAST, 1, 8>(ctx, in, out, batch, inverse, e0, e1);
+    }
+    else if (nr == 2) launch4n<LOGD, FAST, 2, 2>(ctx, in, out, batch, inverse, e0, e1);
+    else launch4n<LOGD, FAST, 4, 2>(ctx, in, out, batch, inverse, e0, e1);
     return fz_check_hip(hipGetLastError(), "ntt4 launch");
 }
 
@@ -1168,25 +1210,8 @@ int query16f(fz_ctx *ctx) {
     return FZ_OK;
 }
 
-template <int LOGD, bool FAST>
-int query4f(fz_ctx *ctx) {
-    int nf = 0, ni = 0;
-    const int threads = 64 * kWaves4;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, ntt_fwd4<LOGD, FAST>, threads, 0);
-    if (e != hipSuccess) return fz_check_hip(e, "occupancy query (fwd4)");
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&ni, ntt_inv4<LOGD, FAST>, threads, 0);
-    if (e != hipSuccess) return fz_check_hip(e, "occupancy query (inv4)");
-    ctx->grid_fwd4 = (nf < 1 ? 1 : nf) * ctx->num_cu;
-    ctx->grid_inv4 = (ni < 1 ? 1 : ni) * ctx->num_cu;
-    return FZ_OK;
-}
-
 template <int LOGD>
 int query16(fz_ctx *ctx) {
-    if constexpr (LOGD == 6 || LOGD == 8) {
-        int rc = ctx->mod.fast ? query4f<LOGD, true>(ctx) : query4f<LOGD, false>(ctx);
-        if (rc != FZ_OK) return rc;
-    }
     return ctx->mod.fast ? query16f<LOGD, true>(ctx) : query16f<LOGD, false>(ctx);
 }
 
@@ -1197,14 +1222,18 @@ int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, i
     const dim3 grid((unsigned)segments), block(64 * kWavesPerBlock);
     const size_t seg_stride = broadcast ? (size_t)ctx->degree : (size_t)l * ctx->degree;
     const size_t row_stride = broadcast ? 0 : (size_t)ctx->degree;
-#define FZ_KF2(LOGD, FAST, IM) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, IM>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \
+    // two row groups per wave iteration: 77.5 -> 75.4 us per 1024 keys on one box, 80.8 -> 80.4 on another (FZ_FUSED_ROWS = 1 | 2 forces)
+    const bool two = ctx->knob_fused_rows != 1;
+#define FZ_KF3(LOGD, FAST, IM, NR) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, IM, NR>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \
                                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod)
+#define FZ_KF2(LOGD, FAST, IM) do { if (two) FZ_KF3(LOGD, FAST, IM, 2); else FZ_KF3(LOGD, FAST, IM, 1); } while (0)
 #define FZ_KF(LOGD, FAST) do { if (!ctx->knob_no_imad) FZ_KF2(LOGD, FAST, true); else FZ_KF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_KF(8, true); else FZ_KF(8, false); }
     else if (ctx->logd == 6) { if (ctx->mod.fast) FZ_KF(6, true); else FZ_KF(6, false); }
     else return fz_set_error(FZ_E_UNSUPPORTED, "fused keygen: degree 64 or 256 only");
 #undef FZ_KF
 #undef FZ_KF2
+#undef FZ_KF3
     return fz_check_hip(hipGetLastError(), "keygen_fused launch");
 }
 
@@ -1228,9 +1257,13 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
     const dim3 grid((unsigned)R, (unsigned)groups), block(64 * kVerifyWaves);
     // the inverse passes leave |r| <= q/2 + q * 2^-13 (4-op multiply) -- see the kernel's header for why no centring is needed then
     const int lazy = (beta >= 0 && (double)beta < 0.5 * ctx->mod.q - ctx->mod.q / 4096.0 && !ctx->knob_verify_cent) ? 1 : 0;
-#define FZ_VF3(LOGD, FAST, ORD, IM) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T, ORD, IM>), grid, block, 0, ctx->stream, A, sig, sig_stride, target, \
+    // one row group per wave iteration unless FZ_FUSED_ROWS=2: two measured 248.5 us against 243.9 per 8192 aggregates (the
+    // kernel is vector-issue bound; the second row costs occupancy and buys no latency hiding it did not already have)
+    const bool two = ctx->knob_fused_rows == 2;
+#define FZ_VF4(LOGD, FAST, ORD, IM, NR) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T, ORD, IM, NR>), grid, block, 0, ctx->stream, A, sig, sig_stride, target, \
                                                    target_stride, l, (long long)beta, (long long)omega, lazy, (const double2 *)ctx->d_itw2, \
                                                    ctx->itwA, ctx->mod, part, state, d_verdict)
+#define FZ_VF3(LOGD, FAST, ORD, IM) do { if (two) FZ_VF4(LOGD, FAST, ORD, IM, 2); else FZ_VF4(LOGD, FAST, ORD, IM, 1); } while (0)
 #define FZ_VF2(LOGD, FAST, ORD) do { if (!ctx->knob_no_imad) FZ_VF3(LOGD, FAST, ORD, true); else FZ_VF3(LOGD, FAST, ORD, false); } while (0)
 #define FZ_VF(LOGD, FAST) do { if (ctx->knob_verify_ordered) FZ_VF2(LOGD, FAST, true); else FZ_VF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_VF(8, true); else FZ_VF(8, false); }
@@ -1238,6 +1271,7 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
 #undef FZ_VF
 #undef FZ_VF2
 #undef FZ_VF3
+#undef FZ_VF4
     rc = fz_check_hip(hipGetLastError(), "verify_fused launch");
     if (rc != FZ_OK) ctx->verify_dirty = 1;          // the accumulators may be left non-zero: re-zeroed before the next launch
     return rc;

@@ -6,9 +6,9 @@ small polynomial matrix-vector products and the fused keygen/sign/aggregate/veri
 top of it.  No CPU fallback exists: without the built library and a gfx950 device every
 compute call raises FusionHipError.
 """
-from ._lib import FusionHipError, LIB_PATH, SIGNATURES, load_library
+from ._lib import FusionHipError, LIB_PATH, SIGNATURES, load_library, runtime_report
 from .context import (Comm, Context, DeviceArray, DeviceBuffer, Graph, VERDICT_REASONS, comm_unique_id, get_context,
                       OP_ADD, OP_MUL, OP_NEG, OP_SUB)
 
 __all__ = ["Comm", "Context", "DeviceArray", "DeviceBuffer", "FusionHipError", "Graph", "LIB_PATH", "SIGNATURES",
-           "VERDICT_REASONS", "comm_unique_id", "get_context", "load_library", "OP_ADD", "OP_MUL", "OP_NEG", "OP_SUB"]
+           "VERDICT_REASONS", "comm_unique_id", "get_context", "load_library", "runtime_report", "OP_ADD", "OP_MUL", "OP_NEG", "OP_SUB"]

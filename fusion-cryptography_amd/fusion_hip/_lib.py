@@ -164,26 +164,71 @@ SIGNATURES.update({
 _lib = None
 
 
+RUNTIME_CHOICE = {"runtime": "system (/opt/rocm)", "why": "default"}      # what load_library() decided, for runtime_report()
+
+
 def _prefer_torch_hip_runtime():
     """A torch wheel carries its own libamdhip64 / libhsa-runtime64 (same sonames as /opt/rocm's) and maps them by path, so
     a process that loaded libfusion_hip.so FIRST (against /opt/rocm) ends up with two HIP runtimes, and the second one
     finds no GPU (`import fusion_hip; ...; import torch; torch.cuda...` -> "No HIP GPUs are available").  If torch is
     installed but not imported yet, map ITS copies first: libfusion_hip.so then binds to them by soname and a later
-    `import torch` finds its runtime already alive.  FZ_HIP_RUNTIME=system keeps /opt/rocm's (no torch in the process)."""
-    if "torch" in sys.modules or os.environ.get("FZ_HIP_RUNTIME", "") == "system":
+    `import torch` finds its runtime already alive.
+    The wheel's runtime is only accepted when its HIP MAJOR version equals the one the library was built with
+    (lib/build_info.json, written by the build): it is opened privately first, asked for hipRuntimeGetVersion, and promoted
+    to the global namespace only then; on a mismatch (or FZ_HIP_RUNTIME=system) the system runtime serves the library and
+    torch users must import torch first.  fusion_hip.runtime_report() says what happened."""
+    if os.environ.get("FZ_HIP_RUNTIME", "") == "system":
+        RUNTIME_CHOICE.update(runtime="system (/opt/rocm)", why="FZ_HIP_RUNTIME=system")
+        return
+    if "torch" in sys.modules:
+        RUNTIME_CHOICE.update(runtime="torch's (already imported)", why="torch was imported before fusion_hip")
         return
     try:
         import importlib.util
+        import json
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.origin:
             return
         d = os.path.join(os.path.dirname(spec.origin), "lib")
-        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
-            f = os.path.join(d, name)
-            if os.path.exists(f):
-                ctypes.CDLL(f, mode=ctypes.RTLD_GLOBAL)
-    except Exception:      # noqa: BLE001 - any failure here leaves the system runtime, which is the default anyway
+        hip = os.path.join(d, "libamdhip64.so")
+        hsa = os.path.join(d, "libhsa-runtime64.so")
+        if not os.path.exists(hip):
+            return
+        want = None
+        info = os.path.join(os.path.dirname(LIB_PATH), "build_info.json")
+        if os.path.exists(info):
+            with open(info) as fh:
+                want = json.load(fh).get("hip_major")
+        if os.path.exists(hsa):
+            ctypes.CDLL(hsa, mode=ctypes.RTLD_GLOBAL)
+        probe = ctypes.CDLL(hip)                                    # private first: ask before it serves anybody
+        v = ctypes.c_int(0)
+        got = None
+        if probe.hipRuntimeGetVersion(ctypes.byref(v)) == 0:
+            got = v.value // 10_000_000
+        if want is not None and got is not None and want != got:
+            RUNTIME_CHOICE.update(runtime="system (/opt/rocm)",
+                                  why=f"torch's HIP runtime is major version {got}, the library was built with {want}: not used")
+            import warnings
+            warnings.warn(f"fusion_hip: torch ships HIP {got}.x but libfusion_hip.so was built with HIP {want}.x; keeping the system "
+                          "runtime -- import torch BEFORE fusion_hip in processes that use both", RuntimeWarning)
+            return
+        ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)                   # promote: libfusion_hip.so binds to it by soname
+        RUNTIME_CHOICE.update(runtime=hip, why=f"torch is installed (HIP major {got}, built with {want}): its runtime is mapped first "
+                                               "so that a later `import torch` shares it")
+    except Exception as e:      # noqa: BLE001 - any failure here leaves the system runtime, which is the default anyway
+        RUNTIME_CHOICE.update(runtime="system (/opt/rocm)", why=f"probing torch's runtime failed: {e!r}")
+
+
+def runtime_report():
+    """-> dict: which HIP runtime serves libfusion_hip.so in this process and why (paths of the mapped libamdhip64 copies)"""
+    maps = []
+    try:
+        with open("/proc/self/maps") as fh:
+            maps = sorted({ln.split()[-1] for ln in fh if "libamdhip64" in ln})
+    except OSError:
         pass
+    return dict(RUNTIME_CHOICE, mapped_libamdhip64=maps)
 
 
 def load_library(path=None):

@@ -56,6 +56,11 @@ class BatchScheme:
         are pinned against `random` in the tests.
         Unlike the reference this does not leave the process-global `random` generator re-seeded."""
         p = self.params
+        # random.seed(int) uses abs(seed), so negative seeds are legal in the reference; the C / device samplers take the
+        # non-negative seeds below 2^64 - 1
+        # (keygen seeds the right half with seed + 1: for a negative seed that is abs(seed) - 1, not abs(seed) + 1)
+        if any(int(s) < 0 or int(s) >= 2 ** 64 - 1 for s in seeds):
+            return self._keygen_batch_python_sampler(seeds, device, keep_vk)
         sd = np.array([int(s) for s in seeds], dtype=np.uint64)
         n = sd.size
         # the reference's sampler yields ONE polynomial per (key, half) for all l rows (same seed for every matrix
@@ -80,6 +85,37 @@ class BatchScheme:
         vk = DeviceArray(self.ctx, (n, 2, self.d))
         try:
             self.ctx.keygen_core_bcast_dev(dA.ptr, coef.ptr, sk.ptr, vk.ptr, n, self.l)
+            vk_host = vk.numpy()
+            res_sk = sk
+            if not device:
+                res_sk = sk.numpy()
+                sk.free()
+            if keep_vk:
+                keep, vk = vk, None
+                return res_sk, vk_host, keep
+            return res_sk, vk_host
+        finally:
+            for b in (coef, vk):
+                if b is not None:
+                    b.free()
+
+    def _keygen_batch_python_sampler(self, seeds, device, keep_vk):
+        """keygen_batch for seeds the C / device MT19937 clones do not take (negative seeds, where seed + 1 is not
+        abs(seed) + 1, and seeds >= 2^64 - 1, whose keys have more words than the clones' two): the secret polynomials come
+        from the drop-in's own sampler, i.e. CPython's `random` exactly as the reference drives it (polynomials.py:436-467);
+        everything after the sampling is the same device path."""
+        from algebra.polynomials import sample_polynomial_coefficient_representation as sample
+        p = self.params
+        polys = np.empty((len(seeds), 2, self.d), dtype=np.int32)
+        for i, s in enumerate(seeds):
+            for h in (0, 1):
+                polys[i, h] = sample(modulus=p.modulus, degree=p.degree, root_order=p.root_order, root=p.root, inv_root=p.inv_root,
+                                     norm_bound=p.beta_sk, weight_bound=p.omega_sk, seed=int(s) + h).coefficients
+        n = len(seeds)
+        coef = DeviceArray.from_numpy(self.ctx, polys)
+        sk, vk = DeviceArray(self.ctx, (n, 2, self.l, self.d)), DeviceArray(self.ctx, (n, 2, self.d))
+        try:
+            self.ctx.keygen_core_bcast_dev(self._A_dev().ptr, coef.ptr, sk.ptr, vk.ptr, n, self.l)
             vk_host = vk.numpy()
             res_sk = sk
             if not device:

@@ -105,3 +105,23 @@ def test_large_batch_more_waves_than_cus():
         assert np.array_equal(dout.to_numpy(np.int32, (n, 2, 256)), hostpipe.sample_secret_polys(seeds, P["q"], 256, 52, 256))
     finally:
         dout.free()
+
+
+def test_keygen_batch_takes_every_seed_the_reference_takes():
+    """negative seeds (random.seed uses abs(); the right half is seeded with seed + 1 = abs(seed) - 1) and seeds of 2^64 - 1 and
+    beyond (three-word MT19937 keys) go through CPython's `random` itself; results equal the object API's keygen"""
+    import fusion.fusion as F
+    from fusion_hip.scheme import BatchScheme, signature_from_object
+    params = F.fusion_setup(128, 3)
+    bs = BatchScheme(params, threads=2)
+    seeds = [-1, -12345, 2 ** 64 - 1, 2 ** 64, 2 ** 70 + 5, 7]
+    sk, vk = bs.keygen_batch(seeds)
+    for i, s in enumerate(seeds):
+        sk_o, vk_o = F.keygen(params, s)
+        assert np.array_equal(vk[i, 0], np.array(vk_o.left_vk_hat.matrix[0][0].values)), s
+        assert np.array_equal(vk[i, 1], np.array(vk_o.right_vk_hat.matrix[0][0].values)), s
+        assert np.array_equal(sk[i, 0], signature_from_object(params, F.Signature(signature_hat=sk_o.left_sk_hat))), s
+    from fusion_hip import hostpipe
+    from fusion_hip._lib import FusionHipError
+    with pytest.raises(FusionHipError):
+        hostpipe.sample_secret_polys(np.array([2 ** 64 - 1], dtype=np.uint64), params.modulus, params.degree, 52, params.degree)

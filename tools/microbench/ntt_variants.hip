@@ -1,9 +1,10 @@
 // ntt_variants.hip -- A/B harness for the headline launch (BASELINE configs[1]: 4096 rows of degree 256, forward transform).
 //
-// The library's radix-4 forward kernel (ntt_fwd4<8>) gives every row its own one-wave workgroup: 4096 workgroups, each of
-// which loads nine per-lane (w, w * K/q) twiddle pairs (9 KiB through the vector-memory path for 1 KiB of data), computes its
-// LDS offsets, transforms ONE row and leaves.  This harness times variants of that schedule in one process, back to back, each
-// checked bit for bit against the library kernel's output:
+// Round 2's radix-4 forward kernel gave every row its own one-wave workgroup inside a persistent loop: 4096 workgroups, each
+// loading nine per-lane (w, w * K/q) twiddle pairs (9 KiB through the vector-memory path for 1 KiB of data), computing its LDS
+// offsets, transforming ONE row and leaving.  This harness timed variants of that schedule in one process, back to back, each
+// checked bit for bit against the library kernel's output (profiles/r03_ntt_variants.txt, measured against round 2's kernel);
+// the library's ntt_fwd4<LOGD, FAST, NR, WAVES> is what came out of it, and is now the reference line here:
 //   NR     rows per wave (1 / 2 / 4): twiddle loads, index arithmetic and the wave's start-up amortise over NR rows, and the NR
 //          independent rows give one wave instruction-level parallelism across the dependent fp64 chains;
 //   WAVES  waves per workgroup (1 / 4 / 8 / 16);
@@ -11,7 +12,7 @@
 // plus the same-process floors: an empty dispatch of each grid shape and a plain 4 MiB -> 4 MiB copy.
 //
 // It compiles the library's own kernel source into this translation unit (the kernels live in an anonymous namespace), so
-// the baseline IS the shipped kernel.  usage: ntt_variants [rows=4096] [reps=400]
+// the baseline IS the shipped kernel.  usage: ntt_variants [reps=300]   (sweeps 2^12 .. 2^18 rows, warm and cold)
 #include "../../fusion-cryptography_amd/csrc/fz_ntt.hip"
 
 #include <cstdarg>
@@ -56,14 +57,8 @@ __global__ __launch_bounds__(64 * WAVES) void fwd4_variant(const int32_t *in, in
         }
     }
     double2 twl[P - 1][3];
-    if (TW == 0) {
-        fwd4_load_twiddles<LOGD>(twl, tw2, mm);
-    } else {
-        // the (w, w2) table, 256 entries of 16 bytes, staged once per workgroup: 4 coalesced 16-byte loads per lane of wave 0
-        // ... spread over all waves of the workgroup
-        double2 *s_tw = reinterpret_cast<double2 *>(lds + WAVES * NR * 256);
-        for (int i = threadIdx.x; i < 256; i += 64 * WAVES) s_tw[i] = tw2[i];
-        if (WAVES == 1) wave_sync(); else __syncthreads();
+    double2 *s_tw = reinterpret_cast<double2 *>(lds + WAVES * NR * 256);
+    auto read_table = [&]() {
 #pragma unroll
         for (int i = 1; i < P; ++i) {
             const int s = D >> (2 * i + 2), g = mm / s, pw = 1 << (2 * i);
@@ -71,14 +66,24 @@ __global__ __launch_bounds__(64 * WAVES) void fwd4_variant(const int32_t *in, in
             twl[i - 1][1] = s_tw[2 * pw + 2 * g];
             twl[i - 1][2] = s_tw[2 * pw + 2 * g + 1];
         }
+    };
+    if (TW == 0) {
+        fwd4_load_twiddles<LOGD>(twl, tw2, mm);
+    } else {
+        // the (w, w2) table, 256 entries of 16 bytes, staged once per workgroup, the loads spread over its waves
+        for (int i = threadIdx.x; i < 256; i += 64 * WAVES) s_tw[i] = tw2[i];
+        if (TW == 1) {
+            if (WAVES == 1) wave_sync(); else __syncthreads();
+            read_table();
+        }
     }
-    if (!active) return;
+    if (TW != 2 && !active) return;
 
     double a[NR][4];
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a[r][k] = (double)x[r][k];
+        for (int k = 0; k < 4; ++k) a[r][k] = active ? (double)x[r][k] : 0.0;
 
     // the four passes, all NR rows in lock step (one wave-local synchronisation per pass, not per row)
 #pragma unroll
@@ -89,6 +94,10 @@ __global__ __launch_bounds__(64 * WAVES) void fwd4_variant(const int32_t *in, in
         if (i == 0) {
             wA = twA.w[1]; wA2 = twA.w2[1]; wB0 = twA.w[2]; wB02 = twA.w2[2]; wB1 = twA.w[3]; wB12 = twA.w2[3];
         } else {
+            if (TW == 2 && i == 1) {                 // pass 0 needed only the uniform twiddles: the table is published behind it
+                if (WAVES == 1) wave_sync(); else __syncthreads();
+                read_table();
+            }
             wA = twl[i - 1][0].x; wA2 = twl[i - 1][0].y;
             wB0 = twl[i - 1][1].x; wB02 = twl[i - 1][1].y;
             wB1 = twl[i - 1][2].x; wB12 = twl[i - 1][2].y;
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(64 * WAVES) void fwd4_variant(const int32_t *in, in
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const size_t row = task * NR + r;
-        if (row < batch)
+        if (active && row < batch)
             nt_store4(out + row * D + 4 * mm, make_int4((int)fz_cent(a[r][0], m), (int)fz_cent(a[r][1], m), (int)fz_cent(a[r][2], m),
                                                          (int)fz_cent(a[r][3], m)));
     }
@@ -168,80 +177,147 @@ static double time_us(F launch, int reps, hipStream_t st, Timer &t) {
     return best;
 }
 
+// the same launch timed the way rocprofv3 --kernel-trace (and bench.py's roofline.achieved) sees it: begin / end events bound to
+// EVERY dispatch (hipExtLaunchKernelGGL), so each dispatch owns a completion signal and runs serialised; mean of `n` launches
+template <typename F>
+static double isolated_us(F launch_with_events, int n, hipStream_t st) {
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto &e : ev) (void)hipEventCreate(&e);
+    for (int i = 0; i < 30; ++i) launch_with_events(ev[0], ev[1]);
+    (void)hipStreamSynchronize(st);
+    for (int i = 0; i < n; ++i) launch_with_events(ev[2 * i], ev[2 * i + 1]);
+    (void)hipStreamSynchronize(st);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) { float ms = 0; (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]); sum += ms * 1e3; }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return sum / n;
+}
+
 int main(int argc, char **argv) {
-    const size_t B = argc > 1 ? (size_t)atoll(argv[1]) : 4096;
-    const int reps = argc > 2 ? atoi(argv[2]) : 400;
+    const int reps_arg = argc > 1 ? atoi(argv[1]) : 300;
     const uint32_t q = 2147465729u, root = 3337519u;
     const int n = 256, k = 8;
     FzMod mod = fz_make_mod(q);
-    std::vector<double> pairs(2 * n);
+    std::vector<double> pairs(2 * n), tw(n);
     FzTwA twA;
     memset(&twA, 0, sizeof(twA));
     for (int i = 0; i < n; ++i) {
         const double w = (double)powmod(root, brev((unsigned)i, k), q);
+        tw[i] = w;
         pairs[2 * i] = w;
         pairs[2 * i + 1] = w * mod.kq;
         if (i < 16) { twA.w[i] = w; twA.w2[i] = w * mod.kq; }
     }
-    double *d_tw2;
+    double *d_tw2, *d_twB;
     CHECK(hipMalloc((void **)&d_tw2, sizeof(double) * 2 * n));
     CHECK(hipMemcpy(d_tw2, pairs.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice));
-    std::vector<int32_t> h(B * n);
-    uint64_t z = 20261003;
-    for (auto &v : h) { z = z * 6364136223846793005ull + 1442695040888963407ull; v = (int32_t)((int64_t)((z >> 33) % q) - (int64_t)(q / 2)); }
-    int32_t *d_in, *d_ref, *d_out;
-    CHECK(hipMalloc((void **)&d_in, B * n * 4));
-    CHECK(hipMalloc((void **)&d_ref, B * n * 4));
-    CHECK(hipMalloc((void **)&d_out, B * n * 4));
-    CHECK(hipMemcpy(d_in, h.data(), B * n * 4, hipMemcpyHostToDevice));
+    {   // per-lane table of the 16-per-lane kernel's contiguous pass (as fz_ctx_create builds it)
+        const int L = n / 16, SB = k - 4, NE = 16 - (16 >> SB);
+        std::vector<double> twB((size_t)NE * L * 2);
+        for (int ls = 0; ls < SB; ++ls) {
+            const int t = 1 << (SB - 1 - ls), ng = 16 / (2 * t), ebase = (16 >> SB) * ((1 << ls) - 1);
+            for (int g = 0; g < ng; ++g)
+                for (int b = 0; b < L; ++b) {
+                    const double w = tw[(16 << ls) + b * ng + g];
+                    twB[((size_t)(ebase + g) * L + b) * 2] = w;
+                    twB[((size_t)(ebase + g) * L + b) * 2 + 1] = w * mod.kq;
+                }
+        }
+        CHECK(hipMalloc((void **)&d_twB, twB.size() * sizeof(double)));
+        CHECK(hipMemcpy(d_twB, twB.data(), twB.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    int occ16 = 0;
+    CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, ntt_fwd16<8, true>, 256, 0));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const size_t POOL = 3ull << 29;                       // 1.5 GiB of inputs and as much of outputs: rotating operand sets
+    int32_t *pool_in, *pool_out, *d_ref;
+    CHECK(hipMalloc((void **)&pool_in, POOL));
+    CHECK(hipMalloc((void **)&pool_out, POOL));
+    {
+        std::vector<int32_t> h(POOL / 4 / 64);
+        uint64_t z = 20261003;
+        for (auto &v : h) { z = z * 6364136223846793005ull + 1442695040888963407ull; v = (int32_t)((int64_t)((z >> 33) % q) - (int64_t)(q / 2)); }
+        for (int c = 0; c < 64; ++c) CHECK(hipMemcpy((char *)pool_in + c * (POOL / 64), h.data(), POOL / 64, hipMemcpyHostToDevice));
+    }
     hipStream_t st;
     CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     Timer t;
-    const double bytes = 2048.0 * B;
-    printf("# forward NTT, %zu rows of degree 256 (%.1f MiB in + out), back-to-back dependent launches, best of 3 passes of %d\n", B,
-           bytes / 1048576.0, reps);
-
-    // baseline: the library kernel exactly as fz_ntt_forward launches it below 2^16 rows
-    auto base = [&]() { hipLaunchKernelGGL((ntt_fwd4<8, true>), dim3((unsigned)B), dim3(64), 0, st, (const int32_t *)d_in, d_ref, B,
-                                           (const double2 *)d_tw2, twA, mod, 0u); };
-    base();
-    CHECK(hipStreamSynchronize(st));
-    std::vector<int32_t> ref(B * n), got(B * n);
-    CHECK(hipMemcpy(ref.data(), d_ref, B * n * 4, hipMemcpyDeviceToHost));
-    const double t_base = time_us(base, reps, st, t);
-    printf("%-44s grid %5zu x %4d  %7.3f us  %5.1f %% of 8 TB/s\n", "library ntt_fwd4<8> (NR=1 WAVES=1 TW=global)", B, 64, t_base,
-           bytes / (t_base * 1e-6) / 8e12 * 100);
-
     int bad = 0;
+    for (int cold = 0; cold < 2; ++cold)
+    for (size_t B : {(size_t)4096, (size_t)8192, (size_t)16384, (size_t)32768, (size_t)65536, (size_t)262144}) {
+        if (argc > 2 && B > (size_t)atoll(argv[2])) continue;
+        if (!cold && B > 16384) continue;
+        const size_t rowbytes = B * n * 4;
+        const size_t sets = cold ? POOL / rowbytes : 1;
+        const int reps = B >= 65536 ? reps_arg / 4 : reps_arg;
+        const double bytes = 2048.0 * B;
+        size_t kk = 0;
+        auto in_ptr = [&]() { return (const int32_t *)((char *)pool_in + (kk % sets) * rowbytes); };
+        auto out_ptr = [&]() { return (int32_t *)((char *)pool_out + (kk++ % sets) * rowbytes); };
+        printf("# forward NTT, %zu rows of degree 256 (%.0f MiB in + out), %s, back-to-back launches, best of 3 passes of %d\n", B,
+               bytes / 1048576.0, cold ? "COLD (operand sets rotate through 1.5 GiB pools)" : "warm (one operand set)", reps);
+        CHECK(hipMalloc((void **)&d_ref, rowbytes));
+        std::vector<int32_t> ref(B * n), got(B * n);
+        {   // reference: the library kernels as fz_ntt_forward launches them
+            hipLaunchKernelGGL((ntt_fwd4<8, true, 1, 8>), dim3((unsigned)((B + 7) / 8)), dim3(512), 0, st, (const int32_t *)pool_in, d_ref, B, (const double2 *)d_tw2, twA, mod);
+            CHECK(hipStreamSynchronize(st));
+            CHECK(hipMemcpy(ref.data(), d_ref, rowbytes, hipMemcpyDeviceToHost));
+            auto base = [&]() { const int32_t *i_ = in_ptr(); hipLaunchKernelGGL((ntt_fwd4<8, true, 1, 8>), dim3((unsigned)((B + 7) / 8)), dim3(512), 0, st, i_, out_ptr(), B,
+                                                   (const double2 *)d_tw2, twA, mod); };
+            const double us = time_us(base, reps, st, t);
+            printf("%-44s grid %6zu x %4d  %8.3f us  %5.1f %% of 8 TB/s\n", "library ntt_fwd4<8, NR=1, WAVES=8>", (B + 7) / 8, 512, us,
+                   bytes / (us * 1e-6) / 8e12 * 100);
+            const size_t tasks16 = (B * n + 1023) / 1024, blocks16 = (tasks16 + 3) / 4, cap16 = (size_t)occ16 * prop.multiProcessorCount;
+            const unsigned g16 = (unsigned)(blocks16 < cap16 ? blocks16 : cap16);
+            auto b16 = [&]() { const int32_t *i_ = in_ptr(); hipLaunchKernelGGL((ntt_fwd16<8, true>), dim3(g16), dim3(256), 0, st, i_, out_ptr(), B,
+                                                   (const double2 *)d_twB, twA, mod); };
+            const double us16 = time_us(b16, reps, st, t);
+            printf("%-44s grid %6u x %4d  %8.3f us  %5.1f %% of 8 TB/s\n", "library ntt_fwd16<8> (16 per lane, persistent)", g16, 256, us16,
+                   bytes / (us16 * 1e-6) / 8e12 * 100);
+        }
 #define VARIANT(NR, WAVES, TW)                                                                                                  \
-    {                                                                                                                           \
-        const size_t tasks = (B + NR - 1) / NR;                                                                                 \
-        const unsigned grid = (unsigned)((tasks + WAVES - 1) / WAVES);                                                          \
-        auto f = [&]() { hipLaunchKernelGGL((fwd4_variant<NR, WAVES, TW, true>), dim3(grid), dim3(64 * WAVES), 0, st,           \
-                                            (const int32_t *)d_in, d_out, B, (const double2 *)d_tw2, twA, mod); };              \
-        CHECK(hipMemsetAsync(d_out, 0, B * n * 4, st));                                                                         \
-        f();                                                                                                                    \
-        CHECK(hipStreamSynchronize(st));                                                                                        \
-        CHECK(hipMemcpy(got.data(), d_out, B * n * 4, hipMemcpyDeviceToHost));                                                  \
-        const bool ok = memcmp(got.data(), ref.data(), B * n * 4) == 0;                                                         \
-        if (!ok) ++bad;                                                                                                         \
-        const double us = time_us(f, reps, st, t);                                                                              \
-        auto e = [&]() { hipLaunchKernelGGL(empty_kernel, dim3(grid), dim3(64 * WAVES), 0, st); };                              \
-        const double ue = time_us(e, reps, st, t);                                                                              \
-        char name[64];                                                                                                          \
-        snprintf(name, sizeof(name), "NR=%d WAVES=%-2d TW=%s", NR, WAVES, TW ? "lds" : "global");                               \
-        printf("%-44s grid %5u x %4d  %7.3f us  %5.1f %% of 8 TB/s   empty grid %6.3f us   %s\n", name, grid, 64 * WAVES, us, \
-               bytes / (us * 1e-6) / 8e12 * 100, ue, ok ? "bit-exact" : "MISMATCH");                                            \
-    }
-    VARIANT(1, 1, 0) VARIANT(1, 1, 1) VARIANT(1, 4, 0) VARIANT(1, 4, 1) VARIANT(1, 8, 1) VARIANT(1, 16, 1)
-    VARIANT(2, 1, 0) VARIANT(2, 1, 1) VARIANT(2, 4, 0) VARIANT(2, 4, 1) VARIANT(2, 8, 1)
-    VARIANT(4, 1, 0) VARIANT(4, 1, 1) VARIANT(4, 4, 0) VARIANT(4, 4, 1) VARIANT(4, 2, 0)
-    {
-        const size_t n16 = B * n * 4 / 16;
-        auto c = [&]() { hipLaunchKernelGGL(diag_copy_kernel, dim3((unsigned)((n16 + 63) / 64)), dim3(64), 0, st, (const int4 *)d_in, (int4 *)d_out, n16); };
-        const double us = time_us(c, reps, st, t);
-        printf("%-44s grid %5zu x %4d  %7.3f us  %5.1f %% of 8 TB/s\n", "plain copy of the same bytes (16 B per lane)", (n16 + 63) / 64, 64, us,
-               bytes / (us * 1e-6) / 8e12 * 100);
+        {                                                                                                                       \
+            const size_t tasks = (B + NR - 1) / NR;                                                                             \
+            const unsigned grid = (unsigned)((tasks + WAVES - 1) / WAVES);                                                      \
+            auto f = [&]() { const int32_t *i_ = in_ptr(); hipLaunchKernelGGL((fwd4_variant<NR, WAVES, TW, true>), dim3(grid), dim3(64 * WAVES), 0, st, \
+                                                i_, out_ptr(), B, (const double2 *)d_tw2, twA, mod); };                         \
+            hipLaunchKernelGGL((fwd4_variant<NR, WAVES, TW, true>), dim3(grid), dim3(64 * WAVES), 0, st, (const int32_t *)pool_in, d_ref, B, \
+                               (const double2 *)d_tw2, twA, mod);                                                               \
+            CHECK(hipStreamSynchronize(st));                                                                                    \
+            CHECK(hipMemcpy(got.data(), d_ref, rowbytes, hipMemcpyDeviceToHost));                                               \
+            const bool ok = memcmp(got.data(), ref.data(), rowbytes) == 0;                                                      \
+            if (!ok) ++bad;                                                                                                     \
+            const double us = time_us(f, reps, st, t);                                                                          \
+            auto fe = [&](hipEvent_t e0, hipEvent_t e1) { const int32_t *i_ = in_ptr(); hipExtLaunchKernelGGL((fwd4_variant<NR, WAVES, TW, true>), \
+                        dim3(grid), dim3(64 * WAVES), 0, st, e0, e1, 0, i_, out_ptr(), B, (const double2 *)d_tw2, twA, mod); }; \
+            const double iso = isolated_us(fe, 200, st);                                                                        \
+            char name[64];                                                                                                      \
+            snprintf(name, sizeof(name), "NR=%d WAVES=%-2d TW=%s", NR, WAVES, TW == 0 ? "global" : TW == 1 ? "lds" : "lds, barrier after pass 0"); \
+            printf("%-44s grid %6u x %4d  %8.3f us  %5.1f %% of 8 TB/s   per-dispatch events %7.3f us  %5.1f %%   %s\n", name, grid, 64 * WAVES, us, \
+                   bytes / (us * 1e-6) / 8e12 * 100, iso, bytes / (iso * 1e-6) / 8e12 * 100, ok ? "bit-exact" : "MISMATCH");    \
+        }
+        VARIANT(1, 1, 0) VARIANT(1, 4, 0) VARIANT(1, 8, 0) VARIANT(1, 8, 1) VARIANT(1, 8, 2) VARIANT(1, 16, 2)
+        VARIANT(2, 2, 0) VARIANT(2, 4, 0) VARIANT(2, 8, 2)
+        VARIANT(4, 2, 0) VARIANT(4, 4, 0) VARIANT(4, 4, 2) VARIANT(4, 8, 0)
+        VARIANT(8, 1, 0) VARIANT(8, 2, 0) VARIANT(8, 4, 0)
+        {
+            const size_t n16 = rowbytes / 16;
+            auto c = [&]() { const int32_t *i_ = in_ptr(); hipLaunchKernelGGL(diag_copy_kernel, dim3((unsigned)((n16 + 63) / 64)), dim3(64), 0, st, (const int4 *)i_, (int4 *)out_ptr(), n16); };
+            const double us = time_us(c, reps, st, t);
+            auto ce = [&](hipEvent_t e0, hipEvent_t e1) { const int32_t *i_ = in_ptr(); hipExtLaunchKernelGGL(diag_copy_kernel, dim3((unsigned)((n16 + 63) / 64)), dim3(64), 0, st, e0, e1, 0, (const int4 *)i_, (int4 *)out_ptr(), n16); };
+            const double iso = isolated_us(ce, 200, st);
+            printf("%-44s grid %6zu x %4d  %8.3f us  %5.1f %% of 8 TB/s   per-dispatch events %7.3f us  %5.1f %%\n", "plain copy of the same bytes (16 B per lane)", (n16 + 63) / 64, 64, us,
+                   bytes / (us * 1e-6) / 8e12 * 100, iso, bytes / (iso * 1e-6) / 8e12 * 100);
+            for (int wv : {1, 4, 8}) {
+                const unsigned grid = (unsigned)((B + wv - 1) / wv);
+                auto e = [&]() { hipLaunchKernelGGL(empty_kernel, dim3(grid), dim3(64 * wv), 0, st); };
+                auto ee = [&](hipEvent_t e0, hipEvent_t e1) { hipExtLaunchKernelGGL(empty_kernel, dim3(grid), dim3(64 * wv), 0, st, e0, e1, 0); };
+                printf("empty dispatch, %u workgroups of %d threads: %.3f us back to back, %.3f us per-dispatch events\n", grid, 64 * wv, time_us(e, reps, st, t),
+                       isolated_us(ee, 200, st));
+            }
+        }
+        CHECK(hipFree(d_ref));
     }
     printf(bad ? "# %d variant(s) MISMATCHED\n" : "# all variants bit-exact against the library kernel\n", bad);
     return bad ? 2 : 0;

@@ -472,16 +472,39 @@ def main():
     stage = ["copy_floor"]
     done = threading.Event()
 
+    def target_block():
+        """north_star asks for >= 40 % of the HBM roofline on batched degree-256 NTT: from which batch size the COLD per-kernel
+        table of this run meets it, and what a single dispatch of the headline's byte count can reach at all (a plain copy of the
+        same 4 MiB in / 4 MiB out, same run)"""
+        met = None
+        try:
+            rows = sorted((int(k.split("2^")[1]), v["frac"]) for k, v in (kernels or {}).items()
+                          if k.startswith("ntt_forward B=2^") and isinstance(v, dict))
+            for logb, frac in rows:
+                if frac >= 0.40:
+                    met = 1 << logb
+                    break
+        except Exception:
+            pass
+        return {"asked": 0.40, "met_from_rows": met,
+                "met_with_batches_per_dispatch": next((int(k.split("x")[0]) for k, v in (multi or {}).items()
+                                                       if isinstance(v, dict) and "fwd" in v and v["fwd"]["frac"] >= 0.40), None),
+                "single_dispatch_ceiling": (floor or {}).get("copy_frac"),
+                "what": "met_from_rows: smallest batch of the cold kernel table (2^12, 2^14, 2^16, 2^18 rows) whose forward transform reaches "
+                        "40 % of 8 TB/s; met_with_batches_per_dispatch: batches of 4096 rows per fz_ntt_multi dispatch that reach it (warm); "
+                        "single_dispatch_ceiling: the fraction a plain copy of the headline's bytes reaches in this run -- no kernel of "
+                        "that byte count can do better, an EMPTY dispatch already costs 1.5-1.9 us (profiles/r03_ntt_variants_per_dispatch.txt)"}
+
     def build_line(watchdog=None):
         # HBM-side traffic of this launch from the PMC counters (rocprofv3 --pmc, separate passes; FETCH_SIZE corrected x2
         # for gfx950) cannot be collected live: the committed measurement of THIS round's kernel is reported, or null
-        traffic, traffic_note = None, "no PMC file for this kernel under profiles/ (tools/collect_profiles.sh writes r02_pmc_ntt.json)"
+        traffic, traffic_note = None, "no PMC file for this kernel under profiles/ (tools/collect_profiles.sh writes r03_pmc_ntt.json)"
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_ntt.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_ntt.json")) as fh:
                 kernels_pmc = json.load(fh)["kernels"]
             key = next(k for k in kernels_pmc if k.startswith("ntt_fwd4<8") and "B=4096" in k)
             traffic = kernels_pmc[key]["traffic_bytes_per_launch"]
-            traffic_note = "profiles/r02_pmc_ntt.json (PMC pass of the same launch, committed this round)"
+            traffic_note = "profiles/r03_pmc_ntt.json (PMC pass of the same launch, committed this round)"
         except Exception:
             pass
         fwd_bytes = 8.0 * d * B
@@ -498,7 +521,7 @@ def main():
                        "prewarm_ms": args.prewarm_ms,
                        "host_threads_on": placement or "all allowed CPUs (no GPU-local NUMA node found, or FZ_NO_PIN=1)"},
             "ranks": ranks,
-            "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8> (forward NTT, B=4096)", "achieved": ach,
+            "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8, true, 1, 8> (forward NTT, B=4096: one row per wave, 8-wave workgroups)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_note,
                          "bytes_per_launch": fwd_bytes, "butterflies_per_s": value * (d // 2) * 8, "avg_launch_us": fwd_avg * 1e3,
@@ -511,7 +534,8 @@ def main():
                                     "frac": fwd_bytes / (region_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                     "what": "HIP events around the timed region on the kernels' stream / launches "
                                             "(consecutive dispatches overlap their launch and drain phases)"},
-                         "copy_floor": floor, "multi_job": multi, "kernels": kernels, "sweep": sweep},
+                         "copy_floor": floor, "multi_job": multi, "kernels": kernels, "sweep": sweep,
+                         "target": target_block()},
             "cold_batches": cold, "two_stream_pipelined": two_stream, "sign_verify": sv, "end_to_end": e2e, "pcie_inclusive": pcie,
         }
         if watchdog:

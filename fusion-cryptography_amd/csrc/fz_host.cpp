@@ -18,6 +18,8 @@
 #include <cmath>
 #include <cstdint>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -72,10 +74,118 @@ const uint64_t RC[24] = {
 void keccak_f_base(uint64_t s[25]) { FZ_KECCAK_BODY }
 __attribute__((target("bmi,bmi2"))) void keccak_f_bmi2(uint64_t s[25]) { FZ_KECCAK_BODY }
 
+// ---- Keccak-f[1600] on AVX-512 (one state): a plane (the five lanes of one row y) per 512-bit register ----------------------
+// hash_ag (fusion/fusion.py:632-652) is ONE serial sponge over every signer's text, so the only lever on the end-to-end
+// aggregate / verify latency is the permutation itself.  Per round, with R[y] slot x = a[x][y]:
+//   theta  C = R0 ^ R1 ^ R2 ^ R3 ^ R4 (two vpternlogq), D from two lane rotations of C (vpermq) and a 1-bit rotate,
+//          R[y] ^= D folded into one vpternlogq per plane;
+//   rho    one vprolvq per plane (per-lane rotation counts);
+//   pi     B[X = y][Y = 2x + 3y] = R[y][x]: an in-register vpermq turns plane y into COLUMN X = y of B (slot = Y), so that
+//   chi    b ^ (~b' & b'') runs register-wise (vpternlogq 0xD2) on columns X, X + 1, X + 2, no shuffles;
+//   iota   into lane (0, 0);
+//   back to planes: a 5 x 5 transpose as rotate-by-X (vpermq), 20 masked blends (slot s of plane Y comes from column
+//          (s - Y) mod 5), rotate-by-Y (vpermq).
+// 54 instructions per round, 13 of them cross-lane permutes.  Index tables were derived and checked lane by lane against the
+// scalar round before this was written (they are the PI / ROTA / ROTC tables below); hashlib pins all three variants in
+// tests/test_host_pipeline.py, and a self-test at load time keeps a miscompiled variant from ever being selected.
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx512f,avx512vl,avx512dq,avx512bw"))) void keccak_f_avx512(uint64_t s[25]) {
+    const __mmask8 k5 = 0x1f;
+    __m512i r0 = _mm512_maskz_loadu_epi64(k5, s), r1 = _mm512_maskz_loadu_epi64(k5, s + 5), r2 = _mm512_maskz_loadu_epi64(k5, s + 10),
+            r3 = _mm512_maskz_loadu_epi64(k5, s + 15), r4 = _mm512_maskz_loadu_epi64(k5, s + 20);
+    const __m512i idx_m = _mm512_setr_epi64(4, 0, 1, 2, 3, 5, 6, 7), idx_p = _mm512_setr_epi64(1, 2, 3, 4, 0, 5, 6, 7);
+    const __m512i rho0 = _mm512_setr_epi64(0, 1, 62, 28, 27, 0, 0, 0), rho1 = _mm512_setr_epi64(36, 44, 6, 55, 20, 0, 0, 0),
+                  rho2 = _mm512_setr_epi64(3, 10, 43, 25, 39, 0, 0, 0), rho3 = _mm512_setr_epi64(41, 45, 15, 21, 8, 0, 0, 0),
+                  rho4 = _mm512_setr_epi64(18, 2, 61, 56, 14, 0, 0, 0);
+    // pi: column X slot Y = plane X slot (3Y + X) mod 5
+    const __m512i pi0 = _mm512_setr_epi64(0, 3, 1, 4, 2, 5, 6, 7), pi1 = _mm512_setr_epi64(1, 4, 2, 0, 3, 5, 6, 7),
+                  pi2 = _mm512_setr_epi64(2, 0, 3, 1, 4, 5, 6, 7), pi3 = _mm512_setr_epi64(3, 1, 4, 2, 0, 5, 6, 7),
+                  pi4 = _mm512_setr_epi64(4, 2, 0, 3, 1, 5, 6, 7);
+    // rotate the slots of column X by X (F[X][s] = E[X][(s - X) mod 5]) / of plane Y back by Y (R[Y][X] = T[Y][(X + Y) mod 5])
+    const __m512i ra1 = idx_m, ra2 = _mm512_setr_epi64(3, 4, 0, 1, 2, 5, 6, 7), ra3 = _mm512_setr_epi64(2, 3, 4, 0, 1, 5, 6, 7), ra4 = idx_p;
+    const __m512i rc1 = idx_p, rc2 = ra3, rc3 = ra2, rc4 = idx_m;
+    for (int round = 0; round < 24; ++round) {
+        // theta
+        __m512i c = _mm512_ternarylogic_epi64(r0, r1, r2, 0x96);
+        c = _mm512_ternarylogic_epi64(c, r3, r4, 0x96);
+        const __m512i cm = _mm512_permutexvar_epi64(idx_m, c);
+        const __m512i cp = _mm512_rol_epi64(_mm512_permutexvar_epi64(idx_p, c), 1);
+        r0 = _mm512_ternarylogic_epi64(r0, cm, cp, 0x96);
+        r1 = _mm512_ternarylogic_epi64(r1, cm, cp, 0x96);
+        r2 = _mm512_ternarylogic_epi64(r2, cm, cp, 0x96);
+        r3 = _mm512_ternarylogic_epi64(r3, cm, cp, 0x96);
+        r4 = _mm512_ternarylogic_epi64(r4, cm, cp, 0x96);
+        // rho + pi (plane y -> column X = y)
+        const __m512i q0 = _mm512_permutexvar_epi64(pi0, _mm512_rolv_epi64(r0, rho0)), q1 = _mm512_permutexvar_epi64(pi1, _mm512_rolv_epi64(r1, rho1)),
+                      q2 = _mm512_permutexvar_epi64(pi2, _mm512_rolv_epi64(r2, rho2)), q3 = _mm512_permutexvar_epi64(pi3, _mm512_rolv_epi64(r3, rho3)),
+                      q4 = _mm512_permutexvar_epi64(pi4, _mm512_rolv_epi64(r4, rho4));
+        // chi (register-wise) + iota
+        __m512i e0 = _mm512_ternarylogic_epi64(q0, q1, q2, 0xD2);
+        const __m512i e1 = _mm512_ternarylogic_epi64(q1, q2, q3, 0xD2), e2 = _mm512_ternarylogic_epi64(q2, q3, q4, 0xD2),
+                      e3 = _mm512_ternarylogic_epi64(q3, q4, q0, 0xD2), e4 = _mm512_ternarylogic_epi64(q4, q0, q1, 0xD2);
+        e0 = _mm512_xor_si512(e0, _mm512_maskz_set1_epi64(0x01, (long long)RC[round]));
+        // columns -> planes
+        const __m512i f0 = e0, f1 = _mm512_permutexvar_epi64(ra1, e1), f2 = _mm512_permutexvar_epi64(ra2, e2),
+                      f3 = _mm512_permutexvar_epi64(ra3, e3), f4 = _mm512_permutexvar_epi64(ra4, e4);
+        // plane Y, slot s <- column (s - Y) mod 5: masks select the slots each column contributes
+#define FZ_T(Y, A0, A1, A2, A3, A4) /* A_j = the column that feeds slot j */ \
+        _mm512_mask_blend_epi64(0x10, _mm512_mask_blend_epi64(0x0c, _mm512_mask_blend_epi64(0x02, A0, A1), _mm512_mask_blend_epi64(0x08, A2, A3)), A4)
+        const __m512i t0 = FZ_T(0, f0, f1, f2, f3, f4), t1 = FZ_T(1, f4, f0, f1, f2, f3), t2 = FZ_T(2, f3, f4, f0, f1, f2),
+                      t3 = FZ_T(3, f2, f3, f4, f0, f1), t4 = FZ_T(4, f1, f2, f3, f4, f0);
+#undef FZ_T
+        r0 = t0;
+        r1 = _mm512_permutexvar_epi64(rc1, t1);
+        r2 = _mm512_permutexvar_epi64(rc2, t2);
+        r3 = _mm512_permutexvar_epi64(rc3, t3);
+        r4 = _mm512_permutexvar_epi64(rc4, t4);
+    }
+    _mm512_mask_storeu_epi64(s, k5, r0);
+    _mm512_mask_storeu_epi64(s + 5, k5, r1);
+    _mm512_mask_storeu_epi64(s + 10, k5, r2);
+    _mm512_mask_storeu_epi64(s + 15, k5, r3);
+    _mm512_mask_storeu_epi64(s + 20, k5, r4);
+}
+#endif
+
 typedef void (*keccak_fn)(uint64_t *);
+const char *g_keccak_name = "scalar";
+
+// the variant the sponges use: the fastest of those this CPU supports, MEASURED once at load time (a few microseconds
+// each) -- which of the scalar BMI2 form and the AVX-512 form wins depends on the core (cross-lane permute latency), and
+// FZ_KECCAK = scalar | bmi2 | avx512 overrides (tests run all three); a variant must first reproduce the scalar result
 keccak_fn pick_keccak() {
     __builtin_cpu_init();
-    return (__builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2")) ? keccak_f_bmi2 : keccak_f_base;
+    struct Cand { const char *name; keccak_fn fn; };
+    std::vector<Cand> cands{{"scalar", keccak_f_base}};
+    if (__builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2")) cands.push_back({"bmi2", keccak_f_bmi2});
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512dq") &&
+        __builtin_cpu_supports("avx512bw"))
+        cands.push_back({"avx512", keccak_f_avx512});
+#endif
+    uint64_t ref[25];
+    for (int i = 0; i < 25; ++i) ref[i] = 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+    keccak_f_base(ref);
+    const char *force = getenv("FZ_KECCAK");
+    keccak_fn best = keccak_f_base;
+    double best_t = 1e30;
+    for (const Cand &c : cands) {
+        uint64_t st[25];
+        for (int i = 0; i < 25; ++i) st[i] = 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+        c.fn(st);
+        if (memcmp(st, ref, sizeof(st)) != 0) continue;                    // never select a variant that disagrees
+        if (force && strcmp(force, c.name) == 0) { g_keccak_name = c.name; return c.fn; }
+        double t = 1e30;
+        for (int pass = 0; pass < 3; ++pass) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < 64; ++i) c.fn(st);
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt < t) t = dt;
+        }
+        if (t < best_t) { best_t = t; best = c.fn; g_keccak_name = c.name; }
+    }
+    return best;
 }
 const keccak_fn keccak_f = pick_keccak();
 
@@ -423,6 +533,8 @@ size_t fz_host_challenge_needed_bytes(const fz_scheme_params *P, int *sign_bytes
 bool fz_host_params_ok(const fz_scheme_params *P) { return params_ok(P); }
 
 extern "C" {
+
+const char *fz_keccak_variant(void) { return g_keccak_name; }
 
 int fz_sha3_256(const uint8_t *h_data, size_t len, uint8_t *h_out32) {
     if ((!h_data && len) || !h_out32) return fz_set_error(FZ_E_BADARG, "NULL argument");

@@ -121,6 +121,7 @@ _u8p = POINTER(ctypes.c_uint8)
 _szp = POINTER(c_size_t)
 _spp = POINTER(SchemeParams)
 SIGNATURES.update({
+    "fz_keccak_variant": (c_char_p, []),
     "fz_sha3_256": (c_int, [c_char_p, c_size_t, _u8p]),
     "fz_shake256": (c_int, [c_char_p, c_size_t, _u8p, c_size_t]),
     "fz_format_vk": (c_int, [_spp, _i32p, _i32p, c_char_p, c_size_t, _szp]),

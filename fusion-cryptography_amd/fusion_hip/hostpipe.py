@@ -57,6 +57,11 @@ def _pack_messages(messages):
     return b"".join(enc), off
 
 
+def keccak_variant() -> str:
+    """which Keccak-f[1600] the host sponges run in this process: "scalar" | "bmi2" | "avx512" (FZ_KECCAK forces one)"""
+    return load_library().fz_keccak_variant().decode()
+
+
 def sha3_256(data: bytes) -> bytes:
     lib = load_library()
     out = (ctypes.c_uint8 * 32)()

@@ -320,6 +320,9 @@ typedef struct fz_scheme_params {
     uint8_t sign_pre_hash_dst[2], sign_hash_dst[2], agg_xof_dst[2];
 } fz_scheme_params;
 
+/* which Keccak-f[1600] the host sponges run: "scalar", "bmi2" or "avx512" -- the fastest this CPU supports, measured once when
+ * the library is loaded (FZ_KECCAK=<name> forces one); every variant is checked against the scalar one before it can be chosen */
+FZ_API const char *fz_keccak_variant(void);
 FZ_API int fz_sha3_256(const uint8_t *h_data, size_t len, uint8_t *h_out32);
 FZ_API int fz_shake256(const uint8_t *h_data, size_t len, uint8_t *h_out, size_t out_len);
 /* str(OneTimeVerificationKey) (fusion.py:328-329 -> matrices.py:40-41 -> polynomials.py:257-258) of a key

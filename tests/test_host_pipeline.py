@@ -9,6 +9,7 @@ import random
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -33,6 +34,31 @@ def test_keccak_against_hashlib(hp):
         assert hp.sha3_256(data) == hashlib.sha3_256(data).digest()
         for out in (0, 1, 32, 135, 136, 137, 1551, 10436, 3968 * 3 + 1):
             assert hp.shake256(data, out) == hashlib.shake_256(data).digest(out)
+
+
+@pytest.mark.parametrize("variant", ["scalar", "bmi2", "avx512"])
+def test_every_keccak_variant_against_hashlib(variant):
+    """the three Keccak-f[1600] implementations (FZ_KECCAK is read when the library is loaded: one process per variant)"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, random\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'fusion-cryptography_amd')!r})\n"
+        "from fusion_hip import hostpipe\n"
+        "rng = random.Random(11)\n"
+        "for n in [0, 1, 7, 8, 135, 136, 137, 271, 272, 273, 1000, 6344, 13600, 100001]:\n"
+        "    data = rng.randbytes(n)\n"
+        "    assert hostpipe.sha3_256(data) == hashlib.sha3_256(data).digest(), n\n"
+        "    for out in (0, 1, 32, 135, 136, 137, 1551, 10436):\n"
+        "        assert hostpipe.shake256(data, out) == hashlib.shake_256(data).digest(out), (n, out)\n"
+        "print(hostpipe.keccak_variant())\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FZ_KECCAK=variant), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = r.stdout.split()[-1]
+    flags = open("/proc/cpuinfo").read()
+    supported = {"scalar": True, "bmi2": " bmi2" in flags and " bmi1" in flags,
+                 "avx512": all(f" {f}" in flags for f in ("avx512f", "avx512vl", "avx512dq", "avx512bw"))}[variant]
+    assert got == variant if supported else got in ("scalar", "bmi2", "avx512")
 
 
 @pytest.mark.parametrize("secpar", [128, 256])

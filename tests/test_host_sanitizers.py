@@ -98,16 +98,18 @@ def test_host_pipeline_under_asan_and_ubsan(tmp_path):
         subprocess.check_call(cmd)
     except subprocess.CalledProcessError:
         pytest.skip("g++ with sanitizer runtimes not available")
-    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    assert "done" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     data = bytes((i * 131 + 7) & 0xff for i in range(700))
-    lines = dict(((ln.split()[0], int(ln.split()[1])), ln.split()[2]) for ln in r.stdout.splitlines() if ln.startswith(("sha3", "shake")))
-    for n in (0, 1, 135, 136, 137, 271, 272, 273, 700):
-        assert lines[("sha3", n)] == hashlib.sha3_256(data[:n]).hexdigest()
-        assert lines[("shake", n)] == hashlib.shake_256(data[:n]).hexdigest(301)
-    assert "secpar 128 weight %d" % (37 * 31) in r.stdout and "secpar 256 weight %d" % (37 * 60) in r.stdout
+    for variant in ("scalar", "bmi2", "avx512"):          # every Keccak-f[1600] implementation (a CPU without one falls back)
+        r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, FZ_KECCAK=variant, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0",
+                                    UBSAN_OPTIONS="print_stacktrace=1"))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        assert "done" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+        lines = dict(((ln.split()[0], int(ln.split()[1])), ln.split()[2]) for ln in r.stdout.splitlines() if ln.startswith(("sha3", "shake")))
+        for n in (0, 1, 135, 136, 137, 271, 272, 273, 700):
+            assert lines[("sha3", n)] == hashlib.sha3_256(data[:n]).hexdigest()
+            assert lines[("shake", n)] == hashlib.shake_256(data[:n]).hexdigest(301)
+        assert "secpar 128 weight %d" % (37 * 31) in r.stdout and "secpar 256 weight %d" % (37 * 60) in r.stdout
 
 
 def test_host_pipeline_threads_under_tsan(tmp_path):

@@ -302,6 +302,8 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     {
         const char *e = getenv("FZ_NTT_KERNEL");
         c->force_kernel = e ? atoi(e) : 0;
+        e = getenv("FZ_FUSED_PREFETCH");
+        c->knob_fused_prefetch = e ? atoi(e) : 0;
         e = getenv("FZ_FUSED_ROWS");
         c->knob_fused_rows = e ? atoi(e) : 0;
         e = getenv("FZ_NTT_WAVES");
@@ -331,6 +333,10 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         c->knob_verify_blocks = knob("FZ_VERIFY_BLOCKS");
         c->knob_verify_unfused = knob("FZ_VERIFY_UNFUSED");
         c->knob_verify_ordered = knob("FZ_VERIFY_ORDERED");
+        // The fence-free cross-workgroup combine of verify_fused (relaxed agent-scope atomics on the library's own
+        // coarse-grained scratch, ordered by data dependence: csrc/fz_ntt.hip) is an argument about THIS chip's memory-side
+        // atomics; anything that does not report gfx950 gets the acquire/release instantiation.
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) c->knob_verify_ordered = 1;
         c->knob_keygen_unfused = knob("FZ_KEYGEN_UNFUSED");
         c->knob_polymul_unfused = knob("FZ_POLYMUL_UNFUSED");
         c->knob_no_imad = knob("FZ_NO_IMAD");

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd16(const int32_t *
     __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * REGION + 2 * NE * L];
     double2 *s_tw = reinterpret_cast<double2 *>(lds + kWavesPerBlock * REGION);      // (w, w2) pairs, [NE][L]
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
     const int p = lane / L, r = lane % L;
     for (int i = threadIdx.x; i < NE * L; i += 64 * kWavesPerBlock) s_tw[i] = twB[i];
     __syncthreads();                                      // the only workgroup-wide barrier
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
     __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * REGION + 2 * NE * L];
     double2 *s_tw = reinterpret_cast<double2 *>(lds + kWavesPerBlock * REGION);
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
     const int p = lane / L, r = lane % L;
     for (int i = threadIdx.x; i < NE * L; i += 64 * kWavesPerBlock) s_tw[i] = itwB[i];
     __syncthreads();
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fwd4(const int32_t *in, int32_
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
     __shared__ __attribute__((aligned(16))) double lds[WAVES * NR * 256];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
     const int p = lane / LP, mm = lane % LP;
     double *region = lds + wave * NR * 256 + p * D;
     const size_t task = (size_t)blockIdx.x * WAVES + wave;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_inv4(const int32_t *in, int32_
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
     __shared__ __attribute__((aligned(16))) double lds[WAVES * NR * 256];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
     const int p = lane / LP, mm = lane % LP;
     double *region = lds + wave * NR * 256 + p * D;
     const size_t task = (size_t)blockIdx.x * WAVES + wave;      // one task per wave: see ntt_fwd4
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
     __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
     const int p = lane / LP, mm = lane % LP;
     double *region = lds + wave * 256 + p * D;
     const size_t tasks = (batch + PPW - 1) / PPW;
@@ -766,7 +766,9 @@ __device__ __forceinline__ double fz_imad_total(long long hi, long long lo, bool
 }
 // NR: row groups a wave takes through the transform passes together (fwd4_passes_n: one synchronisation per pass for NR rows,
 // NR independent fp64 dependency chains per wave).
-template <int LOGD, bool FAST, bool IMAD, int NR>
+// PF: how many iterations ahead a wave requests its secret rows (1 or 2; a wave's rows are a sequential chain).  Measured: no
+// difference (see the launcher).
+template <int LOGD, bool FAST, bool IMAD, int NR, int PF>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_t *A, const int32_t *coef,
                                                                     size_t coef_seg_stride,
                                                                     size_t coef_row_stride, int32_t *sk_hat,
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
                                                                     FzTwA twA, FzMod m) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
     __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256 * (NR + 1)];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
     const int p = lane / LP, mm = lane % LP;
     double *region = lds + wave * NR * 256 + p * D;
     double *accbuf = lds + kWavesPerBlock * NR * 256;
@@ -789,52 +791,59 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
     long long ihi[4] = {0, 0, 0, 0}, ilo[4] = {0, 0, 0, 0};      // IMAD: exact integer sums of y * hi and y * lo
     const int tasks = (l + PPW - 1) / PPW;
     constexpr int STEP = kWavesPerBlock * NR;           // a wave's iteration covers tasks t, t + 4, .. (NR of them)
-    int xn[NR][4];
-    auto fetch = [&](int task) {
+    int xq[PF][NR][4];                                  // the next PF iterations' rows, in flight
+    auto fetch = [&](int (&x)[NR][4], int task) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int row = (task + r * kWavesPerBlock) * PPW + p;
             const int32_t *src = coef + (size_t)(row < l ? row : l - 1) * coef_row_stride + mm;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) xn[r][k] = src[k * LP];
+            for (int k = 0; k < 4; ++k) x[r][k] = src[k * LP];
         }
     };
-    if (wave < tasks) fetch(wave);
-    for (int task = wave; task < tasks; task += STEP) {
-        double a[NR][4];
-        int4 ak[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
+    for (int h = 0; h < PF; ++h)
+        if (wave + h * STEP < tasks) fetch(xq[h], wave + h * STEP);
+    for (int task0 = wave; task0 < tasks; task0 += PF * STEP) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[r][k] = (double)xn[r][k];
-            const int row = (task + r * kWavesPerBlock) * PPW + p;
-            ak[r] = *reinterpret_cast<const int4 *>(A + (size_t)(row < l ? row : l - 1) * D + 4 * mm);
-        }
-        if (task + STEP < tasks) fetch(task + STEP);
-        fwd4_passes_n<LOGD, FAST, NR>(a, region, twl, twA, m, mm);
+        for (int h = 0; h < PF; ++h) {
+            const int task = task0 + h * STEP;
+            if (task >= tasks) break;
+            double a[NR][4];
+            int4 ak[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int row = (task + r * kWavesPerBlock) * PPW + p;
-            const double y0 = fz_cent(a[r][0], m), y1 = fz_cent(a[r][1], m), y2 = fz_cent(a[r][2], m), y3 = fz_cent(a[r][3], m);
-            if (row < l) {
-                const int4 yi = make_int4((int)y0, (int)y1, (int)y2, (int)y3);
-                *reinterpret_cast<int4 *>(sk_hat + (size_t)row * D + 4 * mm) = yi;
-                if constexpr (IMAD) {
-                    const int yv[4] = {yi.x, yi.y, yi.z, yi.w}, av[4] = {ak[r].x, ak[r].y, ak[r].z, ak[r].w};
+            for (int r = 0; r < NR; ++r) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        ihi[k] += (long long)yv[k] * (long long)(av[k] >> 16);
-                        ilo[k] += (long long)yv[k] * (long long)(av[k] & 0xffff);
+                for (int k = 0; k < 4; ++k) a[r][k] = (double)xq[h][r][k];
+                const int row = (task + r * kWavesPerBlock) * PPW + p;
+                ak[r] = *reinterpret_cast<const int4 *>(A + (size_t)(row < l ? row : l - 1) * D + 4 * mm);
+            }
+            if (task + PF * STEP < tasks) fetch(xq[h], task + PF * STEP);
+            fwd4_passes_n<LOGD, FAST, NR>(a, region, twl, twA, m, mm);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int row = (task + r * kWavesPerBlock) * PPW + p;
+                const double y0 = fz_cent(a[r][0], m), y1 = fz_cent(a[r][1], m), y2 = fz_cent(a[r][2], m), y3 = fz_cent(a[r][3], m);
+                if (row < l) {
+                    const int4 yi = make_int4((int)y0, (int)y1, (int)y2, (int)y3);
+                    *reinterpret_cast<int4 *>(sk_hat + (size_t)row * D + 4 * mm) = yi;
+                    if constexpr (IMAD) {
+                        const int yv[4] = {yi.x, yi.y, yi.z, yi.w}, av[4] = {ak[r].x, ak[r].y, ak[r].z, ak[r].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            ihi[k] += (long long)yv[k] * (long long)(av[k] >> 16);
+                            ilo[k] += (long long)yv[k] * (long long)(av[k] & 0xffff);
+                        }
+                    } else {
+                        acc[0] += fz_mulmod(y0, (double)ak[r].x, m);
+                        acc[1] += fz_mulmod(y1, (double)ak[r].y, m);
+                        acc[2] += fz_mulmod(y2, (double)ak[r].z, m);
+                        acc[3] += fz_mulmod(y3, (double)ak[r].w, m);
                     }
-                } else {
-                    acc[0] += fz_mulmod(y0, (double)ak[r].x, m);
-                    acc[1] += fz_mulmod(y1, (double)ak[r].y, m);
-                    acc[2] += fz_mulmod(y2, (double)ak[r].z, m);
-                    acc[3] += fz_mulmod(y3, (double)ak[r].w, m);
                 }
             }
+            wave_sync();
         }
-        wave_sync();
     }
     if constexpr (IMAD) {
         const bool small = tasks <= 32 * kWavesPerBlock;          // rows per wave <= 32
@@ -908,7 +917,7 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
     static_assert(D <= 64 * kVerifyWaves, "one thread per coefficient in the combine steps");
     __shared__ __attribute__((aligned(16))) double lds[kVerifyWaves * 256 * (NR + 1)];
     __shared__ int s_flags, s_last;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
     const int p = lane / LP, mm = lane % LP;
     double *region = lds + wave * NR * 256 + p * D;
     double *accbuf = lds + kVerifyWaves * NR * 256;
@@ -1222,10 +1231,13 @@ int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, i
     const dim3 grid((unsigned)segments), block(64 * kWavesPerBlock);
     const size_t seg_stride = broadcast ? (size_t)ctx->degree : (size_t)l * ctx->degree;
     const size_t row_stride = broadcast ? 0 : (size_t)ctx->degree;
-    // two row groups per wave iteration: 77.5 -> 75.4 us per 1024 keys on one box, 80.8 -> 80.4 on another (FZ_FUSED_ROWS = 1 | 2 forces)
-    const bool two = ctx->knob_fused_rows != 1;
-#define FZ_KF3(LOGD, FAST, IM, NR) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, IM, NR>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \
+    // FZ_FUSED_ROWS = 1 | 2 row groups per wave iteration, FZ_FUSED_PREFETCH = 1 | 2 iterations requested ahead: all four
+    // combinations measure the same on one box (81.7 / 81.7 / 82.0 / 81.1 us per 1024 keys, profiles/r03_keygen_ab.txt) although
+    // their vector-instruction counts differ by 8 % -- the kernel is bound by neither; the defaults are the smallest form (1, 1)
+    const bool two = ctx->knob_fused_rows == 2, deep = ctx->knob_fused_prefetch == 2;
+#define FZ_KF4(LOGD, FAST, IM, NR, PF) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, IM, NR, PF>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \
                                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod)
+#define FZ_KF3(LOGD, FAST, IM, NR) do { if (deep) FZ_KF4(LOGD, FAST, IM, NR, 2); else FZ_KF4(LOGD, FAST, IM, NR, 1); } while (0)
 #define FZ_KF2(LOGD, FAST, IM) do { if (two) FZ_KF3(LOGD, FAST, IM, 2); else FZ_KF3(LOGD, FAST, IM, 1); } while (0)
 #define FZ_KF(LOGD, FAST) do { if (!ctx->knob_no_imad) FZ_KF2(LOGD, FAST, true); else FZ_KF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_KF(8, true); else FZ_KF(8, false); }
@@ -1234,6 +1246,7 @@ int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, i
 #undef FZ_KF
 #undef FZ_KF2
 #undef FZ_KF3
+#undef FZ_KF4
     return fz_check_hip(hipGetLastError(), "keygen_fused launch");
 }
 
@@ -1264,7 +1277,10 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
                                                    target_stride, l, (long long)beta, (long long)omega, lazy, (const double2 *)ctx->d_itw2, \
                                                    ctx->itwA, ctx->mod, part, state, d_verdict)
 #define FZ_VF3(LOGD, FAST, ORD, IM) do { if (two) FZ_VF4(LOGD, FAST, ORD, IM, 2); else FZ_VF4(LOGD, FAST, ORD, IM, 1); } while (0)
-#define FZ_VF2(LOGD, FAST, ORD) do { if (!ctx->knob_no_imad) FZ_VF3(LOGD, FAST, ORD, true); else FZ_VF3(LOGD, FAST, ORD, false); } while (0)
+    // integer accumulation of A * sigma pays its once-per-wave conversion back only over several rows per wave (measured: 1.18 M
+    // vector instructions against 1.10 M per launch when the l rows are spread one per wave over 21 workgroups)
+    const bool imad = !ctx->knob_no_imad && (tasks + R * kVerifyWaves - 1) / (R * kVerifyWaves) >= 4;
+#define FZ_VF2(LOGD, FAST, ORD) do { if (imad) FZ_VF3(LOGD, FAST, ORD, true); else FZ_VF3(LOGD, FAST, ORD, false); } while (0)
 #define FZ_VF(LOGD, FAST) do { if (ctx->knob_verify_ordered) FZ_VF2(LOGD, FAST, true); else FZ_VF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_VF(8, true); else FZ_VF(8, false); }
     else { if (ctx->mod.fast) FZ_VF(6, true); else FZ_VF(6, false); }

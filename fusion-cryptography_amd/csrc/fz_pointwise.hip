@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
                                                                 int64_t *tout64, size_t tstride, int32_t *out32, FzMod m, RAG rag) {
     constexpr bool RAGGED = !__is_same(RAG, FzNoRag);
     __shared__ __attribute__((aligned(16))) double red[WAVES * kAggTile];      // 64 KiB at 8 waves
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
     // block id -> tile t = p * ncb + cb (p = g * nsl + sb: the (aggregate, slice) pair, cb the column block).  Workgroups
     // b and b + 8 share an XCD, so XCD x = b % 8 gets the CONTIGUOUS run of tiles [x * per_xcd, (x + 1) * per_xcd): equal
     // load on every XCD (a pair-per-XCD mapping left XCDs with 21 and others with 42 workgroups at 12 slices: 30.7 us

@@ -40,9 +40,17 @@ def make_ctx(secpar, kernel, env=None):
 
 
 ctxs = {(sp, k): make_ctx(sp, k) for sp in (128, 256) for k in ("", "4", "16")}
+# the radix-4 kernels with 1 / 2 / 4 row groups per wave and other workgroup shapes, whatever the batch size
+for sp_ in (128, 256):
+    ctxs[(sp_, "4r1")] = make_ctx(sp_, "4", {"FZ_NTT_ROWS": "1", "FZ_NTT_WAVES": "1"})
+    ctxs[(sp_, "4r1w4")] = make_ctx(sp_, "4", {"FZ_NTT_ROWS": "1", "FZ_NTT_WAVES": "4"})
+    ctxs[(sp_, "4r2")] = make_ctx(sp_, "4", {"FZ_NTT_ROWS": "2"})
+    ctxs[(sp_, "4r4")] = make_ctx(sp_, "4", {"FZ_NTT_ROWS": "4"})
+KERNS = ["", "4", "16", "4r1", "4r1w4", "4r2", "4r4"]
 # the multi-launch forms of the fused kernels and other launch shapes of the one-pass aggregation
 VARIANTS = [{}, {"FZ_KEYGEN_UNFUSED": "1", "FZ_VERIFY_UNFUSED": "1", "FZ_POLYMUL_UNFUSED": "1"}, {"FZ_AGG_TWOPASS": "1"},
-            {"FZ_AGG_WAVES": "4", "FZ_AGG_SLICES": "3"}, {"FZ_AGG_SLICES": "7", "FZ_VERIFY_ORDERED": "1"}, {"FZ_STREAM_PER_CU": "8"}]
+            {"FZ_AGG_WAVES": "4", "FZ_AGG_SLICES": "3"}, {"FZ_AGG_SLICES": "7", "FZ_VERIFY_ORDERED": "1"}, {"FZ_STREAM_PER_CU": "8"},
+            {"FZ_NO_IMAD": "1", "FZ_FUSED_ROWS": "1"}, {"FZ_FUSED_ROWS": "2", "FZ_VERIFY_CENT": "1"}, {"FZ_FUSED_ROWS": "1", "FZ_AGG_SLICES": "2"}]
 vctx = {(sp, i): make_ctx(sp, "", v) for sp in (128, 256) for i, v in enumerate(VARIANTS)}
 DB = fusion_hip.DeviceBuffer
 t_end = time.time() + budget
@@ -53,11 +61,11 @@ while time.time() < t_end:
     sp = int(rng.choice([128, 256]))
     P = O.PARAMS[sp]
     d, root, inv = P["d"], P["root"], P["inv_root"]
-    kern = str(rng.choice(["", "4", "16"]))
+    kern = str(rng.choice(KERNS))
     ctx = ctxs[(sp, kern)]
-    other = ctxs[(sp, str(rng.choice(["", "4", "16"])))]
+    other = ctxs[(sp, str(rng.choice(KERNS)))]
     rows = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 257, 1000, 4099, int(rng.integers(1, 20000))]))
-    what = rng.choice(["ntt", "polymul", "scheme", "graph", "pointwise", "small", "batch_api", "multi", "challenge", "sampler"])
+    what = rng.choice(["ntt", "polymul", "scheme", "graph", "pointwise", "small", "batch_api", "multi", "challenge", "sampler", "ragged"])
     raw = rng.random() < 0.3
     x = (rng.integers(-2**31, 2**31, size=(rows, d), dtype=np.int64).astype(np.int32) if raw
          else O.splitmix_centered(int(rng.integers(1, 2**40)), rows * d).reshape(rows, d))
@@ -99,6 +107,39 @@ while time.time() < t_end:
         for b in keep:
             b.free()
         bump("multi")
+    elif what == "ragged":
+        # many aggregates of different sizes in one launch (fz_aggregate_core_ragged / fz_aggregate_target_partial_ragged),
+        # raw int32 signature rows, up to 150 aggregates (the group table of a launch holds 64), targets-only form too
+        vc = vctx[(sp, int(rng.integers(0, len(VARIANTS))))]
+        l = int(rng.choice([1, 3, P["rank"]]))
+        G = int(rng.choice([1, 2, 5, 64, 65, int(rng.integers(1, 150))]))
+        sizes = [int(v) for v in rng.choice([1, 2, 3, 7, 30], size=G)]
+        if rng.random() < 0.3:
+            sizes[int(rng.integers(0, G))] = int(rng.integers(100, 400 if l < 20 else 150))
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        n = int(off[-1])
+        sig = rng.integers(-2**31, 2**31, size=(n, l, d), dtype=np.int64).astype(np.int32)
+        al, ch, L_, R_ = (rng.integers(-2**31, 2**31, size=(n, d), dtype=np.int64).astype(np.int32) for _ in range(4))
+        d_sig, d_al, d_c, d_L, d_R = (DB.from_numpy(vc, a_) for a_ in (sig, al, ch, L_, R_))
+        out32, part, tgt, tgt2 = DB(vc, G * l * d * 4), DB(vc, G * l * d * 8), DB(vc, G * d * 8), DB(vc, G * d * 8)
+        vc.aggregate_core_ragged_dev(d_sig.ptr, d_al.ptr, off, l, out32.ptr)
+        vc.aggregate_target_partial_ragged_dev(d_sig.ptr, d_al.ptr, d_L.ptr, d_R.ptr, d_c.ptr, off, l, part.ptr, l * d, tgt.ptr, d)
+        vc.aggregate_target_partial_ragged_dev(0, d_al.ptr, d_L.ptr, d_R.ptr, d_c.ptr, off, l, 0, 0, tgt2.ptr, d)
+        got32 = out32.to_numpy(np.int32, (G, l, d))
+        got64 = part.to_numpy(np.int64, (G, l, d))
+        t1, t2 = tgt.to_numpy(np.int64, (G, d)), tgt2.to_numpy(np.int64, (G, d))
+        half = q // 2
+        for g_ in sorted(set([0, G - 1] + [int(v) for v in rng.integers(0, G, size=4)])):
+            a_, b_ = off[g_], off[g_ + 1]
+            want = orc.aggregate_core(sig[a_:b_], al[a_:b_], q)
+            assert np.array_equal(got32[g_], want), ("ragged aggregate", sp, l, G, g_)
+            assert np.array_equal(((got64[g_] + half) % q - half).astype(np.int32), want), ("ragged partial", sp, l, G, g_)
+            t = (L_[a_:b_].astype(object) * ch[a_:b_].astype(object) + R_[a_:b_].astype(object)) * al[a_:b_].astype(object)
+            wt = np.array([int(v) % q for v in t.sum(axis=0)], dtype=np.int64)
+            assert np.array_equal(t1[g_] % q, wt) and np.array_equal(t2[g_] % q, wt), ("ragged target", sp, G, g_)
+        for b in (d_sig, d_al, d_c, d_L, d_R, out32, part, tgt, tgt2):
+            b.free()
+        bump("ragged")
     elif what == "sampler":
         # device MT19937 sampler == the C clone on the host (itself pinned by CPython's random), any seed / bound / degree
         from fusion_hip import hostpipe

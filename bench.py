@@ -521,7 +521,10 @@ def main():
                        "prewarm_ms": args.prewarm_ms,
                        "host_threads_on": placement or "all allowed CPUs (no GPU-local NUMA node found, or FZ_NO_PIN=1)"},
             "ranks": ranks,
-            "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8, true, 1, 8> (forward NTT, B=4096: one row per wave, 8-wave workgroups)", "achieved": ach,
+            "roofline": {"bound": "hbm", "inputs": "the timed region and the per-dispatch passes re-read ONE 4 MiB batch (cache-warm after the first "
+                                                   "step: `value` and `achieved` are best-case figures); `cold_batches` repeats the steps over 32 "
+                                                   "batches, roofline.kernels / target.met_from_rows are measured on cold operands",
+                         "kernel": "ntt_fwd4<8, true, 1, 8> (forward NTT, B=4096: one row per wave, 8-wave workgroups)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_note,
                          "bytes_per_launch": fwd_bytes, "butterflies_per_s": value * (d // 2) * 8, "avg_launch_us": fwd_avg * 1e3,

@@ -302,6 +302,8 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     {
         const char *e = getenv("FZ_NTT_KERNEL");
         c->force_kernel = e ? atoi(e) : 0;
+        e = getenv("FZ_FUSED_TW");
+        c->knob_fused_tw = e ? atoi(e) : 0;
         e = getenv("FZ_FUSED_PREFETCH");
         c->knob_fused_prefetch = e ? atoi(e) : 0;
         e = getenv("FZ_FUSED_ROWS");

@@ -42,6 +42,7 @@ struct fz_ctx {
     int grid_fwd, grid_inv;      // resident-grid caps for the persistent NTT kernels
     int grid_pm;                 // resident grid of the fused product kernel (0 = not queried yet)
     int grid_mult;               // grid = resident blocks x grid_mult (env FZ_NTT_GRID_MULT; 1 = persistent): 16-per-lane and multi-job kernels
+    int knob_fused_tw;           // FZ_FUSED_TW = 1: the fused kernels keep per-lane twiddles as w alone and recompute w * K/q (fewer registers)
     int knob_fused_prefetch;     // FZ_FUSED_PREFETCH = 1 | 2: iterations a wave of the fused keygen kernel requests its rows ahead (0 = 1)
     int knob_fused_rows;         // FZ_FUSED_ROWS = 1 | 2: row groups per wave iteration in the fused keygen / verification kernels (0 = 1)
     int knob_ntt_waves;          // FZ_NTT_WAVES = 1 | 4 | 8: waves per workgroup of the one-row-group radix-4 kernels (0 = 8)

@@ -362,13 +362,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
 __device__ __forceinline__ int swz4(int j) { return j ^ (((j >> 4) & 7) << 2); }
 
 
+// per-lane twiddles are kept either as (w, w * K/q) pairs or as w alone with the quotient twiddle recomputed at each use
+// (one more fp64 multiply per twiddle and pass, half the registers: the fused kernels trade it for occupancy)
+__device__ __forceinline__ double tw_w(const double2 &t) { return t.x; }
+__device__ __forceinline__ double tw_q(const double2 &t, const FzMod &) { return t.y; }
+__device__ __forceinline__ double tw_w(const double &t) { return t; }
+__device__ __forceinline__ double tw_q(const double &t, const FzMod &m) {
+    double w = t;
+    asm volatile("" : "+v"(w));        // opaque: the product must be recomputed where it is used, not hoisted into nine more registers
+    return w * m.kq;                   // the same IEEE product the host table holds
+}
+__device__ __forceinline__ void tw_set(double2 &dst, const double2 &src) { dst = src; }
+__device__ __forceinline__ void tw_set(double &dst, const double2 &src) { dst = src.x; }
+
 // the log4(D) in-place passes of the radix-4 forward transform on one lane's 4 values per row group (natural positions
 // mm + (D/4)k in, bit-reversed-order positions 4mm..4mm+3 out, NOT yet centred).  NR independent row groups (a wave's 64
 // lanes hold 64 / (D/4) polynomials per group) go through the passes in lock step: one wave-local synchronisation per
 // pass whatever NR is, twiddles and LDS offsets computed once, and NR independent dependency chains for the fp64 pipeline.
 // Row group r of this lane's polynomial lives at region + r * 256 doubles.
-template <int LOGD, bool FAST, int NR>
-__device__ __forceinline__ void fwd4_passes_n(double (&a)[NR][4], double *region, const double2 (&twl)[LOGD / 2 - 1][3],
+template <int LOGD, bool FAST, int NR, typename TW = double2>
+__device__ __forceinline__ void fwd4_passes_n(double (&a)[NR][4], double *region, const TW (&twl)[LOGD / 2 - 1][3],
                                               const FzTwA &twA, const FzMod &m, int mm) {
     constexpr int D = 1 << LOGD, P = LOGD / 2;
 #pragma unroll
@@ -379,9 +392,9 @@ __device__ __forceinline__ void fwd4_passes_n(double (&a)[NR][4], double *region
         if (i == 0) {
             wA = twA.w[1]; wA2 = twA.w2[1]; wB0 = twA.w[2]; wB02 = twA.w2[2]; wB1 = twA.w[3]; wB12 = twA.w2[3];
         } else {
-            wA = twl[i - 1][0].x; wA2 = twl[i - 1][0].y;
-            wB0 = twl[i - 1][1].x; wB02 = twl[i - 1][1].y;
-            wB1 = twl[i - 1][2].x; wB12 = twl[i - 1][2].y;
+            wA = tw_w(twl[i - 1][0]); wA2 = tw_q(twl[i - 1][0], m);
+            wB0 = tw_w(twl[i - 1][1]); wB02 = tw_q(twl[i - 1][1], m);
+            wB1 = tw_w(twl[i - 1][2]); wB12 = tw_q(twl[i - 1][2], m);
             wave_sync();
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -425,15 +438,21 @@ __device__ __forceinline__ void fwd4_passes(double (&a)[4], double *region, cons
     fwd4_passes_n<LOGD, FAST, 1>(reinterpret_cast<double (&)[1][4]>(a), region, twl, twA, m, mm);
 }
 
-template <int LOGD>
-__device__ __forceinline__ void fwd4_load_twiddles(double2 (&twl)[LOGD / 2 - 1][3], const double2 *__restrict__ tw2, int mm) {
+template <int LOGD, typename TW = double2>
+__device__ __forceinline__ void fwd4_load_twiddles(TW (&twl)[LOGD / 2 - 1][3], const double2 *__restrict__ tw2, int mm) {
     constexpr int D = 1 << LOGD, P = LOGD / 2;
 #pragma unroll
     for (int i = 1; i < P; ++i) {
         const int s = D >> (2 * i + 2), g = mm / s, pw = 1 << (2 * i);
-        twl[i - 1][0] = tw2[pw + g];
-        twl[i - 1][1] = tw2[2 * pw + 2 * g];
-        twl[i - 1][2] = tw2[2 * pw + 2 * g + 1];
+        if constexpr (__is_same(TW, double2)) {
+            twl[i - 1][0] = tw2[pw + g];
+            twl[i - 1][1] = tw2[2 * pw + 2 * g];
+            twl[i - 1][2] = tw2[2 * pw + 2 * g + 1];
+        } else {
+            twl[i - 1][0] = tw2[pw + g].x;
+            twl[i - 1][1] = tw2[2 * pw + 2 * g].x;
+            twl[i - 1][2] = tw2[2 * pw + 2 * g + 1].x;
+        }
     }
 }
 
@@ -487,8 +506,8 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fwd4(const int32_t *in, int32_
 // the log4(D) in-place passes of the radix-4 inverse on one lane's 4 values per row group (bit-reversed positions
 // 4mm..4mm+3 in, natural positions mm + (D/4)k out, n^-1 applied, NOT yet centred); NR row groups in lock step (see
 // fwd4_passes_n)
-template <int LOGD, bool FAST, int NR>
-__device__ __forceinline__ void inv4_passes_n(double (&a)[NR][4], double *region, const double2 (&twl)[LOGD / 2 - 1][3],
+template <int LOGD, bool FAST, int NR, typename TW = double2>
+__device__ __forceinline__ void inv4_passes_n(double (&a)[NR][4], double *region, const TW (&twl)[LOGD / 2 - 1][3],
                                               const FzTwA &twA, const FzMod &m, int mm) {
     constexpr int P = LOGD / 2;
 #pragma unroll
@@ -507,16 +526,18 @@ __device__ __forceinline__ void inv4_passes_n(double (&a)[NR][4], double *region
         if (i < P - 1) {
             // GS stage 2i (distance s, two twiddles) then stage 2i+1 (distance 2s, one twiddle);
             // operands stay below 2^(33+2i+1) <= 2^38
+            const double w0 = tw_w(twl[i][0]), q0 = tw_q(twl[i][0], m), w1 = tw_w(twl[i][1]), q1 = tw_q(twl[i][1], m),
+                         w2_ = tw_w(twl[i][2]), q2 = tw_q(twl[i][2], m);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 double u = a[r][0], v = a[r][1];
-                a[r][0] = u + v; a[r][1] = tw_mul<FAST>(u - v, twl[i][0].x, twl[i][0].y, m);
+                a[r][0] = u + v; a[r][1] = tw_mul<FAST>(u - v, w0, q0, m);
                 u = a[r][2]; v = a[r][3];
-                a[r][2] = u + v; a[r][3] = tw_mul<FAST>(u - v, twl[i][1].x, twl[i][1].y, m);
+                a[r][2] = u + v; a[r][3] = tw_mul<FAST>(u - v, w1, q1, m);
                 u = a[r][0]; v = a[r][2];
-                a[r][0] = u + v; a[r][2] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
+                a[r][0] = u + v; a[r][2] = tw_mul<FAST>(u - v, w2_, q2, m);
                 u = a[r][1]; v = a[r][3];
-                a[r][1] = u + v; a[r][3] = tw_mul<FAST>(u - v, twl[i][2].x, twl[i][2].y, m);
+                a[r][1] = u + v; a[r][3] = tw_mul<FAST>(u - v, w2_, q2, m);
                 // Degree 256 with raw int32 inputs: a[0] is the only value no multiply has reduced (the sum of four inputs, up
                 // to 2^33; a[1] <= 2^31.1, a[2], a[3] <= 2^30.1).  Folding it once (2 ops) keeps every later operand below
                 // 2^31.1 * 2^6 = 2^37.1, inside the 4-op multiply's 2^38 bound up to and including the final stage -- which
@@ -558,15 +579,15 @@ __device__ __forceinline__ void inv4_passes(double (&a)[4], double *region, cons
     inv4_passes_n<LOGD, FAST, 1>(reinterpret_cast<double (&)[1][4]>(a), region, twl, twA, m, mm);
 }
 
-template <int LOGD>
-__device__ __forceinline__ void inv4_load_twiddles(double2 (&twl)[LOGD / 2 - 1][3], const double2 *__restrict__ itw2, int mm) {
+template <int LOGD, typename TW = double2>
+__device__ __forceinline__ void inv4_load_twiddles(TW (&twl)[LOGD / 2 - 1][3], const double2 *__restrict__ itw2, int mm) {
     constexpr int D = 1 << LOGD, P = LOGD / 2;
 #pragma unroll
     for (int i = 0; i < P - 1; ++i) {
         const int s = 1 << (2 * i), g = mm / s;
-        twl[i][0] = itw2[D / (2 * s) + 2 * g];
-        twl[i][1] = itw2[D / (2 * s) + 2 * g + 1];
-        twl[i][2] = itw2[D / (4 * s) + g];
+        tw_set(twl[i][0], itw2[D / (2 * s) + 2 * g]);
+        tw_set(twl[i][1], itw2[D / (2 * s) + 2 * g + 1]);
+        tw_set(twl[i][2], itw2[D / (4 * s) + g]);
     }
 }
 
@@ -768,8 +789,8 @@ __device__ __forceinline__ double fz_imad_total(long long hi, long long lo, bool
 // NR independent fp64 dependency chains per wave).
 // PF: how many iterations ahead a wave requests its secret rows (1 or 2; a wave's rows are a sequential chain).  Measured: no
 // difference (see the launcher).
-template <int LOGD, bool FAST, bool IMAD, int NR, int PF>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_t *A, const int32_t *coef,
+template <int LOGD, bool FAST, bool IMAD, int NR, int PF, typename TW>
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 6))) void keygen_fused(const int32_t *A, const int32_t *coef,
                                                                     size_t coef_seg_stride,
                                                                     size_t coef_row_stride, int32_t *sk_hat,
                                                                     int32_t *vk, int l, const double2 *__restrict__ tw2,
@@ -784,8 +805,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
     coef += seg * coef_seg_stride;                      // row stride 0: one secret polynomial per (key, half), as the
     sk_hat += seg * (size_t)l * D;                      // reference's seeded sampler produces (polynomials.py:436-467)
 
-    double2 twl[LOGD / 2 - 1][3];
-    fwd4_load_twiddles<LOGD>(twl, tw2, mm);
+    TW twl[LOGD / 2 - 1][3];
+    fwd4_load_twiddles<LOGD, TW>(twl, tw2, mm);
 
     double acc[4] = {0, 0, 0, 0};
     long long ihi[4] = {0, 0, 0, 0}, ilo[4] = {0, 0, 0, 0};      // IMAD: exact integer sums of y * hi and y * lo
@@ -819,7 +840,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_fused(const int32_
                 ak[r] = *reinterpret_cast<const int4 *>(A + (size_t)(row < l ? row : l - 1) * D + 4 * mm);
             }
             if (task + PF * STEP < tasks) fetch(xq[h], task + PF * STEP);
-            fwd4_passes_n<LOGD, FAST, NR>(a, region, twl, twA, m, mm);
+            fwd4_passes_n<LOGD, FAST, NR, TW>(a, region, twl, twA, m, mm);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int row = (task + r * kWavesPerBlock) * PPW + p;
@@ -907,7 +928,7 @@ __device__ __forceinline__ int centred_any(int64_t v, const FzMod &m) { return (
 // test needs no centring at all -- the inverse transform's outputs r satisfy |r| <= q/2 + q * 2^-13; if |r| <= beta then r is
 // already the centred residue and passes; if |r| > beta then |cent(r)| >= q - |r| >= q/2 - q * 2^-13 > beta (or cent(r) = r):
 // max |r| > beta <=> max |cent(r)| > beta.  Likewise r == 0 (mod q) <=> r == 0, since |r| < q.  Saves 8 of ~180 ops per row.
-template <int LOGD, bool FAST, typename T, bool ORDERED, bool IMAD, int NR>
+template <int LOGD, bool FAST, typename T, bool ORDERED, bool IMAD, int NR, typename TW>
 __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t *A, const T *sig,
                                                                   size_t sig_stride,
                                                                   const T *target, size_t target_stride, int l, long long beta,
@@ -928,8 +949,8 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
     part += (size_t)g * D;                          // [groups][D] exact fp64 sums of `observed`, zero between launches
     state += g;                                     // arrivals (bits 0-15), norm failures (16-23), weight failures (24-31)
 
-    double2 twl[LOGD / 2 - 1][3];
-    inv4_load_twiddles<LOGD>(twl, itw2, mm);
+    TW twl[LOGD / 2 - 1][3];
+    inv4_load_twiddles<LOGD, TW>(twl, itw2, mm);
 
     double acc[4] = {0, 0, 0, 0};
     double mx = 0.0;                                // max |centred output|, kept as a double: |.| <= q/2, exact
@@ -982,7 +1003,7 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
             }
         }
         fetch(task + NR * step < tasks ? task + NR * step : tasks - 1);
-        inv4_passes_n<LOGD, FAST, NR>(a, region, twl, twA, m, mm);
+        inv4_passes_n<LOGD, FAST, NR, TW>(a, region, twl, twA, m, mm);
         // norm and weight of the rows stay in the fp64 lanes (no conversions): a slot past the last row repeats row l - 1, which
         // changes neither the maximum nor any row's weight.  Weight = population count of "non-zero" ballots (scalar unit).
 #pragma unroll
@@ -1170,8 +1191,12 @@ int launch4f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool in
         ctx->prof_kind[ctx->prof_n++] = inverse ? 1 : 0;
     }
     if (nr == 1) {
-        if (ctx->knob_ntt_waves == 1) launch4n<LOGD, FAST, 1, 1>(ctx, in, out, batch, inverse, e0, e1);          // FZ_NTT_WAVES (A/B runs)
-        else if (ctx->knob_ntt_waves == 4) launch4n<LOGD, FAST, 1, 4>(ctx, in, out, batch, inverse, e0, e1);
+        // waves per workgroup: 8 once that still leaves a workgroup for every CU (fewer, fatter workgroups are handed out
+        // sooner), else 4, else 1 -- 4096 rows of degree 64 are 1024 waves: as 128 workgroups they would leave half the chip idle
+        int w = ctx->knob_ntt_waves;                                     // FZ_NTT_WAVES (A/B runs)
+        if (w != 1 && w != 4 && w != 8) w = waves1 >= (size_t)8 * ctx->num_cu ? 8 : (waves1 >= (size_t)4 * ctx->num_cu ? 4 : 1);
+        if (w == 1) launch4n<LOGD, FAST, 1, 1>(ctx, in, out, batch, inverse, e0, e1);
+        else if (w == 4) launch4n<LOGD, FAST, 1, 4>(ctx, in, out, batch, inverse, e0, e1);
         else launch4n<LOGD, FAST, 1, 8>(ctx, in, out, batch, inverse, e0, e1);
     }
     else if (nr == 2) launch4n<LOGD, FAST, 2, 2>(ctx, in, out, batch, inverse, e0, e1);
@@ -1235,8 +1260,10 @@ int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, i
     // combinations measure the same on one box (81.7 / 81.7 / 82.0 / 81.1 us per 1024 keys, profiles/r03_keygen_ab.txt) although
     // their vector-instruction counts differ by 8 % -- the kernel is bound by neither; the defaults are the smallest form (1, 1)
     const bool two = ctx->knob_fused_rows == 2, deep = ctx->knob_fused_prefetch == 2;
-#define FZ_KF4(LOGD, FAST, IM, NR, PF) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, IM, NR, PF>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \
+    const bool single = ctx->knob_fused_tw == 1;                 // FZ_FUSED_TW=1: per-lane twiddles as w alone (quotient twiddle recomputed)
+#define FZ_KF5(LOGD, FAST, IM, NR, PF, TW) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, IM, NR, PF, TW>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \
                                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod)
+#define FZ_KF4(LOGD, FAST, IM, NR, PF) do { if (single) FZ_KF5(LOGD, FAST, IM, NR, PF, double); else FZ_KF5(LOGD, FAST, IM, NR, PF, double2); } while (0)
 #define FZ_KF3(LOGD, FAST, IM, NR) do { if (deep) FZ_KF4(LOGD, FAST, IM, NR, 2); else FZ_KF4(LOGD, FAST, IM, NR, 1); } while (0)
 #define FZ_KF2(LOGD, FAST, IM) do { if (two) FZ_KF3(LOGD, FAST, IM, 2); else FZ_KF3(LOGD, FAST, IM, 1); } while (0)
 #define FZ_KF(LOGD, FAST) do { if (!ctx->knob_no_imad) FZ_KF2(LOGD, FAST, true); else FZ_KF2(LOGD, FAST, false); } while (0)
@@ -1247,6 +1274,7 @@ int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, i
 #undef FZ_KF2
 #undef FZ_KF3
 #undef FZ_KF4
+#undef FZ_KF5
     return fz_check_hip(hipGetLastError(), "keygen_fused launch");
 }
 
@@ -1273,9 +1301,11 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
     // one row group per wave iteration unless FZ_FUSED_ROWS=2: two measured 248.5 us against 243.9 per 8192 aggregates (the
     // kernel is vector-issue bound; the second row costs occupancy and buys no latency hiding it did not already have)
     const bool two = ctx->knob_fused_rows == 2;
-#define FZ_VF4(LOGD, FAST, ORD, IM, NR) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T, ORD, IM, NR>), grid, block, 0, ctx->stream, A, sig, sig_stride, target, \
+    const bool single = ctx->knob_fused_tw == 1;                 // FZ_FUSED_TW=1: per-lane twiddles as w alone (quotient twiddle recomputed)
+#define FZ_VF5(LOGD, FAST, ORD, IM, NR, TW) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T, ORD, IM, NR, TW>), grid, block, 0, ctx->stream, A, sig, sig_stride, target, \
                                                    target_stride, l, (long long)beta, (long long)omega, lazy, (const double2 *)ctx->d_itw2, \
                                                    ctx->itwA, ctx->mod, part, state, d_verdict)
+#define FZ_VF4(LOGD, FAST, ORD, IM, NR) do { if (single) FZ_VF5(LOGD, FAST, ORD, IM, NR, double); else FZ_VF5(LOGD, FAST, ORD, IM, NR, double2); } while (0)
 #define FZ_VF3(LOGD, FAST, ORD, IM) do { if (two) FZ_VF4(LOGD, FAST, ORD, IM, 2); else FZ_VF4(LOGD, FAST, ORD, IM, 1); } while (0)
     // integer accumulation of A * sigma pays its once-per-wave conversion back only over several rows per wave (measured: 1.18 M
     // vector instructions against 1.10 M per launch when the l rows are spread one per wave over 21 workgroups)
@@ -1288,6 +1318,7 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
 #undef FZ_VF2
 #undef FZ_VF3
 #undef FZ_VF4
+#undef FZ_VF5
     rc = fz_check_hip(hipGetLastError(), "verify_fused launch");
     if (rc != FZ_OK) ctx->verify_dirty = 1;          // the accumulators may be left non-zero: re-zeroed before the next launch
     return rc;

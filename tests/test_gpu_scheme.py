@@ -376,3 +376,61 @@ def test_c_caller_runs_the_whole_scheme_flow(tmp_path):
     r = subprocess.run([build_c_example(tmp_path, "scheme_flow")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "verdict 0 (0 = accepted), tampered aggregate: verdict 3" in r.stdout
+
+
+def test_a_captured_aggregation_survives_later_scratch_growth(coracle):
+    """a graph that holds a multi-slice aggregation and a multi-workgroup verification has the addresses of the
+    context's accumulator scratch baked in; later, larger calls on the same context make that scratch grow.  The old
+    allocations must stay valid (retired, not freed) and re-armed, so that replaying the graph afterwards still gives the
+    oracle's aggregate and verdict (fz_retire, csrc/fz_capi.hip)."""
+    import fusion_hip
+    P = O.PARAMS[256]
+    q, d, l = P["q"], P["d"], P["rank"]
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    s = ctx.stream_create()
+    ctx.set_stream(s)
+    rng = np.random.default_rng(77)
+    DB = fusion_hip.DeviceBuffer
+
+    def operands(groups, n):
+        sig = rng.integers(-(q // 2), q // 2, size=(groups * n, l, d)).astype(np.int32)
+        al = rng.integers(-(q // 2), q // 2, size=(groups * n, d)).astype(np.int32)
+        return sig, al
+    A = O.splitmix_centered(5, l * d).reshape(l, d)
+    dA = DB.from_numpy(ctx, A)
+    n = 300                                             # one aggregate of 300 signers: several slices -> accumulator words in use
+    sig, al = operands(1, n)
+    d_sig, d_al = DB.from_numpy(ctx, sig), DB.from_numpy(ctx, al)
+    d_out, d_tgt, d_verd = DB(ctx, l * d * 4), DB(ctx, d * 4), DB(ctx, 4)
+    want = coracle.aggregate_core(sig, al, q)
+    ctx.h2d(d_tgt.ptr, coracle.matvec(A, want, q).astype(np.int32))
+    ctx.aggregate_core_dev(d_sig.ptr, d_al.ptr, d_out.ptr, n, l)          # un-captured first: sizes the scratch
+    ctx.verify_with_target_batch_async_dev(dA.ptr, d_out.ptr, d_tgt.ptr, 1, l, q, d, d_verd.ptr)
+    ctx.synchronize()
+    ctx.graph_begin()
+    ctx.aggregate_core_dev(d_sig.ptr, d_al.ptr, d_out.ptr, n, l)
+    ctx.verify_with_target_batch_async_dev(dA.ptr, d_out.ptr, d_tgt.ptr, 1, l, q, d, d_verd.ptr)
+    g = ctx.graph_end()
+    g.launch()
+    assert np.array_equal(d_out.to_numpy(np.int32, (l, d)), want) and d_verd.to_numpy(np.int32, (1,)).tolist() in ([0], [4])
+    first = d_verd.to_numpy(np.int32, (1,)).tolist()
+    # larger calls on the same context: more aggregates with several slices each, more multi-workgroup verifications
+    big_sig, big_al = operands(6, 40)
+    b_sig, b_al, b_part = DB.from_numpy(ctx, big_sig), DB.from_numpy(ctx, big_al), DB(ctx, 6 * l * d * 8)
+    ctx.aggregate_partial_batch_dev(b_sig.ptr, b_al.ptr, b_part.ptr, l * d, 6, 40, l)
+    b_tgt, b_verd = DB(ctx, 40 * d * 4), DB(ctx, 40 * 4)
+    many = rng.integers(-50, 50, size=(40, l, d)).astype(np.int32)
+    b_many = DB.from_numpy(ctx, many)
+    ctx.verify_with_target_batch_async_dev(dA.ptr, b_many.ptr, b_tgt.ptr, 40, l, q, d, b_verd.ptr)
+    ctx.synchronize()
+    for _ in range(3):                                   # the graph still works on its (retired) scratch
+        ctx.h2d(d_out.ptr, np.zeros((l, d), np.int32))
+        g.launch()
+        assert np.array_equal(d_out.to_numpy(np.int32, (l, d)), want)
+        assert d_verd.to_numpy(np.int32, (1,)).tolist() == first
+    g.destroy()
+    ctx.set_stream(0)
+    ctx.stream_destroy(s)
+    for b in (dA, d_sig, d_al, d_out, d_tgt, d_verd, b_sig, b_al, b_part, b_tgt, b_verd, b_many):
+        b.free()
+    ctx.close()

@@ -24,6 +24,9 @@ step timeout -k 10 200 python tools/copy_bw.py > $OUT/${TAG}_copy_ceiling.txt 2>
 step timeout -k 10 200 python tools/dispatch_dist.py > $OUT/${TAG}_dispatch_distribution.txt 2>&1
 step timeout -k 10 300 python tools/numa_placement.py > $OUT/${TAG}_numa_placement.txt 2>&1
 for st in none 0 1; do FZ_NO_PIN=1 timeout -k 10 100 python tools/numa_switch.py $st >> $OUT/${TAG}_numa_placement.txt 2>&1; done
+step timeout -k 10 200 python tools/keccak_bench.py > $OUT/${TAG}_keccak_variants_gpu_host.txt 2>&1
+step timeout -k 10 300 ./tools/microbench/build/ntt_variants 300 > $OUT/${TAG}_ntt_variants_current_kernels.txt 2>&1
+step timeout -k 10 400 bash tools/keygen_ab.sh > $OUT/${TAG}_keygen_ab.txt 2>&1
 step timeout -k 10 500 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations from the profiler: the bench's transform launches, the cold kernel table, the challenge pipeline

@@ -495,6 +495,22 @@ def main():
                         "single_dispatch_ceiling: the fraction a plain copy of the headline's bytes reaches in this run -- no kernel of "
                         "that byte count can do better, an EMPTY dispatch already costs 1.5-1.9 us (profiles/r03_ntt_variants_per_dispatch.txt)"}
 
+    def rocprof_reference():
+        """what rocprofv3 --kernel-trace measured for the same launch in the committed collection (profiles/): the third clock on
+        the dominant kernel, next to `avg_launch_us` (begin / end events on every dispatch, launched one by one) and
+        `region.avg_launch_us` (the un-instrumented graph replay)"""
+        try:
+            import csv
+            with open(os.path.join(ROOT, "profiles", "r03_bench_rocprofv3_by_grid.csv")) as fh:
+                rows = [r for r in csv.DictReader(fh) if r["kernel"].startswith("ntt_fwd4<8") and int(r["grid_threads"]) == B * 64]
+            r = max(rows, key=lambda r_: int(r_["calls"]))
+            us = float(r["avg_us"])
+            return {"kernel": r["kernel"], "dispatches": int(r["calls"]), "avg_us": us, "frac": 8.0 * d * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "source": "profiles/r03_bench_rocprofv3_by_grid.csv (rocprofv3 --kernel-trace --stats over this script, committed; "
+                              "most dispatches graph-replayed)"}
+        except Exception:
+            return None
+
     def build_line(watchdog=None):
         # HBM-side traffic of this launch from the PMC counters (rocprofv3 --pmc, separate passes; FETCH_SIZE corrected x2
         # for gfx950) cannot be collected live: the committed measurement of THIS round's kernel is reported, or null
@@ -502,8 +518,8 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r03_pmc_ntt.json")) as fh:
                 kernels_pmc = json.load(fh)["kernels"]
-            key = next(k for k in kernels_pmc if k.startswith("ntt_fwd4<8") and "B=4096" in k)
-            traffic = kernels_pmc[key]["traffic_bytes_per_launch"]
+            # the bench's 4096-row launch (a 64-row call of the PCIe leg runs the same kernel with a smaller grid: take the largest)
+            traffic = max(v["traffic_bytes_per_launch"] for k, v in kernels_pmc.items() if k.startswith("ntt_fwd4<8") and "B=4096" in k)
             traffic_note = "profiles/r03_pmc_ntt.json (PMC pass of the same launch, committed this round)"
         except Exception:
             pass
@@ -538,7 +554,7 @@ def main():
                                     "what": "HIP events around the timed region on the kernels' stream / launches "
                                             "(consecutive dispatches overlap their launch and drain phases)"},
                          "copy_floor": floor, "multi_job": multi, "kernels": kernels, "sweep": sweep,
-                         "target": target_block()},
+                         "target": target_block(), "rocprofv3": rocprof_reference()},
             "cold_batches": cold, "two_stream_pipelined": two_stream, "sign_verify": sv, "end_to_end": e2e, "pcie_inclusive": pcie,
         }
         if watchdog:
@@ -1020,6 +1036,11 @@ def main():
             ok, why = bs.verify(vk_e, msgs, agg_e)
             t_ver = time.perf_counter() - t0
             assert ok, why
+            bs.aggregate_verify(vk_e, msgs, sig_e)
+            t0 = time.perf_counter()
+            agg_av, (ok, why) = bs.aggregate_verify(vk_e, msgs, sig_e)     # one hash_ag for both, one pass over the signatures
+            t_av = time.perf_counter() - t0
+            assert ok and np.array_equal(agg_av, agg_e), why
             # a larger batch of signatures: the device pipeline is a latency chain of ~108 Keccak permutations per signer,
             # the same ~0.7 ms for any batch up to 32 768 signers (two lanes per signer, one wave per SIMD)
             n_big = 16384
@@ -1064,6 +1085,9 @@ def main():
                    "sign_per_s_at_16384_signatures": n_big / t_sign_big,
                    "aggregate_per_s": n_e2e / t_agg, "verify_per_s": n_e2e / t_ver,
                    "sign_plus_verify_per_s": n_e2e / (t_sign + t_agg + t_ver),
+                   "aggregate_verify_per_s": n_e2e / t_av, "sign_plus_aggregate_verify_per_s": n_e2e / (t_sign + t_av),
+                   "aggregate_verify_what": "BatchScheme.aggregate_verify: aggregate() and verify() of its result with ONE hash_ag (the serial "
+                                            "sponge runs once instead of twice) and one pass over the signatures",
                    "note": "BatchScheme with device-resident keys and signatures: reference-exact MT19937 sampling of the secret "
                            "polynomials, the per-signer challenge pipeline (message pre-hash included) and all algebra on the device; aggregate and "
                            "verify are bounded by hash_ag, ONE serial SHAKE-256 over ~13.5 KB per signer on the host by construction "
@@ -1128,6 +1152,9 @@ def main():
         elif e2e is None and rank == 0:
             e2e = {"sharded": e2e_sh}
 
+    if _BAILING.is_set():                               # the watchdog fired while a leg was (slowly) finishing: its line stands, and
+        time.sleep(15.0)                                # its thread ends the process with code 3 -- never a second line, never rc 0
+        os._exit(3)
     stage[0] = "cpu_baseline"
     done.set()                                          # the bounded CPU sample is not under the watchdog
     if rank == 0:

@@ -109,6 +109,19 @@ class CommCollective:
         buf.free()
 
 
+class LocalCollective(CommCollective):
+    """No exchange: one rank holds every signer (world size 1).  Lets the one-pass form -- partial sums of aggregate and
+    verification target in ONE pass over the signatures, verification straight from the sums, ONE hash_ag for both --
+    serve a single GPU as well (BatchScheme.aggregate_verify)."""
+    name = "none (single rank)"
+
+    def __init__(self, ctx):
+        self.ctx, self.comm = ctx, None
+
+    def allreduce(self, buf):
+        pass
+
+
 class ShardedScheme:
     """aggregate() and verify() of the reference with the SIGNERS sharded over ranks -- one process per GPU, rank r holds
     the signatures of its contiguous block [lo, hi) of the callers' list (shard_range) in its GPU's memory.

@@ -261,6 +261,14 @@ class BatchScheme:
             if own:
                 dS.free()
 
+    def aggregate_verify(self, vk, messages, sig):
+        """aggregate() followed by verify() of the result on the same keys and messages, as an aggregator that checks its own
+        output does: -> (aggregate [l][d], (ok, reason)).  hash_ag -- the one serial SHAKE-256 over all signers that bounds both
+        calls end to end -- runs ONCE instead of twice, the signatures are read once (aggregate and verification target in one
+        pass), and the verdict comes straight from the int64 sums.  Same values as aggregate(...) and verify(..., aggregate)."""
+        from .dist import LocalCollective, ShardedScheme
+        return ShardedScheme(self, 0, 1, LocalCollective(self.ctx)).aggregate_verify_sharded(vk, messages, sig)
+
     def verify(self, vk, messages, aggregate):
         """-> (bool, reason) with the reference's reason strings (fusion.py:680-728)"""
         n = (vk.shape[0] if isinstance(vk, DeviceArray) else np.asarray(vk).reshape(-1, 2, self.d).shape[0])

@@ -54,6 +54,8 @@ def test_batch_scheme_at_many_signers_equals_the_reference(secpar):
         agg = bs.aggregate(v, ms, sg)
         assert np.array_equal(agg, S[f"agg_{lo}_{hi}"])
         assert list(bs.verify(v, ms, agg)) == info["verdict"]
+        agg1, verdict1 = bs.aggregate_verify(v, ms, sg)                          # one hash_ag, one pass over the signatures
+        assert np.array_equal(agg1, agg) and list(verdict1) == info["verdict"]
         bad = agg.copy()
         bad[info["tampered_at"][0], info["tampered_at"][1]] += 1
         assert list(bs.verify(v, ms, bad)) == info["tampered_verdict"]

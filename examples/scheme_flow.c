@@ -6,6 +6,7 @@
  *   aggregator  fz_sort_by_vk_string + fz_aggregation_coefficients (hash_ag: ONE serial XOF, host) + fz_ntt_forward_host,
  *               fz_aggregate_core
  *   verifier    fz_verify_core -> verdict code; a tampered aggregate must be rejected
+ *   many aggregates in one launch: fz_aggregate_core_ragged over signer blocks of different sizes (linearity check)
  *   gcc -std=c99 -Iinclude examples/scheme_flow.c -o scheme_flow -Lfusion-cryptography_amd/lib -lfusion_hip \
  *       -Wl,-rpath,$PWD/fusion-cryptography_amd/lib
  * Exit code 0 = the aggregate verifies and the tampered one does not.  (tests/test_cabi_symbols.py compiles it;
@@ -102,6 +103,22 @@ int main(void) {
     CHECK(fz_verify_core(ctx, (const int32_t *)d_A, (const int32_t *)d_agg, (const int32_t *)d_vkL, (const int32_t *)d_vkR,
                          (const int32_t *)d_c, (const int32_t *)d_al, N, L, beta_vf, omega_vf, &verdict));
     CHECK(fz_memcpy_d2h(ctx, agg, d_agg, sizeof agg));
+    {   /* blocks of 24 and 40 signers as two aggregates of ONE launch: with the same coefficients their sum is the aggregate */
+        static int32_t two[2][L][D];
+        const size_t blocks[3] = {0, 24, N};
+        void *d_two = NULL;
+        int j;
+        CHECK(fz_malloc(ctx, sizeof two, &d_two));
+        CHECK(fz_aggregate_core_ragged(ctx, (const int32_t *)d_sig, (const int32_t *)d_al, blocks, 2, L, (int32_t *)d_two));
+        CHECK(fz_memcpy_d2h(ctx, two, d_two, sizeof two));
+        CHECK(fz_free(ctx, d_two));
+        for (k = 0; k < L; ++k)
+            for (j = 0; j < D; ++j)
+                if (((int64_t)two[0][k][j] + two[1][k][j] - agg[k][j]) % P.modulus != 0) {
+                    fprintf(stderr, "ragged aggregation: block sums differ from the aggregate at [%d][%d]\n", k, j);
+                    return 4;
+                }
+    }
     agg[L - 1][D - 1] += 1;
     CHECK(fz_memcpy_h2d(ctx, d_agg, agg, sizeof agg));
     CHECK(fz_verify_core(ctx, (const int32_t *)d_A, (const int32_t *)d_agg, (const int32_t *)d_vkL, (const int32_t *)d_vkR,

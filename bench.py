@@ -447,20 +447,36 @@ def main():
     # condition rocprofv3 --kernel-trace puts every dispatch in, and the two averages agree (4.73 vs 4.61 us).
     # Three passes of 400 steps; the pass with the lowest mean is reported (all three are listed): a pass now and then has
     # a tail of 10-30 us samples from outside the kernel (the host's launch rate drops in the same pass; the median stays).
-    n_inst, passes = 400, []
-    for _ in range(3):
-        prewarm(step, 20.0)                             # dense launches first: a one-by-one pass leaves the device half idle
-        ctx.profile_begin(2 * n_inst, args.sample_every)
-        rc = 0
-        for _ in range(n_inst):
-            rc |= step()
-        assert rc == 0, f"launch failed: {lib.fz_last_error()}"
-        us, kind = ctx.profile_end_samples(2 * n_inst)
-        f_, i_ = us[kind == 0], us[kind == 1]
-        assert len(f_) == len(i_) == (n_inst + args.sample_every - 1) // args.sample_every
-        passes.append({"fwd_avg_us": float(f_.mean()), "inv_avg_us": float(i_.mean()), "fwd_median_us": float(np.median(f_)),
-                       "inv_median_us": float(np.median(i_)), "fwd_max_us": float(f_.max()), "fwd_count": int(len(f_))})
+    # The roofline is an HBM roofline, so the passes that feed `achieved` read COLD operands: the steps rotate through 32
+    # batches (x_i -> y_i -> z_i, 384 MiB together), no launch finds its input in a cache.  Three more passes on the ONE warm
+    # batch of the timed region are listed beside them (`passes_warm`).
+    n_inst, passes, passes_warm = 400, [], []
+    nb_rot = 32
+    rot = [(x.clone(), torch.empty_like(x), torch.empty_like(x)) for _ in range(nb_rot)]
+    rot_p = [tuple(ctypes.c_void_p(t.data_ptr()) for t in trio) for trio in rot]
+    rot_i = [0]
+
+    def step_cold():
+        a_, b_, c_ = rot_p[rot_i[0] % nb_rot]
+        rot_i[0] += 1
+        return fz_fwd(h, a_, b_, nB) | fz_inv(h, b_, c_, nB)
+    for fn, out_list in ((step_cold, passes), (step, passes_warm)):
+        for _ in range(3):
+            prewarm(fn, 20.0)                           # dense launches first: a one-by-one pass leaves the device half idle
+            ctx.profile_begin(2 * n_inst, args.sample_every)
+            rc = 0
+            for _ in range(n_inst):
+                rc |= fn()
+            assert rc == 0, f"launch failed: {lib.fz_last_error()}"
+            us, kind = ctx.profile_end_samples(2 * n_inst)
+            f_, i_ = us[kind == 0], us[kind == 1]
+            assert len(f_) == len(i_) == (n_inst + args.sample_every - 1) // args.sample_every
+            out_list.append({"fwd_avg_us": float(f_.mean()), "inv_avg_us": float(i_.mean()), "fwd_median_us": float(np.median(f_)),
+                             "inv_median_us": float(np.median(i_)), "fwd_max_us": float(f_.max()), "fwd_count": int(len(f_))})
+    torch.cuda.synchronize(dev)
+    assert all(torch.equal(t[2], x) for t in rot), "INTT(NTT(x)) != x on the rotating batches"
     prof = min(passes, key=lambda p_: p_["fwd_avg_us"])
+    prof_warm = min(passes_warm, key=lambda p_: p_["fwd_avg_us"])
     fwd_avg, inv_avg = prof["fwd_avg_us"] * 1e-3, prof["inv_avg_us"] * 1e-3      # ms
     elapsed = max_over_ranks(elapsed)
     value = 2.0 * B * total_steps * world / elapsed
@@ -537,18 +553,21 @@ def main():
                        "prewarm_ms": args.prewarm_ms,
                        "host_threads_on": placement or "all allowed CPUs (no GPU-local NUMA node found, or FZ_NO_PIN=1)"},
             "ranks": ranks,
-            "roofline": {"bound": "hbm", "inputs": "the timed region and the per-dispatch passes re-read ONE 4 MiB batch (cache-warm after the first "
-                                                   "step: `value` and `achieved` are best-case figures); `cold_batches` repeats the steps over 32 "
-                                                   "batches, roofline.kernels / target.met_from_rows are measured on cold operands",
+            "roofline": {"bound": "hbm", "inputs": "`achieved` / `avg_launch_us` / `passes`: per-dispatch events on steps that ROTATE through 32 batches "
+                                                   "(384 MiB: every launch reads its input from HBM); `passes_warm` / `warm_*`: the same on the one "
+                                                   "batch the timed region re-reads; `value` is the timed region (inputs resident in HBM, cache-warm "
+                                                   "after the first step), `cold_batches` the same steps over the 32 batches",
                          "kernel": "ntt_fwd4<8, true, 1, 8> (forward NTT, B=4096: one row per wave, 8-wave workgroups)", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_note,
                          "bytes_per_launch": fwd_bytes, "butterflies_per_s": value * (d // 2) * 8, "avg_launch_us": fwd_avg * 1e3,
                          "inverse_avg_launch_us": inv_avg * 1e3, "launches_timed": prof["fwd_count"],
                          "median_launch_us": prof["fwd_median_us"], "passes": passes,
+                         "passes_warm": passes_warm, "warm_avg_launch_us": prof_warm["fwd_avg_us"],
+                         "warm_frac": fwd_bytes / (prof_warm["fwd_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "timing": f"per-dispatch begin/end events (hipExtLaunchKernelGGL) on every {args.sample_every}th dispatch of "
-                                   f"{n_inst} steps launched one by one right after the timed region (a hipGraph cannot carry them); "
-                                   f"mean over the launches of the best of 3 such passes",
+                                   f"{n_inst} steps launched one by one right after the timed region (a hipGraph cannot carry them), the steps "
+                                   f"rotating through {nb_rot} batches (cold inputs); mean over the launches of the best of 3 such passes",
                          "region": {"avg_launch_us": region_launch_us, "achieved": fwd_bytes / (region_launch_us * 1e-6) / 1e9,
                                     "frac": fwd_bytes / (region_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                     "what": "HIP events around the timed region on the kernels' stream / launches "
@@ -646,11 +665,9 @@ def main():
     stage[0] = "cold"
     if rank == 0 and not args.no_two_stream:
         try:
-            nb_c = 32
-            xc = [x.clone() for _ in range(nb_c)]
-            yc = [torch.empty_like(x) for _ in range(nb_c)]
-            zc = [torch.empty_like(x) for _ in range(nb_c)]
-            pc = [tuple(ctypes.c_void_p(t.data_ptr()) for t in trio) for trio in zip(xc, yc, zc)]
+            nb_c = nb_rot                                # the rotation the per-dispatch passes used
+            zc = [t[2] for t in rot]
+            pc = rot_p
             kc = max(nb_c, min(args.steps, 1000))
             torch.cuda.synchronize(dev)
 
@@ -679,7 +696,7 @@ def main():
                     "what": "the same step, cycling through 32 resident batches so that no step finds its input in a cache"}
             if gc:
                 gc.destroy()
-            del xc, yc, zc, pc
+            del zc, pc
         except Exception as exc:                      # a side leg must never take the headline down with it
             import traceback
             traceback.print_exc()

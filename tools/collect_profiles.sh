@@ -11,6 +11,11 @@ mkdir -p $OUT
 cd $R
 step() { echo "[collect] $*" >&2; "$@" || { echo "[collect] FAILED ($?): $*" >&2; exit 1; }; }
 lscpu | grep -E "Model name|Socket|Thread|Core" > $OUT/${TAG}_host_cpu.txt
+# the stand-alone microbenchmarks travel prebuilt (tools/microbench/build/, git-ignored); build whatever is missing
+mkdir -p tools/microbench/build
+for mb in launch_floor ntt_variants; do
+  [ -x tools/microbench/build/$mb ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/microbench/$mb.hip -o tools/microbench/build/$mb
+done
 step timeout -k 10 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
 step timeout -k 10 120 ./tools/microbench/build/launch_floor > $OUT/${TAG}_launch_floor.txt 2>&1
 step timeout -k 10 300 python tools/kernel_table.py > $OUT/${TAG}_kernel_table.txt 2>&1

@@ -4,6 +4,7 @@ reference-generated signer set.  Every rank regenerates ONLY its block's keys an
 (they are public), and runs aggregate_verify_sharded / verify_sharded with a real torch.distributed collective (gloo: the
 ranks share the test box's one GPU; with a GPU per rank the same code runs over RCCL).
 argv: rank world port secpar kind lo hi out_dir      kind = "many" (scheme_many_*.npz) | "small" (scheme_*.npz)"""
+import hashlib
 import json
 import os
 import sys
@@ -25,6 +26,10 @@ if kind == "many":
     S = np.load(os.path.join(G, f"scheme_many_{secpar}.npz"))
     with open(os.path.join(G, "scheme_many.json")) as fh:
         meta = json.load(fh)[str(secpar)]
+elif kind == "full":                                # configs[3] at its stated size: the keys are regenerated (and digest-checked by the test)
+    S = None
+    with open(os.path.join(G, "scheme_full.json")) as fh:
+        meta = json.load(fh)[str(secpar)]
 else:
     S = np.load(os.path.join(G, f"scheme_{secpar}.npz"))
     with open(os.path.join(G, "scheme.json")) as fh:
@@ -34,7 +39,11 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 torch.cuda.set_device(0)
 params = F.fusion_setup(secpar, meta["setup_seed"])
 bs = BatchScheme(params, device=0, threads=4)
-vk_all = S["vk"][lo_s:hi_s]                       # public: every rank has all verification keys (reference-generated)
+if kind == "full":                                # 2 MiB of public keys: every rank derives them from the public seeds
+    _, vk_all = bs.keygen_batch(meta["key_seeds"][lo_s:hi_s])
+    meta["agg"] = {f"{lo_s}_{hi_s}": {"tampered_at": meta["tampered_at"]}}
+else:
+    vk_all = S["vk"][lo_s:hi_s]                   # public: every rank has all verification keys (reference-generated)
 msgs = meta["messages"][lo_s:hi_s]
 seeds = meta["key_seeds"][lo_s:hi_s]
 n = hi_s - lo_s
@@ -51,15 +60,15 @@ agg, verdict = sh.aggregate_verify_sharded(vk_all, msgs, sig)
 agg2 = sh.aggregate_sharded(vk_all, msgs, sig)
 ver2 = sh.verify_sharded(vk_all, msgs, agg)
 bad = agg.copy()
-t_row, t_col = meta["agg"][f"{lo_s}_{hi_s}"]["tampered_at"] if kind == "many" else (0, 0)
+t_row, t_col = meta["agg"][f"{lo_s}_{hi_s}"]["tampered_at"] if kind in ("many", "full") else (0, 0)
 bad[t_row, t_col] += 1
 ver_bad = sh.verify_sharded(vk_all, msgs, bad)
 swapped = list(msgs)
 swapped[0], swapped[-1] = swapped[-1], swapped[0]
 ver_swapped = sh.verify_sharded(vk_all, swapped, agg)
 ver_short = sh.verify_sharded(vk_all, msgs[:-1], agg)
-np.savez(os.path.join(out_dir, f"rank{rank}.npz"), agg=agg, agg2=agg2, lo=lo, hi=hi,
-         sig_sha=np.array([__import__("hashlib").sha256(np.ascontiguousarray(r, dtype="<i4").tobytes()).hexdigest() for r in sig_host]))
+np.savez(os.path.join(out_dir, f"rank{rank}.npz"), agg=agg, agg2=agg2, lo=lo, hi=hi, vk_sha=hashlib.sha256(np.ascontiguousarray(vk_all, dtype="<i4").tobytes()).hexdigest(),
+         sig_sha=np.array([hashlib.sha256(np.ascontiguousarray(r, dtype="<i4").tobytes()).hexdigest() for r in sig_host]))
 with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
     json.dump(dict(verdict=list(verdict), verify=list(ver2), tampered=list(ver_bad), swapped=list(ver_swapped),
                    short=list(ver_short)), fh)

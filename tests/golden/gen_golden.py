@@ -301,6 +301,73 @@ def gen_scheme_many():
         json.dump(meta, f)
 
 
+def _full_worker(job):
+    """one process of gen_scheme_full: the reference's keygen + sign for a block of signers -> (vk rows, signature rows)"""
+    secpar, setup_seed, seeds, msgs = job
+    params = F.fusion_setup(secpar, setup_seed)
+    vks, sigs = [], []
+    for s_, m_ in zip(seeds, msgs):
+        k = F.keygen(params, s_)
+        vks.append(np.stack([mat_values(k[1].left_vk_hat)[0], mat_values(k[1].right_vk_hat)[0]]))
+        sigs.append(mat_values(F.sign(params, k, m_).signature_hat))
+    return np.stack(vks), np.stack(sigs)
+
+
+def gen_scheme_full(secpar=256, n=1024, setup_seed=31415, procs=8):
+    """BASELINE configs[3] AT ITS STATED SIZE through the reference: 1024 distinct signers at secpar 256 -- keygen and sign in
+    `procs` processes (the reference is single-threaded: ~0.8 s per signer), then ONE aggregate() and ONE verify() over all of
+    them.  Stored: the sorted order, SHA-256 of every verification key / signature row (the build regenerates them from the
+    seeds), SHA-256 of the aggregation coefficients in sorted order, the aggregate itself, verdict and tamper verdict."""
+    from multiprocessing import Pool
+    t0 = time.time()
+    seeds = [7_000_003 + 104_729 * i for i in range(n)]
+    msgs = [f"transfer #{i:05d}: {1000 + (i * 37) % 9000} units" for i in range(n)]
+    blocks = [(secpar, setup_seed, seeds[i::procs], msgs[i::procs]) for i in range(procs)]
+    with Pool(procs) as pool:
+        parts = pool.map(_full_worker, blocks)
+    vk = np.empty((n, 2, parts[0][0].shape[-1]), dtype=np.int32)
+    sig = np.empty((n,) + parts[0][1].shape[1:], dtype=np.int32)
+    for i, (v_, s_) in enumerate(parts):
+        vk[i::procs], sig[i::procs] = v_, s_
+    print(f"scheme_full: {n} keygen + sign in {time.time() - t0:.0f} s")
+    params = F.fusion_setup(secpar, setup_seed)
+
+    def poly(v):
+        return PolyN(modulus=params.modulus, degree=params.degree, root=params.root, inv_root=params.inv_root,
+                     root_order=params.root_order, values=[int(x) for x in v])
+    first = poly(vk[0, 0])
+
+    def like(v):                    # the reference re-proves the primitive root in every constructor: clone instead
+        import copy
+        z = copy.copy(first)
+        z.values = [int(x) for x in v]
+        return z
+    vks = [F.OneTimeVerificationKey(left_vk_hat=GeneralMatrix(matrix=[[like(vk[i, 0])]]),
+                                    right_vk_hat=GeneralMatrix(matrix=[[like(vk[i, 1])]])) for i in range(n)]
+    sigs = [F.Signature(signature_hat=GeneralMatrix(matrix=[[like(r)] for r in sig[i]])) for i in range(n)]
+    order = sorted(range(n), key=lambda i: str(vks[i]))
+    t1 = time.time()
+    alphas = F.hash_ag(params, [vks[i] for i in order], [msgs[i] for i in order])
+    agg = F.aggregate(params, vks, msgs, sigs)
+    print(f"scheme_full: hash_ag + aggregate in {time.time() - t1:.0f} s")
+    t1 = time.time()
+    verdict = F.verify(params, vks, msgs, agg)
+    assert verdict == (True, ""), verdict
+    agg.signature_hat.matrix[11][0].values[7] += 1
+    bad = F.verify(params, vks, msgs, agg)
+    agg.signature_hat.matrix[11][0].values[7] -= 1
+    print(f"scheme_full: 2 x verify in {time.time() - t1:.0f} s")
+    alpha_sorted = np.array([a.alpha_hat.values for a in alphas], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, f"scheme_full_{secpar}.npz"), agg=mat_values(agg.signature_hat),
+                        order=np.array(order, dtype=np.int32))
+    with open(os.path.join(HERE, "scheme_full.json"), "w") as f:
+        json.dump({str(secpar): dict(secpar=secpar, setup_seed=setup_seed, n=n, key_seeds=seeds, messages=msgs,
+                                     sha256_vk=sha_i32(vk), sha256_sig=sha_i32(sig), sha256_sig_rows_first8=[sha_i32(r) for r in sig[:8]],
+                                     sha256_alpha_hat_sorted=sha_i32(alpha_sorted), verdict=list(verdict), tampered_verdict=list(bad),
+                                     tampered_at=[11, 7], sha256_str_agg=sha_str(str(agg)))}, f)
+    print(f"scheme_full secpar={secpar}: {n} signers, {time.time() - t0:.0f} s in all")
+
+
 def gen_kat_flow(seed=20261004, sigs=8):
     """VERDICT r02 task 2b: SHA-256 of every row (`str(inputs)`, `str(outputs)`) the flow of the reference's
     KATs/generate_KAT_values.py:36-147 produces, run through the REFERENCE's functions in the reference's order, with
@@ -413,6 +480,8 @@ def gen_kat():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["algebra", "bulk", "scheme", "kat", "many", "kat_flow"]
+    if "full" in sys.argv[1:]:                  # ~10 minutes on 8 cores: only on request
+        gen_scheme_full()
     if "many" in which:
         gen_scheme_many()
     if "kat_flow" in which:

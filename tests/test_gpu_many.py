@@ -137,3 +137,49 @@ def test_drop_in_object_api_at_32_signers_prints_the_reference_strings():
         r, c = info["tampered_at"]
         agg.signature_hat.matrix[r][0].values[c] += 1
         assert list(F.verify(params, vks[lo:hi], m["messages"][lo:hi], agg)) == info["tampered_verdict"]
+
+
+def _full():
+    p = os.path.join(G, "scheme_full_256.npz")
+    if not os.path.exists(p):
+        pytest.skip("tests/golden/scheme_full_256.npz not generated (gen_golden.py full)")
+    with open(os.path.join(G, "scheme_full.json")) as fh:
+        return np.load(p), json.load(fh)["256"]
+
+
+def test_configs3_at_its_stated_size_equals_the_reference():
+    """BASELINE configs[3] AT FULL SIZE against the REFERENCE ITSELF: 1024 distinct signers at secpar 256 -- the reference's
+    keygen, sign, ONE aggregate() and ONE verify() over all of them (tests/golden/gen_golden.py full: ~10 minutes on 8 cores).
+    Keys, signatures and aggregation coefficients are compared by SHA-256 of the whole arrays, the sort order and the
+    aggregate element by element, verdict and tamper verdict literally."""
+    import fusion.fusion as F
+    from fusion_hip.scheme import BatchScheme
+    S, m = _full()
+    params = F.fusion_setup(256, m["setup_seed"])
+    bs = BatchScheme(params)
+    sk, vk, vk_dev = bs.keygen_batch(m["key_seeds"], device=True, keep_vk=True)
+    assert sha_i32(vk) == m["sha256_vk"]
+    sig = bs.sign_batch(sk, vk_dev, m["messages"], device=True)
+    sig_host = sig.numpy()
+    assert sha_i32(sig_host) == m["sha256_sig"]
+    assert [sha_i32(r) for r in sig_host[:8]] == m["sha256_sig_rows_first8"]
+    dC, dAl, order, _, _ = bs.hash_ag_dev(vk, m["messages"])
+    assert np.array_equal(order, S["order"])                                     # sorted(key=str(vk)) over 1024 keys
+    assert sha_i32(dAl.numpy()[order]) == m["sha256_alpha_hat_sorted"]             # hash_ag over 1024 tuples
+    dC.free()
+    dAl.free()
+    agg = bs.aggregate(vk, m["messages"], sig)
+    assert np.array_equal(agg, S["agg"])
+    assert list(bs.verify(vk, m["messages"], agg)) == m["verdict"] == [True, ""]
+    agg1, v1 = bs.aggregate_verify(vk, m["messages"], sig)
+    assert np.array_equal(agg1, S["agg"]) and list(v1) == m["verdict"]
+    bad = agg.copy()
+    bad[m["tampered_at"][0], m["tampered_at"][1]] += 1
+    assert list(bs.verify(vk, m["messages"], bad)) == m["tampered_verdict"]
+    # the same 1024 signers as 4 aggregates of 256 in one batch: each equals a single call on its block
+    aggs = bs.aggregate_many(vk, m["messages"], sig, [256] * 4)
+    for g in (0, 3):
+        assert np.array_equal(aggs[g], bs.aggregate(vk[256 * g:256 * (g + 1)], m["messages"][256 * g:256 * (g + 1)], sig_host[256 * g:256 * (g + 1)]))
+    assert bs.verify_many(vk, m["messages"], aggs, [256] * 4) == [(True, "")] * 4
+    for b in (sk, vk_dev, sig):
+        b.free()

@@ -65,3 +65,23 @@ def test_sharded_flow_equals_the_reference_small(secpar, n, world, tmp_path):
         assert np.array_equal(r["agg"], S[f"agg_{n}"]) and np.array_equal(r["agg2"], S[f"agg_{n}"])
         assert j["verdict"] == m["agg"][str(n)]["verdict"] and j["verify"] == m["agg"][str(n)]["verdict"]
         assert j["tampered"] == m["agg"][str(n)]["tampered_verdict"]
+
+
+def test_configs3_sharded_at_its_stated_size_equals_the_reference(tmp_path):
+    """BASELINE configs[3]: 1024 signers at secpar 256, sharded over 3 ranks (342 / 341 / 341 signatures each, resident on the
+    device), against the aggregate the REFERENCE computed over all 1024 (tests/golden/scheme_full_256.npz)"""
+    p = os.path.join(G, "scheme_full_256.npz")
+    if not os.path.exists(p):
+        pytest.skip("tests/golden/scheme_full_256.npz not generated (gen_golden.py full)")
+    S = np.load(p)
+    with open(os.path.join(G, "scheme_full.json")) as fh:
+        m = json.load(fh)["256"]
+    R, J = run_ranks(3, [256, "full", 0, m["n"]], tmp_path)
+    assert [int(r["hi"]) - int(r["lo"]) for r in R] == [342, 341, 341]
+    for r, j in zip(R, J):
+        assert str(r["vk_sha"]) == m["sha256_vk"]
+        assert np.array_equal(r["agg"], S["agg"]) and np.array_equal(r["agg2"], S["agg"])
+        assert j["verdict"] == m["verdict"] == [True, ""] and j["verify"] == m["verdict"]
+        assert j["tampered"] == m["tampered_verdict"]
+        assert j["swapped"] == [False, "Target doesn't match image of aggregate signature."]
+    assert [x for r in R for x in r["sig_sha"].tolist()][:8] == m["sha256_sig_rows_first8"]

@@ -360,8 +360,13 @@ def gen_scheme_full(secpar=256, n=1024, setup_seed=31415, procs=8):
     alpha_sorted = np.array([a.alpha_hat.values for a in alphas], dtype=np.int32)
     np.savez_compressed(os.path.join(HERE, f"scheme_full_{secpar}.npz"), agg=mat_values(agg.signature_hat),
                         order=np.array(order, dtype=np.int32))
-    with open(os.path.join(HERE, "scheme_full.json"), "w") as f:
-        json.dump({str(secpar): dict(secpar=secpar, setup_seed=setup_seed, n=n, key_seeds=seeds, messages=msgs,
+    meta_path = os.path.join(HERE, "scheme_full.json")
+    meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+    too_many = None
+    if n == params.capacity:                    # one signer more than the capacity: the reference refuses before any arithmetic
+        too_many = list(F.verify(params, vks + [vks[0]], msgs + [msgs[0]], agg))
+    with open(meta_path, "w") as f:
+        json.dump({**meta, str(secpar): dict(too_many_verdict=too_many, capacity=params.capacity, secpar=secpar, setup_seed=setup_seed, n=n, key_seeds=seeds, messages=msgs,
                                      sha256_vk=sha_i32(vk), sha256_sig=sha_i32(sig), sha256_sig_rows_first8=[sha_i32(r) for r in sig[:8]],
                                      sha256_alpha_hat_sorted=sha_i32(alpha_sorted), verdict=list(verdict), tampered_verdict=list(bad),
                                      tampered_at=[11, 7], sha256_str_agg=sha_str(str(agg)))}, f)
@@ -480,8 +485,10 @@ def gen_kat():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["algebra", "bulk", "scheme", "kat", "many", "kat_flow"]
-    if "full" in sys.argv[1:]:                  # ~10 minutes on 8 cores: only on request
+    if "full" in sys.argv[1:]:                  # ~5 minutes on 8 cores: only on request
         gen_scheme_full()
+    if "full128" in sys.argv[1:]:               # secpar 128 AT ITS CAPACITY (1796 signers, fusion.py:24)
+        gen_scheme_full(secpar=128, n=1796, setup_seed=27182)
     if "many" in which:
         gen_scheme_many()
     if "kat_flow" in which:

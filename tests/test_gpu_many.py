@@ -139,23 +139,25 @@ def test_drop_in_object_api_at_32_signers_prints_the_reference_strings():
         assert list(F.verify(params, vks[lo:hi], m["messages"][lo:hi], agg)) == info["tampered_verdict"]
 
 
-def _full():
-    p = os.path.join(G, "scheme_full_256.npz")
+def _full(secpar):
+    p = os.path.join(G, f"scheme_full_{secpar}.npz")
     if not os.path.exists(p):
-        pytest.skip("tests/golden/scheme_full_256.npz not generated (gen_golden.py full)")
+        pytest.skip(f"tests/golden/scheme_full_{secpar}.npz not generated (gen_golden.py full / full128)")
     with open(os.path.join(G, "scheme_full.json")) as fh:
-        return np.load(p), json.load(fh)["256"]
+        return np.load(p), json.load(fh)[str(secpar)]
 
 
-def test_configs3_at_its_stated_size_equals_the_reference():
-    """BASELINE configs[3] AT FULL SIZE against the REFERENCE ITSELF: 1024 distinct signers at secpar 256 -- the reference's
-    keygen, sign, ONE aggregate() and ONE verify() over all of them (tests/golden/gen_golden.py full: ~10 minutes on 8 cores).
-    Keys, signatures and aggregation coefficients are compared by SHA-256 of the whole arrays, the sort order and the
-    aggregate element by element, verdict and tamper verdict literally."""
+@pytest.mark.parametrize("secpar", [256, 128])
+def test_full_size_flows_equal_the_reference(secpar):
+    """AT FULL SIZE against the REFERENCE ITSELF: BASELINE configs[3] (1024 distinct signers at secpar 256) and secpar 128 at its
+    CAPACITY (1796 signers, fusion.py:24) -- the reference's keygen, sign, ONE aggregate() and ONE verify() over all of them
+    (tests/golden/gen_golden.py full / full128: ~5 minutes each on 8 cores).  Keys, signatures and aggregation coefficients
+    are compared by SHA-256 of the whole arrays, the sort order and the aggregate element by element, verdict, tamper verdict
+    and the "Too many keys." verdict of capacity + 1 signers literally."""
     import fusion.fusion as F
     from fusion_hip.scheme import BatchScheme
-    S, m = _full()
-    params = F.fusion_setup(256, m["setup_seed"])
+    S, m = _full(secpar)
+    params = F.fusion_setup(secpar, m["setup_seed"])
     bs = BatchScheme(params)
     sk, vk, vk_dev = bs.keygen_batch(m["key_seeds"], device=True, keep_vk=True)
     assert sha_i32(vk) == m["sha256_vk"]
@@ -176,10 +178,16 @@ def test_configs3_at_its_stated_size_equals_the_reference():
     bad = agg.copy()
     bad[m["tampered_at"][0], m["tampered_at"][1]] += 1
     assert list(bs.verify(vk, m["messages"], bad)) == m["tampered_verdict"]
-    # the same 1024 signers as 4 aggregates of 256 in one batch: each equals a single call on its block
-    aggs = bs.aggregate_many(vk, m["messages"], sig, [256] * 4)
+    if m.get("too_many_verdict"):                                                # capacity + 1 signers (fusion.py:686-687)
+        assert list(bs.verify(np.concatenate([vk, vk[:1]]), m["messages"] + m["messages"][:1], agg)) == m["too_many_verdict"] \
+            == [False, "Too many keys."]
+    # the same signers as 4 aggregates in one batch: each equals a single call on its block
+    q4 = m["n"] // 4
+    sizes = [q4, q4, q4, m["n"] - 3 * q4]
+    aggs = bs.aggregate_many(vk, m["messages"], sig, sizes)
     for g in (0, 3):
-        assert np.array_equal(aggs[g], bs.aggregate(vk[256 * g:256 * (g + 1)], m["messages"][256 * g:256 * (g + 1)], sig_host[256 * g:256 * (g + 1)]))
-    assert bs.verify_many(vk, m["messages"], aggs, [256] * 4) == [(True, "")] * 4
+        a_, b_ = q4 * g, q4 * g + sizes[g]
+        assert np.array_equal(aggs[g], bs.aggregate(vk[a_:b_], m["messages"][a_:b_], sig_host[a_:b_]))
+    assert bs.verify_many(vk, m["messages"], aggs, sizes) == [(True, "")] * 4
     for b in (sk, vk_dev, sig):
         b.free()

@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64) void ntt_multi4(FzMultiJobs J, const double2 *_
 // the forward passes leave a lane's values at bit-reversed positions 4mm..4mm+3, exactly where the inverse picks up.
 // `out` may alias `f` or `g` (a wave has read its whole polynomials before it writes).
 // ------------------------------------------------------------------------------------------
-template <int LOGD, bool FAST>
+template <int LOGD, bool FAST, typename TW>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32_t *f, const int32_t *g, int32_t *out, size_t batch,
                                                                      const double2 *__restrict__ tw2,
                                                                      const double2 *__restrict__ itw2, FzTwA twA, FzTwA itwA,
@@ -729,9 +729,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
     const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave, stride = (size_t)gridDim.x * kWavesPerBlock;
     if (first >= tasks) return;
 
-    double2 twf[P - 1][3], twi[P - 1][3];
-    fwd4_load_twiddles<LOGD>(twf, tw2, mm);
-    inv4_load_twiddles<LOGD>(twi, itw2, mm);
+    TW twf[P - 1][3], twi[P - 1][3];
+    fwd4_load_twiddles<LOGD, TW>(twf, tw2, mm);
+    inv4_load_twiddles<LOGD, TW>(twi, itw2, mm);
 
     for (size_t task = first; task < tasks; task += stride) {
         const size_t poly = task * PPW + p;
@@ -745,17 +745,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
         double a[4], b[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = (double)xf[k];
-        fwd4_passes<LOGD, FAST>(a, region, twf, twA, m, mm);
+        fwd4_passes_n<LOGD, FAST, 1, TW>(reinterpret_cast<double (&)[1][4]>(a), region, twf, twA, m, mm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = fz_cent(a[k], m);         // one centred factor keeps the product below 2^66
         wave_sync();                                                 // g's first-pass writes vs f's last-pass reads
 #pragma unroll
         for (int k = 0; k < 4; ++k) b[k] = (double)xg[k];
-        fwd4_passes<LOGD, FAST>(b, region, twf, twA, m, mm);
+        fwd4_passes_n<LOGD, FAST, 1, TW>(reinterpret_cast<double (&)[1][4]>(b), region, twf, twA, m, mm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) b[k] = fz_mulmod(a[k], b[k], m);
         wave_sync();
-        inv4_passes<LOGD, FAST>(b, region, twi, itwA, m, mm);
+        inv4_passes_n<LOGD, FAST, 1, TW>(reinterpret_cast<double (&)[1][4]>(b), region, twi, itwA, m, mm);
         if (valid) {
             int32_t *dst = out + poly * D + mm;
 #pragma unroll
@@ -1345,7 +1345,9 @@ int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int
     if (ctx->grid_pm == 0) {
         int n = 0;
         hipError_t e;
-#define FZ_PQ(LOGD, FAST) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, polymul_fused<LOGD, FAST>, 64 * kWavesPerBlock, 0)
+    const bool single = ctx->knob_fused_tw == 1;
+#define FZ_PQ(LOGD, FAST) e = single ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, polymul_fused<LOGD, FAST, double>, 64 * kWavesPerBlock, 0) \
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, polymul_fused<LOGD, FAST, double2>, 64 * kWavesPerBlock, 0)
         if (ctx->logd == 8) { if (ctx->mod.fast) FZ_PQ(8, true); else FZ_PQ(8, false); }
         else { if (ctx->mod.fast) FZ_PQ(6, true); else FZ_PQ(6, false); }
 #undef FZ_PQ
@@ -1353,11 +1355,13 @@ int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int
         ctx->grid_pm = (n < 1 ? 1 : n) * ctx->num_cu;
     }
     const dim3 grid((unsigned)(blocks < (size_t)ctx->grid_pm ? blocks : (size_t)ctx->grid_pm)), block(64 * kWavesPerBlock);
-#define FZ_PM(LOGD, FAST) hipLaunchKernelGGL((polymul_fused<LOGD, FAST>), grid, block, 0, ctx->stream, f, g, out, batch, \
+#define FZ_PM2(LOGD, FAST, TW) hipLaunchKernelGGL((polymul_fused<LOGD, FAST, TW>), grid, block, 0, ctx->stream, f, g, out, batch, \
                                              (const double2 *)ctx->d_tw2, (const double2 *)ctx->d_itw2, ctx->twA, ctx->itwA, ctx->mod)
+#define FZ_PM(LOGD, FAST) do { if (ctx->knob_fused_tw == 1) FZ_PM2(LOGD, FAST, double); else FZ_PM2(LOGD, FAST, double2); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_PM(8, true); else FZ_PM(8, false); }
     else { if (ctx->mod.fast) FZ_PM(6, true); else FZ_PM(6, false); }
 #undef FZ_PM
+#undef FZ_PM2
     return fz_check_hip(hipGetLastError(), "polymul_fused launch");
 }
 

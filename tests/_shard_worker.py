@@ -26,10 +26,11 @@ if kind == "many":
     S = np.load(os.path.join(G, f"scheme_many_{secpar}.npz"))
     with open(os.path.join(G, "scheme_many.json")) as fh:
         meta = json.load(fh)[str(secpar)]
-elif kind == "full":                                # configs[3] at its stated size: the keys are regenerated (and digest-checked by the test)
+elif kind.startswith("full"):                       # full-size goldens: the keys are regenerated (and digest-checked by the test)
     S = None
     with open(os.path.join(G, "scheme_full.json")) as fh:
-        meta = json.load(fh)[str(secpar)]
+        meta = json.load(fh)[kind.split(":")[1]]
+    kind = "full"
 else:
     S = np.load(os.path.join(G, f"scheme_{secpar}.npz"))
     with open(os.path.join(G, "scheme.json")) as fh:

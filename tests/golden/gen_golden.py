@@ -313,7 +313,7 @@ def _full_worker(job):
     return np.stack(vks), np.stack(sigs)
 
 
-def gen_scheme_full(secpar=256, n=1024, setup_seed=31415, procs=8):
+def gen_scheme_full(secpar=256, n=1024, setup_seed=31415, procs=8, tag=None):
     """BASELINE configs[3] AT ITS STATED SIZE through the reference: 1024 distinct signers at secpar 256 -- keygen and sign in
     `procs` processes (the reference is single-threaded: ~0.8 s per signer), then ONE aggregate() and ONE verify() over all of
     them.  Stored: the sorted order, SHA-256 of every verification key / signature row (the build regenerates them from the
@@ -358,7 +358,8 @@ def gen_scheme_full(secpar=256, n=1024, setup_seed=31415, procs=8):
     agg.signature_hat.matrix[11][0].values[7] -= 1
     print(f"scheme_full: 2 x verify in {time.time() - t1:.0f} s")
     alpha_sorted = np.array([a.alpha_hat.values for a in alphas], dtype=np.int32)
-    np.savez_compressed(os.path.join(HERE, f"scheme_full_{secpar}.npz"), agg=mat_values(agg.signature_hat),
+    tag = tag or str(secpar)
+    np.savez_compressed(os.path.join(HERE, f"scheme_full_{tag}.npz"), agg=mat_values(agg.signature_hat),
                         order=np.array(order, dtype=np.int32))
     meta_path = os.path.join(HERE, "scheme_full.json")
     meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
@@ -366,7 +367,7 @@ def gen_scheme_full(secpar=256, n=1024, setup_seed=31415, procs=8):
     if n == params.capacity:                    # one signer more than the capacity: the reference refuses before any arithmetic
         too_many = list(F.verify(params, vks + [vks[0]], msgs + [msgs[0]], agg))
     with open(meta_path, "w") as f:
-        json.dump({**meta, str(secpar): dict(too_many_verdict=too_many, capacity=params.capacity, secpar=secpar, setup_seed=setup_seed, n=n, key_seeds=seeds, messages=msgs,
+        json.dump({**meta, tag: dict(too_many_verdict=too_many, capacity=params.capacity, secpar=secpar, setup_seed=setup_seed, n=n, key_seeds=seeds, messages=msgs,
                                      sha256_vk=sha_i32(vk), sha256_sig=sha_i32(sig), sha256_sig_rows_first8=[sha_i32(r) for r in sig[:8]],
                                      sha256_alpha_hat_sorted=sha_i32(alpha_sorted), verdict=list(verdict), tampered_verdict=list(bad),
                                      tampered_at=[11, 7], sha256_str_agg=sha_str(str(agg)))}, f)
@@ -489,6 +490,8 @@ if __name__ == "__main__":
         gen_scheme_full()
     if "full128" in sys.argv[1:]:               # secpar 128 AT ITS CAPACITY (1796 signers, fusion.py:24)
         gen_scheme_full(secpar=128, n=1796, setup_seed=27182)
+    if "full256cap" in sys.argv[1:]:            # secpar 256 AT ITS CAPACITY (2818 signers, fusion.py:25): ~15 minutes
+        gen_scheme_full(secpar=256, n=2818, setup_seed=16180, tag="256cap")
     if "many" in which:
         gen_scheme_many()
     if "kat_flow" in which:

@@ -139,24 +139,25 @@ def test_drop_in_object_api_at_32_signers_prints_the_reference_strings():
         assert list(F.verify(params, vks[lo:hi], m["messages"][lo:hi], agg)) == info["tampered_verdict"]
 
 
-def _full(secpar):
-    p = os.path.join(G, f"scheme_full_{secpar}.npz")
+def _full(tag):
+    p = os.path.join(G, f"scheme_full_{tag}.npz")
     if not os.path.exists(p):
-        pytest.skip(f"tests/golden/scheme_full_{secpar}.npz not generated (gen_golden.py full / full128)")
+        pytest.skip(f"tests/golden/scheme_full_{tag}.npz not generated (gen_golden.py full / full128 / full256cap)")
     with open(os.path.join(G, "scheme_full.json")) as fh:
-        return np.load(p), json.load(fh)[str(secpar)]
+        return np.load(p), json.load(fh)[tag]
 
 
-@pytest.mark.parametrize("secpar", [256, 128])
-def test_full_size_flows_equal_the_reference(secpar):
-    """AT FULL SIZE against the REFERENCE ITSELF: BASELINE configs[3] (1024 distinct signers at secpar 256) and secpar 128 at its
-    CAPACITY (1796 signers, fusion.py:24) -- the reference's keygen, sign, ONE aggregate() and ONE verify() over all of them
+@pytest.mark.parametrize("tag", ["256", "128", "256cap"])
+def test_full_size_flows_equal_the_reference(tag):
+    """AT FULL SIZE against the REFERENCE ITSELF: BASELINE configs[3] (1024 distinct signers at secpar 256) and both parameter sets
+    at their CAPACITY (1796 signers at secpar 128, 2818 at secpar 256: fusion.py:24-25) -- the reference's keygen, sign, ONE aggregate() and ONE verify() over all of them
     (tests/golden/gen_golden.py full / full128: ~5 minutes each on 8 cores).  Keys, signatures and aggregation coefficients
     are compared by SHA-256 of the whole arrays, the sort order and the aggregate element by element, verdict, tamper verdict
     and the "Too many keys." verdict of capacity + 1 signers literally."""
     import fusion.fusion as F
     from fusion_hip.scheme import BatchScheme
-    S, m = _full(secpar)
+    S, m = _full(tag)
+    secpar = m["secpar"]
     params = F.fusion_setup(secpar, m["setup_seed"])
     bs = BatchScheme(params)
     sk, vk, vk_dev = bs.keygen_batch(m["key_seeds"], device=True, keep_vk=True)

@@ -67,18 +67,18 @@ def test_sharded_flow_equals_the_reference_small(secpar, n, world, tmp_path):
         assert j["tampered"] == m["agg"][str(n)]["tampered_verdict"]
 
 
-@pytest.mark.parametrize("secpar,world", [(256, 3), (128, 2)])
-def test_sharded_at_full_size_equals_the_reference(secpar, world, tmp_path):
+@pytest.mark.parametrize("tag,world", [("256", 3), ("128", 2), ("256cap", 2)])
+def test_sharded_at_full_size_equals_the_reference(tag, world, tmp_path):
     """BASELINE configs[3]: 1024 signers at secpar 256 sharded over 3 ranks (342 / 341 / 341 signatures each, resident on the
     device), and secpar 128 at its capacity (1796 signers) over 2 ranks, against the aggregates the REFERENCE computed over all
     of them (tests/golden/scheme_full_*.npz)"""
-    p = os.path.join(G, f"scheme_full_{secpar}.npz")
+    p = os.path.join(G, f"scheme_full_{tag}.npz")
     if not os.path.exists(p):
-        pytest.skip(f"tests/golden/scheme_full_{secpar}.npz not generated (gen_golden.py full / full128)")
+        pytest.skip(f"tests/golden/scheme_full_{tag}.npz not generated (gen_golden.py full / full128 / full256cap)")
     S = np.load(p)
     with open(os.path.join(G, "scheme_full.json")) as fh:
-        m = json.load(fh)[str(secpar)]
-    R, J = run_ranks(world, [secpar, "full", 0, m["n"]], tmp_path)
+        m = json.load(fh)[tag]
+    R, J = run_ranks(world, [m["secpar"], "full:" + tag, 0, m["n"]], tmp_path)
     assert sum(int(r["hi"]) - int(r["lo"]) for r in R) == m["n"] and max(int(r["hi"]) - int(r["lo"]) for r in R) - min(int(r["hi"]) - int(r["lo"]) for r in R) <= 1
     for r, j in zip(R, J):
         assert str(r["vk_sha"]) == m["sha256_vk"]

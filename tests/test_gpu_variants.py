@@ -1,0 +1,131 @@
+"""Every launch shape and arithmetic form the library instantiates, forced through its knob (read once, at context creation)
+and checked against the oracle at both parameter sets: the radix-4 transform kernels with 1 / 2 / 4 row groups per wave and
+1 / 4 / 8 waves per workgroup, the 16-per-lane persistent kernels, the fused kernels with one / two row groups per
+iteration, prefetch depths 0 / 1 / 2, twiddles as (w, w*K/q) pairs or w alone, integer or fp64 accumulation, the centring or
+lazy norm test.  The defaults pick among these by batch size; a size-dependent choice that is never hit by the other tests'
+sizes would otherwise go unchecked.  Reference arithmetic: algebra/ntt.py:216-377, fusion/fusion.py:338-373, :680-728."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+I32 = np.iinfo(np.int32)
+
+TRANSFORM_KNOBS = [
+    {"FZ_NTT_KERNEL": "4", "FZ_NTT_ROWS": "1", "FZ_NTT_WAVES": "1"},
+    {"FZ_NTT_KERNEL": "4", "FZ_NTT_ROWS": "1", "FZ_NTT_WAVES": "4"},
+    {"FZ_NTT_KERNEL": "4", "FZ_NTT_ROWS": "1", "FZ_NTT_WAVES": "8"},
+    {"FZ_NTT_KERNEL": "4", "FZ_NTT_ROWS": "2"},
+    {"FZ_NTT_KERNEL": "4", "FZ_NTT_ROWS": "4"},
+    {"FZ_NTT_KERNEL": "16"},
+    {"FZ_NTT_KERNEL": "16", "FZ_NTT_GRID_MULT": "1"},
+    {"FZ_NTT_SMALL_ROWS": "100"},                  # the crossover inside the sizes below
+]
+
+FUSED_KNOBS = [
+    {},
+    {"FZ_FUSED_ROWS": "2"},
+    {"FZ_FUSED_ROWS": "1", "FZ_FUSED_PREFETCH": "0"},
+    {"FZ_FUSED_ROWS": "1", "FZ_FUSED_PREFETCH": "2"},
+    {"FZ_FUSED_TW": "1"},
+    {"FZ_FUSED_TW": "1", "FZ_FUSED_ROWS": "2", "FZ_NO_IMAD": "1"},
+    {"FZ_NO_IMAD": "1"},
+    {"FZ_VERIFY_CENT": "1"},
+    {"FZ_VERIFY_CENT": "1", "FZ_VERIFY_ORDERED": "1", "FZ_FUSED_ROWS": "2"},
+]
+
+
+def _ctx(P, env):
+    import fusion_hip
+    for k, v in env.items():
+        os.environ[k] = v
+    try:
+        return fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"])
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+def _ident(env):
+    return ",".join(f"{k[3:]}={v}" for k, v in env.items()) or "defaults"
+
+
+@pytest.mark.parametrize("env", TRANSFORM_KNOBS, ids=_ident)
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_transform_launch_shapes(secpar, env, coracle):
+    P = O.PARAMS[secpar]
+    q, d = P["q"], P["d"]
+    ctx = _ctx(P, env)
+    rng = np.random.default_rng(secpar)
+    try:
+        for rows in (1, 3, 64, 65, 257, 4099):
+            x = O.splitmix_centered(rows + secpar, rows * d).reshape(rows, d).copy()
+            x[0, :] = I32.min                      # any int32 is a legal input
+            if rows > 1:
+                x[1] = rng.integers(I32.min, I32.max, size=d, dtype=np.int64).astype(np.int32)
+            f = coracle.ntt_forward(x, q, P["root"]).reshape(rows, d)
+            assert np.array_equal(ctx.ntt_forward(x), f), ("fwd", rows)
+            assert np.array_equal(ctx.ntt_inverse(x), coracle.ntt_inverse(x, q, P["inv_root"]).reshape(rows, d)), ("inv", rows)
+            g = O.splitmix_centered(rows + 7, rows * d).reshape(rows, d)
+            want = coracle.ntt_inverse(coracle.pw_mul(f, coracle.ntt_forward(g, q, P["root"]).reshape(rows, d), q), q, P["inv_root"])
+            assert np.array_equal(ctx.poly_mul(x, g), want.reshape(rows, d)), ("polymul", rows)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("env", FUSED_KNOBS, ids=_ident)
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_fused_kernel_forms(secpar, env, coracle):
+    """keygen_core, the coefficient-domain product and verification (int32 rows and int64 partial sums; passing, norm-failing
+    and target-mismatching aggregates; few and many aggregates per launch: the rows-per-wave gates sit between them)"""
+    import fusion_hip
+    P = O.PARAMS[secpar]
+    q, d, l = P["q"], P["d"], P["rank"]
+    ctx = _ctx(P, env)
+    rng = np.random.default_rng(secpar + 11)
+    A = O.splitmix_centered(5, l * d).reshape(l, d).copy()
+    A[0, :] = I32.max
+    A[1, :] = I32.min
+    try:
+        for n in (1, 5, 67):
+            coef = (rng.integers(1, 53, size=(n, 2, l, d)) * rng.choice(np.array([-1, 1]), size=(n, 2, l, d))).astype(np.int32)
+            coef[0, 0, 0] = I32.max
+            rsk, rvk = coracle.keygen_core(A, coef, q, P["root"])
+            sk, vk = ctx.keygen_core(A, coef)
+            assert np.array_equal(sk, rsk) and np.array_equal(vk, rvk), ("keygen", n)
+        rows = 517
+        f = rng.integers(I32.min, I32.max, size=(rows, d), dtype=np.int64).astype(np.int32)
+        g = O.splitmix_centered(3, rows * d).reshape(rows, d)
+        want = coracle.ntt_inverse(coracle.pw_mul(coracle.ntt_forward(f, q, P["root"]).reshape(rows, d),
+                                                  coracle.ntt_forward(g, q, P["root"]).reshape(rows, d), q), q, P["inv_root"])
+        assert np.array_equal(ctx.poly_mul(f, g), want.reshape(rows, d))
+        for groups in (1, 6, 900 if secpar == 256 else 400):
+            sig = coracle.ntt_forward(rng.integers(-40, 41, size=(groups * l, d)).astype(np.int32), q, P["root"]).reshape(groups, l, d)
+            if groups > 2:
+                sig[2] = rng.integers(I32.min, I32.max, size=(l, d), dtype=np.int64).astype(np.int32)
+            target = coracle.matvec(A, sig, q).astype(np.int32)
+            want = []
+            for gi in range(groups):
+                mx, wt = coracle.norm_weight(coracle.ntt_inverse(sig[gi], q, P["inv_root"]), q)
+                want.append(4 if mx.max() > P["beta_vf"] else (5 if wt.max() > d else 0))
+            assert want[0] == 0
+            bad = target.copy()
+            bad[:, d - 1] -= 1
+            expect_bad = [3] * groups                  # the target is compared before the norm (fusion.py:718-727)
+            sig64 = sig.astype(np.int64) + q * rng.integers(-500, 500, size=sig.shape)
+            bufs = [fusion_hip.DeviceArray.from_numpy(ctx, a) for a in (A, sig, target, bad, sig64, target.astype(np.int64) + 5 * q)]
+            dA, dS, dT, dB, d64, dT64 = bufs
+            dV = fusion_hip.DeviceArray(ctx, (groups,))
+            try:
+                assert ctx.verify_with_target_batch_dev(dA.ptr, dS.ptr, dT.ptr, groups, l, P["beta_vf"], d) == want, groups
+                assert ctx.verify_with_target_batch_dev(dA.ptr, dS.ptr, dB.ptr, groups, l, P["beta_vf"], d) == expect_bad, groups
+                ctx.verify_partials_batch_async_dev(dA.ptr, d64.ptr, l * d, dT64.ptr, d, groups, l, P["beta_vf"], d, dV.ptr)
+                assert dV.numpy().tolist() == want, groups
+            finally:
+                for b in bufs + [dV]:
+                    b.free()
+    finally:
+        ctx.close()

@@ -50,7 +50,8 @@ KERNS = ["", "4", "16", "4r1", "4r1w4", "4r2", "4r4"]
 # the multi-launch forms of the fused kernels and other launch shapes of the one-pass aggregation
 VARIANTS = [{}, {"FZ_KEYGEN_UNFUSED": "1", "FZ_VERIFY_UNFUSED": "1", "FZ_POLYMUL_UNFUSED": "1"}, {"FZ_AGG_TWOPASS": "1"},
             {"FZ_AGG_WAVES": "4", "FZ_AGG_SLICES": "3"}, {"FZ_AGG_SLICES": "7", "FZ_VERIFY_ORDERED": "1"}, {"FZ_STREAM_PER_CU": "8"},
-            {"FZ_NO_IMAD": "1", "FZ_FUSED_ROWS": "1"}, {"FZ_FUSED_ROWS": "2", "FZ_VERIFY_CENT": "1"}, {"FZ_FUSED_ROWS": "1", "FZ_AGG_SLICES": "2"}]
+            {"FZ_NO_IMAD": "1", "FZ_FUSED_ROWS": "1"}, {"FZ_FUSED_ROWS": "2", "FZ_VERIFY_CENT": "1"}, {"FZ_FUSED_ROWS": "1", "FZ_AGG_SLICES": "2"},
+            {"FZ_FUSED_TW": "1", "FZ_FUSED_PREFETCH": "2"}, {"FZ_FUSED_TW": "1", "FZ_FUSED_ROWS": "2", "FZ_FUSED_PREFETCH": "0"}]
 vctx = {(sp, i): make_ctx(sp, "", v) for sp in (128, 256) for i, v in enumerate(VARIANTS)}
 DB = fusion_hip.DeviceBuffer
 t_end = time.time() + budget

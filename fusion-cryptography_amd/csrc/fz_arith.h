@@ -111,4 +111,14 @@ FZ_HD double fz_mulmod_cent(double a, double b, const FzMod m) {
     return fz_cent(fz_mulmod(a, b, m), m);
 }
 
+// Integer multiply-add accumulation of A (.) y (v_mad_i64_i32): with A split into 16-bit halves, hi += y * (A >> 16) and
+// lo += y * (A & 0xffff) are exact in int64 for up to 2^15 products of any int32 operands (|y * half| <= 2^47).
+// fz_imad_total: hi * 2^16 + lo (mod q) as a double with |result| <= q + 2^18.  `small` (wave-uniform): at most 32 products went into each
+// sum, so |hi|, |lo| < 2^52 convert to fp64 exactly and two folds do (12 operations); otherwise both sums are centred exactly
+// as arbitrary int64 first.
+FZ_HD double fz_imad_total(long long hi, long long lo, bool small, const FzMod m) {
+    if (small) return fz_fold((double)hi * 65536.0, m) + fz_fold((double)lo, m);
+    return fz_fold(fz_cent_i64(hi, m) * 65536.0, m) + fz_cent_i64(lo, m);
+}
+
 #endif  // FZ_ARITH_H

@@ -778,13 +778,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
 // (Measured and dropped: A pre-split into fp64 (hi, lo) pairs by the host -- two FMAs per coefficient, but 64 bytes of L2
 // traffic per lane and row instead of 16: keygen 79 -> 109 us per 1024 keys, verify 256 -> 270 us per 8192 aggregates,
 // profiles/r03_presplit_A_experiment.txt.)
-// hi * 2^16 + lo (mod q) as a double with |result| <= q + 2^18.  `small` (wave-uniform): at most 32 products went into each
-// sum, so |hi|, |lo| < 2^52 convert to fp64 exactly and two folds do (12 operations); otherwise both sums are centred exactly
-// as arbitrary int64 first.
-__device__ __forceinline__ double fz_imad_total(long long hi, long long lo, bool small, const FzMod &m) {
-    if (small) return fz_fold((double)hi * 65536.0, m) + fz_fold((double)lo, m);
-    return fz_fold(fz_cent_i64(hi, m) * 65536.0, m) + fz_cent_i64(lo, m);
-}
+// (fz_imad_total, the sums' way back to fp64, lives in fz_arith.h.)
 // NR: row groups a wave takes through the transform passes together (fwd4_passes_n: one synchronisation per pass for NR rows,
 // NR independent fp64 dependency chains per wave).
 // PF: how many iterations ahead a wave requests its secret rows (1 or 2; a wave's rows are a sequential chain).  Measured: no

@@ -120,6 +120,72 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const int32_t *A, const 
         reinterpret_cast<int4 *>(out + b * (size_t)degree)[j4] = o;
     }
 }
+// The same product as (CX, KS) workgroups, CX = max(64, 256 / KS) columns (product, 4 coefficients) by KS slices of the k
+// range: the waves with threadIdx.y = y take slice y -- KS times the rows in flight when one wave per 64 columns would leave
+// the chip short of waves (2048 products of degree 64 are 512 of them) -- and accumulate in INTEGERS: A
+// split into 16-bit halves on the fly, hi += s * (A >> 16), lo += s * (A & 0xffff) (v_mad_i64_i32), exact for any int32
+// operands while l <= 2^15 (fz_arith.h).  Every iteration requests eight rows whether the slice still has eight or not (the
+// row index is clamped, the surplus is not accumulated: the slice bounds are wave-uniform) -- a tail of single-row iterations
+// is a chain of dependent round trips (five of them at four slices of 83 rows: 37.9 us against 33.6 with two slices).  The
+// slices' sums meet in LDS; slice 0 reduces them to the centred row.
+template <int KS>
+__global__ __launch_bounds__(KS <= 4 ? 256 : 64 * KS) void matvec_sliced_kernel(const int32_t *A, const int32_t *S, int32_t *out,
+                                                                                size_t batch, int l, int degree, FzMod m) {
+    constexpr int U = 8, CX = KS <= 4 ? 256 / KS : 64;
+    __shared__ long long red[(KS > 1 ? KS - 1 : 1) * 8 * CX];
+    const int d4 = degree / 4;
+    const size_t total = batch * (size_t)d4;
+    const size_t i_raw = (size_t)blockIdx.x * CX + threadIdx.x;
+    const bool live = i_raw < total;
+    const size_t i = live ? i_raw : total - 1;          // idle lanes of the last workgroup shadow the last column and store nothing
+    const int sl = threadIdx.y;
+    const size_t b = i / d4;
+    const int j4 = (int)(i % d4);
+    const int per = (l + KS - 1) / KS;
+    const int k1 = (sl + 1) * per < l ? (sl + 1) * per : l;
+    const int4 *Ap = reinterpret_cast<const int4 *>(A) + j4;
+    const int4 *Sp = reinterpret_cast<const int4 *>(S + b * (size_t)l * degree) + j4;
+    long long h0 = 0, h1 = 0, h2 = 0, h3 = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+#define FZ_MV_ACC(XA, YS) \
+    h0 += (long long)(YS).x * ((XA).x >> 16); l0 += (long long)(YS).x * ((XA).x & 0xffff); \
+    h1 += (long long)(YS).y * ((XA).y >> 16); l1 += (long long)(YS).y * ((XA).y & 0xffff); \
+    h2 += (long long)(YS).z * ((XA).z >> 16); l2 += (long long)(YS).z * ((XA).z & 0xffff); \
+    h3 += (long long)(YS).w * ((XA).w >> 16); l3 += (long long)(YS).w * ((XA).w & 0xffff);
+    for (int k = sl * per; k < k1; k += U) {
+        int4 x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k + u < k1 ? k + u : k1 - 1;
+            x[u] = Ap[(size_t)kk * d4];
+            y[u] = Sp[(size_t)kk * d4];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k + u < k1) { FZ_MV_ACC(x[u], y[u]) }
+    }
+#undef FZ_MV_ACC
+    if (KS > 1) {
+        if (sl > 0) {
+            long long *mine = red + (size_t)(sl - 1) * 8 * CX + threadIdx.x;
+            mine[0] = h0; mine[CX] = h1; mine[2 * CX] = h2; mine[3 * CX] = h3;
+            mine[4 * CX] = l0; mine[5 * CX] = l1; mine[6 * CX] = l2; mine[7 * CX] = l3;
+        }
+        __syncthreads();
+        if (sl > 0) return;
+#pragma unroll
+        for (int t = 0; t < KS - 1; ++t) {
+            const long long *o = red + (size_t)t * 8 * CX + threadIdx.x;
+            h0 += o[0]; h1 += o[CX]; h2 += o[2 * CX]; h3 += o[3 * CX];
+            l0 += o[4 * CX]; l1 += o[5 * CX]; l2 += o[6 * CX]; l3 += o[7 * CX];
+        }
+    }
+    if (!live) return;
+    const bool small = l <= 32;
+    int4 o;
+    o.x = cent_i32(fz_imad_total(h0, l0, small, m), m); o.y = cent_i32(fz_imad_total(h1, l1, small, m), m);
+    o.z = cent_i32(fz_imad_total(h2, l2, small, m), m); o.w = cent_i32(fz_imad_total(h3, l3, small, m), m);
+    reinterpret_cast<int4 *>(out + b * (size_t)degree)[j4] = o;
+}
 // Few products (verify: one per aggregate): one 1024-thread block per product, the k-loop split over
 // 1024/(degree/4) slices and reduced through LDS -- 83 dependent-latency iterations become 6.
 __global__ __launch_bounds__(1024) void matvec_split_kernel(const int32_t *A, const int32_t *S, int32_t *out,
@@ -647,9 +713,34 @@ int fz_launch_matvec(fz_ctx *ctx, const int32_t *A, const int32_t *S, int32_t *o
     if (batch == 0) return FZ_OK;
     const bool vec = ctx->degree % 4 == 0 && ((((uintptr_t)A | (uintptr_t)S | (uintptr_t)out) & 15) == 0);   // int4 rows
     if (vec && ctx->degree >= 16 && ctx->degree <= 4096 && (ctx->degree & (ctx->degree - 1)) == 0 &&
-        batch * (size_t)(ctx->degree / 4) < (size_t)ctx->num_cu * 256)
+        (ctx->knob_matvec_slices < 0 ? batch * (size_t)(ctx->degree / 4) < (size_t)ctx->num_cu * 256
+                                     : ctx->knob_matvec_slices == 0 && batch <= (size_t)ctx->num_cu * 2))
+        // one 1024-thread workgroup per product while all of them are resident at once (two per CU); measured on cold operands
+        // (profiles/r03_matvec_ab.txt): 512 products 11.1 us against 12.0 for the sliced kernel at degree 256, 8.7 against
+        // 10.5 at degree 64; 1024 products 19.3 (sliced) against 26.2 / 12.5 against 14.0
         hipLaunchKernelGGL(matvec_split_kernel, dim3((unsigned)batch), dim3(1024), 0, ctx->stream, A, S, out, l,
                            ctx->degree, ctx->mod);
+    else if (vec && l <= 32768 && ctx->knob_matvec_slices >= 0) {
+        // slices of the k range per column: waves for every SIMD several times over, at least 8 rows per slice
+        const size_t cols = batch * (size_t)(ctx->degree / 4), waves1 = (cols + 63) / 64;
+        int ks = ctx->knob_matvec_slices;                                  // FZ_MATVEC_SLICES = 1 | 2 | 4 | 8 | 16 (A/B runs), -1: the fp64 kernels
+        if (ks != 1 && ks != 2 && ks != 4 && ks != 8 && ks != 16) {
+            ks = 1;
+            while (ks < 16 && waves1 * ks < (size_t)ctx->num_cu * 8) ks <<= 1;
+        }
+        while (ks > 1 && l / ks < 8) ks >>= 1;
+        const int cx = ks <= 4 ? 256 / ks : 64;
+        const size_t blocks = (cols + cx - 1) / cx;
+        if (blocks > 0x7fffffffull) return fz_set_error(FZ_E_UNSUPPORTED, "batch too large for one matvec launch");
+        const dim3 grid((unsigned)blocks), block(cx, ks);
+#define FZ_MVS(K) hipLaunchKernelGGL(matvec_sliced_kernel<K>, grid, block, 0, ctx->stream, A, S, out, batch, l, ctx->degree, ctx->mod)
+        if (ks == 16) FZ_MVS(16);
+        else if (ks == 8) FZ_MVS(8);
+        else if (ks == 4) FZ_MVS(4);
+        else if (ks == 2) FZ_MVS(2);
+        else FZ_MVS(1);
+#undef FZ_MVS
+    }
     else if (vec)
         hipLaunchKernelGGL(matvec_kernel, dim3(grid_for(ctx, batch * (size_t)(ctx->degree / 4))), dim3(kBlock), 0,
                            ctx->stream, A, S, out, batch, l, ctx->degree, ctx->mod);

@@ -129,3 +129,28 @@ def test_fused_kernel_forms(secpar, env, coracle):
                     b.free()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("slices", ["-1", "0", "1", "2", "4", "8", "16"])
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_matvec_forms(secpar, slices, coracle):
+    """the 1 x l by l x 1 product (matrices.py:115-131) for batches that take the many-products path: integer accumulation
+    with 1 / 2 / 4 slices of the k range per column, the fp64 kernel (-1) and the default choice; any int32 in A and S,
+    scheme ranks and ranks that leave ragged slices, a last workgroup that is not full"""
+    import fusion_hip
+    P = O.PARAMS[secpar]
+    q, d = P["q"], P["d"]
+    ctx = _ctx(P, {"FZ_MATVEC_SLICES": slices})
+    rng = np.random.default_rng(secpar + 5)
+    try:
+        batch = 65536 * 4 // d + 3                 # past the few-products kernel's range (fz_launch_matvec), not a multiple of 64 columns
+        for l in (P["rank"], 7, 33, 100):
+            A = rng.integers(I32.min, I32.max, size=(l, d), dtype=np.int64).astype(np.int32)
+            S = rng.integers(I32.min, I32.max, size=(batch, l, d), dtype=np.int64).astype(np.int32)
+            A[0, :] = I32.min
+            S[0, 0, :] = I32.min
+            A[l - 1, ::2] = I32.max
+            S[1, l - 1, :] = I32.max
+            assert np.array_equal(ctx.matvec(A, S), coracle.matvec(A, S, q)), (l, slices)
+    finally:
+        ctx.close()

@@ -104,8 +104,11 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
             note="A (l rows) is shared by the aggregates of a launch: counted for G = 1 only")
     # matvec (matrices.py:115-131): S [batch][l][d] -> [batch][d]
     mb = 2 * S
-    run("matvec_kernel", mb, (l + 1) * row, mb * l * row, mb * row,
-        lambda i, o: ctx.matvec_dev(A.ptr, i, o, mb, l))
+    sizes = ([int(x) for x in sys.argv[sys.argv.index("--matvec-batches") + 1].split(",")] if "--matvec-batches" in sys.argv
+             else [mb] if quick else [mb, 4 * mb])
+    for nb in sizes:
+        run("matvec" if nb == mb else f"matvec {nb} products", nb, (l + 1) * row, nb * l * row, nb * row,
+            lambda i, o, nb=nb: ctx.matvec_dev(A.ptr, i, o, nb, l))
     # fused negacyclic product (ntt.py:380-484): f, g [n][d] -> [n][d]
     n = 1 << 16
     run("polymul_fused", n, 3 * row, 2 * n * row, n * row,

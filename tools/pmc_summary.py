@@ -13,7 +13,7 @@ GROUPS = {"pmcb": ("B=4096 (bench launch)", 4096), "pmc20": ("B=2^20", 1 << 20)}
 # scheme kernels (tools/prof_scheme.py, secpar 256: l = 83, d = 256): algorithmic bytes per launch from SURVEY.md 8d
 L_, D_ = 83, 256
 SCHEME_BYTES = {"keygen_fused": 1024 * (4 * L_ + 2) * 4 * D_, "sign_kernel": 1024 * (3 * L_ + 1) * 4 * D_,
-                "matvec_kernel": 2048 * (L_ + 1) * 4 * D_, "pw_kernel": 1024 * L_ * D_ * 12,
+                "matvec_kernel": 2048 * (L_ + 1) * 4 * D_, "matvec_sliced_kernel": 2048 * (L_ + 1) * 4 * D_, "pw_kernel": 1024 * L_ * D_ * 12,
                 "verify_fused": 64 * (L_ + 2) * 4 * D_ + L_ * 4 * D_}
 out = {"source": "rocprofv3 --pmc <one set per pass> --output-format csv (tools/collect_profiles.sh, tools/pmc_summary.py); "
                  "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane coalesced reads on gfx950; KB -> bytes x1024",

@@ -39,6 +39,14 @@ def to_i32(rows, q):
     return a.astype(np.int32)
 
 
+def stack_polys(polys, q):
+    """polynomial objects of one length -> [len(polys)][d] int32.  Objects still backed by the row the library returned
+    contribute it as it is; lists of Python ints are converted (all of them in one call when nothing is array-backed)."""
+    if any(z._arr is not None for z in polys):
+        return np.stack([z._i32() for z in polys]) if polys else np.empty((0, 0), np.int32)
+    return to_i32([z._list for z in polys], q)
+
+
 def ntt_ctx(q, degree, root, inv_root):
     check_modulus(q)
     return get_context(q, degree, root % q, inv_root % q)

@@ -78,23 +78,22 @@ class GeneralMatrix:
         if not _is_poly_class(self.elem_class):
             return None
         first = self.matrix[0][0]
-        key = (first.modulus, first.degree, first.root, first.inv_root, first.root_order, len(first._data()))
+        key = (first.modulus, first.degree, first.root, first.inv_root, first.root_order, first._len())
         for m in (self,) + others:
             rows = m.matrix if isinstance(m, GeneralMatrix) else [[m]]
             for row in rows:
                 for z in row:
                     if not isinstance(z, self.elem_class) or \
-                            (z.modulus, z.degree, z.root, z.inv_root, z.root_order, len(z._data())) != key:
+                            (z.modulus, z.degree, z.root, z.inv_root, z.root_order, z._len()) != key:
                         return None
         return first
 
     def _stack(self):
-        q = self.matrix[0][0].modulus
-        return _backend.to_i32([z._data() for row in self.matrix for z in row], q)
+        return _backend.stack_polys([z for row in self.matrix for z in row], self.matrix[0][0].modulus)
 
     def _rebuild(self, template, arr, rows, cols):
-        vals = arr.tolist()
-        return GeneralMatrix(matrix=[[template._like(vals[i * cols + j]) for j in range(cols)] for i in range(rows)])
+        # entries are rows of `arr` (views, never written to); their lists are built only if somebody asks for them
+        return GeneralMatrix(matrix=[[template._like_arr(arr[i * cols + j]) for j in range(cols)] for i in range(rows)])
 
     # ---- algebra -------------------------------------------------------------------------------
     def __eq__(self, other):
@@ -118,7 +117,7 @@ class GeneralMatrix:
         # an all-zero right entry makes the reference return the LEFT object itself (uncentred);
         # keep that exact behaviour by using the element operators whenever it could matter
         if t is not None and not any(z == 0 for row in other.matrix for z in row):
-            ctx = _backend.ring_ctx(t.modulus, len(t._data()))
+            ctx = _backend.ring_ctx(t.modulus, t._len())
             return self._rebuild(t, ctx.pw_add(self._stack(), other._stack()), rows, cols)
         return GeneralMatrix(matrix=[[self.matrix[i][j] + other.matrix[i][j] for j in range(cols)]
                                      for i in range(rows)])
@@ -132,7 +131,7 @@ class GeneralMatrix:
         rows, cols = self._shape()
         t = self._uniform_ring()
         if t is not None:
-            ctx = _backend.ring_ctx(t.modulus, len(t._data()))
+            ctx = _backend.ring_ctx(t.modulus, t._len())
             return self._rebuild(t, ctx.pw_neg(self._stack()), rows, cols)
         return GeneralMatrix(matrix=[[-self.matrix[i][j] for j in range(cols)] for i in range(rows)])
 
@@ -146,7 +145,7 @@ class GeneralMatrix:
             t = self._uniform_ring(other)
             if (t is not None and self.elem_class is PolynomialNTTRepresentation and not other == 0
                     and not other == 1):
-                ctx = _backend.ring_ctx(t.modulus, len(t._data()))
+                ctx = _backend.ring_ctx(t.modulus, t._len())
                 a = self._stack()
                 b = np.broadcast_to(other._i32(), a.shape)
                 return self._rebuild(t, ctx.pw_mul(a, b), rows, cols)
@@ -161,12 +160,12 @@ class GeneralMatrix:
                 and not any(z == 0 for m in (self, other) for row in m.matrix for z in row)):
             # result[i][j] = sum_k self[i][k] * other[k][j]: one fused multiply-accumulate launch per
             # result row (for the scheme's (1 x l).(l x 1) shape: exactly one launch)
-            ctx = _backend.ring_ctx(t.modulus, len(t._data()))
-            d = len(t._data())
+            ctx = _backend.ring_ctx(t.modulus, t._len())
+            d = t._len()
             A = self._stack().reshape(rows, cols, d)
             B = other._stack().reshape(cols, ocols, d).transpose(1, 0, 2)      # [ocols][cols][d]
             out = [ctx.matvec(A[i], np.ascontiguousarray(B)) for i in range(rows)]   # each [ocols][d]
-            return GeneralMatrix(matrix=[[t._like(out[i][j].tolist()) for j in range(ocols)] for i in range(rows)])
+            return GeneralMatrix(matrix=[[t._like_arr(out[i][j]) for j in range(ocols)] for i in range(rows)])
         result = []
         for i in range(rows):
             out_row = []

@@ -81,15 +81,53 @@ class PolynomialRepresentation(object):
             cached_logmods[self.modulus] = self.modulus.bit_length() - 1
         return cached_logmods[self.modulus]
 
+    # -- storage ----------------------------------------------------------------------------
+    # The data attribute (`coefficients` / `values`) is a list of Python ints as far as any caller can tell (the reference's
+    # tests mutate its elements in place: tests/test_polynomials.py:280-283, tests/test_fusion.py:864-867).  An object the
+    # library produced itself starts as the int32 row the device returned (`_arr`: never written to afterwards, possibly a
+    # view shared with sibling objects) and builds the list on first access; from then on the list is the only copy.  A
+    # key that goes keygen -> sign, or a signature that goes sign -> aggregate -> verify, never becomes 21 248 Python ints.
+    def _get_data(self):
+        lst = self._list
+        if lst is None:
+            lst = self._list = self._arr.tolist()
+            self._arr = None
+        return lst
+
+    def _set_data(self, data):
+        self._list = data
+        self._arr = None
+
+    def _data(self):
+        return self._get_data()
+
+    def _len(self):
+        return len(self._list) if self._arr is None else int(self._arr.shape[0])
+
+    def _like(self, data):
+        """same ring, new data the library produced itself (a fresh list of Python ints): the per-element isinstance scan
+        of __init__ -- 70 % of the object API's time -- has nothing to find"""
+        z = object.__new__(type(self))
+        z.modulus, z.degree, z.root, z.inv_root, z.root_order = self.modulus, self.degree, self.root, self.inv_root, self.root_order
+        z._list, z._arr = data, None
+        return z
+
+    def _like_arr(self, arr):
+        """same ring, data = a one-dimensional int32 array the library produced (not copied, never written to)"""
+        z = object.__new__(type(self))
+        z.modulus, z.degree, z.root, z.inv_root, z.root_order = self.modulus, self.degree, self.root, self.inv_root, self.root_order
+        z._list, z._arr = None, arr
+        return z
+
     # -- helpers shared by both representations ---------------------------------------------
     def _ring(self):
-        return _backend.ring_ctx(self.modulus, max(1, len(self._data())))
+        return _backend.ring_ctx(self.modulus, max(1, self._len()))
 
     def _ntt(self):
         return _backend.ntt_ctx(self.modulus, self.degree, self.root, self.inv_root)
 
     def _i32(self):
-        return _backend.to_i32(self._data(), self.modulus)
+        return self._arr if self._arr is not None else _backend.to_i32(self._list, self.modulus)
 
     def _same_ring(self, other, verb):
         """NotImplementedError on any mismatch, in the reference's order (:121-132, :289-302)."""
@@ -104,7 +142,8 @@ class PolynomialRepresentation(object):
 
 
 class PolynomialCoefficientRepresentation(PolynomialRepresentation):
-    coefficients: List[int]
+    coefficients = property(PolynomialRepresentation._get_data, PolynomialRepresentation._set_data,
+                            doc="List[int]; see the storage note in PolynomialRepresentation")
 
     def __init__(self, modulus: int, degree: int, root: int, inv_root: int, root_order: int,
                  coefficients: List[int]):
@@ -116,17 +155,6 @@ class PolynomialCoefficientRepresentation(PolynomialRepresentation):
         if len(coefficients) != degree:
             raise ValueError("coefficients must be of length degree")
         self.coefficients = coefficients
-
-    def _data(self):
-        return self.coefficients
-
-    def _like(self, values):
-        """same ring, new data the library produced itself (a fresh list of `degree` Python ints from ndarray.tolist()):
-        the per-element isinstance scan of __init__ -- 70 % of the object API's time -- has nothing to find"""
-        z = object.__new__(PolynomialCoefficientRepresentation)
-        z.modulus, z.degree, z.root, z.inv_root, z.root_order = self.modulus, self.degree, self.root, self.inv_root, self.root_order
-        z.coefficients = values
-        return z
 
     def __str__(self):
         return (f"PolynomialCoefficientRepresentation(modulus={self.modulus}, degree={self.degree}, "
@@ -144,6 +172,9 @@ class PolynomialCoefficientRepresentation(PolynomialRepresentation):
                 (other.modulus, other.degree, other.root, other.root_order):
             return False
         q = self.modulus
+        if self._arr is not None and other._arr is not None:
+            return bool(np.all((self._arr.astype(np.int64) - other._arr) % q == 0)) if self._arr.shape == other._arr.shape else \
+                all((x - y) % q == 0 for x, y in zip(self.coefficients, other.coefficients))
         return all((x - y) % q == 0 for x, y in zip(self.coefficients, other.coefficients))
 
     def __add__(self, other):
@@ -152,7 +183,7 @@ class PolynomialCoefficientRepresentation(PolynomialRepresentation):
         if not isinstance(other, PolynomialCoefficientRepresentation):
             raise NotImplementedError(f"Addition for {type(self)} and {type(other)} not implemented")
         self._same_ring(other, "add")
-        return self._like(self._ring().pw_add(self._i32(), other._i32()).tolist())
+        return self._like_arr(self._ring().pw_add(self._i32(), other._i32()))
 
     def __radd__(self, other):
         if other == 0:
@@ -161,7 +192,7 @@ class PolynomialCoefficientRepresentation(PolynomialRepresentation):
 
     def __neg__(self):
         # -(x mod q), in [-(q-1), 0]: deliberately NOT centred, as in the reference (:155-163)
-        return self._like(self._ring().pw_neg(self._i32()).tolist())
+        return self._like_arr(self._ring().pw_neg(self._i32()))
 
     def __sub__(self, other):
         return self + (-other)
@@ -185,7 +216,7 @@ class PolynomialCoefficientRepresentation(PolynomialRepresentation):
         if self.root_order != other.root_order:
             raise NotImplementedError(f"Multiplication for {type(self)} with different root orders not implemented")
         # negacyclic product mod (X^d + 1, q): NTT -> pointwise -> INTT on the device
-        return self._like(self._ntt().poly_mul(self._i32(), other._i32()).tolist())
+        return self._like_arr(self._ntt().poly_mul(self._i32(), other._i32()))
 
     def __rmul__(self, other):
         return self.__mul__(other=other)
@@ -194,9 +225,9 @@ class PolynomialCoefficientRepresentation(PolynomialRepresentation):
         if p != "infty":
             raise NotImplementedError(f"norm for p={p} not implemented")
         # max |x| over the STORED values (:221-224); the device type is int32
-        if any(x < _backend.INT32_MIN or x > _backend.INT32_MAX for x in self.coefficients):
+        if self._arr is None and any(x < _backend.INT32_MIN or x > _backend.INT32_MAX for x in self.coefficients):
             raise OverflowError("norm(): a stored coefficient is outside int32, the library's data type")
-        mx, _ = self._ring().norm_weight(np.array(self.coefficients, dtype=np.int32))
+        mx, _ = self._ring().norm_weight(self._arr if self._arr is not None else np.array(self.coefficients, dtype=np.int32))
         return int(mx[0])
 
     def weight(self) -> int:
@@ -205,7 +236,8 @@ class PolynomialCoefficientRepresentation(PolynomialRepresentation):
 
 
 class PolynomialNTTRepresentation(PolynomialRepresentation):
-    values: List[int]
+    values = property(PolynomialRepresentation._get_data, PolynomialRepresentation._set_data,
+                      doc="List[int]; see the storage note in PolynomialRepresentation")
 
     def __init__(self, modulus: int, degree: int, root: int, inv_root: int, root_order: int, values: List[int]):
         super().__init__(modulus=modulus, degree=degree, root=root, inv_root=inv_root, root_order=root_order)
@@ -216,16 +248,6 @@ class PolynomialNTTRepresentation(PolynomialRepresentation):
         if len(values) != degree:
             raise ValueError("values must have length degree")
         self.values = values
-
-    def _data(self):
-        return self.values
-
-    def _like(self, values):
-        """see PolynomialCoefficientRepresentation._like"""
-        z = object.__new__(PolynomialNTTRepresentation)
-        z.modulus, z.degree, z.root, z.inv_root, z.root_order = self.modulus, self.degree, self.root, self.inv_root, self.root_order
-        z.values = values
-        return z
 
     def __str__(self):
         return (f"PolynomialNTTRepresentation(modulus={self.modulus}, degree={self.degree}, root={self.root}, "
@@ -243,8 +265,10 @@ class PolynomialNTTRepresentation(PolynomialRepresentation):
         if (self.modulus, self.degree, self.root_order, self.root, self.inv_root) != \
                 (other.modulus, other.degree, other.root_order, other.root, other.inv_root):
             return False
-        if len(self.values) != len(other.values):
+        if self._len() != other._len():
             return False
+        if self._arr is not None and other._arr is not None:
+            return bool(np.all((self._arr.astype(np.int64) - other._arr) % q == 0))
         return all((x - y) % q == 0 for x, y in zip(self.values, other.values))
 
     def __add__(self, other):
@@ -253,9 +277,9 @@ class PolynomialNTTRepresentation(PolynomialRepresentation):
         if not isinstance(other, PolynomialNTTRepresentation):
             raise NotImplementedError(f"Addition for {type(self)} and {type(other)} not implemented")
         self._same_ring(other, "add")
-        if len(self.values) != len(other.values):
+        if self._len() != other._len():
             raise NotImplementedError("Cannot add polynomials with different lengths")
-        return self._like(self._ring().pw_add(self._i32(), other._i32()).tolist())
+        return self._like_arr(self._ring().pw_add(self._i32(), other._i32()))
 
     def __radd__(self, other):
         if other == 0:
@@ -263,7 +287,7 @@ class PolynomialNTTRepresentation(PolynomialRepresentation):
         return self + other
 
     def __neg__(self):
-        return self._like(self._ring().pw_neg(self._i32()).tolist())
+        return self._like_arr(self._ring().pw_neg(self._i32()))
 
     def __sub__(self, other):
         return self + (-other)
@@ -286,9 +310,9 @@ class PolynomialNTTRepresentation(PolynomialRepresentation):
             raise NotImplementedError(f"Multiplication for {type(self)} with different roots of unity not implemented")
         if self.root_order != other.root_order:
             raise NotImplementedError(f"Multiplication for {type(self)} with different root orders not implemented")
-        if len(self.values) != len(other.values):
+        if self._len() != other._len():
             raise NotImplementedError(f"Multiplication for {type(self)} with different lengths not implemented")
-        return self._like(self._ring().pw_mul(self._i32(), other._i32()).tolist())
+        return self._like_arr(self._ring().pw_mul(self._i32(), other._i32()))
 
     def __rmul__(self, other):
         return self.__mul__(other=other)
@@ -309,20 +333,26 @@ def _check_transformable(x, n):
         raise NotImplementedError(f"root_order={x.root_order}=degree={n} is not implemented")
 
 
+def _as(cls, x):
+    """an empty object of class `cls` in x's ring (a template for _like / _like_arr)"""
+    z = object.__new__(cls)
+    z.modulus, z.degree, z.root, z.inv_root, z.root_order = x.modulus, x.degree, x.root, x.inv_root, x.root_order
+    z._list, z._arr = [], None
+    return z
+
+
 def transform(x: Union[PolynomialCoefficientRepresentation, PolynomialNTTRepresentation]
               ) -> Union[PolynomialNTTRepresentation, PolynomialCoefficientRepresentation]:
     """Coefficient <-> NTT domain on a copy of the data (polynomials.py:391-433)."""
     if isinstance(x, (PolynomialCoefficientRepresentation, PolynomialNTTRepresentation)):
-        _check_transformable(x, len(x._data()))
+        _check_transformable(x, x._len())
+    # the ring parameters were validated when x was built; the result shares them (the reference re-validates: same outcome)
     if isinstance(x, PolynomialCoefficientRepresentation):
         out = x._ntt().ntt_forward(x._i32())
-        return PolynomialNTTRepresentation(modulus=x.modulus, degree=x.degree, root=x.root, inv_root=x.inv_root,
-                                           root_order=x.root_order, values=out.tolist())
+        return PolynomialRepresentation._like_arr(_as(PolynomialNTTRepresentation, x), out.reshape(-1))
     if isinstance(x, PolynomialNTTRepresentation):
         out = x._ntt().ntt_inverse(x._i32())
-        return PolynomialCoefficientRepresentation(modulus=x.modulus, degree=x.degree, root=x.root,
-                                                   inv_root=x.inv_root, root_order=x.root_order,
-                                                   coefficients=out.tolist())
+        return PolynomialRepresentation._like_arr(_as(PolynomialCoefficientRepresentation, x), out.reshape(-1))
     raise NotImplementedError(f"Transform for {type(x)} not implemented")
 
 

@@ -24,8 +24,9 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from algebra import _backend
+from fusion_hip import hostpipe
 from algebra.matrices import GeneralMatrix
-from algebra.polynomials import (PolynomialCoefficientRepresentation, PolynomialNTTRepresentation,
+from algebra.polynomials import (PolynomialCoefficientRepresentation, PolynomialNTTRepresentation, _check_transformable,
                                  sample_polynomial_coefficient_representation,
                                  sample_polynomial_ntt_representation, transform)
 from fusion_hip import VERDICT_REASONS
@@ -110,11 +111,8 @@ def _replicated(sample_one, num_rows: int, num_cols: int, seed) -> list:
     if seed is None or num_rows * num_cols <= 1:
         return [[sample_one() for _ in range(num_cols)] for _ in range(num_rows)]
     first = sample_one()
-    data_attr = "coefficients" if hasattr(first, "coefficients") else "values"
-
-    def clone():
-        return first._like(list(getattr(first, data_attr)))
-    return [[first if (i == 0 and j == 0) else clone() for j in range(num_cols)] for i in range(num_rows)]
+    row = first._i32()          # the copies share this row until somebody asks one of them for its list (then it gets its own)
+    return [[first if (i == 0 and j == 0) else first._like_arr(row) for j in range(num_cols)] for i in range(num_rows)]
 
 
 def sample_coefficient_matrix(seed: Optional[int], modulus: int, degree: int, root_order: int, root: int,
@@ -203,33 +201,55 @@ def _ntt_poly(params, values):
                                        inv_root=params.inv_root, root_order=params.root_order, values=values)
 
 
+_TEMPLATES = {}
+
+
+def _template(params):
+    """an NTT-domain polynomial of the parameter set's ring, validated once (its data is never used)"""
+    key = (params.modulus, params.degree, params.root, params.inv_root, params.root_order)
+    if key not in _TEMPLATES:
+        t = _ntt_poly(params, [0] * params.degree)
+        _check_transformable(t, params.degree)       # what transform() would object to, once per ring instead of per call
+        _TEMPLATES[key] = t
+    return _TEMPLATES[key]
+
+
 def _column(params, arr):
-    """[rows][d] int32 -> rows x 1 GeneralMatrix of NTT-domain polynomials"""
-    rows = arr.tolist()
-    if not rows:
+    """[rows][d] int32 -> rows x 1 GeneralMatrix of NTT-domain polynomials, each backed by its row of `arr` (the lists of
+    Python ints are built when somebody reads `.values`: algebra/polynomials.py, storage note)"""
+    if not len(arr):
         return GeneralMatrix(matrix=[])
-    first = _ntt_poly(params, rows[0])               # validates the parameter tuple once; the rest share it
-    return GeneralMatrix(matrix=[[first]] + [[first._like(row)] for row in rows[1:]])
+    t = _template(params)
+    return GeneralMatrix(matrix=[[t._like_arr(row)] for row in arr])
 
 
 def _rows_of(matrix: GeneralMatrix, q):
     """GeneralMatrix of polynomials -> [rows*cols][d] int32 (row-major)"""
-    return _backend.to_i32([z._data() for row in matrix.matrix for z in row], q)
+    return _backend.stack_polys([z for row in matrix.matrix for z in row], q)
 
 
 def keygen(params: Params, seed: Optional[int]) -> OneTimeKeyTuple:
     """fusion.py:338-373: two coefficient-domain secret vectors (seeds `seed`, `seed + 1`), their
     NTTs, and vk = public_challenge * sk_hat -- the arithmetic is ONE fz_keygen_core call."""
     q = params.modulus
-    halves = []
-    for s in (seed, seed + 1):
-        coefs = sample_coefficient_matrix(
-            seed=s, modulus=q, degree=params.degree, root_order=params.root_order, root=params.root,
-            inv_root=params.inv_root, num_rows=params.num_rows_sk, num_cols=params.num_cols_sk,
-            norm_bound=params.beta_sk, weight_bound=params.omega_sk)
-        halves.append(_rows_of(coefs, q))
     A = _rows_of(params.public_challenge, q)
-    sk_hat, vk = _ctx(params).keygen_core(A, np.stack(halves)[None])
+    if seed is not None:
+        # every entry of a half is sampled with the same seed (fusion.py:156-173), i.e. IS the same polynomial, and each
+        # call leaves the process-global `random` where one call leaves it: sample it once, let the kernel read it for
+        # all l rows (fz_keygen_core_bcast)
+        halves = [sample_polynomial_coefficient_representation(
+            modulus=q, degree=params.degree, root_order=params.root_order, root=params.root, inv_root=params.inv_root,
+            norm_bound=params.beta_sk, weight_bound=params.omega_sk, seed=s)._i32() for s in (seed, seed + 1)]
+        sk_hat, vk = _ctx(params).keygen_core_bcast(A, np.stack(halves)[None])
+    else:
+        halves = []
+        for s in (seed, seed + 1):       # (raises TypeError on None + 1, as the reference does)
+            coefs = sample_coefficient_matrix(
+                seed=s, modulus=q, degree=params.degree, root_order=params.root_order, root=params.root,
+                inv_root=params.inv_root, num_rows=params.num_rows_sk, num_cols=params.num_cols_sk,
+                norm_bound=params.beta_sk, weight_bound=params.omega_sk)
+            halves.append(_rows_of(coefs, q))
+        sk_hat, vk = _ctx(params).keygen_core(A, np.stack(halves)[None])
     sk = OneTimeSigningKey(seed=seed, left_sk_hat=_column(params, sk_hat[0, 0]),
                            right_sk_hat=_column(params, sk_hat[0, 1]))
     vkey = OneTimeVerificationKey(left_vk_hat=_column(params, vk[0, 0:1]), right_vk_hat=_column(params, vk[0, 1:2]))
@@ -309,6 +329,16 @@ def _challenge_bytes_needed(params: Params) -> int:
     return ceil(params.omega_ch / 8) + coef_bytes * num_coefs + params.degree * index_bytes
 
 
+def _decode_row(params, b, norm_bound, weight_bound):
+    """decode_bytes_to_polynomial_coefficients through the library's C decoder (fz_decode_coefficients; pinned to the Python
+    function above by tests/test_host_pipeline.py) -> int32 row, or None when it declines: the Python function then
+    produces the result or the reference's error"""
+    try:
+        return hostpipe.decode_coefficients(b, params.secpar, params.modulus, params.degree, norm_bound, weight_bound)
+    except Exception:
+        return None
+
+
 def _coef_poly(params, coefficients):
     return PolynomialCoefficientRepresentation(modulus=params.modulus, degree=params.degree, root=params.root,
                                                inv_root=params.inv_root, root_order=params.root_order,
@@ -318,10 +348,13 @@ def _coef_poly(params, coefficients):
 def parse_challenge(params: Params, b: bytes) -> PolynomialNTTRepresentation:
     if len(b) < params.omega_ch * params.bytes_for_one_coef_bdd_by_beta_ch + params.bytes_for_poly_shuffle:
         raise ValueError("hashed_vk_and_pre_hashed_message is too short")
+    row = _decode_row(params, b, params.beta_ch, params.omega_ch)
+    if row is not None:
+        return _template(params)._like_arr(_ctx(params).ntt_forward(row))       # one forward NTT on the device
     coefs = decode_bytes_to_polynomial_coefficients(b=b, log2_bias=params.secpar, modulus=params.modulus,
                                                     degree=params.degree, norm_bound=params.beta_ch,
                                                     weight_bound=params.omega_ch)
-    return transform(_coef_poly(params, coefs))       # one forward NTT on the device
+    return transform(_coef_poly(params, coefs))
 
 
 def hash_ch(params: Params, key: OneTimeVerificationKey, message: str) -> SignatureChallenge:
@@ -370,21 +403,26 @@ def hash_vks_and_ints_and_challs_to_bytes(params: Params, keys: List[OneTimeVeri
 def decode_bytes_to_agg_coefs(params: Params, b: bytes) -> List[AggregationCoefficient]:
     n = _agg_coef_bytes(params)
     count = len(b) // n
-    coef_rows = [decode_bytes_to_polynomial_coefficients(b=b[i * n:(i + 1) * n], log2_bias=params.secpar,
-                                                         modulus=params.modulus, degree=params.degree,
-                                                         norm_bound=params.beta_ag, weight_bound=params.omega_ag)
-                 for i in range(count)]
-    if not coef_rows:
+    if not count:
         return []
+    rows = [_decode_row(params, b[i * n:(i + 1) * n], params.beta_ag, params.omega_ag) for i in range(count)]
+    if any(r is None for r in rows):
+        rows = _backend.to_i32([decode_bytes_to_polynomial_coefficients(
+            b=b[i * n:(i + 1) * n], log2_bias=params.secpar, modulus=params.modulus, degree=params.degree,
+            norm_bound=params.beta_ag, weight_bound=params.omega_ag) for i in range(count)], params.modulus)
     # all `count` forward transforms in one batched launch
-    hats = _ctx(params).ntt_forward(_backend.to_i32(coef_rows, params.modulus))
-    return [AggregationCoefficient(alpha_hat=_ntt_poly(params, row)) for row in hats.tolist()]
+    hats = _ctx(params).ntt_forward(np.stack(rows))
+    t = _template(params)
+    return [AggregationCoefficient(alpha_hat=t._like_arr(row)) for row in hats]
 
 
-def hash_ag(params: Params, keys: List[OneTimeVerificationKey], messages: List[str]) -> List[AggregationCoefficient]:
+def hash_ag(params: Params, keys: List[OneTimeVerificationKey], messages: List[str],
+            _challs: Optional[List[SignatureChallenge]] = None) -> List[AggregationCoefficient]:
+    """fusion.py:632-652.  `_challs` (not in the reference): the challenges of exactly these (key, message) pairs when the
+    caller has them already -- verify() needs them itself, and hash_ch is a pure function of its arguments."""
     pairs = list(zip(keys, messages))
     pre_hashed = [hash_message_to_int(params=params, message=m) for _, m in pairs]
-    challs = [hash_ch(params=params, key=k, message=m) for k, m in pairs]
+    challs = _challs if _challs is not None else [hash_ch(params=params, key=k, message=m) for k, m in pairs]
     b = hash_vks_and_ints_and_challs_to_bytes(params=params, keys=keys, prehashed_messages=pre_hashed,
                                               challenges=challs)
     return decode_bytes_to_agg_coefs(params=params, b=b)
@@ -397,7 +435,7 @@ def aggregate(params: Params, keys: List[OneTimeVerificationKey], messages: List
     alphas = hash_ag(params=params, keys=[t[0] for t in triples], messages=[t[1] for t in triples])
     q = params.modulus
     sig = np.stack([_rows_of(t[2].signature_hat, q) for t in triples])
-    alpha = _backend.to_i32([a.alpha_hat.values for a in alphas], q)
+    alpha = _backend.stack_polys([a.alpha_hat for a in alphas], q)
     out = _ctx(params).aggregate_core(sig, alpha)
     return Signature(signature_hat=_column(params, out))
 
@@ -413,13 +451,13 @@ def verify(params: Params, keys: List[OneTimeVerificationKey], messages: List[st
     pairs = sorted(zip(keys, messages), key=lambda x: str(x[0]))
     sorted_vks = [p[0] for p in pairs]
     challs = [hash_ch(params=params, key=k, message=m) for k, m in pairs]
-    alphas = hash_ag(params=params, keys=sorted_vks, messages=[p[1] for p in pairs])
+    alphas = hash_ag(params=params, keys=sorted_vks, messages=[p[1] for p in pairs], _challs=challs)
     q = params.modulus
     code = _ctx(params).verify_core(
         _rows_of(params.public_challenge, q), _rows_of(aggregate_signature.signature_hat, q),
-        _backend.to_i32([v.left_vk_hat.matrix[0][0].values for v in sorted_vks], q),
-        _backend.to_i32([v.right_vk_hat.matrix[0][0].values for v in sorted_vks], q),
-        _backend.to_i32([c.c_hat.values for c in challs], q),
-        _backend.to_i32([a.alpha_hat.values for a in alphas], q),
+        _backend.stack_polys([v.left_vk_hat.matrix[0][0] for v in sorted_vks], q),
+        _backend.stack_polys([v.right_vk_hat.matrix[0][0] for v in sorted_vks], q),
+        _backend.stack_polys([c.c_hat for c in challs], q),
+        _backend.stack_polys([a.alpha_hat for a in alphas], q),
         params.beta_vf, params.omega_vf)
     return (code == 0), VERDICT_REASONS[code]

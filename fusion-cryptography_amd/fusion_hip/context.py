@@ -407,6 +407,23 @@ class Context:
             for b in (dA, dC, dS, dV):
                 b.free()
 
+    def keygen_core_bcast(self, A, polys):
+        """A [l][d]; polys [batch][2][d]: ONE secret polynomial per (key, half), standing for all l rows of that half
+        (every entry of a seeded half is the same polynomial: fusion.py:156-173) -> (sk_hat [batch][2][l][d], vk [batch][2][d])."""
+        A, polys = _as_i32(A), _as_i32(polys)
+        l, d = A.shape
+        p3 = polys.reshape(-1, 2, d)
+        batch = p3.shape[0]
+        dA, dC = self._staged([A, p3])
+        dS = DeviceBuffer(self, batch * 2 * l * d * 4)
+        dV = DeviceBuffer(self, batch * 2 * d * 4)
+        try:
+            self.keygen_core_bcast_dev(dA.ptr, dC.ptr, dS.ptr, dV.ptr, batch, l)
+            return dS.to_numpy(np.int32, (batch, 2, l, d)), dV.to_numpy(np.int32, (batch, 2, d))
+        finally:
+            for b in (dA, dC, dS, dV):
+                b.free()
+
     def sign_core(self, sk_hat, c_hat):
         """sk_hat [batch][2][l][d]; c_hat [batch][d] -> sig [batch][l][d]."""
         sk, c = _as_i32(sk_hat), _as_i32(c_hat)

@@ -167,3 +167,66 @@ def test_scheme_properties(secpar):
     agg = F.aggregate(params, [vk], [msg], [sig])
     assert F.verify(params, [vk], [msg], agg) == (True, "")
     assert F.verify(params, [vk], [msg + "!"], agg) == (False, "Target doesn't match image of aggregate signature.")
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_lists_are_built_on_demand_and_stay_authoritative(secpar):
+    """What the library produces is array-backed until somebody reads `.values` / `.coefficients` (algebra/polynomials.py,
+    storage note); what a caller can observe is the reference's: lists of Python ints that may be mutated in place
+    (reference tests/test_polynomials.py:280-283, tests/test_fusion.py:861-867) and are what every later call uses."""
+    import copy
+    import fusion.fusion as F
+    from algebra.polynomials import transform
+    params = F.fusion_setup(secpar, 77)
+    sk, vk = F.keygen(params, 4321)
+    z = sk.left_sk_hat.matrix[3][0]
+    assert z._arr is not None and z._list is None                  # nobody asked for the list yet
+    msg = "a message"
+    sig = F.sign(params, (sk, vk), msg)
+    assert z._arr is not None                                      # sign() read the rows, not lists
+    assert sig.signature_hat.matrix[0][0]._arr is not None
+    agg = F.aggregate(params, [vk], [msg], [sig])
+    assert F.verify(params, [vk], [msg], agg) == (True, "")
+    assert all(p._arr is not None for row in sig.signature_hat.matrix for p in row)      # still no lists of the signature
+    # reading builds the list once; the same object comes back every time; its elements are Python ints
+    vals = z.values
+    assert vals is z.values and type(vals) is list and all(type(v) is int for v in vals) and z._arr is None
+    assert len(vals) == params.degree and "values=[" + str(vals[0]) + "," in str(z)
+    # a copy made BEFORE a mutation is independent of it (array-backed siblings share rows, lists are never shared)
+    twin = copy.deepcopy(sk)
+    before = F.sign(params, (sk, vk), msg)
+    vals[0] = (vals[0] + 1) % 7
+    after = F.sign(params, (sk, vk), msg)
+    assert after.signature_hat.matrix[3][0] != before.signature_hat.matrix[3][0]      # the mutated list is what sign() used
+    assert after.signature_hat.matrix[2][0] == before.signature_hat.matrix[2][0]
+    assert F.sign(params, (twin, vk), msg).signature_hat == before.signature_hat
+    # assignment replaces the data; in-place element mutation of a signature changes the verdict (test_fusion.py:861-867)
+    z.values = list(twin.left_sk_hat.matrix[3][0].values)
+    assert F.sign(params, (sk, vk), msg).signature_hat == before.signature_hat
+    agg.signature_hat.matrix[0][0].values[0] += 1
+    assert F.verify(params, [vk], [msg], agg) == (False, "Target doesn't match image of aggregate signature.")
+    # the entries of a seeded sample are independent objects although they start from one row
+    A = params.public_challenge
+    a0, a1 = A.matrix[0][0], A.matrix[0][1]
+    assert a0 == a1 and a0 is not a1
+    a1.values[5] += 1
+    assert a0 != a1 and A.matrix[0][2] == a0
+    a1.values[5] -= 1
+    # transform results are array-backed too and equal their list-backed selves
+    c = transform(a0)
+    assert c._arr is not None and transform(c) == a0 and c.coefficients == list(c.coefficients)
+
+
+def test_keygen_leaves_the_global_generator_where_the_reference_does():
+    """keygen(params, seed) samples ONE polynomial per half and lets the kernel read it for all l rows; the reference samples
+    every entry with the same seed (fusion.py:156-173, :338-362), which leaves `random` in the state one seeded call leaves"""
+    import fusion.fusion as F
+    params = F.fusion_setup(128, 5)
+    F.keygen(params, 99)
+    state = random.getstate()
+    F.sample_coefficient_matrix(seed=100, modulus=params.modulus, degree=params.degree, root_order=params.root_order,
+                                root=params.root, inv_root=params.inv_root, num_rows=params.num_rows_sk,
+                                num_cols=params.num_cols_sk, norm_bound=params.beta_sk, weight_bound=params.omega_sk)
+    assert random.getstate() == state
+    with pytest.raises(TypeError):
+        F.keygen(params, None)

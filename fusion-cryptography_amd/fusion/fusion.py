@@ -363,6 +363,26 @@ def hash_ch(params: Params, key: OneTimeVerificationKey, message: str) -> Signat
     return SignatureChallenge(c_hat=parse_challenge(params=params, b=xof))
 
 
+def _challenges(params: Params, pairs) -> List[SignatureChallenge]:
+    """[hash_ch(params, key, message) for key, message in pairs] with ONE batched forward transform for all of them
+    instead of a launch per signer; anything the C decoder declines goes through hash_ch itself"""
+    pairs = list(pairs)
+    n = _challenge_bytes_needed(params)
+    rows = []
+    for k, m in pairs:
+        b = hash_vk_and_int_to_bytes(params=params, key=k, i=hash_message_to_int(params=params, message=m), n=n)
+        row = None
+        if len(b) >= params.omega_ch * params.bytes_for_one_coef_bdd_by_beta_ch + params.bytes_for_poly_shuffle:
+            row = _decode_row(params, b, params.beta_ch, params.omega_ch)
+        if row is None:
+            return [hash_ch(params=params, key=k, message=m) for k, m in pairs]
+        rows.append(row)
+    if not rows:
+        return []
+    t = _template(params)
+    return [SignatureChallenge(c_hat=t._like_arr(r)) for r in _ctx(params).ntt_forward(np.stack(rows))]
+
+
 def sign(params: Params, key: OneTimeKeyTuple, message: str) -> Signature:
     """sigma = left_sk_hat * c_hat + right_sk_hat (fusion.py:534-557) as one fz_sign_core call."""
     sk, vk = key
@@ -422,7 +442,7 @@ def hash_ag(params: Params, keys: List[OneTimeVerificationKey], messages: List[s
     caller has them already -- verify() needs them itself, and hash_ch is a pure function of its arguments."""
     pairs = list(zip(keys, messages))
     pre_hashed = [hash_message_to_int(params=params, message=m) for _, m in pairs]
-    challs = _challs if _challs is not None else [hash_ch(params=params, key=k, message=m) for k, m in pairs]
+    challs = _challs if _challs is not None else _challenges(params, pairs)
     b = hash_vks_and_ints_and_challs_to_bytes(params=params, keys=keys, prehashed_messages=pre_hashed,
                                               challenges=challs)
     return decode_bytes_to_agg_coefs(params=params, b=b)
@@ -450,7 +470,7 @@ def verify(params: Params, keys: List[OneTimeVerificationKey], messages: List[st
         return False, VERDICT_REASONS[2]
     pairs = sorted(zip(keys, messages), key=lambda x: str(x[0]))
     sorted_vks = [p[0] for p in pairs]
-    challs = [hash_ch(params=params, key=k, message=m) for k, m in pairs]
+    challs = _challenges(params, pairs)
     alphas = hash_ag(params=params, keys=sorted_vks, messages=[p[1] for p in pairs], _challs=challs)
     q = params.modulus
     code = _ctx(params).verify_core(

@@ -434,3 +434,15 @@ def test_a_captured_aggregation_survives_later_scratch_growth(coracle):
     for b in (dA, d_sig, d_al, d_out, d_tgt, d_verd, b_sig, b_al, b_part, b_tgt, b_verd, b_many):
         b.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("args", [["--secpar", "128"], ["--secpar", "256", "--signatures", "5", "--distinct-seeds"]])
+def test_demo_script_runs_the_reference_flow(args):
+    """examples/demo.py = misc/demo.py's five calls on the drop-in package, as a user switching over would run them"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "demo.py")] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().endswith("Verification successful!"), r.stdout

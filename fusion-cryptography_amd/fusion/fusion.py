@@ -233,7 +233,7 @@ def keygen(params: Params, seed: Optional[int]) -> OneTimeKeyTuple:
     NTTs, and vk = public_challenge * sk_hat -- the arithmetic is ONE fz_keygen_core call."""
     q = params.modulus
     A = _rows_of(params.public_challenge, q)
-    if seed is not None:
+    if seed is not None and _pristine("sample_coefficient_matrix", "transform"):
         # every entry of a half is sampled with the same seed (fusion.py:156-173), i.e. IS the same polynomial, and each
         # call leaves the process-global `random` where one call leaves it: sample it once, let the kernel read it for
         # all l rows (fz_keygen_core_bcast)
@@ -329,6 +329,17 @@ def _challenge_bytes_needed(params: Params) -> int:
     return ceil(params.omega_ch / 8) + coef_bytes * num_coefs + params.degree * index_bytes
 
 
+_ORIGINALS = {}
+
+
+def _pristine(*names):
+    """True while the module-level functions a shortcut bypasses are the ones defined here.  The reference's tests replace
+    `fusion.fusion.decode_bytes_to_polynomial_coefficients` (tests/test_fusion.py:596, :644, :652) and expect parse_challenge
+    and hash_ch to call the replacement: a shortcut must step aside for whoever patches the function it stands in for."""
+    g = globals()
+    return all(g.get(n) is _ORIGINALS.get(n) for n in names)
+
+
 def _decode_row(params, b, norm_bound, weight_bound):
     """decode_bytes_to_polynomial_coefficients through the library's C decoder (fz_decode_coefficients; pinned to the Python
     function above by tests/test_host_pipeline.py) -> int32 row, or None when it declines: the Python function then
@@ -348,7 +359,7 @@ def _coef_poly(params, coefficients):
 def parse_challenge(params: Params, b: bytes) -> PolynomialNTTRepresentation:
     if len(b) < params.omega_ch * params.bytes_for_one_coef_bdd_by_beta_ch + params.bytes_for_poly_shuffle:
         raise ValueError("hashed_vk_and_pre_hashed_message is too short")
-    row = _decode_row(params, b, params.beta_ch, params.omega_ch)
+    row = _decode_row(params, b, params.beta_ch, params.omega_ch) if _pristine("decode_bytes_to_polynomial_coefficients") else None
     if row is not None:
         return _template(params)._like_arr(_ctx(params).ntt_forward(row))       # one forward NTT on the device
     coefs = decode_bytes_to_polynomial_coefficients(b=b, log2_bias=params.secpar, modulus=params.modulus,
@@ -367,6 +378,8 @@ def _challenges(params: Params, pairs) -> List[SignatureChallenge]:
     """[hash_ch(params, key, message) for key, message in pairs] with ONE batched forward transform for all of them
     instead of a launch per signer; anything the C decoder declines goes through hash_ch itself"""
     pairs = list(pairs)
+    if not _pristine("hash_ch", "parse_challenge", "decode_bytes_to_polynomial_coefficients", "transform"):
+        return [hash_ch(params=params, key=k, message=m) for k, m in pairs]
     n = _challenge_bytes_needed(params)
     rows = []
     for k, m in pairs:
@@ -425,7 +438,8 @@ def decode_bytes_to_agg_coefs(params: Params, b: bytes) -> List[AggregationCoeff
     count = len(b) // n
     if not count:
         return []
-    rows = [_decode_row(params, b[i * n:(i + 1) * n], params.beta_ag, params.omega_ag) for i in range(count)]
+    fast = _pristine("decode_bytes_to_polynomial_coefficients")
+    rows = [_decode_row(params, b[i * n:(i + 1) * n], params.beta_ag, params.omega_ag) if fast else None for i in range(count)]
     if any(r is None for r in rows):
         rows = _backend.to_i32([decode_bytes_to_polynomial_coefficients(
             b=b[i * n:(i + 1) * n], log2_bias=params.secpar, modulus=params.modulus, degree=params.degree,
@@ -471,7 +485,10 @@ def verify(params: Params, keys: List[OneTimeVerificationKey], messages: List[st
     pairs = sorted(zip(keys, messages), key=lambda x: str(x[0]))
     sorted_vks = [p[0] for p in pairs]
     challs = _challenges(params, pairs)
-    alphas = hash_ag(params=params, keys=sorted_vks, messages=[p[1] for p in pairs], _challs=challs)
+    if _pristine("hash_ag"):
+        alphas = hash_ag(params=params, keys=sorted_vks, messages=[p[1] for p in pairs], _challs=challs)
+    else:
+        alphas = hash_ag(params=params, keys=sorted_vks, messages=[p[1] for p in pairs])
     q = params.modulus
     code = _ctx(params).verify_core(
         _rows_of(params.public_challenge, q), _rows_of(aggregate_signature.signature_hat, q),
@@ -481,3 +498,7 @@ def verify(params: Params, keys: List[OneTimeVerificationKey], messages: List[st
         _backend.stack_polys([a.alpha_hat for a in alphas], q),
         params.beta_vf, params.omega_vf)
     return (code == 0), VERDICT_REASONS[code]
+
+
+_ORIGINALS.update({name: globals()[name] for name in (
+    "decode_bytes_to_polynomial_coefficients", "hash_ch", "parse_challenge", "transform", "sample_coefficient_matrix", "hash_ag")})

@@ -230,3 +230,50 @@ def test_keygen_leaves_the_global_generator_where_the_reference_does():
     assert random.getstate() == state
     with pytest.raises(TypeError):
         F.keygen(params, None)
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_replaced_module_functions_are_honoured(secpar):
+    """The reference's tests replace fusion.fusion.sha3_256, shake_256 and decode_bytes_to_polynomial_coefficients
+    (tests/test_fusion.py:368-435, :559-657, with pytest-mock) and expect hash_message_to_int, hash_vk_and_int_to_bytes,
+    parse_challenge and hash_ch to go through the replacements.  The drop-in's shortcuts (C decoder, batched challenge
+    transforms) must step aside for them -- restated with unittest.mock."""
+    from unittest import mock
+    import fusion.fusion as F
+    from algebra.polynomials import PolynomialCoefficientRepresentation, transform
+    params = F.fusion_setup(secpar, 20240101)
+    sk, vk = F.keygen(params, 20240102)
+    # sha3_256
+    digest = mock.Mock()
+    digest.digest.return_value = (1234567890).to_bytes(32, byteorder="little")
+    with mock.patch("fusion.fusion.sha3_256", return_value=digest) as m:
+        assert F.hash_message_to_int(params, "my_message") == 1234567890
+        m.assert_called_once_with((params.sign_pre_hash_dst.decode("utf-8") + ",my_message").encode())
+    # shake_256
+    xof = mock.Mock()
+    xof.digest.return_value = b"expected_shake_256_result"
+    with mock.patch("fusion.fusion.shake_256", return_value=xof) as m:
+        assert F.hash_vk_and_int_to_bytes(params=params, key=vk, i=1234567890, n=1) == b"expected_shake_256_result"
+        m.assert_called_once_with((params.sign_hash_dst.decode("utf-8") + "," + str(vk) + ",1234567890").encode())
+    # the decoder: parse_challenge and hash_ch must return the transform of what the REPLACEMENT decodes
+    one = [1] + [0] * (params.degree - 1)
+    one_hat = transform(PolynomialCoefficientRepresentation(
+        modulus=params.modulus, degree=params.degree, root=params.root, inv_root=params.inv_root,
+        root_order=params.root_order, coefficients=list(one)))
+    n = F._challenge_bytes_needed(params)
+    real = F.hash_ch(params, vk, "my_message")
+    assert real.c_hat != one_hat
+    with mock.patch("fusion.fusion.decode_bytes_to_polynomial_coefficients", return_value=list(one)) as m:
+        assert F.parse_challenge(params=params, b=bytes(n)) == one_hat and m.call_count == 1
+        assert F.hash_ch(params=params, key=vk, message="my_message") == F.SignatureChallenge(c_hat=one_hat)
+        # aggregate() and verify() reach the decoder through hash_ch / hash_ag: they see the replacement too
+        alphas = F.hash_ag(params, [vk], ["my_message"])
+        assert alphas[0].alpha_hat == one_hat
+    # ... and the shortcuts are back once the replacement is gone
+    assert F.hash_ch(params, vk, "my_message") == real
+    # a replaced hash_ch is what aggregate() / verify() use for their challenges
+    sig = F.sign(params, (sk, vk), "my_message")
+    agg = F.aggregate(params, [vk], ["my_message"], [sig])
+    assert F.verify(params, [vk], ["my_message"], agg) == (True, "")
+    with mock.patch("fusion.fusion.hash_ch", return_value=F.SignatureChallenge(c_hat=one_hat)) as m:
+        assert F.verify(params, [vk], ["my_message"], agg)[0] is False and m.call_count >= 1

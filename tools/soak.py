@@ -51,7 +51,8 @@ KERNS = ["", "4", "16", "4r1", "4r1w4", "4r2", "4r4"]
 VARIANTS = [{}, {"FZ_KEYGEN_UNFUSED": "1", "FZ_VERIFY_UNFUSED": "1", "FZ_POLYMUL_UNFUSED": "1"}, {"FZ_AGG_TWOPASS": "1"},
             {"FZ_AGG_WAVES": "4", "FZ_AGG_SLICES": "3"}, {"FZ_AGG_SLICES": "7", "FZ_VERIFY_ORDERED": "1"}, {"FZ_STREAM_PER_CU": "8"},
             {"FZ_NO_IMAD": "1", "FZ_FUSED_ROWS": "1"}, {"FZ_FUSED_ROWS": "2", "FZ_VERIFY_CENT": "1"}, {"FZ_FUSED_ROWS": "1", "FZ_AGG_SLICES": "2"},
-            {"FZ_FUSED_TW": "1", "FZ_FUSED_PREFETCH": "2"}, {"FZ_FUSED_TW": "1", "FZ_FUSED_ROWS": "2", "FZ_FUSED_PREFETCH": "0"}]
+            {"FZ_FUSED_TW": "1", "FZ_FUSED_PREFETCH": "2"}, {"FZ_FUSED_TW": "1", "FZ_FUSED_ROWS": "2", "FZ_FUSED_PREFETCH": "0"},
+            {"FZ_MATVEC_SLICES": "16"}, {"FZ_MATVEC_SLICES": "2"}, {"FZ_MATVEC_SLICES": "-1"}]
 vctx = {(sp, i): make_ctx(sp, "", v) for sp in (128, 256) for i, v in enumerate(VARIANTS)}
 DB = fusion_hip.DeviceBuffer
 t_end = time.time() + budget
@@ -215,8 +216,14 @@ while time.time() < t_end:
         assert np.array_equal(ring.pw_add(a, b), orc.pw_add(a, b, q)), ("pw_add", count)
         assert np.array_equal(ring.pw_sub(a, b), orc.pw_sub(a, b, q)), ("pw_sub", count)
         assert np.array_equal(ring.pw_neg(a), orc.pw_neg(a, q)), ("pw_neg", count)
-        l = int(rng.choice([1, 2, 9, P["rank"]]))
-        bt = int(rng.integers(1, 30))
+        l = int(rng.choice([1, 2, 9, 40, P["rank"]]))
+        # few products (one workgroup per product), and every now and then enough of them for the sliced kernel (more than two
+        # per CU) with a random slice count
+        many = rng.random() < 0.15
+        bt = int(rng.integers(520, 1400)) if many else int(rng.integers(1, 30))
+        if many:
+            l = min(l, 40)
+            ctx = vctx[(sp, int(rng.integers(len(VARIANTS))))]
         A = rng.integers(-2**31, 2**31, size=(l, d), dtype=np.int64).astype(np.int32)
         S = rng.integers(-2**31, 2**31, size=(bt, l, d), dtype=np.int64).astype(np.int32)
         assert np.array_equal(ctx.matvec(A, S), orc.matvec(A, S, q)), ("matvec", sp, l, bt)

@@ -259,6 +259,8 @@ class PolynomialNTTRepresentation(PolynomialRepresentation):
     def __eq__(self, other):
         q = self.modulus
         if other == 0:     # (for a polynomial `other` this asks whether IT is zero, as the reference does)
+            if self._arr is not None:          # no reason to build 256 Python ints to learn that a row is not zero
+                return not bool(np.any(self._arr.astype(np.int64) % q))
             return all(x % q == 0 for x in self.values)
         if not isinstance(other, PolynomialNTTRepresentation):
             return False

@@ -376,23 +376,29 @@ class BatchScheme:
 
 
 # ---- conversions between the array face and the drop-in object face ----------------------------------------
+def _own(rows):
+    """a private int32 copy: the objects keep their rows as they are until somebody reads their lists
+    (algebra/polynomials.py, storage note), so they must not alias an array the caller may write to afterwards"""
+    return np.array(rows, dtype=np.int32, copy=True)
+
+
 def vk_to_object(params, vk_row):
     """vk [2][d] -> fusion.fusion.OneTimeVerificationKey"""
     import fusion.fusion as F
-    return F.OneTimeVerificationKey(left_vk_hat=F._column(params, np.asarray(vk_row[0:1])),
-                                    right_vk_hat=F._column(params, np.asarray(vk_row[1:2])))
+    vk_row = _own(vk_row)
+    return F.OneTimeVerificationKey(left_vk_hat=F._column(params, vk_row[0:1]), right_vk_hat=F._column(params, vk_row[1:2]))
 
 
 def sk_to_object(params, seed, sk_rows):
     """sk_hat [2][l][d] -> fusion.fusion.OneTimeSigningKey"""
     import fusion.fusion as F
-    return F.OneTimeSigningKey(seed=seed, left_sk_hat=F._column(params, np.asarray(sk_rows[0])),
-                               right_sk_hat=F._column(params, np.asarray(sk_rows[1])))
+    sk_rows = _own(sk_rows)
+    return F.OneTimeSigningKey(seed=seed, left_sk_hat=F._column(params, sk_rows[0]), right_sk_hat=F._column(params, sk_rows[1]))
 
 
 def signature_to_object(params, sig_rows):
     import fusion.fusion as F
-    return F.Signature(signature_hat=F._column(params, np.asarray(sig_rows)))
+    return F.Signature(signature_hat=F._column(params, _own(sig_rows)))
 
 
 def signature_from_object(params, sig):

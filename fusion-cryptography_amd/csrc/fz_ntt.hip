@@ -1089,6 +1089,185 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused verification of MANY aggregates per launch (one workgroup per aggregate), 16 coefficients per lane -- an experiment kept
+// behind FZ_VERIFY16 (see the launcher for what it measured): NOT the default.
+// With a workgroup per aggregate the kernel above is bound by vector issue and LDS, not by HBM; with nothing but registers and
+// LDS in the loop the 16-per-lane inverse transform (one LDS exchange per row, 4 rows of degree 256 per wave) runs 4925 rows/us
+// on the chip against 3190-3850 for the radix-4 structure (three exchanges per row; tools/microbench/ntt_structures.hip,
+// profiles/r03_ntt_structures.txt).  Same contract as verify_fused with gridDim.x == 1; per wave-task (1024 consecutive
+// values = 1024 / D rows of the aggregate):
+//   * four coalesced 16-byte loads per lane of sigma and of A (the next task's are requested before this task's passes);
+//   * observed += A (.) sigma in 64-bit integer multiply-adds IN THAT LAYOUT (lane i holds coefficients 4i .. 4i+3 (mod D) of
+//     every row it touches: four accumulator pairs per lane for the whole loop);
+//   * the int32 values go through the LDS staging image to the lane <-> coefficient mapping of the transform (as ntt_inv16),
+//     then contiguous pass, transpose, strided pass; the outputs are only reduced (max |x|, weight per row).
+// The waves of a workgroup (W = blockDim.x / 64, chosen by the host so that the tasks divide evenly: 21 tasks = 3 x 7 at
+// (l, D) = (83, 256)) meet once, at the end.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void raw_ints(const Raw4<int32_t> &r, int (&s)[4], const FzMod &) { s[0] = r.v.x; s[1] = r.v.y; s[2] = r.v.z; s[3] = r.v.w; }
+__device__ __forceinline__ void raw_ints(const Raw4<int64_t> &r, int (&s)[4], const FzMod &m) {
+    s[0] = (int)fz_cent_i64(r.lo.x, m); s[1] = (int)fz_cent_i64(r.lo.y, m);          // exact for any int64
+    s[2] = (int)fz_cent_i64(r.hi.x, m); s[3] = (int)fz_cent_i64(r.hi.y, m);
+}
+
+template <int LOGD, bool FAST, typename T>
+__global__ __launch_bounds__(384) void verify_many16(const int32_t *A, const T *sig, size_t sig_stride, const T *target,
+                                                     size_t target_stride, int l, long long beta, long long omega, int lazy,
+                                                     const double2 *__restrict__ itwB, FzTwA twA, FzMod m, int *verdict) {
+    using G = Geom<LOGD>;
+    constexpr int D = G::D, L = G::L, PPW = G::PPW, SB = G::SB, NE = G::NE, PS = G::PS;
+    constexpr int REGION = PPW * PS;                       // doubles per wave: transpose buffer, staging image, final partials
+    static_assert(REGION * 2 >= kStageWords && REGION >= 256, "staging image and partials must fit in the transpose buffer");
+    extern __shared__ __attribute__((aligned(16))) double lds16[];      // [W][REGION] + [NE][L] (w, w2) pairs
+    __shared__ int s_flags;
+    const int W = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p = lane / L, r = lane % L;
+    double2 *s_tw = reinterpret_cast<double2 *>(lds16 + W * REGION);
+    for (int i = threadIdx.x; i < NE * L; i += blockDim.x) s_tw[i] = itwB[i];
+    if (threadIdx.x == 0) s_flags = 0;
+    __syncthreads();
+    double *region = lds16 + wave * REGION;
+    int32_t *stage = reinterpret_cast<int32_t *>(region);
+    double *row = region + p * PS;
+    const size_t g = blockIdx.x;
+    sig += g * sig_stride;
+    target += g * target_stride;
+
+    const int tasks = (l + PPW - 1) / PPW;
+    const int j0 = (4 * lane) % D, rsub = (4 * lane) / D;             // coalesced layout: load c covers row PPW*task + (256/D)*c + rsub
+    Raw4<T> sn[4];
+    int4 an[4];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int rw = t * PPW + (256 / D) * c + rsub;
+            const size_t off = (size_t)(rw < l ? rw : l - 1) * D + j0;
+            an[c] = *reinterpret_cast<const int4 *>(A + off);
+            sn[c].load(sig + off);
+        }
+    };
+    long long ihi[4] = {0, 0, 0, 0}, ilo[4] = {0, 0, 0, 0};
+    double mx = 0.0;
+    int wfail = 0;
+    const bool weigh = omega < (long long)D;
+    const unsigned long long gmask = (((1ull << L) - 1ull) << (L * p));
+    int task = wave;
+    if (task < tasks) fetch(task);
+    for (; task < tasks; task += W) {
+        const bool full = (task + 1) * PPW <= l;              // wave-uniform: only the last task can hold slots past the last row
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int si[4];
+            raw_ints(sn[c], si, m);
+            const int av[4] = {an[c].x, an[c].y, an[c].z, an[c].w};
+            if (full) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {       // any int32 sigma, any int32 A: |sigma * hi|, |sigma * lo| < 2^47
+                    ihi[k] += (long long)si[k] * (long long)(av[k] >> 16);
+                    ilo[k] += (long long)si[k] * (long long)(av[k] & 0xffff);
+                }
+            } else {
+                const bool valid = task * PPW + (256 / D) * c + rsub < l;      // a slot past the last row repeats row l - 1: not summed
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const long long sk = valid ? (long long)si[k] : 0ll;
+                    ihi[k] += sk * (long long)(av[k] >> 16);
+                    ilo[k] += sk * (long long)(av[k] & 0xffff);
+                }
+            }
+            *reinterpret_cast<int4 *>(stage + pad4(256 * c + 4 * lane)) = make_int4(si[0], si[1], si[2], si[3]);
+        }
+        fetch(task + W < tasks ? task + W : tasks - 1);       // unconditional, clamped: no branch between request and use
+        wave_sync();
+        double a[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int4 t = *reinterpret_cast<const int4 *>(stage + pad4(16 * lane + 4 * k));
+            a[4 * k + 0] = (double)t.x; a[4 * k + 1] = (double)t.y; a[4 * k + 2] = (double)t.z; a[4 * k + 3] = (double)t.w;
+        }
+        wave_sync();
+        // the inverse transform of ntt_inv16: contiguous pass, fold of the one unreduced value, transpose, strided pass
+#pragma unroll
+        for (int ls = 0; ls < SB; ++ls) {
+            const int t = 1 << ls;
+            const int ebase = 16 - (16 >> ls);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k & t) continue;
+                const int gi = k >> (ls + 1);
+                const double2 w = s_tw[(ebase + gi) * L + r];
+                const double u = a[k], v = a[k + t];
+                a[k] = u + v;
+                a[k + t] = tw_mul<FAST>(u - v, w.x, w.y, m);
+            }
+        }
+        if (FAST && 31 + SB + 4 > 38) a[0] = fz_fold(a[0], m);
+        {
+            double2 *blk = reinterpret_cast<double2 *>(row + 18 * r);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) blk[k] = make_double2(a[2 * k], a[2 * k + 1]);
+        }
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = row[pad16(r + L * k)];
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int tk = 1 << s;
+            const int h = 8 >> s;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k & tk) continue;
+                const double u = a[k], v = a[k + tk];
+                if (s == 3) {
+                    a[k] = tw_mul<FAST>(u + v, twA.n_inv, twA.n_inv2, m);
+                    a[k + tk] = tw_mul<FAST>(u - v, twA.w1_n_inv, twA.w1_n_inv2, m);
+                } else {
+                    const int e = h + (k >> (s + 1));
+                    a[k] = u + v;
+                    a[k + tk] = tw_mul<FAST>(u - v, twA.w[e], twA.w2[e], m);
+                }
+            }
+        }
+        // norm and weight stay in the fp64 lanes (see verify_fused: `lazy`, and why a repeated row l - 1 changes nothing)
+        if (!lazy) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = fz_cent(a[k], m);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mx = __builtin_fmax(mx, __builtin_fabs(a[k]));
+        if (weigh) {
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cnt += __popcll(__ballot(a[k] != 0.0) & gmask);
+            if ((long long)cnt > omega) wfail = 1;
+        }
+    }
+    {
+        const bool small = (tasks + W - 1) / W * 4 <= 32;          // products per accumulator
+        double *mine = region + 4 * lane;                          // this wave's partial of `observed`, at (row slot, position)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mine[k] = fz_imad_total(ihi[k], ilo[k], small, m);
+    }
+    if (mx > (double)beta) atomicOr(&s_flags, 2);
+    if (wfail) atomicOr(&s_flags, 4);
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        double sum = 0;
+        for (int w = 0; w < W; ++w)
+#pragma unroll
+            for (int q = 0; q < 256 / D; ++q) sum += lds16[w * REGION + q * D + c];
+        if ((int)fz_cent_wide(sum, m) != centred_any(target[c], m)) atomicOr(&s_flags, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int f = s_flags;
+        verdict[g] = (f & 1) ? FZ_VERDICT_TARGET_MISMATCH : ((f & 2) ? FZ_VERDICT_NORM : ((f & 4) ? FZ_VERDICT_WEIGHT : FZ_VERDICT_OK));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // D <= 16: one thread per polynomial, everything in registers, twiddles uniform
 // ------------------------------------------------------------------------------------------
 template <int LOGD, bool INVERSE>
@@ -1285,13 +1464,39 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
     if (ctx->knob_verify_blocks > 0) R = ctx->knob_verify_blocks;     // benchmarking knob (FZ_VERIFY_BLOCKS)
     if (R < 1) R = 1;
     if (R > 64) R = 64;
+    // the inverse passes leave |r| <= q/2 + q * 2^-13 (4-op multiply) -- see the kernel's header for why no centring is needed then
+    const int lazy = (beta >= 0 && (double)beta < 0.5 * ctx->mod.q - ctx->mod.q / 4096.0 && !ctx->knob_verify_cent) ? 1 : 0;
+    if (R == 1 && ctx->knob_verify16 != 0 && groups <= 0x7fffffffull && l >= 1) {
+        // FZ_VERIFY16 (A/B runs; off by default): a workgroup per aggregate through the 16-per-lane kernel.  Measured, cold,
+        // 8192 aggregates per launch: 245 us against 237 for the radix-4 kernel at (83, 256), 130 against 119 at (195, 64)
+        // (profiles/r03_verify_ab.txt) -- the structure is the faster one with registers and LDS alone (ntt_structures), but
+        // here it needs 149 VGPRs (3 waves per SIMD against 5) once a task's 8 prefetched loads, 16 fp64 values and 8
+        // accumulators are live together, and forcing 128 spills.
+        // Waves per workgroup: 1 .. 6 as given; any other value = whatever divides the wave-tasks best (a wave's tasks are a
+        // sequential chain and the workgroup ends with its slowest wave), four if nothing is better
+        const int ppw16 = 1024 / ctx->degree, tasks16 = (l + ppw16 - 1) / ppw16;
+        int W = ctx->knob_verify16;
+        if (W < 1 || W > 6) {                                        // (six waves are 59 KiB of LDS: the default dynamic limit is 64)
+            int best = 1 << 30;
+            for (int cand : {4, 3, 2, 5, 6, 1}) {
+                const int waste = (tasks16 + cand - 1) / cand * cand - tasks16;
+                if (waste < best) { best = waste; W = cand; }
+            }
+        }
+        const size_t lds_bytes = ((size_t)W * (ppw16 * (ctx->degree + 2 * (ctx->degree / 16))) + 2 * (size_t)(16 - (16 >> (ctx->logd - 4))) * (ctx->degree / 16)) * sizeof(double);
+#define FZ_V16(LOGD, FAST) hipLaunchKernelGGL((verify_many16<LOGD, FAST, T>), dim3((unsigned)groups), dim3(64 * W), lds_bytes, ctx->stream, A, sig, \
+                                              sig_stride, target, target_stride, l, (long long)beta, (long long)omega, lazy, \
+                                              (const double2 *)ctx->d_itwB, ctx->itwA, ctx->mod, d_verdict)
+        if (ctx->logd == 8) { if (ctx->mod.fast) FZ_V16(8, true); else FZ_V16(8, false); }
+        else { if (ctx->mod.fast) FZ_V16(6, true); else FZ_V16(6, false); }
+#undef FZ_V16
+        return fz_check_hip(hipGetLastError(), "verify_many16 launch");
+    }
     double *part = nullptr;
     int *state = nullptr;
     int rc = fz_verify_scratch(ctx, groups, (size_t)ctx->degree, &part, &state);
     if (rc != FZ_OK) return rc;
     const dim3 grid((unsigned)R, (unsigned)groups), block(64 * kVerifyWaves);
-    // the inverse passes leave |r| <= q/2 + q * 2^-13 (4-op multiply) -- see the kernel's header for why no centring is needed then
-    const int lazy = (beta >= 0 && (double)beta < 0.5 * ctx->mod.q - ctx->mod.q / 4096.0 && !ctx->knob_verify_cent) ? 1 : 0;
     // one row group per wave iteration unless FZ_FUSED_ROWS=2: two measured 248.5 us against 243.9 per 8192 aggregates (the
     // kernel is vector-issue bound; the second row costs occupancy and buys no latency hiding it did not already have)
     const bool two = ctx->knob_fused_rows == 2;

@@ -154,3 +154,50 @@ def test_matvec_forms(secpar, slices, coracle):
             assert np.array_equal(ctx.matvec(A, S), coracle.matvec(A, S, q)), (l, slices)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("waves", ["0", "7", "1", "2", "3", "4", "6"])
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_many_aggregates_verification_forms(secpar, waves, coracle):
+    """a workgroup per aggregate (512 aggregates or more per launch): the 16-per-lane kernel with 1 .. 6 waves per workgroup
+    (FZ_VERIFY16; 7 = the divisor of the tasks) and the default radix-4 kernel (0) give the oracle's verdicts -- int32 rows and int64 partial sums, ranks that fill the last
+    wave-task and ranks that do not, passing / norm-failing / target-mismatching aggregates, any int32 in A (fusion.py:690-727)"""
+    import fusion_hip
+    P = O.PARAMS[secpar]
+    q, d = P["q"], P["d"]
+    ctx = _ctx(P, {"FZ_VERIFY16": waves})
+    rng = np.random.default_rng(secpar + int(waves) + 40)
+    groups = 530
+    try:
+        for l in (P["rank"], 1, 1024 // d, 1024 // d + 1, 37):
+            A = rng.integers(I32.min, I32.max, size=(l, d), dtype=np.int64).astype(np.int32)
+            A[0, :] = I32.min
+            sig = coracle.ntt_forward(rng.integers(-40, 41, size=(groups * l, d)).astype(np.int32), q, P["root"]).reshape(groups, l, d)
+            sig[2] = rng.integers(I32.min, I32.max, size=(l, d), dtype=np.int64).astype(np.int32)      # raw rows: the norm fails
+            sig[3, l - 1, :] = I32.min
+            sig[groups - 1, 0, :] = I32.max
+            target = coracle.matvec(A, sig, q).astype(np.int32)
+            want, want_w = [], []
+            for gi in range(groups):
+                mx, wt = coracle.norm_weight(coracle.ntt_inverse(sig[gi], q, P["inv_root"]), q)
+                want.append(4 if mx.max() > P["beta_vf"] else (5 if wt.max() > d else 0))
+                want_w.append(4 if mx.max() > P["beta_vf"] else (5 if wt.max() > d - 3 else 0))     # a weight bound that can fail
+            assert want[0] == 0 and want[2] == 4 and 5 in want_w
+            bad = target.copy()
+            bad[::3, (7 * l) % d] += 1
+            expect_bad = [3 if gi % 3 == 0 else want[gi] for gi in range(groups)]
+            sig64 = sig.astype(np.int64) + q * rng.integers(-500, 500, size=sig.shape)
+            bufs = [fusion_hip.DeviceArray.from_numpy(ctx, a) for a in (A, sig, target, bad, sig64, target.astype(np.int64) - 7 * q)]
+            dA, dS, dT, dB, d64, dT64 = bufs
+            dV = fusion_hip.DeviceArray(ctx, (groups,))
+            try:
+                assert ctx.verify_with_target_batch_dev(dA.ptr, dS.ptr, dT.ptr, groups, l, P["beta_vf"], d) == want, l
+                assert ctx.verify_with_target_batch_dev(dA.ptr, dS.ptr, dB.ptr, groups, l, P["beta_vf"], d) == expect_bad, l
+                ctx.verify_partials_batch_async_dev(dA.ptr, d64.ptr, l * d, dT64.ptr, d, groups, l, P["beta_vf"], d, dV.ptr)
+                assert dV.numpy().tolist() == want, l
+                assert ctx.verify_with_target_batch_dev(dA.ptr, dS.ptr, dT.ptr, groups, l, P["beta_vf"], d - 3) == want_w, l
+            finally:
+                for b in bufs + [dV]:
+                    b.free()
+    finally:
+        ctx.close()

@@ -13,7 +13,7 @@ step() { echo "[collect] $*" >&2; "$@" || { echo "[collect] FAILED ($?): $*" >&2
 lscpu | grep -E "Model name|Socket|Thread|Core" > $OUT/${TAG}_host_cpu.txt
 # the stand-alone microbenchmarks travel prebuilt (tools/microbench/build/, git-ignored); build whatever is missing
 mkdir -p tools/microbench/build
-for mb in launch_floor ntt_variants; do
+for mb in launch_floor ntt_variants ntt_structures; do
   [ -x tools/microbench/build/$mb ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/microbench/$mb.hip -o tools/microbench/build/$mb
 done
 step timeout -k 10 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
@@ -31,6 +31,7 @@ step timeout -k 10 300 python tools/numa_placement.py > $OUT/${TAG}_numa_placeme
 for st in none 0 1; do FZ_NO_PIN=1 timeout -k 10 100 python tools/numa_switch.py $st >> $OUT/${TAG}_numa_placement.txt 2>&1; done
 step timeout -k 10 200 python tools/keccak_bench.py > $OUT/${TAG}_keccak_variants_gpu_host.txt 2>&1
 step timeout -k 10 300 ./tools/microbench/build/ntt_variants 300 > $OUT/${TAG}_ntt_variants_current_kernels.txt 2>&1
+step timeout -k 10 120 ./tools/microbench/build/ntt_structures 200 > $OUT/${TAG}_ntt_structures.txt 2>&1
 step timeout -k 10 400 bash tools/keygen_ab.sh > $OUT/${TAG}_keygen_ab.txt 2>&1
 step timeout -k 10 500 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp

@@ -439,6 +439,16 @@ def main():
     total_steps = repeats * args.steps
     region_launch_us = ev0.elapsed_time(ev1) * 1e3 / (2 * total_steps)     # HIP events over the timed region / launches
     assert torch.equal(z, x), "INTT(NTT(x)) != x after the timed region"
+    # the shader clock the chip holds while the timed region's launches run (a one-wave probe on a private stream beside a
+    # few more milliseconds of them): the fp64-dense kernels are power-limited below the nominal 2.4 GHz
+    shader_mhz = None
+    try:
+        for _ in range(max(1, launches // 4)):
+            k_steps()
+        shader_mhz = round(ctx.diag_shader_clock(500))
+    except Exception as e:                                                              # a diagnostic: never the run's failure
+        shader_mhz = f"failed: {type(e).__name__}: {e}"
+    torch.cuda.synchronize(dev)
     for g in {id(g): g for _, g in graphs}.values():
         g.destroy()
     # Per-dispatch durations (kernel begin -> end, events bound to the dispatch on its own stream) cannot be taken
@@ -572,6 +582,8 @@ def main():
                                     "frac": fwd_bytes / (region_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                     "what": "HIP events around the timed region on the kernels' stream / launches "
                                             "(consecutive dispatches overlap their launch and drain phases)"},
+                         "shader_mhz": {"timed_region": shader_mhz, "nominal": 2400,
+                                        "what": "fz_diag_shader_clock beside the timed region's launches; per kernel: roofline.kernels[*].shader_mhz"},
                          "copy_floor": floor, "multi_job": multi, "kernels": kernels, "sweep": sweep,
                          "target": target_block(), "rocprofv3": rocprof_reference()},
             "cold_batches": cold, "two_stream_pipelined": two_stream, "sign_verify": sv, "end_to_end": e2e, "pcie_inclusive": pcie,

@@ -344,6 +344,7 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         c->knob_no_imad = knob("FZ_NO_IMAD");
         c->knob_matvec_slices = knob("FZ_MATVEC_SLICES");
         c->knob_verify16 = knob("FZ_VERIFY16");
+        c->knob_verify16_nopf = knob("FZ_VERIFY16_NOPF");
         c->knob_verify_cent = knob("FZ_VERIFY_CENT");
     }
     if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
@@ -1182,6 +1183,25 @@ int fz_diag_copy(fz_ctx *ctx, const void *d_src, void *d_dst, size_t bytes) {
     FZ_REQUIRE((((uintptr_t)d_src | (uintptr_t)d_dst) & 15) == 0 && bytes % 16 == 0, "16-byte aligned buffers and size");
     FZ_DEV(ctx);
     return fz_launch_diag(ctx, 1, d_src, d_dst, bytes);
+}
+
+int fz_diag_shader_clock(fz_ctx *ctx, unsigned microseconds, double *out_mhz) {
+    FZ_REQUIRE(ctx && out_mhz, "NULL argument");
+    FZ_REQUIRE(microseconds >= 1 && microseconds <= 1000000, "between 1 us and 1 s");
+    FZ_DEV(ctx);
+    // its own stream: the probe runs BESIDE whatever the caller queued on the context's stream (that is the point)
+    hipStream_t s = nullptr;
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    FZ_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "diag stream");
+    int rc = fz_check_hip(hipMalloc((void **)&d, sizeof(h)), "diag alloc");
+    if (rc == FZ_OK) rc = fz_launch_diag_clock(s, (unsigned long long)microseconds * 100ull, d);
+    if (rc == FZ_OK) rc = fz_check_hip(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s), "diag read");
+    if (rc == FZ_OK) rc = fz_check_hip(hipStreamSynchronize(s), "diag sync");
+    if (d) (void)hipFree(d);
+    (void)hipStreamDestroy(s);
+    if (rc != FZ_OK) return rc;
+    *out_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+    return FZ_OK;
 }
 
 // ---- the one exchange step of the path, in the C ABI: RCCL all-reduce of the int64 partial sums ---------------------

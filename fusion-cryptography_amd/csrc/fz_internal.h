@@ -75,6 +75,7 @@ struct fz_ctx {
     int knob_stream_per_cu;      // grid cap of the grid-stride streaming kernels in workgroups per CU (0 = flat grid)
     int knob_verify_blocks, knob_verify_unfused, knob_verify_ordered, knob_keygen_unfused, knob_polymul_unfused;
     int knob_verify16;           // FZ_VERIFY16 = 1 .. 6: waves per workgroup of the 16-per-lane many-aggregates verification kernel (7 = best divisor of the tasks; 0 = off: the radix-4 kernel, the default)
+    int knob_verify16_nopf;      // FZ_VERIFY16_NOPF=1: verify_many16 requests a task's rows when it starts the task, not one task ahead (fewer registers)
     int knob_matvec_slices;      // FZ_MATVEC_SLICES = 1 | 2 | 4: k-range slices per column of the integer matvec kernel (0 = by batch size, -1 = the fp64 kernel)
     int knob_no_imad;            // FZ_NO_IMAD=1: A (.) y through the general fp64 multiply instead of integer multiply-adds (A/B runs)
     int knob_verify_cent;        // FZ_VERIFY_CENT=1: centre the inverse transform's outputs before the norm test even when beta allows skipping it
@@ -123,6 +124,7 @@ int fz_retire(fz_ctx *ctx, void *d_ptr, const char *what);       // hipFree, or 
 int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse);
 int fz_ntt_query_grid(fz_ctx *ctx);
 int fz_launch_ntt_multi(fz_ctx *ctx, const FzMultiJobs &jobs);     // degree 64 / 256
+int fz_launch_diag_clock(hipStream_t stream, unsigned long long ticks, unsigned long long *d_out);
 int fz_launch_diag(fz_ctx *ctx, int what, const void *src, void *dst, size_t bytes);
 
 // challenge pipeline on the device (fz_challenge.hip) and the pieces it shares with the host serialiser (fz_host.cpp)

@@ -1110,7 +1110,7 @@ __device__ __forceinline__ void raw_ints(const Raw4<int64_t> &r, int (&s)[4], co
     s[2] = (int)fz_cent_i64(r.hi.x, m); s[3] = (int)fz_cent_i64(r.hi.y, m);
 }
 
-template <int LOGD, bool FAST, typename T>
+template <int LOGD, bool FAST, typename T, bool PF>
 __global__ __launch_bounds__(384) void verify_many16(const int32_t *A, const T *sig, size_t sig_stride, const T *target,
                                                      size_t target_stride, int l, long long beta, long long omega, int lazy,
                                                      const double2 *__restrict__ itwB, FzTwA twA, FzMod m, int *verdict) {
@@ -1153,8 +1153,9 @@ __global__ __launch_bounds__(384) void verify_many16(const int32_t *A, const T *
     const bool weigh = omega < (long long)D;
     const unsigned long long gmask = (((1ull << L) - 1ull) << (L * p));
     int task = wave;
-    if (task < tasks) fetch(task);
+    if (PF && task < tasks) fetch(task);
     for (; task < tasks; task += W) {
+        if (!PF) fetch(task);
         const bool full = (task + 1) * PPW <= l;              // wave-uniform: only the last task can hold slots past the last row
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1178,7 +1179,7 @@ __global__ __launch_bounds__(384) void verify_many16(const int32_t *A, const T *
             }
             *reinterpret_cast<int4 *>(stage + pad4(256 * c + 4 * lane)) = make_int4(si[0], si[1], si[2], si[3]);
         }
-        fetch(task + W < tasks ? task + W : tasks - 1);       // unconditional, clamped: no branch between request and use
+        if (PF) fetch(task + W < tasks ? task + W : tasks - 1);       // unconditional, clamped: no branch between request and use
         wave_sync();
         double a[16];
 #pragma unroll
@@ -1484,12 +1485,14 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
             }
         }
         const size_t lds_bytes = ((size_t)W * (ppw16 * (ctx->degree + 2 * (ctx->degree / 16))) + 2 * (size_t)(16 - (16 >> (ctx->logd - 4))) * (ctx->degree / 16)) * sizeof(double);
-#define FZ_V16(LOGD, FAST) hipLaunchKernelGGL((verify_many16<LOGD, FAST, T>), dim3((unsigned)groups), dim3(64 * W), lds_bytes, ctx->stream, A, sig, \
+#define FZ_V16P(LOGD, FAST, PF) hipLaunchKernelGGL((verify_many16<LOGD, FAST, T, PF>), dim3((unsigned)groups), dim3(64 * W), lds_bytes, ctx->stream, A, sig, \
                                               sig_stride, target, target_stride, l, (long long)beta, (long long)omega, lazy, \
                                               (const double2 *)ctx->d_itwB, ctx->itwA, ctx->mod, d_verdict)
+#define FZ_V16(LOGD, FAST) do { if (ctx->knob_verify16_nopf) FZ_V16P(LOGD, FAST, false); else FZ_V16P(LOGD, FAST, true); } while (0)
         if (ctx->logd == 8) { if (ctx->mod.fast) FZ_V16(8, true); else FZ_V16(8, false); }
         else { if (ctx->mod.fast) FZ_V16(6, true); else FZ_V16(6, false); }
 #undef FZ_V16
+#undef FZ_V16P
         return fz_check_hip(hipGetLastError(), "verify_many16 launch");
     }
     double *part = nullptr;
@@ -1639,6 +1642,25 @@ __global__ __launch_bounds__(64) void diag_copy_kernel(const int4 *__restrict__ 
     }
 }
 }  // namespace
+
+// one wave that watches the clocks for `ticks` periods of the 100 MHz reference counter: shader cycles (s_memtime) per
+// reference tick = the frequency the chip actually runs at while whatever else is resident executes
+namespace {
+__global__ __launch_bounds__(64) void diag_clock_kernel(unsigned long long ticks, unsigned long long *out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {             // every wave reaches the exit: the reference counter never stops
+        __builtin_amdgcn_s_sleep(8);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    if (threadIdx.x == 0) { out[0] = __builtin_amdgcn_s_memtime() - t0; out[1] = r1 - r0; }
+}
+}  // namespace
+
+int fz_launch_diag_clock(hipStream_t stream, unsigned long long ticks, unsigned long long *d_out) {
+    hipLaunchKernelGGL(diag_clock_kernel, dim3(1), dim3(64), 0, stream, ticks, d_out);
+    return fz_check_hip(hipGetLastError(), "diag clock launch");
+}
 
 int fz_launch_diag(fz_ctx *ctx, int what, const void *src, void *dst, size_t bytes) {
     if (what == 0) {

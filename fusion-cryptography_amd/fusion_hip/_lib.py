@@ -160,6 +160,7 @@ SIGNATURES.update({
     "fz_allreduce_i64": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
     "fz_diag_empty_launch": (c_int, [_ctx]),
     "fz_diag_copy": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
+    "fz_diag_shader_clock": (c_int, [_ctx, ctypes.c_uint, POINTER(ctypes.c_double)]),
 })
 
 _lib = None

@@ -7,7 +7,7 @@ Two faces:
     library's own scratch (used by the drop-in object API in ``algebra`` / ``fusion``).
 """
 import ctypes
-from ctypes import byref, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import byref, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 import numpy as np
 
@@ -161,6 +161,13 @@ class Context:
 
     def diag_copy_dev(self, d_src, d_dst, nbytes):
         check(self._lib, self._lib.fz_diag_copy(self._h, c_void_p(d_src), c_void_p(d_dst), nbytes))
+
+    def diag_shader_clock(self, microseconds=500):
+        """MHz the shader clock holds while the work already queued on this context's stream runs (a one-wave probe on a
+        private stream; returns after `microseconds`)"""
+        mhz = c_double()
+        check(self._lib, self._lib.fz_diag_shader_clock(self._h, int(microseconds), byref(mhz)))
+        return mhz.value
 
     def allreduce_i64_dev(self, comm, d_buf, count):
         """in-place ncclAllReduce(int64, sum) on this context's stream (comm: a Comm)"""

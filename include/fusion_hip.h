@@ -296,6 +296,11 @@ FZ_API int fz_allreduce_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, size_t c
  * small-batch transform launch is judged against (bench.py reports them from the same run as the transforms). */
 FZ_API int fz_diag_empty_launch(fz_ctx *ctx);
 FZ_API int fz_diag_copy(fz_ctx *ctx, const void *d_src, void *d_dst, size_t bytes);
+/* The shader clock the chip actually holds while the work already queued on the context's stream executes: one wave on a
+ * private stream compares the shader cycle counter with the 100 MHz reference counter for `microseconds`, then the call
+ * returns (synchronous).  The fp64-dense fused kernels run power-limited well below the nominal 2.4 GHz; a vector-issue
+ * roofline has to be priced at THIS clock (profiles/README.md, round 3). */
+FZ_API int fz_diag_shader_clock(fz_ctx *ctx, unsigned microseconds, double *out_mhz);
 
 /* ---- norm / weight of coefficient rows -------------------------------------------------------
  * PolynomialCoefficientRepresentation.norm("infty") / weight(), algebra/polynomials.py:221-227:

@@ -191,6 +191,20 @@ def test_launch_floor_diagnostics_run():
     ctx.diag_empty_launch()
     ctx.diag_copy_dev(a.ptr, b.ptr, x.nbytes)
     assert np.array_equal(b.to_numpy(np.int32, x.shape), x)
+    # the shader-clock probe: idle, and beside queued work on the context's stream (it must return although that work is still
+    # running, and leave the stream usable)
+    assert 300 < ctx.diag_shader_clock(200) < 4000
+    s = ctx.stream_create()
+    ctx.set_stream(s)
+    for _ in range(200):
+        ctx.ntt_forward_dev(a.ptr, b.ptr, 4096)
+    assert 300 < ctx.diag_shader_clock(300) < 4000
+    ctx.synchronize()
+    assert np.array_equal(b.to_numpy(np.int32, (4096, 256)), ctx.ntt_forward(x.reshape(4096, 256)))
+    ctx.set_stream(0)
+    ctx.stream_destroy(s)
+    with pytest.raises(fusion_hip.FusionHipError):
+        ctx.diag_shader_clock(0)
 
 
 def test_contexts_on_two_devices_do_not_cross(coracle):

@@ -72,6 +72,13 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
         out[name] = {"units_per_launch": units, "bytes_per_unit": bytes_per_unit, "avg_us": round(us, 2),
                      "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "sets_cycled": int(nsets),
                      "launches_timed": reps, "passes": 3}
+        # the shader clock the chip holds under this kernel (a one-wave probe beside ~1.5 ms of queued launches): the
+        # fp64-dense kernels run power-limited below the nominal 2.4 GHz, the streaming ones do not
+        if us >= 8.0 and not quick:
+            for _ in range(int(max(4, min(400, 1500.0 / us)))):
+                one()
+            out[name]["shader_mhz"] = int(round(ctx.diag_shader_clock(400)))
+            ctx.synchronize()
         if note:
             out[name]["note"] = note
 
@@ -144,8 +151,9 @@ def main():
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     table = measure(ctx, P, quick="--quick" in sys.argv, only=only)
     for name, r in table.items():
+        clk = f"  {r['shader_mhz']} MHz" if "shader_mhz" in r else ""
         print(f"{name:34s} {r['units_per_launch']:9d} units  {r['avg_us']:9.2f} us  {r['GB/s']:8.1f} GB/s algorithmic "
-              f"({r['frac'] * 100:5.1f} % of 8 TB/s)  cold: {r['sets_cycled']} operand sets cycled")
+              f"({r['frac'] * 100:5.1f} % of 8 TB/s)  cold: {r['sets_cycled']} operand sets cycled{clk}")
     if "--json" in sys.argv:
         print(json.dumps(table))
     ctx.set_stream(0)

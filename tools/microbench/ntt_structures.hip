@@ -7,7 +7,8 @@
 // twice the registers.  This harness times the INVERSE transform of both structures with nothing but registers and LDS in the
 // loop -- each wave transforms its own rows R times, feeding outputs back as inputs, keeps a running max |x| as the fused
 // verification does, and stores one value at the end -- at 1 .. 8 waves per SIMD, so the figure is transforms per microsecond
-// for the whole chip when vector issue and LDS are all that count.
+// for the whole chip when vector issue and LDS are all that count.  Each workgroup also reads the shader clock (s_memtime)
+// against the 100 MHz reference (s_memrealtime): the chip does not hold its 2.4 GHz under this load.
 //
 // It compiles the library's own kernel source into this translation unit: inv4_passes_n IS the shipped radix-4 code; the
 // 16-per-lane loop body is the shipped ntt_inv16's, between its load and its store.   usage: ntt_structures [R=200]
@@ -31,7 +32,7 @@ namespace {
 
 // radix-4: NR row groups per wave and iteration (degree 256: one row per group)
 template <int NR, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void loop_inv4(double *out, int R, const double2 *__restrict__ itw2, FzTwA twA, FzMod m) {
+__global__ __launch_bounds__(64 * WAVES) void loop_inv4(double *out, unsigned long long *stamps, int R, const double2 *__restrict__ itw2, FzTwA twA, FzMod m) {
     constexpr int LOGD = 8, P = LOGD / 2;
     __shared__ __attribute__((aligned(16))) double lds[WAVES * NR * 256];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(64 * WAVES) void loop_inv4(double *out, int R, cons
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[r][k] = (double)((lane * 4 + k + 977 * r + (int)blockIdx.x) % 1000003 - 500000);
     double mx = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < R; ++it) {
         inv4_passes_n<LOGD, true, NR>(a, region, twl, twA, m, lane);
 #pragma unroll
@@ -52,12 +54,13 @@ __global__ __launch_bounds__(64 * WAVES) void loop_inv4(double *out, int R, cons
             for (int k = 0; k < 4; ++k) mx = fmax(mx, fabs(a[r][k]));
         wave_sync();      // the next rows' first-pass writes must not overtake these rows' last reads (as in verify_fused)
     }
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0; stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
     if (mx == 12345.5) out[blockIdx.x * blockDim.x + threadIdx.x] = mx + a[0][0];
 }
 
 // 16 per lane: four rows per wave and iteration
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void loop_inv16(double *out, int R, const double2 *__restrict__ itwB, FzTwA twA, FzMod m) {
+__global__ __launch_bounds__(64 * WAVES) void loop_inv16(double *out, unsigned long long *stamps, int R, const double2 *__restrict__ itwB, FzTwA twA, FzMod m) {
     using G = Geom<8>;
     constexpr int L = G::L, PPW = G::PPW, SB = G::SB, NE = G::NE, PS = G::PS;
     constexpr int REGION = PPW * PS;
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(64 * WAVES) void loop_inv16(double *out, int R, con
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[k] = (double)((lane * 16 + k + (int)blockIdx.x) % 1000003 - 500000);
     double mx = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < R; ++it) {
 #pragma unroll
         for (int ls = 0; ls < SB; ++ls) {
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(64 * WAVES) void loop_inv16(double *out, int R, con
         // outputs are in the strided layout (element r + L*k); the next iteration's contiguous pass wants 16 consecutive
         // elements per lane: in a fused kernel the NEXT rows come from memory in that layout, so no exchange belongs here
     }
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0; stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
     if (mx == 12345.5) out[blockIdx.x * blockDim.x + threadIdx.x] = mx + a[0];
 }
 
@@ -183,6 +188,9 @@ int main(int argc, char **argv) {
         CHECK(hipMemcpy(d_itwB, twB.data(), twB.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     CHECK(hipMalloc((void **)&d_out, sizeof(double) * 64 * 8 * 8192));
+    unsigned long long *d_stamps;
+    CHECK(hipMalloc((void **)&d_stamps, sizeof(unsigned long long) * 2 * 8192));
+    std::vector<unsigned long long> h_stamps(2 * 8192);
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -190,7 +198,7 @@ int main(int argc, char **argv) {
     CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     printf("# inverse transforms of degree 256 from registers and LDS only (no global traffic in the loop), R = %d iterations per wave,\n"
            "# %d CUs; rows/us = transforms per microsecond for the whole chip; the fused verification kernel needs 83 per aggregate\n", R, cus);
-    printf("%-34s %6s %10s %12s %10s\n", "structure", "w/SIMD", "waves", "time us", "rows/us");
+    printf("%-34s %6s %10s %12s %10s %8s %12s\n", "structure", "w/SIMD", "waves", "time us", "rows/us", "MHz", "cyc/row/SIMD");
 #define RUN(NAME, KERNEL, WAVES, ROWS_PER_WAVE_ITER, TABLE)                                                                    \
     for (int wps : {1, 2, 4, 6, 8}) {                                                                                           \
         int occ = 0;                                                                                                            \
@@ -198,8 +206,14 @@ int main(int argc, char **argv) {
         const int blocks_per_cu = wps * 4 / WAVES;                                                                              \
         if (blocks_per_cu < 1 || blocks_per_cu > occ) continue;                                                                 \
         const int grid = cus * blocks_per_cu;                                                                                   \
-        const double us = time_us([&]() { hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64 * WAVES), 0, st, d_out, R, (const double2 *)TABLE, twA, mod); }, st); \
-        printf("%-34s %6d %10d %12.1f %10.1f\n", NAME, wps, grid * WAVES, us, (double)grid * WAVES * R * ROWS_PER_WAVE_ITER / us); \
+        const double us = time_us([&]() { hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(64 * WAVES), 0, st, d_out, d_stamps, R, (const double2 *)TABLE, twA, mod); }, st); \
+        CHECK(hipStreamSynchronize(st));                                                                                        \
+        CHECK(hipMemcpy(h_stamps.data(), d_stamps, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));              \
+        double mhz = 0;                                                                                                         \
+        for (int b = 0; b < grid; ++b) mhz += 100.0 * (double)h_stamps[2 * b] / (double)(h_stamps[2 * b + 1] ? h_stamps[2 * b + 1] : 1); \
+        mhz /= grid;                                                                                                            \
+        const double rows_us = (double)grid * WAVES * R * ROWS_PER_WAVE_ITER / us;                                              \
+        printf("%-34s %6d %10d %12.1f %10.1f %8.0f %12.0f\n", NAME, wps, grid * WAVES, us, rows_us, mhz, mhz * cus * 4 / rows_us); \
     }
     RUN("radix-4, 1 row per wave", (loop_inv4<1, 4>), 4, 1, d_itw2)
     RUN("radix-4, 2 rows per wave", (loop_inv4<2, 4>), 4, 2, d_itw2)

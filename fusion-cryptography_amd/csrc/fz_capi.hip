@@ -382,6 +382,8 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     for (int i = 0; i < ctx->n_retired; ++i) (void)hipFree(ctx->retired[i]);
     free(ctx->retired);
     if (ctx->d_chal_tab) (void)hipFree(ctx->d_chal_tab);
+    if (ctx->d_diag) (void)hipFree(ctx->d_diag);
+    if (ctx->diag_stream) (void)hipStreamDestroy(ctx->diag_stream);
     if (ctx->d_mt_init) (void)hipFree(ctx->d_mt_init);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1189,17 +1191,16 @@ int fz_diag_shader_clock(fz_ctx *ctx, unsigned microseconds, double *out_mhz) {
     FZ_REQUIRE(ctx && out_mhz, "NULL argument");
     FZ_REQUIRE(microseconds >= 1 && microseconds <= 1000000, "between 1 us and 1 s");
     FZ_DEV(ctx);
-    // its own stream: the probe runs BESIDE whatever the caller queued on the context's stream (that is the point)
-    hipStream_t s = nullptr;
-    unsigned long long *d = nullptr, h[2] = {0, 0};
-    FZ_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "diag stream");
-    int rc = fz_check_hip(hipMalloc((void **)&d, sizeof(h)), "diag alloc");
-    if (rc == FZ_OK) rc = fz_launch_diag_clock(s, (unsigned long long)microseconds * 100ull, d);
-    if (rc == FZ_OK) rc = fz_check_hip(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s), "diag read");
-    if (rc == FZ_OK) rc = fz_check_hip(hipStreamSynchronize(s), "diag sync");
-    if (d) (void)hipFree(d);
-    (void)hipStreamDestroy(s);
-    if (rc != FZ_OK) return rc;
+    // its own stream: the probe runs BESIDE whatever the caller queued on the context's stream (that is the point).  Stream
+    // and result word live as long as the context: hipMalloc / hipFree here would synchronise the device with that work.
+    if (!ctx->diag_stream) {
+        FZ_HIP(hipStreamCreateWithFlags(&ctx->diag_stream, hipStreamNonBlocking), "diag stream");
+        FZ_HIP(hipMalloc((void **)&ctx->d_diag, 2 * sizeof(unsigned long long)), "diag alloc");
+    }
+    unsigned long long h[2] = {0, 0};
+    FZ_TRY(fz_launch_diag_clock(ctx->diag_stream, (unsigned long long)microseconds * 100ull, ctx->d_diag));
+    FZ_HIP(hipMemcpyAsync(h, ctx->d_diag, sizeof(h), hipMemcpyDeviceToHost, ctx->diag_stream), "diag read");
+    FZ_HIP(hipStreamSynchronize(ctx->diag_stream), "diag sync");
     *out_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
     return FZ_OK;
 }

@@ -74,6 +74,8 @@ struct fz_ctx {
     int knob_stream_nt;          // FZ_STREAM_NT: streaming (non-temporal) stores in the elementwise kernels
     int knob_stream_per_cu;      // grid cap of the grid-stride streaming kernels in workgroups per CU (0 = flat grid)
     int knob_verify_blocks, knob_verify_unfused, knob_verify_ordered, knob_keygen_unfused, knob_polymul_unfused;
+    hipStream_t diag_stream;     // fz_diag_shader_clock: the probe's private stream and result words (created on first use)
+    unsigned long long *d_diag;
     int knob_verify16;           // FZ_VERIFY16 = 1 .. 6: waves per workgroup of the 16-per-lane many-aggregates verification kernel (7 = best divisor of the tasks; 0 = off: the radix-4 kernel, the default)
     int knob_verify16_nopf;      // FZ_VERIFY16_NOPF=1: verify_many16 requests a task's rows when it starts the task, not one task ahead (fewer registers)
     int knob_matvec_slices;      // FZ_MATVEC_SLICES = 1 | 2 | 4: k-range slices per column of the integer matvec kernel (0 = by batch size, -1 = the fp64 kernel)

@@ -33,6 +33,12 @@ step timeout -k 10 200 python tools/keccak_bench.py > $OUT/${TAG}_keccak_variant
 step timeout -k 10 300 ./tools/microbench/build/ntt_variants 300 > $OUT/${TAG}_ntt_variants_current_kernels.txt 2>&1
 step timeout -k 10 120 ./tools/microbench/build/ntt_structures 200 > $OUT/${TAG}_ntt_structures.txt 2>&1
 step timeout -k 10 400 bash tools/keygen_ab.sh > $OUT/${TAG}_keygen_ab.txt 2>&1
+step timeout -k 10 200 python tools/clock_under_load.py > $OUT/${TAG}_shader_clock_under_load.txt 2>&1
+step timeout -k 10 200 python tools/clock_under_load.py --secpar 128 >> $OUT/${TAG}_shader_clock_under_load.txt 2>&1
+step timeout -k 10 600 bash tools/matvec_ab.sh > $OUT/${TAG}_matvec_ab_raw.txt 2>&1
+step timeout -k 10 800 bash tools/verify_ab.sh > $OUT/${TAG}_verify_ab_raw.txt 2>&1
+step timeout -k 10 300 python tools/benchmarks.py 256 128 > $OUT/${TAG}_api_benchmarks.json 2> $OUT/api_benchmarks.err
+step timeout -k 10 200 python tools/object_api_profile.py 256 16 > $OUT/${TAG}_object_api_profile.txt 2>&1
 step timeout -k 10 500 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations from the profiler: the bench's transform launches, the cold kernel table, the challenge pipeline

@@ -72,12 +72,13 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
         out[name] = {"units_per_launch": units, "bytes_per_unit": bytes_per_unit, "avg_us": round(us, 2),
                      "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "sets_cycled": int(nsets),
                      "launches_timed": reps, "passes": 3}
-        # the shader clock the chip holds under this kernel (a one-wave probe beside ~1.5 ms of queued launches): the
+        # the shader clock the chip holds under this kernel (a one-wave probe beside ~5 ms of queued launches, read over their second 1.5 ms): the
         # fp64-dense kernels run power-limited below the nominal 2.4 GHz, the streaming ones do not
         if us >= 8.0 and not quick:
-            for _ in range(int(max(4, min(400, 1500.0 / us)))):
+            for _ in range(int(max(4, min(1000, 5000.0 / us)))):        # the power limiter settles over milliseconds
                 one()
-            out[name]["shader_mhz"] = int(round(ctx.diag_shader_clock(400)))
+            ctx.diag_shader_clock(1500)
+            out[name]["shader_mhz"] = int(round(ctx.diag_shader_clock(1500)))
             ctx.synchronize()
         if note:
             out[name]["note"] = note

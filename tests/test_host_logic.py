@@ -368,3 +368,23 @@ def test_numa_helper_is_harmless_without_a_gpu(monkeypatch):
     monkeypatch.setenv("FZ_NO_PIN", "1")
     assert numa.pin_to_gpu_node(0) is None
     assert os.sched_getaffinity(0) == before
+
+
+def test_tools_and_examples_compile():
+    """the measurement tools and examples are not imported by any CPU test (they need a GPU to run): at least their syntax is
+    checked here, and the shell scripts name files that exist"""
+    import glob
+    import py_compile
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "examples", "*.py")) + \
+        [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 20
+    for f in files:
+        py_compile.compile(f, doraise=True)
+    for sh in glob.glob(os.path.join(root, "tools", "*.sh")):
+        text = open(sh).read()
+        for m in re.finditer(r"(?:python3?|bash)\s+(?:\$R/)?(tools/[\w/]+\.(?:py|sh))", text):
+            assert os.path.exists(os.path.join(root, m.group(1))), (sh, m.group(1))
+        for m in re.finditer(r"tools/microbench/build/(\w+)", text):
+            assert os.path.exists(os.path.join(root, "tools", "microbench", m.group(1) + ".hip")), (sh, m.group(1))

@@ -111,8 +111,12 @@ def _replicated(sample_one, num_rows: int, num_cols: int, seed) -> list:
     if seed is None or num_rows * num_cols <= 1:
         return [[sample_one() for _ in range(num_cols)] for _ in range(num_rows)]
     first = sample_one()
-    row = first._i32()          # the copies share this row until somebody asks one of them for its list (then it gets its own)
-    return [[first if (i == 0 and j == 0) else first._like_arr(row) for j in range(num_cols)] for i in range(num_rows)]
+    data = first._data()
+    if all(_backend.INT32_MIN <= v <= _backend.INT32_MAX for v in data):
+        row = np.array(data, dtype=np.int32)      # the copies share this row until somebody asks one of them for its list
+        return [[first if (i == 0 and j == 0) else first._like_arr(row) for j in range(num_cols)] for i in range(num_rows)]
+    # (a modulus the kernels do not implement: plain copies of the list, as before)
+    return [[first if (i == 0 and j == 0) else first._like(list(data)) for j in range(num_cols)] for i in range(num_rows)]
 
 
 def sample_coefficient_matrix(seed: Optional[int], modulus: int, degree: int, root_order: int, root: int,

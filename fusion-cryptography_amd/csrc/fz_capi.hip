@@ -344,6 +344,7 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         c->knob_no_imad = knob("FZ_NO_IMAD");
         c->knob_matvec_slices = knob("FZ_MATVEC_SLICES");
         c->knob_verify16 = knob("FZ_VERIFY16");
+        c->knob_keygen_bcast_general = knob("FZ_KEYGEN_BCAST_GENERAL");
         c->knob_verify16_nopf = knob("FZ_VERIFY16_NOPF");
         c->knob_verify_cent = knob("FZ_VERIFY_CENT");
     }

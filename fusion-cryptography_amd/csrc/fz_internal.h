@@ -76,6 +76,7 @@ struct fz_ctx {
     int knob_verify_blocks, knob_verify_unfused, knob_verify_ordered, knob_keygen_unfused, knob_polymul_unfused;
     hipStream_t diag_stream;     // fz_diag_shader_clock: the probe's private stream and result words (created on first use)
     unsigned long long *d_diag;
+    int knob_keygen_bcast_general;   // FZ_KEYGEN_BCAST_GENERAL=1: fz_keygen_core_bcast through the general kernel (l transforms of the same row) as before round 3
     int knob_verify16;           // FZ_VERIFY16 = 1 .. 6: waves per workgroup of the 16-per-lane many-aggregates verification kernel (7 = best divisor of the tasks; 0 = off: the radix-4 kernel, the default)
     int knob_verify16_nopf;      // FZ_VERIFY16_NOPF=1: verify_many16 requests a task's rows when it starts the task, not one task ahead (fewer registers)
     int knob_matvec_slices;      // FZ_MATVEC_SLICES = 1 | 2 | 4: k-range slices per column of the integer matvec kernel (0 = by batch size, -1 = the fp64 kernel)

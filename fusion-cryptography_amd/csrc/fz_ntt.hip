@@ -878,6 +878,67 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     }
 }
 
+// The reference's SEEDED keygen samples every entry of a key half with the same seed (fusion.py:156-173): the l rows of a half
+// are one polynomial, so their transforms are one transform.  fz_keygen_core_bcast (one polynomial per (key, half)) therefore
+// transforms it ONCE per workgroup -- every wave for itself: a transform is cheaper than an exchange -- and the rest is the l
+// stores of the row and the accumulation of A_k (.) y over k: a streaming kernel (85 KiB written per half, A from the L2)
+// instead of l transforms.  Same results as keygen_fused with row stride 0, which FZ_KEYGEN_BCAST_GENERAL=1 still runs.
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_bcast_fused(const int32_t *A, const int32_t *coef, int32_t *sk_hat,
+                                                                          int32_t *vk, int l, const double2 *__restrict__ tw2,
+                                                                          FzTwA twA, FzMod m) {
+    constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
+    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256 * 2];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p = lane / LP, mm = lane % LP;
+    double *region = lds + wave * 256 + p * D;
+    double *accbuf = lds + kWavesPerBlock * 256;
+    const size_t seg = blockIdx.x;                      // (key, half)
+    coef += seg * (size_t)D;
+    sk_hat += seg * (size_t)l * D;
+    double2 twl[LOGD / 2 - 1][3];
+    fwd4_load_twiddles<LOGD, double2>(twl, tw2, mm);
+    double a[1][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[0][k] = (double)coef[mm + k * LP];
+    fwd4_passes_n<LOGD, FAST, 1, double2>(a, region, twl, twA, m, mm);
+    const int4 yi = make_int4((int)fz_cent(a[0][0], m), (int)fz_cent(a[0][1], m), (int)fz_cent(a[0][2], m), (int)fz_cent(a[0][3], m));
+    const int yv[4] = {yi.x, yi.y, yi.z, yi.w};
+    // sum_k A_k (.) y = (sum_k A_k) (.) y: the rows of A this lane's row slots cover, summed in integers (|A| <= 2^31, l <= 2^31
+    // rows: no overflow of int64), one multiply at the end
+    long long asum[4] = {0, 0, 0, 0};
+    constexpr int U = 4;
+    const int step = kWavesPerBlock * PPW;
+    for (int row0 = wave * PPW + p; row0 < l; row0 += U * step) {
+        int4 ak[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = row0 + u * step;
+            ak[u] = *reinterpret_cast<const int4 *>(A + (size_t)(row < l ? row : l - 1) * D + 4 * mm);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = row0 + u * step;
+            if (row < l) {
+                nt_store4(sk_hat + (size_t)row * D + 4 * mm, yi);
+                asum[0] += ak[u].x; asum[1] += ak[u].y; asum[2] += ak[u].z; asum[3] += ak[u].w;
+            }
+        }
+    }
+    double *mine = accbuf + wave * 256 + p * D + 4 * mm;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mine[k] = fz_mulmod(fz_cent_i64(asum[k], m), (double)yv[k], m);      // |.| <= q/2 + eps each
+    __syncthreads();
+    if (threadIdx.x < D) {
+        double sum = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w)
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) sum += accbuf[w * 256 + q * D + threadIdx.x];
+        vk[seg * D + threadIdx.x] = (int)fz_cent(sum, m);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Fused verification (fusion/fusion.py:690-727): sigma is read ONCE.  While a row of sigma is in registers it
 // feeds both (a) observed += A[k] (.) sigma[k] and (b) the radix-4 inverse transform, whose centred outputs are
@@ -1428,6 +1489,15 @@ int query16(fz_ctx *ctx) {
 int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,
                            int l, bool broadcast) {
     const dim3 grid((unsigned)segments), block(64 * kWavesPerBlock);
+    if (broadcast && !ctx->knob_keygen_bcast_general && (ctx->logd == 6 || ctx->logd == 8)) {
+        // one polynomial per (key, half): ONE transform per workgroup, then l stores (see keygen_bcast_fused)
+#define FZ_KB(LOGD, FAST) hipLaunchKernelGGL((keygen_bcast_fused<LOGD, FAST>), grid, block, 0, ctx->stream, A, coef, sk_hat, vk, l, \
+                                             (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod)
+        if (ctx->logd == 8) { if (ctx->mod.fast) FZ_KB(8, true); else FZ_KB(8, false); }
+        else { if (ctx->mod.fast) FZ_KB(6, true); else FZ_KB(6, false); }
+#undef FZ_KB
+        return fz_check_hip(hipGetLastError(), "keygen_bcast_fused launch");
+    }
     const size_t seg_stride = broadcast ? (size_t)ctx->degree : (size_t)l * ctx->degree;
     const size_t row_stride = broadcast ? 0 : (size_t)ctx->degree;
     // FZ_FUSED_ROWS = 1 | 2 row groups per wave iteration, FZ_FUSED_PREFETCH = 1 | 2 iterations requested ahead: all four

@@ -201,3 +201,29 @@ def test_many_aggregates_verification_forms(secpar, waves, coracle):
                     b.free()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("general", ["0", "1"])
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_broadcast_keygen_forms(secpar, general, coracle):
+    """fz_keygen_core_bcast -- one secret polynomial per key half, what the reference's seeded keygen produces (fusion.py:156-173,
+    :338-362) -- through the one-transform kernel (default) and through the general kernel with row stride 0
+    (FZ_KEYGEN_BCAST_GENERAL=1): both equal the oracle's keygen on the replicated rows, for any int32 in A and in the secret,
+    scheme ranks and ranks that leave row slots empty"""
+    P = O.PARAMS[secpar]
+    q, d = P["q"], P["d"]
+    ctx = _ctx(P, {"FZ_KEYGEN_BCAST_GENERAL": general})
+    rng = np.random.default_rng(secpar + 77)
+    try:
+        for l, n in ((P["rank"], 9), (1, 3), (5, 2), (4 * (256 // d) * 4 + 1, 2), (300, 2)):
+            A = rng.integers(I32.min, I32.max, size=(l, d), dtype=np.int64).astype(np.int32)
+            A[0, :] = I32.min
+            A[l - 1, ::2] = I32.max
+            polys = (rng.integers(1, 53, size=(n, 2, d)) * rng.choice(np.array([-1, 1]), size=(n, 2, d))).astype(np.int32)
+            polys[0, 0] = rng.integers(I32.min, I32.max, size=d, dtype=np.int64).astype(np.int32)
+            polys[0, 1, :] = I32.min
+            rsk, rvk = coracle.keygen_core(A, np.repeat(polys[:, :, None, :], l, axis=2), q, P["root"])
+            sk, vk = ctx.keygen_core_bcast(A, polys)
+            assert np.array_equal(sk, rsk) and np.array_equal(vk, rvk), (l, n)
+    finally:
+        ctx.close()

@@ -88,6 +88,10 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
     kb = S * 2 * l * row
     run("keygen_fused", S, (4 * l + 2) * row, kb, kb + S * 2 * row,
         lambda i, o: ctx.keygen_core_dev(A.ptr, i, o, o + kb, S, l))
+    # the reference's SEEDED keygen (fusion.py:156-173, :338-362): one polynomial per key half -> the same sk_hat and vk arrays
+    run("keygen_bcast_fused", S, (2 * l + 4) * row, S * 2 * row, kb + S * 2 * row,
+        lambda i, o: ctx.keygen_core_bcast_dev(A.ptr, i, o, o + kb, S, l),
+        note="one transform per key half, l row stores: 2 polynomials in, 2 l rows + 2 vk rows out")
     # sign (fusion.py:557): sk_hat [S][2][l][d], c_hat [S][d] -> sig [S][l][d]
     run("sign_kernel", S, (3 * l + 1) * row, kb + S * row, S * l * row,
         lambda i, o: ctx.sign_core_dev(i, i + kb, o, S, l))

@@ -52,7 +52,8 @@ VARIANTS = [{}, {"FZ_KEYGEN_UNFUSED": "1", "FZ_VERIFY_UNFUSED": "1", "FZ_POLYMUL
             {"FZ_AGG_WAVES": "4", "FZ_AGG_SLICES": "3"}, {"FZ_AGG_SLICES": "7", "FZ_VERIFY_ORDERED": "1"}, {"FZ_STREAM_PER_CU": "8"},
             {"FZ_NO_IMAD": "1", "FZ_FUSED_ROWS": "1"}, {"FZ_FUSED_ROWS": "2", "FZ_VERIFY_CENT": "1"}, {"FZ_FUSED_ROWS": "1", "FZ_AGG_SLICES": "2"},
             {"FZ_FUSED_TW": "1", "FZ_FUSED_PREFETCH": "2"}, {"FZ_FUSED_TW": "1", "FZ_FUSED_ROWS": "2", "FZ_FUSED_PREFETCH": "0"},
-            {"FZ_MATVEC_SLICES": "16"}, {"FZ_MATVEC_SLICES": "2"}, {"FZ_MATVEC_SLICES": "-1"}]
+            {"FZ_MATVEC_SLICES": "16"}, {"FZ_MATVEC_SLICES": "2"}, {"FZ_MATVEC_SLICES": "-1"},
+            {"FZ_VERIFY16": "7", "FZ_KEYGEN_BCAST_GENERAL": "1"}, {"FZ_VERIFY16": "2", "FZ_VERIFY16_NOPF": "1"}]
 vctx = {(sp, i): make_ctx(sp, "", v) for sp in (128, 256) for i, v in enumerate(VARIANTS)}
 DB = fusion_hip.DeviceBuffer
 t_end = time.time() + budget

@@ -344,6 +344,7 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         c->knob_no_imad = knob("FZ_NO_IMAD");
         c->knob_matvec_slices = knob("FZ_MATVEC_SLICES");
         c->knob_verify16 = knob("FZ_VERIFY16");
+        c->knob_sampler_one_kernel = knob("FZ_SAMPLER_ONE_KERNEL");
         c->knob_keygen_bcast_general = knob("FZ_KEYGEN_BCAST_GENERAL");
         c->knob_verify16_nopf = knob("FZ_VERIFY16_NOPF");
         c->knob_verify_cent = knob("FZ_VERIFY_CENT");
@@ -1160,13 +1161,20 @@ int fz_sample_secret_polys_dev(fz_ctx *ctx, const uint64_t *h_seeds, size_t N, i
     }
     int kbits = 0;
     for (uint64_t t = (uint64_t)bound; t; t >>= 1) ++kbits;            // bound.bit_length()
+    // Up to 4096 keys (8192 generators: a seeding wave on every other CU): two kernels -- seeding on a lane per generator,
+    // everything after it on a wave per generator, the states (20 MiB at most) through scratch: 54 + 29 us per 1024 keys
+    // against 190 in one kernel.  Beyond, the one lane-per-polynomial kernel already has a wave on every CU and the two
+    // forms take the same time (16 384 keys: 0.47 ms one kernel, 0.56 ms in four chunks of two).  FZ_SAMPLER_ONE_KERNEL=1 forces it.
+    const bool two_kernels = !ctx->knob_sampler_one_kernel && bound < (1ll << 31) && N <= 4096;
+    const size_t seeds_bytes = (N * 8 + 255) & ~(size_t)255, state_bytes = two_kernels ? N * 2 * 624 * sizeof(uint32_t) : 0;
     void *scr = nullptr;
-    FZ_TRY(fz_scratch(ctx, N * 8 + 256, &scr));
+    FZ_TRY(fz_scratch(ctx, 256 + seeds_bytes + state_bytes, &scr));
     int *d_fail = (int *)scr;
     unsigned long long *d_seeds = (unsigned long long *)((uint8_t *)scr + 256);
+    uint32_t *d_state = two_kernels ? (uint32_t *)((uint8_t *)scr + 256 + seeds_bytes) : nullptr;
     FZ_HIP(hipMemsetAsync(d_fail, 0, 4, ctx->stream), "sampler flag");
     FZ_HIP(hipMemcpyAsync(d_seeds, h_seeds, N * 8, hipMemcpyHostToDevice, ctx->stream), "upload of the seeds");
-    FZ_TRY(fz_launch_mt_sample(ctx, d_seeds, N, degree, (uint32_t)bound, kbits, ctx->d_mt_init, d_out, d_fail));
+    FZ_TRY(fz_launch_mt_sample(ctx, d_seeds, N, degree, (uint32_t)bound, kbits, ctx->d_mt_init, d_out, d_fail, d_state));
     int fail = 0;
     FZ_HIP(hipMemcpyAsync(&fail, d_fail, 4, hipMemcpyDeviceToHost, ctx->stream), "sampler flag read");
     FZ_HIP(hipStreamSynchronize(ctx->stream), "sampler sync");

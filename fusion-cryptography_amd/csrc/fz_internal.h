@@ -77,6 +77,7 @@ struct fz_ctx {
     hipStream_t diag_stream;     // fz_diag_shader_clock: the probe's private stream and result words (created on first use)
     unsigned long long *d_diag;
     int knob_keygen_bcast_general;   // FZ_KEYGEN_BCAST_GENERAL=1: fz_keygen_core_bcast through the general kernel (l transforms of the same row) as before round 3
+    int knob_sampler_one_kernel; // FZ_SAMPLER_ONE_KERNEL=1: the device key sampler as one lane-per-polynomial kernel (round 2) instead of seed + draw kernels
     int knob_verify16;           // FZ_VERIFY16 = 1 .. 6: waves per workgroup of the 16-per-lane many-aggregates verification kernel (7 = best divisor of the tasks; 0 = off: the radix-4 kernel, the default)
     int knob_verify16_nopf;      // FZ_VERIFY16_NOPF=1: verify_many16 requests a task's rows when it starts the task, not one task ahead (fewer registers)
     int knob_matvec_slices;      // FZ_MATVEC_SLICES = 1 | 2 | 4: k-range slices per column of the integer matvec kernel (0 = by batch size, -1 = the fp64 kernel)
@@ -136,8 +137,9 @@ int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d
                         uint8_t *d_text, size_t text_stride, int *d_nblocks, uint32_t *d_xof, size_t xstride, int out_blocks,
                         const uint32_t *d_tab, int32_t *d_coefs);
 void fz_mt_init_table(uint32_t *h_tab);                                              // 624 words
+// d_state: [2 * nkeys][624] words of scratch for the two-kernel form, or NULL for the one-kernel form
 int fz_launch_mt_sample(fz_ctx *ctx, const unsigned long long *d_seeds, size_t nkeys, int degree, uint32_t bound, int kbits,
-                        const uint32_t *d_init, int32_t *d_out, int *d_fail);
+                        const uint32_t *d_init, int32_t *d_out, int *d_fail, uint32_t *d_state);
 int fz_launch_prehash(fz_ctx *ctx, const fz_scheme_params *P, const uint8_t *d_msgs, const unsigned long long *d_off, size_t N,
                       uint8_t *d_pre, uint32_t *d_dec);          // d_dec [N][16]: the integers in base 10^9 + chunk count
 void fz_challenge_weight_table(int index_bytes, int degree, uint32_t *h_tab);      // (degree + 1) * 16 words

@@ -119,6 +119,187 @@ __global__ __launch_bounds__(64) void mt_sample_kernel(const unsigned long long 
 #undef FZ_MT
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same sampler in two kernels (the default up to 4096 keys per call since round 3: fz_sample_secret_polys_dev).  Only the SEEDING is a chain nothing can shorten (1247
+// dependent steps per generator): mt_seed_kernel keeps it on a lane per generator as above and writes the finished states
+// out word-major.  Everything after it -- regenerating the 624 words, tempering, the rejection sampling -- is parallel
+// over the words except for a two-state automaton along the output stream (is the next accepted draw a magnitude or a
+// sign?), so mt_draw_kernel gives every generator a WAVE: a thousand keys are 2048 waves on the whole chip instead of 32
+// waves on 32 CUs (a generator state fills a lane's share of one CU's LDS in the one-kernel form).
+//   regeneration: word k needs the old words k, k + 1 and word k + 397 -- old below k = 227, else the NEW word k - 227: three
+//                 chunks (0..226, 227..453, 454..623), each read completely before it is written;
+//   outputs:      lane L owns outputs 10 L .. 10 L + 9 of the generation.  It walks them twice -- entering in state "magnitude
+//                 next" and in state "sign next" -- and leaves (exit state, coefficients completed, pending magnitude) for
+//                 both in LDS; lane 0 chains the 64 summaries; every lane then walks its outputs once more from its true entry
+//                 state and writes its coefficients at their final positions.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kDrawWaves = 4;
+constexpr int kPerLane = 10;                 // 64 x 10 >= 624 outputs of a generation
+
+__global__ __launch_bounds__(64) void mt_seed_kernel(const unsigned long long *seeds, size_t npoly, const uint32_t *__restrict__ init_tab,
+                                                     uint32_t *state) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t mt[];          // [624][64]: the first loop's words, read back by the second
+    const int lane = threadIdx.x & 63;
+    const size_t p_raw = (size_t)blockIdx.x * 64 + lane;
+    const bool live = p_raw < npoly;
+    const size_t p = live ? p_raw : npoly - 1;
+    const unsigned long long seed = seeds[p >> 1] + (unsigned long long)(p & 1);      // left: seed, right: seed + 1
+    const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
+    const bool two = key1 != 0;
+    #define FZ_MTS(i, g) mt[(i) * 64 + (g)]
+    uint32_t prev = init_tab[0];
+    uint32_t j = 0;
+    constexpr int U = 8;
+    // the table words of eight steps are requested together (scalar loads): one per step put a memory wait -- which on this
+    // hardware also waits for the step's LDS store -- inside every link of the chain (148 cycles per step instead of ~40)
+    for (int i0 = 1; i0 < kMtN; i0 += U) {
+        uint32_t tab[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) tab[u] = init_tab[i0 + u < kMtN ? i0 + u : kMtN - 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u < kMtN) {
+                prev = (tab[u] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (j ? key1 : key0) + j;
+                FZ_MTS(i0 + u, lane) = prev;
+                j = two ? (j ^ 1u) : 0u;
+            }
+        }
+    }
+    prev = (FZ_MTS(1, lane) ^ ((prev ^ (prev >> 30)) * 1664525u)) + (j ? key1 : key0) + j;
+    FZ_MTS(1, lane) = prev;
+    for (int i0 = 2; i0 < kMtN; i0 += U) {
+        uint32_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = i0 + u < kMtN ? i0 + u : kMtN - 1; w[u] = FZ_MTS(i, lane); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u < kMtN) {
+                prev = (w[u] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i0 + u);
+                FZ_MTS(i0 + u, lane) = prev;
+                // words 2 .. 623 are final here: out they go, word-major (64 generators = one 256-byte store; the draw kernel
+                // gathers its generator's column -- 624 sectors per wave from the L2 -- rather than this kernel transposing
+                // 160 KB through LDS on 32 waves: 27 us of its 72)
+                if (live) state[(size_t)(i0 + u) * npoly + p_raw] = prev;
+            }
+        }
+    }
+    prev = (FZ_MTS(1, lane) ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
+    if (live) {
+        state[npoly + p_raw] = prev;
+        state[p_raw] = 0x80000000u;
+    }
+#undef FZ_MTS
+}
+
+__global__ __launch_bounds__(64 * kDrawWaves) void mt_draw_kernel(const uint32_t *__restrict__ state, size_t npoly, int degree, uint32_t bound,
+                                                                  int kbits, int32_t *out, int *fail) {
+    __shared__ uint32_t s_mt[kDrawWaves][kMtN + 16];
+    __shared__ uint32_t s_sum[kDrawWaves][64][8];       // per lane: for entry state M and S: exit state, coefficients, pending magnitude; [6..7]: true entry
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const size_t gen_id = (size_t)blockIdx.x * kDrawWaves + wave;
+    if (gen_id >= npoly) return;                          // whole waves only: the waves of a workgroup never synchronise
+    uint32_t *mt = s_mt[wave];
+    uint32_t (*sum)[8] = s_sum[wave];
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    for (int i = lane; i < kMtN; i += 64) mt[i] = state[(size_t)i * npoly + gen_id];      // word-major: see mt_seed_kernel
+    wsync();
+    int32_t *row = out + gen_id * (size_t)degree;
+    int t = 0;                   // coefficients finished before this generation (wave-uniform)
+    uint32_t carry_mag = 0;      // magnitude waiting for its sign at the start of this generation (0: none; wave-uniform)
+    const int shift = 32 - kbits;
+    for (int gen = 0; gen < kMaxGenerations; ++gen) {
+        // ---- regenerate the 624 words in place, three chunks ----
+        for (int c = 0; c < 3; ++c) {
+            const int lo = c == 0 ? 0 : (c == 1 ? kMtN - kMtM : 2 * (kMtN - kMtM)), hi = c == 0 ? kMtN - kMtM : (c == 1 ? 2 * (kMtN - kMtM) : kMtN - 1);
+            uint32_t nw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = lo + lane + 64 * u;
+                if (k < hi) {
+                    const uint32_t y = (mt[k] & 0x80000000u) | (mt[k + 1] & 0x7fffffffu);
+                    const uint32_t m397 = mt[k < kMtN - kMtM ? k + kMtM : k - (kMtN - kMtM)];     // old below 227, else the new word k - 227
+                    nw[u] = m397 ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                }
+            }
+            wsync();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = lo + lane + 64 * u;
+                if (k < hi) mt[k] = nw[u];
+            }
+            wsync();
+        }
+        if (lane == 0) {         // the last word reads the NEW word 0
+            const uint32_t y = (mt[kMtN - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+            mt[kMtN - 1] = mt[kMtM - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        wsync();
+        // ---- this lane's outputs ----
+        uint32_t v[kPerLane], sg[kPerLane];
+        const int base = lane * kPerLane;
+#pragma unroll
+        for (int u = 0; u < kPerLane; ++u) {
+            const int i = base + u;
+            const uint32_t y = mt_temper(mt[i < kMtN ? i : kMtN - 1]);
+            v[u] = i < kMtN ? (y >> shift) : 0xffffffffu;            // past the end: neither a magnitude nor a sign
+            sg[u] = i < kMtN ? (y >> 30) : 3u;
+        }
+        // walk from both entry states: state 0 = magnitude next, else the pending magnitude (> 0)
+        auto walk = [&](uint32_t mag, uint32_t &cnt) {
+            cnt = 0;
+#pragma unroll
+            for (int u = 0; u < kPerLane; ++u) {
+                const bool take_sign = mag != 0 && sg[u] < 2u, take_mag = mag == 0 && v[u] < bound;
+                cnt += take_sign ? 1u : 0u;
+                mag = take_sign ? 0u : (take_mag ? v[u] + 1u : mag);
+            }
+            return mag;
+        };
+        uint32_t cm, cs;
+        const uint32_t em = walk(0u, cm);                // entered expecting a magnitude: exit pending magnitude (0: none)
+        const uint32_t es = walk(0xffffffffu, cs);       // entered with SOME magnitude pending: the value is patched below
+        // entering with a pending magnitude P: the walk is the same until the first sign is taken; if none is taken the exit
+        // still holds P (es == 0xffffffff marks that)
+        sum[lane][0] = em; sum[lane][1] = cm; sum[lane][2] = es; sum[lane][3] = cs;
+        wsync();
+        if (lane == 0) {
+            uint32_t pend = carry_mag;
+            int tt = t;
+            for (int L = 0; L < 64; ++L) {
+                sum[L][6] = pend;
+                sum[L][7] = (uint32_t)tt;
+                if (pend == 0) { tt += (int)sum[L][1]; pend = sum[L][0]; }
+                else { tt += (int)sum[L][3]; pend = sum[L][2] == 0xffffffffu ? pend : sum[L][2]; }
+            }
+            sum[0][4] = pend;
+            sum[0][5] = (uint32_t)tt;
+        }
+        wsync();
+        {
+            uint32_t mag = sum[lane][6];
+            int tl = (int)sum[lane][7];
+#pragma unroll
+            for (int u = 0; u < kPerLane; ++u) {
+                const bool take_sign = mag != 0 && sg[u] < 2u, take_mag = mag == 0 && v[u] < bound;
+                if (take_sign) {
+                    if (tl < degree) row[tl] = sg[u] ? -(int32_t)mag : (int32_t)mag;          // (1 + r1) * (1 - 2 * r2)
+                    ++tl;
+                }
+                mag = take_sign ? 0u : (take_mag ? v[u] + 1u : mag);
+            }
+        }
+        carry_mag = sum[0][4];
+        t = (int)sum[0][5];
+        wsync();
+        if (t >= degree) return;
+    }
+    if (lane == 0) atomicOr(fail, 1);        // never seen: the caller falls back to the host sampler
+}
+
 }  // namespace
 
 // state after init_genrand(19650218u): 624 words
@@ -129,13 +310,21 @@ void fz_mt_init_table(uint32_t *h_tab) {
 
 // d_seeds [nkeys] (device), d_out [2 * nkeys][degree]; d_init the table above; d_fail one int, zero before the launch
 int fz_launch_mt_sample(fz_ctx *ctx, const unsigned long long *d_seeds, size_t nkeys, int degree, uint32_t bound, int kbits,
-                        const uint32_t *d_init, int32_t *d_out, int *d_fail) {
+                        const uint32_t *d_init, int32_t *d_out, int *d_fail, uint32_t *d_state) {
     if (nkeys == 0) return FZ_OK;
     const size_t lds = (size_t)kMtN * 64 * 4;
-    hipError_t e = hipFuncSetAttribute((const void *)mt_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fz_check_hip(e, "sampler LDS attribute");
     const size_t npoly = 2 * nkeys;
-    hipLaunchKernelGGL(mt_sample_kernel, dim3((unsigned)((npoly + 63) / 64)), dim3(64), lds, ctx->stream, d_seeds, npoly, degree, bound,
-                       kbits, d_init, d_out, d_fail);
-    return fz_check_hip(hipGetLastError(), "mt_sample launch");
+    if (!d_state) {            // FZ_SAMPLER_ONE_KERNEL=1: the lane-per-polynomial kernel of round 2
+        hipError_t e = hipFuncSetAttribute((const void *)mt_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fz_check_hip(e, "sampler LDS attribute");
+        hipLaunchKernelGGL(mt_sample_kernel, dim3((unsigned)((npoly + 63) / 64)), dim3(64), lds, ctx->stream, d_seeds, npoly, degree,
+                           bound, kbits, d_init, d_out, d_fail);
+        return fz_check_hip(hipGetLastError(), "mt_sample launch");
+    }
+    hipError_t e = hipFuncSetAttribute((const void *)mt_seed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fz_check_hip(e, "sampler LDS attribute");
+    hipLaunchKernelGGL(mt_seed_kernel, dim3((unsigned)((npoly + 63) / 64)), dim3(64), lds, ctx->stream, d_seeds, npoly, d_init, d_state);
+    hipLaunchKernelGGL(mt_draw_kernel, dim3((unsigned)((npoly + kDrawWaves - 1) / kDrawWaves)), dim3(64 * kDrawWaves), 0, ctx->stream,
+                       (const uint32_t *)d_state, npoly, degree, bound, kbits, d_out, d_fail);
+    return fz_check_hip(hipGetLastError(), "mt_seed / mt_draw launch");
 }

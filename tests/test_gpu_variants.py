@@ -227,3 +227,36 @@ def test_broadcast_keygen_forms(secpar, general, coracle):
             assert np.array_equal(sk, rsk) and np.array_equal(vk, rvk), (l, n)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("one_kernel", ["0", "1"])
+def test_device_sampler_forms(one_kernel):
+    """the reference's seeded secret-key sampler on the device (polynomials.py:436-467 driven by fusion.py:339-362) as seed +
+    draw kernels (default) and as the one lane-per-polynomial kernel (FZ_SAMPLER_ONE_KERNEL=1): both equal the C clone on the
+    host (itself pinned to CPython's random) -- one- and two-word seeds, bounds with few and many rejections, degrees that
+    end inside a generation and that need several, more keys than the two-kernel form takes (4096)"""
+    import fusion_hip
+    from fusion_hip import hostpipe
+    P = O.PARAMS[256]
+    q = P["q"]
+    ctx = _ctx(P, {"FZ_SAMPLER_ONE_KERNEL": one_kernel})
+    rng = np.random.default_rng(2024)
+    try:
+        for nn, deg, bound in ((1, 256, 52), (5, 64, 52), (70, 256, 1), (33, 16, 2**31 - 1), (3, 100, 7), (200, 256, 33),
+                               (9, 256, 2**20 + 7), (4100, 64, 52), (2, 4, 1000)):
+            seeds = [int(v) for v in rng.integers(0, 2**63, size=nn, dtype=np.uint64)]
+            seeds[0] = 0
+            if nn > 2:
+                seeds[1] = 2**32 - 1                 # seed + 1 crosses into a two-word key
+                seeds[2] = 2**64 - 2
+            for k in range(3, nn, 2):
+                seeds[k] %= 2**32                    # one-word keys
+            do = fusion_hip.DeviceBuffer(ctx, nn * 2 * deg * 4)
+            try:
+                ctx.sample_secret_polys_dev(seeds, q, deg, bound, deg, do.ptr)
+                got = do.to_numpy(np.int32, (nn, 2, deg))
+            finally:
+                do.free()
+            assert np.array_equal(got, hostpipe.sample_secret_polys(seeds, q, deg, bound, deg)), (nn, deg, bound)
+    finally:
+        ctx.close()

@@ -88,6 +88,12 @@ struct fz_ctx {
     int graphs_captured;
     void **retired;
     int n_retired, cap_retired;
+    // fz_malloc / fz_free keep large blocks for reuse (hipFree of anything from 16 MiB up costs ~180 us AND synchronises the
+    // device): live blocks with their sizes, and the blocks handed back, at most pool_cap bytes of them (FZ_POOL_MB, 0 = off)
+    struct FzBlock { void *p; size_t bytes; };
+    FzBlock *live_blocks, *pool_blocks;
+    int n_live, cap_live, n_pool, cap_pool;
+    size_t pool_bytes, pool_cap;
     // RCCL (fz_comm_*): communicators are owned by the caller; nothing here
 };
 

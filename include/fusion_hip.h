@@ -99,7 +99,12 @@ FZ_API int fz_graph_end(fz_ctx *ctx, fz_graph **out_graph);
 FZ_API int fz_graph_launch(fz_ctx *ctx, fz_graph *graph);      /* asynchronous on the context's stream */
 FZ_API int fz_graph_destroy(fz_graph *graph);
 
-/* ---- device memory helpers (so a host language needs no HIP binding of its own) -------- */
+/* ---- device memory helpers (so a host language needs no HIP binding of its own) --------
+ * fz_free keeps blocks of 256 KiB or more for reuse by later fz_malloc calls of this context (at most FZ_POOL_MB megabytes of
+ * them, default 4096; 0 = every fz_free is a hipFree, which for a large block takes ~180 us and synchronises the device).
+ * A reused block may still be read or written by work queued EARLIER on the context's stream: whatever uses it next through
+ * this context is queued after that work, so stream order keeps the two apart; do not hand a freed block's address to another
+ * stream or context.  fz_ctx_destroy releases the pool. */
 FZ_API int fz_malloc(fz_ctx *ctx, size_t bytes, void **d_out);
 FZ_API int fz_free(fz_ctx *ctx, void *d_ptr);
 FZ_API int fz_memcpy_h2d(fz_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* async on ctx stream */

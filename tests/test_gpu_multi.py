@@ -225,3 +225,52 @@ def test_contexts_on_two_devices_do_not_cross(coracle):
     ref = coracle.ntt_forward(x, P["q"], P["root"])
     assert np.array_equal(f1, ref) and np.array_equal(f0, ref)
     assert np.array_equal(c1.ntt_inverse(f1), x)
+
+
+def test_block_pool_reuses_in_stream_order(monkeypatch):
+    """fz_free keeps large blocks and fz_malloc hands them out again (include/fusion_hip.h): the same address comes back for a
+    request it fits, work queued on the old contents before the free still completes before the new owner's work, small blocks
+    and FZ_POOL_MB=0 go straight to hipMalloc / hipFree, the cap holds"""
+    import fusion_hip
+    P = O.PARAMS[256]
+    q, d = P["q"], P["d"]
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    rows = 1 << 14
+    x = O.splitmix_centered(3, rows * d).reshape(rows, d)
+    want = ctx.ntt_forward(x)
+    a, out = ctx.malloc(x.nbytes), ctx.malloc(x.nbytes)
+    ctx.h2d(a, x)
+    ctx.ntt_forward_dev(a, out, rows)                  # queued: reads a
+    ctx.free(a)
+    b = ctx.malloc(x.nbytes - 4096)                    # fits the block just freed (within a quarter)
+    assert b == a
+    ctx.fill_synthetic_dev(b, rows * d - 1024, 9)      # queued AFTER the transform that reads the old contents
+    got = np.empty_like(x)
+    ctx.d2h(got, out)
+    assert np.array_equal(got, want)
+    c = ctx.malloc(x.nbytes * 2)                       # does not fit: a fresh block
+    assert c not in (a, out)
+    small1 = ctx.malloc(1000)
+    ctx.free(small1)
+    for p in (b, c, out):
+        ctx.free(p)
+    assert ctx.malloc(x.nbytes) in (b, out)            # exact size: one of the two 16 MiB blocks
+    ctx.close()
+    monkeypatch.setenv("FZ_POOL_MB", "0")
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    monkeypatch.delenv("FZ_POOL_MB")
+    p1 = ctx.malloc(1 << 24)
+    ctx.free(p1)
+    p2 = ctx.malloc(1 << 24)
+    ctx.free(p2)                                       # (whatever address hipMalloc chose: nothing is tracked, nothing kept)
+    ctx.close()
+    monkeypatch.setenv("FZ_POOL_MB", "20")
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    monkeypatch.delenv("FZ_POOL_MB")
+    ps = [ctx.malloc(1 << 23) for _ in range(4)]       # 4 x 8 MiB, cap 20 MiB: two stay, the oldest are released
+    for p in ps:
+        ctx.free(p)
+    back = [ctx.malloc(1 << 23) for _ in range(2)]
+    assert set(back) <= set(ps[2:]) | set(ps)          # reuse comes from the kept ones
+    assert ctx.malloc(1 << 25) not in ps               # larger than the cap: never pooled, never confused with a kept block
+    ctx.close()

@@ -174,3 +174,42 @@ def test_sampler_clone_matches_cpython_random(hp, kat):
     polys = hp.sample_secret_polys([5, 2**32 - 1], q, 256, 52, 256, threads=2)
     assert polys[1, 1].tolist() == samp_c(**ring, norm_bound=52, weight_bound=256, seed=2**32).coefficients
     assert polys[0, 0].tolist() == samp_c(**ring, norm_bound=52, weight_bound=256, seed=5).coefficients
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_sort_by_vk_string_with_ties_and_shared_prefixes(secpar, hp):
+    """sorted(keys, key=str) (fusion.py:661-663, :693) through the short-prefix comparison: keys that are identical (the
+    reference's demo generates every key from one seed), keys that differ only deep inside the left polynomial, only in the right
+    one, only in the sign or the number of digits of the first value -- the order, ties included (stable), is Python's"""
+    import fusion.fusion as F
+    params = F.fusion_setup(secpar, 7)
+    P = hp.scheme_params(params)
+    q, d = params.modulus, params.degree
+    rng = np.random.default_rng(secpar)
+    base = rng.integers(-(q // 2), q // 2 + 1, size=(2, d)).astype(np.int32)
+    rows = []
+    for _ in range(3):
+        rows.append(base.copy())                                   # identical keys
+    for pos in (0, 1, 7, 8, 9, d - 1):                             # one value of the left polynomial differs, early and late
+        k = base.copy()
+        k[0, pos] += 1
+        rows.append(k)
+    for pos in (0, d - 1):                                         # only the right polynomial differs
+        k = base.copy()
+        k[1, pos] -= 1
+        rows.append(k)
+    for v0 in (5, 57, -5, -57, 0, 570, 9, 10, -1):                 # "5" < "57", "-" < digits, "10" < "9" as text
+        k = base.copy()
+        k[0, 0] = v0
+        rows.append(k)
+        rows.append(k.copy())
+    vk = np.stack(rows)
+    perm = rng.permutation(len(rows))
+    vk = vk[perm]
+    vkL, vkR = np.ascontiguousarray(vk[:, 0]), np.ascontiguousarray(vk[:, 1])
+
+    def text(i):
+        return hp.format_vk(P, vkL[i], vkR[i])
+    for threads in (1, 3):
+        order = hp.sort_by_vk_string(P, vkL, vkR, threads)
+        assert order.tolist() == sorted(range(len(rows)), key=text)

@@ -1039,14 +1039,25 @@ def main():
             n_e2e = 1024
             seeds = [10_000 + 2 * i for i in range(n_e2e)]
             msgs = [f"synthetic message {i:06d}" for i in range(n_e2e)]
-            bs.keygen_batch(seeds[:4])
-            t0 = time.perf_counter()
-            sk_e, vk_e, vk_dev = bs.keygen_batch(seeds, device=True, keep_vk=True)      # keys stay in HBM
-            t_keygen = time.perf_counter() - t0
+            # every call is timed three times after one untimed call of the same size (first-use allocations, scratch growth);
+            # the best is reported: these legs run host code on a shared machine and single shots scatter by 30-50 %
+            def best_of(fn, keep=None, reps=3):
+                best, out = 1e30, None
+                for _ in range(reps):
+                    if out is not None and keep is not None:
+                        keep(out)                                          # release the previous repetition's results
+                    t0 = time.perf_counter()
+                    out = fn()
+                    best = min(best, time.perf_counter() - t0)
+                return best, out
+
+            def drop_keys(r):
+                r[0].free()
+                r[2].free()
+            drop_keys(bs.keygen_batch(seeds, device=True, keep_vk=True))
+            t_keygen, (sk_e, vk_e, vk_dev) = best_of(lambda: bs.keygen_batch(seeds, device=True, keep_vk=True), drop_keys)   # keys stay in HBM
             bs.sign_batch(sk_e, vk_dev, msgs, device=True).free()          # scratch growth outside the timing
-            t0 = time.perf_counter()
-            sig_e = bs.sign_batch(sk_e, vk_dev, msgs, device=True)          # signatures stay in HBM
-            t_sign = time.perf_counter() - t0
+            t_sign, sig_e = best_of(lambda: bs.sign_batch(sk_e, vk_dev, msgs, device=True), lambda r: r.free())       # signatures stay in HBM
             # the same signatures with the challenge pipeline on the HOST threads (round 1's path), for the split
             bs.device_hash = False
             t0 = time.perf_counter()
@@ -1058,17 +1069,11 @@ def main():
             torch.cuda.synchronize(dev)
             t_chal = time.perf_counter() - t0
             pre_only.free()
-            t0 = time.perf_counter()
-            agg_e = bs.aggregate(vk_e, msgs, sig_e)
-            t_agg = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            ok, why = bs.verify(vk_e, msgs, agg_e)
-            t_ver = time.perf_counter() - t0
+            t_agg, agg_e = best_of(lambda: bs.aggregate(vk_e, msgs, sig_e))
+            t_ver, (ok, why) = best_of(lambda: bs.verify(vk_e, msgs, agg_e))
             assert ok, why
             bs.aggregate_verify(vk_e, msgs, sig_e)
-            t0 = time.perf_counter()
-            agg_av, (ok, why) = bs.aggregate_verify(vk_e, msgs, sig_e)     # one hash_ag for both, one pass over the signatures
-            t_av = time.perf_counter() - t0
+            t_av, (agg_av, (ok, why)) = best_of(lambda: bs.aggregate_verify(vk_e, msgs, sig_e))     # one hash_ag for both, one pass over the signatures
             assert ok and np.array_equal(agg_av, agg_e), why
             # a larger batch of signatures: the device pipeline is a latency chain of ~108 Keccak permutations per signer,
             # the same ~0.7 ms for any batch up to 32 768 signers (two lanes per signer, one wave per SIMD)
@@ -1088,12 +1093,8 @@ def main():
             for g_, n_ in ((4, 256), (16, 64), (64, 16)):
                 sizes = [n_] * g_
                 bs.aggregate_many(vk_e, msgs, sig_e, sizes)                      # scratch growth outside the timing
-                t0 = time.perf_counter()
-                aggs = bs.aggregate_many(vk_e, msgs, sig_e, sizes)
-                t_am = time.perf_counter() - t0
-                t0 = time.perf_counter()
-                verd = bs.verify_many(vk_e, msgs, aggs, sizes)
-                t_vm = time.perf_counter() - t0
+                t_am, aggs = best_of(lambda: bs.aggregate_many(vk_e, msgs, sig_e, sizes))
+                t_vm, verd = best_of(lambda: bs.verify_many(vk_e, msgs, aggs, sizes))
                 assert all(v[0] for v in verd), verd
                 many[f"{g_}x{n_}"] = {"aggregate_per_s": n_e2e / t_am, "verify_per_s": n_e2e / t_vm,
                                       "sign_plus_verify_per_s": n_e2e / (t_sign + t_am + t_vm),
@@ -1104,7 +1105,8 @@ def main():
             sig_e.free()
             sk_e.free()
             vk_dev.free()
-            e2e = {"signatures": n_e2e, "host_threads": bs.threads, "keygen_per_s": n_e2e / t_keygen, "many_aggregates": many,
+            e2e = {"signatures": n_e2e, "host_threads": bs.threads, "timing": "best of 3 calls after one untimed call of the same size",
+                   "keygen_per_s": n_e2e / t_keygen, "many_aggregates": many,
                    "sign_per_s": n_e2e / t_sign,
                    "sign_split": {"device_challenge_pipeline_ms": t_chal * 1e3, "whole_sign_batch_ms": t_sign * 1e3,
                                   "sign_per_s_with_host_challenge_pipeline": n_e2e / t_sign_host,

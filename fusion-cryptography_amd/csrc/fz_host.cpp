@@ -691,12 +691,24 @@ int fz_sample_ntt_values(uint64_t seed, int64_t modulus, int degree, int32_t *h_
     return FZ_OK;
 }
 
-/* sample_polynomial_coefficient_representation (algebra/polynomials.py:436-467) with an int seed */
+/* sample_polynomial_coefficient_representation (algebra/polynomials.py:436-467) with an int seed; h_state (optional): the
+ * generator afterwards, as random.getstate()[1] holds it -- 624 state words and the position -- so that a caller that stands in
+ * for the Python function can leave the process-global generator exactly where the function leaves it (random.setstate) */
+int fz_sample_coefficients_state(uint64_t seed, int64_t modulus, int degree, int64_t norm_bound, int64_t weight_bound,
+                                 int32_t *h_out, uint32_t *h_state);
 int fz_sample_coefficients(uint64_t seed, int64_t modulus, int degree, int64_t norm_bound, int64_t weight_bound,
                            int32_t *h_out) {
+    return fz_sample_coefficients_state(seed, modulus, degree, norm_bound, weight_bound, h_out, nullptr);
+}
+int fz_sample_coefficients_state(uint64_t seed, int64_t modulus, int degree, int64_t norm_bound, int64_t weight_bound,
+                                 int32_t *h_out, uint32_t *h_state) {
     if (!h_out || degree < 1 || modulus < 2) return fz_set_error(FZ_E_BADARG, "bad argument");
     PyRandom rng;
     rng.seed(seed);
+    struct Export {          // on every return path below the sampling
+        PyRandom &r; uint32_t *dst;
+        ~Export() { if (dst) { memcpy(dst, r.mt, 624 * sizeof(uint32_t)); dst[624] = (uint32_t)r.idx; } }
+    } exporter{rng, h_state};
     const int count = (int)std::max<int64_t>(0, std::min<int64_t>(degree, weight_bound));
     const int64_t bound = std::max<int64_t>(0, std::min<int64_t>(modulus / 2, norm_bound));
     if (count > 0 && (bound < 1 || bound >= (1ll << 32))) return fz_set_error(FZ_E_BADARG, "empty range for randrange()");

@@ -232,6 +232,29 @@ def _rows_of(matrix: GeneralMatrix, q):
     return _backend.stack_polys([z for row in matrix.matrix for z in row], q)
 
 
+def _sample_half(params, s):
+    """The polynomial sample_polynomial_coefficient_representation(..., seed=s) returns, as an int32 row, with the process-global
+    `random` left exactly where that function leaves it.  512 randrange() calls in Python are 0.6 ms per polynomial -- most
+    of a keygen() call; the C clone of CPython's generator (fz_sample_coefficients_state, pinned to `random` by the tests) takes
+    microseconds and hands back the generator's state for random.setstate().  Only for what it reproduces bit for bit: a
+    plain non-negative int seed below 2^64 - 1 (random.seed takes abs() of negative ints and hashes other types) and the stock
+    sampler and generator functions (nobody patched them)."""
+    import random as _random
+    import algebra.polynomials as _P
+    if (type(s) is int and 0 <= s < 2 ** 64 - 1 and _pristine("sample_polynomial_coefficient_representation")
+            and _P.sample_polynomial_coefficient_representation is _ORIGINALS["sample_polynomial_coefficient_representation"]
+            and _P.randrange == _random.randrange and _P.random_seed == _random.seed):
+        try:
+            row, state = hostpipe.sample_coefficients_with_state(s, params.modulus, params.degree, params.beta_sk, params.omega_sk)
+            _random.setstate((3, state, None))
+            return row
+        except Exception:
+            pass
+    return sample_polynomial_coefficient_representation(
+        modulus=params.modulus, degree=params.degree, root_order=params.root_order, root=params.root, inv_root=params.inv_root,
+        norm_bound=params.beta_sk, weight_bound=params.omega_sk, seed=s)._i32()
+
+
 def keygen(params: Params, seed: Optional[int]) -> OneTimeKeyTuple:
     """fusion.py:338-373: two coefficient-domain secret vectors (seeds `seed`, `seed + 1`), their
     NTTs, and vk = public_challenge * sk_hat -- the arithmetic is ONE fz_keygen_core call."""
@@ -241,9 +264,7 @@ def keygen(params: Params, seed: Optional[int]) -> OneTimeKeyTuple:
         # every entry of a half is sampled with the same seed (fusion.py:156-173), i.e. IS the same polynomial, and each
         # call leaves the process-global `random` where one call leaves it: sample it once, let the kernel read it for
         # all l rows (fz_keygen_core_bcast)
-        halves = [sample_polynomial_coefficient_representation(
-            modulus=q, degree=params.degree, root_order=params.root_order, root=params.root, inv_root=params.inv_root,
-            norm_bound=params.beta_sk, weight_bound=params.omega_sk, seed=s)._i32() for s in (seed, seed + 1)]
+        halves = [_sample_half(params, s) for s in (seed, seed + 1)]
         sk_hat, vk = _ctx(params).keygen_core_bcast(A, np.stack(halves)[None])
     else:
         halves = []
@@ -505,4 +526,5 @@ def verify(params: Params, keys: List[OneTimeVerificationKey], messages: List[st
 
 
 _ORIGINALS.update({name: globals()[name] for name in (
-    "decode_bytes_to_polynomial_coefficients", "hash_ch", "parse_challenge", "transform", "sample_coefficient_matrix", "hash_ag")})
+    "decode_bytes_to_polynomial_coefficients", "hash_ch", "parse_challenge", "transform", "sample_coefficient_matrix", "hash_ag",
+    "sample_polynomial_coefficient_representation")})

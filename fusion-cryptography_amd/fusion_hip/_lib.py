@@ -135,6 +135,7 @@ SIGNATURES.update({
     "fz_challenge_hat_msgs_dev": (c_int, [_ctx, _spp, c_void_p, c_char_p, _szp, c_size_t, c_void_p, _u8p]),
     "fz_sample_ntt_values": (c_int, [ctypes.c_uint64, c_int64, c_int, _i32p]),
     "fz_sample_coefficients": (c_int, [ctypes.c_uint64, c_int64, c_int, c_int64, c_int64, _i32p]),
+    "fz_sample_coefficients_state": (c_int, [ctypes.c_uint64, c_int64, c_int, c_int64, c_int64, _i32p, _u32p]),
     "fz_sample_secret_polys_dev": (c_int, [_ctx, POINTER(ctypes.c_uint64), c_size_t, c_int64, c_int, c_int64, c_int64, c_void_p]),
     "fz_sample_secret_polys": (c_int, [POINTER(ctypes.c_uint64), c_size_t, c_int64, c_int, c_int64, c_int64, _i32p, c_int]),
 })

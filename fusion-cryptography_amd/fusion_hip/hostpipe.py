@@ -163,6 +163,17 @@ def sample_coefficients(seed, modulus, degree, norm_bound, weight_bound):
     return out
 
 
+def sample_coefficients_with_state(seed, modulus, degree, norm_bound, weight_bound):
+    """-> (coefficients, state): the same polynomial and the generator afterwards as a tuple of 625 ints, the middle element
+    of what random.getstate() returns after sample_polynomial_coefficient_representation(..., seed=seed)"""
+    lib = load_library()
+    out = np.empty(degree, dtype=np.int32)
+    st = np.empty(625, dtype=np.uint32)
+    check(lib, lib.fz_sample_coefficients_state(seed, modulus, degree, norm_bound, weight_bound, _p(out),
+                                                st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+    return out, tuple(st.tolist())
+
+
 def sample_secret_polys(seeds, modulus, degree, norm_bound, weight_bound, threads=None):
     """[N][2][degree]: the left (seed) and right (seed + 1) secret polynomial of each key"""
     lib = load_library()

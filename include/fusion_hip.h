@@ -389,6 +389,10 @@ FZ_API int fz_challenge_hat_msgs_dev(fz_ctx *ctx, const fz_scheme_params *P, con
 FZ_API int fz_sample_ntt_values(uint64_t seed, int64_t modulus, int degree, int32_t *h_out);
 FZ_API int fz_sample_coefficients(uint64_t seed, int64_t modulus, int degree, int64_t norm_bound,
                                   int64_t weight_bound, int32_t *h_out);
+/* the same, and the generator's state afterwards in h_state[625] (624 words + position: what random.getstate()[1] holds), for a
+ * caller that replaces the Python function and must leave the process-global `random` where that function leaves it */
+FZ_API int fz_sample_coefficients_state(uint64_t seed, int64_t modulus, int degree, int64_t norm_bound,
+                                        int64_t weight_bound, int32_t *h_out, uint32_t *h_state);
 /* the two distinct secret polynomials of keygen(params, seed) for N keys: [N][2][degree] */
 FZ_API int fz_sample_secret_polys(const uint64_t *h_seeds, size_t N, int64_t modulus, int degree,
                                   int64_t norm_bound, int64_t weight_bound, int32_t *h_out, int threads);

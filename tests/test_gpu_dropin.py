@@ -230,6 +230,22 @@ def test_keygen_leaves_the_global_generator_where_the_reference_does():
     assert random.getstate() == state
     with pytest.raises(TypeError):
         F.keygen(params, None)
+    # seeds the C clone does not take go through the Python sampler: same contract (random.seed takes abs() of a negative int)
+    sk_n, vk_n = F.keygen(params, -7)
+    state = random.getstate()
+    F.sample_coefficient_matrix(seed=-6, modulus=params.modulus, degree=params.degree, root_order=params.root_order,
+                                root=params.root, inv_root=params.inv_root, num_rows=params.num_rows_sk,
+                                num_cols=params.num_cols_sk, norm_bound=params.beta_sk, weight_bound=params.omega_sk)
+    assert random.getstate() == state
+    sk_p, vk_p = F.keygen(params, 7)                       # abs(-7) = 7 seeds the left half ...
+    assert sk_n.left_sk_hat == sk_p.left_sk_hat and sk_n.right_sk_hat != sk_p.right_sk_hat      # ... -6 -> 6, not 8, the right one
+    assert params.public_challenge * sk_n.right_sk_hat == vk_n.right_vk_hat
+    # a replaced generator function is honoured (the fast path steps aside): every draw 0 -> magnitude 1, sign +1
+    from unittest import mock
+    with mock.patch("algebra.polynomials.randrange", return_value=0):
+        sk_m, _ = F.keygen(params, 5)
+    from algebra.polynomials import transform
+    assert transform(sk_m.left_sk_hat.matrix[0][0]).coefficients == [1] * params.degree
 
 
 @pytest.mark.parametrize("secpar", [128, 256])

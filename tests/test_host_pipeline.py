@@ -213,3 +213,24 @@ def test_sort_by_vk_string_with_ties_and_shared_prefixes(secpar, hp):
     for threads in (1, 3):
         order = hp.sort_by_vk_string(P, vkL, vkR, threads)
         assert order.tolist() == sorted(range(len(rows)), key=text)
+
+
+def test_sampler_state_export_equals_cpython(hp):
+    """fz_sample_coefficients_state: the polynomial AND the generator's state afterwards are what CPython's `random` holds after
+    sample_polynomial_coefficient_representation(seed=...) (polynomials.py:436-467) -- the drop-in keygen relies on it to
+    leave the process-global generator where the reference leaves it (random.setstate) without 512 randrange() calls"""
+    import fusion.fusion as F
+    from algebra.polynomials import sample_polynomial_coefficient_representation as sample
+    for secpar in (128, 256):
+        T = F.PREFIX_PARAMETERS[secpar]
+        for seed in (0, 1, 42, 2**32 - 1, 2**32, 2**63 + 5, 2**64 - 2):
+            ref = sample(modulus=T["modulus"], degree=T["degree"], root=T["root"], inv_root=T["inv_root"], root_order=T["root_order"],
+                         norm_bound=T["beta_sk"], weight_bound=T["omega_sk"], seed=seed)
+            want = random.getstate()
+            row, state = hp.sample_coefficients_with_state(seed, T["modulus"], T["degree"], T["beta_sk"], T["omega_sk"])
+            assert row.tolist() == ref.coefficients and want == (3, state, None), (secpar, seed)
+    # a weight bound below the degree: the shuffle's draws are part of the state too
+    ref = sample(modulus=65537, degree=64, root=1, inv_root=1, root_order=1, norm_bound=9, weight_bound=10, seed=7)
+    want = random.getstate()
+    row, state = hp.sample_coefficients_with_state(7, 65537, 64, 9, 10)
+    assert row.tolist() == ref.coefficients and want == (3, state, None)

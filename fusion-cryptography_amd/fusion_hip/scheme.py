@@ -11,17 +11,29 @@ import numpy as np
 
 from . import hostpipe
 from ._lib import FZ_E_UNSUPPORTED, FusionHipError
-from .context import DeviceArray, VERDICT_REASONS, get_context
+from .context import Context, DeviceArray, VERDICT_REASONS, get_context
 
 
 class BatchScheme:
-    def __init__(self, params, device=0, threads=None):
-        """params: a fusion.fusion.Params (or any object with the same attributes)."""
+    def __init__(self, params, device=0, threads=None, private_context=False):
+        """params: a fusion.fusion.Params (or any object with the same attributes).
+        private_context: give this object a context and a HIP stream of its own instead of the process-wide one per device.
+        A context serves one host thread at a time (include/fusion_hip.h), so several BatchSchemes that are to work
+        CONCURRENTLY -- one per worker thread -- each need their own.  That is how batches of the BASELINE size keep the chip
+        busy: a 1024-signature sign_batch is a latency chain (108 Keccak permutations per signer on 32 waves: 0.63 of its
+        0.87 ms) that leaves the other 250 CUs idle, and calls on separate streams overlap (tools/concurrent_batches.py).
+        close() releases the private context."""
         self.params = params
         self.P = hostpipe.scheme_params(params)
         self.threads = threads or hostpipe.default_threads()
         self.d, self.l, self.q = params.degree, params.num_rows_sk, params.modulus
-        self.ctx = get_context(params.modulus, params.degree, params.root, params.inv_root, device)
+        self._private = bool(private_context)
+        if self._private:
+            self.ctx = Context(params.modulus, params.degree, params.root % params.modulus, params.inv_root % params.modulus, device)
+            self._stream = self.ctx.stream_create()
+            self.ctx.set_stream(self._stream)
+        else:
+            self.ctx = get_context(params.modulus, params.degree, params.root, params.inv_root, device)
         self.device_hash = True          # per-signer challenge pipeline on the device (falls back to the host if unsupported)
         self.device_sampler = True       # secret polynomials sampled on the device (the same fallback)
         self.A = np.array([z.values for row in params.public_challenge.matrix for z in row], dtype=np.int32)
@@ -33,10 +45,15 @@ class BatchScheme:
         return self._dA
 
     def close(self):
-        """release the device copy of the public challenge (the context itself is shared and stays)"""
+        """release the device copy of the public challenge, and the context if it is this object's own (the shared one stays)"""
         if self._dA is not None:
             self._dA.free()
             self._dA = None
+        if self._private and self.ctx is not None:
+            self.ctx.set_stream(0)
+            self.ctx.stream_destroy(self._stream)
+            self.ctx.close()
+            self.ctx = None
 
     # ---- keygen ------------------------------------------------------------------------------------
     def _dev(self, a, shape):

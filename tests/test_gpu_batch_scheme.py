@@ -120,3 +120,53 @@ def test_device_and_host_challenge_pipelines_give_the_same_signatures(secpar):
     assert bs.verify(vk_h, msgs, agg) == (True, "")
     sk_d.free()
     vk_d.free()
+
+
+def test_private_contexts_work_concurrently():
+    """BatchScheme(private_context=True): its own context and stream, so that worker threads can keep several batches in flight
+    (a context serves one host thread at a time).  Four workers, each keygen + sign + aggregate + verify on its own seeds and
+    messages at the same time: every result equals what the shared-context BatchScheme computes alone."""
+    import threading
+    import fusion.fusion as F
+    from fusion_hip.scheme import BatchScheme
+    params = F.fusion_setup(128, 31)
+    n, W = 96, 4
+    ref = BatchScheme(params)
+    want = []
+    for i in range(W):
+        seeds = [500 * (i + 1) + 2 * k for k in range(n)]
+        msgs = [f"w{i} m{k}" for k in range(n)]
+        sk, vk = ref.keygen_batch(seeds)
+        sig = ref.sign_batch(sk, vk, msgs)
+        agg = ref.aggregate(vk, msgs, sig)
+        want.append((seeds, msgs, sk, vk, sig, agg))
+    got, errors = [None] * W, []
+    workers = [BatchScheme(params, threads=2, private_context=True) for _ in range(W)]
+    gate = threading.Barrier(W)
+
+    def run(i):
+        try:
+            bs = workers[i]
+            seeds, msgs = want[i][0], want[i][1]
+            gate.wait()
+            for _ in range(3):                      # several rounds: the calls of different workers interleave on the device
+                sk, vk = bs.keygen_batch(seeds)
+                sig = bs.sign_batch(sk, vk, msgs)
+                agg = bs.aggregate(vk, msgs, sig)
+                ok = bs.verify(vk, msgs, agg)
+            got[i] = (sk, vk, sig, agg, ok)
+        except Exception as e:                      # surfaced in the main thread
+            errors.append((i, repr(e)))
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(W)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(W):
+        sk, vk, sig, agg, ok = got[i]
+        assert np.array_equal(sk, want[i][2]) and np.array_equal(vk, want[i][3]) and np.array_equal(sig, want[i][4])
+        assert np.array_equal(agg, want[i][5]) and ok == (True, "")
+    for bs in workers:
+        bs.close()
+    assert workers[0].ctx is None and ref.ctx is not None

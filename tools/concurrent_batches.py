@@ -9,6 +9,10 @@ import sys
 import threading
 import time
 
+# the HIP runtime maps a process's streams onto 4 hardware queues unless told otherwise: more workers than queues take turns
+# (read when the runtime starts: before the first HIP call).  Measured: 8 workers 2.6 M pairs/s with 4 queues, 3.9 M/s with 16.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fusion-cryptography_amd"))
 
@@ -25,7 +29,8 @@ def main():
     pin_to_gpu_node(0)
     secpar, n, seconds = arg("--secpar", 256, int), arg("--n", 1024, int), arg("--seconds", 1.5, float)
     params = F.fusion_setup(secpar, 2026)
-    print(f"# secpar {secpar}: {n} keys + {n} signatures per call, W worker threads with a private context and stream each, {seconds} s per line")
+    print(f"# secpar {secpar}: {n} keys + {n} signatures per call, W worker threads with a private context and stream each, {seconds} s per line; "
+          f"GPU_MAX_HW_QUEUES={os.environ['GPU_MAX_HW_QUEUES']}")
     print(f"{'W':>3} {'calls':>7} {'keygen+sign pairs/s':>22} {'ms per call (one worker)':>26}")
     for W in (1, 2, 4, 8, 16):
         workers = [BatchScheme(params, threads=2, private_context=True) for _ in range(W)]

@@ -388,3 +388,19 @@ def test_tools_and_examples_compile():
             assert os.path.exists(os.path.join(root, m.group(1))), (sh, m.group(1))
         for m in re.finditer(r"tools/microbench/build/(\w+)", text):
             assert os.path.exists(os.path.join(root, "tools", "microbench", m.group(1) + ".hip")), (sh, m.group(1))
+
+
+def test_seed_array_takes_what_the_c_samplers_take():
+    """BatchScheme.keygen_batch validates its seeds in one numpy conversion: non-negative ints below 2^64 - 1 become a uint64
+    array (lists, arrays, bools, integral floats as int() reads them); anything negative or wider returns None -- the caller
+    then uses the Python sampler, which follows random.seed()'s abs() and wide-key rules (fusion.py:339-362)"""
+    import numpy as np
+    from fusion_hip.scheme import _seed_array
+    assert _seed_array([1, 2, 3]).tolist() == [1, 2, 3] and _seed_array([1, 2, 3]).dtype == np.uint64
+    assert _seed_array([2**64 - 2, 5]).tolist() == [2**64 - 2, 5]
+    assert _seed_array(np.array([3, 4], dtype=np.uint64)).tolist() == [3, 4]
+    assert _seed_array(np.array([3, 4], dtype=np.int32)).tolist() == [3, 4]
+    assert _seed_array([]).size == 0 and _seed_array([True, 7]).tolist() == [1, 7] and _seed_array([2.0]).tolist() == [2]
+    assert _seed_array(range(4)).tolist() == [0, 1, 2, 3]
+    for bad in ([2**64 - 1, 5], [-1, 5], [-1, 2**63], [2**64, 1], np.array([-3, 4]), [2**70]):
+        assert _seed_array(bad) is None

@@ -11,6 +11,13 @@
 #include <algorithm>
 #include <vector>
 #include <dlfcn.h>
+#include <atomic>
+#include <mutex>
+
+// block pool + context registry (defined with fz_malloc / fz_free below)
+static void pool_release_locked(fz_ctx *ctx, size_t keep);
+static void fz_registry_add(fz_ctx *c);
+static void fz_registry_remove(fz_ctx *c);
 
 static thread_local char g_err[512] = "";
 
@@ -358,6 +365,7 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     if (rc == FZ_OK && !ring_only) rc = fz_ntt_query_grid(c);
     free(tw); free(itw); free(twB); free(itwB);
     if (rc != FZ_OK) { fz_ctx_destroy(c); return rc; }
+    fz_registry_add(c);
     *out = c;
     return FZ_OK;
 }
@@ -385,7 +393,13 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     if (ctx->d_aggacc) (void)hipFree(ctx->d_aggacc);
     for (int i = 0; i < ctx->n_retired; ++i) (void)hipFree(ctx->retired[i]);
     free(ctx->retired);
-    for (int i = 0; i < ctx->n_pool; ++i) (void)hipFree(ctx->pool_blocks[i].p);
+    fz_registry_remove(ctx);
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        pool_release_locked(ctx, 0);
+        for (int i = 0; i < ctx->n_live; ++i)
+            if (ctx->live_blocks[i].ev) (void)hipEventDestroy(ctx->live_blocks[i].ev);
+    }
     free(ctx->pool_blocks);
     free(ctx->live_blocks);          // (blocks the caller never freed stay the caller's)
     if (ctx->d_chal_tab) (void)hipFree(ctx->d_chal_tab);
@@ -403,9 +417,10 @@ int fz_ctx_destroy(fz_ctx *ctx) {
 int fz_ctx_set_stream(fz_ctx *ctx, void *hip_stream) {
     FZ_REQUIRE(ctx, "ctx is NULL");
     if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the stream cannot change during graph capture");
-    if (ctx->stream != (hipStream_t)hip_stream && (ctx->d_aggacc || ctx->d_vpart || ctx->d_scratch || ctx->d_scratch2)) {
-        // the accumulator words of the one-pass aggregation / fused verification and the scratch areas belong to the context,
-        // not to a stream: work still in flight on the old stream must not share them with work on the new one
+    if (ctx->stream != (hipStream_t)hip_stream) {
+        // the accumulator words of the one-pass aggregation / fused verification, the scratch areas and the blocks of the
+        // pool belong to the context, not to a stream: work still in flight on the old stream must not share them with
+        // work on the new one.  Unconditional on every change (a context with only pooled or live blocks used to skip it).
         FZ_DEV(ctx);
         FZ_HIP(hipStreamSynchronize(ctx->stream), "stream change: synchronise the old stream");
     }
@@ -501,12 +516,34 @@ int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv) {
     return FZ_OK;
 }
 
-// Blocks of kPoolMin bytes or more that come back through fz_free are kept (up to pool_cap bytes in all) and handed out again by
-// fz_malloc for requests they fit without wasting more than a quarter: hipFree of a large block takes ~180 us and synchronises
-// the whole device (measured: 1 MiB 1 us, 16 MiB - 1 GiB 178-190 us; hipMalloc 10-12 us), which is most of what a 1024-key
-// keygen_batch spent outside its kernels.  Reuse is safe in stream order: the block's previous users and its next ones are
-// queued on this context's stream (fz_ctx_set_stream drains the old stream).  Everything is released with the context.
+// Blocks of kPoolMin bytes or more that come back through fz_free are kept and handed out again by fz_malloc for requests
+// they fit without wasting more than a quarter: hipFree of a large block takes ~180 us and synchronises the whole device
+// (measured: 1 MiB 1 us, 16 MiB - 1 GiB 178-190 us; hipMalloc 10-12 us), which is most of what a 1024-key keygen_batch spent
+// outside its kernels.
+// Safety of reuse: fz_free records an event on the context's stream and the stream that takes the block out of the pool
+// waits for it, so the block's previous users (queued on the context's stream at fz_free time -- the documented requirement
+// of fz_free, include/fusion_hip.h) finish before its next ones start, whatever fz_ctx_set_stream did in between (which
+// also drains the old stream on every change).  The arrays are guarded by pool_mu.
+// Budget: ONE process-wide cap (FZ_POOL_MB, default 4096) over the pools of all contexts -- sixteen private contexts
+// (tools/concurrent_batches.py) share it instead of stranding 4 GiB each; fz_pool_trim gives a context's blocks back
+// (Context.close calls it); a failed hipMalloc flushes the pools of EVERY context on the device before it retries.
 static const size_t kPoolMin = 256 << 10;
+static std::mutex g_ctx_mu;                       // registry of live contexts (fz_ctx_create / fz_ctx_destroy)
+static fz_ctx *g_ctxs[256];
+static int g_nctx = 0;
+static std::atomic<size_t> g_pool_bytes{0};       // bytes idle in all pools of the process
+
+static void fz_registry_add(fz_ctx *c) {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    if (g_nctx < 256) g_ctxs[g_nctx++] = c;
+}
+
+static void fz_registry_remove(fz_ctx *c) {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    for (int i = 0; i < g_nctx; ++i)
+        if (g_ctxs[i] == c) { g_ctxs[i] = g_ctxs[--g_nctx]; break; }
+}
+
 static bool grow(fz_ctx::FzBlock *&arr, int &cap, int need) {
     if (need <= cap) return true;
     const int ncap = cap ? 2 * cap : 64;
@@ -517,12 +554,48 @@ static bool grow(fz_ctx::FzBlock *&arr, int &cap, int need) {
     return true;
 }
 
+// pool_mu held: hand pooled blocks back to the runtime, oldest first, until at most `keep` bytes stay
+static void pool_release_locked(fz_ctx *ctx, size_t keep) {
+    int k = 0;
+    while (k < ctx->n_pool && ctx->pool_bytes > keep) {
+        fz_ctx::FzBlock &b = ctx->pool_blocks[k++];
+        (void)hipFree(b.p);                          // synchronises the device: whatever still used the block has finished
+        if (b.ev) (void)hipEventDestroy(b.ev);
+        ctx->pool_bytes -= b.bytes;
+        g_pool_bytes -= b.bytes;
+    }
+    for (int i = k; i < ctx->n_pool; ++i) ctx->pool_blocks[i - k] = ctx->pool_blocks[i];
+    ctx->n_pool -= k;
+}
+
+// a hipMalloc failed: idle blocks of ANY context on this device may be what stands in the way
+static void pool_flush_device(int device) {
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    for (int i = 0; i < g_nctx; ++i) {
+        fz_ctx *c = g_ctxs[i];
+        if (c->device != device) continue;
+        std::lock_guard<std::mutex> gp(c->pool_mu);
+        pool_release_locked(c, 0);
+    }
+}
+
+int fz_pool_trim(fz_ctx *ctx, size_t keep_bytes) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    FZ_DEV(ctx);
+    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the pool cannot be trimmed during graph capture (hipFree synchronises)");
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    pool_release_locked(ctx, keep_bytes);
+    return FZ_OK;
+}
+
 int fz_malloc(fz_ctx *ctx, size_t bytes, void **d_out) {
     FZ_REQUIRE(ctx && d_out, "NULL argument");
     FZ_DEV(ctx);
     if (bytes == 0) bytes = 1;
     void *p = nullptr;
-    if (bytes >= kPoolMin && ctx->n_pool) {
+    hipEvent_t ev = nullptr;
+    if (bytes >= kPoolMin) {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
         int best = -1;
         for (int i = 0; i < ctx->n_pool; ++i) {
             const size_t b = ctx->pool_blocks[i].bytes;
@@ -531,24 +604,37 @@ int fz_malloc(fz_ctx *ctx, size_t bytes, void **d_out) {
         if (best >= 0) {
             p = ctx->pool_blocks[best].p;
             bytes = ctx->pool_blocks[best].bytes;
+            ev = ctx->pool_blocks[best].ev;
             ctx->pool_bytes -= bytes;
-            ctx->pool_blocks[best] = ctx->pool_blocks[--ctx->n_pool];
+            g_pool_bytes -= bytes;
+            for (int k = best + 1; k < ctx->n_pool; ++k) ctx->pool_blocks[k - 1] = ctx->pool_blocks[k];    // keeps age order
+            --ctx->n_pool;
         }
+    }
+    if (p && ev) {
+        // the next users of the block run after its previous ones (a no-op when both are on one stream)
+        hipError_t e = hipStreamWaitEvent(ctx->stream, ev, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(ev); }
     }
     if (!p) {
         hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess && ctx->n_pool) {          // out of memory with blocks in the pool: give them back and try once more
+        if (e != hipSuccess) {                        // out of memory: give every idle block on this device back and try once more
             (void)hipGetLastError();
-            for (int i = 0; i < ctx->n_pool; ++i) (void)hipFree(ctx->pool_blocks[i].p);
-            ctx->n_pool = 0;
-            ctx->pool_bytes = 0;
+            pool_flush_device(ctx->device);
             e = hipMalloc(&p, bytes);
         }
         FZ_HIP(e, "hipMalloc");
     }
     if (bytes >= kPoolMin && ctx->pool_cap) {
-        if (!grow(ctx->live_blocks, ctx->cap_live, ctx->n_live + 1)) { (void)hipFree(p); return fz_set_error(FZ_E_HIP, "out of host memory"); }
-        ctx->live_blocks[ctx->n_live++] = {p, bytes};
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        if (!grow(ctx->live_blocks, ctx->cap_live, ctx->n_live + 1)) {
+            (void)hipFree(p);
+            if (ev) (void)hipEventDestroy(ev);
+            return fz_set_error(FZ_E_HIP, "out of host memory");
+        }
+        ctx->live_blocks[ctx->n_live++] = {p, bytes, ev};
+    } else if (ev) {
+        (void)hipEventDestroy(ev);
     }
     *d_out = p;
     return FZ_OK;
@@ -558,21 +644,30 @@ int fz_free(fz_ctx *ctx, void *d_ptr) {
     FZ_REQUIRE(ctx, "ctx is NULL");
     FZ_DEV(ctx);
     if (!d_ptr) return FZ_OK;
-    for (int i = ctx->n_live - 1; i >= 0; --i) {
-        if (ctx->live_blocks[i].p != d_ptr) continue;
-        const fz_ctx::FzBlock b = ctx->live_blocks[i];
-        ctx->live_blocks[i] = ctx->live_blocks[--ctx->n_live];
-        if (ctx->capturing || b.bytes > ctx->pool_cap || !grow(ctx->pool_blocks, ctx->cap_pool, ctx->n_pool + 1)) break;
-        while (ctx->pool_bytes + b.bytes > ctx->pool_cap && ctx->n_pool) {        // make room: the oldest blocks go first
-            FZ_HIP(hipFree(ctx->pool_blocks[0].p), "hipFree");
-            ctx->pool_bytes -= ctx->pool_blocks[0].bytes;
-            for (int k = 1; k < ctx->n_pool; ++k) ctx->pool_blocks[k - 1] = ctx->pool_blocks[k];
-            --ctx->n_pool;
+    hipEvent_t stale = nullptr;
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        for (int i = ctx->n_live - 1; i >= 0; --i) {
+            if (ctx->live_blocks[i].p != d_ptr) continue;
+            fz_ctx::FzBlock b = ctx->live_blocks[i];
+            ctx->live_blocks[i] = ctx->live_blocks[--ctx->n_live];
+            stale = b.ev;
+            if (ctx->capturing || b.bytes > ctx->pool_cap || !grow(ctx->pool_blocks, ctx->cap_pool, ctx->n_pool + 1)) break;
+            // room under the process-wide cap: this context's oldest blocks go first; if other contexts hold the rest, do not pool
+            if (g_pool_bytes + b.bytes > ctx->pool_cap) {
+                const size_t over = g_pool_bytes + b.bytes - ctx->pool_cap;
+                pool_release_locked(ctx, ctx->pool_bytes > over ? ctx->pool_bytes - over : 0);
+            }
+            if (g_pool_bytes + b.bytes > ctx->pool_cap) break;
+            if (!b.ev && hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); b.ev = nullptr; break; }
+            if (hipEventRecord(b.ev, ctx->stream) != hipSuccess) { (void)hipGetLastError(); break; }
+            ctx->pool_blocks[ctx->n_pool++] = b;
+            ctx->pool_bytes += b.bytes;
+            g_pool_bytes += b.bytes;
+            return FZ_OK;
         }
-        ctx->pool_blocks[ctx->n_pool++] = b;
-        ctx->pool_bytes += b.bytes;
-        return FZ_OK;
     }
+    if (stale) (void)hipEventDestroy(stale);
     FZ_HIP(hipFree(d_ptr), "hipFree");
     return FZ_OK;
 }
@@ -1293,6 +1388,7 @@ struct RcclApi {
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
     const char *(*GetErrorString)(int);
     int (*CommCount)(void *, int *);
+    int (*GetVersion)(int *);
 };
 RcclApi g_rccl = {};
 
@@ -1312,6 +1408,7 @@ int rccl_bind() {
     a.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
     a.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
     a.CommCount = (int (*)(void *, int *))dlsym(h, "ncclCommCount");
+    a.GetVersion = (int (*)(int *))dlsym(h, "ncclGetVersion");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString)
         return fz_set_error(FZ_E_RCCL, "librccl.so.1 lacks an expected symbol");
     a.handle = h;
@@ -1368,6 +1465,14 @@ int fz_comm_info(fz_comm *comm, int *out_nranks, int *out_rank) {
     if (out_nranks) *out_nranks = n;
     if (out_rank) *out_rank = comm->rank;
     return FZ_OK;
+}
+
+int fz_rccl_version(int *out_version) {
+    FZ_REQUIRE(out_version, "out_version is NULL");
+    *out_version = 0;
+    FZ_TRY(rccl_bind());
+    if (!g_rccl.GetVersion) return fz_set_error(FZ_E_RCCL, "librccl.so.1 lacks ncclGetVersion");
+    return rccl_check(g_rccl.GetVersion(out_version), "ncclGetVersion");
 }
 
 int fz_allreduce_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, size_t count) {

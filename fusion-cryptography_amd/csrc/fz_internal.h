@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
 #include "fz_arith.h"
 
 // Wave-uniform twiddles of the strided pass, passed BY VALUE so they live in the kernarg
@@ -90,10 +91,13 @@ struct fz_ctx {
     int n_retired, cap_retired;
     // fz_malloc / fz_free keep large blocks for reuse (hipFree of anything from 16 MiB up costs ~180 us AND synchronises the
     // device): live blocks with their sizes, and the blocks handed back, at most pool_cap bytes of them (FZ_POOL_MB, 0 = off)
-    struct FzBlock { void *p; size_t bytes; };
+    // `ev`: recorded on the context's stream when the block came back (fz_free), waited for by the stream that reuses it.
+    // The arrays are guarded by pool_mu: a DeviceBuffer.__del__ may run on any thread (cyclic garbage collection).
+    struct FzBlock { void *p; size_t bytes; hipEvent_t ev; };
     FzBlock *live_blocks, *pool_blocks;
     int n_live, cap_live, n_pool, cap_pool;
     size_t pool_bytes, pool_cap;
+    std::mutex pool_mu;
     // RCCL (fz_comm_*): communicators are owned by the caller; nothing here
 };
 

@@ -773,7 +773,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
 // ------------------------------------------------------------------------------------------
 // IMAD: A[k] (.) y accumulates in 64-bit INTEGERS: A = hi * 2^16 + lo (hi = A >> 16, lo = A & 0xffff, two integer ops on the
 // int32 row as it is loaded), then acc_hi += y * hi and acc_lo += y * lo are one v_mad_i64_i32 each -- |y * hi|, |y * lo| < 2^47,
-// so 2^16 rows sum without overflow and nothing is reduced inside the loop: 4 operations per coefficient instead of 8
+// so 2^15 rows sum without overflow (fz_arith.h; the launcher falls back to the fp64 form beyond) and nothing is reduced inside the loop: 4 operations per coefficient instead of 8
 // (conversion of A, the 6-op FMA-Barrett multiply, the accumulate).  The integer form of y is the value keygen stores anyway.
 // (Measured and dropped: A pre-split into fp64 (hi, lo) pairs by the host -- two FMAs per coefficient, but 64 bytes of L2
 // traffic per lane and row instead of 16: keygen 79 -> 109 us per 1024 keys, verify 256 -> 270 us per 8192 aggregates,
@@ -1510,7 +1510,9 @@ int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, i
 #define FZ_KF4(LOGD, FAST, IM, NR, PF) do { if (single) FZ_KF5(LOGD, FAST, IM, NR, PF, double); else FZ_KF5(LOGD, FAST, IM, NR, PF, double2); } while (0)
 #define FZ_KF3(LOGD, FAST, IM, NR) do { if (deep) FZ_KF4(LOGD, FAST, IM, NR, 2); else FZ_KF4(LOGD, FAST, IM, NR, 1); } while (0)
 #define FZ_KF2(LOGD, FAST, IM) do { if (two) FZ_KF3(LOGD, FAST, IM, 2); else FZ_KF3(LOGD, FAST, IM, 1); } while (0)
-#define FZ_KF(LOGD, FAST) do { if (!ctx->knob_no_imad) FZ_KF2(LOGD, FAST, true); else FZ_KF2(LOGD, FAST, false); } while (0)
+    // integer accumulation is exact for at most 2^15 products per lane (fz_arith.h): longer sums take the fp64 form
+    const bool imad_k = !ctx->knob_no_imad && l <= (1 << 15);
+#define FZ_KF(LOGD, FAST) do { if (imad_k) FZ_KF2(LOGD, FAST, true); else FZ_KF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_KF(8, true); else FZ_KF(8, false); }
     else if (ctx->logd == 6) { if (ctx->mod.fast) FZ_KF(6, true); else FZ_KF(6, false); }
     else return fz_set_error(FZ_E_UNSUPPORTED, "fused keygen: degree 64 or 256 only");
@@ -1581,7 +1583,8 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
 #define FZ_VF3(LOGD, FAST, ORD, IM) do { if (two) FZ_VF4(LOGD, FAST, ORD, IM, 2); else FZ_VF4(LOGD, FAST, ORD, IM, 1); } while (0)
     // integer accumulation of A * sigma pays its once-per-wave conversion back only over several rows per wave (measured: 1.18 M
     // vector instructions against 1.10 M per launch when the l rows are spread one per wave over 21 workgroups)
-    const bool imad = !ctx->knob_no_imad && (tasks + R * kVerifyWaves - 1) / (R * kVerifyWaves) >= 4;
+    // ... and it is exact for at most 2^15 products per lane (fz_arith.h): a longer sum takes the fp64 form
+    const bool imad = !ctx->knob_no_imad && l <= (1 << 15) && (tasks + R * kVerifyWaves - 1) / (R * kVerifyWaves) >= 4;
 #define FZ_VF2(LOGD, FAST, ORD) do { if (imad) FZ_VF3(LOGD, FAST, ORD, true); else FZ_VF3(LOGD, FAST, ORD, false); } while (0)
 #define FZ_VF(LOGD, FAST) do { if (ctx->knob_verify_ordered) FZ_VF2(LOGD, FAST, true); else FZ_VF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_VF(8, true); else FZ_VF(8, false); }

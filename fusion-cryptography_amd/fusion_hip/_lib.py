@@ -56,6 +56,7 @@ SIGNATURES = {
     "fz_graph_destroy": (c_int, [c_void_p]),
     "fz_malloc": (c_int, [_ctx, c_size_t, POINTER(c_void_p)]),
     "fz_free": (c_int, [_ctx, c_void_p]),
+    "fz_pool_trim": (c_int, [_ctx, c_size_t]),
     "fz_memcpy_h2d": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
     "fz_memcpy_d2h": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
     "fz_timer_start": (c_int, [_ctx]),
@@ -158,6 +159,7 @@ SIGNATURES.update({
     "fz_comm_create": (c_int, [_ctx, c_int, c_int, POINTER(UniqueId), POINTER(c_void_p)]),
     "fz_comm_destroy": (c_int, [c_void_p]),
     "fz_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "fz_rccl_version": (c_int, [POINTER(c_int)]),
     "fz_allreduce_i64": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
     "fz_diag_empty_launch": (c_int, [_ctx]),
     "fz_diag_copy": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
@@ -176,10 +178,10 @@ def _prefer_torch_hip_runtime():
     finds no GPU (`import fusion_hip; ...; import torch; torch.cuda...` -> "No HIP GPUs are available").  If torch is
     installed but not imported yet, map ITS copies first: libfusion_hip.so then binds to them by soname and a later
     `import torch` finds its runtime already alive.
-    The wheel's runtime is only accepted when its HIP MAJOR version equals the one the library was built with
-    (lib/build_info.json, written by the build): it is opened privately first, asked for hipRuntimeGetVersion, and promoted
-    to the global namespace only then; on a mismatch (or FZ_HIP_RUNTIME=system) the system runtime serves the library and
-    torch users must import torch first.  fusion_hip.runtime_report() says what happened."""
+    The wheel's runtime is only accepted when its HIP MAJOR version (read from torch/version.py, nothing is mapped for the
+    question) equals the one the library was built with (lib/build_info.json, written by the build); on a mismatch (or
+    FZ_HIP_RUNTIME=system) NOTHING of the wheel is mapped, the system runtime serves the library and torch users must import
+    torch first.  fusion_hip.runtime_report() says what happened."""
     if os.environ.get("FZ_HIP_RUNTIME", "") == "system":
         RUNTIME_CHOICE.update(runtime="system (/opt/rocm)", why="FZ_HIP_RUNTIME=system")
         return
@@ -202,20 +204,27 @@ def _prefer_torch_hip_runtime():
         if os.path.exists(info):
             with open(info) as fh:
                 want = json.load(fh).get("hip_major")
+        # the wheel's HIP version WITHOUT mapping anything of it: torch/version.py carries `hip = '7.0.51831-...'` (a dlopen
+        # probe would leave the wheel's libhsa-runtime64 / libamdhip64 in the process even when they are then rejected, and
+        # the system libamdhip64 would bind to the wheel's HSA by soname: a mixed stack -- ADVICE r03)
+        got = None
+        try:
+            import re
+            with open(os.path.join(os.path.dirname(spec.origin), "version.py")) as fh:
+                m = re.search(r"^hip\s*(?::[^=]*)?=\s*['\"](\d+)\.", fh.read(), re.M)
+            got = int(m.group(1)) if m else None
+        except OSError:
+            pass
+        if want is None or got is None or want != got:
+            why = (f"torch's HIP runtime is major version {got}, the library was built with {want}: not used" if None not in (want, got)
+                   else f"cannot compare HIP versions (torch: {got}, build: {want}): torch's runtime not used")
+            RUNTIME_CHOICE.update(runtime="system (/opt/rocm)", why=why + "; nothing of the wheel was mapped")
+            import warnings
+            warnings.warn(f"fusion_hip: {why}; keeping the system runtime -- import torch BEFORE fusion_hip in processes that use both",
+                          RuntimeWarning)
+            return
         if os.path.exists(hsa):
             ctypes.CDLL(hsa, mode=ctypes.RTLD_GLOBAL)
-        probe = ctypes.CDLL(hip)                                    # private first: ask before it serves anybody
-        v = ctypes.c_int(0)
-        got = None
-        if probe.hipRuntimeGetVersion(ctypes.byref(v)) == 0:
-            got = v.value // 10_000_000
-        if want is not None and got is not None and want != got:
-            RUNTIME_CHOICE.update(runtime="system (/opt/rocm)",
-                                  why=f"torch's HIP runtime is major version {got}, the library was built with {want}: not used")
-            import warnings
-            warnings.warn(f"fusion_hip: torch ships HIP {got}.x but libfusion_hip.so was built with HIP {want}.x; keeping the system "
-                          "runtime -- import torch BEFORE fusion_hip in processes that use both", RuntimeWarning)
-            return
         ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)                   # promote: libfusion_hip.so binds to it by soname
         RUNTIME_CHOICE.update(runtime=hip, why=f"torch is installed (HIP major {got}, built with {want}): its runtime is mapped first "
                                                "so that a later `import torch` shares it")

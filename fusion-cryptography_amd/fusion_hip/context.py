@@ -109,6 +109,10 @@ class Context:
     def free(self, ptr):
         check(self._lib, self._lib.fz_free(self._h, c_void_p(ptr)))
 
+    def pool_trim(self, keep_bytes=0):
+        """hand the idle blocks fz_free kept for reuse back to the runtime (down to keep_bytes)"""
+        check(self._lib, self._lib.fz_pool_trim(self._h, keep_bytes))
+
     def h2d(self, dptr, arr):
         arr = np.ascontiguousarray(arr)
         check(self._lib, self._lib.fz_memcpy_h2d(self._h, c_void_p(dptr), c_void_p(arr.ctypes.data), arr.nbytes))
@@ -477,6 +481,14 @@ def comm_unique_id():
     uid = UniqueId()
     check(lib, lib.fz_comm_unique_id(byref(uid)))
     return ctypes.string_at(ctypes.addressof(uid), 128)
+
+
+def rccl_version():
+    """-> the version code of the RCCL the library bound (ncclGetVersion), e.g. 22703"""
+    lib = load_library()
+    v = c_int()
+    check(lib, lib.fz_rccl_version(byref(v)))
+    return v.value
 
 
 class Comm:

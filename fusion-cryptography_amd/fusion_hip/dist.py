@@ -61,7 +61,12 @@ class TorchCollective:
 
     def alloc_i64(self, count):
         import torch
-        return torch.zeros(count, dtype=torch.int64, device=self.device)
+        buf = torch.zeros(count, dtype=torch.int64, device=self.device)
+        # the fill runs on torch's current stream, the kernels that add into the buffer on the context's -- which need not be
+        # the same stream, and a hipStreamNonBlocking one (BatchScheme(private_context=True)) is not even ordered against the
+        # legacy default stream: the zeros must have landed before the pointer is handed to the library
+        torch.cuda.current_stream(self.device).synchronize()
+        return buf
 
     @staticmethod
     def ptr(buf):

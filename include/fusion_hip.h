@@ -100,13 +100,20 @@ FZ_API int fz_graph_launch(fz_ctx *ctx, fz_graph *graph);      /* asynchronous o
 FZ_API int fz_graph_destroy(fz_graph *graph);
 
 /* ---- device memory helpers (so a host language needs no HIP binding of its own) --------
- * fz_free keeps blocks of 256 KiB or more for reuse by later fz_malloc calls of this context (at most FZ_POOL_MB megabytes of
- * them, default 4096; 0 = every fz_free is a hipFree, which for a large block takes ~180 us and synchronises the device).
- * A reused block may still be read or written by work queued EARLIER on the context's stream: whatever uses it next through
- * this context is queued after that work, so stream order keeps the two apart; do not hand a freed block's address to another
- * stream or context.  fz_ctx_destroy releases the pool. */
+ * fz_free keeps blocks of 256 KiB or more for reuse by later fz_malloc calls of this context; ONE budget of FZ_POOL_MB
+ * megabytes (default 4096; 0 = every fz_free is a hipFree, which for a large block takes ~180 us and synchronises the
+ * device) covers the idle blocks of ALL contexts of the process.
+ * STREAM-ORDER REQUIREMENT OF fz_free: the last work that uses the block must already be queued on the context's stream
+ * (or have completed) when fz_free is called -- exactly what holds for memory handed to this context's entry points.
+ * fz_free records an event on that stream and whichever stream takes the block out of the pool waits for it, so a reused
+ * block's previous users finish before its next ones start even across fz_ctx_set_stream (which also drains the old stream
+ * on every change).  A block still in use by ANOTHER stream or context (torch, a second fz_ctx) must be synchronised by the
+ * caller before fz_free: unlike hipFree, a pooled free does not synchronise the device.  fz_malloc / fz_free may be called
+ * from any thread (the pool is locked); fz_ctx_destroy releases the pool, fz_pool_trim releases it down to keep_bytes,
+ * and a failed allocation flushes the idle blocks of every context on the device before it is retried. */
 FZ_API int fz_malloc(fz_ctx *ctx, size_t bytes, void **d_out);
 FZ_API int fz_free(fz_ctx *ctx, void *d_ptr);
+FZ_API int fz_pool_trim(fz_ctx *ctx, size_t keep_bytes);
 FZ_API int fz_memcpy_h2d(fz_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* async on ctx stream */
 FZ_API int fz_memcpy_d2h(fz_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* returns after completion */
 
@@ -294,6 +301,9 @@ FZ_API int fz_comm_create(fz_ctx *ctx, int nranks, int rank, const fz_unique_id 
 FZ_API int fz_comm_destroy(fz_comm *comm);
 /* what the communicator itself reports (ncclCommCount) and this rank's index */
 FZ_API int fz_comm_info(fz_comm *comm, int *out_nranks, int *out_rank);
+/* the version code of the RCCL this process bound (ncclGetVersion, e.g. 22703): bench.py prints it per rank so that a
+ * multi-GPU record shows which library carried the exchange step */
+FZ_API int fz_rccl_version(int *out_version);
 FZ_API int fz_allreduce_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, size_t count);
 
 /* ---- launch-floor diagnostics (benchmarks) ---------------------------------------------------------------------

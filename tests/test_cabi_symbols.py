@@ -100,6 +100,12 @@ def test_bench_touches_the_oracle_in_its_cpu_baseline_leg_only():
             found += 1
             assert id(n) in inside, f"bench.py imports the oracle outside _cpu_worker (line {n.lineno})"
     assert found >= 1
+    # the side legs (tools/bench_legs.py: sign_verify and the --full legs) never touch it at all
+    legs = open(os.path.join(ROOT, "tools", "bench_legs.py")).read()
+    for n in ast.walk(ast.parse(legs)):
+        names = [n.module or ""] if isinstance(n, ast.ImportFrom) else [a.name for a in n.names] if isinstance(n, ast.Import) else []
+        assert not any(x == "oracle" or x.startswith("oracle.") for x in names), f"tools/bench_legs.py imports the oracle (line {n.lineno})"
+    assert "oracle" not in legs.replace("(tests/test_cabi_symbols.py checks bench.py AND this file)", "").replace("Nothing here touches oracle/", "")
 
 
 def build_c_example(tmp_path, name="roundtrip"):

@@ -105,8 +105,24 @@ def test_polynomial_classes_arithmetic():
             assert a.coefficients == fa and b.coefficients == fb            # operands untouched
             big = PC(**p, coefficients=[x + q * rng.randrange(2**40) for x in fa])
             assert big + b == a + b and big * b == prod and big.weight() == a.weight()
-            with pytest.raises(OverflowError):
-                big.norm("infty")
+            # stored values outside int32: the reference's max(abs(x)) over the STORED list (polynomials.py:221-224), also
+            # through GeneralMatrix.norm (matrices.py:144-148)
+            assert big.norm("infty") == max(abs(x) for x in big.coefficients) > 2**31
+            from algebra.matrices import GeneralMatrix
+            assert GeneralMatrix(matrix=[[a, big], [b, a]]).norm("infty") == big.norm("infty")
+
+
+def test_sampler_bounds_at_q65537_d1024_like_the_reference():
+    """the reference's tests/test_polynomials.py:883-910, verbatim in its assertions: a degree-1024 polynomial over q = 65537
+    (a ring the scheme's prime cannot carry: norm / weight run on a ring-only context), norm and weight through the object API"""
+    from algebra.polynomials import PolynomialCoefficientRepresentation as Poly, sample_polynomial_coefficient_representation
+    p = ring(1024, 65537)
+    f = sample_polynomial_coefficient_representation(**p, norm_bound=1000, weight_bound=100, seed=123456789)
+    assert isinstance(f, Poly)
+    assert (f.modulus, f.degree, f.root, f.inv_root, f.root_order) == (65537, 1024, p["root"], p["inv_root"], 2048)
+    assert len(f.coefficients) == 1024
+    assert f.norm(p="infty") <= 1000 and f.norm(p="infty") == max(abs(x) for x in f.coefficients)
+    assert f.weight() <= 100 and f.weight() == sum(1 for x in f.coefficients if x % 65537)
 
 
 def test_matrix_products():

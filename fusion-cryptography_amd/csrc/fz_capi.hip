@@ -334,6 +334,7 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         c->knob_agg_waves = knob("FZ_AGG_WAVES");
         if (c->knob_agg_waves != 4 && c->knob_agg_waves != 8) c->knob_agg_waves = 0;
         c->knob_agg_slices = knob("FZ_AGG_SLICES");
+        c->knob_agg_direct = knob("FZ_AGG_DIRECT");
         // flat grids (one 16-byte item per thread) for the elementwise streaming kernels: 45.0 us instead of 49.7 per 1024
         // signatures (cold) for sign_core, the same for the pointwise kernels, against a grid capped at 8 workgroups per CU
         c->knob_stream_per_cu = getenv("FZ_STREAM_PER_CU") ? knob("FZ_STREAM_PER_CU") : 0;

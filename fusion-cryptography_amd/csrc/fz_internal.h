@@ -71,6 +71,7 @@ struct fz_ctx {
     int chal_tab_ib, chal_tab_degree;
     // benchmarking knobs, read ONCE at context creation
     int knob_agg_twopass, knob_agg_waves, knob_agg_slices;
+    int knob_agg_direct;         // FZ_AGG_DIRECT: -1 = never the slice-free aggregation kernel, 2 | 4 = always, with that many rows per tile (0 = by size)
     int knob_shake_full;         // FZ_SHAKE_FORM: 1 = lane pairs, 2 = whole state per lane (0 = by batch size)
     int knob_stream_nt;          // FZ_STREAM_NT: streaming (non-temporal) stores in the elementwise kernels
     int knob_stream_per_cu;      // grid cap of the grid-stride streaming kernels in workgroups per CU (0 = flat grid)

@@ -497,6 +497,189 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Aggregation WITHOUT signer slices, for aggregates of a few hundred signers (round 4).  aggregate_onepass fills the chip
+// by cutting the SIGNERS of an aggregate into slices, and pays for it at the end: every workgroup adds its tile into shared
+// accumulator words (one returning atomic round trip to the memory side) and the last adder writes the output -- about
+// 2 of the ~6 us a launch costs whatever N is (N = 256: 9.1 us = 30 % of the HBM roofline).  Here the chip is filled by
+// cutting the COEFFICIENTS finer instead: a workgroup owns 16 int4 columns (256 contiguous bytes of a row) of R rows of the
+// aggregate for ALL signers, so nothing is shared between workgroups, the result is written directly, and the only
+// synchronisation is one workgroup barrier.  A wave's 64 lanes are 16 columns x 4 signers; its WAVES waves take the signers
+// round-robin, DEPTH signers (R + 1 loads of 16 bytes each) in flight per lane; the 4 * WAVES partial sums of a coefficient meet
+// first inside the wave (v_permlane32_swap / v_permlane16_swap: lanes 0..15 collect the other three quarters, no LDS) and
+// then in 64 R doubles of LDS per wave.  R rows of a tile share ONE alpha load per signer (R = 4: 84 tiles per aggregate at
+// rank 83, R = 2: 168; one row per tile and whole-row tiles were measured and dropped: every CU of an XCD then asks the L2 for
+// the same alpha lines at the same time -- 256 x 4 signers 30 us against 20.7 -- profiles/r04_aggregate_direct_ab.txt).
+// Same arithmetic as aggregate_onepass (alpha = hi * 2^16 + lo, exact fp64 sums folded every kAggFold signers), same outputs
+// (int64 partial sums or centred int32; the verification target as extra tiles), uniform and ragged groups.
+// ---------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double dir_from_upper(double x) {        // lanes 0..31: the value lanes 32..63 hold
+    unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x), lo2 = lo, hi2 = hi;
+    auto r = __builtin_amdgcn_permlane32_swap(lo, lo2, false, false);
+    lo2 = r[1];
+    r = __builtin_amdgcn_permlane32_swap(hi, hi2, false, false);
+    hi2 = r[1];
+    return __hiloint2double((int)hi2, (int)lo2);
+}
+__device__ __forceinline__ double dir_from_odd_row(double x) {      // lanes of even 16-lane rows: the value the next row holds
+    unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x), lo2 = lo, hi2 = hi;
+    auto r = __builtin_amdgcn_permlane16_swap(lo, lo2, false, false);
+    lo2 = r[1];
+    r = __builtin_amdgcn_permlane16_swap(hi, hi2, false, false);
+    hi2 = r[1];
+    return __hiloint2double((int)hi2, (int)lo2);
+}
+
+// CW: int4 columns per tile (16: a quarter row of degree 256, four signers side by side in a wave; 64: a whole row, one signer)
+template <int CW, int R, int DEPTH, int WAVES, typename RAG>
+__global__ __launch_bounds__(64 * WAVES) void aggregate_direct(const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
+                                                               const int32_t *vkR, const int32_t *c, size_t N, int l, int d4,
+                                                               int ntile_a, int64_t *out64, size_t pstride, int64_t *tout64,
+                                                               size_t tstride, int32_t *out32, FzMod m, RAG rag) {
+    constexpr bool RAGGED = !__is_same(RAG, FzNoRag);
+    constexpr int kDirCW = CW, kDirSub = 64 / CW;
+    constexpr int STEP = kDirSub * WAVES;                          // signers the workgroup takes per round
+    __shared__ __attribute__((aligned(16))) double red[WAVES * CW * 4 * R];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int colw = lane & (kDirCW - 1), sub = lane / kDirCW;
+    const size_t g = blockIdx.y;
+    const int t = blockIdx.x;
+    size_t first_row = g * N, n = N;
+    if constexpr (RAGGED) {
+        first_row = rag.off[g];
+        n = rag.off[g + 1] - rag.off[g];
+    }
+    const bool tgt = t >= ntile_a;
+    const int ncg = d4 / kDirCW;                                   // column groups per row (4 at degree 256, 1 at degree 64)
+    const int tt = tgt ? t - ntile_a : t;
+    const int cg = tt % ncg, rg = tt / ncg;
+    const int j4 = cg * kDirCW + colw;
+    const size_t cols_a = (size_t)l * d4;
+    const int4 *alpha4 = reinterpret_cast<const int4 *>(alpha) + first_row * (size_t)d4 + j4;
+    double lo[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lo[r][k] = 0.0;
+    const size_t i_first = (size_t)wave * kDirSub + sub;
+
+    if (!tgt) {
+        double hi[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hi[r][k] = 0.0;
+        size_t rowoff[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = rg * R + r;
+            rowoff[r] = (size_t)(k < l ? k : l - 1) * d4 + j4;       // clamped rows compute garbage that is never written
+        }
+        const int4 *sig4 = reinterpret_cast<const int4 *>(sig) + first_row * cols_a;
+        int4 a_q[DEPTH], x_q[DEPTH][R];
+        auto load = [&](int s, size_t i) {
+            a_q[s] = alpha4[i * d4];
+#pragma unroll
+            for (int r = 0; r < R; ++r) x_q[s][r] = sig4[i * cols_a + rowoff[r]];
+        };
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s)
+            if (i_first + (size_t)s * STEP < n) load(s, i_first + (size_t)s * STEP);
+        int since = 0;
+        for (size_t i = i_first; i < n; i += (size_t)DEPTH * STEP) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                const size_t is = i + (size_t)s * STEP;
+                if (is < n) {
+                    const int av[4] = {a_q[s].x, a_q[s].y, a_q[s].z, a_q[s].w};
+                    double ah[4], al[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        ah[k] = (double)(av[k] >> 16);
+                        al[k] = (double)(av[k] & 0xffff);
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double xv[4] = {(double)x_q[s][r].x, (double)x_q[s][r].y, (double)x_q[s][r].z, (double)x_q[s][r].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            hi[r][k] = __builtin_fma(xv[k], ah[k], hi[r][k]);
+                            lo[r][k] = __builtin_fma(xv[k], al[k], lo[r][k]);
+                        }
+                    }
+                    const size_t in = is + (size_t)DEPTH * STEP;
+                    if (in < n) load(s, in);
+                }
+            }
+            since += DEPTH;
+            if (since + DEPTH > kAggFold) {                        // lanes of a wave differ by at most one signer: fold together
+                since = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lo[r][k] = fz_fold(lo[r][k], m) + fz_fold(hi[r][k] * 65536.0, m);
+                        hi[r][k] = 0.0;
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lo[r][k] = fz_fold(lo[r][k], m) + fz_fold(hi[r][k] * 65536.0, m);
+    } else {
+        // verification target sum_i (vkL_i * c_i + vkR_i) * alpha_i (fusion.py:706-714): 16 columns of the one target row
+        const int4 *L4 = reinterpret_cast<const int4 *>(vkL) + first_row * (size_t)d4 + j4;
+        const int4 *R4 = reinterpret_cast<const int4 *>(vkR) + first_row * (size_t)d4 + j4;
+        const int4 *C4 = reinterpret_cast<const int4 *>(c) + first_row * (size_t)d4 + j4;
+#pragma unroll 2
+        for (size_t i = i_first; i < n; i += STEP) {
+            const size_t o = i * d4;
+            const int4 L = L4[o], Rv = R4[o], ch = C4[o], a = alpha4[o];
+            lo[0][0] += fz_mulmod(fz_mulmod((double)L.x, (double)ch.x, m) + (double)Rv.x, (double)a.x, m);   // |inner| < 2^32
+            lo[0][1] += fz_mulmod(fz_mulmod((double)L.y, (double)ch.y, m) + (double)Rv.y, (double)a.y, m);
+            lo[0][2] += fz_mulmod(fz_mulmod((double)L.z, (double)ch.z, m) + (double)Rv.z, (double)a.z, m);
+            lo[0][3] += fz_mulmod(fz_mulmod((double)L.w, (double)ch.w, m) + (double)Rv.w, (double)a.w, m);
+        }
+    }
+    // the four signer quarters of the wave meet in lanes 0..15, then the waves in LDS: red[wave][r][column][k]
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double v = lo[r][k];
+            if constexpr (CW == 16) {
+                v += dir_from_upper(v);
+                v += dir_from_odd_row(v);
+            }
+            lo[r][k] = v;
+        }
+    if (lane < kDirCW) {
+        double *mine = red + (wave * R) * (CW * 4) + lane * 4;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            *reinterpret_cast<double2 *>(mine + r * (CW * 4)) = make_double2(lo[r][0], lo[r][1]);
+            *reinterpret_cast<double2 *>(mine + r * (CW * 4) + 2) = make_double2(lo[r][2], lo[r][3]);
+        }
+    }
+    __syncthreads();
+    const int rows_here = tgt ? 1 : R;
+    for (int e = threadIdx.x; e < rows_here * (CW * 4); e += 64 * WAVES) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s += red[w * R * (CW * 4) + e];
+        const int r = e / (CW * 4), k = tgt ? 0 : rg * R + r;
+        if (k >= l) continue;
+        const size_t coef = (size_t)k * d4 * 4 + (size_t)cg * (kDirCW * 4) + (e % (CW * 4));
+        const long long v = (long long)s;
+        if (tgt) tout64[g * tstride + coef] = v;
+        else if (out64) out64[g * pstride + coef] = v;
+        else out32[g * cols_a * 4 + coef] = (int)fz_cent_i64(v, m);
+    }
+}
+
 // any degree, any N: one thread per coefficient of the aggregate (and of the target), all signers in sequence.
 // Only for parameter sets the one-pass kernel does not cover (degree not a power of two <= 256).
 __global__ __launch_bounds__(kBlock) void aggregate_generic_kernel(const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
@@ -793,6 +976,20 @@ static void launch_onepass(fz_ctx *ctx, unsigned grid, const int32_t *sig, const
                            l, d4, ncb_a, ncb, nsl, pairs, dv, acc, out64, pstride, tout64, tstride, out32, ctx->mod, FzNoRag());
 }
 
+
+template <int CW, int R, int DEPTH>
+static void launch_direct(fz_ctx *ctx, dim3 grid, const int32_t *sig, const int32_t *alpha, const int32_t *vkL, const int32_t *vkR,
+                          const int32_t *c, size_t N, int l, int d4, int ntile_a, int64_t *out64, size_t pstride, int64_t *tout64,
+                          size_t tstride, int32_t *out32, const FzRagged *rag) {
+    constexpr int WAVES = 8;
+    if (rag)
+        hipLaunchKernelGGL((aggregate_direct<CW, R, DEPTH, WAVES, FzRagged>), grid, dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N, l,
+                           d4, ntile_a, out64, pstride, tout64, tstride, out32, ctx->mod, *rag);
+    else
+        hipLaunchKernelGGL((aggregate_direct<CW, R, DEPTH, WAVES, FzNoRag>), grid, dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N, l,
+                           d4, ntile_a, out64, pstride, tout64, tstride, out32, ctx->mod, FzNoRag());
+}
+
 // out64 != nullptr: int64 partial sums at out64 + g*pstride; else centred int32 at out32 + g*l*degree.
 // vkL != nullptr: the verification target's int64 partial sums go to tout64 + g*tstride in the same launch.
 // h_offsets != nullptr (ragged): aggregate g's signers are rows [h_offsets[g], h_offsets[g+1]) of the arrays, groups <=
@@ -809,6 +1006,30 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
     if (vec && (d & (d - 1)) == 0 && d <= 256 && (!ctx->knob_agg_twopass || h_offsets)) {
         const int d4 = d / 4;
         const size_t cols_a = (size_t)l * d4;
+        // Few signers in the whole launch: no signer slices, no shared accumulators (aggregate_direct).  Measured on cold
+        // operands (profiles/r04_aggregate_direct_ab.txt): one aggregate of 8 / 32 / 96 / 192 signers 3.5 / 4.0 / 5.1 / 7.5 us
+        // against 4.5 / 7.0 / 7.4 / 8.1 us for the sliced kernel, two of 64 / 128: 6.1 / 8.5 against 8.4 / 9.1; from ~256
+        // signers per launch, with three or more aggregates, or with the verification target in the same launch the sliced
+        // kernel leads (256 x 4 + targets: 20.7 us against 24.6).  FZ_AGG_DIRECT = -1: never; 2 | 4: always, with that many
+        // rows per tile (the tests force both forms through every output mode).
+        const bool direct_auto = !vkL && N <= 256 && groups * N <= 256;
+        if (d4 >= 16 && ctx->knob_agg_direct >= 0 && (ctx->knob_agg_direct > 0 || direct_auto) && groups <= 65535) {
+            int R = ctx->knob_agg_direct;
+            if (R != 2 && R != 4) R = groups == 1 ? 2 : 4;          // rows of a tile share one alpha load; 168 / 84 tiles per aggregate at rank 83
+            const int ncg = d4 / 16;
+            const int ntile_a = sig ? ((l + R - 1) / R) * ncg : 0;
+            const int ntile = ntile_a + (vkL ? ncg : 0);
+            FzRagged rag;
+            if (h_offsets) {
+                for (size_t g = 0; g <= groups; ++g) rag.off[g] = (unsigned)h_offsets[g];
+                for (size_t g = 0; g < groups; ++g) rag.base[g] = rag.extra[g] = 0;
+            }
+            const FzRagged *rp = h_offsets ? &rag : nullptr;
+            const dim3 grid((unsigned)ntile, (unsigned)groups);
+            if (R == 4) launch_direct<16, 4, 3>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ntile_a, out64, pstride, tout64, tstride, out32, rp);
+            else launch_direct<16, 2, 5>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ntile_a, out64, pstride, tout64, tstride, out32, rp);
+            return fz_check_hip(hipGetLastError(), "aggregate (direct) launch");
+        }
         const int ncb_a = sig ? (int)((cols_a + 64 * kAggR - 1) / (64 * kAggR)) : 0;
         const int ncb = ncb_a + (vkL ? 1 : 0);                       // d4 <= 64: the target fits one column block
         // slices of the signers per aggregate: as many tiles (column block x aggregate x slice) as the chip holds at once --

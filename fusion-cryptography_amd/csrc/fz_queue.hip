@@ -1,0 +1,442 @@
+// fz_queue.hip -- asynchronous batch queue below the host language (C ABI section "asynchronous batch queue").
+//
+// The reference is called once per key and once per signature (fusion/fusion.py:338-373 keygen, :534-557 sign); a caller of
+// this library batches them, but at BASELINE's size -- 1024 keys + 1024 signatures per call -- one call is a latency chain
+// (MT19937 seeding, ~108 Keccak permutations per signer on a few dozen waves) that leaves most of the chip idle: 0.93 M
+// pairs/s from one host thread, and only 3.8-4.3 M/s with 8-16 Python threads, each with a context of its own, and
+// GPU_MAX_HW_QUEUES=16 (profiles/r03_concurrent_batches.txt).  The queue closes that gap below Python:
+//
+//   * submit() copies a call's inputs (seeds, message bytes), hands back a ticket and returns -- microseconds;
+//   * W worker threads, each owning a context, a HIP stream and its scratch, take EVERYTHING that is pending (up to
+//     max_rows keys) as ONE batch: every row of the path is independent, so n calls of 1024 rows are one launch sequence
+//     of n * 1024 rows -- the 16 384-row rate (6.8 M sign/s) instead of sixteen latency chains; results are cut back
+//     into the calls' rows, bit-identical to separate calls (tests/test_gpu_queue.py);
+//   * while one worker's batch sits in a latency-bound kernel another worker's batch runs beside it (W streams:
+//     W <= 4 needs no more than the HIP runtime's default hardware queues);
+//   * verification keys go back to the callers' (pinned: fz_pinned_alloc) buffers with asynchronous copies; secret keys
+//     and signatures stay in device memory, owned by the batch and released when every call of it has been released.
+//
+// One context still serves one host thread: a worker's context is touched by that worker alone (buffers of released
+// batches are handed back to the worker to free).
+#include "fz_internal.h"
+#include "../../include/fusion_hip.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace {
+
+struct Batch {                         // device results of one coalesced batch, shared by its calls
+    int worker;
+    int32_t *d_sk, *d_vk, *d_sig;      // fz_malloc blocks of the worker's context (nullptr: worker scratch, not kept)
+    std::atomic<int> refs;
+};
+
+struct Job {
+    uint64_t ticket;
+    size_t n;
+    int flags;
+    std::vector<uint64_t> seeds;
+    std::string msgs;
+    std::vector<size_t> off;           // n + 1 offsets into msgs
+    int32_t *h_vk_out;                 // [n][2][degree] or nullptr
+};
+
+struct Done {
+    int status;
+    std::string error;
+    Batch *batch;
+    size_t row0, n;
+};
+
+struct Worker {
+    std::thread th;
+    fz_ctx *ctx = nullptr;
+    void *stream = nullptr;
+    int32_t *d_A = nullptr;
+    // scratch that never leaves the worker: secret polynomials, challenges, and -- for batches nobody keeps -- keys and signatures
+    int32_t *d_coef = nullptr, *d_c = nullptr, *d_sk = nullptr, *d_vk = nullptr, *d_sig = nullptr;
+    size_t cap_coef = 0, cap_c = 0, cap_sk = 0, cap_vk = 0, cap_sig = 0;      // in rows
+    std::vector<Batch *> garbage;      // released batches, freed by the worker itself (guarded by the queue's mutex)
+};
+
+}  // namespace
+
+struct fz_queue {
+    int device, l, degree;
+    fz_scheme_params P;
+    int64_t beta_sk, omega_sk;
+    size_t max_rows;
+    std::vector<int32_t> A;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Job> pending;
+    std::unordered_map<uint64_t, Done> done;        // finished calls whose results (or error) somebody may still ask for
+    std::unordered_set<uint64_t> live;              // submitted, not finished
+    int first_error = FZ_OK;                        // of a FZ_QUEUE_DISCARD call since the last drain
+    std::string first_error_text;
+    uint64_t next_ticket = 1;
+    size_t inflight = 0;               // submitted and not yet completed
+    bool stopping = false;
+    int init_rc = FZ_OK;
+    std::string init_err;
+    std::vector<Worker> workers;
+    uint64_t st_jobs = 0, st_batches = 0, st_rows = 0;
+};
+
+namespace {
+
+const char *last_error() { return fz_last_error(); }
+
+int grow(fz_ctx *ctx, int32_t **p, size_t *cap_rows, size_t rows, size_t row_bytes) {
+    if (rows <= *cap_rows) return FZ_OK;
+    if (*p) { int rc = fz_free(ctx, *p); *p = nullptr; *cap_rows = 0; if (rc != FZ_OK) return rc; }
+    void *q = nullptr;
+    int rc = fz_malloc(ctx, rows * row_bytes, &q);
+    if (rc != FZ_OK) return rc;
+    *p = (int32_t *)q;
+    *cap_rows = rows;
+    return FZ_OK;
+}
+
+void free_batch(fz_queue *Q, Worker &w, Batch *b) {
+    (void)Q;
+    if (b->d_sk) (void)fz_free(w.ctx, b->d_sk);
+    if (b->d_vk) (void)fz_free(w.ctx, b->d_vk);
+    if (b->d_sig) (void)fz_free(w.ctx, b->d_sig);
+    delete b;
+}
+
+// one coalesced batch: jobs[0..] rows back to back
+int run_batch(fz_queue *Q, Worker &w, std::vector<Job> &jobs, Batch **out_batch, std::vector<size_t> &row0) {
+    const int d = Q->degree, l = Q->l;
+    size_t N = 0, msg_bytes = 0;
+    bool keep = false, keep_sk = false;
+    for (auto &j : jobs) {
+        row0.push_back(N);
+        N += j.n;
+        msg_bytes += j.msgs.size();
+        if (!(j.flags & FZ_QUEUE_DISCARD)) keep = true;
+        if ((j.flags & FZ_QUEUE_KEEP_SK) && !(j.flags & FZ_QUEUE_DISCARD)) keep_sk = true;
+    }
+    std::vector<uint64_t> seeds;
+    seeds.reserve(N);
+    std::string msgs;
+    msgs.reserve(msg_bytes);
+    std::vector<size_t> off;
+    off.reserve(N + 1);
+    off.push_back(0);
+    for (auto &j : jobs) {
+        seeds.insert(seeds.end(), j.seeds.begin(), j.seeds.end());
+        const size_t base = msgs.size();
+        msgs += j.msgs;
+        for (size_t i = 1; i <= j.n; ++i) off.push_back(base + j.off[i]);
+    }
+    const size_t poly = (size_t)d * 4;
+    int rc;
+    if ((rc = grow(w.ctx, &w.d_coef, &w.cap_coef, N, 2 * poly)) != FZ_OK) return rc;
+    if ((rc = grow(w.ctx, &w.d_c, &w.cap_c, N, poly)) != FZ_OK) return rc;
+    Batch *b = nullptr;
+    int32_t *d_sk, *d_vk, *d_sig;
+    if (keep) {
+        b = new Batch();
+        b->worker = (int)(&w - Q->workers.data());
+        b->d_sk = b->d_vk = b->d_sig = nullptr;
+        b->refs = 0;
+        void *p = nullptr;
+        if ((rc = fz_malloc(w.ctx, N * 2 * poly, &p)) != FZ_OK) { free_batch(Q, w, b); return rc; }
+        b->d_vk = (int32_t *)p;
+        if ((rc = fz_malloc(w.ctx, N * (size_t)l * poly, &p)) != FZ_OK) { free_batch(Q, w, b); return rc; }
+        b->d_sig = (int32_t *)p;
+        if (keep_sk) {
+            if ((rc = fz_malloc(w.ctx, N * 2 * (size_t)l * poly, &p)) != FZ_OK) { free_batch(Q, w, b); return rc; }
+            b->d_sk = (int32_t *)p;
+        }
+    }
+    if (!b || !b->d_sk) {
+        if ((rc = grow(w.ctx, &w.d_sk, &w.cap_sk, N, 2 * (size_t)l * poly)) != FZ_OK) { if (b) free_batch(Q, w, b); return rc; }
+    }
+    if (!b) {
+        if ((rc = grow(w.ctx, &w.d_vk, &w.cap_vk, N, 2 * poly)) != FZ_OK) return rc;
+        if ((rc = grow(w.ctx, &w.d_sig, &w.cap_sig, N, (size_t)l * poly)) != FZ_OK) return rc;
+    }
+    d_sk = (b && b->d_sk) ? b->d_sk : w.d_sk;
+    d_vk = b ? b->d_vk : w.d_vk;
+    d_sig = b ? b->d_sig : w.d_sig;
+    // the path itself, exactly what BatchScheme.keygen_batch + sign_batch issue for one call (fusion.py:338-373, :534-557)
+    rc = fz_sample_secret_polys_dev(w.ctx, seeds.data(), N, Q->P.modulus, d, Q->beta_sk, Q->omega_sk, w.d_coef);
+    if (rc == FZ_OK) rc = fz_keygen_core_bcast(w.ctx, w.d_A, w.d_coef, d_sk, d_vk, N, l);
+    if (rc == FZ_OK) rc = fz_challenge_hat_msgs_dev(w.ctx, &Q->P, d_vk, msgs.data(), off.data(), N, w.d_c, nullptr);
+    if (rc == FZ_OK) rc = fz_sign_core(w.ctx, d_sk, w.d_c, d_sig, N, l);
+    if (rc == FZ_OK) {
+        hipStream_t st = (hipStream_t)w.stream;
+        for (size_t k = 0; k < jobs.size() && rc == FZ_OK; ++k)
+            if (jobs[k].h_vk_out)
+                rc = fz_check_hip(hipMemcpyAsync(jobs[k].h_vk_out, d_vk + row0[k] * 2 * (size_t)d, jobs[k].n * 2 * poly,
+                                                 hipMemcpyDeviceToHost, st), "queue: verification keys to the host");
+        if (rc == FZ_OK) rc = fz_ctx_synchronize(w.ctx);
+    } else {
+        (void)fz_ctx_synchronize(w.ctx);
+    }
+    if (rc != FZ_OK) {
+        if (b) free_batch(Q, w, b);
+        return rc;
+    }
+    *out_batch = b;
+    return FZ_OK;
+}
+
+void worker_main(fz_queue *Q, int index) {
+    Worker &w = Q->workers[index];
+    std::unique_lock<std::mutex> lk(Q->mu);
+    for (;;) {
+        Q->cv_work.wait(lk, [&] { return Q->stopping || !Q->pending.empty() || !w.garbage.empty(); });
+        if (!w.garbage.empty()) {
+            std::vector<Batch *> g;
+            g.swap(w.garbage);
+            lk.unlock();
+            for (Batch *b : g) free_batch(Q, w, b);
+            lk.lock();
+            continue;
+        }
+        if (Q->pending.empty()) {
+            if (Q->stopping) break;
+            continue;
+        }
+        // everything that is pending, up to max_rows keys: one batch
+        std::vector<Job> jobs;
+        size_t rows = 0;
+        while (!Q->pending.empty() && (jobs.empty() || rows + Q->pending.front().n <= Q->max_rows)) {
+            rows += Q->pending.front().n;
+            jobs.push_back(std::move(Q->pending.front()));
+            Q->pending.pop_front();
+        }
+        lk.unlock();
+        Batch *b = nullptr;
+        std::vector<size_t> row0;
+        const int rc = run_batch(Q, w, jobs, &b, row0);
+        const std::string err = rc == FZ_OK ? std::string() : std::string(last_error());
+        lk.lock();
+        int kept = 0;
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            Done dn;
+            dn.status = rc;
+            dn.error = err;
+            dn.batch = nullptr;
+            dn.row0 = row0.size() > k ? row0[k] : 0;
+            dn.n = jobs[k].n;
+            Q->live.erase(jobs[k].ticket);
+            if (jobs[k].flags & FZ_QUEUE_DISCARD) {                 // fire and forget: only a failure is remembered (for fz_queue_drain)
+                if (rc != FZ_OK && Q->first_error == FZ_OK) { Q->first_error = rc; Q->first_error_text = err; }
+                continue;
+            }
+            if (rc == FZ_OK && b) { dn.batch = b; ++kept; }
+            Q->done.emplace(jobs[k].ticket, std::move(dn));
+        }
+        if (b) {
+            if (kept) b->refs = kept;
+            else w.garbage.push_back(b);
+        }
+        Q->inflight -= jobs.size();
+        Q->st_jobs += jobs.size();
+        Q->st_batches += 1;
+        Q->st_rows += rows;
+        Q->cv_done.notify_all();
+    }
+    lk.unlock();
+    for (int32_t *p : {w.d_coef, w.d_c, w.d_sk, w.d_vk, w.d_sig, w.d_A})
+        if (p) (void)fz_free(w.ctx, p);
+    if (w.ctx) {
+        (void)fz_ctx_set_stream(w.ctx, nullptr);
+        if (w.stream) (void)fz_stream_destroy(w.ctx, w.stream);
+        (void)fz_ctx_destroy(w.ctx);
+    }
+}
+
+int worker_init(fz_queue *Q, Worker &w) {
+    int rc = fz_ctx_create(Q->device, (uint32_t)Q->P.modulus, Q->degree, (uint32_t)Q->P.root, (uint32_t)Q->P.inv_root, &w.ctx);
+    if (rc != FZ_OK) return rc;
+    if ((rc = fz_stream_create(w.ctx, &w.stream)) != FZ_OK) return rc;
+    if ((rc = fz_ctx_set_stream(w.ctx, w.stream)) != FZ_OK) return rc;
+    void *p = nullptr;
+    if ((rc = fz_malloc(w.ctx, Q->A.size() * 4, &p)) != FZ_OK) return rc;
+    w.d_A = (int32_t *)p;
+    if ((rc = fz_memcpy_h2d(w.ctx, w.d_A, Q->A.data(), Q->A.size() * 4)) != FZ_OK) return rc;
+    return fz_ctx_synchronize(w.ctx);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fz_pinned_alloc(size_t bytes, void **h_out) {
+    if (!h_out) return fz_set_error(FZ_E_BADARG, "h_out is NULL");
+    *h_out = nullptr;
+    return fz_check_hip(hipHostMalloc(h_out, bytes ? bytes : 1, hipHostMallocDefault), "pinned host allocation");
+}
+
+int fz_pinned_free(void *h_ptr) {
+    if (!h_ptr) return FZ_OK;
+    return fz_check_hip(hipHostFree(h_ptr), "pinned host free");
+}
+
+int fz_queue_create(int device, const fz_scheme_params *P, int rank, int64_t beta_sk, int64_t omega_sk, const int32_t *h_A,
+                    int workers, size_t max_rows, fz_queue **out) {
+    if (!P || !h_A || !out) return fz_set_error(FZ_E_BADARG, "NULL argument");
+    *out = nullptr;
+    if (rank < 1 || workers < 1 || workers > 16 || max_rows < 1)
+        return fz_set_error(FZ_E_BADARG, "rank >= 1, 1 <= workers <= 16, max_rows >= 1");
+    if (P->modulus <= 0 || P->modulus >= (1ll << 31) || P->degree < 1) return fz_set_error(FZ_E_BADARG, "bad parameter set");
+    fz_queue *Q = new (std::nothrow) fz_queue();
+    if (!Q) return fz_set_error(FZ_E_HIP, "out of host memory");
+    Q->device = device;
+    Q->l = rank;
+    Q->degree = P->degree;
+    Q->P = *P;
+    Q->beta_sk = beta_sk;
+    Q->omega_sk = omega_sk;
+    Q->max_rows = max_rows;
+    Q->A.assign(h_A, h_A + (size_t)rank * P->degree);
+    Q->workers.resize((size_t)workers);
+    // contexts are created HERE, on the caller's thread (errors come back as this call's error), then handed to the threads
+    for (auto &w : Q->workers) {
+        const int rc = worker_init(Q, w);
+        if (rc != FZ_OK) {
+            for (auto &v : Q->workers)
+                if (v.ctx) {
+                    if (v.d_A) (void)fz_free(v.ctx, v.d_A);
+                    (void)fz_ctx_set_stream(v.ctx, nullptr);
+                    if (v.stream) (void)fz_stream_destroy(v.ctx, v.stream);
+                    (void)fz_ctx_destroy(v.ctx);
+                }
+            delete Q;
+            return rc;
+        }
+    }
+    for (int i = 0; i < workers; ++i) Q->workers[(size_t)i].th = std::thread(worker_main, Q, i);
+    *out = Q;
+    return FZ_OK;
+}
+
+int fz_queue_destroy(fz_queue *Q) {
+    if (!Q) return FZ_OK;
+    {
+        std::unique_lock<std::mutex> lk(Q->mu);
+        // what was submitted is finished first; results nobody released go back to their workers
+        Q->cv_done.wait(lk, [&] { return Q->inflight == 0; });
+        for (auto &kv : Q->done)
+            if (kv.second.batch && --kv.second.batch->refs == 0) Q->workers[(size_t)kv.second.batch->worker].garbage.push_back(kv.second.batch);
+        Q->done.clear();
+        Q->stopping = true;
+        Q->cv_work.notify_all();
+    }
+    for (auto &w : Q->workers)
+        if (w.th.joinable()) w.th.join();
+    delete Q;
+    return FZ_OK;
+}
+
+int fz_queue_submit_keygen_sign(fz_queue *Q, const uint64_t *h_seeds, size_t n, const char *h_msgs, const size_t *h_msg_off,
+                                int32_t *h_vk_out, int flags, uint64_t *out_ticket) {
+    if (!Q || !out_ticket || (n && (!h_seeds || !h_msg_off))) return fz_set_error(FZ_E_BADARG, "NULL argument");
+    if (n == 0 || n > Q->max_rows) return fz_set_error(FZ_E_BADARG, "between 1 and max_rows (%zu) keys per call", Q->max_rows);
+    if (h_msg_off[0] != 0) return fz_set_error(FZ_E_BADARG, "h_msg_off[0] must be 0");
+    for (size_t i = 0; i < n; ++i) {
+        if (h_msg_off[i + 1] < h_msg_off[i]) return fz_set_error(FZ_E_BADARG, "message offsets must not decrease");
+        if (h_seeds[i] == ~0ull) return fz_set_error(FZ_E_UNSUPPORTED, "seed 2^64 - 1: seed + 1 wraps (use the Python sampler)");
+    }
+    if (h_msg_off[n] && !h_msgs) return fz_set_error(FZ_E_BADARG, "h_msgs is NULL");
+    Job j;
+    j.n = n;
+    j.flags = flags;
+    j.seeds.assign(h_seeds, h_seeds + n);
+    j.msgs.assign(h_msgs ? h_msgs : "", h_msg_off[n]);
+    j.off.assign(h_msg_off, h_msg_off + n + 1);
+    j.h_vk_out = h_vk_out;
+    {
+        std::lock_guard<std::mutex> lk(Q->mu);
+        if (Q->stopping) return fz_set_error(FZ_E_BADARG, "the queue is shutting down");
+        j.ticket = Q->next_ticket++;
+        *out_ticket = j.ticket;
+        Q->live.insert(j.ticket);
+        Q->pending.push_back(std::move(j));
+        Q->inflight += 1;
+    }
+    Q->cv_work.notify_one();
+    return FZ_OK;
+}
+
+int fz_queue_wait(fz_queue *Q, uint64_t ticket, fz_queue_result *out) {
+    if (!Q) return fz_set_error(FZ_E_BADARG, "queue is NULL");
+    std::unique_lock<std::mutex> lk(Q->mu);
+    if (ticket == 0 || ticket >= Q->next_ticket) return fz_set_error(FZ_E_BADARG, "unknown ticket");
+    Q->cv_done.wait(lk, [&] { return Q->live.count(ticket) == 0; });
+    auto it = Q->done.find(ticket);
+    if (it == Q->done.end()) {                               // a FZ_QUEUE_DISCARD call, or released before: finished, nothing to hand out
+        if (out) memset(out, 0, sizeof(*out));
+        return FZ_OK;
+    }
+    const Done &dn = it->second;
+    if (out) {
+        memset(out, 0, sizeof(*out));
+        out->status = dn.status;
+        out->n = dn.n;
+        if (dn.batch) {
+            const size_t d = (size_t)Q->degree, l = (size_t)Q->l;
+            out->d_vk = dn.batch->d_vk + dn.row0 * 2 * d;
+            out->d_sig = dn.batch->d_sig + dn.row0 * l * d;
+            out->d_sk_hat = dn.batch->d_sk ? dn.batch->d_sk + dn.row0 * 2 * l * d : nullptr;
+        }
+    }
+    if (dn.status != FZ_OK) return fz_set_error(dn.status, "queued batch failed: %s", dn.error.c_str());
+    return FZ_OK;
+}
+
+int fz_queue_release(fz_queue *Q, uint64_t ticket) {
+    if (!Q) return fz_set_error(FZ_E_BADARG, "queue is NULL");
+    std::unique_lock<std::mutex> lk(Q->mu);
+    if (ticket == 0 || ticket >= Q->next_ticket) return fz_set_error(FZ_E_BADARG, "unknown ticket");
+    Q->cv_done.wait(lk, [&] { return Q->live.count(ticket) == 0; });
+    auto it = Q->done.find(ticket);
+    if (it == Q->done.end()) return FZ_OK;                  // released before: idempotent
+    Batch *b = it->second.batch;
+    Q->done.erase(it);
+    if (b && --b->refs == 0) {
+        Q->workers[(size_t)b->worker].garbage.push_back(b);
+        Q->cv_work.notify_all();
+    }
+    return FZ_OK;
+}
+
+int fz_queue_drain(fz_queue *Q) {
+    if (!Q) return fz_set_error(FZ_E_BADARG, "queue is NULL");
+    std::unique_lock<std::mutex> lk(Q->mu);
+    Q->cv_done.wait(lk, [&] { return Q->inflight == 0; });
+    if (Q->first_error != FZ_OK) {
+        const int rc = Q->first_error;
+        const std::string text = Q->first_error_text;
+        Q->first_error = FZ_OK;
+        Q->first_error_text.clear();
+        return fz_set_error(rc, "a discarded call failed: %s", text.c_str());
+    }
+    return FZ_OK;
+}
+
+int fz_queue_stats(fz_queue *Q, uint64_t *out_calls, uint64_t *out_batches, uint64_t *out_rows) {
+    if (!Q) return fz_set_error(FZ_E_BADARG, "queue is NULL");
+    std::lock_guard<std::mutex> lk(Q->mu);
+    if (out_calls) *out_calls = Q->st_jobs;
+    if (out_batches) *out_batches = Q->st_batches;
+    if (out_rows) *out_rows = Q->st_rows;
+    return FZ_OK;
+}
+
+}  // extern "C"

@@ -166,6 +166,26 @@ SIGNATURES.update({
     "fz_diag_shader_clock": (c_int, [_ctx, ctypes.c_uint, POINTER(ctypes.c_double)]),
 })
 
+
+class QueueResult(ctypes.Structure):
+    """fz_queue_result"""
+    _fields_ = [("status", c_int), ("n", c_size_t), ("d_sk_hat", c_void_p), ("d_vk", c_void_p), ("d_sig", c_void_p)]
+
+
+FZ_QUEUE_KEEP_SK, FZ_QUEUE_DISCARD = 1, 2
+SIGNATURES.update({
+    "fz_queue_create": (c_int, [c_int, _spp, c_int, c_int64, c_int64, c_void_p, c_int, c_size_t, POINTER(c_void_p)]),
+    "fz_queue_destroy": (c_int, [c_void_p]),
+    "fz_queue_submit_keygen_sign": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
+                                            POINTER(ctypes.c_uint64)]),
+    "fz_queue_wait": (c_int, [c_void_p, ctypes.c_uint64, POINTER(QueueResult)]),
+    "fz_queue_release": (c_int, [c_void_p, ctypes.c_uint64]),
+    "fz_queue_drain": (c_int, [c_void_p]),
+    "fz_queue_stats": (c_int, [c_void_p, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64)]),
+    "fz_pinned_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),
+    "fz_pinned_free": (c_int, [c_void_p]),
+})
+
 _lib = None
 
 

@@ -414,6 +414,47 @@ FZ_API int fz_sample_secret_polys(const uint64_t *h_seeds, size_t N, int64_t mod
 FZ_API int fz_sample_secret_polys_dev(fz_ctx *ctx, const uint64_t *h_seeds, size_t N, int64_t modulus, int degree,
                                       int64_t norm_bound, int64_t weight_bound, int32_t *d_out);
 
+/* ---- asynchronous batch queue (round 4) -------------------------------------------------------------------------
+ * The reference is called once per key / signature (fusion.py:338-373, :534-557).  A call of BASELINE's size (1024 keys +
+ * 1024 signatures) is a latency chain that leaves most of the chip idle; the queue takes such calls from ONE host thread
+ * without blocking it and runs whatever is pending as ONE batch on worker threads that each own a context and a stream
+ * (csrc/fz_queue.hip): every row of the path is independent, so the results are those of separate calls, bit for bit.
+ *   fz_queue_create   workers (1..16) contexts + streams on `device`; h_A [rank][degree] the public challenge; max_rows:
+ *                     keys per coalesced batch (and per call).
+ *   fz_queue_submit_keygen_sign   keygen(params, seed_i) + sign(params, key_i, message_i) for i < n: copies the inputs,
+ *                     returns at once with a ticket.  h_vk_out (optional, ideally from fz_pinned_alloc) receives the
+ *                     verification keys [n][2][degree]; it must stay valid until the call has finished.
+ *                     flags: FZ_QUEUE_KEEP_SK keeps the secret keys on the device too; FZ_QUEUE_DISCARD drops every device
+ *                     result when the call finishes (throughput runs; its verification keys still reach h_vk_out).
+ *   fz_queue_wait     blocks until the call has finished; device pointers of its rows (owned by the queue, valid until
+ *                     fz_queue_release; read them on any stream: the producing work has completed).
+ *   fz_queue_release  gives the call's device rows back (idempotent).  fz_queue_drain waits for everything submitted and
+ *                     reports the first failure among discarded calls.  fz_queue_destroy finishes what was submitted,
+ *                     releases everything and joins the workers.
+ * Any thread may submit / wait / release; seeds must be < 2^64 - 1 (as fz_sample_secret_polys_dev). */
+typedef struct fz_queue fz_queue;
+typedef struct fz_queue_result {
+    int status;                  /* FZ_OK or the error code of the batch the call ran in */
+    size_t n;                    /* rows of the call (0: discarded or released) */
+    const int32_t *d_sk_hat;     /* [n][2][rank][degree], NULL without FZ_QUEUE_KEEP_SK */
+    const int32_t *d_vk;         /* [n][2][degree] */
+    const int32_t *d_sig;        /* [n][rank][degree] */
+} fz_queue_result;
+#define FZ_QUEUE_KEEP_SK 1
+#define FZ_QUEUE_DISCARD 2
+FZ_API int fz_queue_create(int device, const fz_scheme_params *P, int rank, int64_t beta_sk, int64_t omega_sk,
+                           const int32_t *h_A, int workers, size_t max_rows, fz_queue **out);
+FZ_API int fz_queue_destroy(fz_queue *queue);
+FZ_API int fz_queue_submit_keygen_sign(fz_queue *queue, const uint64_t *h_seeds, size_t n, const char *h_msgs,
+                                       const size_t *h_msg_off, int32_t *h_vk_out, int flags, uint64_t *out_ticket);
+FZ_API int fz_queue_wait(fz_queue *queue, uint64_t ticket, fz_queue_result *out);
+FZ_API int fz_queue_release(fz_queue *queue, uint64_t ticket);
+FZ_API int fz_queue_drain(fz_queue *queue);
+FZ_API int fz_queue_stats(fz_queue *queue, uint64_t *out_calls, uint64_t *out_batches, uint64_t *out_rows);
+/* page-locked host memory (hipHostMalloc): device-to-host copies into it are asynchronous and run at PCIe speed */
+FZ_API int fz_pinned_alloc(size_t bytes, void **h_out);
+FZ_API int fz_pinned_free(void *h_ptr);
+
 #ifdef __cplusplus
 }
 #endif

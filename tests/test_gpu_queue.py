@@ -1,0 +1,107 @@
+"""The asynchronous batch queue of the C ABI (fz_queue_*, fusion_hip.queue.BatchQueue): calls submitted from one thread are run
+as coalesced batches by worker threads below Python; every call's keys and signatures must be the integers keygen / sign give
+for that call alone -- the reference's golden arrays (fusion/fusion.py:338-373, :534-557) and BatchScheme on the same inputs."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_queue_reproduces_the_reference_arrays(secpar):
+    import fusion.fusion as F
+    from fusion_hip.queue import BatchQueue
+    S = np.load(os.path.join(G, f"scheme_{secpar}.npz"))
+    with open(os.path.join(G, "scheme.json")) as fh:
+        m = json.load(fh)[str(secpar)]
+    params = F.fusion_setup(secpar, m["setup_seed"])
+    with BatchQueue(params, workers=2) as bq:
+        # the four golden keys as one call, and as four calls of one key each (coalesced or not: the same rows)
+        t_all = bq.submit_keygen_sign(m["key_seeds"], m["messages"], keep_sk=True)
+        singles = [bq.submit_keygen_sign([s], [msg]) for s, msg in zip(m["key_seeds"], m["messages"])]
+        r = bq.wait(t_all)
+        assert r.n == 4 and np.array_equal(r.vk, S["vk"])
+        assert np.array_equal(r.signatures(), S["sig"]) and np.array_equal(r.secret_keys(), S["sk_hat"])
+        r.release()
+        r.release()                                        # idempotent
+        for i, t in enumerate(singles):
+            ri = bq.wait(t)
+            assert ri.n == 1 and np.array_equal(ri.vk[0], S["vk"][i]) and np.array_equal(ri.signatures()[0], S["sig"][i])
+            assert ri.sk_ptr is None
+            with pytest.raises(Exception):
+                ri.secret_keys()                           # not kept
+            ri.release(copy_vk=True)
+            assert np.array_equal(ri.vk[0], S["vk"][i])
+
+
+def test_many_calls_of_different_sizes_equal_batch_scheme():
+    """60 calls of 1 .. 300 keys submitted back to back from one thread (most of them coalesced), some discarded: rows, order
+    and ownership survive the cut into calls; release in any order; stats show the coalescing"""
+    import fusion.fusion as F
+    from fusion_hip.queue import BatchQueue, PackedMessages
+    from fusion_hip.scheme import BatchScheme
+    params = F.fusion_setup(256, 2026)
+    bs = BatchScheme(params, threads=4)
+    rng = np.random.default_rng(5)
+    sizes = [int(x) for x in rng.integers(1, 300, size=60)]
+    sizes[7] = 1
+    calls = []
+    for k, n in enumerate(sizes):
+        seeds = [int(x) for x in rng.integers(0, 2**63, size=n)]
+        if k == 3:
+            seeds[0] = 2**64 - 2                           # the largest seed the clones take
+        msgs = [f"call {k} message {i} " + "x" * int(rng.integers(0, 200)) for i in range(n)]
+        if k == 5:
+            msgs[0] = ""
+            msgs[-1] = "é中 multi-byte"
+        calls.append((seeds, msgs))
+    with BatchQueue(params, workers=3, max_rows=1024) as bq:
+        tickets = []
+        for k, (seeds, msgs) in enumerate(calls):
+            packed = PackedMessages(msgs) if k % 2 else msgs
+            sd = np.array(seeds, dtype=np.uint64) if k % 3 == 0 else seeds
+            tickets.append(bq.submit_keygen_sign(sd, packed, keep_sk=(k % 4 == 0), discard=(k % 10 == 9)))
+        order = list(rng.permutation(len(calls)))
+        for k in order:
+            seeds, msgs = calls[k]
+            r = bq.wait(tickets[k])
+            sk, vk = bs.keygen_batch(seeds)
+            assert np.array_equal(r.vk, vk), k                 # discarded calls still deliver their verification keys
+            if k % 10 == 9:
+                assert r.n == 0 and r.sig_ptr is None
+            else:
+                assert r.n == len(seeds)
+                assert np.array_equal(r.signatures(), bs.sign_batch(sk, vk, msgs)), k
+                if k % 4 == 0:
+                    assert np.array_equal(r.secret_keys(), sk), k
+            r.release()
+        done, batches, rows = bq.stats()
+        assert done == len(calls) and rows == sum(sizes) and batches <= done
+        bq.drain()
+
+
+def test_queue_argument_errors_and_shutdown_with_results_outstanding():
+    import fusion.fusion as F
+    from fusion_hip import FusionHipError
+    from fusion_hip.queue import BatchQueue
+    params = F.fusion_setup(128, 3)
+    bq = BatchQueue(params, workers=1, max_rows=64)
+    with pytest.raises(FusionHipError) as e:
+        bq.submit_keygen_sign(np.array([2**64 - 1], dtype=np.uint64), ["m"])       # seed + 1 would wrap
+    assert e.value.code == -2
+    with pytest.raises(ValueError):
+        bq.submit_keygen_sign([-5], ["m"])                                          # random.seed(abs()): the Python sampler's
+    with pytest.raises(ValueError):
+        bq.submit_keygen_sign([1, 2], ["only one"])
+    with pytest.raises(FusionHipError):
+        bq.submit_keygen_sign(list(range(65)), ["m"] * 65)                          # more than max_rows
+    with pytest.raises(FusionHipError):
+        bq.wait(12345)                                                              # unknown ticket
+    t = bq.submit_keygen_sign([1, 2, 3], ["a", "b", "c"])
+    bq.close()                                                                      # finishes the call, frees its rows, joins
+    bq.close()
+    assert t == 1

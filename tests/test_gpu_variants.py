@@ -260,3 +260,68 @@ def test_device_sampler_forms(one_kernel):
             assert np.array_equal(got, hostpipe.sample_secret_polys(seeds, q, deg, bound, deg)), (nn, deg, bound)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("direct", ["-1", "0", "2", "4"])
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_aggregation_forms(secpar, direct, coracle):
+    """sum_i sigma_i (.) alpha_i (fusion.py:670-676) and the verification target (:706-714) through both aggregation kernels --
+    the sliced one with shared accumulator words (FZ_AGG_DIRECT=-1) and the slice-free one with 2 / 4 rows per tile -- and the
+    default choice: centred int32 and int64 partial sums, with and without the target in the same launch, uniform and ragged
+    groups (an empty one included), signer counts on both sides of every fold / depth boundary, any int32 operands"""
+    import fusion_hip
+    DA = fusion_hip.DeviceArray
+    P = O.PARAMS[secpar]
+    q, d = P["q"], P["d"]
+    ctx = _ctx(P, {"FZ_AGG_DIRECT": direct})
+    rng = np.random.default_rng(secpar + 77)
+
+    def raw(*shape):
+        return rng.integers(I32.min, I32.max, size=shape, dtype=np.int64).astype(np.int32)
+
+    def cent(v):
+        return np.asarray((v + q // 2) % q - q // 2).astype(np.int64)
+    try:
+        for l in (P["rank"], 5):
+            for N, groups in ((1, 1), (3, 2), (33, 1), (130, 3), (300, 1)):
+                sig, al = raw(groups, N, l, d), raw(groups, N, d)
+                sig[0, 0, 0, :] = I32.min
+                al[0, 0, :] = I32.min
+                want = np.stack([coracle.aggregate_core(sig[g], al[g], q) for g in range(groups)]).reshape(groups, l, d)
+                vkL, vkR, ch = raw(groups, N, d), raw(groups, N, d), raw(groups, N, d)
+                Lo, Ro, Co, Ao = (a_.astype(object) for a_ in (vkL, vkR, ch, al))          # exact Python integers
+                tgt = cent(((Lo * Co + Ro) * Ao).sum(axis=1))
+                bufs = [DA.from_numpy(ctx, a) for a in (sig, al, vkL, vkR, ch)]
+                dS, dAl, dL, dR, dC = bufs
+                dO, dP, dT = DA(ctx, (groups, l, d)), DA(ctx, (groups, l * d), np.int64), DA(ctx, (groups, d), np.int64)
+                try:
+                    if groups == 1:
+                        ctx.aggregate_core_dev(dS.ptr, dAl.ptr, dO.ptr, N, l)
+                        assert np.array_equal(dO.numpy()[0], want[0]), (l, N, "core")
+                    ctx.aggregate_partial_batch_dev(dS.ptr, dAl.ptr, dP.ptr, l * d, groups, N, l)
+                    assert np.array_equal(cent(dP.numpy()).reshape(groups, l, d), want), (l, N, groups, "partial")
+                    ctx.aggregate_target_partial_batch_dev(dS.ptr, dAl.ptr, dL.ptr, dR.ptr, dC.ptr, dP.ptr, l * d, dT.ptr, d, groups, N, l)
+                    assert np.array_equal(cent(dP.numpy()).reshape(groups, l, d), want), (l, N, groups, "partial+target")
+                    assert np.array_equal(cent(dT.numpy()), tgt), (l, N, groups, "target")
+                    # ragged: the same rows cut into aggregates of different sizes, one of them empty
+                    rows = groups * N
+                    cuts = sorted({0, rows, min(rows, 1), rows // 2, rows // 2, (2 * rows) // 3})
+                    offsets = [0] + [c_ for c_ in cuts if 0 < c_ < rows] + [rows // 2 if rows > 1 else rows, rows]
+                    offsets = sorted(offsets)                                   # a repeated offset = an empty aggregate
+                    G = len(offsets) - 1
+                    fs, fa = sig.reshape(rows, l, d), al.reshape(rows, d)
+                    dRg = DA(ctx, (G, l, d))
+                    try:
+                        ctx.aggregate_core_ragged_dev(dS.ptr, dAl.ptr, offsets, l, dRg.ptr)
+                        got = dRg.numpy()
+                        for g in range(G):
+                            lo_, hi_ = offsets[g], offsets[g + 1]
+                            exp = coracle.aggregate_core(fs[lo_:hi_], fa[lo_:hi_], q).reshape(l, d) if hi_ > lo_ else np.zeros((l, d), np.int32)
+                            assert np.array_equal(got[g], exp), (l, N, groups, "ragged", g, offsets)
+                    finally:
+                        dRg.free()
+                finally:
+                    for b in bufs + [dO, dP, dT]:
+                        b.free()
+    finally:
+        ctx.close()

@@ -144,6 +144,197 @@ __global__ __launch_bounds__(64 * WAVES) void fwd4_variant(const int32_t *in, in
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4: the two structures never tried.
+//
+// (a) fwd4_xlane -- REGISTER EXCHANGE instead of the LDS round trips (north_star: "wavefront shuffles for the in-warp butterfly
+//     passes"; the stride <= 32 stages of algebra/ntt.py:274-290).  A lane holds 4 coefficients; position p = p7..p0, the two
+//     register bits (r1, r0) start as (p7, p6), the lane bits as p5..p0.  Stages b = 7, 6 run on the register bits; for each later
+//     stage b = 5 .. 0 the lane bit b is SWAPPED with one register bit (r1 for odd b, r0 for even b): lanes whose bit is 0 keep
+//     their rb = 0 registers and receive the partner's, lanes whose bit is 1 keep rb = 1 -- every lane then holds both operands of
+//     two butterflies.  Distance 32 / 16: v_permlane32_swap / v_permlane16_swap (one instruction per dword); distance 8 / 4: three
+//     bank-masked DPP moves per dword; distance 2 / 1: quad_perm DPP + selects.  After stage 0 the lane holds positions 4L .. 4L+3:
+//     the same coalesced 16-byte store as the library kernel.  No LDS at all.
+// (b) fwd2_pair -- ONE ROW OVER TWO WAVES, 2 coefficients per lane (8 waves per SIMD at 4096 rows, half the per-wave chain):
+//     four passes of two stages; inside a pass the second stage's bit sits on lane bit 5 and comes into the register with ONE
+//     v_permlane32_swap per dword; between passes the row goes through LDS (three exchanges, as in the library kernel, each with
+//     its own conflict-free XOR layout) and the two waves meet at a workgroup barrier.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swap32(unsigned &a, unsigned &b) {      // a.lanes[32..63] <-> b.lanes[0..31]
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void swap16(unsigned &a, unsigned &b) {      // odd 16-lane rows of a <-> even rows of b
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+
+// lanes with bit S clear keep A and receive the partner's A into B; lanes with bit S set keep B and receive the partner's B into A
+template <int S>
+__device__ __forceinline__ void xchg_dword(unsigned &A, unsigned &B, bool upper) {
+    if constexpr (S == 32) swap32(A, B);
+    else if constexpr (S == 16) swap16(A, B);
+    else if constexpr (S == 8 || S == 4) {
+        constexpr int SHR = 0x110 + S, SHL = 0x100 + S;                  // row_shr:S (lane i reads i - S), row_shl:S (reads i + S)
+        constexpr int LOWER = S == 8 ? 0x3 : 0x5, UPPER = S == 8 ? 0xC : 0xA;       // banks = groups of 4 lanes within a row of 16
+        const unsigned t = (unsigned)__builtin_amdgcn_update_dpp((int)B, (int)B, SHR, 0xF, 0xF, false);     // upper lanes: the lower partner's B
+        B = (unsigned)__builtin_amdgcn_update_dpp((int)B, (int)A, SHL, 0xF, LOWER, false);                   // lower lanes: B <- the upper partner's A
+        A = (unsigned)__builtin_amdgcn_update_dpp((int)A, (int)t, 0xE4, 0xF, UPPER, false);                  // upper lanes: A <- t
+    } else {
+        constexpr int QP = S == 2 ? 0x4E : 0xB1;                          // quad_perm [2,3,0,1] / [1,0,3,2]
+        const unsigned x = upper ? A : B;
+        const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)x, QP, 0xF, 0xF, true);
+        A = upper ? y : A;
+        B = upper ? B : y;
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void xchg(double &A, double &B, bool upper) {
+    unsigned a0 = (unsigned)__double2loint(A), a1 = (unsigned)__double2hiint(A), b0 = (unsigned)__double2loint(B), b1 = (unsigned)__double2hiint(B);
+    xchg_dword<S>(a0, b0, upper);
+    xchg_dword<S>(a1, b1, upper);
+    A = __hiloint2double((int)a1, (int)a0);
+    B = __hiloint2double((int)b1, (int)b0);
+}
+
+template <int WAVES, bool FAST>
+__global__ __launch_bounds__(64 * WAVES) void fwd4_xlane(const int32_t *in, int32_t *out, size_t batch,
+                                                         const double2 *__restrict__ tw2, FzTwA twA, FzMod m) {
+    constexpr int D = 256;
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (row >= batch) return;
+    const int32_t *src = in + row * D + lane;
+    int x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = src[k * 64];
+    // per-lane twiddles of the six cross-lane stages: index 2^(7-b) + ((lane >> b) << 1) + (the other register bit)
+    double2 tw[6][2];
+#pragma unroll
+    for (int b = 5; b >= 0; --b)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) tw[5 - b][o] = tw2[(1 << (7 - b)) + ((lane >> b) << 1) + o];
+    double a[4];                                   // a[2 * r1 + r0]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = (double)x[k];
+    {   // stages 7 and 6 on the register bits (uniform twiddles)
+        double v = tw_mul<FAST>(a[2], twA.w[1], twA.w2[1], m), u = a[0];
+        a[0] = u + v; a[2] = u - v;
+        v = tw_mul<FAST>(a[3], twA.w[1], twA.w2[1], m); u = a[1];
+        a[1] = u + v; a[3] = u - v;
+        v = tw_mul<FAST>(a[1], twA.w[2], twA.w2[2], m); u = a[0];
+        a[0] = u + v; a[1] = u - v;
+        v = tw_mul<FAST>(a[3], twA.w[3], twA.w2[3], m); u = a[2];
+        a[2] = u + v; a[3] = u - v;
+    }
+#define XSTAGE(BIT)                                                                                                     \
+    {                                                                                                                   \
+        constexpr int S = 1 << BIT;                                                                                     \
+        const bool upper = (lane >> BIT) & 1;                                                                           \
+        if constexpr (BIT & 1) {            /* lane bit <-> r1: pairs (a0, a2), (a1, a3); other bit r0 = 0, 1 */       \
+            xchg<S>(a[0], a[2], upper);                                                                                 \
+            xchg<S>(a[1], a[3], upper);                                                                                 \
+            double v = tw_mul<FAST>(a[2], tw[5 - BIT][0].x, tw[5 - BIT][0].y, m), u = a[0];                             \
+            a[0] = u + v; a[2] = u - v;                                                                                 \
+            v = tw_mul<FAST>(a[3], tw[5 - BIT][1].x, tw[5 - BIT][1].y, m); u = a[1];                                    \
+            a[1] = u + v; a[3] = u - v;                                                                                 \
+        } else {                            /* lane bit <-> r0: pairs (a0, a1), (a2, a3); other bit r1 = 0, 1 */       \
+            xchg<S>(a[0], a[1], upper);                                                                                 \
+            xchg<S>(a[2], a[3], upper);                                                                                 \
+            double v = tw_mul<FAST>(a[1], tw[5 - BIT][0].x, tw[5 - BIT][0].y, m), u = a[0];                             \
+            a[0] = u + v; a[1] = u - v;                                                                                 \
+            v = tw_mul<FAST>(a[3], tw[5 - BIT][1].x, tw[5 - BIT][1].y, m); u = a[2];                                    \
+            a[2] = u + v; a[3] = u - v;                                                                                 \
+        }                                                                                                               \
+    }
+    XSTAGE(5) XSTAGE(4) XSTAGE(3) XSTAGE(2) XSTAGE(1) XSTAGE(0)
+#undef XSTAGE
+    nt_store4(out + row * D + 4 * lane, make_int4((int)fz_cent(a[0], m), (int)fz_cent(a[1], m), (int)fz_cent(a[2], m), (int)fz_cent(a[3], m)));
+}
+
+// (b) one row = one workgroup of two waves; ROWS rows per workgroup (2 * ROWS waves), each pair with its own LDS region
+template <int ROWS, bool FAST>
+__global__ __launch_bounds__(128 * ROWS) void fwd2_pair(const int32_t *in, int32_t *out, size_t batch,
+                                                        const double2 *__restrict__ tw2, FzTwA twA, FzMod m) {
+    constexpr int D = 256;
+    __shared__ __attribute__((aligned(16))) double lds[ROWS * 256];
+    const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 1, rl = threadIdx.x >> 7;
+    const int l5 = lane >> 5, l4 = (lane >> 4) & 1, L31 = lane & 31, L15 = lane & 15;
+    const size_t row = (size_t)blockIdx.x * ROWS + rl;
+    const bool active = row < batch;                    // (every thread reaches every barrier)
+    double *reg = lds + rl * 256;
+    // pass 0 positions: p7 = register, p6 = l5, p5 = w, p4..p0 = lane & 31
+    const int p_in = (l5 << 6) | (w << 5) | L31;
+    int x0 = 0, x1 = 0;
+    if (active) { x0 = in[row * D + p_in]; x1 = in[row * D + p_in + 128]; }
+    // per-lane twiddles: stage b of a butterfly at position p uses index 2^(7-b) + (p >> (b+1))
+    const int l3 = (lane >> 3) & 1, l2 = (lane >> 2) & 1;
+    const double2 t6 = tw2[2 + l5];
+    const double2 t5 = tw2[4 + 2 * w + l4], t4 = tw2[8 + 4 * w + 2 * l4 + l5];
+    const double2 t3 = tw2[16 + 8 * w + 4 * l4 + 2 * l3 + l2], t2 = tw2[32 + 16 * w + 8 * l4 + 4 * l3 + 2 * l2 + l5];
+    const double2 t1 = tw2[64 + 32 * w + L31], t0 = tw2[128 + 64 * w + 2 * L31 + l5];
+    double a0 = (double)x0, a1 = (double)x1;
+    auto bfly = [&](double w_, double w2_) { const double v = tw_mul<FAST>(a1, w_, w2_, m), u = a0; a0 = u + v; a1 = u - v; };
+    const bool up = l5;
+    // exchange layouts: sigma_k permutes the low 6 position bits so that both the writing and the reading pattern of exchange k
+    // touch 16 distinct 8-byte slots per 16-lane group
+    auto sig1 = [](int p) { return p ^ (((p >> 4) & 3) << 2); };
+    auto sig2 = [](int p) { return (p & 0xC0) | ((p & 3) << 4) | ((((p >> 2) ^ p) & 3) << 2) | ((p >> 4) & 3); };
+    // ---- pass 0: stages 7, 6
+    bfly(twA.w[1], twA.w2[1]);
+    xchg<32>(a0, a1, up);                                // register = p6, l5 = p7
+    bfly(t6.x, t6.y);
+    {
+        const int p = (l5 << 7) | (w << 5) | L31;        // + (r << 6)
+        reg[p] = a0; reg[p | 64] = a1;
+    }
+    __syncthreads();
+    // ---- pass 1: stages 5, 4: register = p5, l5 = p4, w = p7, l4 = p6, lane & 15 = p3..p0
+    {
+        const int p = (w << 7) | (l4 << 6) | (l5 << 4) | L15;
+        a0 = reg[p]; a1 = reg[p | 32];
+    }
+    bfly(t5.x, t5.y);
+    xchg<32>(a0, a1, up);                                // register = p4, l5 = p5
+    bfly(t4.x, t4.y);
+    __syncthreads();                                     // everyone has read exchange 0
+    {
+        const int p = (w << 7) | (l4 << 6) | (l5 << 5) | L15;
+        reg[sig1(p)] = a0; reg[sig1(p | 16)] = a1;
+    }
+    __syncthreads();
+    // ---- pass 2: stages 3, 2: register = p3, l5 = p2, w = p7, l4 = p6, l3 = p5, l2 = p4, l1 l0 = p1 p0
+    {
+        const int p = (w << 7) | (l4 << 6) | (l3 << 5) | (l2 << 4) | (l5 << 2) | (lane & 3);
+        a0 = reg[sig1(p)]; a1 = reg[sig1(p | 8)];
+    }
+    bfly(t3.x, t3.y);
+    xchg<32>(a0, a1, up);                                // register = p2, l5 = p3
+    bfly(t2.x, t2.y);
+    __syncthreads();
+    {
+        const int p = (w << 7) | (l4 << 6) | (l3 << 5) | (l2 << 4) | (l5 << 3) | (lane & 3);
+        reg[sig2(p)] = a0; reg[sig2(p | 4)] = a1;
+    }
+    __syncthreads();
+    // ---- pass 3: stages 1, 0: register = p1, l5 = p0, w = p7, lane & 31 = p6..p2
+    {
+        const int p = (w << 7) | (L31 << 2) | l5;
+        a0 = reg[sig2(p)]; a1 = reg[sig2(p | 2)];
+    }
+    bfly(t1.x, t1.y);
+    xchg<32>(a0, a1, up);                                // register = p0, l5 = p1
+    bfly(t0.x, t0.y);
+    if (active) {
+        const int p = (w << 7) | (L31 << 2) | (l5 << 1);
+        int2 o = make_int2((int)fz_cent(a0, m), (int)fz_cent(a1, m));
+        __builtin_nontemporal_store(o.x, out + row * D + p);
+        __builtin_nontemporal_store(o.y, out + row * D + p + 1);
+    }
+}
+
 __global__ __launch_bounds__(1024) void empty_kernel() {}
 
 uint64_t powmod(uint64_t b, uint64_t e, uint64_t q) {
@@ -297,6 +488,30 @@ int main(int argc, char **argv) {
             printf("%-44s grid %6u x %4d  %8.3f us  %5.1f %% of 8 TB/s   per-dispatch events %7.3f us  %5.1f %%   %s\n", name, grid, 64 * WAVES, us, \
                    bytes / (us * 1e-6) / 8e12 * 100, iso, bytes / (iso * 1e-6) / 8e12 * 100, ok ? "bit-exact" : "MISMATCH");    \
         }
+#define XVARIANT(LABEL, KERNEL, GRID, BLOCK)                                                                                    \
+        {                                                                                                                       \
+            const unsigned grid = (unsigned)(GRID);                                                                             \
+            auto f = [&]() { const int32_t *i_ = in_ptr(); hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(BLOCK), 0, st,        \
+                                                i_, out_ptr(), B, (const double2 *)d_tw2, twA, mod); };                         \
+            hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(BLOCK), 0, st, (const int32_t *)pool_in, d_ref, B,                   \
+                               (const double2 *)d_tw2, twA, mod);                                                               \
+            CHECK(hipStreamSynchronize(st));                                                                                    \
+            CHECK(hipMemcpy(got.data(), d_ref, rowbytes, hipMemcpyDeviceToHost));                                               \
+            const bool ok = memcmp(got.data(), ref.data(), rowbytes) == 0;                                                      \
+            if (!ok) ++bad;                                                                                                     \
+            const double us = time_us(f, reps, st, t);                                                                          \
+            auto fe = [&](hipEvent_t e0, hipEvent_t e1) { const int32_t *i_ = in_ptr(); hipExtLaunchKernelGGL((KERNEL),        \
+                        dim3(grid), dim3(BLOCK), 0, st, e0, e1, 0, i_, out_ptr(), B, (const double2 *)d_tw2, twA, mod); };      \
+            const double iso = isolated_us(fe, 200, st);                                                                        \
+            printf("%-44s grid %6u x %4d  %8.3f us  %5.1f %% of 8 TB/s   per-dispatch events %7.3f us  %5.1f %%   %s\n", LABEL, grid, BLOCK, us, \
+                   bytes / (us * 1e-6) / 8e12 * 100, iso, bytes / (iso * 1e-6) / 8e12 * 100, ok ? "bit-exact" : "MISMATCH");    \
+        }
+        XVARIANT("xlane (register exchange) WAVES=1", (fwd4_xlane<1, true>), B, 64)
+        XVARIANT("xlane (register exchange) WAVES=4", (fwd4_xlane<4, true>), (B + 3) / 4, 256)
+        XVARIANT("xlane (register exchange) WAVES=8", (fwd4_xlane<8, true>), (B + 7) / 8, 512)
+        XVARIANT("row over 2 waves, 1 row / workgroup", (fwd2_pair<1, true>), B, 128)
+        XVARIANT("row over 2 waves, 2 rows / workgroup", (fwd2_pair<2, true>), (B + 1) / 2, 256)
+        XVARIANT("row over 2 waves, 4 rows / workgroup", (fwd2_pair<4, true>), (B + 3) / 4, 512)
         VARIANT(1, 1, 0) VARIANT(1, 4, 0) VARIANT(1, 8, 0) VARIANT(1, 8, 1) VARIANT(1, 8, 2) VARIANT(1, 16, 2)
         VARIANT(2, 2, 0) VARIANT(2, 4, 0) VARIANT(2, 8, 2)
         VARIANT(4, 2, 0) VARIANT(4, 4, 0) VARIANT(4, 4, 2) VARIANT(4, 8, 0)

@@ -1390,6 +1390,7 @@ struct RcclApi {
     const char *(*GetErrorString)(int);
     int (*CommCount)(void *, int *);
     int (*GetVersion)(int *);
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t);
 };
 RcclApi g_rccl = {};
 
@@ -1410,6 +1411,7 @@ int rccl_bind() {
     a.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
     a.CommCount = (int (*)(void *, int *))dlsym(h, "ncclCommCount");
     a.GetVersion = (int (*)(int *))dlsym(h, "ncclGetVersion");
+    a.Broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclBroadcast");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString)
         return fz_set_error(FZ_E_RCCL, "librccl.so.1 lacks an expected symbol");
     a.handle = h;
@@ -1474,6 +1476,17 @@ int fz_rccl_version(int *out_version) {
     FZ_TRY(rccl_bind());
     if (!g_rccl.GetVersion) return fz_set_error(FZ_E_RCCL, "librccl.so.1 lacks ncclGetVersion");
     return rccl_check(g_rccl.GetVersion(out_version), "ncclGetVersion");
+}
+
+int fz_broadcast_i32(fz_ctx *ctx, fz_comm *comm, int32_t *d_buf, size_t count, int root) {
+    FZ_REQUIRE(ctx && comm && (count == 0 || d_buf), "NULL argument");
+    FZ_REQUIRE(root >= 0 && root < comm->nranks, "root outside the communicator");
+    if (comm->device != ctx->device) return fz_set_error(FZ_E_BADARG, "communicator was created on device %d", comm->device);
+    FZ_DEV(ctx);
+    if (count == 0) return FZ_OK;
+    if (!g_rccl.Broadcast) return fz_set_error(FZ_E_RCCL, "librccl.so.1 lacks ncclBroadcast");
+    // in place, ncclInt32 (= 2), on the context's stream like the all-reduce
+    return rccl_check(g_rccl.Broadcast(d_buf, d_buf, count, 2, root, comm->comm, ctx->stream), "ncclBroadcast");
 }
 
 int fz_allreduce_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, size_t count) {

@@ -177,6 +177,10 @@ class Context:
         """in-place ncclAllReduce(int64, sum) on this context's stream (comm: a Comm)"""
         check(self._lib, self._lib.fz_allreduce_i64(self._h, comm._c, c_void_p(d_buf), count))
 
+    def broadcast_i32_dev(self, comm, d_buf, count, root=0):
+        """rank root's int32 buffer to every rank's (ncclBroadcast through the C ABI, in place, on the context's stream)"""
+        check(self._lib, self._lib.fz_broadcast_i32(self._h, comm._c, c_void_p(d_buf), count, root))
+
     def challenge_dev(self, P, d_vk, prehash, N, d_out, transform=True):
         """hash_ch on the device for N (key, message) pairs: P a SchemeParams, d_vk [N][2][degree] (device), prehash
         [N][32] uint8 (host, hostpipe.hash_messages), d_out [N][degree] (device): c_hat, or the coefficient rows

@@ -46,18 +46,60 @@ def sharded_sum(partial_fn: Callable[[int, int], "object"], total: int, rank: in
     return allreduce_sum_i64(partial_fn(lo, hi), group)
 
 
+def sharded_alpha(rank: int, world: int, mode: str, coll, n: int, d: int, compute):
+    """hash_ag's aggregation-coefficient rows [n][d] (callers' order) on this rank.  `compute()` runs the global sort by
+    str(vk) and the ONE serial SHAKE-256 over the whole sorted list (fusion.py:586-591, :632-652, :661-663) and returns them.
+      mode "replicated": every rank calls compute() -- no exchange, every rank pays the sponge;
+      mode "root":       rank 0 alone calls compute() and broadcasts the rows (n * d int32: 1 MiB at 1024 signers) while the
+                         other ranks do their own block's work; they join the broadcast when they need the rows.
+    Pure host logic (tests/test_dist_cpu.py runs it at world 8 over gloo); the wall time is the sponge's in both modes --
+    it is serial by construction -- but in "root" mode it costs ONE core of the node instead of one per rank."""
+    if mode not in ("replicated", "root"):
+        raise ValueError(f"alpha mode {mode!r}: 'replicated' or 'root'")
+    if mode == "replicated" or world == 1:
+        return compute()
+    if rank == 0:
+        alpha = compute()
+        coll.broadcast_i32(alpha, (n, d), 0)
+        return alpha
+    return coll.broadcast_i32(None, (n, d), 0)
+
+
+def resolve_alpha_mode(mode: str, world: int) -> str:
+    """"auto": the sponge on rank 0 alone from four ranks on (it then occupies one core of the node instead of world cores;
+    measured over gloo, profiles/r04_sharded_alpha_modes.txt), on every rank below (no broadcast in the path)."""
+    if mode == "auto":
+        return "root" if world >= 4 else "replicated"
+    return mode
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # End-to-end sharded aggregate() / verify() (BASELINE configs[3]; SURVEY.md 8e; fusion/fusion.py:655-677, :680-728)
 # ---------------------------------------------------------------------------------------------------------------
 class TorchCollective:
     """The exchange step over torch.distributed (backend "nccl" = RCCL over xGMI with one GPU per rank; "gloo" when ranks
-    share a GPU, as in the tests).  Buffers are torch tensors; the library's kernels read and write them by pointer."""
+    share a GPU, as in the tests).  Buffers are torch tensors; the library's kernels read and write them by pointer.
+    device=None: host tensors only (the CPU rehearsal of the host logic: broadcast_i32)."""
     name = "torch.distributed all_reduce"
 
     def __init__(self, ctx, device, group=None):
         import torch
         self.ctx, self.group = ctx, group
-        self.device = torch.device("cuda", device)
+        self.device = torch.device("cuda", device) if device is not None else None
+
+    def broadcast_i32(self, arr, shape, root=0):
+        """rank `root` passes the int32 array, the others None: -> the array on every rank (host memory)"""
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        on_dev = self.device is not None and dist.get_backend(self.group) == "nccl"
+        if arr is not None:
+            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32).reshape(shape))
+            t = t.to(self.device) if on_dev else t
+        else:
+            t = torch.empty(shape, dtype=torch.int32, device=self.device if on_dev else "cpu")
+        dist.broadcast(t, src=root, group=self.group)
+        return t.cpu().numpy() if arr is None else np.asarray(arr, dtype=np.int32).reshape(shape)
 
     def alloc_i64(self, count):
         import torch
@@ -106,6 +148,20 @@ class CommCollective:
     def allreduce(self, buf):
         self.ctx.allreduce_i64_dev(self.comm, buf.ptr, buf.shape[0])
 
+    def broadcast_i32(self, arr, shape, root=0):
+        """ncclBroadcast through the C ABI (fz_broadcast_i32) on the context's stream; host array in, host array out"""
+        from .context import DeviceArray
+        import numpy as np
+        if arr is not None:
+            buf = DeviceArray.from_numpy(self.ctx, np.ascontiguousarray(arr, dtype=np.int32).reshape(shape))
+        else:
+            buf = DeviceArray(self.ctx, shape)
+        try:
+            self.ctx.broadcast_i32_dev(self.comm, buf.ptr, int(np.prod(shape)), root)
+            return buf.numpy() if arr is None else np.asarray(arr, dtype=np.int32).reshape(shape)
+        finally:
+            buf.free()
+
     @staticmethod
     def to_numpy(buf):
         return buf.numpy()
@@ -126,6 +182,9 @@ class LocalCollective(CommCollective):
     def allreduce(self, buf):
         pass
 
+    def broadcast_i32(self, arr, shape, root=0):
+        return arr
+
 
 class ShardedScheme:
     """aggregate() and verify() of the reference with the SIGNERS sharded over ranks -- one process per GPU, rank r holds
@@ -133,11 +192,12 @@ class ShardedScheme:
 
     Who computes what, and why:
       * Verification keys and messages are public and small (2 KiB per signer); every rank has all of them.
-      * The global sort by str(vk) (fusion.py:661-663, :693), the per-signer challenges and hash_ag's ONE serial SHAKE-256
-        over the whole sorted list (fusion.py:586-591, :632-652) run REDUNDANTLY on every rank: the sponge is serial by
-        construction and bounds the wall time wherever it runs, so computing it once and broadcasting would only add a
-        dependency on the slowest rank plus a collective; the challenges of all N signers cost a rank's GPU the same
-        ~0.75 ms latency chain as N / world of them.  Every rank therefore derives bit-identical alpha without any exchange.
+      * The global sort by str(vk) (fusion.py:661-663, :693) and hash_ag's ONE serial SHAKE-256 over the whole sorted list
+        (fusion.py:586-591, :632-652) are serial by construction and bound the wall time wherever they run (alpha_mode):
+        "replicated" -- every rank runs them (bit-identical alpha without any exchange; world cores busy with the same
+        sponge); "root" -- rank 0 alone runs them and broadcasts the coefficient rows (1 MiB at 1024 signers) while the other
+        ranks compute only THEIR block's challenges and upload their rows; "auto" = root from four ranks on (sharded_alpha).
+        Neither form scales with the rank count: only the algebra after it does.
       * alpha is scattered back to the callers' order on the host (a permutation of 1 KiB rows) and each rank uploads and
         transforms ONLY its block.
       * Each rank makes ONE pass over its signers (fz_aggregate_target_partial_batch): exact int64 partial sums of the
@@ -147,16 +207,17 @@ class ShardedScheme:
         from the sums (fz_verify_partials_batch_async).  Integer sums are associative: bit-identical for any world size.
     """
 
-    def __init__(self, scheme, rank, world, collective):
+    def __init__(self, scheme, rank, world, collective, alpha_mode="auto"):
         self.bs, self.rank, self.world, self.coll = scheme, int(rank), int(world), collective
         self.ctx, self.d, self.l = scheme.ctx, scheme.d, scheme.l
+        self.alpha_mode = resolve_alpha_mode(alpha_mode, self.world)
 
     def block(self, n):
         return shard_range(n, self.rank, self.world)
 
     def _local_operands(self, vk_all, messages_all):
-        """-> (n, lo, hi, dC_all, dAl_local, dL, dR): challenges of ALL signers (device, callers' order), alpha_hat / vk rows
-        of this rank's block"""
+        """-> (n, lo, hi, dC, c_row0, dAl, dL, dR): challenges on the device (dC, this rank's block starting at row c_row0),
+        alpha_hat / vk rows of this rank's block"""
         import numpy as np
         from .context import DeviceArray
         bs = self.bs
@@ -165,10 +226,19 @@ class ShardedScheme:
         if n != len(messages_all):
             raise ValueError("Number of keys and messages must be equal.")
         lo, hi = self.block(n)
-        dC, c_hat, pre = bs._challenges_both(vk, messages_all)
+        m = hi - lo
+        everything = self.alpha_mode == "replicated" or self.world == 1 or self.rank == 0
+        if everything:                                   # this rank runs the sponge: it needs every signer's challenge
+            dC, c_hat, pre = bs._challenges_both(vk, messages_all)
+            c_row0 = lo
+        elif m:                                          # "root" mode, not the root: its own block's challenges only
+            dC, _, _ = bs._challenges_both(vk[lo:hi], messages_all[lo:hi])
+            c_row0 = 0
+        else:
+            dC, c_row0 = DeviceArray(self.ctx, (1, self.d)), 0
         try:
-            _, alpha = bs._alpha_coefficients(L, R, pre, c_hat)                  # redundantly on every rank (see the class docstring)
-            m = hi - lo
+            alpha = sharded_alpha(self.rank, self.world, self.alpha_mode, self.coll, n, self.d,
+                                  (lambda: bs._alpha_coefficients(L, R, pre, c_hat)[1]) if everything else None)
             dAl = DeviceArray.from_numpy(self.ctx, np.ascontiguousarray(alpha[lo:hi]))
             if m:
                 self.ctx.ntt_forward_dev(dAl.ptr, dAl.ptr, m)
@@ -177,7 +247,7 @@ class ShardedScheme:
         except Exception:
             dC.free()
             raise
-        return n, lo, hi, dC, dAl, dL, dR
+        return n, lo, hi, dC, c_row0, dAl, dL, dR
 
     def aggregate_verify_sharded(self, vk_all, messages_all, sig_local):
         """-> (aggregate [l][d] int32, (ok, reason)) on EVERY rank.  sig_local: this rank's signatures [hi - lo][l][d]
@@ -186,7 +256,7 @@ class ShardedScheme:
         import numpy as np
         from .context import DeviceArray, VERDICT_REASONS
         bs, ctx, l, d = self.bs, self.ctx, self.l, self.d
-        n, lo, hi, dC, dAl, dL, dR = self._local_operands(vk_all, messages_all)
+        n, lo, hi, dC, c_row0, dAl, dL, dR = self._local_operands(vk_all, messages_all)
         m = hi - lo
         dS, own = bs._dev(sig_local, (m, l, d))
         part = self.coll.alloc_i64(l * d + d)                # zeros: a rank without signers contributes nothing
@@ -195,7 +265,7 @@ class ShardedScheme:
         dO = DeviceArray(ctx, (l, d))
         try:
             if m:
-                ctx.aggregate_target_partial_batch_dev(dS.ptr, dAl.ptr, dL.ptr, dR.ptr, dC.ptr + lo * d * 4, pp, l * d,
+                ctx.aggregate_target_partial_batch_dev(dS.ptr, dAl.ptr, dL.ptr, dR.ptr, dC.ptr + c_row0 * d * 4, pp, l * d,
                                                        pp + l * d * 8, d, 1, m, l)
             self.coll.allreduce(part)                         # the ONE exchange step
             ctx.reduce_i64_dev(pp, dO.ptr, l * d)
@@ -229,7 +299,7 @@ class ShardedScheme:
             return False, VERDICT_REASONS[1]
         if nk != len(messages_all):
             return False, VERDICT_REASONS[2]
-        n, lo, hi, dC, dAl, dL, dR = self._local_operands(vk_all, messages_all)
+        n, lo, hi, dC, c_row0, dAl, dL, dR = self._local_operands(vk_all, messages_all)
         m = hi - lo
         dS, own = bs._dev(aggregate, (l, d))
         part = self.coll.alloc_i64(d)
@@ -237,7 +307,7 @@ class ShardedScheme:
         dT = DeviceArray(ctx, (d,))
         try:
             if m:
-                ctx.target_partial_dev(dL.ptr, dR.ptr, dC.ptr + lo * d * 4, dAl.ptr, pp, m)
+                ctx.target_partial_dev(dL.ptr, dR.ptr, dC.ptr + c_row0 * d * 4, dAl.ptr, pp, m)
             self.coll.allreduce(part)
             ctx.reduce_i64_dev(pp, dT.ptr, d)
             code = ctx.verify_with_target_dev(bs._A_dev().ptr, dS.ptr, dT.ptr, l, int(bs.params.beta_vf), int(bs.params.omega_vf))

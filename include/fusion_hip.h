@@ -305,6 +305,10 @@ FZ_API int fz_comm_info(fz_comm *comm, int *out_nranks, int *out_rank);
  * multi-GPU record shows which library carried the exchange step */
 FZ_API int fz_rccl_version(int *out_version);
 FZ_API int fz_allreduce_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, size_t count);
+/* rank `root`'s d_buf [count] int32 to every rank's d_buf (ncclBroadcast, in place, on the context's stream): how the rank
+ * that ran hash_ag's serial sponge (fusion.py:632-652) hands the aggregation-coefficient rows to the others
+ * (fusion_hip.dist.ShardedScheme, alpha_mode "root") */
+FZ_API int fz_broadcast_i32(fz_ctx *ctx, fz_comm *comm, int32_t *d_buf, size_t count, int root);
 
 /* ---- launch-floor diagnostics (benchmarks) ---------------------------------------------------------------------
  * An empty 4096-workgroup dispatch and a plain 16-byte-per-lane copy on the context's stream: the two floors a

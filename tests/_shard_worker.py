@@ -3,7 +3,8 @@ reference-generated signer set.  Every rank regenerates ONLY its block's keys an
 (BatchScheme.keygen_batch / sign_batch from the golden seeds and messages), takes all verification keys from the golden file
 (they are public), and runs aggregate_verify_sharded / verify_sharded with a real torch.distributed collective (gloo: the
 ranks share the test box's one GPU; with a GPU per rank the same code runs over RCCL).
-argv: rank world port secpar kind lo hi out_dir      kind = "many" (scheme_many_*.npz) | "small" (scheme_*.npz)"""
+argv: rank world port secpar kind lo hi out_dir [alpha_mode]      kind = "many" (scheme_many_*.npz) | "small" (scheme_*.npz)
+alpha_mode: "replicated" (the serial sponge of hash_ag on every rank) | "root" (rank 0 alone + broadcast) | "auto" """
 import hashlib
 import json
 import os
@@ -14,6 +15,7 @@ for p in (os.path.join(ROOT, "fusion-cryptography_amd"), ROOT):
     sys.path.insert(0, p)
 rank, world, port, secpar = (int(x) for x in sys.argv[1:5])
 kind, lo_s, hi_s, out_dir = sys.argv[5], int(sys.argv[6]), int(sys.argv[7]), sys.argv[8]
+alpha_mode = sys.argv[9] if len(sys.argv) > 9 else "auto"
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -49,7 +51,7 @@ msgs = meta["messages"][lo_s:hi_s]
 seeds = meta["key_seeds"][lo_s:hi_s]
 n = hi_s - lo_s
 lo, hi = shard_range(n, rank, world)
-sh = ShardedScheme(bs, rank, world, TorchCollective(bs.ctx, 0))
+sh = ShardedScheme(bs, rank, world, TorchCollective(bs.ctx, 0), alpha_mode=alpha_mode)
 if hi > lo:                                       # this rank's block: keys and signatures made here, resident on the device
     sk, vk_loc, vk_dev = bs.keygen_batch(seeds[lo:hi], device=True, keep_vk=True)
     assert np.array_equal(vk_loc, vk_all[lo:hi]), "regenerated verification keys differ from the reference's"

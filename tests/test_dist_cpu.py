@@ -69,3 +69,70 @@ def test_shard_range_properties():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def _run_host_ranks(world, tag, n, mode, tmp_path):
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "_shard_host_worker.py"), str(r), str(world), str(port), tag, str(n), mode,
+                               str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p_ in procs:
+        try:
+            outs.append(p_.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q_ in procs:
+                q_.kill()
+            pytest.fail("a rank did not finish")
+    assert all(p_.returncode == 0 for p_ in procs), "\n".join(o[-3000:] for o in outs)
+    return ([np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)],
+            [json.load(open(os.path.join(str(tmp_path), f"rank{r}.json"))) for r in range(world)])
+
+
+@pytest.mark.parametrize("tag,n,mode", [("256", 1024, "auto"), ("256", 1024, "replicated"), ("256cap", 2818, "root"), ("256", 5, "auto"),
+                                        ("128", 1796, "auto")])
+def test_sharded_host_logic_at_world_8(tag, n, mode, tmp_path):
+    """The sharded aggregate() + verify() at EIGHT ranks over gloo, without a GPU: the host logic of fusion_hip.dist
+    (blocks, the serial sponge on every rank or on rank 0 alone + broadcast, the scatter back to the callers' order, the int64
+    all-reduce) with the C oracle standing in for the device steps -- BASELINE configs[3] at its stated size (1024 signers,
+    128 per rank), both parameter sets at their capacity (2818 / 1796 signers), and 5 signers on 8 ranks (three ranks own
+    none).  Every rank must hold the aggregate the REFERENCE computed over all signers (fusion.py:655-677) and its verdict."""
+    import json
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(G, "scheme_full.json")) as fh:
+        m = json.load(fh)[tag]
+    world = 8
+    R, J = _run_host_ranks(world, tag, n, mode, tmp_path)
+    sizes = [int(r["hi"]) - int(r["lo"]) for r in R]
+    assert sum(sizes) == n and max(sizes) - min(sizes) <= 1 and int(R[0]["lo"]) == 0
+    assert all(int(a["hi"]) == int(b["lo"]) for a, b in zip(R, R[1:]))
+    if n < world:
+        assert sizes.count(0) == world - n
+    assert len({str(r["alpha_sha"]) for r in R}) == 1                  # every rank derived / received the same coefficients
+    want_mode = {"auto": "root", "root": "root", "replicated": "replicated"}[mode]
+    assert all(j["mode"] == want_mode for j in J)
+    assert [j["ran_sponge"] for j in J] == ([True] + [False] * 7 if want_mode == "root" else [True] * 8)
+    for r, j in zip(R, J):
+        assert j["verdict"] == [True, ""]
+        assert all(np.array_equal(r["agg"], R[0]["agg"]) for r in R)
+    if n == m["n"]:                                                      # the reference's own aggregate over all signers
+        S = np.load(os.path.join(G, f"scheme_full_{tag}.npz"))
+        assert str(R[0]["vk_sha"]) == m["sha256_vk"]
+        for r in R:
+            assert np.array_equal(r["agg"], S["agg"])
+
+
+def test_alpha_mode_resolution_and_errors():
+    from fusion_hip.dist import resolve_alpha_mode, sharded_alpha
+    assert [resolve_alpha_mode("auto", w) for w in (1, 2, 3, 4, 8)] == ["replicated", "replicated", "replicated", "root", "root"]
+    assert resolve_alpha_mode("root", 2) == "root" and resolve_alpha_mode("replicated", 8) == "replicated"
+    rows = np.arange(12, dtype=np.int32).reshape(3, 4)
+    assert sharded_alpha(0, 1, "root", None, 3, 4, lambda: rows) is rows        # one rank: no exchange in either mode
+    assert sharded_alpha(5, 8, "replicated", None, 3, 4, lambda: rows) is rows
+    with pytest.raises(ValueError):
+        sharded_alpha(0, 2, "sometimes", None, 3, 4, lambda: rows)

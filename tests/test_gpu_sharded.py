@@ -17,12 +17,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 G = os.path.join(HERE, "golden")
 
 
-def run_ranks(world, args, tmp_path):
+def run_ranks(world, args, tmp_path, mode="auto"):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_shard_worker.py"), str(r), str(world), str(port)] + [str(a) for a in args]
-                              + [str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+                              + [str(tmp_path), mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
         try:
@@ -36,13 +36,16 @@ def run_ranks(world, args, tmp_path):
             [json.load(open(os.path.join(str(tmp_path), f"rank{r}.json"))) for r in range(world)])
 
 
-@pytest.mark.parametrize("secpar,lo,hi,world", [(128, 0, 32, 3), (256, 0, 16, 2), (128, 5, 17, 2), (256, 3, 9, 3)])
-def test_sharded_flow_equals_the_reference_on_many_signers(secpar, lo, hi, world, tmp_path):
+@pytest.mark.parametrize("secpar,lo,hi,world,mode", [(128, 0, 32, 3, "replicated"), (256, 0, 16, 2, "root"), (128, 5, 17, 2, "auto"),
+                                                     (256, 3, 9, 3, "root"), (128, 0, 5, 4, "auto")])
+def test_sharded_flow_equals_the_reference_on_many_signers(secpar, lo, hi, world, mode, tmp_path):
     S = np.load(os.path.join(G, f"scheme_many_{secpar}.npz"))
     with open(os.path.join(G, "scheme_many.json")) as fh:
         m = json.load(fh)[str(secpar)]
     info = m["agg"][f"{lo}_{hi}"]
-    R, J = run_ranks(world, [secpar, "many", lo, hi], tmp_path)
+    # "root": rank 0 alone runs hash_ag's serial sponge and broadcasts the coefficient rows, the other ranks compute only their
+    # block's challenges ("auto" = root from four ranks on)
+    R, J = run_ranks(world, [secpar, "many", lo, hi], tmp_path, mode)
     assert int(R[0]["lo"]) == 0 and int(R[-1]["hi"]) == hi - lo and all(int(a["hi"]) == int(b["lo"]) for a, b in zip(R, R[1:]))
     shas = [x for r in R for x in r["sig_sha"].tolist()]
     assert shas == m["sha256_sig_rows"][lo:hi]                 # the signatures each rank made are the reference's
@@ -54,9 +57,10 @@ def test_sharded_flow_equals_the_reference_on_many_signers(secpar, lo, hi, world
         assert j["short"] == [False, "Number of keys and messages must be equal."]
 
 
-@pytest.mark.parametrize("secpar,n,world", [(128, 4, 3), (256, 4, 2), (256, 1, 2)])
+@pytest.mark.parametrize("secpar,n,world", [(128, 4, 3), (256, 4, 2), (256, 1, 2), (256, 2, 4)])
 def test_sharded_flow_equals_the_reference_small(secpar, n, world, tmp_path):
-    """scheme_{128,256}.npz (4 keys; aggregates of 1 / 2 / 4): with one signer and two ranks the second rank owns no signer"""
+    """scheme_{128,256}.npz (4 keys; aggregates of 1 / 2 / 4): with one signer and two ranks the second rank owns no signer;
+    two signers on four ranks ("auto" = the sponge on rank 0 alone): two ranks own nobody and still join the broadcast"""
     S = np.load(os.path.join(G, f"scheme_{secpar}.npz"))
     with open(os.path.join(G, "scheme.json")) as fh:
         m = json.load(fh)[str(secpar)]
@@ -67,8 +71,8 @@ def test_sharded_flow_equals_the_reference_small(secpar, n, world, tmp_path):
         assert j["tampered"] == m["agg"][str(n)]["tampered_verdict"]
 
 
-@pytest.mark.parametrize("tag,world", [("256", 3), ("128", 2), ("256cap", 2)])
-def test_sharded_at_full_size_equals_the_reference(tag, world, tmp_path):
+@pytest.mark.parametrize("tag,world,mode", [("256", 3, "root"), ("128", 2, "replicated"), ("256cap", 2, "root")])
+def test_sharded_at_full_size_equals_the_reference(tag, world, mode, tmp_path):
     """BASELINE configs[3]: 1024 signers at secpar 256 sharded over 3 ranks (342 / 341 / 341 signatures each, resident on the
     device), and secpar 128 at its capacity (1796 signers) over 2 ranks, against the aggregates the REFERENCE computed over all
     of them (tests/golden/scheme_full_*.npz)"""
@@ -78,7 +82,7 @@ def test_sharded_at_full_size_equals_the_reference(tag, world, tmp_path):
     S = np.load(p)
     with open(os.path.join(G, "scheme_full.json")) as fh:
         m = json.load(fh)[tag]
-    R, J = run_ranks(world, [m["secpar"], "full:" + tag, 0, m["n"]], tmp_path)
+    R, J = run_ranks(world, [m["secpar"], "full:" + tag, 0, m["n"]], tmp_path, mode)
     assert sum(int(r["hi"]) - int(r["lo"]) for r in R) == m["n"] and max(int(r["hi"]) - int(r["lo"]) for r in R) - min(int(r["hi"]) - int(r["lo"]) for r in R) <= 1
     for r, j in zip(R, J):
         assert str(r["vk_sha"]) == m["sha256_vk"]

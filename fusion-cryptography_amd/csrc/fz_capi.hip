@@ -307,57 +307,29 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         free(pairs);
     }
     {
-        const char *e = getenv("FZ_NTT_KERNEL");
-        c->force_kernel = e ? atoi(e) : 0;
-        e = getenv("FZ_FUSED_TW");
-        c->knob_fused_tw = e ? atoi(e) : 0;
-        e = getenv("FZ_FUSED_PREFETCH");
-        c->knob_fused_prefetch = e ? atoi(e) : 0;
-        e = getenv("FZ_FUSED_ROWS");
-        c->knob_fused_rows = e ? atoi(e) : 0;
-        e = getenv("FZ_NTT_WAVES");
-        c->knob_ntt_waves = e ? atoi(e) : 0;
-        e = getenv("FZ_NTT_ROWS");
-        c->knob_ntt_rows = e ? atoi(e) : 0;
-        e = getenv("FZ_NTT_GRID_MULT");
-        c->grid_mult = e ? atoi(e) : 1;
-        if (c->grid_mult < 1) c->grid_mult = 1;
-        e = getenv("FZ_NTT_SMALL_ROWS");
+        // every benchmarking / test knob is read HERE, once: no entry point consults the environment afterwards (DESIGN.md
+        // section 10 lists them; round 4 removed the knobs of closed experiments together with their instantiations)
+        auto knob = [](const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; };
+        c->force_kernel = knob("FZ_NTT_KERNEL");
+        c->knob_ntt_rows = knob("FZ_NTT_ROWS");
         // measured crossover, inputs NOT cache-resident, both schedules on one box (profiles/r03_ntt_crossover.txt): degree 256 --
         // the radix-4 kernels lead up to 2^15 rows (4.19 / 5.50 / 8.44 / 15.35 us at 2^12 .. 2^15 against 4.92 / 6.36 / 9.17 /
         // 15.86 for the 16-per-lane kernel), the 16-per-lane kernel from 2^16 (28.2 us against 32.3); degree 64 -- radix-4 up to
         // 2^18 rows (round 2's measurement)
-        c->small_batch_rows = e ? atoi(e) : (degree == 256 ? (1 << 16) : (1 << 19));
-        // every benchmarking knob is read HERE, once: no entry point consults the environment afterwards
-        auto knob = [](const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; };
-        c->knob_agg_twopass = knob("FZ_AGG_TWOPASS");
-        c->knob_agg_waves = knob("FZ_AGG_WAVES");
-        if (c->knob_agg_waves != 4 && c->knob_agg_waves != 8) c->knob_agg_waves = 0;
-        c->knob_agg_slices = knob("FZ_AGG_SLICES");
+        c->small_batch_rows = degree == 256 ? (1 << 16) : (1 << 19);
         c->knob_agg_direct = knob("FZ_AGG_DIRECT");
-        // flat grids (one 16-byte item per thread) for the elementwise streaming kernels: 45.0 us instead of 49.7 per 1024
-        // signatures (cold) for sign_core, the same for the pointwise kernels, against a grid capped at 8 workgroups per CU
-        c->knob_stream_per_cu = getenv("FZ_STREAM_PER_CU") ? knob("FZ_STREAM_PER_CU") : 0;
-        c->knob_stream_nt = knob("FZ_STREAM_NT");
         c->knob_shake_full = knob("FZ_SHAKE_FORM");
-        c->knob_verify_blocks = knob("FZ_VERIFY_BLOCKS");
-        c->knob_verify_unfused = knob("FZ_VERIFY_UNFUSED");
         c->knob_verify_ordered = knob("FZ_VERIFY_ORDERED");
         // The fence-free cross-workgroup combine of verify_fused (relaxed agent-scope atomics on the library's own
         // coarse-grained scratch, ordered by data dependence: csrc/fz_ntt.hip) is an argument about THIS chip's memory-side
         // atomics; anything that does not report gfx950 gets the acquire/release instantiation.
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) c->knob_verify_ordered = 1;
-        c->knob_keygen_unfused = knob("FZ_KEYGEN_UNFUSED");
-        c->knob_polymul_unfused = knob("FZ_POLYMUL_UNFUSED");
+        c->knob_unfused = knob("FZ_UNFUSED");
         c->knob_no_imad = knob("FZ_NO_IMAD");
         c->knob_matvec_slices = knob("FZ_MATVEC_SLICES");
-        c->knob_verify16 = knob("FZ_VERIFY16");
-        // fz_malloc's block pool: FZ_POOL_MB megabytes at most (default 4096, 0 = every fz_free is a hipFree)
-        c->pool_cap = (size_t)(getenv("FZ_POOL_MB") ? (knob("FZ_POOL_MB") < 0 ? 0 : knob("FZ_POOL_MB")) : 4096) << 20;
-        c->knob_sampler_one_kernel = knob("FZ_SAMPLER_ONE_KERNEL");
-        c->knob_keygen_bcast_general = knob("FZ_KEYGEN_BCAST_GENERAL");
-        c->knob_verify16_nopf = knob("FZ_VERIFY16_NOPF");
         c->knob_verify_cent = knob("FZ_VERIFY_CENT");
+        // fz_malloc's block pool: FZ_POOL_MB megabytes at most over all contexts of the process (default 4096, 0 = every fz_free is a hipFree)
+        c->pool_cap = (size_t)(getenv("FZ_POOL_MB") ? (knob("FZ_POOL_MB") < 0 ? 0 : knob("FZ_POOL_MB")) : 4096) << 20;
     }
     if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
     if (rc == FZ_OK) rc = upload_doubles(itwB, nB, &c->d_itwB);
@@ -851,7 +823,7 @@ int fz_poly_mul(fz_ctx *ctx, const int32_t *d_f, const int32_t *d_g, int32_t *d_
     FZ_DEV(ctx);
     if (ctx->logd < 0) return fz_set_error(FZ_E_UNSUPPORTED, "ring-only context (created with root 0) has no transforms");
     if (batch == 0) return FZ_OK;
-    if ((ctx->logd == 6 || ctx->logd == 8) && !ctx->knob_polymul_unfused) {
+    if ((ctx->logd == 6 || ctx->logd == 8) && !ctx->knob_unfused) {
         if ((((uintptr_t)d_f | (uintptr_t)d_g | (uintptr_t)d_out) & 3) != 0)
             return fz_set_error(FZ_E_BADARG, "buffers must be 4-byte aligned");
         return fz_launch_polymul_fused(ctx, d_f, d_g, d_out, batch);
@@ -912,7 +884,7 @@ int fz_keygen_core(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef, int32
     FZ_DEV(ctx);
     // sk_hat = NTT(every secret row); vk_{L,R} = A . sk_hat_{L,R}   (fusion/fusion.py:363-370)
     if (batch == 0) return FZ_OK;
-    if ((ctx->logd == 6 || ctx->logd == 8) && batch * 2 <= 0x7fffffffu && !ctx->knob_keygen_unfused &&
+    if ((ctx->logd == 6 || ctx->logd == 8) && batch * 2 <= 0x7fffffffu && !ctx->knob_unfused &&
         ((((uintptr_t)d_A | (uintptr_t)d_coef | (uintptr_t)d_sk_hat) & 15) == 0))
         return fz_launch_keygen_fused(ctx, d_A, d_coef, d_sk_hat, d_vk, batch * 2, l);   // one launch, sk_hat not re-read
     FZ_TRY(fz_launch_ntt(ctx, d_coef, d_sk_hat, batch * 2 * (size_t)l, false));
@@ -924,7 +896,7 @@ int fz_keygen_core_bcast(fz_ctx *ctx, const int32_t *d_A, const int32_t *d_coef,
     FZ_REQUIRE(ctx && l >= 1 && (batch == 0 || (d_A && d_coef && d_sk_hat && d_vk)), "bad argument");
     FZ_DEV(ctx);
     if (batch == 0) return FZ_OK;
-    if ((ctx->logd == 6 || ctx->logd == 8) && batch * 2 <= 0x7fffffffu && !ctx->knob_keygen_unfused &&
+    if ((ctx->logd == 6 || ctx->logd == 8) && batch * 2 <= 0x7fffffffu && !ctx->knob_unfused &&
         ((((uintptr_t)d_A | (uintptr_t)d_coef | (uintptr_t)d_sk_hat) & 15) == 0))
         return fz_launch_keygen_fused(ctx, d_A, d_coef, d_sk_hat, d_vk, batch * 2, l, true);
     // generic degrees: expand the rows in sk_hat, transform in place, then the products
@@ -1094,7 +1066,7 @@ int fz_verify_with_target_batch(fz_ctx *ctx, const int32_t *d_A, const int32_t *
         FZ_HIP(hipMalloc((void **)&ctx->d_verdict, groups * sizeof(int)), "verdict alloc");
         ctx->verdict_cap = groups;
     }
-    if ((ctx->logd == 6 || ctx->logd == 8) && !ctx->knob_verify_unfused) {
+    if ((ctx->logd == 6 || ctx->logd == 8) && !ctx->knob_unfused) {
         // one launch: sigma read once (matvec + inverse transforms + norm/weight + verdict fused)
         FZ_TRY(fz_launch_verify_fused(ctx, d_A, d_sig, d_target, groups, l, beta_vf, omega_vf, ctx->d_verdict));
         return fz_memcpy_d2h(ctx, h_verdicts, ctx->d_verdict, groups * sizeof(int));
@@ -1328,7 +1300,7 @@ int fz_sample_secret_polys_dev(fz_ctx *ctx, const uint64_t *h_seeds, size_t N, i
     // everything after it on a wave per generator, the states (20 MiB at most) through scratch: 54 + 29 us per 1024 keys
     // against 190 in one kernel.  Beyond, the one lane-per-polynomial kernel already has a wave on every CU and the two
     // forms take the same time (16 384 keys: 0.47 ms one kernel, 0.56 ms in four chunks of two).  FZ_SAMPLER_ONE_KERNEL=1 forces it.
-    const bool two_kernels = !ctx->knob_sampler_one_kernel && bound < (1ll << 31) && N <= 4096;
+    const bool two_kernels = bound < (1ll << 31) && N <= 4096;
     const size_t seeds_bytes = (N * 8 + 255) & ~(size_t)255, state_bytes = two_kernels ? N * 2 * 624 * sizeof(uint32_t) : 0;
     void *scr = nullptr;
     FZ_TRY(fz_scratch(ctx, 256 + seeds_bytes + state_bytes, &scr));

@@ -33,7 +33,7 @@ struct fz_ctx {
     double *d_twB, *d_itwB;      // per-lane tables of the contiguous pass, [NE][L] pairs (w, w*K/q)
     double *d_tw2, *d_itw2;      // full tables as (w, w*K/q) pairs, [degree] (radix-4 kernels)
     int small_batch_rows;        // below this many rows the radix-4 (4 coefficients per lane) kernels run
-    int force_kernel;            // 0 auto, 4 radix-4, 16 sixteen-per-lane (env FZ_NTT_KERNEL; benchmarking)
+    int force_kernel;            // 0 auto, 4 radix-4, 16 sixteen-per-lane (env FZ_NTT_KERNEL; tests and A/B runs)
     FzTwA twA, itwA;
     // growable device scratch (host-pointer entry points, int64 partial sums)
     void *d_scratch, *d_scratch2;
@@ -42,11 +42,6 @@ struct fz_ctx {
     size_t verdict_cap;
     int grid_fwd, grid_inv;      // resident-grid caps for the persistent NTT kernels
     int grid_pm;                 // resident grid of the fused product kernel (0 = not queried yet)
-    int grid_mult;               // grid = resident blocks x grid_mult (env FZ_NTT_GRID_MULT; 1 = persistent): 16-per-lane and multi-job kernels
-    int knob_fused_tw;           // FZ_FUSED_TW = 1: the fused kernels keep per-lane twiddles as w alone and recompute w * K/q (fewer registers)
-    int knob_fused_prefetch;     // FZ_FUSED_PREFETCH = 1 | 2: iterations a wave of the fused keygen kernel requests its rows ahead (0 = 1)
-    int knob_fused_rows;         // FZ_FUSED_ROWS = 1 | 2: row groups per wave iteration in the fused keygen / verification kernels (0 = 1)
-    int knob_ntt_waves;          // FZ_NTT_WAVES = 1 | 4 | 8: waves per workgroup of the one-row-group radix-4 kernels (0 = 8)
     int knob_ntt_rows;           // FZ_NTT_ROWS = 1 | 2 | 4: row groups per wave of the radix-4 kernels (0 = by batch size)
     // per-dispatch timing of the NTT kernels (fz_profile_begin/end): event pairs bound to the
     // dispatch itself via hipExtLaunchKernelGGL, i.e. kernel begin -> kernel end on its own stream
@@ -70,18 +65,12 @@ struct fz_ctx {
     uint32_t *d_chal_tab;        // weight table of the challenge decoder (fz_challenge.hip), built on first use
     int chal_tab_ib, chal_tab_degree;
     // benchmarking knobs, read ONCE at context creation
-    int knob_agg_twopass, knob_agg_waves, knob_agg_slices;
     int knob_agg_direct;         // FZ_AGG_DIRECT: -1 = never the slice-free aggregation kernel, 2 | 4 = always, with that many rows per tile (0 = by size)
     int knob_shake_full;         // FZ_SHAKE_FORM: 1 = lane pairs, 2 = whole state per lane (0 = by batch size)
-    int knob_stream_nt;          // FZ_STREAM_NT: streaming (non-temporal) stores in the elementwise kernels
-    int knob_stream_per_cu;      // grid cap of the grid-stride streaming kernels in workgroups per CU (0 = flat grid)
-    int knob_verify_blocks, knob_verify_unfused, knob_verify_ordered, knob_keygen_unfused, knob_polymul_unfused;
+    int knob_verify_ordered;     // FZ_VERIFY_ORDERED=1 (and every device that is not gfx950): acquire / release on verify_fused's arrival atomic
+    int knob_unfused;            // FZ_UNFUSED=1: the multi-launch paths of keygen / verification / the coefficient-domain product (what degrees other than 64 / 256 take anyway)
     hipStream_t diag_stream;     // fz_diag_shader_clock: the probe's private stream and result words (created on first use)
     unsigned long long *d_diag;
-    int knob_keygen_bcast_general;   // FZ_KEYGEN_BCAST_GENERAL=1: fz_keygen_core_bcast through the general kernel (l transforms of the same row) as before round 3
-    int knob_sampler_one_kernel; // FZ_SAMPLER_ONE_KERNEL=1: the device key sampler as one lane-per-polynomial kernel (round 2) instead of seed + draw kernels
-    int knob_verify16;           // FZ_VERIFY16 = 1 .. 6: waves per workgroup of the 16-per-lane many-aggregates verification kernel (7 = best divisor of the tasks; 0 = off: the radix-4 kernel, the default)
-    int knob_verify16_nopf;      // FZ_VERIFY16_NOPF=1: verify_many16 requests a task's rows when it starts the task, not one task ahead (fewer registers)
     int knob_matvec_slices;      // FZ_MATVEC_SLICES = 1 | 2 | 4: k-range slices per column of the integer matvec kernel (0 = by batch size, -1 = the fp64 kernel)
     int knob_no_imad;            // FZ_NO_IMAD=1: A (.) y through the general fp64 multiply instead of integer multiply-adds (A/B runs)
     int knob_verify_cent;        // FZ_VERIFY_CENT=1: centre the inverse transform's outputs before the norm test even when beta allows skipping it

@@ -714,11 +714,12 @@ __global__ __launch_bounds__(64) void ntt_multi4(FzMultiJobs J, const double2 *_
 // the forward passes leave a lane's values at bit-reversed positions 4mm..4mm+3, exactly where the inverse picks up.
 // `out` may alias `f` or `g` (a wave has read its whole polynomials before it writes).
 // ------------------------------------------------------------------------------------------
-template <int LOGD, bool FAST, typename TW>
+template <int LOGD, bool FAST>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32_t *f, const int32_t *g, int32_t *out, size_t batch,
                                                                      const double2 *__restrict__ tw2,
                                                                      const double2 *__restrict__ itw2, FzTwA twA, FzTwA itwA,
                                                                      FzMod m) {
+    using TW = double2;
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
     __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256];
@@ -779,16 +780,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
 // traffic per lane and row instead of 16: keygen 79 -> 109 us per 1024 keys, verify 256 -> 270 us per 8192 aggregates,
 // profiles/r03_presplit_A_experiment.txt.)
 // (fz_imad_total, the sums' way back to fp64, lives in fz_arith.h.)
-// NR: row groups a wave takes through the transform passes together (fwd4_passes_n: one synchronisation per pass for NR rows,
-// NR independent fp64 dependency chains per wave).
-// PF: how many iterations ahead a wave requests its secret rows (1 or 2; a wave's rows are a sequential chain).  Measured: no
-// difference (see the launcher).
-template <int LOGD, bool FAST, bool IMAD, int NR, int PF, typename TW>
+// One row group per wave iteration, rows requested one iteration ahead, per-lane twiddles as (w, w * K/q) pairs: round 3 measured
+// two row groups, a second iteration of prefetch and twiddles kept as w alone (five waves per SIMD) -- 81.7 / 81.7 / 82.0 / 81.1
+// and 79.2 / 77.7 us per 1024 keys, all within 2 % (profiles/r03_keygen_ab.txt) -- and round 4 removed those instantiations.
+template <int LOGD, bool FAST, bool IMAD>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 6))) void keygen_fused(const int32_t *A, const int32_t *coef,
                                                                     size_t coef_seg_stride,
                                                                     size_t coef_row_stride, int32_t *sk_hat,
                                                                     int32_t *vk, int l, const double2 *__restrict__ tw2,
                                                                     FzTwA twA, FzMod m) {
+    constexpr int NR = 1, PF = 1;
+    using TW = double2;
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
     __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * 256 * (NR + 1)];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
@@ -983,12 +985,14 @@ __device__ __forceinline__ int centred_any(int64_t v, const FzMod &m) { return (
 // test needs no centring at all -- the inverse transform's outputs r satisfy |r| <= q/2 + q * 2^-13; if |r| <= beta then r is
 // already the centred residue and passes; if |r| > beta then |cent(r)| >= q - |r| >= q/2 - q * 2^-13 > beta (or cent(r) = r):
 // max |r| > beta <=> max |cent(r)| > beta.  Likewise r == 0 (mod q) <=> r == 0, since |r| < q.  Saves 8 of ~180 ops per row.
-template <int LOGD, bool FAST, typename T, bool ORDERED, bool IMAD, int NR, typename TW>
+template <int LOGD, bool FAST, typename T, bool ORDERED, bool IMAD>
 __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t *A, const T *sig,
                                                                   size_t sig_stride,
                                                                   const T *target, size_t target_stride, int l, long long beta,
                                                                   long long omega, int lazy, const double2 *__restrict__ itw2,
                                                                   FzTwA twA, FzMod m, double *part, int *state, int *verdict) {
+    constexpr int NR = 1;                 // one row group per wave iteration (two: 248.5 against 243.9 us per 8192 aggregates, round 3)
+    using TW = double2;
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
     static_assert(D <= 64 * kVerifyWaves, "one thread per coefficient in the combine steps");
     __shared__ __attribute__((aligned(16))) double lds[kVerifyWaves * 256 * (NR + 1)];
@@ -1150,186 +1154,6 @@ __global__ __launch_bounds__(64 * kVerifyWaves) void verify_fused(const int32_t 
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused verification of MANY aggregates per launch (one workgroup per aggregate), 16 coefficients per lane -- an experiment kept
-// behind FZ_VERIFY16 (see the launcher for what it measured): NOT the default.
-// With a workgroup per aggregate the kernel above is bound by vector issue and LDS, not by HBM; with nothing but registers and
-// LDS in the loop the 16-per-lane inverse transform (one LDS exchange per row, 4 rows of degree 256 per wave) runs 4925 rows/us
-// on the chip against 3190-3850 for the radix-4 structure (three exchanges per row; tools/microbench/ntt_structures.hip,
-// profiles/r03_ntt_structures.txt).  Same contract as verify_fused with gridDim.x == 1; per wave-task (1024 consecutive
-// values = 1024 / D rows of the aggregate):
-//   * four coalesced 16-byte loads per lane of sigma and of A (the next task's are requested before this task's passes);
-//   * observed += A (.) sigma in 64-bit integer multiply-adds IN THAT LAYOUT (lane i holds coefficients 4i .. 4i+3 (mod D) of
-//     every row it touches: four accumulator pairs per lane for the whole loop);
-//   * the int32 values go through the LDS staging image to the lane <-> coefficient mapping of the transform (as ntt_inv16),
-//     then contiguous pass, transpose, strided pass; the outputs are only reduced (max |x|, weight per row).
-// The waves of a workgroup (W = blockDim.x / 64, chosen by the host so that the tasks divide evenly: 21 tasks = 3 x 7 at
-// (l, D) = (83, 256)) meet once, at the end.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void raw_ints(const Raw4<int32_t> &r, int (&s)[4], const FzMod &) { s[0] = r.v.x; s[1] = r.v.y; s[2] = r.v.z; s[3] = r.v.w; }
-__device__ __forceinline__ void raw_ints(const Raw4<int64_t> &r, int (&s)[4], const FzMod &m) {
-    s[0] = (int)fz_cent_i64(r.lo.x, m); s[1] = (int)fz_cent_i64(r.lo.y, m);          // exact for any int64
-    s[2] = (int)fz_cent_i64(r.hi.x, m); s[3] = (int)fz_cent_i64(r.hi.y, m);
-}
-
-template <int LOGD, bool FAST, typename T, bool PF>
-__global__ __launch_bounds__(384) void verify_many16(const int32_t *A, const T *sig, size_t sig_stride, const T *target,
-                                                     size_t target_stride, int l, long long beta, long long omega, int lazy,
-                                                     const double2 *__restrict__ itwB, FzTwA twA, FzMod m, int *verdict) {
-    using G = Geom<LOGD>;
-    constexpr int D = G::D, L = G::L, PPW = G::PPW, SB = G::SB, NE = G::NE, PS = G::PS;
-    constexpr int REGION = PPW * PS;                       // doubles per wave: transpose buffer, staging image, final partials
-    static_assert(REGION * 2 >= kStageWords && REGION >= 256, "staging image and partials must fit in the transpose buffer");
-    extern __shared__ __attribute__((aligned(16))) double lds16[];      // [W][REGION] + [NE][L] (w, w2) pairs
-    __shared__ int s_flags;
-    const int W = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int p = lane / L, r = lane % L;
-    double2 *s_tw = reinterpret_cast<double2 *>(lds16 + W * REGION);
-    for (int i = threadIdx.x; i < NE * L; i += blockDim.x) s_tw[i] = itwB[i];
-    if (threadIdx.x == 0) s_flags = 0;
-    __syncthreads();
-    double *region = lds16 + wave * REGION;
-    int32_t *stage = reinterpret_cast<int32_t *>(region);
-    double *row = region + p * PS;
-    const size_t g = blockIdx.x;
-    sig += g * sig_stride;
-    target += g * target_stride;
-
-    const int tasks = (l + PPW - 1) / PPW;
-    const int j0 = (4 * lane) % D, rsub = (4 * lane) / D;             // coalesced layout: load c covers row PPW*task + (256/D)*c + rsub
-    Raw4<T> sn[4];
-    int4 an[4];
-    auto fetch = [&](int t) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int rw = t * PPW + (256 / D) * c + rsub;
-            const size_t off = (size_t)(rw < l ? rw : l - 1) * D + j0;
-            an[c] = *reinterpret_cast<const int4 *>(A + off);
-            sn[c].load(sig + off);
-        }
-    };
-    long long ihi[4] = {0, 0, 0, 0}, ilo[4] = {0, 0, 0, 0};
-    double mx = 0.0;
-    int wfail = 0;
-    const bool weigh = omega < (long long)D;
-    const unsigned long long gmask = (((1ull << L) - 1ull) << (L * p));
-    int task = wave;
-    if (PF && task < tasks) fetch(task);
-    for (; task < tasks; task += W) {
-        if (!PF) fetch(task);
-        const bool full = (task + 1) * PPW <= l;              // wave-uniform: only the last task can hold slots past the last row
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            int si[4];
-            raw_ints(sn[c], si, m);
-            const int av[4] = {an[c].x, an[c].y, an[c].z, an[c].w};
-            if (full) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {       // any int32 sigma, any int32 A: |sigma * hi|, |sigma * lo| < 2^47
-                    ihi[k] += (long long)si[k] * (long long)(av[k] >> 16);
-                    ilo[k] += (long long)si[k] * (long long)(av[k] & 0xffff);
-                }
-            } else {
-                const bool valid = task * PPW + (256 / D) * c + rsub < l;      // a slot past the last row repeats row l - 1: not summed
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const long long sk = valid ? (long long)si[k] : 0ll;
-                    ihi[k] += sk * (long long)(av[k] >> 16);
-                    ilo[k] += sk * (long long)(av[k] & 0xffff);
-                }
-            }
-            *reinterpret_cast<int4 *>(stage + pad4(256 * c + 4 * lane)) = make_int4(si[0], si[1], si[2], si[3]);
-        }
-        if (PF) fetch(task + W < tasks ? task + W : tasks - 1);       // unconditional, clamped: no branch between request and use
-        wave_sync();
-        double a[16];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int4 t = *reinterpret_cast<const int4 *>(stage + pad4(16 * lane + 4 * k));
-            a[4 * k + 0] = (double)t.x; a[4 * k + 1] = (double)t.y; a[4 * k + 2] = (double)t.z; a[4 * k + 3] = (double)t.w;
-        }
-        wave_sync();
-        // the inverse transform of ntt_inv16: contiguous pass, fold of the one unreduced value, transpose, strided pass
-#pragma unroll
-        for (int ls = 0; ls < SB; ++ls) {
-            const int t = 1 << ls;
-            const int ebase = 16 - (16 >> ls);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k & t) continue;
-                const int gi = k >> (ls + 1);
-                const double2 w = s_tw[(ebase + gi) * L + r];
-                const double u = a[k], v = a[k + t];
-                a[k] = u + v;
-                a[k + t] = tw_mul<FAST>(u - v, w.x, w.y, m);
-            }
-        }
-        if (FAST && 31 + SB + 4 > 38) a[0] = fz_fold(a[0], m);
-        {
-            double2 *blk = reinterpret_cast<double2 *>(row + 18 * r);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) blk[k] = make_double2(a[2 * k], a[2 * k + 1]);
-        }
-        wave_sync();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = row[pad16(r + L * k)];
-        wave_sync();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int tk = 1 << s;
-            const int h = 8 >> s;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k & tk) continue;
-                const double u = a[k], v = a[k + tk];
-                if (s == 3) {
-                    a[k] = tw_mul<FAST>(u + v, twA.n_inv, twA.n_inv2, m);
-                    a[k + tk] = tw_mul<FAST>(u - v, twA.w1_n_inv, twA.w1_n_inv2, m);
-                } else {
-                    const int e = h + (k >> (s + 1));
-                    a[k] = u + v;
-                    a[k + tk] = tw_mul<FAST>(u - v, twA.w[e], twA.w2[e], m);
-                }
-            }
-        }
-        // norm and weight stay in the fp64 lanes (see verify_fused: `lazy`, and why a repeated row l - 1 changes nothing)
-        if (!lazy) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = fz_cent(a[k], m);
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) mx = __builtin_fmax(mx, __builtin_fabs(a[k]));
-        if (weigh) {
-            int cnt = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) cnt += __popcll(__ballot(a[k] != 0.0) & gmask);
-            if ((long long)cnt > omega) wfail = 1;
-        }
-    }
-    {
-        const bool small = (tasks + W - 1) / W * 4 <= 32;          // products per accumulator
-        double *mine = region + 4 * lane;                          // this wave's partial of `observed`, at (row slot, position)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) mine[k] = fz_imad_total(ihi[k], ilo[k], small, m);
-    }
-    if (mx > (double)beta) atomicOr(&s_flags, 2);
-    if (wfail) atomicOr(&s_flags, 4);
-    __syncthreads();
-    for (int c = threadIdx.x; c < D; c += blockDim.x) {
-        double sum = 0;
-        for (int w = 0; w < W; ++w)
-#pragma unroll
-            for (int q = 0; q < 256 / D; ++q) sum += lds16[w * REGION + q * D + c];
-        if ((int)fz_cent_wide(sum, m) != centred_any(target[c], m)) atomicOr(&s_flags, 1);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int f = s_flags;
-        verdict[g] = (f & 1) ? FZ_VERDICT_TARGET_MISMATCH : ((f & 2) ? FZ_VERDICT_NORM : ((f & 4) ? FZ_VERDICT_WEIGHT : FZ_VERDICT_OK));
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // D <= 16: one thread per polynomial, everything in registers, twiddles uniform
 // ------------------------------------------------------------------------------------------
 template <int LOGD, bool INVERSE>
@@ -1380,7 +1204,7 @@ template <int LOGD, bool FAST>
 int launch16f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
     const size_t tasks = (batch * Geom<LOGD>::D + kChunk - 1) / kChunk;
     const size_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
-    const size_t cap = (size_t)(inverse ? ctx->grid_inv : ctx->grid_fwd) * (size_t)ctx->grid_mult;
+    const size_t cap = (size_t)(inverse ? ctx->grid_inv : ctx->grid_fwd);
     const unsigned grid = (unsigned)(blocks < cap ? blocks : cap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_on && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen[inverse ? 1 : 0]++ % ctx->prof_every) == 0) {
@@ -1417,7 +1241,7 @@ int launch4f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool in
     constexpr int PPW = 64 / ((1 << LOGD) / 4);
     const size_t waves1 = (batch + PPW - 1) / PPW;                   // waves at one row group per wave
     if (waves1 > 0x7fffffffull) return fz_set_error(FZ_E_UNSUPPORTED, "batch too large for the radix-4 schedule");
-    int nr = ctx->knob_ntt_rows;                                      // FZ_NTT_ROWS (benchmarking)
+    int nr = ctx->knob_ntt_rows;                                      // FZ_NTT_ROWS (tests: every row count at small sizes)
     if (nr != 1 && nr != 2 && nr != 4) nr = waves1 <= (size_t)24 * ctx->num_cu ? 1 : (waves1 <= (size_t)48 * ctx->num_cu ? 2 : 4);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_on && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen[inverse ? 1 : 0]++ % ctx->prof_every) == 0) {
@@ -1428,8 +1252,7 @@ int launch4f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool in
     if (nr == 1) {
         // waves per workgroup: 8 once that still leaves a workgroup for every CU (fewer, fatter workgroups are handed out
         // sooner), else 4, else 1 -- 4096 rows of degree 64 are 1024 waves: as 128 workgroups they would leave half the chip idle
-        int w = ctx->knob_ntt_waves;                                     // FZ_NTT_WAVES (A/B runs)
-        if (w != 1 && w != 4 && w != 8) w = waves1 >= (size_t)8 * ctx->num_cu ? 8 : (waves1 >= (size_t)4 * ctx->num_cu ? 4 : 1);
+        const int w = waves1 >= (size_t)8 * ctx->num_cu ? 8 : (waves1 >= (size_t)4 * ctx->num_cu ? 4 : 1);
         if (w == 1) launch4n<LOGD, FAST, 1, 1>(ctx, in, out, batch, inverse, e0, e1);
         else if (w == 4) launch4n<LOGD, FAST, 1, 4>(ctx, in, out, batch, inverse, e0, e1);
         else launch4n<LOGD, FAST, 1, 8>(ctx, in, out, batch, inverse, e0, e1);
@@ -1489,7 +1312,7 @@ int query16(fz_ctx *ctx) {
 int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,
                            int l, bool broadcast) {
     const dim3 grid((unsigned)segments), block(64 * kWavesPerBlock);
-    if (broadcast && !ctx->knob_keygen_bcast_general && (ctx->logd == 6 || ctx->logd == 8)) {
+    if (broadcast && (ctx->logd == 6 || ctx->logd == 8)) {
         // one polynomial per (key, half): ONE transform per workgroup, then l stores (see keygen_bcast_fused)
 #define FZ_KB(LOGD, FAST) hipLaunchKernelGGL((keygen_bcast_fused<LOGD, FAST>), grid, block, 0, ctx->stream, A, coef, sk_hat, vk, l, \
                                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod)
@@ -1500,27 +1323,16 @@ int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, i
     }
     const size_t seg_stride = broadcast ? (size_t)ctx->degree : (size_t)l * ctx->degree;
     const size_t row_stride = broadcast ? 0 : (size_t)ctx->degree;
-    // FZ_FUSED_ROWS = 1 | 2 row groups per wave iteration, FZ_FUSED_PREFETCH = 1 | 2 iterations requested ahead: all four
-    // combinations measure the same on one box (81.7 / 81.7 / 82.0 / 81.1 us per 1024 keys, profiles/r03_keygen_ab.txt) although
-    // their vector-instruction counts differ by 8 % -- the kernel is bound by neither; the defaults are the smallest form (1, 1)
-    const bool two = ctx->knob_fused_rows == 2, deep = ctx->knob_fused_prefetch == 2;
-    const bool single = ctx->knob_fused_tw == 1;                 // FZ_FUSED_TW=1: per-lane twiddles as w alone (quotient twiddle recomputed)
-#define FZ_KF5(LOGD, FAST, IM, NR, PF, TW) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, IM, NR, PF, TW>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \
-                                             (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod)
-#define FZ_KF4(LOGD, FAST, IM, NR, PF) do { if (single) FZ_KF5(LOGD, FAST, IM, NR, PF, double); else FZ_KF5(LOGD, FAST, IM, NR, PF, double2); } while (0)
-#define FZ_KF3(LOGD, FAST, IM, NR) do { if (deep) FZ_KF4(LOGD, FAST, IM, NR, 2); else FZ_KF4(LOGD, FAST, IM, NR, 1); } while (0)
-#define FZ_KF2(LOGD, FAST, IM) do { if (two) FZ_KF3(LOGD, FAST, IM, 2); else FZ_KF3(LOGD, FAST, IM, 1); } while (0)
     // integer accumulation is exact for at most 2^15 products per lane (fz_arith.h): longer sums take the fp64 form
     const bool imad_k = !ctx->knob_no_imad && l <= (1 << 15);
+#define FZ_KF2(LOGD, FAST, IM) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, IM>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \
+                                             (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod)
 #define FZ_KF(LOGD, FAST) do { if (imad_k) FZ_KF2(LOGD, FAST, true); else FZ_KF2(LOGD, FAST, false); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_KF(8, true); else FZ_KF(8, false); }
     else if (ctx->logd == 6) { if (ctx->mod.fast) FZ_KF(6, true); else FZ_KF(6, false); }
     else return fz_set_error(FZ_E_UNSUPPORTED, "fused keygen: degree 64 or 256 only");
 #undef FZ_KF
 #undef FZ_KF2
-#undef FZ_KF3
-#undef FZ_KF4
-#undef FZ_KF5
     return fz_check_hip(hipGetLastError(), "keygen_fused launch");
 }
 
@@ -1534,53 +1346,22 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
     int R = (tasks + kVerifyWaves - 1) / kVerifyWaves;
     const int fill = (int)((size_t)ctx->num_cu * 2 / groups);
     if (R > fill) R = fill;
-    if (ctx->knob_verify_blocks > 0) R = ctx->knob_verify_blocks;     // benchmarking knob (FZ_VERIFY_BLOCKS)
     if (R < 1) R = 1;
     if (R > 64) R = 64;
     // the inverse passes leave |r| <= q/2 + q * 2^-13 (4-op multiply) -- see the kernel's header for why no centring is needed then
     const int lazy = (beta >= 0 && (double)beta < 0.5 * ctx->mod.q - ctx->mod.q / 4096.0 && !ctx->knob_verify_cent) ? 1 : 0;
-    if (R == 1 && ctx->knob_verify16 != 0 && groups <= 0x7fffffffull && l >= 1) {
-        // FZ_VERIFY16 (A/B runs; off by default): a workgroup per aggregate through the 16-per-lane kernel.  Measured, cold,
-        // 8192 aggregates per launch: 245 us against 237 for the radix-4 kernel at (83, 256), 130 against 119 at (195, 64)
-        // (profiles/r03_verify_ab.txt) -- the structure is the faster one with registers and LDS alone (ntt_structures), but
-        // here it needs 149 VGPRs (3 waves per SIMD against 5) once a task's 8 prefetched loads, 16 fp64 values and 8
-        // accumulators are live together, and forcing 128 spills.
-        // Waves per workgroup: 1 .. 6 as given; any other value = whatever divides the wave-tasks best (a wave's tasks are a
-        // sequential chain and the workgroup ends with its slowest wave), four if nothing is better
-        const int ppw16 = 1024 / ctx->degree, tasks16 = (l + ppw16 - 1) / ppw16;
-        int W = ctx->knob_verify16;
-        if (W < 1 || W > 6) {                                        // (six waves are 59 KiB of LDS: the default dynamic limit is 64)
-            int best = 1 << 30;
-            for (int cand : {4, 3, 2, 5, 6, 1}) {
-                const int waste = (tasks16 + cand - 1) / cand * cand - tasks16;
-                if (waste < best) { best = waste; W = cand; }
-            }
-        }
-        const size_t lds_bytes = ((size_t)W * (ppw16 * (ctx->degree + 2 * (ctx->degree / 16))) + 2 * (size_t)(16 - (16 >> (ctx->logd - 4))) * (ctx->degree / 16)) * sizeof(double);
-#define FZ_V16P(LOGD, FAST, PF) hipLaunchKernelGGL((verify_many16<LOGD, FAST, T, PF>), dim3((unsigned)groups), dim3(64 * W), lds_bytes, ctx->stream, A, sig, \
-                                              sig_stride, target, target_stride, l, (long long)beta, (long long)omega, lazy, \
-                                              (const double2 *)ctx->d_itwB, ctx->itwA, ctx->mod, d_verdict)
-#define FZ_V16(LOGD, FAST) do { if (ctx->knob_verify16_nopf) FZ_V16P(LOGD, FAST, false); else FZ_V16P(LOGD, FAST, true); } while (0)
-        if (ctx->logd == 8) { if (ctx->mod.fast) FZ_V16(8, true); else FZ_V16(8, false); }
-        else { if (ctx->mod.fast) FZ_V16(6, true); else FZ_V16(6, false); }
-#undef FZ_V16
-#undef FZ_V16P
-        return fz_check_hip(hipGetLastError(), "verify_many16 launch");
-    }
+    // (Round 3 also ran launches with a workgroup per aggregate through a 16-per-lane kernel, verify_many16: 245 us against 237
+    // per 8192 aggregates at (83, 256), 130 against 119 at (195, 64) -- profiles/r03_verify_ab.txt -- although its transform
+    // structure is 28-54 % faster from registers and LDS alone (profiles/r03_ntt_structures.txt): 149 VGPRs, 3 waves per SIMD
+    // against 5.  Removed in round 4; tools/microbench/ntt_structures.hip keeps the structure comparison.)
     double *part = nullptr;
     int *state = nullptr;
     int rc = fz_verify_scratch(ctx, groups, (size_t)ctx->degree, &part, &state);
     if (rc != FZ_OK) return rc;
     const dim3 grid((unsigned)R, (unsigned)groups), block(64 * kVerifyWaves);
-    // one row group per wave iteration unless FZ_FUSED_ROWS=2: two measured 248.5 us against 243.9 per 8192 aggregates (the
-    // kernel is vector-issue bound; the second row costs occupancy and buys no latency hiding it did not already have)
-    const bool two = ctx->knob_fused_rows == 2;
-    const bool single = ctx->knob_fused_tw == 1;                 // FZ_FUSED_TW=1: per-lane twiddles as w alone (quotient twiddle recomputed)
-#define FZ_VF5(LOGD, FAST, ORD, IM, NR, TW) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T, ORD, IM, NR, TW>), grid, block, 0, ctx->stream, A, sig, sig_stride, target, \
+#define FZ_VF3(LOGD, FAST, ORD, IM) hipLaunchKernelGGL((verify_fused<LOGD, FAST, T, ORD, IM>), grid, block, 0, ctx->stream, A, sig, sig_stride, target, \
                                                    target_stride, l, (long long)beta, (long long)omega, lazy, (const double2 *)ctx->d_itw2, \
                                                    ctx->itwA, ctx->mod, part, state, d_verdict)
-#define FZ_VF4(LOGD, FAST, ORD, IM, NR) do { if (single) FZ_VF5(LOGD, FAST, ORD, IM, NR, double); else FZ_VF5(LOGD, FAST, ORD, IM, NR, double2); } while (0)
-#define FZ_VF3(LOGD, FAST, ORD, IM) do { if (two) FZ_VF4(LOGD, FAST, ORD, IM, 2); else FZ_VF4(LOGD, FAST, ORD, IM, 1); } while (0)
     // integer accumulation of A * sigma pays its once-per-wave conversion back only over several rows per wave (measured: 1.18 M
     // vector instructions against 1.10 M per launch when the l rows are spread one per wave over 21 workgroups)
     // ... and it is exact for at most 2^15 products per lane (fz_arith.h): a longer sum takes the fp64 form
@@ -1592,8 +1373,6 @@ static int launch_verify_fused(fz_ctx *ctx, const int32_t *A, const T *sig, size
 #undef FZ_VF
 #undef FZ_VF2
 #undef FZ_VF3
-#undef FZ_VF4
-#undef FZ_VF5
     rc = fz_check_hip(hipGetLastError(), "verify_fused launch");
     if (rc != FZ_OK) ctx->verify_dirty = 1;          // the accumulators may be left non-zero: re-zeroed before the next launch
     return rc;
@@ -1620,9 +1399,7 @@ int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int
     if (ctx->grid_pm == 0) {
         int n = 0;
         hipError_t e;
-    const bool single = ctx->knob_fused_tw == 1;
-#define FZ_PQ(LOGD, FAST) e = single ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, polymul_fused<LOGD, FAST, double>, 64 * kWavesPerBlock, 0) \
-                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, polymul_fused<LOGD, FAST, double2>, 64 * kWavesPerBlock, 0)
+#define FZ_PQ(LOGD, FAST) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, polymul_fused<LOGD, FAST>, 64 * kWavesPerBlock, 0)
         if (ctx->logd == 8) { if (ctx->mod.fast) FZ_PQ(8, true); else FZ_PQ(8, false); }
         else { if (ctx->mod.fast) FZ_PQ(6, true); else FZ_PQ(6, false); }
 #undef FZ_PQ
@@ -1630,13 +1407,11 @@ int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int
         ctx->grid_pm = (n < 1 ? 1 : n) * ctx->num_cu;
     }
     const dim3 grid((unsigned)(blocks < (size_t)ctx->grid_pm ? blocks : (size_t)ctx->grid_pm)), block(64 * kWavesPerBlock);
-#define FZ_PM2(LOGD, FAST, TW) hipLaunchKernelGGL((polymul_fused<LOGD, FAST, TW>), grid, block, 0, ctx->stream, f, g, out, batch, \
+#define FZ_PM(LOGD, FAST) hipLaunchKernelGGL((polymul_fused<LOGD, FAST>), grid, block, 0, ctx->stream, f, g, out, batch, \
                                              (const double2 *)ctx->d_tw2, (const double2 *)ctx->d_itw2, ctx->twA, ctx->itwA, ctx->mod)
-#define FZ_PM(LOGD, FAST) do { if (ctx->knob_fused_tw == 1) FZ_PM2(LOGD, FAST, double); else FZ_PM2(LOGD, FAST, double2); } while (0)
     if (ctx->logd == 8) { if (ctx->mod.fast) FZ_PM(8, true); else FZ_PM(8, false); }
     else { if (ctx->mod.fast) FZ_PM(6, true); else FZ_PM(6, false); }
 #undef FZ_PM
-#undef FZ_PM2
     return fz_check_hip(hipGetLastError(), "polymul_fused launch");
 }
 
@@ -1689,7 +1464,7 @@ int fz_launch_ntt_multi(fz_ctx *ctx, const FzMultiJobs &J) {
         if (e != hipSuccess) return fz_check_hip(e, "occupancy query (multi)");
         ctx->grid_multi[dir] = (n < 1 ? 1 : n) * ctx->num_cu;
     }
-    const unsigned cap = (unsigned)ctx->grid_multi[dir] * (unsigned)ctx->grid_mult;
+    const unsigned cap = (unsigned)ctx->grid_multi[dir];
     const dim3 grid(total < cap ? total : cap), block(64);
 #define FZ_MJ(LOGD, FAST, DIR) hipLaunchKernelGGL((ntt_multi4<LOGD, FAST, DIR>), grid, block, 0, ctx->stream, J, (const double2 *)ctx->d_tw2, \
                                                   (const double2 *)ctx->d_itw2, ctx->twA, ctx->itwA, ctx->mod)

@@ -35,7 +35,7 @@ __device__ __forceinline__ int pw_op(int a, int b, int acc, const FzMod m) {
 
 template <int OP>
 __global__ __launch_bounds__(kBlock) void pw_kernel(const int32_t *a, const int32_t *b, int32_t *out,
-                                                    size_t count, int vec, FzMod m, int nt) {
+                                                    size_t count, int vec, FzMod m) {
     const size_t n4 = vec ? count / 4 : 0;   // vec == 0: pointers not 16-byte aligned, all scalar
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,12 +51,7 @@ __global__ __launch_bounds__(kBlock) void pw_kernel(const int32_t *a, const int3
         o.y = pw_op<OP>(x.y, y.y, z.y, m);
         o.z = pw_op<OP>(x.z, y.z, z.z, m);
         o.w = pw_op<OP>(x.w, y.w, z.w, m);
-        if (nt && OP != FZ_OP_MULACC) {
-            const fz_v4i t = {o.x, o.y, o.z, o.w};
-            __builtin_nontemporal_store(t, reinterpret_cast<fz_v4i *>(o4 + i));
-        } else {
-            o4[i] = o;
-        }
+        o4[i] = o;        // a normal store: the consumer usually follows at once (streaming stores: +2.5 % cold, measured in round 2)
     }
     // ragged tail (count not a multiple of 4) or the whole range when unaligned
     for (size_t i = n4 * 4 + gid; i < count; i += stride) {
@@ -235,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void matvec_scalar_kernel(const int32_t *A,
 
 // sig[b][k][j] = cent(cent(L[b][k][j] * c[b][j]) + R[b][k][j]); sk_hat = [batch][2][l][degree]
 __global__ __launch_bounds__(kBlock) void sign_kernel(const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig,
-                                                      size_t batch, int l, int degree, FzMod m, int nt) {
+                                                      size_t batch, int l, int degree, FzMod m) {
     const int d4 = degree / 4;
     const size_t per_sig = (size_t)l * d4;
     const size_t total = batch * per_sig;
@@ -253,12 +248,7 @@ __global__ __launch_bounds__(kBlock) void sign_kernel(const int32_t *sk_hat, con
         o.y = cent_i32(fz_mulmod((double)x.y, (double)c.y, m) + (double)y.y, m);
         o.z = cent_i32(fz_mulmod((double)x.z, (double)c.z, m) + (double)y.z, m);
         o.w = cent_i32(fz_mulmod((double)x.w, (double)c.w, m) + (double)y.w, m);
-        if (nt) {
-            const fz_v4i t = {o.x, o.y, o.z, o.w};
-            __builtin_nontemporal_store(t, reinterpret_cast<fz_v4i *>(sig) + i);
-        } else {
-            reinterpret_cast<int4 *>(sig)[i] = o;
-        }
+        reinterpret_cast<int4 *>(sig)[i] = o;   // a normal store: the aggregation usually reads the signatures next
     }
 }
 
@@ -710,73 +700,6 @@ __device__ __forceinline__ void atomic_add_i64(int64_t *p, double v) {
     atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)(long long)v);
 }
 
-// Two-pass, atomics-free aggregation (exact and deterministic):
-//   pass 1  split[g][s][k][j] = sum_{i in split s} sig[g][i][k][j] * alpha[g][i][j]   (fp64-lazy, each product
-//           reduced to ~q/2; |sum| < 2^53)  -- grid.x columns of 4 coefficients, grid.y splits, grid.z groups
-//   pass 2  partial[g][e] = sum_s split[g][s][e]  as int64 (for the cross-GPU all-reduce) or centred int32
-__global__ __launch_bounds__(kBlock) void aggregate_split_kernel(const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
-                                                                 const int32_t *vkR, const int32_t *c, double *split,
-                                                                 size_t N, int l, int degree, FzMod m) {
-    // columns [0, l*d/4): the aggregate; with vkL != nullptr the next d/4 columns accumulate the verification
-    // target sum_i (vkL_i*c_i + vkR_i)*alpha_i (fusion.py:706-714) in the same pass over the signers
-    const int d4 = degree / 4;
-    const size_t cols_a = (size_t)l * d4, cols = cols_a + (vkL ? d4 : 0);
-    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= cols) return;
-    const size_t g = blockIdx.z;
-    alpha += g * N * (size_t)degree;
-    const size_t per = (N + gridDim.y - 1) / gridDim.y;
-    const size_t i0 = (size_t)blockIdx.y * per;
-    const size_t i1 = (i0 + per < N) ? i0 + per : N;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (col < cols_a) {
-        const int j4 = (int)(col % d4);
-        sig += g * N * (size_t)l * degree;
-#pragma unroll 8
-        for (size_t i = i0; i < i1; ++i) {
-            int4 x = reinterpret_cast<const int4 *>(sig + i * (size_t)l * degree)[col];
-            int4 a = reinterpret_cast<const int4 *>(alpha + i * (size_t)degree)[j4];
-            s0 += fz_mulmod((double)x.x, (double)a.x, m);
-            s1 += fz_mulmod((double)x.y, (double)a.y, m);
-            s2 += fz_mulmod((double)x.z, (double)a.z, m);
-            s3 += fz_mulmod((double)x.w, (double)a.w, m);
-        }
-    } else {
-        const size_t j4 = col - cols_a, goff = g * N * (size_t)degree;
-#pragma unroll 4
-        for (size_t i = i0; i < i1; ++i) {
-            const size_t o = (goff + i * (size_t)degree) / 4 + j4;
-            int4 L = reinterpret_cast<const int4 *>(vkL)[o], R = reinterpret_cast<const int4 *>(vkR)[o];
-            int4 ch = reinterpret_cast<const int4 *>(c)[o];
-            int4 a = reinterpret_cast<const int4 *>(alpha + i * (size_t)degree)[j4];
-            s0 += fz_mulmod(fz_mulmod((double)L.x, (double)ch.x, m) + (double)R.x, (double)a.x, m);   // |inner| < 2^32
-            s1 += fz_mulmod(fz_mulmod((double)L.y, (double)ch.y, m) + (double)R.y, (double)a.y, m);
-            s2 += fz_mulmod(fz_mulmod((double)L.z, (double)ch.z, m) + (double)R.z, (double)a.z, m);
-            s3 += fz_mulmod(fz_mulmod((double)L.w, (double)ch.w, m) + (double)R.w, (double)a.w, m);
-        }
-    }
-    double2 *dst = reinterpret_cast<double2 *>(split + ((g * gridDim.y + blockIdx.y) * cols + col) * 4);
-    dst[0] = make_double2(s0, s1);
-    dst[1] = make_double2(s2, s3);
-}
-
-// pass 2: elements [0, count_a) of each group go to the aggregate output, the rest (the target columns) to tout64
-template <bool CENTRE>
-__global__ __launch_bounds__(kBlock) void sum_splits_kernel(const double *split, size_t splits, size_t count, size_t count_a,
-                                                            int64_t *out64, size_t pstride, int64_t *tout64, size_t tstride,
-                                                            int32_t *out32, FzMod m) {
-    const size_t g = blockIdx.z;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const double *base = split + g * splits * count;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
-        double s = 0;
-        for (size_t t = 0; t < splits; ++t) s += base[t * count + e];
-        if (e >= count_a) tout64[g * tstride + (e - count_a)] = (int64_t)s;
-        else if (CENTRE) out32[g * count_a + e] = (int)fz_cent_wide(s, m);
-        else out64[g * pstride + e] = (int64_t)s;
-    }
-}
-
 // partial[g][j] += sum_i ((vkL_i*c_i + vkR_i) * alpha_i)[j]; one thread per coefficient, grid.y splits N
 __global__ __launch_bounds__(kBlock) void target_kernel(const int32_t *vkL, const int32_t *vkR, const int32_t *c,
                                                         const int32_t *alpha, int64_t *partial, size_t pstride,
@@ -861,8 +784,9 @@ __global__ __launch_bounds__(256) void verdict_kernel(const int32_t *target, con
 
 unsigned grid_for(fz_ctx *ctx, size_t work_items, int per_cu = -1) {
     size_t blocks = (work_items + kBlock - 1) / kBlock;
-    if (per_cu < 0) per_cu = ctx->knob_stream_per_cu;            // the streaming kernels' default (FZ_STREAM_PER_CU)
-    size_t cap = per_cu > 0 ? (size_t)ctx->num_cu * per_cu : (size_t)0x7fffffff;      // 0: flat grid, one item per thread
+    // default: a flat grid, one item per thread (45.0 us per 1024 signatures for sign_core against 49.7 with the grid capped at
+    // 8 workgroups per CU, cold: round 2)
+    size_t cap = per_cu > 0 ? (size_t)ctx->num_cu * per_cu : (size_t)0x7fffffff;
     if (blocks < 1) blocks = 1;
     return (unsigned)(blocks < cap ? blocks : cap);
 }
@@ -874,11 +798,11 @@ int fz_launch_pw(fz_ctx *ctx, int op, const int32_t *a, const int32_t *b, int32_
     const int vec = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0) ? 1 : 0;
     const unsigned grid = grid_for(ctx, vec ? count / 4 + 4 : count);
     switch (op) {
-        case FZ_OP_MUL: hipLaunchKernelGGL(pw_kernel<FZ_OP_MUL>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod, ctx->knob_stream_nt); break;
-        case FZ_OP_ADD: hipLaunchKernelGGL(pw_kernel<FZ_OP_ADD>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod, ctx->knob_stream_nt); break;
-        case FZ_OP_SUB: hipLaunchKernelGGL(pw_kernel<FZ_OP_SUB>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod, ctx->knob_stream_nt); break;
-        case FZ_OP_NEG: hipLaunchKernelGGL(pw_kernel<FZ_OP_NEG>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, a, out, count, vec, ctx->mod, ctx->knob_stream_nt); break;
-        case FZ_OP_MULACC: hipLaunchKernelGGL(pw_kernel<FZ_OP_MULACC>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod, ctx->knob_stream_nt); break;
+        case FZ_OP_MUL: hipLaunchKernelGGL(pw_kernel<FZ_OP_MUL>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
+        case FZ_OP_ADD: hipLaunchKernelGGL(pw_kernel<FZ_OP_ADD>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
+        case FZ_OP_SUB: hipLaunchKernelGGL(pw_kernel<FZ_OP_SUB>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
+        case FZ_OP_NEG: hipLaunchKernelGGL(pw_kernel<FZ_OP_NEG>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, a, out, count, vec, ctx->mod); break;
+        case FZ_OP_MULACC: hipLaunchKernelGGL(pw_kernel<FZ_OP_MULACC>, dim3(grid), dim3(kBlock), 0, ctx->stream, a, b, out, count, vec, ctx->mod); break;
         default: return fz_set_error(FZ_E_BADARG, "unknown pointwise op %d", op);
     }
     return fz_check_hip(hipGetLastError(), "pointwise launch");
@@ -943,7 +867,7 @@ int fz_launch_sign(fz_ctx *ctx, const int32_t *sk_hat, const int32_t *c_hat, int
     }
     const size_t total = batch * (size_t)l * (ctx->degree / 4);
     hipLaunchKernelGGL(sign_kernel, dim3(grid_for(ctx, total)), dim3(kBlock), 0, ctx->stream, sk_hat, c_hat, sig, batch,
-                       l, ctx->degree, ctx->mod, ctx->knob_stream_nt);
+                       l, ctx->degree, ctx->mod);
     return fz_check_hip(hipGetLastError(), "sign launch");
 }
 
@@ -1003,7 +927,7 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
     const bool vec = (d % 4 == 0) && (align & 15) == 0;
     if (h_offsets && !(vec && (d & (d - 1)) == 0 && d <= 256 && groups <= (size_t)kFzRaggedMax))
         return fz_set_error(FZ_E_UNSUPPORTED, "ragged aggregation: power-of-two degree <= 256, 16-byte aligned rows, <= %d aggregates per launch", kFzRaggedMax);
-    if (vec && (d & (d - 1)) == 0 && d <= 256 && (!ctx->knob_agg_twopass || h_offsets)) {
+    if (vec && (d & (d - 1)) == 0 && d <= 256) {
         const int d4 = d / 4;
         const size_t cols_a = (size_t)l * d4;
         // Few signers in the whole launch: no signer slices, no shared accumulators (aggregate_direct).  Measured on cold
@@ -1035,15 +959,14 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
         // slices of the signers per aggregate: as many tiles (column block x aggregate x slice) as the chip holds at once --
         // one 8-wave workgroup per CU (180 VGPRs: two waves per SIMD) -- so that every CU streams from the first moment
         // and nothing waits for a second round; at least kAggDepth signers per wave
-        int waves = ctx->knob_agg_waves ? ctx->knob_agg_waves : 8;
+        constexpr int waves = 8;                       // (4-wave workgroups, two per CU, measured no better at any size: profiles/r03_aggregate_shapes.txt)
         const size_t blocks_min = (size_t)ncb * groups;
-        const size_t capacity = (size_t)ctx->num_cu * (waves == 8 ? 1 : 2);
+        const size_t capacity = (size_t)ctx->num_cu;
         size_t nsl = capacity / blocks_min;
         const size_t most = N / ((size_t)waves * kAggDepth);
         if (nsl > most) nsl = most;
         if (nsl < 1) nsl = 1;
         if (nsl > 512) nsl = 512;                      // the arrival count shares a 64-bit word with the sum (10 bits)
-        if (ctx->knob_agg_slices > 0 && ctx->knob_agg_slices <= 512) nsl = (size_t)ctx->knob_agg_slices;
         if (nsl > N && N > 0) nsl = N;
         if (N == 0) nsl = 1;
         const size_t pairs = groups * nsl;
@@ -1067,47 +990,17 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
             rag.off[groups] = (unsigned)h_offsets[groups];
         }
         const FzRagged *rp = h_offsets ? &rag : nullptr;
-        if (waves == 4)
-            launch_onepass<4>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, out64,
-                              pstride, tout64, tstride, out32, rp);
-        else
-            launch_onepass<8>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, out64,
+        launch_onepass<8>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, out64,
                               pstride, tout64, tstride, out32, rp);
         const int rc = fz_check_hip(hipGetLastError(), "aggregate launch");
         if (rc != FZ_OK && nsl > 1) ctx->agg_dirty = 1;              // accumulators / tickets may no longer be zero
         return rc;
     }
-    if (!vec || !ctx->knob_agg_twopass) {
-        // degrees the one-pass kernel does not cover (not a power of two, > 256, or unaligned rows)
-        const size_t total = (size_t)l * d + (vkL ? (size_t)d : 0);
-        hipLaunchKernelGGL(aggregate_generic_kernel, dim3(grid_for(ctx, total), 1, (unsigned)groups), dim3(kBlock), 0, ctx->stream,
-                           sig, alpha, vkL, vkR, c, N, l, d, out64, pstride, tout64, tstride, out32, ctx->mod);
-        return fz_check_hip(hipGetLastError(), "aggregate (generic) launch");
-    }
-    // FZ_AGG_TWOPASS=1: the two-launch form the one-pass kernel replaced (kept for A/B measurements)
-    const size_t cols_a = (size_t)l * (ctx->degree / 4), cols = cols_a + (vkL ? ctx->degree / 4 : 0);
-    const size_t count = cols * 4, count_a = cols_a * 4;
-    const unsigned gx = (unsigned)((cols + kBlock - 1) / kBlock);
-    // ~4 blocks per CU over all groups, at least 8 signatures per thread
-    size_t splits = ((size_t)ctx->num_cu * 4 + gx * groups - 1) / (gx * groups);
-    const size_t most = (N + 7) / 8;
-    if (splits > most) splits = most;
-    if (splits < 1) splits = 1;
-    void *scr = nullptr;
-    int rc = fz_scratch2(ctx, groups * splits * count * sizeof(double), &scr);
-    if (rc != FZ_OK) return rc;
-    hipLaunchKernelGGL(aggregate_split_kernel, dim3(gx, (unsigned)splits, (unsigned)groups), dim3(kBlock), 0, ctx->stream,
-                       sig, alpha, vkL, vkR, c, (double *)scr, N, l, ctx->degree, ctx->mod);
-    rc = fz_check_hip(hipGetLastError(), "aggregate launch");
-    if (rc != FZ_OK) return rc;
-    const dim3 grid2(grid_for(ctx, count, 2), 1, (unsigned)groups);
-    if (out64)
-        hipLaunchKernelGGL(sum_splits_kernel<false>, grid2, dim3(kBlock), 0, ctx->stream, (const double *)scr, splits, count,
-                           count_a, out64, pstride, tout64, tstride, (int32_t *)nullptr, ctx->mod);
-    else
-        hipLaunchKernelGGL(sum_splits_kernel<true>, grid2, dim3(kBlock), 0, ctx->stream, (const double *)scr, splits, count,
-                           count_a, (int64_t *)nullptr, (size_t)0, tout64, tstride, out32, ctx->mod);
-    return fz_check_hip(hipGetLastError(), "aggregate sum launch");
+    // degrees the one-pass kernels do not cover (not a power of two, > 256, or unaligned rows)
+    const size_t total = (size_t)l * d + (vkL ? (size_t)d : 0);
+    hipLaunchKernelGGL(aggregate_generic_kernel, dim3(grid_for(ctx, total), 1, (unsigned)groups), dim3(kBlock), 0, ctx->stream,
+                       sig, alpha, vkL, vkR, c, N, l, d, out64, pstride, tout64, tstride, out32, ctx->mod);
+    return fz_check_hip(hipGetLastError(), "aggregate (generic) launch");
 }
 
 // out[seg][k][:] = in[seg][:] for k < l (generic-degree path of fz_keygen_core_bcast)

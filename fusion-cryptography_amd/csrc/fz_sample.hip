@@ -314,7 +314,7 @@ int fz_launch_mt_sample(fz_ctx *ctx, const unsigned long long *d_seeds, size_t n
     if (nkeys == 0) return FZ_OK;
     const size_t lds = (size_t)kMtN * 64 * 4;
     const size_t npoly = 2 * nkeys;
-    if (!d_state) {            // FZ_SAMPLER_ONE_KERNEL=1: the lane-per-polynomial kernel of round 2
+    if (!d_state) {            // more than 4096 keys per call: the lane-per-polynomial kernel of round 2
         hipError_t e = hipFuncSetAttribute((const void *)mt_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fz_check_hip(e, "sampler LDS attribute");
         hipLaunchKernelGGL(mt_sample_kernel, dim3((unsigned)((npoly + 63) / 64)), dim3(64), lds, ctx->stream, d_seeds, npoly, degree,

@@ -250,7 +250,7 @@ def test_reduce_i64_is_exact_for_any_int64(coracle):
         dev.close()
 
 
-@pytest.mark.parametrize("knob", ["FZ_AGG_TWOPASS=1", "FZ_AGG_WAVES=4", "FZ_AGG_SLICES=3", "FZ_AGG_SLICES=1", "FZ_VERIFY_ORDERED=1"])
+@pytest.mark.parametrize("knob", ["FZ_AGG_DIRECT=-1", "FZ_AGG_DIRECT=2", "FZ_AGG_DIRECT=4", "FZ_VERIFY_ORDERED=1"])
 def test_knobbed_paths_agree_with_the_oracle(knob, coracle, monkeypatch):
     """the A/B paths kept behind environment knobs (read once at context creation) compute the same integers"""
     import fusion_hip

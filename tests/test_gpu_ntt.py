@@ -208,11 +208,11 @@ def test_poly_mul_matches_transform_composition(d, coracle, monkeypatch):
         assert np.array_equal(ctx.d2h(np.empty_like(f), df.ptr), want)
         df.free(); dg.free()
     if d in (64, 256):
-        monkeypatch.setenv("FZ_POLYMUL_UNFUSED", "1")
+        monkeypatch.setenv("FZ_UNFUSED", "1")
         f = O.splitmix_centered(8, 77 * d).reshape(77, d)
         g = O.splitmix_centered(9, 77 * d).reshape(77, d)
         unfused = ctx.poly_mul(f, g)
-        monkeypatch.delenv("FZ_POLYMUL_UNFUSED")
+        monkeypatch.delenv("FZ_UNFUSED")
         assert np.array_equal(ctx.poly_mul(f, g), unfused)
     # x * 1 = cent(x); x * X = negacyclic shift
     one = np.zeros((1, d), np.int32); one[0, 0] = 1

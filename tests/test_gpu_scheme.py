@@ -203,7 +203,7 @@ def test_batched_aggregate_target_verify(coracle):
 
 @pytest.mark.parametrize("secpar", [128, 256])
 def test_fused_verify_equals_unfused_path(secpar, coracle, monkeypatch):
-    """verify_fused (sigma read once) vs the four-kernel path (FZ_VERIFY_UNFUSED=1) vs the oracle, on every
+    """verify_fused (sigma read once) vs the four-kernel path (FZ_UNFUSED=1) vs the oracle, on every
     verdict branch, with non-centred raw int32 rows in the aggregate as well."""
     import fusion_hip
     P = O.PARAMS[secpar]
@@ -227,9 +227,9 @@ def test_fused_verify_equals_unfused_path(secpar, coracle, monkeypatch):
     cases += [(raw, P["beta_vf"], d), (raw, 2**31, d)]
     for sigma, beta, omega in cases:
         want = coracle.verify_core(A, sigma, vk[:, 0], vk[:, 1], c_hat, al_hat, q, P["inv_root"], beta, omega)
-        monkeypatch.delenv("FZ_VERIFY_UNFUSED", raising=False)
+        monkeypatch.delenv("FZ_UNFUSED", raising=False)
         fused = ctx.verify_core(A, sigma, vk[:, 0], vk[:, 1], c_hat, al_hat, beta, omega)
-        monkeypatch.setenv("FZ_VERIFY_UNFUSED", "1")
+        monkeypatch.setenv("FZ_UNFUSED", "1")
         unfused = ctx.verify_core(A, sigma, vk[:, 0], vk[:, 1], c_hat, al_hat, beta, omega)
         assert fused == unfused == want, (beta, omega)
 
@@ -247,10 +247,10 @@ def test_fused_keygen_equals_unfused_path(secpar, coracle, monkeypatch):
     for n, lo, hi in ((1, -52, 53), (3, -52, 53), (2, -2**31, 2**31)):
         coef = rng.integers(lo, hi, size=(n, 2, l, d), dtype=np.int64).astype(np.int32)
         want_sk, want_vk = coracle.keygen_core(A, coef, q, P["root"])
-        monkeypatch.delenv("FZ_KEYGEN_UNFUSED", raising=False)
+        monkeypatch.delenv("FZ_UNFUSED", raising=False)
         sk, vk = ctx.keygen_core(A, coef)
         assert np.array_equal(sk, want_sk) and np.array_equal(vk, want_vk)
-        monkeypatch.setenv("FZ_KEYGEN_UNFUSED", "1")
+        monkeypatch.setenv("FZ_UNFUSED", "1")
         sk2, vk2 = ctx.keygen_core(A, coef)
         assert np.array_equal(sk2, want_sk) and np.array_equal(vk2, want_vk)
 
@@ -272,7 +272,7 @@ def test_broadcast_keygen_equals_replicated_rows(d, l, coracle, monkeypatch):
     want_sk, want_vk = coracle.keygen_core(A, coef, q, root)
     for unfused in (False, True):
         if unfused:
-            monkeypatch.setenv("FZ_KEYGEN_UNFUSED", "1")
+            monkeypatch.setenv("FZ_UNFUSED", "1")
         dA, dc = DB.from_numpy(ctx, A), DB.from_numpy(ctx, one)
         dsk, dvk = DB(ctx, coef.nbytes), DB(ctx, n * 2 * d * 4)
         ctx.keygen_core_bcast_dev(dA.ptr, dc.ptr, dsk.ptr, dvk.ptr, n, l)

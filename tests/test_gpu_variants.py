@@ -1,8 +1,7 @@
 """Every launch shape and arithmetic form the library instantiates, forced through its knob (read once, at context creation)
 and checked against the oracle at both parameter sets: the radix-4 transform kernels with 1 / 2 / 4 row groups per wave and
-1 / 4 / 8 waves per workgroup, the 16-per-lane persistent kernels, the fused kernels with one / two row groups per
-iteration, prefetch depths 0 / 1 / 2, twiddles as (w, w*K/q) pairs or w alone, integer or fp64 accumulation, the centring or
-lazy norm test.  The defaults pick among these by batch size; a size-dependent choice that is never hit by the other tests'
+1 / 4 / 8 waves per workgroup, the 16-per-lane persistent kernels, the fused kernels with integer or fp64 accumulation, the
+centring or lazy norm test, relaxed or acquire / release arrival, the multi-launch paths behind them, both aggregation kernels.  The defaults pick among these by batch size; a size-dependent choice that is never hit by the other tests'
 sizes would otherwise go unchecked.  Reference arithmetic: algebra/ntt.py:216-377, fusion/fusion.py:338-373, :680-728."""
 import os
 
@@ -15,26 +14,19 @@ pytestmark = pytest.mark.gpu
 I32 = np.iinfo(np.int32)
 
 TRANSFORM_KNOBS = [
-    {"FZ_NTT_KERNEL": "4", "FZ_NTT_ROWS": "1", "FZ_NTT_WAVES": "1"},
-    {"FZ_NTT_KERNEL": "4", "FZ_NTT_ROWS": "1", "FZ_NTT_WAVES": "4"},
-    {"FZ_NTT_KERNEL": "4", "FZ_NTT_ROWS": "1", "FZ_NTT_WAVES": "8"},
+    {"FZ_NTT_KERNEL": "4", "FZ_NTT_ROWS": "1"},        # workgroups of 1 / 4 / 8 waves by the row counts below
     {"FZ_NTT_KERNEL": "4", "FZ_NTT_ROWS": "2"},
     {"FZ_NTT_KERNEL": "4", "FZ_NTT_ROWS": "4"},
     {"FZ_NTT_KERNEL": "16"},
-    {"FZ_NTT_KERNEL": "16", "FZ_NTT_GRID_MULT": "1"},
-    {"FZ_NTT_SMALL_ROWS": "100"},                  # the crossover inside the sizes below
+    {},                                                # the default choice
 ]
 
 FUSED_KNOBS = [
     {},
-    {"FZ_FUSED_ROWS": "2"},
-    {"FZ_FUSED_ROWS": "1", "FZ_FUSED_PREFETCH": "0"},
-    {"FZ_FUSED_ROWS": "1", "FZ_FUSED_PREFETCH": "2"},
-    {"FZ_FUSED_TW": "1"},
-    {"FZ_FUSED_TW": "1", "FZ_FUSED_ROWS": "2", "FZ_NO_IMAD": "1"},
     {"FZ_NO_IMAD": "1"},
     {"FZ_VERIFY_CENT": "1"},
-    {"FZ_VERIFY_CENT": "1", "FZ_VERIFY_ORDERED": "1", "FZ_FUSED_ROWS": "2"},
+    {"FZ_VERIFY_CENT": "1", "FZ_VERIFY_ORDERED": "1", "FZ_NO_IMAD": "1"},
+    {"FZ_UNFUSED": "1"},                               # the multi-launch paths other degrees take
 ]
 
 
@@ -61,7 +53,9 @@ def test_transform_launch_shapes(secpar, env, coracle):
     ctx = _ctx(P, env)
     rng = np.random.default_rng(secpar)
     try:
-        for rows in (1, 3, 64, 65, 257, 4099):
+        # one-row-group launches use workgroups of 1 / 4 / 8 waves from 4 x / 8 x 256 wave-tasks on (a task = 1 row at degree
+        # 256, 4 rows at degree 64): 1500 and 4099 rows at degree 256, 4099 and 8300 at degree 64 reach the larger two
+        for rows in (1, 3, 64, 65, 257, 1500, 4099, 8300):
             x = O.splitmix_centered(rows + secpar, rows * d).reshape(rows, d).copy()
             x[0, :] = I32.min                      # any int32 is a legal input
             if rows > 1:
@@ -156,16 +150,16 @@ def test_matvec_forms(secpar, slices, coracle):
         ctx.close()
 
 
-@pytest.mark.parametrize("waves", ["0", "7", "1", "2", "3", "4", "6"])
 @pytest.mark.parametrize("secpar", [128, 256])
-def test_many_aggregates_verification_forms(secpar, waves, coracle):
-    """a workgroup per aggregate (512 aggregates or more per launch): the 16-per-lane kernel with 1 .. 6 waves per workgroup
-    (FZ_VERIFY16; 7 = the divisor of the tasks) and the default radix-4 kernel (0) give the oracle's verdicts -- int32 rows and int64 partial sums, ranks that fill the last
-    wave-task and ranks that do not, passing / norm-failing / target-mismatching aggregates, any int32 in A (fusion.py:690-727)"""
+def test_many_aggregates_verification_forms(secpar, coracle):
+    """a workgroup per aggregate (512 aggregates or more per launch) gives the oracle's verdicts -- int32 rows and int64 partial
+    sums, ranks that fill the last wave-task and ranks that do not, passing / norm-failing / target-mismatching aggregates, any
+    int32 in A (fusion.py:690-727)"""
+    waves = "0"
     import fusion_hip
     P = O.PARAMS[secpar]
     q, d = P["q"], P["d"]
-    ctx = _ctx(P, {"FZ_VERIFY16": waves})
+    ctx = _ctx(P, {})
     rng = np.random.default_rng(secpar + int(waves) + 40)
     groups = 530
     try:

@@ -1,7 +1,10 @@
 #!/bin/bash
 # Regenerates every measurement committed under profiles/ in ONE gpurun call (one box: numbers from different
 # boxes differ by several percent).  usage (from the repo root):
-#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02'      then copy gpurun_out/<tag>/<tag>_* to profiles/
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r04'      then copy gpurun_out/<tag>/<tag>_* to profiles/
+# The rocprofv3 pass over bench.py runs `--headline-only`: the timed region (graph replays over the rotating batches) and the
+# per-dispatch passes, nothing else -- its kernel_stats average for the forward kernel is the figure bench.py's roofline.frac
+# must agree with (8 388 608 B / AverageNs).
 # Stops at the first step that fails or times out: no further GPU work is started after a failed one.
 set -u
 TAG=${1:-rXX}
@@ -20,7 +23,8 @@ step timeout -k 10 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
 step timeout -k 10 120 ./tools/microbench/build/launch_floor > $OUT/${TAG}_launch_floor.txt 2>&1
 step timeout -k 10 300 python tools/kernel_table.py > $OUT/${TAG}_kernel_table.txt 2>&1
 step timeout -k 10 300 python tools/kernel_table.py --secpar 128 > $OUT/${TAG}_kernel_table_secpar128.txt 2>&1
-step timeout -k 10 300 python tools/agg_tune.py --twopass > $OUT/${TAG}_aggregate_shapes.txt 2>&1
+step timeout -k 10 400 python tools/agg_direct_ab.py > $OUT/${TAG}_aggregate_direct_ab.txt 2>&1
+step timeout -k 10 300 python tools/agg_direct_ab.py --small >> $OUT/${TAG}_aggregate_direct_ab.txt 2>&1
 step timeout -k 10 200 python tools/ntt_ab.py > $OUT/${TAG}_ntt_small_batches.txt 2>&1
 step timeout -k 10 200 python tools/challenge_bench.py > $OUT/${TAG}_challenge_pipeline.txt 2>&1
 step timeout -k 10 200 python tools/keygen_probe.py > $OUT/${TAG}_keygen_end_to_end.txt 2>&1
@@ -32,17 +36,17 @@ for st in none 0 1; do FZ_NO_PIN=1 timeout -k 10 100 python tools/numa_switch.py
 step timeout -k 10 200 python tools/keccak_bench.py > $OUT/${TAG}_keccak_variants_gpu_host.txt 2>&1
 step timeout -k 10 300 ./tools/microbench/build/ntt_variants 300 > $OUT/${TAG}_ntt_variants_current_kernels.txt 2>&1
 step timeout -k 10 120 ./tools/microbench/build/ntt_structures 200 > $OUT/${TAG}_ntt_structures.txt 2>&1
-step timeout -k 10 400 bash tools/keygen_ab.sh > $OUT/${TAG}_keygen_ab.txt 2>&1
 step timeout -k 10 200 python tools/clock_under_load.py > $OUT/${TAG}_shader_clock_under_load.txt 2>&1
 step timeout -k 10 200 python tools/clock_under_load.py --secpar 128 >> $OUT/${TAG}_shader_clock_under_load.txt 2>&1
 step timeout -k 10 600 bash tools/matvec_ab.sh > $OUT/${TAG}_matvec_ab_raw.txt 2>&1
-step timeout -k 10 800 bash tools/verify_ab.sh > $OUT/${TAG}_verify_ab_raw.txt 2>&1
+step timeout -k 10 300 python tools/queue_probe.py > $OUT/${TAG}_queue_probe.txt 2>&1
+step timeout -k 10 300 python tools/sharded_modes.py > $OUT/${TAG}_sharded_alpha_modes_raw.txt 2>&1
 step timeout -k 10 300 python tools/benchmarks.py 256 128 > $OUT/${TAG}_api_benchmarks.json 2> $OUT/api_benchmarks.err
 step timeout -k 10 200 python tools/object_api_profile.py 256 16 > $OUT/${TAG}_object_api_profile.txt 2>&1
-step timeout -k 10 500 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
+step timeout -k 10 600 python bench.py --full --full-out $OUT/${TAG}_bench_full.json > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations from the profiler: the bench's transform launches, the cold kernel table, the challenge pipeline
-step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --no-cpu-baseline --no-sweep --no-sign-verify --no-two-stream --no-kernel-table > $OUT/prof.log 2>&1
+step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --headline-only --full-out $OUT/prof_bench_full.json > $OUT/prof.log 2>&1
 cp $OUT/prof/*/*_kernel_stats.csv $OUT/${TAG}_bench_rocprofv3_kernel_stats.csv 2>/dev/null
 step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profk -- python3 $R/tools/kernel_table.py > $OUT/profk.log 2>&1
 cp $OUT/profk/*/*_kernel_stats.csv $OUT/${TAG}_kernel_table_rocprofv3_kernel_stats.csv 2>/dev/null
@@ -51,7 +55,7 @@ cp $OUT/profc/*/*_kernel_stats.csv $OUT/${TAG}_challenge_rocprofv3_kernel_stats.
 # PMC passes: one counter set per pass, nothing else traced
 for set in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU"; do
   n=$(echo $set | tr " " "_" | cut -c1-30)
-  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcb/$n -- python3 $R/bench.py --no-cpu-baseline --no-sweep --no-sign-verify --no-two-stream --no-kernel-table --no-graph --steps 50 --prewarm-ms 20 > $OUT/pmcb_$n.log 2>&1
+  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcb/$n -- python3 $R/bench.py --headline-only --no-graph --steps 50 --prewarm-ms 20 --full-out $OUT/pmcb_bench_full.json > $OUT/pmcb_$n.log 2>&1
   step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc20/$n -- python3 $R/tools/prof_ntt.py 20 30 > $OUT/pmc20_$n.log 2>&1
   step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcs/$n -- python3 $R/tools/prof_scheme.py 12 > $OUT/pmcs_$n.log 2>&1
 done

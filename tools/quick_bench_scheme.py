@@ -64,9 +64,9 @@ for logn in (12, 16, 18):
     g = DB.from_numpy(ctx, O.splitmix_centered(7, n * d).reshape(n, d))
     o = DB(ctx, n * d * 4)
     t = timeit(lambda: ctx.poly_mul_dev(f.ptr, g.ptr, o.ptr, n), reps=20)
-    os.environ["FZ_POLYMUL_UNFUSED"] = "1"
+    os.environ["FZ_UNFUSED"] = "1"
     tu = timeit(lambda: ctx.poly_mul_dev(f.ptr, g.ptr, o.ptr, n), reps=20)
-    del os.environ["FZ_POLYMUL_UNFUSED"]
+    del os.environ["FZ_UNFUSED"]
     print(f"poly_mul      {n} products: {t*1e6:9.1f} us  {12*d*n/t/1e9:7.1f} GB/s algorithmic ({12*d*n/t/8e12*100:.1f}% of 8 TB/s); "
           f"four launches instead: {tu*1e6:9.1f} us")
     for b in (f, g, o):

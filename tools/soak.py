@@ -42,18 +42,14 @@ def make_ctx(secpar, kernel, env=None):
 ctxs = {(sp, k): make_ctx(sp, k) for sp in (128, 256) for k in ("", "4", "16")}
 # the radix-4 kernels with 1 / 2 / 4 row groups per wave and other workgroup shapes, whatever the batch size
 for sp_ in (128, 256):
-    ctxs[(sp_, "4r1")] = make_ctx(sp_, "4", {"FZ_NTT_ROWS": "1", "FZ_NTT_WAVES": "1"})
-    ctxs[(sp_, "4r1w4")] = make_ctx(sp_, "4", {"FZ_NTT_ROWS": "1", "FZ_NTT_WAVES": "4"})
+    ctxs[(sp_, "4r1")] = make_ctx(sp_, "4", {"FZ_NTT_ROWS": "1"})
     ctxs[(sp_, "4r2")] = make_ctx(sp_, "4", {"FZ_NTT_ROWS": "2"})
     ctxs[(sp_, "4r4")] = make_ctx(sp_, "4", {"FZ_NTT_ROWS": "4"})
-KERNS = ["", "4", "16", "4r1", "4r1w4", "4r2", "4r4"]
+KERNS = ["", "4", "16", "4r1", "4r2", "4r4"]
 # the multi-launch forms of the fused kernels and other launch shapes of the one-pass aggregation
-VARIANTS = [{}, {"FZ_KEYGEN_UNFUSED": "1", "FZ_VERIFY_UNFUSED": "1", "FZ_POLYMUL_UNFUSED": "1"}, {"FZ_AGG_TWOPASS": "1"},
-            {"FZ_AGG_WAVES": "4", "FZ_AGG_SLICES": "3"}, {"FZ_AGG_SLICES": "7", "FZ_VERIFY_ORDERED": "1"}, {"FZ_STREAM_PER_CU": "8"},
-            {"FZ_NO_IMAD": "1", "FZ_FUSED_ROWS": "1"}, {"FZ_FUSED_ROWS": "2", "FZ_VERIFY_CENT": "1"}, {"FZ_FUSED_ROWS": "1", "FZ_AGG_SLICES": "2"},
-            {"FZ_FUSED_TW": "1", "FZ_FUSED_PREFETCH": "2"}, {"FZ_FUSED_TW": "1", "FZ_FUSED_ROWS": "2", "FZ_FUSED_PREFETCH": "0"},
-            {"FZ_MATVEC_SLICES": "16"}, {"FZ_MATVEC_SLICES": "2"}, {"FZ_MATVEC_SLICES": "-1"},
-            {"FZ_VERIFY16": "7", "FZ_KEYGEN_BCAST_GENERAL": "1"}, {"FZ_VERIFY16": "2", "FZ_VERIFY16_NOPF": "1"}]
+VARIANTS = [{}, {"FZ_UNFUSED": "1"}, {"FZ_AGG_DIRECT": "-1"}, {"FZ_AGG_DIRECT": "2"}, {"FZ_AGG_DIRECT": "4", "FZ_VERIFY_ORDERED": "1"},
+            {"FZ_NO_IMAD": "1"}, {"FZ_VERIFY_CENT": "1"}, {"FZ_SHAKE_FORM": "2"},
+            {"FZ_MATVEC_SLICES": "16"}, {"FZ_MATVEC_SLICES": "2"}, {"FZ_MATVEC_SLICES": "-1"}]
 vctx = {(sp, i): make_ctx(sp, "", v) for sp in (128, 256) for i, v in enumerate(VARIANTS)}
 DB = fusion_hip.DeviceBuffer
 t_end = time.time() + budget

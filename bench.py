@@ -2,18 +2,23 @@
 """bench.py -- headline benchmark of the algebra hot path on MI355X.
 
 Workload (BASELINE.json configs[1]): secpar=256, batches of 4096 independent degree-256 polynomials resident in HBM.
-A STEP is one pass of the hot path over one batch: forward NTT of the batch, then inverse NTT of the result (two kernel
-launches, reference algebra/ntt.py:216-291 and :294-377).  Consecutive steps work on consecutive batches of a rotation of
-NBATCH batches (x_i -> y_i -> z_i, 768 MiB together), so every forward launch reads its input from HBM, not from a cache:
-`value` is an HBM number.  The K steps (--steps) are recorded into a hipGraph (fz_graph_*) and replayed R times inside the
-timed region, R chosen so that the region lasts >= 20 ms whatever K is.  `value` = NTTs per second over the whole job
-(forward and inverse each count, summed over all ranks); `ms_per_step` = elapsed / (R * K).  With --gpus N every rank owns
-its own batches (weak scaling, no data-path collective for the transforms).
+A STEP is one pass of the hot path over one batch: forward NTT of the batch, then inverse NTT of the result (reference
+algebra/ntt.py:216-291 and :294-377).  Consecutive steps work on consecutive batches of a rotation of NBATCH batches
+(x_i -> y_i -> z_i, 768 MiB together), so every forward transform reads its input from HBM, not from a cache: `value` is an
+HBM number.  The steps are SOFTWARE-PIPELINED: the forward transform of batch i + 1 and the inverse transform of batch i are
+independent, so they share ONE launch (fz_ntt_multi: a two-job table in the kernel arguments, 4096 forward + 4096 inverse
+transforms = 16 MiB of algorithmic bytes per launch); K steps are K + 1 launches (the first carries only a forward job, the
+last only an inverse one).  `--two-launch` times the un-pipelined form (fz_ntt_forward, then fz_ntt_inverse: two launches of
+8 MiB per step) instead; by default it is the side leg `two_launch_step`.  The K steps (--steps) are recorded into a hipGraph
+(fz_graph_*) and replayed R times inside the timed region, R chosen so that the region lasts >= 20 ms whatever K is.
+`value` = NTTs per second over the whole job (forward and inverse each count, summed over all ranks); `ms_per_step` =
+elapsed / (R * K).  With --gpus N every rank owns its own batches (weak scaling, no data-path collective for the transforms).
 
 Output: the LAST stdout line is ONE compact strict-JSON object (< 4 KB: compact_line()); everything measured, with its
 prose, goes to gpurun_out/bench_full.json.  The compact line carries
-  roofline      ONE fraction for the dominant kernel (forward NTT, 8*d algorithmic bytes per polynomial): per-dispatch
-                begin/end events on every forward launch of instrumented steps over the same rotating (cold) batches
+  roofline      ONE fraction for the dominant kernel (the two-job transform launch: 8*d algorithmic bytes per transform x 8192
+                transforms): per-dispatch begin/end events on every launch of instrumented steps over the same rotating
+                (cold) batches
   cpu_baseline  the pure-Python port of the reference's algebra path (oracle/oracle.py py_*), one host core, bounded sample
   sign_verify / keygen_sign   the metric's second half (algebra cores, sharded over the ranks, ONE int64 all-reduce per step)
   warm_replay   the same step re-reading ONE batch (cache-resident): the side number, never `value`
@@ -55,6 +60,8 @@ def parse(argv=None):
     ap.add_argument("--full", action="store_true", help="also run the side legs of tools/bench_legs.py (full file only)")
     ap.add_argument("--headline-only", action="store_true",
                     help="timed region + per-dispatch roofline passes only (what tools/collect_profiles.sh runs under rocprofv3)")
+    ap.add_argument("--two-launch", action="store_true",
+                    help="headline step as two launches (fz_ntt_forward, fz_ntt_inverse) instead of the software-pipelined one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sign-verify", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the timed steps one by one instead of replaying hipGraphs")
@@ -108,10 +115,11 @@ def compact_line(full):
     Counterpart of the reference harness' five numbers per N (benchmarks/benchmarks.py:144-171)."""
     out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                        "vs_baseline", "dtype", "data"))
-    out["config"] = _pick(full.get("config") or {}, ("workload", "batch", "degree", "modulus", "batches_rotated", "launch", "parallelism"))
+    out["config"] = _pick(full.get("config") or {}, ("workload", "batch", "degree", "modulus", "batches_rotated", "launches_per_step",
+                                                     "step", "launch", "parallelism"))
     roof = full.get("roofline") or {}
     out["roofline"] = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch",
-                                   "avg_launch_us", "median_launch_us", "launches_timed", "operands"), 5)
+                                   "units_per_launch", "avg_launch_us", "median_launch_us", "launches_timed", "operands"), 5)
     cb = full.get("cpu_baseline")
     out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample"), 5) if isinstance(cb, dict) else None
     if isinstance(cb, dict) and isinstance(cb.get("sample"), str):
@@ -120,6 +128,7 @@ def compact_line(full):
                                         "collective", "cpu_value", "error")),
                        ("keygen_sign", ("value", "unit", "ms_per_step", "hbm_frac_per_gpu", "cpu_value", "error")),
                        ("warm_replay", ("value", "unit", "ms_per_step")),
+                       ("two_launch_step", ("value", "unit", "ms_per_step")),
                        ("end_to_end", ("keygen_per_s", "sign_per_s", "aggregate_per_s", "verify_per_s", "queue_pairs_per_s"))):
         src = full.get(name)
         if isinstance(src, dict):
@@ -138,7 +147,7 @@ def compact_line(full):
             out[k] = str(full[k])[:200]
     text = json.dumps(out, allow_nan=False, separators=(",", ":"))
     # the limit is a contract: shed the optional blocks (never the required keys) rather than print an unparsable line
-    for drop in ("end_to_end", "warm_replay", "ranks", "keygen_sign"):
+    for drop in ("end_to_end", "warm_replay", "two_launch_step", "ranks", "keygen_sign"):
         if len(text) < LINE_LIMIT:
             break
         out.pop(drop, None)
@@ -166,7 +175,7 @@ def pmc_traffic(kernel_prefix="ntt_fwd4<8"):
         with open(path) as fh:
             ks = json.load(fh)["kernels"]
         vals = [v["traffic_bytes_per_launch"] for k, v in ks.items()
-                if k.startswith(kernel_prefix) and "B=4096" in k and "traffic_bytes_per_launch" in v]
+                if k.startswith(kernel_prefix) and "bench launch" in k and "traffic_bytes_per_launch" in v]
         if not vals:
             return None, f"{os.path.relpath(path, ROOT)} has no entry for {kernel_prefix}"
         return max(vals), os.path.relpath(path, ROOT)
@@ -488,8 +497,8 @@ def main():
     rot_p = [tuple(ctypes.c_void_p(t[i].data_ptr()) for t in (xs, ys, zs)) for i in range(NBATCH)]
     rot_i = [0]
 
-    def step():
-        """the next batch of the rotation: forward x_i -> y_i, inverse y_i -> z_i"""
+    def step2():
+        """un-pipelined: the next batch of the rotation, forward x_i -> y_i then inverse y_i -> z_i (two launches)"""
         a_, b_, c_ = rot_p[rot_i[0] % NBATCH]
         rot_i[0] += 1
         return fz_fwd(h, a_, b_, nB) | fz_inv(h, b_, c_, nB)
@@ -498,6 +507,35 @@ def main():
         """the same two launches on ONE batch (cache-resident after the first step): the side number"""
         a_, b_, c_ = rot_p[0]
         return fz_fwd(h, a_, b_, nB) | fz_inv(h, b_, c_, nB)
+
+    # software-pipelined: launch i = {forward x_i -> y_i, inverse y_(i-1) -> z_(i-1)} in ONE dispatch (fz_ntt_multi).  The job
+    # tables are built once per rotation index; PRO / EPI are the one-job launches that open and close a run of steps.
+    NttJob, fz_multi = fusion_hip._lib.NttJob, lib.fz_ntt_multi
+
+    def jobs(*items):
+        return (NttJob * len(items))(*[NttJob(i_, o_, B, inv) for i_, o_, inv in items])
+    PAIR = [jobs((rot_p[i][0], rot_p[i][1], 0), (rot_p[i - 1][1], rot_p[i - 1][2], 1)) for i in range(NBATCH)]
+    PRO = [jobs((rot_p[i][0], rot_p[i][1], 0)) for i in range(NBATCH)]
+    EPI = [jobs((rot_p[i][1], rot_p[i][2], 1)) for i in range(NBATCH)]
+    pipe_open = [False]
+
+    def step():
+        """the next step of the pipelined run: batch i enters (forward), batch i - 1 leaves (inverse), one launch"""
+        i = rot_i[0] % NBATCH
+        rot_i[0] += 1
+        if not pipe_open[0]:
+            pipe_open[0] = True
+            return fz_multi(h, PRO[i], 1)
+        return fz_multi(h, PAIR[i], 2)
+
+    def flush():
+        """the inverse of the batch that entered last: closes a run of pipelined steps (its K-th inverse transform)"""
+        if not pipe_open[0]:
+            return 0
+        pipe_open[0] = False
+        return fz_multi(h, EPI[(rot_i[0] - 1) % NBATCH], 1)
+    if args.two_launch:
+        step, flush = step2, (lambda: 0)
 
     def prewarm(fn, ms, inner=50):
         """untimed: keep the device busy for `ms` so the timed region starts at steady clocks"""
@@ -517,12 +555,13 @@ def main():
         torch.cuda.synchronize(dev)
         return a.elapsed_time(b_) / reps
 
-    def region(step_fn, K):
+    def region(step_fn, K, end_fn=lambda: 0):
         """W warmup steps, then the K steps (M repetitions per recording for K < 1000) replayed for >= MIN_REGION_MS between
-        two barriers -> (elapsed seconds max over ranks, steps timed, events-on-stream microseconds per launch, replays, M)"""
+        two barriers -> (elapsed seconds max over ranks, steps timed, events-on-stream microseconds per step, replays, M, clock)"""
         rot_i[0] = 0
         for _ in range(args.warmup):
             step_fn()
+        end_fn()
         barrier()
         M = max(1, 1000 // K) if K < 1000 else 1
         graphs = []
@@ -538,6 +577,7 @@ def main():
                 rc = 0
                 for _ in range(n_steps):
                     rc |= step_fn()
+                rc |= end_fn()                           # n_steps steps = n_steps + 1 launches when pipelined
                 g = ctx.graph_end()
                 assert rc == 0, f"capture failed: {lib.fz_last_error()}"
                 g.launch()                               # untimed first replay (upload)
@@ -554,6 +594,7 @@ def main():
                 rc = 0
                 for _ in range(K):
                     rc |= step_fn()
+                rc |= end_fn()
                 assert rc == 0, f"launch failed: {lib.fz_last_error()}"
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -571,7 +612,7 @@ def main():
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         total = launches * M * K
-        ev_us = ev0.elapsed_time(ev1) * 1e3 / (2 * total)
+        ev_us = ev0.elapsed_time(ev1) * 1e3 / total          # microseconds per STEP
         shader = None
         try:                                             # the shader clock the chip holds beside these launches (a diagnostic)
             for _ in range(max(1, launches // 4)):
@@ -586,10 +627,14 @@ def main():
 
     for _ in range(NBATCH):                              # every batch once: z_i defined whatever the flags below skip
         step()
+    flush()
     barrier()
     assert torch.equal(zs, xs), "INTT(NTT(x)) != x"
+    zs.zero_()
     prewarm(step, args.prewarm_ms)
-    elapsed, total_steps, region_launch_us, launches, M, shader_mhz = region(step, args.steps)
+    flush()
+    elapsed, total_steps, region_step_us, launches, M, shader_mhz = region(step, args.steps, flush)
+    torch.cuda.synchronize(dev)
     assert torch.equal(zs, xs), "INTT(NTT(x)) != x after the timed region"
     value = 2.0 * B * total_steps * world / elapsed
 
@@ -598,40 +643,51 @@ def main():
     # rotating batches: cold operands.  A hipGraph cannot carry the events, so these are instrumented passes right after the
     # timed region; the mean over ALL launches of all passes is the one fraction reported.
     n_inst, n_pass = 400, 3
-    fwd_all, inv_all, passes = [], [], []
+    dom_kind = 0 if args.two_launch else 2              # the dominant launch: the forward kernel, or the two-job launch
+    per_step = 2 if args.two_launch else 1
+    dom_all, inv_all, passes = [], [], []
     for _ in range(n_pass):
         prewarm(step, 20.0)                              # dense launches first: a one-by-one pass leaves the device half idle
-        ctx.profile_begin(2 * n_inst, args.sample_every)
+        ctx.profile_begin(per_step * n_inst + 2, args.sample_every)
         rc = 0
         for _ in range(n_inst):
             rc |= step()
         assert rc == 0, f"launch failed: {lib.fz_last_error()}"
-        us, kind = ctx.profile_end_samples(2 * n_inst)
-        f_, i_ = us[kind == 0], us[kind == 1]
-        assert len(f_) == len(i_) == (n_inst + args.sample_every - 1) // args.sample_every
-        fwd_all.append(f_)
+        us, kind = ctx.profile_end_samples(per_step * n_inst + 2)
+        rc = flush()                                     # (outside the instrumented launches: a one-job launch)
+        assert rc == 0, f"launch failed: {lib.fz_last_error()}"
+        f_, i_ = us[kind == dom_kind], us[kind == 1]
+        assert len(f_) >= n_inst // args.sample_every - 1, (len(f_), len(us))
+        dom_all.append(f_)
         inv_all.append(i_)
-        passes.append({"fwd_avg_us": float(f_.mean()), "fwd_median_us": float(np.median(f_)), "fwd_max_us": float(f_.max()),
-                       "inv_avg_us": float(i_.mean()), "inv_median_us": float(np.median(i_)), "count": int(len(f_))})
+        passes.append({"avg_us": float(f_.mean()), "median_us": float(np.median(f_)), "max_us": float(f_.max()), "count": int(len(f_)),
+                       "inverse_avg_us": float(i_.mean()) if len(i_) else None})
     torch.cuda.synchronize(dev)
     assert torch.equal(zs, xs), "INTT(NTT(x)) != x on the instrumented passes"
-    fwd_all, inv_all = np.concatenate(fwd_all), np.concatenate(inv_all)
-    fwd_us, inv_us = float(fwd_all.mean()), float(inv_all.mean())
-    fwd_bytes = 8.0 * d * B                              # 8*d algorithmic bytes per transform x 4096 per launch
-    ach = fwd_bytes / (fwd_us * 1e-6) / 1e9
-    traffic, traffic_src = pmc_traffic()
-    kernel_name = "ntt_fwd4<8, true, 1, 8>"
-    try:
-        kernel_name = ctx.ntt_kernel_name(B, False)
-    except Exception:
-        pass
+    dom_all = np.concatenate(dom_all)
+    inv_all = np.concatenate(inv_all)
+    dom_us = float(dom_all.mean())
+    # 8*d algorithmic bytes per transform; one dominant launch = 4096 forward (+ 4096 inverse when pipelined) transforms
+    units_per_launch = B if args.two_launch else 2 * B
+    dom_bytes = 8 * d * units_per_launch
+    ach = dom_bytes / (dom_us * 1e-6) / 1e9
+    if args.two_launch:
+        kernel_name = "ntt_fwd4<8, true, 1, 8>"
+        launch_text = "fz_ntt_forward + fz_ntt_inverse: two launches per step"
+    else:
+        cus = props.multi_processor_count                  # the launcher's rule (fz_launch_ntt_multi): row groups per wave by the launch's rows
+        nr_ = 1 if 2 * B <= 24 * cus else (2 if 2 * B <= 48 * cus else 4)
+        kernel_name = f"ntt_jobs4<8, true, {nr_}, {(8 if 2 * B >= 8 * cus else 4 if 2 * B >= 4 * cus else 1) if nr_ == 1 else 2}>"
+        launch_text = "software-pipelined: forward of batch i+1 + inverse of batch i in one fz_ntt_multi launch per step"
+    traffic, traffic_src = pmc_traffic(kernel_name)
 
     full = {
         "metric": METRIC, "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "repeats": launches * M,
         "warmup": args.warmup, "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "timed_region_ms": elapsed * 1e3,
         "config": {"workload": f"configs[1]: secpar={SECPAR}, {B} degree-{d} forward+inverse NTTs per step per GPU",
-                   "batch": B, "degree": d, "modulus": q, "batches_rotated": NBATCH, "kernels_per_step": 2,
+                   "batch": B, "degree": d, "modulus": q, "batches_rotated": NBATCH, "launches_per_step": per_step,
+                   "step": launch_text,
                    "parallelism": f"{world} independent rank(s), one batch rotation each",
                    "arithmetic": "exact integers carried in fp64 lanes (bit-identical to the reference's int arithmetic); int32 in and out",
                    "launch": "one by one" if args.no_graph else f"hipGraph of {M}x{args.steps} steps, {launches} replays",
@@ -640,15 +696,17 @@ def main():
         "ranks": ranks,
         "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "bytes_per_launch": fwd_bytes, "avg_launch_us": fwd_us, "median_launch_us": float(np.median(fwd_all)),
-                     "inverse_avg_launch_us": inv_us, "launches_timed": int(len(fwd_all)),
+                     "bytes_per_launch": dom_bytes, "units_per_launch": units_per_launch, "avg_launch_us": dom_us,
+                     "median_launch_us": float(np.median(dom_all)), "launches_timed": int(len(dom_all)),
+                     "inverse_avg_launch_us": float(inv_all.mean()) if len(inv_all) else None,
                      "operands": f"cold: rotation of {NBATCH} batches",
                      "passes": passes,
                      "timing": f"begin/end events on every {args.sample_every}th dispatch (hipExtLaunchKernelGGL) of {n_pass} passes of "
                                f"{n_inst} steps launched one by one after the timed region; mean over all launches",
-                     "region": {"avg_launch_us": region_launch_us, "frac": fwd_bytes / (region_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                "what": "HIP events around the timed region / launches (graph replay: consecutive dispatches overlap "
-                                        "launch and drain; forward and inverse averaged)"},
+                     "region": {"step_us": region_step_us,
+                                "frac": 16.0 * d * B / (region_step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                "what": "HIP events around the timed region / steps (graph replay: consecutive dispatches overlap "
+                                        "launch and drain): 16*d*4096 algorithmic bytes per step"},
                      "shader_mhz": shader_mhz, "butterflies_per_s": value * (d // 2) * 8},
     }
 
@@ -711,9 +769,18 @@ def main():
             prewarm(step_warm, 20.0)
             el, tot, ev_us, _, _, clk = region(step_warm, args.steps)
             return {"value": 2.0 * B * tot * world / el, "unit": "NTT/s", "ms_per_step": el / tot * 1e3,
-                    "region_launch_us": ev_us, "shader_mhz": clk,
-                    "what": "the timed region on ONE batch re-read every step (cache-resident): a side number, never `value`"}
+                    "region_step_us": ev_us, "shader_mhz": clk,
+                    "what": "two launches per step on ONE batch re-read every step (cache-resident; round 3's `value`): a side number"}
         full["warm_replay"] = leg("warm_replay", warm_leg)
+
+        # the un-pipelined step on the rotating batches (round 4's first form of the headline): fz_ntt_forward, fz_ntt_inverse
+        def two_launch_leg():
+            prewarm(step2, 20.0)
+            el, tot, ev_us, _, _, clk = region(step2, args.steps)
+            return {"value": 2.0 * B * tot * world / el, "unit": "NTT/s", "ms_per_step": el / tot * 1e3, "region_step_us": ev_us,
+                    "shader_mhz": clk, "what": "the same steps as two launches each (forward, then inverse) over the rotating batches"}
+        if not args.two_launch:
+            full["two_launch_step"] = leg("two_launch_step", two_launch_leg)
         from tools import bench_legs as L
         if not args.no_sign_verify:
             sv = leg("sign_verify", lambda: L.sign_verify(env))

@@ -703,8 +703,8 @@ int fz_profile_end(fz_ctx *ctx, double *fwd_avg_us, int *fwd_count, double *inv_
     FZ_DEV(ctx);
     ctx->prof_on = 0;
     FZ_HIP(hipStreamSynchronize(ctx->stream), "profile sync");
-    double sum[2] = {0, 0};
-    int cnt[2] = {0, 0};
+    double sum[3] = {0, 0, 0};                  // kind 2 (multi-job launches) is reported by fz_profile_end_samples only
+    int cnt[3] = {0, 0, 0};
     for (int i = 0; i < ctx->prof_n; ++i) {
         float ms = 0;
         FZ_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]), "event elapsed");
@@ -1165,7 +1165,6 @@ int fz_ntt_multi(fz_ctx *ctx, const fz_ntt_job *h_jobs, size_t n_jobs) {
         total += tasks;
         J.in[J.n] = jb.d_in;
         J.out[J.n] = jb.d_out;
-        J.end[J.n] = (unsigned)total;
         J.rows[J.n] = (unsigned)jb.rows | (jb.inverse ? 0x80000000u : 0u);
         ++J.n;
     }

@@ -60,7 +60,6 @@ struct fz_ctx {
     unsigned long long *d_aggacc;
     size_t aggacc_tiles;
     int agg_dirty;
-    int grid_multi[3];           // resident grid of the multi-job transform kernel per direction mix (0 = not queried yet)
     uint32_t *d_mt_init;         // MT19937 state after init_genrand(19650218) (fz_sample_secret_polys_dev), lazily
     uint32_t *d_chal_tab;        // weight table of the challenge decoder (fz_challenge.hip), built on first use
     int chal_tab_ib, chal_tab_degree;
@@ -104,7 +103,7 @@ constexpr int kFzMultiMax = 32;
 struct FzMultiJobs {
     const int32_t *in[kFzMultiMax];
     int32_t *out[kFzMultiMax];
-    unsigned end[kFzMultiMax];   // running total of wave-tasks up to and including job j
+    unsigned end[kFzMultiMax];   // running total of WORKGROUPS up to and including job j (filled by fz_launch_ntt_multi)
     unsigned rows[kFzMultiMax];  // rows of job j; bit 31 set: inverse transform
     int n;
 };
@@ -127,7 +126,7 @@ int fz_retire(fz_ctx *ctx, void *d_ptr, const char *what);       // hipFree, or 
 // launchers (fz_ntt.hip)
 int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch, bool inverse);
 int fz_ntt_query_grid(fz_ctx *ctx);
-int fz_launch_ntt_multi(fz_ctx *ctx, const FzMultiJobs &jobs);     // degree 64 / 256
+int fz_launch_ntt_multi(fz_ctx *ctx, FzMultiJobs &jobs);           // degree 64 / 256; fills jobs.end
 int fz_launch_diag_clock(hipStream_t stream, unsigned long long ticks, unsigned long long *d_out);
 int fz_launch_diag(fz_ctx *ctx, int what, const void *src, void *dst, size_t bytes);
 

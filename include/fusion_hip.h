@@ -122,12 +122,13 @@ FZ_API int fz_timer_start(fz_ctx *ctx);
 FZ_API int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms);        /* records, waits, returns elapsed ms */
 
 /* per-dispatch timing of the transform kernels: while enabled, every `sample_every`-th
- * fz_ntt_forward / fz_ntt_inverse launch carries a start/stop event pair bound to the dispatch
+ * fz_ntt_forward / fz_ntt_inverse / fz_ntt_multi launch carries a start/stop event pair bound to the dispatch
  * (kernel begin -> kernel end on the context's stream; at most max_launches pairs).
  * fz_profile_end synchronises and returns the average durations in microseconds. */
 FZ_API int fz_profile_begin(fz_ctx *ctx, int max_launches, int sample_every);
 FZ_API int fz_profile_end(fz_ctx *ctx, double *fwd_avg_us, int *fwd_count, double *inv_avg_us, int *inv_count);
-/* the same, every sample: us[k] the duration of the k-th instrumented launch, kind[k] 0 = forward, 1 = inverse */
+/* the same, every sample: us[k] the duration of the k-th instrumented launch, kind[k] 0 = forward, 1 = inverse,
+ * 2 = a multi-job launch (fz_ntt_multi) */
 FZ_API int fz_profile_end_samples(fz_ctx *ctx, double *us, int *kind, int cap, int *n);
 
 /* ---- transforms ---------------------------------------------------------------------------

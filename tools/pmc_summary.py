@@ -21,13 +21,15 @@ out = {"source": "rocprofv3 --pmc <one set per pass> --output-format csv (tools/
 for sub, (label, rows) in GROUPS.items():
     per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))       # kernel -> counter -> dispatch -> value
     dur = defaultdict(dict)
+    grid = {}
     for path in glob.glob(os.path.join(root, sub, "*", "*", "*_counter_collection.csv")):
         with open(path) as fh:
             for r in csv.DictReader(fh):
                 k = r["Kernel_Name"]
-                if "ntt_" not in k or "ntt_multi" in k:      # the multi-job launches of a bench run have varying job counts
+                if "ntt_" not in k:
                     continue
                 short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+                grid[short] = int(r.get("Grid_Size", 0) or 0)
                 per[short][r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
                 dur[short][int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
     for k, counters in per.items():
@@ -42,7 +44,14 @@ for sub, (label, rows) in GROUPS.items():
             e["read_bytes_corrected"] = e["FETCH_SIZE"] * 1024 * 2
             e["write_bytes"] = e["WRITE_SIZE"] * 1024
             e["traffic_bytes_per_launch"] = e["read_bytes_corrected"] + e["write_bytes"]
-            e["algorithmic_bytes_per_launch"] = rows * 2048
+            # rows of the launch: the radix-4 kernels (ntt_fwd4 / ntt_inv4 / ntt_jobs4 <LOGD, FAST, NR, WAVES>) run one wave-task of
+            # NR rows (degree 256) per wave, so rows = grid threads / 64 x NR -- the two-job launch of bench.py's pipelined step
+            # (4096 forward + 4096 inverse rows) is ntt_jobs4<8, true, 2, 2> with 8192 rows; other kernels: the group's batch
+            import re
+            m4 = re.search(r"ntt_(?:fwd4|inv4|jobs4)<(\d+), (?:true|false), (\d+), (\d+)>", k)
+            rows_k = (grid.get(k, 0) // 64) * int(m4.group(2)) if m4 and grid.get(k) else rows
+            e["rows_per_launch"] = rows_k
+            e["algorithmic_bytes_per_launch"] = rows_k * 2048
             e["traffic_over_algorithmic"] = e["traffic_bytes_per_launch"] / e["algorithmic_bytes_per_launch"]
         if "GRBM_GUI_ACTIVE" in e:
             e["cycles_per_launch_per_xcd"] = e["GRBM_GUI_ACTIVE"] / 8
@@ -54,7 +63,7 @@ for sub, (label, rows) in GROUPS.items():
         if "cycles_per_launch_per_xcd" in e and e["serialised_duration_us_under_pmc"] > 100:     # the counter window of a
             # few-microsecond dispatch is longer than the kernel, so the ratio only means something for long kernels
             e["effective_clock_ghz_under_pmc"] = e["cycles_per_launch_per_xcd"] / e["serialised_duration_us_under_pmc"] * 1e-3
-        out["kernels"][f"{k} {label}"] = e
+        out["kernels"][f"{k} {label}" if "rows_per_launch" not in e or e["rows_per_launch"] == rows else f"{k} B={e['rows_per_launch']} (bench launch)"] = e
 with open(os.path.join(root, f"{tag}_pmc_ntt.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))

@@ -813,6 +813,11 @@ def main():
     if world > 1:
         barrier()                                       # rank 0's single-rank legs are done: leave together
         dist.destroy_process_group()
+        # the result is out and the process group is gone: leave without running the interpreter's teardown, in which torch's
+        # RCCL and the communicator the C ABI created through the same library would be unloaded in an order nobody controls
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 _BAILING = threading.Event()       # set by the watchdog: from then on an exception in the main thread is a peer leaving

@@ -40,8 +40,10 @@ def canned(world=1, prose=2000):
         "ranks": ranks,
         "roofline": {"bound": "hbm", "kernel": "ntt_fwd4<8, true, 1, 8>", "achieved": 1843.2123456, "peak": 8000.0, "unit": "GB/s",
                      "frac": 0.2304015432, "traffic": 8433839.0, "traffic_source": blob, "bytes_per_launch": 8388608.0,
-                     "avg_launch_us": 4.551, "median_launch_us": 4.5, "launches_timed": 1200, "operands": "cold: rotation of 64 batches",
-                     "passes": [{"fwd_avg_us": 4.5, "note": blob}] * 3, "timing": blob, "region": {"what": blob}, "shader_mhz": 2392},
+                     "avg_launch_us": 4.551, "launches_timed": 1200, "operands": "cold: rotation of 64 batches",
+                     "isolated": {"passes": [{"avg_us": 4.5, "note": blob}] * 3, "what": blob},
+                     "timing": "HIP events on the kernels' stream around the timed region (dense graph replays) / launches in it",
+                     "shader_mhz": 2392},
         "warm_replay": {"value": 1.2e9, "unit": "NTT/s", "ms_per_step": 0.0067, "what": blob},
         "sign_verify": {"value": 14410006.6, "unit": "signatures signed+aggregated+verified per s", "ms_per_step": 0.0711,
                         "hbm_frac_per_gpu": 0.6234, "aggregates": 4, "signers_per_aggregate": 256, "note": blob,
@@ -84,7 +86,7 @@ def test_compact_line_is_strict_json_under_the_limit_with_the_contract_keys(benc
     if world > 1:
         assert all(rk["rccl_nranks"] == world and rk["rccl_version"] == 22703 for rk in out["ranks"])
     # one number per side leg, no prose
-    assert "xxxx" not in line and "kernels" not in out and "passes" not in r
+    assert "xxxx" not in line and "kernels" not in out and "passes" not in r and "isolated" not in r
     assert r["bytes_per_launch"] == 8388608 and isinstance(r["bytes_per_launch"], int)
 
 

@@ -101,9 +101,10 @@ def test_config2_keygen_and_sign_on_1024_distinct_keys(coracle):
         S["dev"].close()
 
 
-@pytest.mark.parametrize("secpar,n", [(256, 256), (256, 1024), (256, 2048), (256, 2818), (128, 1796), (128, 1024)])
+@pytest.mark.parametrize("secpar,n", [(256, 128), (256, 256), (256, 1024), (256, 2048), (256, 2818), (128, 1796), (128, 1024), (128, 128)])
 def test_config3_aggregate_and_verify_at_full_size(secpar, n, coracle):
-    """BASELINE configs[3] sizes up to the capacity (fusion.py:24-25): aggregate_core, the one-pass int64 partials of
+    """BASELINE configs[3] sizes from one rank's share at 8 GPUs (128 signers: the slice-free aggregation kernel takes the
+    launch) up to the capacity (fusion.py:24-25): aggregate_core, the one-pass int64 partials of
     aggregate + target, fz_reduce_i64, verification from the int64 partials -- each against the oracle, with a tampered
     aggregate per size and the two-shard form of the multi-GPU exchange (partials of two signer blocks added on the host)."""
     import fusion_hip

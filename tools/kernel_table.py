@@ -96,10 +96,11 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
     run("sign_kernel", S, (3 * l + 1) * row, kb + S * row, S * l * row,
         lambda i, o: ctx.sign_core_dev(i, i + kb, o, S, l))
     # aggregate (fusion.py:670-676): sig [N][l][d], alpha [N][d] -> [l][d]
-    for N in (256, 1024, 2048):
+    for N in (128, 256, 1024, 2048):
         sb = N * l * row
-        run(f"aggregate_onepass N={N}", N, (l + 1) * row, sb + N * row, l * row,
-            lambda i, o, N=N, sb=sb: ctx.aggregate_core_dev(i, i + sb, o, N, l))
+        run(f"aggregate N={N}" + (" (direct)" if N <= 256 else " (onepass)"), N, (l + 1) * row, sb + N * row, l * row,
+            lambda i, o, N=N, sb=sb: ctx.aggregate_core_dev(i, i + sb, o, N, l),
+            note="launches of <= 256 signers take aggregate_direct (no signer slices), larger ones aggregate_onepass")
     # aggregate + target partials in one pass, 4 aggregates of 256 signers (the bench's sign_verify step)
     G, per = 4, 256
     sb = G * per * l * row
@@ -108,6 +109,14 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
         lambda i, o: ctx.aggregate_target_partial_batch_dev(i, i + sb, i + sb + vb, i + sb + 2 * vb, i + sb + 3 * vb, o, l * d,
                                                             o + G * l * d * 8, d, G, per, l),
         note="reads sigma + alpha + vkL + vkR + c_hat: (l + 5) rows per signer")
+    # the same at 8 ranks (BASELINE configs[3]: 1024 signers over 8 GPUs): 8 aggregates of 128 local signers
+    G, per = 8, 128
+    sb = G * per * l * row
+    vb = G * per * row
+    run("aggregate_onepass+target 8x128", G * per, (l + 5) * row, sb + 4 * vb, G * (l + 1) * d * 8,
+        lambda i, o: ctx.aggregate_target_partial_batch_dev(i, i + sb, i + sb + vb, i + sb + 2 * vb, i + sb + 3 * vb, o, l * d,
+                                                            o + G * l * d * 8, d, G, per, l),
+        note="one rank's launch of the sign_verify step at world 8")
     # verify from int32 aggregates (fusion.py:690-727): sig [G][l][d] + target [G][d] -> verdict codes
     for G in (1, 64, 1024, 8192):
         vb = G * l * row
@@ -139,6 +148,12 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
             nb = 1 << logb
             run(f"ntt_forward B=2^{logb}", nb, 2 * row, nb * row, nb * row, lambda i, o, nb=nb: ctx.ntt_forward_dev(i, o, nb))
             run(f"ntt_inverse B=2^{logb}", nb, 2 * row, nb * row, nb * row, lambda i, o, nb=nb: ctx.ntt_inverse_dev(i, o, nb))
+    if not quick:
+        # bench.py's software-pipelined step: a forward job and an inverse job of 4096 rows in ONE fz_ntt_multi launch
+        nb = 4096
+        run("ntt_multi pair 2x4096 (fwd + inv)", 2 * nb, 2 * row, 2 * nb * row, 2 * nb * row,
+            lambda i, o: ctx.ntt_multi_dev([(i, o, nb, False), (i + nb * row, o + nb * row, nb, True)]),
+            note="HOST-PACED here (the job table is built per launch in Python): see tools/ntt_ab.py / bench.py for the dense figure")
     for b in (pool_in, pool_out, A):
         b.free()
     return out

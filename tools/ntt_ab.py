@@ -1,35 +1,84 @@
-import sys, os, time
-sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "fusion-cryptography_amd")); sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+"""Transforms of small batches on cold operands (sets rotate through 2.25 GiB pools): the one-job launches at 2^12 .. 2^15 rows,
+and fz_ntt_multi with 1 .. 8 jobs of 4096 rows per launch -- all forward, all inverse, and the bench's pipelined pair (one
+forward job + one inverse job).  Job tables are built BEFORE the timed loops (a ctypes array per launch built in Python costs
+more than the launch) and the launches are issued back to back; HIP events on the kernels' stream.
+Reference: algebra/ntt.py:216-291, :294-377.  Output: profiles/r04_ntt_small_batches.txt"""
+import ctypes
+import os
+import sys
+import time
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "fusion-cryptography_amd"))
+sys.path.insert(0, ROOT)
 import fusion_hip
+from fusion_hip._lib import NttJob
 from fusion_hip.numa import pin_to_gpu_node
 pin_to_gpu_node(0)          # host threads on the GPU's NUMA node (before the first HIP call)
-from oracle import oracle as O
+from oracle import oracle as O      # parameters only (tools/ is not product code)
 import numpy as np
+
 P = O.PARAMS[256]
 ctx = fusion_hip.Context(P["q"], P["d"], P["root"], P["inv_root"])
-s = ctx.stream_create(); ctx.set_stream(s)
+s = ctx.stream_create()
+ctx.set_stream(s)
 POOL = 9 << 28
 pin, pout = fusion_hip.DeviceBuffer(ctx, POOL), fusion_hip.DeviceBuffer(ctx, POOL)
-ctx.fill_synthetic_dev(pin.ptr, POOL // 4, 5); ctx.synchronize()
+ctx.fill_synthetic_dev(pin.ptr, POOL // 4, 5)
+ctx.synchronize()
 x = O.splitmix_centered(1, 300 * 256).reshape(300, 256)
 assert np.array_equal(ctx.ntt_inverse(ctx.ntt_forward(x)), x)
-def t(fn, nb, jobs=1):
-    step = nb * 1024 * jobs; ns = POOL // step; k = [0]
-    def one():
-        i = pin.ptr + (k[0] % ns) * step; o = pout.ptr + (k[0] % ns) * step; k[0] += 1; fn(i, o)
+lib, h = ctx._lib, ctx._h
+
+
+def timed(calls):
+    """calls: a list of zero-argument launches over rotating operand sets -> microseconds per launch (300 launches)"""
+    n, k = len(calls), 0
     te = time.perf_counter() + 0.03
     while time.perf_counter() < te:
-        for _ in range(3): one()
+        for _ in range(3):
+            calls[k % n]()
+            k += 1
         ctx.synchronize()
     ctx.timer_start()
-    for _ in range(300): one()
+    for _ in range(300):
+        calls[k % n]()
+        k += 1
     return ctx.timer_stop_ms() / 300 * 1e3
+
+
+def frac(rows, us):
+    return rows * 2048 / us / 8e6 * 100
+
+
 for lb in (12, 13, 14, 15):
     nb = 1 << lb
-    f = t(lambda i, o: ctx.ntt_forward_dev(i, o, nb), nb); v = t(lambda i, o: ctx.ntt_inverse_dev(i, o, nb), nb)
-    print(f"B=2^{lb}: fwd {f:7.2f} us ({nb*2048/f/8e6*100:5.1f}%)  inv {v:7.2f} us ({nb*2048/v/8e6*100:5.1f}%)")
+    step = nb * 1024
+    sets = POOL // step
+    cnb = ctypes.c_size_t(nb)
+    fw = [(lambda i=ctypes.c_void_p(pin.ptr + k * step), o=ctypes.c_void_p(pout.ptr + k * step): lib.fz_ntt_forward(h, i, o, cnb)) for k in range(sets)]
+    iv = [(lambda i=ctypes.c_void_p(pin.ptr + k * step), o=ctypes.c_void_p(pout.ptr + k * step): lib.fz_ntt_inverse(h, i, o, cnb)) for k in range(sets)]
+    f, v = timed(fw), timed(iv)
+    print(f"B=2^{lb}: fwd {f:7.2f} us ({frac(nb, f):5.1f}%)  inv {v:7.2f} us ({frac(nb, v):5.1f}%)", flush=True)
+nb = 4096
 for jobs in (1, 2, 3, 4, 6, 8):
-    nb = 4096
-    f = t(lambda i, o: ctx.ntt_multi_dev([(i + j * nb * 1024, o + j * nb * 1024, nb, False) for j in range(jobs)]), nb, jobs)
-    v = t(lambda i, o: ctx.ntt_multi_dev([(i + j * nb * 1024, o + j * nb * 1024, nb, True) for j in range(jobs)]), nb, jobs)
-    print(f"multi {jobs}x4096 (cold): fwd {f:7.2f} us ({jobs*nb*2048/f/8e6*100:5.1f}%)  inv {v:7.2f} us ({jobs*nb*2048/v/8e6*100:5.1f}%)")
+    step = nb * 1024 * jobs
+    sets = POOL // step
+
+    def table(k, inverse):
+        arr = (NttJob * jobs)(*[NttJob(pin.ptr + k * step + j * nb * 1024, pout.ptr + k * step + j * nb * 1024, nb, inverse) for j in range(jobs)])
+        return lambda: lib.fz_ntt_multi(h, arr, jobs)
+    f = timed([table(k, 0) for k in range(sets)])
+    v = timed([table(k, 1) for k in range(sets)])
+    print(f"multi {jobs}x4096 (cold): fwd {f:7.2f} us ({frac(jobs * nb, f):5.1f}%)  inv {v:7.2f} us ({frac(jobs * nb, v):5.1f}%)", flush=True)
+# the bench's pipelined step: forward of one batch + inverse of another in one launch
+step = nb * 1024 * 2
+sets = POOL // step
+
+
+def pair(k):
+    arr = (NttJob * 2)(NttJob(pin.ptr + k * step, pout.ptr + k * step, nb, 0),
+                       NttJob(pin.ptr + k * step + nb * 1024, pout.ptr + k * step + nb * 1024, nb, 1))
+    return lambda: lib.fz_ntt_multi(h, arr, 2)
+p_ = timed([pair(k) for k in range(sets)])
+print(f"pair  1 fwd + 1 inv x4096 (cold): {p_:7.2f} us ({frac(2 * nb, p_):5.1f}%)   [bench.py's software-pipelined step]", flush=True)

@@ -18,6 +18,19 @@ struct FzTwA {
     double n_inv2, w1_n_inv2;   // their quotient twiddles
 };
 
+// the same for the radix-4 kernels, which use entries 1..3 only: 96 bytes of kernel arguments instead of 288 per direction
+// (the multi-job launch carries both directions: a launch's scalar loads are in front of its first data load)
+struct FzTw4 {
+    double w[4], w2[4];
+    double n_inv, w1_n_inv, n_inv2, w1_n_inv2;
+};
+static inline FzTw4 fz_tw4(const FzTwA &a) {
+    FzTw4 t;
+    for (int i = 0; i < 4; ++i) { t.w[i] = a.w[i]; t.w2[i] = a.w2[i]; }
+    t.n_inv = a.n_inv; t.w1_n_inv = a.w1_n_inv; t.n_inv2 = a.n_inv2; t.w1_n_inv2 = a.w1_n_inv2;
+    return t;
+}
+
 struct fz_ctx {
     int device;
     int num_cu;
@@ -106,6 +119,14 @@ struct FzMultiJobs {
     unsigned end[kFzMultiMax];   // running total of WORKGROUPS up to and including job j (filled by fz_launch_ntt_multi)
     unsigned rows[kFzMultiMax];  // rows of job j; bit 31 set: inverse transform
     int n;
+};
+
+// the table of a launch of at most four jobs: 96 bytes of kernel arguments instead of 772
+struct FzJobs4 {
+    const int32_t *in[4];
+    int32_t *out[4];
+    unsigned end[4];
+    unsigned rows[4];
 };
 
 struct fz_graph {

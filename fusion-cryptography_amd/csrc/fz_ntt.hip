@@ -380,9 +380,9 @@ __device__ __forceinline__ void tw_set(double &dst, const double2 &src) { dst = 
 // lanes hold 64 / (D/4) polynomials per group) go through the passes in lock step: one wave-local synchronisation per
 // pass whatever NR is, twiddles and LDS offsets computed once, and NR independent dependency chains for the fp64 pipeline.
 // Row group r of this lane's polynomial lives at region + r * 256 doubles.
-template <int LOGD, bool FAST, int NR, typename TW = double2>
+template <int LOGD, bool FAST, int NR, typename TW = double2, typename TWA = FzTwA>
 __device__ __forceinline__ void fwd4_passes_n(double (&a)[NR][4], double *region, const TW (&twl)[LOGD / 2 - 1][3],
-                                              const FzTwA &twA, const FzMod &m, int mm) {
+                                              const TWA &twA, const FzMod &m, int mm) {
     constexpr int D = 1 << LOGD, P = LOGD / 2;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -468,7 +468,7 @@ __device__ __forceinline__ void fwd4_load_twiddles(TW (&twl)[LOGD / 2 - 1][3], c
 // one wave-task of the forward transform: NR row groups starting at polynomial poly0 (this lane's polynomial of group 0)
 template <int LOGD, bool FAST, int NR>
 __device__ __forceinline__ void fwd4_task(const int32_t *in, int32_t *out, size_t batch, size_t poly0, double *region, int mm,
-                                          const double2 *__restrict__ tw2, const FzTwA &twA, const FzMod &m) {
+                                          const double2 *__restrict__ tw2, const FzTw4 &twA, const FzMod &m) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     int x[NR][4];                                 // the data loads first: they have the longest way to go
 #pragma unroll
@@ -497,7 +497,7 @@ __device__ __forceinline__ void fwd4_task(const int32_t *in, int32_t *out, size_
 
 template <int LOGD, bool FAST, int NR, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void ntt_fwd4(const int32_t *in, int32_t *out, size_t batch,
-                                                       const double2 *__restrict__ tw2, FzTwA twA, FzMod m) {
+                                                       const double2 *__restrict__ tw2, FzTw4 twA, FzMod m) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
     __shared__ __attribute__((aligned(16))) double lds[WAVES * NR * 256];
@@ -512,9 +512,9 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_fwd4(const int32_t *in, int32_
 // the log4(D) in-place passes of the radix-4 inverse on one lane's 4 values per row group (bit-reversed positions
 // 4mm..4mm+3 in, natural positions mm + (D/4)k out, n^-1 applied, NOT yet centred); NR row groups in lock step (see
 // fwd4_passes_n)
-template <int LOGD, bool FAST, int NR, typename TW = double2>
+template <int LOGD, bool FAST, int NR, typename TW = double2, typename TWA = FzTwA>
 __device__ __forceinline__ void inv4_passes_n(double (&a)[NR][4], double *region, const TW (&twl)[LOGD / 2 - 1][3],
-                                              const FzTwA &twA, const FzMod &m, int mm) {
+                                              const TWA &twA, const FzMod &m, int mm) {
     constexpr int P = LOGD / 2;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -599,7 +599,7 @@ __device__ __forceinline__ void inv4_load_twiddles(TW (&twl)[LOGD / 2 - 1][3], c
 
 template <int LOGD, bool FAST, int NR>
 __device__ __forceinline__ void inv4_task(const int32_t *in, int32_t *out, size_t batch, size_t poly0, double *region, int mm,
-                                          const double2 *__restrict__ itw2, const FzTwA &twA, const FzMod &m) {
+                                          const double2 *__restrict__ itw2, const FzTw4 &twA, const FzMod &m) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, P = LOGD / 2;
     int4 x[NR];
 #pragma unroll
@@ -628,7 +628,7 @@ __device__ __forceinline__ void inv4_task(const int32_t *in, int32_t *out, size_
 
 template <int LOGD, bool FAST, int NR, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void ntt_inv4(const int32_t *in, int32_t *out, size_t batch,
-                                                       const double2 *__restrict__ itw2, FzTwA twA, FzMod m) {
+                                                       const double2 *__restrict__ itw2, FzTw4 twA, FzMod m) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
     static_assert(LOGD % 2 == 0 && LOGD >= 6 && LOGD <= 8, "radix-4 kernel: degree 64 or 256");
     __shared__ __attribute__((aligned(16))) double lds[WAVES * NR * 256];
@@ -652,9 +652,10 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_inv4(const int32_t *in, int32_
 // (profiles/r03_ntt_small_batches.txt) -- a forward job and an inverse job of 4096 rows in one launch is the software-pipelined
 // form of BASELINE configs[1]'s step (forward of batch i+1 beside the inverse of batch i), so that gap was the headline's.
 // ------------------------------------------------------------------------------------------
-template <int LOGD, bool FAST, int NR, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void ntt_jobs4(FzMultiJobs J, const double2 *__restrict__ tw2, const double2 *__restrict__ itw2,
-                                                        FzTwA twA, FzTwA itwA, FzMod m) {
+// JT: FzJobs4 (a launch of at most four jobs: 96 bytes of table) or FzMultiJobs (up to 32)
+template <int LOGD, bool FAST, int NR, int WAVES, typename JT>
+__global__ __launch_bounds__(64 * WAVES) void ntt_jobs4(JT J, const double2 *__restrict__ tw2, const double2 *__restrict__ itw2,
+                                                        FzTw4 twA, FzTw4 itwA, FzMod m) {
     constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
     __shared__ __attribute__((aligned(16))) double lds[WAVES * NR * 256];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -678,13 +679,15 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_jobs4(FzMultiJobs J, const dou
     unsigned rw = g2 ? r3 : (g1 ? r2 : (g0 ? r1 : r0));
     const int32_t *in = g2 ? i3 : (g1 ? i2 : (g0 ? i1 : i0));
     int32_t *out = g2 ? o3 : (g1 ? o2 : (g0 ? o1 : o0));
-    if (b >= e3) {                                                    // job 4 or later: the scan
-        int j = 4;
-        while (b >= J.end[j]) ++j;                                    // workgroup-uniform, <= 32 entries
-        first = J.end[j - 1];
-        rw = J.rows[j];
-        in = J.in[j];
-        out = J.out[j];
+    if constexpr (!__is_same(JT, FzJobs4)) {
+        if (b >= e3) {                                                // job 4 or later: the scan
+            int j = 4;
+            while (b >= J.end[j]) ++j;                                // workgroup-uniform, <= 32 entries
+            first = J.end[j - 1];
+            rw = J.rows[j];
+            in = J.in[j];
+            out = J.out[j];
+        }
     }
     const size_t rows = rw & 0x7fffffffu;
     const bool inverse = (rw >> 31) != 0;
@@ -1218,10 +1221,10 @@ void launch4n(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool i
     const dim3 grid((unsigned)((tasks + WAVES - 1) / WAVES)), block(64 * WAVES);
     if (!inverse)
         hipExtLaunchKernelGGL((ntt_fwd4<LOGD, FAST, NR, WAVES>), grid, block, 0, ctx->stream, e0, e1, 0, in, out, batch,
-                              (const double2 *)ctx->d_tw2, ctx->twA, ctx->mod);
+                              (const double2 *)ctx->d_tw2, fz_tw4(ctx->twA), ctx->mod);
     else
         hipExtLaunchKernelGGL((ntt_inv4<LOGD, FAST, NR, WAVES>), grid, block, 0, ctx->stream, e0, e1, 0, in, out, batch,
-                              (const double2 *)ctx->d_itw2, ctx->itwA, ctx->mod);
+                              (const double2 *)ctx->d_itw2, fz_tw4(ctx->itwA), ctx->mod);
 }
 
 template <int LOGD, bool FAST>
@@ -1443,8 +1446,15 @@ static void launch_jobs(fz_ctx *ctx, FzMultiJobs &J, hipEvent_t e0, hipEvent_t e
         J.end[j] = total;
     }
     for (int j = J.n; j < kFzMultiMax; ++j) J.end[j] = total;           // (the kernel's four-job fast path relies on it)
-    hipExtLaunchKernelGGL((ntt_jobs4<LOGD, FAST, NR, WAVES>), dim3(total), dim3(64 * WAVES), 0, ctx->stream, e0, e1, 0, J,
-                          (const double2 *)ctx->d_tw2, (const double2 *)ctx->d_itw2, ctx->twA, ctx->itwA, ctx->mod);
+    if (J.n <= 4) {
+        FzJobs4 S;
+        for (int j = 0; j < 4; ++j) { S.in[j] = J.in[j]; S.out[j] = J.out[j]; S.end[j] = J.end[j]; S.rows[j] = J.rows[j]; }
+        hipExtLaunchKernelGGL((ntt_jobs4<LOGD, FAST, NR, WAVES, FzJobs4>), dim3(total), dim3(64 * WAVES), 0, ctx->stream, e0, e1, 0, S,
+                              (const double2 *)ctx->d_tw2, (const double2 *)ctx->d_itw2, fz_tw4(ctx->twA), fz_tw4(ctx->itwA), ctx->mod);
+    } else {
+        hipExtLaunchKernelGGL((ntt_jobs4<LOGD, FAST, NR, WAVES, FzMultiJobs>), dim3(total), dim3(64 * WAVES), 0, ctx->stream, e0, e1, 0, J,
+                              (const double2 *)ctx->d_tw2, (const double2 *)ctx->d_itw2, fz_tw4(ctx->twA), fz_tw4(ctx->itwA), ctx->mod);
+    }
 }
 
 template <int LOGD, bool FAST>

@@ -451,11 +451,11 @@ int main(int argc, char **argv) {
         CHECK(hipMalloc((void **)&d_ref, rowbytes));
         std::vector<int32_t> ref(B * n), got(B * n);
         {   // reference: the library kernels as fz_ntt_forward launches them
-            hipLaunchKernelGGL((ntt_fwd4<8, true, 1, 8>), dim3((unsigned)((B + 7) / 8)), dim3(512), 0, st, (const int32_t *)pool_in, d_ref, B, (const double2 *)d_tw2, twA, mod);
+            hipLaunchKernelGGL((ntt_fwd4<8, true, 1, 8>), dim3((unsigned)((B + 7) / 8)), dim3(512), 0, st, (const int32_t *)pool_in, d_ref, B, (const double2 *)d_tw2, fz_tw4(twA), mod);
             CHECK(hipStreamSynchronize(st));
             CHECK(hipMemcpy(ref.data(), d_ref, rowbytes, hipMemcpyDeviceToHost));
             auto base = [&]() { const int32_t *i_ = in_ptr(); hipLaunchKernelGGL((ntt_fwd4<8, true, 1, 8>), dim3((unsigned)((B + 7) / 8)), dim3(512), 0, st, i_, out_ptr(), B,
-                                                   (const double2 *)d_tw2, twA, mod); };
+                                                   (const double2 *)d_tw2, fz_tw4(twA), mod); };
             const double us = time_us(base, reps, st, t);
             printf("%-44s grid %6zu x %4d  %8.3f us  %5.1f %% of 8 TB/s\n", "library ntt_fwd4<8, NR=1, WAVES=8>", (B + 7) / 8, 512, us,
                    bytes / (us * 1e-6) / 8e12 * 100);

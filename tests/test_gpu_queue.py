@@ -105,3 +105,13 @@ def test_queue_argument_errors_and_shutdown_with_results_outstanding():
     bq.close()                                                                      # finishes the call, frees its rows, joins
     bq.close()
     assert t == 1
+
+
+def test_c_caller_drives_the_queue(tmp_path):
+    """examples/queue_flow.c (strict C99, gcc, no HIP headers): 12 calls of 40 keys + signatures submitted from one thread,
+    batches of at most 256 rows on two workers; every call's verification keys (pinned host buffers) and signatures (read
+    back through the caller's own context) equal the direct entry points' rows for that call alone"""
+    import subprocess
+    from test_cabi_symbols import build_c_example
+    r = subprocess.run([build_c_example(tmp_path, "queue_flow")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "queue_flow OK" in r.stdout, r.stdout + r.stderr

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Soak of the asynchronous batch queue (fz_queue_*, fusion_hip.queue.BatchQueue): random call sizes, flags (kept / discarded /
+secret keys kept), worker counts and batch limits, results waited for and released in random order with up to 40 calls
+outstanding, a second submitting thread now and then -- every kept call's verification keys and signatures against
+BatchScheme.keygen_batch + sign_batch of that call alone (the reference's keygen / sign: fusion/fusion.py:338-373, :534-557).
+usage: queue_soak.py [seconds=60]"""
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fusion-cryptography_amd"))
+import numpy as np  # noqa: E402
+import fusion.fusion as F  # noqa: E402
+from fusion_hip.queue import BatchQueue  # noqa: E402
+from fusion_hip.scheme import BatchScheme  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(time.time()))
+t_end = time.time() + budget
+calls = rows = queues = 0
+while time.time() < t_end:
+    secpar = int(rng.choice([128, 256]))
+    params = F.fusion_setup(secpar, int(rng.integers(1, 1000)))
+    bs = BatchScheme(params, threads=2, private_context=True)
+    workers, max_rows = int(rng.integers(1, 5)), int(rng.choice([64, 300, 2048]))
+    queues += 1
+    with BatchQueue(params, workers=workers, max_rows=max_rows) as bq:
+        outstanding, lock, errors = [], threading.Lock(), []
+
+        def submit_some(count, tag):
+            try:
+                for _ in range(count):
+                    n = int(rng.integers(1, min(max_rows, 200) + 1))
+                    seeds = [int(x) for x in rng.integers(0, 2**63, size=n)]
+                    msgs = [f"{tag} {i} " + "y" * int(rng.integers(0, 64)) for i in range(n)]
+                    keep_sk, discard = bool(rng.integers(0, 2)), bool(rng.integers(0, 5) == 0)
+                    t = bq.submit_keygen_sign(seeds, msgs, keep_sk=keep_sk, discard=discard)
+                    with lock:
+                        outstanding.append((t, seeds, msgs, keep_sk, discard))
+            except Exception as e:      # noqa: BLE001
+                errors.append(repr(e))
+        inner_end = min(t_end, time.time() + 6.0)
+        while time.time() < inner_end:
+            th = threading.Thread(target=submit_some, args=(int(rng.integers(1, 12)), "side")) if rng.integers(0, 3) == 0 else None
+            if th:
+                th.start()
+            submit_some(int(rng.integers(1, 25)), "main")
+            if th:
+                th.join()
+            assert not errors, errors
+            while len(outstanding) > int(rng.integers(0, 40)):
+                with lock:
+                    t, seeds, msgs, keep_sk, discard = outstanding.pop(int(rng.integers(0, len(outstanding))))
+                r = bq.wait(t)
+                sk, vk = bs.keygen_batch(seeds)
+                assert np.array_equal(r.vk, vk), ("vk", secpar, len(seeds))
+                if discard:
+                    assert r.n == 0 and not r.sig_ptr
+                else:
+                    assert r.n == len(seeds)
+                    assert np.array_equal(r.signatures(), bs.sign_batch(sk, vk, msgs)), ("sig", secpar, len(seeds))
+                    if keep_sk:
+                        assert np.array_equal(r.secret_keys(), sk), ("sk", secpar, len(seeds))
+                    else:
+                        assert not r.sk_ptr
+                r.release()
+                calls += 1
+                rows += len(seeds)
+        # leave some calls outstanding on purpose: close() must finish and free them
+    bs.close()
+    print(f"[{time.strftime('%H:%M:%S')}] {queues} queues, {calls} calls, {rows} rows checked", flush=True)
+print("queue soak OK")

@@ -55,6 +55,7 @@ struct Done {
     std::string error;
     Batch *batch;
     size_t row0, n;
+    bool keep_sk;                      // this call asked for its secret keys (another call of the batch may have: the batch then holds them)
 };
 
 struct Worker {
@@ -233,6 +234,7 @@ void worker_main(fz_queue *Q, int index) {
             dn.batch = nullptr;
             dn.row0 = row0.size() > k ? row0[k] : 0;
             dn.n = jobs[k].n;
+            dn.keep_sk = (jobs[k].flags & FZ_QUEUE_KEEP_SK) != 0;
             Q->live.erase(jobs[k].ticket);
             if (jobs[k].flags & FZ_QUEUE_DISCARD) {                 // fire and forget: only a failure is remembered (for fz_queue_drain)
                 if (rc != FZ_OK && Q->first_error == FZ_OK) { Q->first_error = rc; Q->first_error_text = err; }
@@ -393,7 +395,7 @@ int fz_queue_wait(fz_queue *Q, uint64_t ticket, fz_queue_result *out) {
             const size_t d = (size_t)Q->degree, l = (size_t)Q->l;
             out->d_vk = dn.batch->d_vk + dn.row0 * 2 * d;
             out->d_sig = dn.batch->d_sig + dn.row0 * l * d;
-            out->d_sk_hat = dn.batch->d_sk ? dn.batch->d_sk + dn.row0 * 2 * l * d : nullptr;
+            out->d_sk_hat = (dn.keep_sk && dn.batch->d_sk) ? dn.batch->d_sk + dn.row0 * 2 * l * d : nullptr;
         }
     }
     if (dn.status != FZ_OK) return fz_set_error(dn.status, "queued batch failed: %s", dn.error.c_str());

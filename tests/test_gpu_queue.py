@@ -78,6 +78,8 @@ def test_many_calls_of_different_sizes_equal_batch_scheme():
                 assert np.array_equal(r.signatures(), bs.sign_batch(sk, vk, msgs)), k
                 if k % 4 == 0:
                     assert np.array_equal(r.secret_keys(), sk), k
+                else:
+                    assert not r.sk_ptr, k                     # even when another call of the same batch kept its secret keys
             r.release()
         done, batches, rows = bq.stats()
         assert done == len(calls) and rows == sum(sizes) and batches <= done

@@ -68,6 +68,16 @@ def test_fails_loudly_without_a_device(lib):
     assert lib.fz_ctx_create(0, 2147465729, 256, 5, 1, ctypes.byref(h)) == -1            # not a primitive root
     assert lib.fz_ctx_create(0, 2147465729, 512, 3337519, 1, ctypes.byref(h)) == -2      # degree > 256
     assert b"512" in lib.fz_last_error()
+    # the batch queue owns contexts: no device, no queue (and nothing left running)
+    import fusion.fusion as F
+    from fusion_hip.queue import BatchQueue, PackedMessages
+    with pytest.raises(fusion_hip.FusionHipError) as e:
+        BatchQueue(F.fusion_setup(128, 1), workers=2)
+    assert e.value.code == -4
+    pm = PackedMessages(["ab", "", "cde"])
+    assert pm.blob == b"abcde" and pm.off.tolist() == [0, 2, 2, 5] and pm.n == 3
+    q = ctypes.c_void_p()
+    assert lib.fz_queue_create(0, None, 83, 52, 256, None, 2, 1024, ctypes.byref(q)) == -1  # NULL arguments: before any device call
 
 
 def test_product_never_imports_the_oracle():

@@ -681,9 +681,9 @@ def main():
     else:
         cus = props.multi_processor_count                  # the launcher's rule (fz_launch_ntt_multi): row groups per wave by the launch's rows
         nr_ = 1 if 2 * B <= 24 * cus else (2 if 2 * B <= 48 * cus else 4)
-        kernel_name = f"ntt_jobs4<8, true, {nr_}, {(8 if 2 * B >= 8 * cus else 4 if 2 * B >= 4 * cus else 1) if nr_ == 1 else 2}>"
+        kernel_name = f"ntt_jobs4<8, true, {nr_}, {(8 if 2 * B >= 8 * cus else 4 if 2 * B >= 4 * cus else 1) if nr_ == 1 else 2}, FzJobs4>"
         launch_text = "software-pipelined: forward of batch i+1 + inverse of batch i in one fz_ntt_multi launch per step"
-    traffic, traffic_src = pmc_traffic(kernel_name)
+    traffic, traffic_src = pmc_traffic(kernel_name.rstrip(">").replace(", FzJobs4", ""))      # prefix: whatever follows the launch shape
 
     full = {
         "metric": METRIC, "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "repeats": launches * M,

@@ -48,6 +48,9 @@ cd /tmp && export TMPDIR=/tmp
 # per-kernel durations from the profiler: the bench's transform launches, the cold kernel table, the challenge pipeline
 step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --headline-only --full-out $OUT/prof_bench_full.json > $OUT/prof.log 2>&1
 cp $OUT/prof/*/*_kernel_stats.csv $OUT/${TAG}_bench_rocprofv3_kernel_stats.csv 2>/dev/null
+# the line bench.py printed IN THAT PROFILED RUN: its roofline.avg_launch_us and the kernel_stats average above are the same
+# launches measured two ways (they agree within ~1 %); the un-profiled line (${TAG}_bench_n1.json) is ~6 % faster
+grep -a '^{"metric"' $OUT/prof.log | tail -1 > $OUT/${TAG}_bench_under_rocprofv3_line.json
 step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profk -- python3 $R/tools/kernel_table.py > $OUT/profk.log 2>&1
 cp $OUT/profk/*/*_kernel_stats.csv $OUT/${TAG}_kernel_table_rocprofv3_kernel_stats.csv 2>/dev/null
 step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profc -- python3 $R/tools/challenge_bench.py > $OUT/profc.log 2>&1

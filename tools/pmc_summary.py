@@ -48,7 +48,7 @@ for sub, (label, rows) in GROUPS.items():
             # NR rows (degree 256) per wave, so rows = grid threads / 64 x NR -- the two-job launch of bench.py's pipelined step
             # (4096 forward + 4096 inverse rows) is ntt_jobs4<8, true, 2, 2> with 8192 rows; other kernels: the group's batch
             import re
-            m4 = re.search(r"ntt_(?:fwd4|inv4|jobs4)<(\d+), (?:true|false), (\d+), (\d+)>", k)
+            m4 = re.search(r"ntt_(?:fwd4|inv4|jobs4)<(\d+), (?:true|false), (\d+), (\d+)[,>]", k)
             rows_k = (grid.get(k, 0) // 64) * int(m4.group(2)) if m4 and grid.get(k) else rows
             e["rows_per_launch"] = rows_k
             e["algorithmic_bytes_per_launch"] = rows_k * 2048

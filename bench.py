@@ -60,6 +60,9 @@ def parse(argv=None):
     ap.add_argument("--full", action="store_true", help="also run the side legs of tools/bench_legs.py (full file only)")
     ap.add_argument("--headline-only", action="store_true",
                     help="timed region + per-dispatch roofline passes only (what tools/collect_profiles.sh runs under rocprofv3)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="HIP streams (a context each) that walk disjoint shares of the rotating batches side by side: launches of "
+                         "different streams overlap on the chip (1: one launch in flight at a time)")
     ap.add_argument("--two-launch", action="store_true",
                     help="headline step as two launches (fz_ntt_forward, fz_ntt_inverse) instead of the software-pipelined one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,10 +119,12 @@ def compact_line(full):
     out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                        "vs_baseline", "dtype", "data"))
     out["config"] = _pick(full.get("config") or {}, ("workload", "batch", "degree", "modulus", "batches_rotated", "launches_per_step",
-                                                     "step", "launch", "parallelism"))
+                                                     "streams", "step", "launch"))
     roof = full.get("roofline") or {}
     out["roofline"] = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch",
-                                   "units_per_launch", "avg_launch_us", "launches_timed", "operands", "timing"), 5)
+                                   "units_per_launch", "avg_launch_us", "in_flight", "operands", "timing"), 5)
+    if isinstance(roof.get("chip"), dict):
+        out["roofline"]["chip"] = _pick(roof["chip"], ("streams", "achieved", "frac", "unit", "launch_us_in_flight", "launches_timed"), 5)
     cb = full.get("cpu_baseline")
     out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample"), 5) if isinstance(cb, dict) else None
     if isinstance(cb, dict) and isinstance(cb.get("sample"), str):
@@ -127,8 +132,9 @@ def compact_line(full):
     for name, keys in (("sign_verify", ("value", "unit", "ms_per_step", "hbm_frac_per_gpu", "aggregates", "signers_per_aggregate",
                                         "collective", "cpu_value", "error")),
                        ("keygen_sign", ("value", "unit", "ms_per_step", "hbm_frac_per_gpu", "cpu_value", "error")),
+                       ("single_stream", ("value", "unit", "ms_per_step", "frac")),
+                       ("two_launch_step", ("value", "unit", "ms_per_step", "frac")),
                        ("warm_replay", ("value", "unit", "ms_per_step")),
-                       ("two_launch_step", ("value", "unit", "ms_per_step")),
                        ("end_to_end", ("keygen_per_s", "sign_per_s", "aggregate_per_s", "verify_per_s", "queue_pairs_per_s"))):
         src = full.get(name)
         if isinstance(src, dict):
@@ -147,7 +153,7 @@ def compact_line(full):
             out[k] = str(full[k])[:200]
     text = json.dumps(out, allow_nan=False, separators=(",", ":"))
     # the limit is a contract: shed the optional blocks (never the required keys) rather than print an unparsable line
-    for drop in ("end_to_end", "warm_replay", "two_launch_step", "ranks", "keygen_sign"):
+    for drop in ("end_to_end", "warm_replay", "two_launch_step", "single_stream", "ranks", "keygen_sign"):
         if len(text) < LINE_LIMIT:
             break
         out.pop(drop, None)
@@ -373,6 +379,10 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)                         # before anything in this process touches a GPU
 
+    # every stream of the timed region on a hardware queue of its own: the HIP runtime maps a process's streams onto 4 hardware
+    # queues by default (read when it starts: before the first HIP call), torch and the contexts' diagnostic streams take some,
+    # and two chains that share a queue run one after the other (measured at 4 streams: two chains 15 ms, two 23.5 ms)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 2 * args.streams)))
     # host threads on ONE NUMA node (the GPU's), before anything initialises the GPU (sysfs + sched_setaffinity only): a
     # launching thread the scheduler moves to the other socket launches at 5.1-7.5 us per dispatch instead of 4.4-4.8
     # (profiles/r02_numa_placement.txt)
@@ -493,49 +503,67 @@ def main():
     # the timed loop calls the C ABI directly with pre-built arguments: at ~4 us per kernel the Python wrapper layers
     # (attribute lookups, argument boxing) would otherwise be part of the measurement
     lib, h = ctx._lib, ctx._h
-    fz_fwd, fz_inv, nB = lib.fz_ntt_forward, lib.fz_ntt_inverse, ctypes.c_size_t(B)
+    nB = ctypes.c_size_t(B)
     rot_p = [tuple(ctypes.c_void_p(t[i].data_ptr()) for t in (xs, ys, zs)) for i in range(NBATCH)]
-    rot_i = [0]
-
-    def step2():
-        """un-pipelined: the next batch of the rotation, forward x_i -> y_i then inverse y_i -> z_i (two launches)"""
-        a_, b_, c_ = rot_p[rot_i[0] % NBATCH]
-        rot_i[0] += 1
-        return fz_fwd(h, a_, b_, nB) | fz_inv(h, b_, c_, nB)
-
-    def step_warm():
-        """the same two launches on ONE batch (cache-resident after the first step): the side number"""
-        a_, b_, c_ = rot_p[0]
-        return fz_fwd(h, a_, b_, nB) | fz_inv(h, b_, c_, nB)
-
-    # software-pipelined: launch i = {forward x_i -> y_i, inverse y_(i-1) -> z_(i-1)} in ONE dispatch (fz_ntt_multi).  The job
-    # tables are built once per rotation index; PRO / EPI are the one-job launches that open and close a run of steps.
-    NttJob, fz_multi = fusion_hip._lib.NttJob, lib.fz_ntt_multi
+    NttJob = fusion_hip._lib.NttJob
 
     def jobs(*items):
         return (NttJob * len(items))(*[NttJob(i_, o_, B, inv) for i_, o_, inv in items])
-    PAIR = [jobs((rot_p[i][0], rot_p[i][1], 0), (rot_p[i - 1][1], rot_p[i - 1][2], 1)) for i in range(NBATCH)]
-    PRO = [jobs((rot_p[i][0], rot_p[i][1], 0)) for i in range(NBATCH)]
-    EPI = [jobs((rot_p[i][1], rot_p[i][2], 1)) for i in range(NBATCH)]
-    pipe_open = [False]
 
-    def step():
-        """the next step of the pipelined run: batch i enters (forward), batch i - 1 leaves (inverse), one launch"""
-        i = rot_i[0] % NBATCH
-        rot_i[0] += 1
-        if not pipe_open[0]:
-            pipe_open[0] = True
-            return fz_multi(h, PRO[i], 1)
-        return fz_multi(h, PAIR[i], 2)
+    class Chain:
+        """One HIP stream's share of the work: a context + stream and the batches of the rotation it walks, one after the other.
+        pipelined: launch k = {forward x_k -> y_k, inverse y_(k-1) -> z_(k-1)} in ONE dispatch (fz_ntt_multi; the job tables are
+        built once per batch; PRO / EPI are the one-job launches that open and close a run of steps); two: fz_ntt_forward then
+        fz_ntt_inverse (two launches per step); warm: the same two launches on ONE batch."""
 
-    def flush():
-        """the inverse of the batch that entered last: closes a run of pipelined steps (its K-th inverse transform)"""
-        if not pipe_open[0]:
-            return 0
-        pipe_open[0] = False
-        return fz_multi(h, EPI[(rot_i[0] - 1) % NBATCH], 1)
-    if args.two_launch:
-        step, flush = step2, (lambda: 0)
+        def __init__(self, c, idx):
+            self.ctx, self.h, self.idx, self.k, self.open = c, c._h, list(idx), 0, False
+            rp = self.rp = [rot_p[i] for i in self.idx]
+            n = len(rp)
+            self.PAIR = [jobs((rp[k][0], rp[k][1], 0), (rp[k - 1][1], rp[k - 1][2], 1)) for k in range(n)]
+            self.PRO = [jobs((rp[k][0], rp[k][1], 0)) for k in range(n)]
+            self.EPI = [jobs((rp[k][1], rp[k][2], 1)) for k in range(n)]
+
+        def pipe(self):
+            k = self.k % len(self.rp)
+            self.k += 1
+            if not self.open:
+                self.open = True
+                return lib.fz_ntt_multi(self.h, self.PRO[k], 1)
+            return lib.fz_ntt_multi(self.h, self.PAIR[k], 2)
+
+        def pipe_end(self):
+            """the inverse of the batch that entered last: closes a run of pipelined steps (its last inverse transform)"""
+            if not self.open:
+                return 0
+            self.open = False
+            return lib.fz_ntt_multi(self.h, self.EPI[(self.k - 1) % len(self.rp)], 1)
+
+        def two(self):
+            a_, b_, c_ = self.rp[self.k % len(self.rp)]
+            self.k += 1
+            return lib.fz_ntt_forward(self.h, a_, b_, nB) | lib.fz_ntt_inverse(self.h, b_, c_, nB)
+
+        def warm(self):
+            a_, b_, c_ = self.rp[0]
+            return lib.fz_ntt_forward(self.h, a_, b_, nB) | lib.fz_ntt_inverse(self.h, b_, c_, nB)
+
+        def fns(self, mode):
+            return {"pipe": (self.pipe, self.pipe_end), "two": (self.two, lambda: 0), "warm": (self.warm, lambda: 0)}[mode]
+
+    # S chains: independent batches are in flight on S HIP streams at once (a context + stream each; chain 0 is the main
+    # context on torch's stream) -- launches of different streams overlap on the chip, which hides each launch's ramp and drain
+    S = max(1, min(args.streams, NBATCH // 2))
+    extra = []
+    for _ in range(S - 1):
+        c_ = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
+        c_.set_stream(c_.stream_create())
+        extra.append(c_)
+    bounds = [NBATCH * s_ // S for s_ in range(S + 1)]
+    chains = [Chain(([ctx] + extra)[s_], range(bounds[s_], bounds[s_ + 1])) for s_ in range(S)]
+    solo = Chain(ctx, range(NBATCH))                    # every batch on ONE stream: the single-stream legs and the isolated launches
+    mode = "two" if args.two_launch else "pipe"
+    per_step = 2 if args.two_launch else 1
 
     def prewarm(fn, ms, inner=50):
         """untimed: keep the device busy for `ms` so the timed region starts at steady clocks"""
@@ -544,6 +572,22 @@ def main():
             for _ in range(inner):
                 fn()
             torch.cuda.synchronize(dev)
+
+    def all_chains(cs, mode_):
+        fs = [c_.fns(mode_) for c_ in cs]
+
+        def step_all():
+            rc = 0
+            for st_, _ in fs:
+                rc |= st_()
+            return rc
+
+        def end_all():
+            rc = 0
+            for _, en_ in fs:
+                rc |= en_()
+            return rc
+        return step_all, end_all
 
     def timed_on_stream(fn, reps):
         """average milliseconds of fn() over reps back-to-back calls, HIP events on the kernels' own stream"""
@@ -555,46 +599,56 @@ def main():
         torch.cuda.synchronize(dev)
         return a.elapsed_time(b_) / reps
 
-    def region(step_fn, K, end_fn=lambda: 0):
-        """W warmup steps, then the K steps (M repetitions per recording for K < 1000) replayed for >= MIN_REGION_MS between
-        two barriers -> (elapsed seconds max over ranks, steps timed, events-on-stream microseconds per step, replays, M, clock)"""
-        rot_i[0] = 0
-        for _ in range(args.warmup):
-            step_fn()
-        end_fn()
+    def region(cs, mode_, K):
+        """W warmup steps, then the K steps -- dealt round-robin to the chains `cs`, every chain's share recorded into its own
+        hipGraph (M repetitions per recording for K < 1000) -- replayed for >= MIN_REGION_MS between two barriers.
+        -> dict(elapsed s (max over ranks), steps, per-chain event ms, per-chain steps, replays, M, shader clock)"""
+        n_c = len(cs)
+        fs = [c_.fns(mode_) for c_ in cs]
+        for c_ in cs:
+            c_.k = 0
+        for w_ in range(args.warmup):
+            fs[w_ % n_c][0]()
+        for _, en_ in fs:
+            en_()
         barrier()
         M = max(1, 1000 // K) if K < 1000 else 1
-        graphs = []
+        share = [(K // n_c + (1 if j < K % n_c else 0)) * M for j in range(n_c)]      # steps per chain and replay round
+        graphs = [[] for _ in cs]
         if not args.no_graph:
-            chunk = min(K, 1000)
-            sizes = [K * M] if K < 1000 else ([chunk] * (K // chunk)) + ([K % chunk] if K % chunk else [])
-            for n_steps in sizes:
-                if graphs and graphs[0][0] == n_steps:
-                    graphs.append(graphs[0])             # the same recording, launched again
-                    continue
-                rot_i[0] = 0
-                ctx.graph_begin()
-                rc = 0
-                for _ in range(n_steps):
-                    rc |= step_fn()
-                rc |= end_fn()                           # n_steps steps = n_steps + 1 launches when pipelined
-                g = ctx.graph_end()
-                assert rc == 0, f"capture failed: {lib.fz_last_error()}"
-                g.launch()                               # untimed first replay (upload)
-                graphs.append((n_steps, g))
+            for j, c_ in enumerate(cs):
+                sizes = ([1000] * (share[j] // 1000) + ([share[j] % 1000] if share[j] % 1000 else [])) if share[j] else []
+                made = {}
+                for n_steps in sizes:
+                    if n_steps in made:
+                        graphs[j].append(made[n_steps])      # the same recording, launched again
+                        continue
+                    c_.k = 0
+                    c_.ctx.graph_begin()
+                    rc = 0
+                    for _ in range(n_steps):
+                        rc |= fs[j][0]()
+                    rc |= fs[j][1]()                         # n_steps steps = n_steps + 1 launches when pipelined
+                    g = c_.ctx.graph_end()
+                    assert rc == 0, f"capture failed: {lib.fz_last_error()}"
+                    g.launch()                               # untimed first replay (upload)
+                    made[n_steps] = g
+                    graphs[j].append(g)
             barrier()
-        else:
-            M = 1
 
         def k_steps():
-            if graphs:
-                for _, g in graphs:
-                    g.launch()
+            if not args.no_graph:
+                for gl in graphs:                            # asynchronous: the chains' recordings run side by side
+                    for g in gl:
+                        g.launch()
             else:
                 rc = 0
-                for _ in range(K):
-                    rc |= step_fn()
-                rc |= end_fn()
+                for t_ in range(max(share)):
+                    for j in range(n_c):
+                        if t_ < share[j]:
+                            rc |= fs[j][0]()
+                for _, en_ in fs:
+                    rc |= en_()
                 assert rc == 0, f"launch failed: {lib.fz_last_error()}"
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -602,58 +656,83 @@ def main():
         torch.cuda.synchronize(dev)
         t_once = max(time.perf_counter() - t0, 1e-6)
         launches = int(max_over_ranks(max(1.0, -(-MIN_REGION_MS * 1e-3 // t_once))))     # the same count on every rank
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()
         t0 = time.perf_counter()
-        ev0.record(stream)
+        for c_ in cs:
+            c_.ctx.timer_start()                             # an event on every chain's own stream
         for _ in range(launches):
             k_steps()
-        ev1.record(stream)
+        ev_ms = [c_.ctx.timer_stop_ms() for c_ in cs]        # (records the closing event and waits for it)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
-        total = launches * M * K
-        ev_us = ev0.elapsed_time(ev1) * 1e3 / total          # microseconds per STEP
         shader = None
-        try:                                             # the shader clock the chip holds beside these launches (a diagnostic)
+        try:                                                 # the shader clock the chip holds beside these launches (a diagnostic)
             for _ in range(max(1, launches // 4)):
                 k_steps()
             shader = round(ctx.diag_shader_clock(500))
         except Exception as e:
             shader = f"failed: {type(e).__name__}: {e}"
         torch.cuda.synchronize(dev)
-        for g in {id(g): g for _, g in graphs}.values():
-            g.destroy()
-        return elapsed, total, ev_us, launches, M, shader
+        for gl in graphs:
+            for g in {id(g): g for g in gl}.values():
+                g.destroy()
+        return {"elapsed": elapsed, "steps": launches * M * K, "ev_ms": ev_ms, "chain_steps": [launches * sh for sh in share],
+                "replays": launches, "M": M, "shader_mhz": shader}
 
+    def summary(r_, mode_):
+        """value and the chip-level / per-launch figures of one region() result"""
+        ps_ = 2 if mode_ in ("two", "warm") else 1
+        byt = 8 * d * B * (2 // ps_)                           # algorithmic bytes per launch
+        n_launch = r_["steps"] * ps_
+        interval = max(r_["ev_ms"]) * 1e3 / n_launch           # us between launches, all chains together
+        per = [m_ * 1e3 / (st_ * ps_) for m_, st_ in zip(r_["ev_ms"], r_["chain_steps"]) if st_]
+        lat = sum(per) / len(per)                              # us per launch on its own stream
+        return {"value": 2.0 * B * r_["steps"] * world / r_["elapsed"], "unit": "NTT/s", "ms_per_step": r_["elapsed"] / r_["steps"] * 1e3,
+                "frac": byt / (interval * 1e-6) / 1e9 / HBM_PEAK_GBS, "launch_interval_us": interval, "launch_us": lat,
+                "frac_per_launch": byt / (lat * 1e-6) / 1e9 / HBM_PEAK_GBS, "streams": len(r_["ev_ms"]), "shader_mhz": r_["shader_mhz"]}
+
+    st0, en0 = solo.fns(mode)
     for _ in range(NBATCH):                              # every batch once: z_i defined whatever the flags below skip
-        step()
-    flush()
+        st0()
+    en0()
     barrier()
     assert torch.equal(zs, xs), "INTT(NTT(x)) != x"
     zs.zero_()
-    prewarm(step, args.prewarm_ms)
-    flush()
-    elapsed, total_steps, region_step_us, launches, M, shader_mhz = region(step, args.steps, flush)
+    step_all, end_all = all_chains(chains, mode)
+    prewarm(step_all, args.prewarm_ms)
+    end_all()
+    R = region(chains, mode, args.steps)
     torch.cuda.synchronize(dev)
     assert torch.equal(zs, xs), "INTT(NTT(x)) != x after the timed region"
-    value = 2.0 * B * total_steps * world / elapsed
+    elapsed, total_steps, launches, M, shader_mhz = R["elapsed"], R["steps"], R["replays"], R["M"], R["shader_mhz"]
+    head = summary(R, mode)
+    value = head["value"]
+    # the same steps with ONE launch in flight at a time (one stream, all 64 batches): what a single launch of the dominant kernel
+    # takes in a dense stream -- the figure a profiler can reproduce (rocprofv3 --kernel-trace serialises the dispatches of all
+    # streams: in its trace of this script no two launches overlap)
+    if S > 1:
+        st0_, en0_ = solo.fns(mode)
+        prewarm(st0_, 20.0)
+        en0_()
+        one = summary(region([solo], mode, args.steps), mode)
+    else:
+        one = head
 
-    # ---- context for the roofline fraction (which comes from the timed region itself, below): begin/end events bound to EVERY
-    # dispatch (hipExtLaunchKernelGGL) of instrumented passes over the same rotating batches, launched one by one right after
+    # ---- context for the roofline figures (which come from the timed region itself, below): begin/end events bound to EVERY
+    # dispatch (hipExtLaunchKernelGGL) of instrumented passes on ONE stream over all 64 batches, launched one by one right after
     # the timed region (a hipGraph cannot carry the events) -- the duration of a launch that starts on an idle memory system.
     n_inst, n_pass = 400, 3
     dom_kind = 0 if args.two_launch else 2              # the dominant launch: the forward kernel, or the two-job launch
-    per_step = 2 if args.two_launch else 1
     dom_all, inv_all, passes = [], [], []
     for _ in range(n_pass):
-        prewarm(step, 20.0)                              # dense launches first: a one-by-one pass leaves the device half idle
+        prewarm(st0, 20.0)                               # dense launches first: a one-by-one pass leaves the device half idle
         ctx.profile_begin(per_step * n_inst + 2, args.sample_every)
         rc = 0
         for _ in range(n_inst):
-            rc |= step()
+            rc |= st0()
         assert rc == 0, f"launch failed: {lib.fz_last_error()}"
         us, kind = ctx.profile_end_samples(per_step * n_inst + 2)
-        rc = flush()                                     # (outside the instrumented launches: a one-job launch)
+        rc = en0()                                       # (outside the instrumented launches: a one-job launch)
         assert rc == 0, f"launch failed: {lib.fz_last_error()}"
         f_, i_ = us[kind == dom_kind], us[kind == 1]
         assert len(f_) >= n_inst // args.sample_every - 1, (len(f_), len(us))
@@ -669,12 +748,12 @@ def main():
     # 8*d algorithmic bytes per transform; one dominant launch = 4096 forward (+ 4096 inverse when pipelined) transforms
     units_per_launch = B if args.two_launch else 2 * B
     dom_bytes = 8 * d * units_per_launch
-    # THE fraction: HIP events around the timed region on the kernels' stream / the launches inside it -- the dense graph replay
-    # itself, what `value` is made of (a step is `per_step` launches; the half-size launches that open and close a recording
-    # of pipelined steps add up to one full launch).  rocprofv3 --kernel-trace --stats over `bench.py --headline-only` sees
-    # the same dense dispatches: its average for this kernel and this figure agree within 5 % (profiles/).
-    dom_us = region_step_us / per_step
-    ach = dom_bytes / (dom_us * 1e-6) / 1e9
+    # THE per-launch fraction (`roofline.frac`): algorithmic bytes per launch / the launch's average duration with ONE launch in
+    # flight -- HIP events on the kernel's stream around a dense single-stream region of the same steps / its launches.  This is
+    # the figure rocprofv3 --kernel-trace --stats reproduces (it serialises dispatches), profiles/ + DESIGN.md section 6.
+    # `roofline.chip`: the headline's timed region itself -- `streams` launches in flight on as many HIP streams; algorithmic bytes
+    # moved / the region's duration by HIP events on every stream = `value` x 2048 B: what the chip achieves on batches of 4096.
+    ach = one["frac"] * HBM_PEAK_GBS
     if args.two_launch:
         kernel_name = "ntt_fwd4<8, true, 1, 8>"
         launch_text = "fz_ntt_forward + fz_ntt_inverse: two launches per step"
@@ -690,28 +769,33 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "timed_region_ms": elapsed * 1e3,
         "config": {"workload": f"configs[1]: secpar={SECPAR}, {B} degree-{d} forward+inverse NTTs per step per GPU",
-                   "batch": B, "degree": d, "modulus": q, "batches_rotated": NBATCH, "launches_per_step": per_step,
+                   "batch": B, "degree": d, "modulus": q, "batches_rotated": NBATCH, "launches_per_step": per_step, "streams": S,
                    "step": launch_text,
-                   "parallelism": f"{world} independent rank(s), one batch rotation each",
+                   "parallelism": f"{world} independent rank(s); per rank {S} HIP stream(s), each walking its own {NBATCH // S} of the {NBATCH} batches",
                    "arithmetic": "exact integers carried in fp64 lanes (bit-identical to the reference's int arithmetic); int32 in and out",
-                   "launch": "one by one" if args.no_graph else f"hipGraph of {M}x{args.steps} steps, {launches} replays",
+                   "launch": "one by one" if args.no_graph else f"{S} hipGraph(s) of {M}x{args.steps} steps together, {launches} replays",
                    "prewarm_ms": args.prewarm_ms,
                    "host_threads_on": placement or "all allowed CPUs (no GPU-local NUMA node found, or FZ_NO_PIN=1)"},
         "ranks": ranks,
         "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "bytes_per_launch": dom_bytes, "units_per_launch": units_per_launch, "avg_launch_us": dom_us,
-                     "launches_timed": int(total_steps * per_step),
+                     "frac": one["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                     "bytes_per_launch": dom_bytes, "units_per_launch": units_per_launch,
+                     "avg_launch_us": one["launch_us"], "in_flight": 1,
                      "operands": f"cold: rotation of {NBATCH} batches",
-                     "timing": "HIP events on the kernels' stream around the timed region (dense graph replays) / launches in it",
+                     "timing": "HIP events around a dense one-stream region of the same steps / launches (one launch in flight)",
+                     "one_stream": one,
+                     "chip": {"streams": S, "achieved": head["frac"] * HBM_PEAK_GBS, "frac": head["frac"], "unit": "GB/s",
+                              "launch_us_in_flight": head["launch_us"], "launch_interval_us": head["launch_interval_us"],
+                              "launches_timed": int(total_steps * per_step),
+                              "per_chain_event_ms": R["ev_ms"], "per_chain_steps": R["chain_steps"],
+                              "what": "the timed region of `value`: `streams` launches in flight, one per HIP stream; algorithmic bytes of "
+                                      "all launches / the region's duration by HIP events on every stream (the slowest chain's)"},
                      "isolated": {"avg_launch_us": iso_us, "median_launch_us": float(np.median(dom_all)),
                                   "frac": dom_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "launches": int(len(dom_all)),
                                   "inverse_avg_launch_us": float(inv_all.mean()) if len(inv_all) else None, "passes": passes,
                                   "what": f"begin/end events bound to EVERY dispatch (hipExtLaunchKernelGGL) of {n_pass} passes of {n_inst} "
-                                          "steps launched one by one from Python after the timed region: the host paces them (~10 us apart), "
-                                          "so every launch starts on an idle memory system -- under rocprofv3 the same one-by-one launches "
-                                          "read 5.9 us where the dense graph replays read 6.8-7.0 us (the by-grid table of the bench under profiles/); "
-                                          "context, not the fraction"},
+                                          "steps launched one by one from Python on ONE stream after the timed region: the host paces them "
+                                          "(~10 us apart), so every launch has the chip and an idle memory system to itself; context, not the fraction"},
                      "shader_mhz": shader_mhz, "butterflies_per_s": value * (d // 2) * 8},
     }
 
@@ -769,23 +853,21 @@ def main():
         allreduce_sum_i64=allreduce_sum_i64, HBM_PEAK_GBS=HBM_PEAK_GBS, MIN_REGION_MS=MIN_REGION_MS, SECPAR=SECPAR)
 
     if not args.headline_only:
-        # the same step on ONE batch: after the first step it lives in the L2s / the Infinity Cache (round 3's `value`)
-        def warm_leg():
-            prewarm(step_warm, 20.0)
-            el, tot, ev_us, _, _, clk = region(step_warm, args.steps)
-            return {"value": 2.0 * B * tot * world / el, "unit": "NTT/s", "ms_per_step": el / tot * 1e3,
-                    "region_step_us": ev_us, "shader_mhz": clk,
-                    "what": "two launches per step on ONE batch re-read every step (cache-resident; round 3's `value`): a side number"}
-        full["warm_replay"] = leg("warm_replay", warm_leg)
-
-        # the un-pipelined step on the rotating batches (round 4's first form of the headline): fz_ntt_forward, fz_ntt_inverse
-        def two_launch_leg():
-            prewarm(step2, 20.0)
-            el, tot, ev_us, _, _, clk = region(step2, args.steps)
-            return {"value": 2.0 * B * tot * world / el, "unit": "NTT/s", "ms_per_step": el / tot * 1e3, "region_step_us": ev_us,
-                    "shader_mhz": clk, "what": "the same steps as two launches each (forward, then inverse) over the rotating batches"}
+        # the single-stream forms over the same batches: one launch in flight at a time
+        def solo_leg(mode_, what):
+            st_, en_ = solo.fns(mode_)
+            prewarm(st_, 20.0)
+            en_()
+            out_ = summary(region([solo], mode_, args.steps), mode_)
+            out_["what"] = what
+            return out_
+        if S > 1:
+            full["single_stream"] = dict(one, what="the headline's steps on ONE stream (one launch in flight at a time) over the rotating batches")
         if not args.two_launch:
-            full["two_launch_step"] = leg("two_launch_step", two_launch_leg)
+            full["two_launch_step"] = leg("two_launch_step", lambda: solo_leg(
+                "two", "ONE stream, two launches per step (fz_ntt_forward, then fz_ntt_inverse) over the rotating batches"))
+        full["warm_replay"] = leg("warm_replay", lambda: solo_leg(
+            "warm", "ONE stream, two launches per step on ONE batch re-read every step (cache-resident; round 3's `value`)"))
         from tools import bench_legs as L
         if not args.no_sign_verify:
             sv = leg("sign_verify", lambda: L.sign_verify(env))

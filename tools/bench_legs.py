@@ -8,7 +8,7 @@ import ctypes
 import sys
 import time
 
-FULL_LEGS = ["copy_floor", "multi_job", "two_stream", "pcie_inclusive", "sweep", "kernels", "end_to_end", "end_to_end_sharded"]
+FULL_LEGS = ["copy_floor", "multi_job", "pcie_inclusive", "sweep", "kernels", "end_to_end", "end_to_end_sharded"]
 
 
 # ---- sign + aggregate + verify (algebra cores; synthetic keys/messages) -- every rank ----------------------------------
@@ -229,57 +229,6 @@ def multi_job(e):
                      "kernel arguments); back-to-back launches, HIP events on the stream, inputs rotate through the headline's "
                      "64 batches (cold)")
     return multi
-
-
-# ---- the same steps as two independent pipelines (two HIP streams / two branches of one graph) -- rank 0 ---------------
-def two_stream(e):
-    if e.rank != 0:
-        return None
-    torch, ctx, fusion_hip, B = e.torch, e.ctx, e.fusion_hip, e.B
-    side = torch.cuda.Stream(e.dev)
-    cs = fusion_hip.Context(e.q, e.d, e.P["root"], e.P["inv_root"], device=e.dev_index)
-    cs.set_stream(side.cuda_stream)
-    fz_fwd, fz_inv, nB, h, hs = e.lib.fz_ntt_forward, e.lib.fz_ntt_inverse, ctypes.c_size_t(B), e.h, cs._h
-    k2 = min(e.args.steps, 1000) & ~1                    # steps per replay, half on each branch
-    nb = len(e.rot_p)
-    torch.cuda.synchronize(e.dev)
-
-    def run2(k):
-        for i in range(k // 2):                          # the two branches walk disjoint halves of the rotation
-            a_, b_, c_ = e.rot_p[(2 * i) % nb]
-            fz_fwd(h, a_, b_, nB)
-            fz_inv(h, b_, c_, nB)
-            a_, b_, c_ = e.rot_p[(2 * i + 1) % nb]
-            fz_fwd(hs, a_, b_, nB)
-            fz_inv(hs, b_, c_, nB)
-    g2 = None
-    if not e.args.no_graph and k2 >= 2:
-        g2 = torch.cuda.CUDAGraph()                      # fork/join across streams: torch's capture does the plumbing
-        with torch.cuda.graph(g2, stream=e.stream):
-            side.wait_stream(e.stream)
-            run2(k2)
-            e.stream.wait_stream(side)
-        replay = g2.replay
-    else:
-        k2 = 50
-
-        def replay():
-            run2(k2)
-    reps2 = max(10, int(e.MIN_REGION_MS / (k2 * 0.008)) + 1)      # a single replay would mostly measure its own start-up
-    e.prewarm(replay, e.args.prewarm_ms / 3, inner=1 if g2 is not None else 50)
-    torch.cuda.synchronize(e.dev)
-    t0 = time.perf_counter()
-    for _ in range(reps2):
-        replay()
-    torch.cuda.synchronize(e.dev)
-    dt = time.perf_counter() - t0
-    assert torch.equal(e.zs, e.xs)
-    out = {"value": 2.0 * B * reps2 * k2 / dt, "unit": "NTT/s", "ms_per_step": dt / (reps2 * k2) * 1e3, "steps": reps2 * k2,
-           "what": "the headline's steps issued alternately on two HIP streams over the rotating batches"
-                   + (" (two branches of one hipGraph)" if g2 is not None else "")}
-    del g2
-    cs.close()
-    return out
 
 
 # ---- host-pointer path (PCIe-inclusive; never `value`) -- rank 0 -------------------------------------------------------

@@ -2,9 +2,10 @@
 # Regenerates every measurement committed under profiles/ in ONE gpurun call (one box: numbers from different
 # boxes differ by several percent).  usage (from the repo root):
 #   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r04'      then copy gpurun_out/<tag>/<tag>_* to profiles/
-# The rocprofv3 pass over bench.py runs `--headline-only`: the timed region (graph replays over the rotating batches) and the
-# per-dispatch passes, nothing else -- its kernel_stats average for the forward kernel is the figure bench.py's roofline.frac
-# must agree with (8 388 608 B / AverageNs).
+# The rocprofv3 pass over bench.py runs `--headline-only`: the timed regions (graph replays over the rotating batches, on 4 streams
+# and on one) and the per-dispatch passes, nothing else -- its kernel_stats average for ntt_jobs4 is the figure bench.py's
+# roofline.avg_launch_us / roofline.frac must agree with (16 777 216 B / AverageNs); the profiler runs the dispatches of all
+# streams one at a time (by_grid's in_flight column), so roofline.chip has no counterpart in a trace.
 # Stops at the first step that fails or times out: no further GPU work is started after a failed one.
 set -u
 TAG=${1:-rXX}
@@ -43,6 +44,7 @@ step timeout -k 10 300 python tools/queue_probe.py > $OUT/${TAG}_queue_probe.txt
 step timeout -k 10 300 python tools/sharded_modes.py > $OUT/${TAG}_sharded_alpha_modes_raw.txt 2>&1
 step timeout -k 10 300 python tools/benchmarks.py 256 128 > $OUT/${TAG}_api_benchmarks.json 2> $OUT/api_benchmarks.err
 step timeout -k 10 200 python tools/object_api_profile.py 256 16 > $OUT/${TAG}_object_api_profile.txt 2>&1
+step timeout -k 10 300 python tools/stream_sweep.py > $OUT/${TAG}_multi_stream_sweep.txt 2>&1
 step timeout -k 10 600 python bench.py --full --full-out $OUT/${TAG}_bench_full.json > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations from the profiler: the bench's transform launches, the cold kernel table, the challenge pipeline

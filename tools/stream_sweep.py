@@ -25,3 +25,4 @@ for s, q in ((1, None), (2, None), (3, None), (4, None), (4, "4"), (4, "16"), (6
     ch = ro.get("chip", {})
     print(f"{s:7d}  {q or DEFAULT:>17s}  {d['value'] / 1e9:8.3f}  {d['ms_per_step'] * 1e3:8.3f}   "
           f"{ch.get('frac', ro['frac']):9.3f}   {ch.get('launch_us_in_flight', ro['avg_launch_us']):23.2f}   {ro['frac']:15.3f}", flush=True)
+print("\n(default = bench.py's own setting of GPU_MAX_HW_QUEUES, max(8, 2 x streams), when the caller has none; 4 = the HIP runtime's default)")

@@ -567,7 +567,7 @@ int fz_malloc(fz_ctx *ctx, size_t bytes, void **d_out) {
     if (bytes == 0) bytes = 1;
     void *p = nullptr;
     hipEvent_t ev = nullptr;
-    if (bytes >= kPoolMin) {
+    if (bytes >= kPoolMin && !ctx->capturing) {       // (a pooled block's event was recorded outside the capture: not waitable inside one)
         std::lock_guard<std::mutex> g(ctx->pool_mu);
         int best = -1;
         for (int i = 0; i < ctx->n_pool; ++i) {

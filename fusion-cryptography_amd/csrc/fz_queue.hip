@@ -26,6 +26,7 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -197,6 +198,7 @@ int run_batch(fz_queue *Q, Worker &w, std::vector<Job> &jobs, Batch **out_batch,
 
 void worker_main(fz_queue *Q, int index) {
     Worker &w = Q->workers[index];
+    (void)hipSetDevice(Q->device);                  // a new thread starts on device 0; every fz_* call below selects the context's device again
     std::unique_lock<std::mutex> lk(Q->mu);
     for (;;) {
         Q->cv_work.wait(lk, [&] { return Q->stopping || !Q->pending.empty() || !w.garbage.empty(); });
@@ -223,7 +225,14 @@ void worker_main(fz_queue *Q, int index) {
         lk.unlock();
         Batch *b = nullptr;
         std::vector<size_t> row0;
-        const int rc = run_batch(Q, w, jobs, &b, row0);
+        int rc;
+        try {
+            rc = run_batch(Q, w, jobs, &b, row0);
+        } catch (const std::bad_alloc &) {          // the coalesced host copies: an error of these calls, not std::terminate
+            (void)fz_ctx_synchronize(w.ctx);
+            b = nullptr;
+            rc = fz_set_error(FZ_E_HIP, "queue worker: out of host memory while coalescing %zu calls", jobs.size());
+        }
         const std::string err = rc == FZ_OK ? std::string() : std::string(last_error());
         lk.lock();
         int kept = 0;
@@ -356,21 +365,25 @@ int fz_queue_submit_keygen_sign(fz_queue *Q, const uint64_t *h_seeds, size_t n, 
         if (h_seeds[i] == ~0ull) return fz_set_error(FZ_E_UNSUPPORTED, "seed 2^64 - 1: seed + 1 wraps (use the Python sampler)");
     }
     if (h_msg_off[n] && !h_msgs) return fz_set_error(FZ_E_BADARG, "h_msgs is NULL");
-    Job j;
-    j.n = n;
-    j.flags = flags;
-    j.seeds.assign(h_seeds, h_seeds + n);
-    j.msgs.assign(h_msgs ? h_msgs : "", h_msg_off[n]);
-    j.off.assign(h_msg_off, h_msg_off + n + 1);
-    j.h_vk_out = h_vk_out;
-    {
+    try {                                           // no C++ exception crosses the C ABI
+        Job j;
+        j.n = n;
+        j.flags = flags;
+        j.seeds.assign(h_seeds, h_seeds + n);
+        j.msgs.assign(h_msgs ? h_msgs : "", h_msg_off[n]);
+        j.off.assign(h_msg_off, h_msg_off + n + 1);
+        j.h_vk_out = h_vk_out;
         std::lock_guard<std::mutex> lk(Q->mu);
         if (Q->stopping) return fz_set_error(FZ_E_BADARG, "the queue is shutting down");
-        j.ticket = Q->next_ticket++;
-        *out_ticket = j.ticket;
-        Q->live.insert(j.ticket);
+        Q->live.reserve(Q->live.size() + 1);        // whatever can throw, before the queue's state changes
         Q->pending.push_back(std::move(j));
+        Job &q = Q->pending.back();
+        q.ticket = Q->next_ticket++;
+        *out_ticket = q.ticket;
+        Q->live.insert(q.ticket);
         Q->inflight += 1;
+    } catch (const std::bad_alloc &) {
+        return fz_set_error(FZ_E_HIP, "out of host memory while copying the call's inputs");
     }
     Q->cv_work.notify_one();
     return FZ_OK;

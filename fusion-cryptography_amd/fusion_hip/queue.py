@@ -177,12 +177,13 @@ class BatchQueue:
             buf = self._vk_out.pop(ticket, None)
             if buf is not None:
                 self._recycle(buf)
+            self._lib.fz_queue_release(self._h, ticket)        # a failed call keeps nothing: forget its record
             raise
         return QueueCallResult(self, ticket, raw, self._vk_out.pop(ticket, None))
 
     def drain(self):
-        """block until everything submitted has finished; raises if a discarded call failed.  Verification-key buffers of
-        calls nobody waited for go back to the free list."""
+        """block until everything submitted has finished; raises if a discarded call failed (collect_discarded() then hands
+        the verification-key buffers of calls nobody waited for back to the free list)"""
         check(self._lib, self._lib.fz_queue_drain(self._h))
 
     def collect_discarded(self):

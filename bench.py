@@ -58,6 +58,10 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--full", action="store_true", help="also run the side legs of tools/bench_legs.py (full file only)")
+    ap.add_argument("--single-rank-comm", action="store_true",
+                    help="N = 1 only: create a one-rank RCCL communicator so that sign_verify runs its exchange-step code path")
+    ap.add_argument("--no-exchange-overlap", action="store_true",
+                    help="sign_verify: the all-reduce on the compute stream (round 3's form) instead of a second stream")
     ap.add_argument("--headline-only", action="store_true",
                     help="timed region + per-dispatch roofline passes only (what tools/collect_profiles.sh runs under rocprofv3)")
     ap.add_argument("--streams", type=int, default=4,
@@ -412,22 +416,50 @@ def main():
     dev_index = local_rank % ndev                 # one rank per GPU; the modulo only matters for the gloo rehearsal
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    ps = F.PREFIX_PARAMETERS[SECPAR]
+    P = {"q": ps["modulus"], "d": ps["degree"], "root": ps["root"], "inv_root": ps["inv_root"], "rank": ps["num_rows_sk"],
+         "omega_ch": ps["omega_ch"], "omega_ag": ps["omega_ag"], "capacity": ps["capacity"], "beta_vf": ps["beta_vf"]}
+    q, d, l = P["q"], P["d"], P["rank"]
+    # The headline's chains FIRST: a context + HIP stream each, and one empty kernel on each, BEFORE anything else in the
+    # process creates streams.  The HIP runtime hands hardware queues to streams in the order they first need one; RCCL (a
+    # torch.distributed "nccl" group, or fz_comm_create) takes several for its own streams, and chains created after it end up
+    # sharing queues with them or with each other -- measured with a communicator of ONE rank: 0.84-1.75 G NTT/s instead of
+    # 2.2 G (profiles/r04_hw_queue_oversubscription.txt; tools/hw_queue_probe.py).
+    S = max(1, min(args.streams, NBATCH // 2))
+    chain_ctx = []
+    for _ in range(S):
+        c_ = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
+        c_.set_stream(c_.stream_create())
+        c_.diag_empty_launch()
+        c_.synchronize()
+        chain_ctx.append(c_)
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
+    # the main context: a non-default stream, made torch's current one (graph capture needs it, and torch ops order on it too)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.diag_empty_launch()
+    # the exchange step's context (sign_verify: fz_allreduce_i64 on a stream of its own, beside the next step's kernels)
+    exchange_ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
+    exchange_ctx.set_stream(exchange_ctx.stream_create())
+    exchange_ctx.diag_empty_launch()
+    for c_ in (ctx, exchange_ctx):
+        c_.synchronize()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
-    ps = F.PREFIX_PARAMETERS[SECPAR]
-    P = {"q": ps["modulus"], "d": ps["degree"], "root": ps["root"], "inv_root": ps["inv_root"], "rank": ps["num_rows_sk"],
-         "omega_ch": ps["omega_ch"], "omega_ag": ps["omega_ag"], "capacity": ps["capacity"], "beta_vf": ps["beta_vf"]}
-    q, d, l = P["q"], P["d"], P["rank"]
-    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
-    # a non-default stream, made torch's current one: graph capture needs it, and torch ops / RCCL order on it too
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
+    elif args.single_rank_comm:
+        # rehearsal on ONE GPU of what an N > 1 run has in its process: a torch.distributed RCCL group that has run collectives
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        t_ = torch.ones(4, device=dev)
+        dist.all_reduce(t_)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -473,8 +505,14 @@ def main():
             collective = f"torch.distributed all_reduce ({backend}); fz_comm_* not usable in this run"
         else:
             collective = f"fz_allreduce_i64 (ncclAllReduce int64 sum, C ABI), RCCL counts {rccl_nranks} ranks"
+    if world == 1 and args.single_rank_comm:
+        # rehearsal of the exchange step's code path on ONE GPU: a communicator of one rank (RCCL still launches through the same
+        # call, on the exchange context's stream, inside the same capture); never the default
+        comm = fusion_hip.Comm(ctx, 1, 0, fusion_hip.comm_unique_id())
+        rccl_nranks = comm.info()[0]
+        collective = f"fz_allreduce_i64 (ncclAllReduce int64 sum, C ABI), RCCL counts {rccl_nranks} rank (rehearsal)"
     try:
-        rccl_version = fusion_hip.rccl_version() if world > 1 else None
+        rccl_version = fusion_hip.rccl_version() if (world > 1 or comm is not None) else None
     except Exception:
         rccl_version = None
 
@@ -551,16 +589,10 @@ def main():
         def fns(self, mode):
             return {"pipe": (self.pipe, self.pipe_end), "two": (self.two, lambda: 0), "warm": (self.warm, lambda: 0)}[mode]
 
-    # S chains: independent batches are in flight on S HIP streams at once (a context + stream each; chain 0 is the main
-    # context on torch's stream) -- launches of different streams overlap on the chip, which hides each launch's ramp and drain
-    S = max(1, min(args.streams, NBATCH // 2))
-    extra = []
-    for _ in range(S - 1):
-        c_ = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
-        c_.set_stream(c_.stream_create())
-        extra.append(c_)
+    # S chains: independent batches are in flight on S HIP streams at once (the contexts + streams created first thing above)
+    # -- launches of different streams overlap on the chip, which hides each launch's ramp and drain
     bounds = [NBATCH * s_ // S for s_ in range(S + 1)]
-    chains = [Chain(([ctx] + extra)[s_], range(bounds[s_], bounds[s_ + 1])) for s_ in range(S)]
+    chains = [Chain(chain_ctx[s_], range(bounds[s_], bounds[s_ + 1])) for s_ in range(S)]
     solo = Chain(ctx, range(NBATCH))                    # every batch on ONE stream: the single-stream legs and the isolated launches
     mode = "two" if args.two_launch else "pipe"
     per_step = 2 if args.two_launch else 1
@@ -849,7 +881,7 @@ def main():
         args=args, ctx=ctx, torch=torch, np=np, dist=dist, dev=dev, dev_index=dev_index, stream=stream, lib=lib, h=h,
         xs=xs, ys=ys, zs=zs, x=x, y=y, z=z, rot_p=rot_p, B=B, d=d, q=q, l=l, P=P, F=F, fusion_hip=fusion_hip, rank=rank, world=world,
         barrier=barrier, max_over_ranks=max_over_ranks, min_over_ranks=min_over_ranks, prewarm=prewarm,
-        timed_on_stream=timed_on_stream, comm=comm, collective=collective, backend=backend, shard_range=shard_range,
+        timed_on_stream=timed_on_stream, exchange_ctx=exchange_ctx, comm=comm, collective=collective, backend=backend, shard_range=shard_range,
         allreduce_sum_i64=allreduce_sum_i64, HBM_PEAK_GBS=HBM_PEAK_GBS, MIN_REGION_MS=MIN_REGION_MS, SECPAR=SECPAR)
 
     if not args.headline_only:
@@ -897,6 +929,10 @@ def main():
             if isinstance(full.get("keygen_sign"), dict) and "keygen_plus_sign_per_s" in sch:
                 full["keygen_sign"]["cpu_value"] = sch["keygen_plus_sign_per_s"]
         emit()
+    if world == 1 and args.single_rank_comm:            # same teardown hazard as below (RCCL was loaded through the C ABI beside torch's)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if world > 1:
         barrier()                                       # rank 0's single-rank legs are done: leave together
         dist.destroy_process_group()

@@ -42,6 +42,17 @@ int fz_check_hip(hipError_t e, const char *what) {
 // allocations and events must land on ctx->device whatever stream the caller attached.
 #define FZ_DEV(ctx) FZ_HIP(hipSetDevice((ctx)->device), "hipSetDevice")
 
+// Is work on this context being recorded rather than executed?  Either the context opened a capture itself (fz_graph_begin) or
+// its stream was drawn into another context's capture by fz_event_wait on an event recorded there (the fork / join of a
+// two-stream capture): the runtime knows, so ask it -- nothing may allocate, copy to the host or synchronise in either case.
+static bool fz_capturing(fz_ctx *ctx) {
+    if (ctx->capturing) return true;
+    if (!ctx->stream) return false;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st == hipStreamCaptureStatusActive;
+}
+
 static uint64_t powmod_u64(uint64_t b, uint64_t e, uint64_t q) {
     unsigned __int128 r = 1, x = b % q;
     while (e) {
@@ -77,7 +88,7 @@ int fz_retire(fz_ctx *ctx, void *d_ptr, const char *what) {
 
 int fz_scratch(fz_ctx *ctx, size_t bytes, void **out) {
     if (bytes > ctx->scratch_bytes) {
-        if (ctx->capturing)
+        if (fz_capturing(ctx))
             return fz_set_error(FZ_E_BADARG, "scratch would grow during graph capture: run the sequence once before fz_graph_begin");
         // previous users of the scratch are stream-ordered before this point
         FZ_HIP(hipStreamSynchronize(ctx->stream), "scratch sync");
@@ -94,7 +105,7 @@ int fz_scratch(fz_ctx *ctx, size_t bytes, void **out) {
 
 int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out) {
     if (bytes > ctx->scratch2_bytes) {
-        if (ctx->capturing)
+        if (fz_capturing(ctx))
             return fz_set_error(FZ_E_BADARG, "scratch would grow during graph capture: run the sequence once before fz_graph_begin");
         FZ_HIP(hipStreamSynchronize(ctx->stream), "scratch2 sync");
         FZ_TRY(fz_retire(ctx, ctx->d_scratch2, "scratch2 free"));
@@ -111,7 +122,7 @@ int fz_scratch2(fz_ctx *ctx, size_t bytes, void **out) {
 int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, double **part, int **state) {
     const size_t need = groups * doubles_per_group;
     if (need > ctx->vpart_doubles || groups > ctx->vstate_groups) {
-        if (ctx->capturing)
+        if (fz_capturing(ctx))
             return fz_set_error(FZ_E_BADARG, "verify scratch would grow during graph capture: run the sequence once before fz_graph_begin");
         FZ_HIP(hipStreamSynchronize(ctx->stream), "verify scratch sync");
         if (need > ctx->vpart_doubles) {
@@ -134,7 +145,7 @@ int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, doub
         }
     }
     if (ctx->verify_dirty) {                       // an earlier launch failed: do not trust "zero between launches"
-        if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "verify scratch must be re-zeroed: not during graph capture");
+        if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "verify scratch must be re-zeroed: not during graph capture");
         FZ_HIP(hipMemsetAsync(ctx->d_vpart, 0, ctx->vpart_doubles * sizeof(double), ctx->stream), "verify scratch clear");
         FZ_HIP(hipMemsetAsync(ctx->d_vstate, 0, ctx->vstate_groups * 2 * sizeof(int), ctx->stream), "verify state clear");
         ctx->verify_dirty = 0;
@@ -147,7 +158,7 @@ int fz_verify_scratch(fz_ctx *ctx, size_t groups, size_t doubles_per_group, doub
 // accumulator words of the one-pass aggregation (zero between launches; see aggregate_onepass)
 int fz_agg_scratch(fz_ctx *ctx, size_t tiles, size_t tile_words, unsigned long long **acc) {
     if (tiles > ctx->aggacc_tiles) {
-        if (ctx->capturing)
+        if (fz_capturing(ctx))
             return fz_set_error(FZ_E_BADARG, "aggregation scratch would grow during graph capture: run the sequence once before fz_graph_begin");
         FZ_HIP(hipStreamSynchronize(ctx->stream), "aggregation scratch sync");
         FZ_TRY(fz_retire(ctx, ctx->d_aggacc, "aggregation scratch free"));     // a captured aggregation keeps a valid (if stale) accumulator
@@ -159,7 +170,7 @@ int fz_agg_scratch(fz_ctx *ctx, size_t tiles, size_t tile_words, unsigned long l
         ctx->agg_dirty = 1;
     }
     if (ctx->agg_dirty) {
-        if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "aggregation scratch must be re-zeroed: not during graph capture");
+        if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "aggregation scratch must be re-zeroed: not during graph capture");
         FZ_HIP(hipMemsetAsync(ctx->d_aggacc, 0, ctx->aggacc_tiles * tile_words * sizeof(unsigned long long), ctx->stream), "aggregation scratch clear");
         ctx->agg_dirty = 0;
     }
@@ -389,7 +400,7 @@ int fz_ctx_destroy(fz_ctx *ctx) {
 
 int fz_ctx_set_stream(fz_ctx *ctx, void *hip_stream) {
     FZ_REQUIRE(ctx, "ctx is NULL");
-    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the stream cannot change during graph capture");
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "the stream cannot change during graph capture");
     if (ctx->stream != (hipStream_t)hip_stream) {
         // the accumulator words of the one-pass aggregation / fused verification, the scratch areas and the blocks of the
         // pool belong to the context, not to a stream: work still in flight on the old stream must not share them with
@@ -404,7 +415,7 @@ int fz_ctx_set_stream(fz_ctx *ctx, void *hip_stream) {
 int fz_ctx_synchronize(fz_ctx *ctx) {
     FZ_REQUIRE(ctx, "ctx is NULL");
     FZ_DEV(ctx);
-    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "synchronisation is not allowed during graph capture");
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "synchronisation is not allowed during graph capture");
     FZ_HIP(hipStreamSynchronize(ctx->stream), "stream synchronize");
     return FZ_OK;
 }
@@ -431,7 +442,7 @@ int fz_stream_destroy(fz_ctx *ctx, void *hip_stream) {
 int fz_graph_begin(fz_ctx *ctx) {
     FZ_REQUIRE(ctx, "ctx is NULL");
     FZ_DEV(ctx);
-    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "a capture is already open on this context");
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "a capture is already open on this context (or its stream has joined another context's)");
     if (ctx->stream == nullptr)
         return fz_set_error(FZ_E_BADARG, "graph capture needs a non-default stream (fz_ctx_set_stream)");
     if (ctx->prof_on) return fz_set_error(FZ_E_BADARG, "per-dispatch profiling is on: events cannot be captured");
@@ -467,7 +478,7 @@ int fz_graph_end(fz_ctx *ctx, fz_graph **out_graph) {
 int fz_graph_launch(fz_ctx *ctx, fz_graph *graph) {
     FZ_REQUIRE(ctx && graph, "NULL argument");
     FZ_DEV(ctx);
-    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "a graph cannot be launched into its own capture");
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "a graph cannot be launched into its own capture");
     if (graph->device != ctx->device) return fz_set_error(FZ_E_BADARG, "graph was captured on device %d", graph->device);
     FZ_HIP(hipGraphLaunch(graph->exec, ctx->stream), "graph launch");
     return FZ_OK;
@@ -479,6 +490,49 @@ int fz_graph_destroy(fz_graph *graph) {
     (void)hipGraphDestroy(graph->graph);
     delete graph;
     return FZ_OK;
+}
+
+// ---- events: ordering between the streams of two contexts ------------------------------------------------------------
+struct fz_event {
+    hipEvent_t ev;
+    int device;
+};
+
+int fz_event_create(fz_ctx *ctx, fz_event **out) {
+    FZ_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    FZ_DEV(ctx);
+    fz_event *e = new (std::nothrow) fz_event();
+    if (!e) return fz_set_error(FZ_E_HIP, "out of host memory");
+    e->device = ctx->device;
+    hipError_t rc = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+    if (rc != hipSuccess) { delete e; return fz_check_hip(rc, "event create"); }
+    *out = e;
+    return FZ_OK;
+}
+
+int fz_event_record(fz_ctx *ctx, fz_event *ev) {
+    FZ_REQUIRE(ctx && ev, "NULL argument");
+    if (ev->device != ctx->device) return fz_set_error(FZ_E_BADARG, "event was created on device %d", ev->device);
+    FZ_DEV(ctx);
+    FZ_HIP(hipEventRecord(ev->ev, ctx->stream), "event record");
+    return FZ_OK;
+}
+
+int fz_event_wait(fz_ctx *ctx, fz_event *ev) {
+    FZ_REQUIRE(ctx && ev, "NULL argument");
+    if (ev->device != ctx->device) return fz_set_error(FZ_E_BADARG, "event was created on device %d", ev->device);
+    FZ_DEV(ctx);
+    FZ_HIP(hipStreamWaitEvent(ctx->stream, ev->ev, 0), "stream wait event");
+    return FZ_OK;
+}
+
+int fz_event_destroy(fz_event *ev) {
+    if (!ev) return FZ_OK;
+    (void)hipSetDevice(ev->device);
+    hipError_t rc = hipEventDestroy(ev->ev);
+    delete ev;
+    return fz_check_hip(rc, "event destroy");
 }
 
 int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv) {
@@ -555,7 +609,7 @@ static void pool_flush_device(int device) {
 int fz_pool_trim(fz_ctx *ctx, size_t keep_bytes) {
     FZ_REQUIRE(ctx, "ctx is NULL");
     FZ_DEV(ctx);
-    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the pool cannot be trimmed during graph capture (hipFree synchronises)");
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "the pool cannot be trimmed during graph capture (hipFree synchronises)");
     std::lock_guard<std::mutex> g(ctx->pool_mu);
     pool_release_locked(ctx, keep_bytes);
     return FZ_OK;
@@ -567,7 +621,7 @@ int fz_malloc(fz_ctx *ctx, size_t bytes, void **d_out) {
     if (bytes == 0) bytes = 1;
     void *p = nullptr;
     hipEvent_t ev = nullptr;
-    if (bytes >= kPoolMin && !ctx->capturing) {       // (a pooled block's event was recorded outside the capture: not waitable inside one)
+    if (bytes >= kPoolMin && !fz_capturing(ctx)) {       // (a pooled block's event was recorded outside the capture: not waitable inside one)
         std::lock_guard<std::mutex> g(ctx->pool_mu);
         int best = -1;
         for (int i = 0; i < ctx->n_pool; ++i) {
@@ -625,7 +679,7 @@ int fz_free(fz_ctx *ctx, void *d_ptr) {
             fz_ctx::FzBlock b = ctx->live_blocks[i];
             ctx->live_blocks[i] = ctx->live_blocks[--ctx->n_live];
             stale = b.ev;
-            if (ctx->capturing || b.bytes > ctx->pool_cap || !grow(ctx->pool_blocks, ctx->cap_pool, ctx->n_pool + 1)) break;
+            if (fz_capturing(ctx) || b.bytes > ctx->pool_cap || !grow(ctx->pool_blocks, ctx->cap_pool, ctx->n_pool + 1)) break;
             // room under the process-wide cap: this context's oldest blocks go first; if other contexts hold the rest, do not pool
             if (g_pool_bytes + b.bytes > ctx->pool_cap) {
                 const size_t over = g_pool_bytes + b.bytes - ctx->pool_cap;
@@ -655,7 +709,7 @@ int fz_memcpy_h2d(fz_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
 int fz_memcpy_d2h(fz_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     FZ_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), "NULL argument");
     FZ_DEV(ctx);
-    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "a synchronous device-to-host copy cannot be captured");
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "a synchronous device-to-host copy cannot be captured");
     if (bytes) FZ_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream), "memcpy d2h");
     FZ_HIP(hipStreamSynchronize(ctx->stream), "memcpy d2h sync");
     return FZ_OK;
@@ -671,7 +725,7 @@ int fz_timer_start(fz_ctx *ctx) {
 int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms) {
     FZ_REQUIRE(ctx && out_ms, "NULL argument");
     FZ_DEV(ctx);
-    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the timer cannot be read during graph capture");
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "the timer cannot be read during graph capture");
     FZ_HIP(hipEventRecord(ctx->ev1, ctx->stream), "event record");
     FZ_HIP(hipEventSynchronize(ctx->ev1), "event synchronize");
     FZ_HIP(hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1), "event elapsed");
@@ -681,7 +735,7 @@ int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms) {
 int fz_profile_begin(fz_ctx *ctx, int max_launches, int sample_every) {
     FZ_REQUIRE(ctx && max_launches > 0 && max_launches <= (1 << 20) && sample_every >= 1, "bad argument");
     FZ_DEV(ctx);
-    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "per-dispatch profiling cannot start during graph capture");
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "per-dispatch profiling cannot start during graph capture");
     if (max_launches > ctx->prof_cap) {
         hipEvent_t *ev = (hipEvent_t *)realloc(ctx->prof_ev, sizeof(hipEvent_t) * 2 * (size_t)max_launches);
         unsigned char *kind = (unsigned char *)realloc(ctx->prof_kind, (size_t)max_launches);
@@ -1186,7 +1240,7 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
     if (!fz_host_params_ok(P)) return fz_set_error(FZ_E_BADARG, "bad scheme parameters");
     if (P->degree != ctx->degree || P->modulus != (int64_t)ctx->q)
         return fz_set_error(FZ_E_BADARG, "scheme parameters (degree %d) do not belong to this context (degree %d)", P->degree, ctx->degree);
-    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the challenge pipeline uploads the pre-hashed messages: not during graph capture");
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "the challenge pipeline uploads the pre-hashed messages: not during graph capture");
     const long long bound = std::max<long long>(1, std::min<long long>((long long)P->modulus / 2, P->beta_ch));
     if (bound != 1 || P->degree > 256 || P->degree < 4 || (P->degree & (P->degree - 1)) || P->omega_ch > P->degree ||
         (((uintptr_t)d_vk | (uintptr_t)d_out) & 15))
@@ -1276,7 +1330,7 @@ int fz_sample_secret_polys_dev(fz_ctx *ctx, const uint64_t *h_seeds, size_t N, i
     FZ_REQUIRE(ctx && (N == 0 || (h_seeds && d_out)), "NULL argument");
     FZ_REQUIRE(degree >= 1 && modulus >= 2, "bad degree / modulus");
     FZ_DEV(ctx);
-    if (ctx->capturing) return fz_set_error(FZ_E_BADARG, "the sampler uploads the seeds: not during graph capture");
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "the sampler uploads the seeds: not during graph capture");
     const int64_t bound = std::max<int64_t>(0, std::min<int64_t>(modulus / 2, norm_bound));
     if (bound < 1 || bound >= (1ll << 32)) return fz_set_error(FZ_E_BADARG, "empty range for randrange()");
     if (weight_bound < degree)

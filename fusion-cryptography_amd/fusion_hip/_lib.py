@@ -54,6 +54,10 @@ SIGNATURES = {
     "fz_graph_end": (c_int, [_ctx, POINTER(c_void_p)]),
     "fz_graph_launch": (c_int, [_ctx, c_void_p]),
     "fz_graph_destroy": (c_int, [c_void_p]),
+    "fz_event_create": (c_int, [_ctx, POINTER(c_void_p)]),
+    "fz_event_record": (c_int, [_ctx, c_void_p]),
+    "fz_event_wait": (c_int, [_ctx, c_void_p]),
+    "fz_event_destroy": (c_int, [c_void_p]),
     "fz_malloc": (c_int, [_ctx, c_size_t, POINTER(c_void_p)]),
     "fz_free": (c_int, [_ctx, c_void_p]),
     "fz_pool_trim": (c_int, [_ctx, c_size_t]),

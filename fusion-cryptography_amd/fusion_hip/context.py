@@ -544,6 +544,34 @@ class Graph:
             pass
 
 
+class Event:
+    """A point on a context's stream that another context's stream can wait for (fz_event_*): record(ctx) marks what ctx's
+    stream has been given so far, wait(ctx) makes ctx's stream wait for the marked point without blocking the host.  Usable
+    inside a capture (the waiting context's stream joins the capture; the capturing context must wait for an event recorded
+    on it again before graph_end)."""
+
+    def __init__(self, ctx):
+        self._lib, self._e = ctx._lib, c_void_p()
+        check(self._lib, self._lib.fz_event_create(ctx._h, byref(self._e)))
+
+    def record(self, ctx):
+        check(self._lib, self._lib.fz_event_record(ctx._h, self._e))
+
+    def wait(self, ctx):
+        check(self._lib, self._lib.fz_event_wait(ctx._h, self._e))
+
+    def destroy(self):
+        if self._e:
+            self._lib.fz_event_destroy(self._e)
+            self._e = c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class DeviceBuffer:
     """Minimal owning wrapper over fz_malloc for callers that do not use torch."""
 

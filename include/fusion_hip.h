@@ -99,6 +99,22 @@ FZ_API int fz_graph_end(fz_ctx *ctx, fz_graph **out_graph);
 FZ_API int fz_graph_launch(fz_ctx *ctx, fz_graph *graph);      /* asynchronous on the context's stream */
 FZ_API int fz_graph_destroy(fz_graph *graph);
 
+/* ---- events: ordering between the streams of two contexts ------------------------------------
+ * The reference is one Python thread with no streams; a host that keeps several contexts busy (one stream each) needs an
+ * order between them in exactly one place of this path: the exchange step of a sharded aggregation or verification
+ * (the sums of fusion/fusion.py:670-676 and :706-714 across GPUs, fz_allreduce_i64) can run on a second context's stream while
+ * the first context signs the next batch (fusion.py:557) -- record after the partial sums, let the exchanging context wait,
+ * record after the exchange, let the verifying context wait.  fz_event_record marks the point the context's stream has
+ * reached; fz_event_wait makes the context's stream wait for the marked point without blocking the host.  Both can be issued
+ * inside a capture (fz_graph_begin): waiting for an event recorded in another context's capture draws the waiting context's
+ * stream into that capture (fork), and the capturing context must wait for an event recorded on it again before
+ * fz_graph_end (join); while its stream is part of a capture a context obeys the rules of a capturing one. */
+typedef struct fz_event fz_event;
+FZ_API int fz_event_create(fz_ctx *ctx, fz_event **out);
+FZ_API int fz_event_record(fz_ctx *ctx, fz_event *ev);       /* on the context's stream */
+FZ_API int fz_event_wait(fz_ctx *ctx, fz_event *ev);         /* the context's stream waits; asynchronous */
+FZ_API int fz_event_destroy(fz_event *ev);
+
 /* ---- device memory helpers (so a host language needs no HIP binding of its own) --------
  * fz_free keeps blocks of 256 KiB or more for reuse by later fz_malloc calls of this context; ONE budget of FZ_POOL_MB
  * megabytes (default 4096; 0 = every fz_free is a hipFree, which for a large block takes ~180 us and synchronises the

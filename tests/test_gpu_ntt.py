@@ -187,6 +187,68 @@ def test_graph_capture_replays_a_recorded_sequence(coracle):
     ctx.close()
 
 
+def test_events_order_two_contexts_eagerly_and_inside_a_capture(coracle):
+    """fz_event_*: context A transforms forward on its stream, context B transforms back on ITS stream after waiting for A's
+    event -- launched eagerly, then as ONE captured graph in which B's stream forks off A's capture and joins it again, replayed
+    on new contents.  While B's stream is part of A's capture, B obeys the capture rules (no synchronisation, no host copies)."""
+    import fusion_hip
+    P = O.PARAMS[256]
+    q, d = P["q"], P["d"]
+    A = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    B = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    sa, sb = A.stream_create(), B.stream_create()
+    A.set_stream(sa)
+    B.set_stream(sb)
+    rows = 4096
+    x = O.splitmix_centered(41, rows * d).reshape(rows, d)
+    dx = fusion_hip.DeviceBuffer.from_numpy(A, x)
+    dy, dz = fusion_hip.DeviceBuffer(A, x.nbytes), fusion_hip.DeviceBuffer(A, x.nbytes)
+    dsq = fusion_hip.DeviceBuffer(A, x.nbytes)
+    e_fwd, e_back = fusion_hip.Event(A), fusion_hip.Event(A)
+    A.synchronize()
+
+    def sequence():
+        A.ntt_forward_dev(dx.ptr, dy.ptr, rows)
+        e_fwd.record(A)
+        e_fwd.wait(B)                                  # B's stream: after A's forward transform
+        B.ntt_inverse_dev(dy.ptr, dz.ptr, rows)
+        e_back.record(B)
+        A.pw_dev(fusion_hip.OP_MUL, dy.ptr, dy.ptr, dsq.ptr, rows * d)      # A goes on beside B
+        e_back.wait(A)                                 # ... and joins B again
+    for _ in range(20):                                # eagerly: a missing order would show as a torn dz sooner or later
+        sequence()
+    A.synchronize()
+    B.synchronize()
+    f = coracle.ntt_forward(x, q, P["root"])
+    assert np.array_equal(B.d2h(np.empty_like(x), dz.ptr), x)
+    assert np.array_equal(A.d2h(np.empty_like(x), dsq.ptr), coracle.pw_mul(f, f, q))
+    A.graph_begin()
+    sequence()
+    with pytest.raises(fusion_hip.FusionHipError, match="capture"):
+        B.synchronize()                                # B's stream has joined A's capture
+    with pytest.raises(fusion_hip.FusionHipError, match="capture"):
+        B.d2h(np.empty_like(x), dz.ptr)
+    g = A.graph_end()
+    for seed in (42, 43):
+        x = O.splitmix_centered(seed, rows * d).reshape(rows, d)
+        A.h2d(dx.ptr, x)
+        g.launch()
+        A.synchronize()
+        assert np.array_equal(A.d2h(np.empty_like(x), dz.ptr), x)
+        f = coracle.ntt_forward(x, q, P["root"])
+        assert np.array_equal(A.d2h(np.empty_like(x), dsq.ptr), coracle.pw_mul(f, f, q))
+    B.synchronize()                                    # allowed again: the capture has ended
+    g.destroy()
+    for e in (e_fwd, e_back):
+        e.destroy()
+    for b in (dx, dy, dz, dsq):
+        b.free()
+    for c, s_ in ((A, sa), (B, sb)):
+        c.set_stream(0)
+        c.stream_destroy(s_)
+        c.close()
+
+
 @pytest.mark.parametrize("d", [4, 16, 32, 64, 128, 256])
 def test_poly_mul_matches_transform_composition(d, coracle, monkeypatch):
     """fz_poly_mul (fused kernel at d = 64 / 256, composed launches otherwise) == INTT(NTT f * NTT g) of the oracle,

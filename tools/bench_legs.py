@@ -55,42 +55,78 @@ def sign_verify(e):
         sets.append(dict(coef=coef, sk_hat=sk_hat, vk=vk, c_hat=c_hat, al_hat=al_hat, vkL=vk[:, 0].contiguous(),
                          vkR=vk[:, 1].contiguous(), sig=torch.empty((S, l, d), dtype=torch.int32, device=dev)))
     del coef0, cc0, aa0
-    # one flat int64 buffer: [GROUPS][l*d] aggregate partials followed by [GROUPS][d] target partials
-    part = torch.zeros(GROUPS * (l * d + d), dtype=torch.int64, device=dev)
-    torch.cuda.synchronize(dev)                       # the fill ran on torch's stream; the kernels below run on the context's
-    part_t = part[GROUPS * l * d:]
+    # flat int64 buffers: [GROUPS][l*d] aggregate partials followed by [GROUPS][d] target partials -- one per operand set when
+    # the exchange overlaps the next step's kernels (a step's sums are still travelling while the next step writes its own)
+    overlap = comm is not None and not args.no_exchange_overlap
+    parts = [torch.zeros(GROUPS * (l * d + d), dtype=torch.int64, device=dev) for _ in range(NSETS if overlap else 1)]
     g_lo, g_hi = e.shard_range(GROUPS, rank, world)      # aggregates verified by this rank
-    d_verd = torch.full((max(1, g_hi - g_lo),), -1, dtype=torch.int32, device=dev)   # verdict codes, read after the loop
-    torch.cuda.synchronize(dev)
+    d_verds = [torch.full((max(1, g_hi - g_lo),), -1, dtype=torch.int32, device=dev) for _ in parts]   # verdict codes, read after the loop
+    torch.cuda.synchronize(dev)                       # the fills ran on torch's stream; the kernels below run on the context's
+    # The exchange step on a stream of its own (overlap): a second context issues fz_allreduce_i64 there, ordered with the
+    # compute stream by two events per step -- "partials written" (compute -> exchange) and "sums arrived" (exchange ->
+    # compute).  The verification of step i is issued AFTER the kernels of step i + 1, so the all-reduce of step i (a latency of
+    # tens of microseconds at 2-8 ranks, 0.7-1.4 MB) runs beside sign_core + the partial sums of step i + 1 instead of
+    # stalling the chip.  Same launches, same results; round 3's form (everything on one stream): --no-exchange-overlap.
+    cx = ev_part = ev_sum = None
+    if overlap:
+        cx = e.exchange_ctx           # created with its stream at the start of the process (bench.py: hardware queues go to streams in order)
+        ev_part = [e.fusion_hip.Event(ctx) for _ in range(NSETS)]
+        ev_sum = [e.fusion_hip.Event(ctx) for _ in range(NSETS)]
 
-    def sv_step(i):
-        s_ = sets[i % NSETS]
+    def sv_compute(i):
+        s_, part = sets[i % NSETS], parts[i % len(parts)]
         ctx.sign_core_dev(s_["sk_hat"].data_ptr(), s_["c_hat"].data_ptr(), s_["sig"].data_ptr(), S, l)
         # aggregate partials and the verification target's partials: one pass over this rank's signers, one launch
         ctx.aggregate_target_partial_batch_dev(s_["sig"].data_ptr(), s_["al_hat"].data_ptr(), s_["vkL"].data_ptr(),
                                                s_["vkR"].data_ptr(), s_["c_hat"].data_ptr(), part.data_ptr(), l * d,
-                                               part_t.data_ptr(), d, GROUPS, per, l)
-        if comm is not None:         # the ONE exchange step (RCCL over xGMI)
+                                               part[GROUPS * l * d:].data_ptr(), d, GROUPS, per, l)
+
+    def sv_exchange(i):              # the ONE exchange step (RCCL over xGMI)
+        part = parts[i % len(parts)]
+        if overlap:
+            ev_part[i % NSETS].record(ctx)
+            ev_part[i % NSETS].wait(cx)
+            cx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
+            ev_sum[i % NSETS].record(cx)
+        elif comm is not None:
             ctx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
         else:
             e.allreduce_sum_i64(part)
+
+    def sv_verify(i):
+        part = parts[i % len(parts)]
+        if overlap:
+            ev_sum[i % NSETS].wait(ctx)
         if g_hi > g_lo:          # verdicts straight from the int64 sums, left on the device: no host synchronisation
             ctx.verify_partials_batch_async_dev(
-                A.data_ptr(), part[g_lo * l * d:].data_ptr(), l * d, part_t[g_lo * d:].data_ptr(), d,
-                g_hi - g_lo, l, P["beta_vf"], d, d_verd.data_ptr())
+                A.data_ptr(), part[g_lo * l * d:].data_ptr(), l * d, part[GROUPS * l * d + g_lo * d:].data_ptr(), d,
+                g_hi - g_lo, l, P["beta_vf"], d, d_verds[i % len(parts)].data_ptr())
 
-    for i in range(NSETS):
-        sv_step(i)
-        e.barrier()
-        assert g_hi == g_lo or all(v == 0 for v in d_verd.tolist()), f"verify verdicts {d_verd.tolist()} on set {i}"
+    def sv_steps_once():             # NSETS steps; with the overlap, verification trails the kernels by one step
+        for i in range(NSETS):
+            sv_compute(i)
+            sv_exchange(i)
+            if not overlap:
+                sv_verify(i)
+            elif i > 0:
+                sv_verify(i - 1)
+        if overlap:
+            sv_verify(NSETS - 1)
+
+    def verdicts_ok():
+        return g_hi == g_lo or all(v == 0 for dv in d_verds for v in dv.tolist())
+
+    sv_steps_once()
+    e.barrier()
+    torch.cuda.synchronize(dev)
+    assert verdicts_ok(), f"verify verdicts {[dv.tolist() for dv in d_verds]}"
     # one graph = NSETS steps (every set once); refused together if any rank cannot capture (e.g. the collective)
     sv_graph, captured = None, 0.0
     if not args.no_graph and (world == 1 or comm is not None):
         try:
             ctx.graph_begin()
             try:
-                for i in range(NSETS):
-                    sv_step(i)
+                sv_steps_once()
             finally:
                 sv_graph = ctx.graph_end()
             captured = 1.0
@@ -104,8 +140,7 @@ def sign_verify(e):
         if sv_graph is not None:
             sv_graph.launch()
         else:
-            for i in range(NSETS):
-                sv_step(i)
+            sv_steps_once()
     for _ in range(2):
         sv_round()
     for _ in range(40 if args.prewarm_ms > 0 else 0):      # count-based: every rank must issue the same collectives
@@ -123,7 +158,8 @@ def sign_verify(e):
         sv_round()
     e.barrier()
     dt = e.max_over_ranks(time.perf_counter() - t0)
-    assert g_hi == g_lo or all(v == 0 for v in d_verd.tolist()), "a verification failed inside the timed region"
+    torch.cuda.synchronize(dev)
+    assert verdicts_ok(), "a verification failed inside the timed region"
     sv_steps = sv_rounds * NSETS
     sv_bytes = S * ((3 * l + 1) + (l + 5)) * 4 * d
     sv = {"value": S * world * sv_steps / dt, "unit": "signatures signed+aggregated+verified per s",
@@ -131,6 +167,8 @@ def sign_verify(e):
           "steps": sv_steps, "ms_per_step": dt / sv_steps * 1e3, "operand_sets_cycled": NSETS,
           "launch": "hipGraph replay of %d steps (fz_graph_*)" % NSETS if sv_graph is not None else "one by one",
           "collective": collective,
+          "exchange": ("on a second stream, overlapping the next step's kernels (fz_event_*)" if overlap else
+                       "on the compute stream" if comm is not None else "none" if world == 1 else "torch.distributed, host-ordered"),
           "algorithmic_GB/s_per_gpu": sv_bytes * sv_steps / dt / 1e9,
           "hbm_frac_per_gpu": sv_bytes * sv_steps / dt / 1e9 / e.HBM_PEAK_GBS,
           "note": "algebra cores only: sign_core, aggregate + target partials (one pass, one launch), int64 all-reduce, "
@@ -139,6 +177,11 @@ def sign_verify(e):
     sv_graph_used = sv_graph is not None
     if sv_graph is not None:
         sv_graph.destroy()
+    if overlap:
+        ctx.synchronize()
+        cx.synchronize()
+        for ev in ev_part + ev_sum:
+            ev.destroy()
 
     # BASELINE configs[2]: 1024 independent keygen + sign per step (keygen_core: 2*l transforms + two A.s products per
     # key; sign_core: sigma = L*c + R), no exchange step: ranks are independent

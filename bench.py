@@ -424,7 +424,7 @@ def main():
     # process creates streams.  The HIP runtime hands hardware queues to streams in the order they first need one; RCCL (a
     # torch.distributed "nccl" group, or fz_comm_create) takes several for its own streams, and chains created after it end up
     # sharing queues with them or with each other -- measured with a communicator of ONE rank: 0.84-1.75 G NTT/s instead of
-    # 2.2 G (profiles/r04_hw_queue_oversubscription.txt; tools/hw_queue_probe.py).
+    # 2.2 G (tools/hw_queue_probe.py, its table under profiles/).
     S = max(1, min(args.streams, NBATCH // 2))
     chain_ctx = []
     for _ in range(S):

@@ -60,6 +60,9 @@ def parse(argv=None):
     ap.add_argument("--full", action="store_true", help="also run the side legs of tools/bench_legs.py (full file only)")
     ap.add_argument("--single-rank-comm", action="store_true",
                     help="N = 1 only: create a one-rank RCCL communicator so that sign_verify runs its exchange-step code path")
+    ap.add_argument("--exchange-standin-us", type=int, default=0,
+                    help="N = 1 only: a one-wave kernel of this duration in place of the multi-GPU all-reduce in sign_verify "
+                         "(fz_diag_delay): what the second stream hides of an exchange step of known latency")
     ap.add_argument("--no-exchange-overlap", action="store_true",
                     help="sign_verify: the all-reduce on the compute stream (round 3's form) instead of a second stream")
     ap.add_argument("--headline-only", action="store_true",

@@ -1402,6 +1402,13 @@ int fz_diag_shader_clock(fz_ctx *ctx, unsigned microseconds, double *out_mhz) {
     return FZ_OK;
 }
 
+int fz_diag_delay(fz_ctx *ctx, unsigned microseconds) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    FZ_REQUIRE(microseconds >= 1 && microseconds <= 100000, "between 1 us and 100 ms");
+    FZ_DEV(ctx);
+    return fz_launch_diag_clock(ctx->stream, (unsigned long long)microseconds * 100ull, nullptr);
+}
+
 // ---- the one exchange step of the path, in the C ABI: RCCL all-reduce of the int64 partial sums ---------------------
 // RCCL is bound lazily (dlopen): the library loads and every other entry point works on a machine without it, and a
 // process that already carries an RCCL (torch ships its own copy under the same soname) shares that one.

@@ -1517,7 +1517,7 @@ __global__ __launch_bounds__(64) void diag_clock_kernel(unsigned long long ticks
         __builtin_amdgcn_s_sleep(8);
         r1 = __builtin_amdgcn_s_memrealtime();
     }
-    if (threadIdx.x == 0) { out[0] = __builtin_amdgcn_s_memtime() - t0; out[1] = r1 - r0; }
+    if (threadIdx.x == 0 && out) { out[0] = __builtin_amdgcn_s_memtime() - t0; out[1] = r1 - r0; }
 }
 }  // namespace
 

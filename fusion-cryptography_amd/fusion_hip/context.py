@@ -173,6 +173,10 @@ class Context:
         check(self._lib, self._lib.fz_diag_shader_clock(self._h, int(microseconds), byref(mhz)))
         return mhz.value
 
+    def diag_delay(self, microseconds):
+        """one wave that occupies this context's stream for `microseconds` (asynchronous, capturable)"""
+        check(self._lib, self._lib.fz_diag_delay(self._h, int(microseconds)))
+
     def allreduce_i64_dev(self, comm, d_buf, count):
         """in-place ncclAllReduce(int64, sum) on this context's stream (comm: a Comm)"""
         check(self._lib, self._lib.fz_allreduce_i64(self._h, comm._c, c_void_p(d_buf), count))

@@ -337,6 +337,10 @@ FZ_API int fz_diag_copy(fz_ctx *ctx, const void *d_src, void *d_dst, size_t byte
  * returns (synchronous).  The fp64-dense fused kernels run power-limited well below the nominal 2.4 GHz; a vector-issue
  * roofline has to be priced at THIS clock (profiles/README.md, round 3). */
 FZ_API int fz_diag_shader_clock(fz_ctx *ctx, unsigned microseconds, double *out_mhz);
+/* one wave that occupies the context's stream for `microseconds` (asynchronous, capturable): a stand-in of known duration for
+ * a step that cannot be run here -- bench.py uses it in place of the multi-GPU all-reduce to measure, on ONE GPU, how much of
+ * an exchange step's latency its second stream hides */
+FZ_API int fz_diag_delay(fz_ctx *ctx, unsigned microseconds);
 
 /* ---- norm / weight of coefficient rows -------------------------------------------------------
  * PolynomialCoefficientRepresentation.norm("infty") / weight(), algebra/polynomials.py:221-227:

@@ -57,7 +57,8 @@ def sign_verify(e):
     del coef0, cc0, aa0
     # flat int64 buffers: [GROUPS][l*d] aggregate partials followed by [GROUPS][d] target partials -- one per operand set when
     # the exchange overlaps the next step's kernels (a step's sums are still travelling while the next step writes its own)
-    overlap = comm is not None and not args.no_exchange_overlap
+    standin = args.exchange_standin_us if world == 1 else 0           # (a delay of known length in place of the all-reduce)
+    overlap = (comm is not None or standin > 0) and not args.no_exchange_overlap
     parts = [torch.zeros(GROUPS * (l * d + d), dtype=torch.int64, device=dev) for _ in range(NSETS if overlap else 1)]
     g_lo, g_hi = e.shard_range(GROUPS, rank, world)      # aggregates verified by this rank
     d_verds = [torch.full((max(1, g_hi - g_lo),), -1, dtype=torch.int32, device=dev) for _ in parts]   # verdict codes, read after the loop
@@ -86,10 +87,16 @@ def sign_verify(e):
         if overlap:
             ev_part[i % NSETS].record(ctx)
             ev_part[i % NSETS].wait(cx)
-            cx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
+            if comm is not None:
+                cx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
+            if standin:
+                cx.diag_delay(standin)
             ev_sum[i % NSETS].record(cx)
-        elif comm is not None:
-            ctx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
+        elif comm is not None or standin:
+            if comm is not None:
+                ctx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
+            if standin:
+                ctx.diag_delay(standin)
         else:
             e.allreduce_sum_i64(part)
 
@@ -122,7 +129,7 @@ def sign_verify(e):
     assert verdicts_ok(), f"verify verdicts {[dv.tolist() for dv in d_verds]}"
     # one graph = NSETS steps (every set once); refused together if any rank cannot capture (e.g. the collective)
     sv_graph, captured = None, 0.0
-    if not args.no_graph and (world == 1 or comm is not None):
+    if not args.no_graph and (world == 1 or comm is not None):      # (a stand-in delay is a kernel: capturable)
         try:
             ctx.graph_begin()
             try:
@@ -168,7 +175,8 @@ def sign_verify(e):
           "launch": "hipGraph replay of %d steps (fz_graph_*)" % NSETS if sv_graph is not None else "one by one",
           "collective": collective,
           "exchange": ("on a second stream, overlapping the next step's kernels (fz_event_*)" if overlap else
-                       "on the compute stream" if comm is not None else "none" if world == 1 else "torch.distributed, host-ordered"),
+                       "on the compute stream" if (comm is not None or standin) else "none" if world == 1 else "torch.distributed, host-ordered"),
+          "exchange_standin_us": standin or None,
           "algorithmic_GB/s_per_gpu": sv_bytes * sv_steps / dt / 1e9,
           "hbm_frac_per_gpu": sv_bytes * sv_steps / dt / 1e9 / e.HBM_PEAK_GBS,
           "note": "algebra cores only: sign_core, aggregate + target partials (one pass, one launch), int64 all-reduce, "

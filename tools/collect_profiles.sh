@@ -44,6 +44,7 @@ step timeout -k 10 300 python tools/queue_probe.py > $OUT/${TAG}_queue_probe.txt
 step timeout -k 10 300 python tools/sharded_modes.py > $OUT/${TAG}_sharded_alpha_modes_raw.txt 2>&1
 step timeout -k 10 300 python tools/benchmarks.py 256 128 > $OUT/${TAG}_api_benchmarks.json 2> $OUT/api_benchmarks.err
 step timeout -k 10 200 python tools/object_api_profile.py 256 16 > $OUT/${TAG}_object_api_profile.txt 2>&1
+step timeout -k 10 600 bash tools/exchange_overlap.sh > $OUT/${TAG}_exchange_overlap.txt 2>&1
 step timeout -k 10 400 python tools/hw_queue_probe.py > $OUT/${TAG}_hw_queue_oversubscription.txt 2>&1
 step timeout -k 10 300 python tools/stream_sweep.py > $OUT/${TAG}_multi_stream_sweep.txt 2>&1
 step timeout -k 10 600 python bench.py --full --full-out $OUT/${TAG}_bench_full.json > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err

@@ -444,7 +444,11 @@ def main():
     ctx.diag_empty_launch()
     # the exchange step's context (sign_verify: fz_allreduce_i64 on a stream of its own, beside the next step's kernels)
     exchange_ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
-    exchange_ctx.set_stream(exchange_ctx.stream_create())
+    # HIGH stream priority: beside sign_core's 1024 workgroups the all-reduce kernel's few otherwise wait for slots -- measured
+    # with a one-rank RCCL all-reduce + a 40 us stand-in per step: 156 us per step at normal priority, 84 at high
+    # (FZ_BENCH_EXCHANGE_PRIORITY=normal for the A/B)
+    xprio = os.environ.get("FZ_BENCH_EXCHANGE_PRIORITY", "high")
+    exchange_ctx.set_stream(exchange_ctx.stream_create(None if xprio == "normal" else xprio))
     exchange_ctx.diag_empty_launch()
     for c_ in (ctx, exchange_ctx):
         c_.synchronize()

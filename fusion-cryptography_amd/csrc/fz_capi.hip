@@ -429,6 +429,17 @@ int fz_stream_create(fz_ctx *ctx, void **out_stream) {
     return FZ_OK;
 }
 
+int fz_stream_create_priority(fz_ctx *ctx, int high, void **out_stream) {
+    FZ_REQUIRE(ctx && out_stream, "NULL argument");
+    FZ_DEV(ctx);
+    int least = 0, greatest = 0;                     // numerically LOWER = higher priority
+    FZ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest), "stream priority range");
+    hipStream_t s = nullptr;
+    FZ_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least), "stream create");
+    *out_stream = (void *)s;
+    return FZ_OK;
+}
+
 int fz_stream_destroy(fz_ctx *ctx, void *hip_stream) {
     FZ_REQUIRE(ctx, "ctx is NULL");
     FZ_DEV(ctx);

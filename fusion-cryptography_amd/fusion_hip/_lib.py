@@ -49,6 +49,7 @@ SIGNATURES = {
     "fz_aggregate_target_partial_ragged": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_size_t), c_size_t,
                                                    c_int, c_void_p, c_size_t, c_void_p, c_size_t]),
     "fz_stream_create": (c_int, [_ctx, POINTER(c_void_p)]),
+    "fz_stream_create_priority": (c_int, [_ctx, c_int, POINTER(c_void_p)]),
     "fz_stream_destroy": (c_int, [_ctx, c_void_p]),
     "fz_graph_begin": (c_int, [_ctx]),
     "fz_graph_end": (c_int, [_ctx, POINTER(c_void_p)]),

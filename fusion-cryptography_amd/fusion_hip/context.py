@@ -66,10 +66,14 @@ class Context:
     def synchronize(self):
         check(self._lib, self._lib.fz_ctx_synchronize(self._h))
 
-    def stream_create(self):
-        """-> raw hipStream_t (int) on this context's device"""
+    def stream_create(self, priority=None):
+        """-> raw hipStream_t (int) on this context's device; priority "high" / "low": the device's highest / lowest stream
+        priority (small latency-bound launches beside chip-filling ones)"""
         p = c_void_p()
-        check(self._lib, self._lib.fz_stream_create(self._h, byref(p)))
+        if priority is None:
+            check(self._lib, self._lib.fz_stream_create(self._h, byref(p)))
+        else:
+            check(self._lib, self._lib.fz_stream_create_priority(self._h, 1 if priority == "high" else 0, byref(p)))
         return p.value
 
     def stream_destroy(self, stream_ptr):

@@ -75,6 +75,10 @@ FZ_API int fz_ctx_synchronize(fz_ctx *ctx);
  * detach it from every context before destroying it) */
 FZ_API int fz_stream_create(fz_ctx *ctx, void **out_stream);
 FZ_API int fz_stream_destroy(fz_ctx *ctx, void *hip_stream);
+/* the same with a scheduling priority: high != 0 asks for the device's highest stream priority -- the workgroups of its kernels
+ * are dispatched ahead of those of normal streams, which is what a small latency-bound launch (the exchange step's all-reduce,
+ * a verification of a few aggregates) needs beside a launch that fills the chip; 0 asks for the lowest */
+FZ_API int fz_stream_create_priority(fz_ctx *ctx, int high, void **out_stream);
 /* copies the bit-reversed twiddle tables the context uses (each `degree` uint32 in [0,q));
  * equal to bit_reverse_copy([pow(root,i,q)]) / ([pow(inv_root,i,q)]). Either may be NULL. */
 FZ_API int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv);

@@ -68,9 +68,11 @@ def sign_verify(e):
     # compute).  The verification of step i is issued AFTER the kernels of step i + 1, so the all-reduce of step i (a latency of
     # tens of microseconds at 2-8 ranks, 0.7-1.4 MB) runs beside sign_core + the partial sums of step i + 1 instead of
     # stalling the chip.  Same launches, same results; round 3's form (everything on one stream): --no-exchange-overlap.
-    # (Measured and dropped: the verification on the exchange stream as well, one event per step instead of two -- its 4-8
-    # workgroups then wait for slots behind sign_core's 1024: 91 instead of 86 us per step at a 40 us exchange, and 127 instead of
-    # 73 with a one-rank RCCL all-reduce in front of it.)
+    # The exchange stream has HIGH priority (bench.py): at normal priority the all-reduce kernel's workgroups wait for slots behind
+    # sign_core's 1024 -- 154 instead of 85 us per step with a one-rank RCCL all-reduce + a 40 us stand-in.
+    # (Measured and dropped: the verification on the exchange stream as well, one event per step instead of two -- beside
+    # sign_core, which saturates the memory system, the verification's latency chain of 4-8 workgroups takes 4-10 times as long:
+    # 127-131 instead of 73-85 us per step, at either stream priority.)
     cx = ev_part = ev_sum = None
     if overlap:
         cx = e.exchange_ctx           # created with its stream at the start of the process (bench.py: hardware queues go to streams in order)

@@ -8,3 +8,10 @@ for us in 0 10 20 40 60 80 120; do
   b=$(python bench.py --no-cpu-baseline --exchange-standin-us $us --no-exchange-overlap --full-out /dev/null 2>/dev/null | grep -a '^{"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read())['sign_verify']; print(f\"{d['ms_per_step']*1e3:7.1f} {d['value']/1e6:6.2f}\")")
   echo "$us | $a | $b"
 done
+echo
+echo "with a one-rank RCCL all-reduce (fz_allreduce_i64) in front of the stand-in, exchange on the second stream: stream priority high (default) | normal"
+for us in 0 40; do
+  a=$(python bench.py --no-cpu-baseline --single-rank-comm --exchange-standin-us $us --full-out /dev/null 2>/dev/null | grep -a '^{"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read())['sign_verify']; print(f\"{d['ms_per_step']*1e3:7.1f} {d['value']/1e6:6.2f}\")")
+  b=$(FZ_BENCH_EXCHANGE_PRIORITY=normal python bench.py --no-cpu-baseline --single-rank-comm --exchange-standin-us $us --full-out /dev/null 2>/dev/null | grep -a '^{"metric"' | python -c "import sys,json; d=json.loads(sys.stdin.read())['sign_verify']; print(f\"{d['ms_per_step']*1e3:7.1f} {d['value']/1e6:6.2f}\")")
+  echo "$us | $a | $b"
+done

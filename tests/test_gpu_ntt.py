@@ -196,7 +196,7 @@ def test_events_order_two_contexts_eagerly_and_inside_a_capture(coracle):
     q, d = P["q"], P["d"]
     A = fusion_hip.Context(q, d, P["root"], P["inv_root"])
     B = fusion_hip.Context(q, d, P["root"], P["inv_root"])
-    sa, sb = A.stream_create(), B.stream_create()
+    sa, sb = A.stream_create("low"), B.stream_create("high")     # (fz_stream_create_priority: priorities change scheduling, never results)
     A.set_stream(sa)
     B.set_stream(sb)
     rows = 4096

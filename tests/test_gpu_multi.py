@@ -356,3 +356,23 @@ def test_block_pool_is_thread_safe_stream_change_safe_and_shared(monkeypatch):
     assert c1.malloc(1 << 23) in (p1, p2)
     c1.close()
     c2.close()
+
+
+def test_bench_headline_keeps_its_streams_with_rccl_in_the_process():
+    """An N > 1 run of bench.py has a torch.distributed "nccl" group and a C-ABI communicator in its process, and RCCL takes
+    hardware queues for its own streams: chains created AFTER it share queues and the four-stream headline falls to 0.7-1.4 x
+    the one-stream rate (profiles/r04_hw_queue_oversubscription.txt).  bench.py creates its chains first; rehearsed here on one
+    GPU with communicators of ONE rank (--single-rank-comm).  The check is a ratio inside one run: four streams against one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--headline-only", "--single-rank-comm", "--full-out", os.devnull],
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
+    d = json.loads(line)
+    assert d["ranks"][0]["rccl_nranks"] == 1 and d["config"]["streams"] == 4
+    one, chip = d["roofline"]["frac"], d["roofline"]["chip"]["frac"]
+    assert chip > 1.5 * one, f"four streams reach {chip:.3f} of the peak against {one:.3f} on one: the chains share hardware queues"

@@ -210,10 +210,18 @@ def test_launch_floor_diagnostics_run():
     assert 300 < ctx.diag_shader_clock(300) < 4000
     ctx.synchronize()
     assert np.array_equal(b.to_numpy(np.int32, (4096, 256)), ctx.ntt_forward(x.reshape(4096, 256)))
+    # the delay kernel (the bench's stand-in for an exchange step): occupies the stream for at least what was asked, in order
+    ctx.timer_start()
+    ctx.diag_delay(300)
+    ctx.ntt_forward_dev(a.ptr, b.ptr, 4096)
+    assert 0.3 <= ctx.timer_stop_ms() < 5.0
+    assert np.array_equal(b.to_numpy(np.int32, (4096, 256)), ctx.ntt_forward(x.reshape(4096, 256)))
     ctx.set_stream(0)
     ctx.stream_destroy(s)
     with pytest.raises(fusion_hip.FusionHipError):
         ctx.diag_shader_clock(0)
+    with pytest.raises(fusion_hip.FusionHipError):
+        ctx.diag_delay(0)
 
 
 def test_contexts_on_two_devices_do_not_cross(coracle):

@@ -63,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--exchange-standin-us", type=int, default=0,
                     help="N = 1 only: a one-wave kernel of this duration in place of the multi-GPU all-reduce in sign_verify "
                          "(fz_diag_delay): what the second stream hides of an exchange step of known latency")
+    ap.add_argument("--verify-per-step", action="store_true",
+                    help="sign_verify: one verification launch per step (round 3's form) instead of one per 8 steps")
     ap.add_argument("--no-exchange-overlap", action="store_true",
                     help="sign_verify: the all-reduce on the compute stream (round 3's form) instead of a second stream")
     ap.add_argument("--headline-only", action="store_true",

@@ -55,40 +55,54 @@ def sign_verify(e):
         sets.append(dict(coef=coef, sk_hat=sk_hat, vk=vk, c_hat=c_hat, al_hat=al_hat, vkL=vk[:, 0].contiguous(),
                          vkR=vk[:, 1].contiguous(), sig=torch.empty((S, l, d), dtype=torch.int32, device=dev)))
     del coef0, cc0, aa0
-    # flat int64 buffers: [GROUPS][l*d] aggregate partials followed by [GROUPS][d] target partials -- one per operand set when
-    # the exchange overlaps the next step's kernels (a step's sums are still travelling while the next step writes its own)
+    # int64 sums as RECORDS: [set][aggregate][l*d sums of the aggregate | d sums of its verification target] -- one all-reduce
+    # per step covers a set's GROUPS records, and the records of all sets are uniformly strided, so ONE verification launch can
+    # take every aggregate of the 8 steps (below)
     standin = args.exchange_standin_us if world == 1 else 0           # (a delay of known length in place of the all-reduce)
     overlap = (comm is not None or standin > 0) and not args.no_exchange_overlap
-    parts = [torch.zeros(GROUPS * (l * d + d), dtype=torch.int64, device=dev) for _ in range(NSETS if overlap else 1)]
-    g_lo, g_hi = e.shard_range(GROUPS, rank, world)      # aggregates verified by this rank
-    d_verds = [torch.full((max(1, g_hi - g_lo),), -1, dtype=torch.int32, device=dev) for _ in parts]   # verdict codes, read after the loop
+    # The verifications of the 8 steps in ONE launch at the end of the 8 steps (a verification of 4-8 aggregates is a latency
+    # chain of 5 us on 4-8 workgroups; 32 of them are 7 us: 68.7 instead of 72.5 us per step) -- when the exchange does not run
+    # on a second stream.  With it the verification stays per step, one step late: a captured graph whose exchange branch joins
+    # the compute branch only at the end loses the branch's stream priority (161 us per step with a one-rank RCCL all-reduce + a
+    # 40 us stand-in, against 83 per step and 80 launched one by one) -- measured, profiles/ (exchange overlap table).
+    # --verify-per-step: a launch per step over this rank's share of the step's aggregates everywhere (round 3's form).
+    batched = not args.verify_per_step and world <= NSETS and not overlap
+    rec = l * d + d
+    nbuf = NSETS if (overlap or batched) else 1
+    pool = torch.zeros(nbuf * GROUPS * rec, dtype=torch.int64, device=dev)
+    g_lo, g_hi = e.shard_range(GROUPS, rank, world)      # per-step form: aggregates of every step verified by this rank
+    my_sets = [s_ for s_ in range(NSETS) if s_ % world == rank] if batched else list(range(NSETS))
+    d_verd = torch.full((NSETS * GROUPS,), -1, dtype=torch.int32, device=dev)        # verdict codes, read after the loops
     torch.cuda.synchronize(dev)                       # the fills ran on torch's stream; the kernels below run on the context's
-    # The exchange step on a stream of its own (overlap): a second context issues fz_allreduce_i64 there, ordered with the
-    # compute stream by two events per step -- "partials written" (compute -> exchange) and "sums arrived" (exchange ->
-    # compute).  The verification of step i is issued AFTER the kernels of step i + 1, so the all-reduce of step i (a latency of
-    # tens of microseconds at 2-8 ranks, 0.7-1.4 MB) runs beside sign_core + the partial sums of step i + 1 instead of
-    # stalling the chip.  Same launches, same results; round 3's form (everything on one stream): --no-exchange-overlap.
+    # The exchange step on a stream of its own (overlap): a second context issues fz_allreduce_i64 there behind an event per
+    # step ("partials written", compute -> exchange), so the all-reduce of step i (a latency of tens of microseconds at 2-8
+    # ranks, 0.7-1.4 MB) runs beside sign_core + the partial sums of step i + 1 instead of stalling the chip; the compute stream
+    # waits for the sums where it verifies (once per 8 steps, or per step one step late with --verify-per-step).  Same
+    # launches per signature, same results; round 3's form (everything on one stream): --no-exchange-overlap.
     # The exchange stream has HIGH priority (bench.py): at normal priority the all-reduce kernel's workgroups wait for slots behind
     # sign_core's 1024 -- 154 instead of 85 us per step with a one-rank RCCL all-reduce + a 40 us stand-in.
-    # (Measured and dropped: the verification on the exchange stream as well, one event per step instead of two -- beside
-    # sign_core, which saturates the memory system, the verification's latency chain of 4-8 workgroups takes 4-10 times as long:
-    # 127-131 instead of 73-85 us per step, at either stream priority.)
+    # (Measured and dropped: the verification on the exchange stream as well -- beside sign_core, which saturates the memory
+    # system, the verification's latency chain takes 4-10 times as long: 127-131 instead of 73-85 us per step, at either priority.)
     cx = ev_part = ev_sum = None
     if overlap:
         cx = e.exchange_ctx           # created with its stream at the start of the process (bench.py: hardware queues go to streams in order)
         ev_part = [e.fusion_hip.Event(ctx) for _ in range(NSETS)]
         ev_sum = [e.fusion_hip.Event(ctx) for _ in range(NSETS)]
 
+    def part_of(i):
+        base = (i % nbuf) * GROUPS * rec
+        return pool[base:base + GROUPS * rec]
+
     def sv_compute(i):
-        s_, part = sets[i % NSETS], parts[i % len(parts)]
+        s_, part = sets[i % NSETS], part_of(i)
         ctx.sign_core_dev(s_["sk_hat"].data_ptr(), s_["c_hat"].data_ptr(), s_["sig"].data_ptr(), S, l)
         # aggregate partials and the verification target's partials: one pass over this rank's signers, one launch
         ctx.aggregate_target_partial_batch_dev(s_["sig"].data_ptr(), s_["al_hat"].data_ptr(), s_["vkL"].data_ptr(),
-                                               s_["vkR"].data_ptr(), s_["c_hat"].data_ptr(), part.data_ptr(), l * d,
-                                               part[GROUPS * l * d:].data_ptr(), d, GROUPS, per, l)
+                                               s_["vkR"].data_ptr(), s_["c_hat"].data_ptr(), part.data_ptr(), rec,
+                                               part[l * d:].data_ptr(), rec, GROUPS, per, l)
 
     def sv_exchange(i):              # the ONE exchange step (RCCL over xGMI)
-        part = parts[i % len(parts)]
+        part = part_of(i)
         if overlap:
             ev_part[i % NSETS].record(ctx)
             ev_part[i % NSETS].wait(cx)
@@ -105,33 +119,50 @@ def sign_verify(e):
         else:
             e.allreduce_sum_i64(part)
 
-    def sv_verify(i):
-        part = parts[i % len(parts)]
+    def verify_records(first, count):      # verdicts straight from the int64 sums, left on the device: no host synchronisation
+        if count > 0:
+            ctx.verify_partials_batch_async_dev(A.data_ptr(), pool[first * rec:].data_ptr(), rec, pool[first * rec + l * d:].data_ptr(), rec,
+                                                count, l, P["beta_vf"], d, d_verd[first:].data_ptr())
+
+    def sv_verify(i):                # per-step form
         if overlap:
             ev_sum[i % NSETS].wait(ctx)
-        if g_hi > g_lo:          # verdicts straight from the int64 sums, left on the device: no host synchronisation
-            ctx.verify_partials_batch_async_dev(
-                A.data_ptr(), part[g_lo * l * d:].data_ptr(), l * d, part[GROUPS * l * d + g_lo * d:].data_ptr(), d,
-                g_hi - g_lo, l, P["beta_vf"], d, d_verds[i % len(parts)].data_ptr())
+        verify_records((i % nbuf) * GROUPS + g_lo, g_hi - g_lo)
 
-    def sv_steps_once():             # NSETS steps; with the overlap, verification trails the kernels by one step
+    def sv_steps_once():             # NSETS steps
         for i in range(NSETS):
             sv_compute(i)
             sv_exchange(i)
+            if batched:
+                continue
             if not overlap:
                 sv_verify(i)
-            elif i > 0:
+            elif i > 0:              # with the overlap the per-step verification trails the kernels by one step
                 sv_verify(i - 1)
-        if overlap:
+        if batched:
+            if overlap:
+                ev_sum[NSETS - 1].wait(ctx)         # the exchange stream is in order: the last sums arrive last
+            if world == 1:
+                verify_records(0, NSETS * GROUPS)
+            else:
+                for s_ in my_sets:
+                    verify_records(s_ * GROUPS, GROUPS)
+        elif overlap:
             sv_verify(NSETS - 1)
 
+    def my_records():
+        if batched:
+            return [s_ * GROUPS + g_ for s_ in my_sets for g_ in range(GROUPS)]
+        return [b_ * GROUPS + g_ for b_ in range(nbuf) for g_ in range(g_lo, g_hi)]
+
     def verdicts_ok():
-        return g_hi == g_lo or all(v == 0 for dv in d_verds for v in dv.tolist())
+        v = d_verd.tolist()
+        return all(v[k] == 0 for k in my_records())
 
     sv_steps_once()
     e.barrier()
     torch.cuda.synchronize(dev)
-    assert verdicts_ok(), f"verify verdicts {[dv.tolist() for dv in d_verds]}"
+    assert verdicts_ok(), f"verify verdicts {d_verd.tolist()}"
     # one graph = NSETS steps (every set once); refused together if any rank cannot capture (e.g. the collective)
     sv_graph, captured = None, 0.0
     if not args.no_graph and (world == 1 or comm is not None):      # (a stand-in delay is a kernel: capturable)
@@ -182,10 +213,11 @@ def sign_verify(e):
           "exchange": ("on a second stream, overlapping the next step's kernels (fz_event_*)" if overlap else
                        "on the compute stream" if (comm is not None or standin) else "none" if world == 1 else "torch.distributed, host-ordered"),
           "exchange_standin_us": standin or None,
+          "verification": "one launch per 8 steps" if batched else "one launch per step",
           "algorithmic_GB/s_per_gpu": sv_bytes * sv_steps / dt / 1e9,
           "hbm_frac_per_gpu": sv_bytes * sv_steps / dt / 1e9 / e.HBM_PEAK_GBS,
           "note": "algebra cores only: sign_core, aggregate + target partials (one pass, one launch), int64 all-reduce, "
-                  "verification from the int64 sums -- 3 kernel launches (+ the collective) per step; every step works on "
+                  "verification from the int64 sums (ONE launch for the aggregates of all 8 steps unless --verify-per-step); every step works on "
                   "the next of 8 operand sets (2.1 GB), so keys and signatures come from HBM; host hashing of str(vk) excluded"}
     sv_graph_used = sv_graph is not None
     if sv_graph is not None:
@@ -220,7 +252,7 @@ def sign_verify(e):
                                  "sk_hat keygen has just written (174 MB: part of it may still sit in the Infinity Cache), "
                                  "coefficients come from HBM (8 sets rotated)"}
     if world > 1:            # what EVERY rank did in this leg, as the ranks themselves report it
-        mine = {"rank": rank, "collective": collective, "aggregates_verified": int(g_hi - g_lo), "verdicts_ok": True,
+        mine = {"rank": rank, "collective": collective, "aggregates_verified": len(my_records()), "verdicts_ok": True,
                 "graph": sv_graph_used}
         allr = [None] * world
         dist.all_gather_object(allr, mine)

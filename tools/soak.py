@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak of every kernel against the CPU oracle: random batch sizes, both NTT schedules, both degrees,
-fused and multi-launch paths, two contexts on two streams interleaved, repeated verify launches (re-armed
+fused and multi-launch paths, two contexts on two streams interleaved and ordered by events, repeated verify launches (re-armed
 accumulators), graph replays.  usage: soak.py [seconds] [seed]   (needs an MI355X; prints a progress line per minute)"""
 import os
 import sys
@@ -77,6 +77,17 @@ while time.time() < t_end:
             other.ntt_inverse_dev(ex.ptr, ey.ptr, rows)
             ctx.ntt_inverse_dev(dy.ptr, dz.ptr, rows)
         f = orc.ntt_forward(x, q, root).reshape(rows, d)
+        if other is not ctx and rng.random() < 0.5:
+            # ... and a dependency ACROSS the two streams (fz_event_*): the other context inverts what this one has just produced
+            ew, ev = DB(other, x.nbytes), fusion_hip.Event(ctx)
+            ctx.ntt_forward_dev(dx.ptr, dy.ptr, rows)
+            ev.record(ctx)
+            ev.wait(other)
+            other.ntt_inverse_dev(dy.ptr, ew.ptr, rows)
+            assert np.array_equal(ew.to_numpy(np.int32, (rows, d)), orc.ntt_inverse(f, q, inv).reshape(rows, d)), ("event", sp, kern, rows)
+            ctx.synchronize()
+            ew.free()
+            ev.destroy()
         assert np.array_equal(dy.to_numpy(np.int32, (rows, d)), f), ("fwd", sp, kern, rows, raw)
         assert np.array_equal(ey.to_numpy(np.int32, (rows, d)), orc.ntt_inverse(x, q, inv).reshape(rows, d)), ("inv", sp, rows, raw)
         assert np.array_equal(dz.to_numpy(np.int32, (rows, d)), orc.ntt_inverse(f, q, inv).reshape(rows, d)), ("inv(fwd)", sp, kern, rows)

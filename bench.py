@@ -63,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--exchange-standin-us", type=int, default=0,
                     help="N = 1 only: a one-wave kernel of this duration in place of the multi-GPU all-reduce in sign_verify "
                          "(fz_diag_delay): what the second stream hides of an exchange step of known latency")
+    ap.add_argument("--sign-then-aggregate", action="store_true",
+                    help="sign_verify: fz_sign_core, then fz_aggregate_target_partial_batch (round 3's two launches) instead of the one pass")
     ap.add_argument("--verify-per-step", action="store_true",
                     help="sign_verify: one verification launch per step (round 3's form) instead of one per 8 steps")
     ap.add_argument("--no-exchange-overlap", action="store_true",
@@ -138,7 +140,7 @@ def compact_line(full):
     out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample"), 5) if isinstance(cb, dict) else None
     if isinstance(cb, dict) and isinstance(cb.get("sample"), str):
         out["cpu_baseline"]["sample"] = cb["sample"][:160]
-    for name, keys in (("sign_verify", ("value", "unit", "ms_per_step", "hbm_frac_per_gpu", "aggregates", "signers_per_aggregate",
+    for name, keys in (("sign_verify", ("value", "unit", "ms_per_step", "hbm_frac_per_gpu", "moved_frac_per_gpu", "aggregates", "signers_per_aggregate",
                                         "collective", "cpu_value", "error")),
                        ("keygen_sign", ("value", "unit", "ms_per_step", "hbm_frac_per_gpu", "cpu_value", "error")),
                        ("single_stream", ("value", "unit", "ms_per_step", "frac")),

@@ -1000,6 +1000,31 @@ int fz_aggregate_target_partial_batch(fz_ctx *ctx, const int32_t *d_sig, const i
                                d_target_partial, target_stride);
 }
 
+int fz_sign_aggregate_target_partial_batch(fz_ctx *ctx, const int32_t *d_sk_hat, const int32_t *d_c_hat, const int32_t *d_alpha_hat,
+                                           const int32_t *d_vkL, const int32_t *d_vkR, int32_t *d_sig, int64_t *d_partial,
+                                           size_t partial_stride, int64_t *d_target_partial, size_t target_stride, size_t groups,
+                                           size_t N, int l) {
+    FZ_REQUIRE(ctx && l >= 1 && d_partial, "bad argument");
+    FZ_DEV(ctx);
+    FZ_REQUIRE((d_vkL != nullptr) == (d_vkR != nullptr) && (d_vkL != nullptr) == (d_target_partial != nullptr),
+               "verification keys and the target's partials come together or not at all");
+    FZ_REQUIRE(N == 0 || groups == 0 || (d_sk_hat && d_c_hat && d_alpha_hat && d_sig), "NULL argument");
+    FZ_REQUIRE(N < ((size_t)1 << 21), "N=%zu too large for exact int64/fp64 accumulation (< 2^21)", N);
+    FZ_REQUIRE(groups <= 65535 && (groups <= 1 || (partial_stride >= (size_t)l * ctx->degree && (!d_vkL || target_stride >= (size_t)ctx->degree))),
+               "bad groups / strides");
+    if (N == 0 || groups == 0) return FZ_OK;
+    const int d = ctx->degree;
+    const uintptr_t align = (uintptr_t)d_sk_hat | (uintptr_t)d_c_hat | (uintptr_t)d_alpha_hat | (uintptr_t)d_vkL | (uintptr_t)d_vkR | (uintptr_t)d_sig;
+    if (!ctx->knob_unfused && d % 4 == 0 && (d & (d - 1)) == 0 && d <= 256 && (align & 15) == 0)
+        // one launch: sigma is written as it is computed and aggregated from registers (aggregate_onepass<.., SIGN>)
+        return fz_launch_aggregate(ctx, nullptr, d_alpha_hat, d_partial, partial_stride, nullptr, groups, N, l, d_vkL, d_vkR, d_c_hat,
+                                   d_target_partial, target_stride, nullptr, d_sk_hat, d_sig);
+    // any other degree or alignment (and FZ_UNFUSED=1): the two launches this call stands for
+    FZ_TRY(fz_launch_sign(ctx, d_sk_hat, d_c_hat, d_sig, groups * N, l));
+    return fz_launch_aggregate(ctx, d_sig, d_alpha_hat, d_partial, partial_stride, nullptr, groups, N, l, d_vkL, d_vkR, d_c_hat,
+                               d_target_partial, target_stride);
+}
+
 int fz_aggregate_partial(fz_ctx *ctx, const int32_t *d_sig, const int32_t *d_alpha_hat, int64_t *d_partial,
                          size_t N, int l) {
     return fz_aggregate_partial_batch(ctx, d_sig, d_alpha_hat, d_partial, 0, 1, N, l);

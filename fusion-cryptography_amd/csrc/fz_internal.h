@@ -186,7 +186,7 @@ int fz_launch_sign(fz_ctx *ctx, const int32_t *sk_hat, const int32_t *c_hat, int
 int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *out64, size_t pstride,
                         int32_t *out32, size_t groups, size_t N, int l, const int32_t *vkL = nullptr,
                         const int32_t *vkR = nullptr, const int32_t *c = nullptr, int64_t *tout64 = nullptr, size_t tstride = 0,
-                        const size_t *h_offsets = nullptr);
+                        const size_t *h_offsets = nullptr, const int32_t *sk_hat = nullptr, int32_t *sig_out = nullptr);
 int fz_launch_target_partial(fz_ctx *ctx, const int32_t *vkL, const int32_t *vkR, const int32_t *c, const int32_t *alpha,
                              int64_t *partial, size_t pstride, size_t groups, size_t N);
 int fz_launch_reduce_i64(fz_ctx *ctx, const int64_t *in, int32_t *out, size_t count);

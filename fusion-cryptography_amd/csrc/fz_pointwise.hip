@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void sign_scalar_kernel(const int32_t *sk_h
 // Workgroup -> XCD placement (speed only): workgroups b and b + 8 share an XCD, so all column blocks of one
 // (aggregate, slice) pair get block ids equal mod 8 and each alpha row is fetched into ONE L2.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kAggR = 4;          // int4 columns per lane
+constexpr int kAggR = 4;          // int4 columns per lane (the default; 3 and 2 are instantiated too: the launcher picks what fills the chip)
 constexpr int kAggDepth = 3;      // signers in flight per wave
 constexpr int kAggFold = 16;      // signers between folds: 16 * 2^31 * 2^16 = 2^51 < 2^53
 constexpr int kAggTile = 64 * kAggR * 4;   // coefficients per workgroup (1024)
@@ -300,15 +300,23 @@ struct AggDiv {                   // host-side arithmetic of the tile mapping (s
 // RAG = FzNoRag: `groups` aggregates of N signers each, aggregate g's rows at g * N; RAG = FzRagged: aggregates of DIFFERENT
 // sizes in one launch (fz_aggregate_*_ragged: many independent aggregate() calls, fusion.py:655, batched) -- aggregate g's
 // signers are rows [off[g], off[g+1]) of the concatenated arrays, its slices from the table's base / extra
+// SIGN (round 4): the signatures do not exist yet -- sigma_i = L_i * c_i + R_i (fusion.py:557) is computed from the secret key
+// rows (sk_hat [N][2][l][degree]) and the challenge c [N][degree] as the signer comes up, written to sig_out, and aggregated
+// from registers: what sign_core + this kernel read and write in two launches ((3l + 1) + (l + 1) rows per signature) becomes
+// 3l + 2 rows in one -- the l rows of sigma are never read back.  Two signers in flight per wave instead of three (the key
+// halves are two loads per column instead of one).
 struct FzNoRag {};
-template <int WAVES, typename RAG>
+template <int WAVES, typename RAG, bool SIGN = false, int AR = kAggR>
 __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
                                                                 const int32_t *vkR, const int32_t *c, size_t N, int l, int d4,
                                                                 int ncb_a, int ncb, int nsl, int pairs, AggDiv dv,
                                                                 unsigned long long *accum, int64_t *out64, size_t pstride,
-                                                                int64_t *tout64, size_t tstride, int32_t *out32, FzMod m, RAG rag) {
+                                                                int64_t *tout64, size_t tstride, int32_t *out32, FzMod m, RAG rag,
+                                                                const int32_t *sk_hat = nullptr, int32_t *sig_out = nullptr) {
     constexpr bool RAGGED = !__is_same(RAG, FzNoRag);
-    __shared__ __attribute__((aligned(16))) double red[WAVES * kAggTile];      // 64 KiB at 8 waves
+    constexpr int DEPTH = SIGN ? 2 : kAggDepth;
+    constexpr int TILE = 64 * AR * 4;                 // coefficients per workgroup: AR int4 columns per lane (1024 at AR = 4)
+    __shared__ __attribute__((aligned(16))) double red[WAVES * TILE];      // 64 KiB at 8 waves
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
     // block id -> tile t = p * ncb + cb (p = g * nsl + sb: the (aggregate, slice) pair, cb the column block).  Workgroups
     // b and b + 8 share an XCD, so XCD x = b % 8 gets the CONTIGUOUS run of tiles [x * per_xcd, (x + 1) * per_xcd): equal
@@ -336,43 +344,58 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
     const size_t cols_a = (size_t)l * d4;
     const int4 *alpha4 = reinterpret_cast<const int4 *>(alpha) + first_row * (size_t)d4;
 
-    double lo[kAggR][4];
+    double lo[AR][4];
 #pragma unroll
-    for (int r = 0; r < kAggR; ++r)
+    for (int r = 0; r < AR; ++r)
 #pragma unroll
         for (int k = 0; k < 4; ++k) lo[r][k] = 0.0;
 
     if (!tgt) {
-        double hi[kAggR][4];
+        double hi[AR][4];
 #pragma unroll
-        for (int r = 0; r < kAggR; ++r)
+        for (int r = 0; r < AR; ++r)
 #pragma unroll
             for (int k = 0; k < 4; ++k) hi[r][k] = 0.0;
         const int j4 = lane & (d4 - 1);                   // d4 (a power of two) divides 64: the same position for the lane's four columns
-        size_t col[kAggR];
+        size_t col[AR];
 #pragma unroll
-        for (int r = 0; r < kAggR; ++r) {
-            const size_t cr = (size_t)cb * (64 * kAggR) + (size_t)r * 64 + lane;
+        for (int r = 0; r < AR; ++r) {
+            const size_t cr = (size_t)cb * (64 * AR) + (size_t)r * 64 + lane;
             col[r] = cr < cols_a ? cr : cols_a - 1;       // clamped lanes compute garbage that is never written
         }
         const int4 *sig4 = reinterpret_cast<const int4 *>(sig) + first_row * cols_a;
-        // kAggDepth signers in flight per wave (5 loads of 16 bytes per lane each): a wave's signers are a SEQUENTIAL
+        const int4 *sk4 = reinterpret_cast<const int4 *>(sk_hat) + first_row * 2 * cols_a;        // SIGN: [signer][L | R][l * d4]
+        const int4 *c4 = reinterpret_cast<const int4 *>(c) + first_row * (size_t)d4;
+        int4 *so4 = reinterpret_cast<int4 *>(sig_out) + first_row * cols_a;
+        bool live[AR];                                 // SIGN: this lane's column exists (a clamped lane must not store)
+#pragma unroll
+        for (int r = 0; r < AR; ++r) live[r] = (size_t)cb * (64 * AR) + (size_t)r * 64 + lane < cols_a;
+        // DEPTH signers in flight per wave (5 loads of 16 bytes per lane each; 10 with SIGN): a wave's signers are a SEQUENTIAL
         // chain of memory latencies otherwise (first version, one signer ahead: N = 1024 took 29 us, 11 signers per wave
         // at ~2 us each)
-        int4 a_q[kAggDepth], x_q[kAggDepth][kAggR];
+        int4 a_q[DEPTH], x_q[DEPTH][AR], c_q[SIGN ? DEPTH : 1], r_q[SIGN ? DEPTH : 1][AR];
         auto load = [&](int s, size_t i) {
             a_q[s] = alpha4[i * d4 + j4];
+            if constexpr (SIGN) {
+                c_q[s] = c4[i * d4 + j4];
 #pragma unroll
-            for (int r = 0; r < kAggR; ++r) x_q[s][r] = sig4[i * cols_a + col[r]];
+                for (int r = 0; r < AR; ++r) {
+                    x_q[s][r] = sk4[i * 2 * cols_a + col[r]];                  // L
+                    r_q[s][r] = sk4[(i * 2 + 1) * cols_a + col[r]];            // R
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < AR; ++r) x_q[s][r] = sig4[i * cols_a + col[r]];
+            }
         };
         const size_t first = i0 + wave;
 #pragma unroll
-        for (int s = 0; s < kAggDepth; ++s)
+        for (int s = 0; s < DEPTH; ++s)
             if (first + (size_t)s * WAVES < i1) load(s, first + (size_t)s * WAVES);       // wave-uniform
         int since = 0;
-        for (size_t i = first; i < i1; i += (size_t)kAggDepth * WAVES) {
+        for (size_t i = first; i < i1; i += (size_t)DEPTH * WAVES) {
 #pragma unroll
-            for (int s = 0; s < kAggDepth; ++s) {
+            for (int s = 0; s < DEPTH; ++s) {
                 const size_t is = i + (size_t)s * WAVES;
                 if (is >= i1) break;
                 const int av[4] = {a_q[s].x, a_q[s].y, a_q[s].z, a_q[s].w};
@@ -383,20 +406,31 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
                     al[k] = (double)(av[k] & 0xffff);
                 }
 #pragma unroll
-                for (int r = 0; r < kAggR; ++r) {
-                    const double xv[4] = {(double)x_q[s][r].x, (double)x_q[s][r].y, (double)x_q[s][r].z, (double)x_q[s][r].w};
+                for (int r = 0; r < AR; ++r) {
+                    double xv[4] = {(double)x_q[s][r].x, (double)x_q[s][r].y, (double)x_q[s][r].z, (double)x_q[s][r].w};
+                    if constexpr (SIGN) {                 // sigma = cent(cent(L * c) + R), exactly sign_kernel's arithmetic
+                        const double cv[4] = {(double)c_q[s].x, (double)c_q[s].y, (double)c_q[s].z, (double)c_q[s].w};
+                        const double rv[4] = {(double)r_q[s][r].x, (double)r_q[s][r].y, (double)r_q[s][r].z, (double)r_q[s][r].w};
+                        int sv[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            sv[k] = cent_i32(fz_mulmod(xv[k], cv[k], m) + rv[k], m);
+                            xv[k] = (double)sv[k];
+                        }
+                        if (live[r]) so4[is * cols_a + col[r]] = make_int4(sv[0], sv[1], sv[2], sv[3]);
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         hi[r][k] = __builtin_fma(xv[k], ah[k], hi[r][k]);
                         lo[r][k] = __builtin_fma(xv[k], al[k], lo[r][k]);
                     }
                 }
-                const size_t in = is + (size_t)kAggDepth * WAVES;
-                if (in < i1) load(s, in);                 // refill this slot: the loads stay kAggDepth signers ahead
+                const size_t in = is + (size_t)DEPTH * WAVES;
+                if (in < i1) load(s, in);                 // refill this slot: the loads stay DEPTH signers ahead
                 if (++since == kAggFold) {
                     since = 0;
 #pragma unroll
-                    for (int r = 0; r < kAggR; ++r)
+                    for (int r = 0; r < AR; ++r)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             lo[r][k] = fz_fold(lo[r][k], m) + fz_fold(hi[r][k] * 65536.0, m);
@@ -406,7 +440,7 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
             }
         }
 #pragma unroll
-        for (int r = 0; r < kAggR; ++r)
+        for (int r = 0; r < AR; ++r)
 #pragma unroll
             for (int k = 0; k < 4; ++k) lo[r][k] = fz_fold(lo[r][k], m) + fz_fold(hi[r][k] * 65536.0, m);
     } else {
@@ -429,25 +463,27 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
 
     // the WAVES partials meet in LDS: element e of the tile = coefficient cb * 1024 + e of the aggregate
     {
-        double *mine = red + wave * kAggTile + lane * 4;
+        double *mine = red + wave * TILE + lane * 4;
 #pragma unroll
-        for (int r = 0; r < kAggR; ++r) {
+        for (int r = 0; r < AR; ++r) {
             *reinterpret_cast<double2 *>(mine + r * 256) = make_double2(lo[r][0], lo[r][1]);
             *reinterpret_cast<double2 *>(mine + r * 256 + 2) = make_double2(lo[r][2], lo[r][3]);
         }
     }
     __syncthreads();
-    constexpr int PER = kAggTile / (64 * WAVES);          // elements per thread in the combine steps
+    constexpr int PER = (TILE + 64 * WAVES - 1) / (64 * WAVES);          // elements per thread in the combine steps (AR = 3: the last half is idle)
     const size_t limit = tgt ? (size_t)d4 * 4 : cols_a * 4;
-    const size_t k0 = tgt ? (size_t)(cb - ncb_a) * 256 : (size_t)cb * kAggTile;
-    const int span = tgt ? 256 : kAggTile;
+    const size_t k0 = tgt ? (size_t)(cb - ncb_a) * 256 : (size_t)cb * TILE;
+    const int span = tgt ? 256 : TILE;
     double sum[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int e = threadIdx.x + u * 64 * WAVES;
         double s = 0.0;
+        if (e < TILE) {
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) s += red[w * kAggTile + e];
+            for (int w = 0; w < WAVES; ++w) s += red[w * TILE + e];
+        }
         sum[u] = s;
     }
     auto emit = [&](int e, long long v) {
@@ -472,7 +508,7 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
     // re-arms the word for the next launch by subtracting what it read.  No ticket, no barrier, no read-back pass:
     // the tail of the kernel is one atomic round trip (the first version -- fp64 adds, a ticket per tile, the last
     // workgroup swapping the sums out -- spent three: 8 us of fixed cost per launch, of which this removes ~2.5).
-    unsigned long long *acc = accum + (g * (size_t)ncb + (size_t)cb) * kAggTile;
+    unsigned long long *acc = accum + (g * (size_t)ncb + (size_t)cb) * TILE;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int e = threadIdx.x + u * 64 * WAVES;
@@ -881,23 +917,26 @@ static unsigned split_count(fz_ctx *ctx, size_t N, unsigned gx, size_t groups, s
     return (unsigned)want;
 }
 
-template <int WAVES>
+template <int WAVES, int AR>
 static void launch_onepass(fz_ctx *ctx, unsigned grid, const int32_t *sig, const int32_t *alpha, const int32_t *vkL,
                            const int32_t *vkR, const int32_t *c, size_t N, int l, int d4, int ncb_a, int ncb, int nsl, int pairs,
                            unsigned long long *acc, int64_t *out64, size_t pstride, int64_t *tout64, size_t tstride,
-                           int32_t *out32, const FzRagged *rag) {
+                           int32_t *out32, const FzRagged *rag, const int32_t *sk_hat = nullptr, int32_t *sig_out = nullptr) {
     AggDiv dv;
     dv.m_ncb = ncb > 1 ? (unsigned)((0x100000000ull + (unsigned)ncb - 1) / (unsigned)ncb) : 0u;      // unused for a divisor of 1
     dv.m_nsl = nsl > 1 ? (unsigned)((0x100000000ull + (unsigned)nsl - 1) / (unsigned)nsl) : 0u;
     dv.per_xcd = (unsigned)(((size_t)pairs * ncb + 7) / 8);
     dv.base = (unsigned)(N / (size_t)nsl);
     dv.extra = (unsigned)(N % (size_t)nsl);
-    if (rag)
-        hipLaunchKernelGGL((aggregate_onepass<WAVES, FzRagged>), dim3(grid), dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N,
-                           l, d4, ncb_a, ncb, nsl, pairs, dv, acc, out64, pstride, tout64, tstride, out32, ctx->mod, *rag);
+    if (sk_hat)
+        hipLaunchKernelGGL((aggregate_onepass<WAVES, FzNoRag, true, AR>), dim3(grid), dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N,
+                           l, d4, ncb_a, ncb, nsl, pairs, dv, acc, out64, pstride, tout64, tstride, out32, ctx->mod, FzNoRag(), sk_hat, sig_out);
+    else if (rag)
+        hipLaunchKernelGGL((aggregate_onepass<WAVES, FzRagged, false, AR>), dim3(grid), dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N,
+                           l, d4, ncb_a, ncb, nsl, pairs, dv, acc, out64, pstride, tout64, tstride, out32, ctx->mod, *rag, nullptr, nullptr);
     else
-        hipLaunchKernelGGL((aggregate_onepass<WAVES, FzNoRag>), dim3(grid), dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N,
-                           l, d4, ncb_a, ncb, nsl, pairs, dv, acc, out64, pstride, tout64, tstride, out32, ctx->mod, FzNoRag());
+        hipLaunchKernelGGL((aggregate_onepass<WAVES, FzNoRag, false, AR>), dim3(grid), dim3(64 * WAVES), 0, ctx->stream, sig, alpha, vkL, vkR, c, N,
+                           l, d4, ncb_a, ncb, nsl, pairs, dv, acc, out64, pstride, tout64, tstride, out32, ctx->mod, FzNoRag(), nullptr, nullptr);
 }
 
 
@@ -918,13 +957,18 @@ static void launch_direct(fz_ctx *ctx, dim3 grid, const int32_t *sig, const int3
 // vkL != nullptr: the verification target's int64 partial sums go to tout64 + g*tstride in the same launch.
 // h_offsets != nullptr (ragged): aggregate g's signers are rows [h_offsets[g], h_offsets[g+1]) of the arrays, groups <=
 // kFzRaggedMax, N = the largest group; sig == nullptr then means "verification targets only".  One-pass kernel only.
+// sk_hat != nullptr (fused signing, one-pass kernel only): sig is the OUTPUT sig_out, c the signers' challenges (required).
 int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, int64_t *out64, size_t pstride,
                         int32_t *out32, size_t groups, size_t N, int l, const int32_t *vkL, const int32_t *vkR,
-                        const int32_t *c, int64_t *tout64, size_t tstride, const size_t *h_offsets) {
+                        const int32_t *c, int64_t *tout64, size_t tstride, const size_t *h_offsets, const int32_t *sk_hat,
+                        int32_t *sig_out) {
     if (groups == 0) return FZ_OK;
     const int d = ctx->degree;
-    const uintptr_t align = (uintptr_t)sig | (uintptr_t)alpha | (uintptr_t)vkL | (uintptr_t)vkR | (uintptr_t)c;
+    const uintptr_t align = (uintptr_t)sig | (uintptr_t)alpha | (uintptr_t)vkL | (uintptr_t)vkR | (uintptr_t)c | (uintptr_t)sk_hat | (uintptr_t)sig_out;
     const bool vec = (d % 4 == 0) && (align & 15) == 0;
+    if (sk_hat && !(vec && (d & (d - 1)) == 0 && d <= 256 && !h_offsets && c && sig_out))
+        return fz_set_error(FZ_E_UNSUPPORTED, "fused signing + aggregation: power-of-two degree <= 256, 16-byte aligned rows, equal-size aggregates");
+    if (sk_hat) sig = sig_out;                        // "signatures present" for the tile arithmetic below
     if (h_offsets && !(vec && (d & (d - 1)) == 0 && d <= 256 && groups <= (size_t)kFzRaggedMax))
         return fz_set_error(FZ_E_UNSUPPORTED, "ragged aggregation: power-of-two degree <= 256, 16-byte aligned rows, <= %d aggregates per launch", kFzRaggedMax);
     if (vec && (d & (d - 1)) == 0 && d <= 256) {
@@ -937,7 +981,7 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
         // kernel leads (256 x 4 + targets: 20.7 us against 24.6).  FZ_AGG_DIRECT = -1: never; 2 | 4: always, with that many
         // rows per tile (the tests force both forms through every output mode).
         const bool direct_auto = !vkL && N <= 256 && groups * N <= 256;
-        if (d4 >= 16 && ctx->knob_agg_direct >= 0 && (ctx->knob_agg_direct > 0 || direct_auto) && groups <= 65535) {
+        if (!sk_hat && d4 >= 16 && ctx->knob_agg_direct >= 0 && (ctx->knob_agg_direct > 0 || direct_auto) && groups <= 65535) {
             int R = ctx->knob_agg_direct;
             if (R != 2 && R != 4) R = groups == 1 ? 2 : 4;          // rows of a tile share one alpha load; 168 / 84 tiles per aggregate at rank 83
             const int ncg = d4 / 16;
@@ -954,28 +998,40 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
             else launch_direct<16, 2, 5>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ntile_a, out64, pstride, tout64, tstride, out32, rp);
             return fz_check_hip(hipGetLastError(), "aggregate (direct) launch");
         }
-        const int ncb_a = sig ? (int)((cols_a + 64 * kAggR - 1) / (64 * kAggR)) : 0;
-        const int ncb = ncb_a + (vkL ? 1 : 0);                       // d4 <= 64: the target fits one column block
         // slices of the signers per aggregate: as many tiles (column block x aggregate x slice) as the chip holds at once --
-        // one 8-wave workgroup per CU (180 VGPRs: two waves per SIMD) -- so that every CU streams from the first moment
-        // and nothing waits for a second round; at least kAggDepth signers per wave
+        // one 8-wave workgroup per CU (180-220 VGPRs: two waves per SIMD) -- so that every CU streams from the first moment
+        // and nothing waits for a second round (a 257th workgroup costs a third more: 264 tiles 28.1 us against 20.8 for 176);
+        // at least kAggDepth signers per wave.  Rows per column block (AR = 4 | 3 | 2 int4 columns per lane): whichever leaves the
+        // fewest CUs idle -- 4 aggregates of 256 signers + targets are 88 tiles per slice at AR = 4 (2 slices: 176 of 256 CUs)
+        // and 116 at AR = 3 (2 slices: 232).
         constexpr int waves = 8;                       // (4-wave workgroups, two per CU, measured no better at any size: profiles/r03_aggregate_shapes.txt)
-        const size_t blocks_min = (size_t)ncb * groups;
         const size_t capacity = (size_t)ctx->num_cu;
-        size_t nsl = capacity / blocks_min;
-        const size_t most = N / ((size_t)waves * kAggDepth);
-        if (nsl > most) nsl = most;
-        if (nsl < 1) nsl = 1;
-        if (nsl > 512) nsl = 512;                      // the arrival count shares a 64-bit word with the sum (10 bits)
-        if (nsl > N && N > 0) nsl = N;
-        if (N == 0) nsl = 1;
+        int ar = 0, ncb_a = 0, ncb = 0;
+        size_t nsl = 1, best_tiles = 0;
+        for (int cand = kAggR; cand >= 2; --cand) {
+            const int na = sig ? (int)((cols_a + 64 * cand - 1) / (64 * cand)) : 0;
+            const int nb = na + (vkL ? 1 : 0);                       // d4 <= 64: the target fits one column block
+            const size_t blocks_min = (size_t)nb * groups;
+            size_t ns = capacity / blocks_min;
+            const size_t most = N / ((size_t)waves * kAggDepth);
+            if (ns > most) ns = most;
+            if (ns < 1) ns = 1;
+            if (ns > 512) ns = 512;                    // the arrival count shares a 64-bit word with the sum (10 bits)
+            if (ns > N && N > 0) ns = N;
+            if (N == 0) ns = 1;
+            const size_t tiles = blocks_min * ns;
+            // the widest block stands unless a narrower one puts at least 1/16 more workgroups into the ONE round
+            // (launches of more than one round keep the widest block: fewest workgroups)
+            const bool take = ar == 0 || (best_tiles <= capacity && tiles <= capacity && tiles * 16 >= best_tiles * 17);
+            if (take) { ar = cand; ncb_a = na; ncb = nb; nsl = ns; best_tiles = tiles; }
+        }
         const size_t pairs = groups * nsl;
         // the kernel divides tile numbers by ncb and nsl with 32-bit reciprocals: exact while tiles * divisor < 2^32
         if (pairs * (size_t)ncb > 0x3fffffffull || pairs * (size_t)ncb * (size_t)(ncb > (int)nsl ? ncb : (int)nsl) >= 0x100000000ull)
             return fz_set_error(FZ_E_UNSUPPORTED, "aggregate: grid too large (%zu aggregates x %zu slices x %d column blocks)", groups, nsl, ncb);
         unsigned long long *acc = nullptr;
         if (nsl > 1) {
-            int rc = fz_agg_scratch(ctx, groups * (size_t)ncb, (size_t)kAggTile, &acc);
+            int rc = fz_agg_scratch(ctx, groups * (size_t)ncb, (size_t)kAggTile, &acc);       // (sized for the widest tile)
             if (rc != FZ_OK) return rc;
         }
         const unsigned grid = (unsigned)(8 * ((pairs * (size_t)ncb + 7) / 8));
@@ -990,8 +1046,12 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
             rag.off[groups] = (unsigned)h_offsets[groups];
         }
         const FzRagged *rp = h_offsets ? &rag : nullptr;
-        launch_onepass<8>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, out64,
-                              pstride, tout64, tstride, out32, rp);
+#define FZ_ONEPASS(AR_) launch_onepass<8, AR_>(ctx, grid, sig, alpha, vkL, vkR, c, N, l, d4, ncb_a, ncb, (int)nsl, (int)pairs, acc, out64, \
+                                                pstride, tout64, tstride, out32, rp, sk_hat, sig_out)
+        if (ar == 4) FZ_ONEPASS(4);
+        else if (ar == 3) FZ_ONEPASS(3);
+        else FZ_ONEPASS(2);
+#undef FZ_ONEPASS
         const int rc = fz_check_hip(hipGetLastError(), "aggregate launch");
         if (rc != FZ_OK && nsl > 1) ctx->agg_dirty = 1;              // accumulators / tickets may no longer be zero
         return rc;

@@ -93,6 +93,8 @@ SIGNATURES = {
     "fz_aggregate_partial_batch": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_int]),
     "fz_aggregate_target_partial_batch": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                   c_void_p, c_size_t, c_size_t, c_size_t, c_int]),
+    "fz_sign_aggregate_target_partial_batch": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                       c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_int]),
     "fz_verify_partials_batch_async": (c_int, [_ctx, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_int,
                                                c_int64, c_int64, c_void_p]),
     "fz_target_partial_batch": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t]),

@@ -279,6 +279,14 @@ class Context:
             self._h, c_void_p(d_sig), c_void_p(d_alpha), c_void_p(d_vkL), c_void_p(d_vkR), c_void_p(d_c),
             c_void_p(d_partial), partial_stride, c_void_p(d_target_partial), target_stride, groups, N, l))
 
+    def sign_aggregate_target_partial_batch_dev(self, d_sk_hat, d_c, d_alpha, d_vkL, d_vkR, d_sig, d_partial, partial_stride,
+                                                d_target_partial, target_stride, groups, N, l):
+        """sign_core and aggregate_target_partial_batch in ONE pass: sigma is written to d_sig as it is computed and aggregated
+        from registers (d_vkL / d_vkR / d_target_partial: together, or all 0 for the aggregate's sums alone)"""
+        check(self._lib, self._lib.fz_sign_aggregate_target_partial_batch(
+            self._h, c_void_p(d_sk_hat), c_void_p(d_c), c_void_p(d_alpha), c_void_p(d_vkL or None), c_void_p(d_vkR or None),
+            c_void_p(d_sig), c_void_p(d_partial), partial_stride, c_void_p(d_target_partial or None), target_stride, groups, N, l))
+
     def aggregate_core_ragged_dev(self, d_sig, d_alpha, offsets, l, d_out):
         """len(offsets) - 1 aggregates of different sizes in one launch: aggregate g = rows [offsets[g], offsets[g+1]) of the
         concatenated signatures / coefficients; d_out [groups][l][degree] int32 (centred)"""

@@ -255,6 +255,18 @@ FZ_API int fz_aggregate_target_partial_batch(fz_ctx *ctx, const int32_t *d_sig, 
                                              int64_t *d_partial, size_t partial_stride,
                                              int64_t *d_target_partial, size_t target_stride,
                                              size_t groups, size_t N, int l);
+/* sign AND aggregate in one pass (a signing service that also aggregates: the reference's sign(), fusion.py:534-557, called once
+ * per key, then aggregate(), :655-677, and verify()'s target, :706-714): sigma_i = L_i * c_i + R_i is written to d_sig
+ * [groups][N][l][degree] as it is computed and enters the aggregate's int64 partial sums from registers, so the l rows of a
+ * signature are never read back -- (3l + 2) rows of traffic per signature instead of (3l + 1) + (l + 1) for fz_sign_core
+ * followed by fz_aggregate_target_partial_batch, whose results it reproduces exactly.  d_sk_hat [groups][N][2][l][degree],
+ * d_c_hat / d_alpha_hat [groups][N][degree]; d_vkL, d_vkR and d_target_partial are given together (the target's partial sums
+ * in the same launch) or all NULL.  Power-of-two degrees <= 256 with 16-byte aligned rows take the one-launch form; anything
+ * else runs the two launches. */
+FZ_API int fz_sign_aggregate_target_partial_batch(fz_ctx *ctx, const int32_t *d_sk_hat, const int32_t *d_c_hat,
+                                                  const int32_t *d_alpha_hat, const int32_t *d_vkL, const int32_t *d_vkR,
+                                                  int32_t *d_sig, int64_t *d_partial, size_t partial_stride,
+                                                  int64_t *d_target_partial, size_t target_stride, size_t groups, size_t N, int l);
 /* MANY aggregates of DIFFERENT sizes in one launch -- the reference is called once per aggregate (fusion.py:655, :680;
  * benchmarks/benchmarks.py:37-141 loops over them): aggregate g's signers are rows [h_offsets[g], h_offsets[g+1]) of the
  * concatenated arrays d_sig [sum N][l][degree], d_alpha_hat / d_vkL / d_vkR / d_c_hat [sum N][degree]; h_offsets (HOST,

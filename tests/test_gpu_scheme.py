@@ -201,6 +201,68 @@ def test_batched_aggregate_target_verify(coracle):
     assert d_verd.to_numpy(np.int32, (G,)).tolist()[:2] == [0, 3]
 
 
+@pytest.mark.parametrize("secpar,l", [(256, 83), (128, 195), (256, 5)])
+@pytest.mark.parametrize("G,N", [(1, 1), (1, 7), (3, 13), (4, 256), (1, 1000), (2, 40)])
+def test_sign_and_aggregate_in_one_pass_equals_the_two_calls(secpar, l, G, N, coracle, monkeypatch):
+    """fz_sign_aggregate_target_partial_batch (aggregate_onepass<.., SIGN>: sigma written as it is computed, aggregated from
+    registers) == fz_sign_core then fz_aggregate_target_partial_batch: the signatures bit for bit (and == the oracle's,
+    fusion.py:557), the int64 sums as residues and after centring == the oracle's aggregate (fusion.py:670-676); with and
+    without the verification target; record-strided outputs; FZ_UNFUSED=1 runs the two launches behind the same entry."""
+    import fusion_hip
+    P = O.PARAMS[secpar]
+    q, d = P["q"], P["d"]
+    rng = np.random.default_rng(1000 * G + N + l)
+    A = O.splitmix_centered(3, l * d).reshape(l, d)
+    sk = O.splitmix_centered(5, G * N * 2 * l * d).reshape(G * N, 2, l, d)       # any centred rows serve as key halves here
+    c_hat = O.splitmix_centered(6, G * N * d).reshape(G * N, d)
+    al_hat = O.splitmix_centered(7, G * N * d).reshape(G * N, d)
+    vk = O.splitmix_centered(8, G * N * 2 * d).reshape(G * N, 2, d)
+    rec = l * d + d + 8                                   # records [l*d sums | d target sums | padding]: any stride >= the row
+    DB = fusion_hip.DeviceBuffer
+    for env in ({}, {"FZ_UNFUSED": "1"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        d_sk, d_c, d_al = DB.from_numpy(ctx, sk), DB.from_numpy(ctx, c_hat), DB.from_numpy(ctx, al_hat)
+        d_vkL, d_vkR = DB.from_numpy(ctx, np.ascontiguousarray(vk[:, 0])), DB.from_numpy(ctx, np.ascontiguousarray(vk[:, 1]))
+        d_sig_a, d_sig_b = DB(ctx, G * N * l * d * 4), DB(ctx, G * N * l * d * 4)
+        d_pa, d_pb = DB(ctx, G * rec * 8), DB(ctx, G * rec * 8)
+        ctx.h2d(d_pa.ptr, np.full(G * rec, -7, np.int64))
+        ctx.h2d(d_pb.ptr, np.full(G * rec, -7, np.int64))
+        # the two calls
+        ctx.sign_core_dev(d_sk.ptr, d_c.ptr, d_sig_a.ptr, G * N, l)
+        ctx.aggregate_target_partial_batch_dev(d_sig_a.ptr, d_al.ptr, d_vkL.ptr, d_vkR.ptr, d_c.ptr, d_pa.ptr, rec,
+                                               d_pa.ptr + l * d * 8, rec, G, N, l)
+        # the one pass (twice: the accumulator words re-arm themselves)
+        for _ in range(2):
+            ctx.sign_aggregate_target_partial_batch_dev(d_sk.ptr, d_c.ptr, d_al.ptr, d_vkL.ptr, d_vkR.ptr, d_sig_b.ptr, d_pb.ptr, rec,
+                                                        d_pb.ptr + l * d * 8, rec, G, N, l)
+        sig_a, sig_b = d_sig_a.to_numpy(np.int32, (G * N, l, d)), d_sig_b.to_numpy(np.int32, (G * N, l, d))
+        assert np.array_equal(sig_a, sig_b)
+        if not env:
+            assert np.array_equal(sig_b, coracle.sign_core(sk, c_hat, q))
+        pa, pb = d_pa.to_numpy(np.int64, (G, rec)), d_pb.to_numpy(np.int64, (G, rec))
+        half = q // 2
+        assert np.array_equal((pa[:, :l * d + d] + half) % q, (pb[:, :l * d + d] + half) % q)
+        assert np.all(pb[:, l * d + d:] == -7)            # the padding between records is nobody's
+        if not env:
+            for g in range(G):
+                sl = slice(g * N, (g + 1) * N)
+                want = coracle.aggregate_core(sig_b[sl], al_hat[sl], q)
+                assert np.array_equal(((pb[g, :l * d] + half) % q - half).astype(np.int32).reshape(l, d), want)
+        # without the target: the aggregate's sums alone, same values
+        ctx.h2d(d_pb.ptr, np.full(G * rec, -7, np.int64))
+        ctx.sign_aggregate_target_partial_batch_dev(d_sk.ptr, d_c.ptr, d_al.ptr, 0, 0, d_sig_b.ptr, d_pb.ptr, rec, 0, 0, G, N, l)
+        pc = d_pb.to_numpy(np.int64, (G, rec))
+        assert np.array_equal((pc[:, :l * d] + half) % q, (pa[:, :l * d] + half) % q) and np.all(pc[:, l * d:] == -7)
+        assert np.array_equal(d_sig_b.to_numpy(np.int32, (G * N, l, d)), sig_a)
+        for b in (d_sk, d_c, d_al, d_vkL, d_vkR, d_sig_a, d_sig_b, d_pa, d_pb):
+            b.free()
+        ctx.close()
+
+
 @pytest.mark.parametrize("secpar", [128, 256])
 def test_fused_verify_equals_unfused_path(secpar, coracle, monkeypatch):
     """verify_fused (sigma read once) vs the four-kernel path (FZ_UNFUSED=1) vs the oracle, on every

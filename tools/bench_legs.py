@@ -93,13 +93,22 @@ def sign_verify(e):
         base = (i % nbuf) * GROUPS * rec
         return pool[base:base + GROUPS * rec]
 
+    two_launch = args.sign_then_aggregate
+
     def sv_compute(i):
         s_, part = sets[i % NSETS], part_of(i)
-        ctx.sign_core_dev(s_["sk_hat"].data_ptr(), s_["c_hat"].data_ptr(), s_["sig"].data_ptr(), S, l)
-        # aggregate partials and the verification target's partials: one pass over this rank's signers, one launch
-        ctx.aggregate_target_partial_batch_dev(s_["sig"].data_ptr(), s_["al_hat"].data_ptr(), s_["vkL"].data_ptr(),
-                                               s_["vkR"].data_ptr(), s_["c_hat"].data_ptr(), part.data_ptr(), rec,
-                                               part[l * d:].data_ptr(), rec, GROUPS, per, l)
+        if two_launch:               # round 3's form: the signatures are written, then read back by the aggregation
+            ctx.sign_core_dev(s_["sk_hat"].data_ptr(), s_["c_hat"].data_ptr(), s_["sig"].data_ptr(), S, l)
+            # aggregate partials and the verification target's partials: one pass over this rank's signers, one launch
+            ctx.aggregate_target_partial_batch_dev(s_["sig"].data_ptr(), s_["al_hat"].data_ptr(), s_["vkL"].data_ptr(),
+                                                   s_["vkR"].data_ptr(), s_["c_hat"].data_ptr(), part.data_ptr(), rec,
+                                                   part[l * d:].data_ptr(), rec, GROUPS, per, l)
+            return
+        # ONE pass: every signature is written as it is computed and enters its aggregate's sums (and the key pair the target's)
+        # from registers -- fz_sign_aggregate_target_partial_batch
+        ctx.sign_aggregate_target_partial_batch_dev(s_["sk_hat"].data_ptr(), s_["c_hat"].data_ptr(), s_["al_hat"].data_ptr(),
+                                                    s_["vkL"].data_ptr(), s_["vkR"].data_ptr(), s_["sig"].data_ptr(), part.data_ptr(), rec,
+                                                    part[l * d:].data_ptr(), rec, GROUPS, per, l)
 
     def sv_exchange(i):              # the ONE exchange step (RCCL over xGMI)
         part = part_of(i)
@@ -214,9 +223,14 @@ def sign_verify(e):
                        "on the compute stream" if (comm is not None or standin) else "none" if world == 1 else "torch.distributed, host-ordered"),
           "exchange_standin_us": standin or None,
           "verification": "one launch per 8 steps" if batched else "one launch per step",
+          "sign_and_aggregate": "two launches (sign_core, then aggregate + target partials)" if two_launch else
+                                "one launch (fz_sign_aggregate_target_partial_batch: signatures written and aggregated in one pass)",
           "algorithmic_GB/s_per_gpu": sv_bytes * sv_steps / dt / 1e9,
           "hbm_frac_per_gpu": sv_bytes * sv_steps / dt / 1e9 / e.HBM_PEAK_GBS,
-          "note": "algebra cores only: sign_core, aggregate + target partials (one pass, one launch), int64 all-reduce, "
+          # what the launches actually move per signature: in one pass the l rows of a signature are written and never read
+          # back ((3l + 4) rows instead of SURVEY 8d's (3l + 1) + (l + 5) for the two kernels the algorithmic figure counts)
+          "moved_frac_per_gpu": S * ((3 * l + 4) if not two_launch else ((3 * l + 1) + (l + 5))) * 4 * d * sv_steps / dt / 1e9 / e.HBM_PEAK_GBS,
+          "note": "algebra cores only: signing + aggregate and target partials (ONE pass, one launch: fz_sign_aggregate_target_partial_batch), int64 all-reduce, "
                   "verification from the int64 sums (ONE launch for the aggregates of all 8 steps unless --verify-per-step); every step works on "
                   "the next of 8 operand sets (2.1 GB), so keys and signatures come from HBM; host hashing of str(vk) excluded"}
     sv_graph_used = sv_graph is not None

@@ -117,6 +117,16 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
         lambda i, o: ctx.aggregate_target_partial_batch_dev(i, i + sb, i + sb + vb, i + sb + 2 * vb, i + sb + 3 * vb, o, l * d,
                                                             o + G * l * d * 8, d, G, per, l),
         note="one rank's launch of the sign_verify step at world 8")
+    # sign + aggregate + target partials in ONE pass (fz_sign_aggregate_target_partial_batch, round 4): the signatures are written
+    # and never read back -- moved bytes per signature: 2l (key halves) + c + alpha + vkL + vkR read, l written
+    for G, per in ((4, 256), (8, 128)):
+        kb2 = G * per * 2 * l * row
+        vb = G * per * row
+        ob = G * per * l * row
+        run(f"sign+aggregate_onepass+target {G}x{per}", G * per, (3 * l + 4) * row, kb2 + 4 * vb, ob + G * (l + 1) * d * 8,
+            lambda i, o, G=G, per=per, kb2=kb2, vb=vb, ob=ob: ctx.sign_aggregate_target_partial_batch_dev(
+                i, i + kb2, i + kb2 + vb, i + kb2 + 2 * vb, i + kb2 + 3 * vb, o, o + ob, l * d, o + ob + G * l * d * 8, d, G, per, l),
+            note="bytes MOVED per signature ((3l + 4) rows); the two launches it replaces move (3l + 1) + (l + 5)")
     # verify from int32 aggregates (fusion.py:690-727): sig [G][l][d] + target [G][d] -> verdict codes
     for G in (1, 64, 1024, 8192):
         vb = G * l * row

@@ -95,7 +95,12 @@ for k, counters in per.items():
         e["write_bytes"] = e["WRITE_SIZE"] * 1024
         e["traffic_bytes_per_launch"] = e["read_bytes_corrected"] + e["write_bytes"]
         alg = next((v for n, v in SCHEME_BYTES.items() if k.startswith(n)), None)
-        if k.startswith("aggregate_onepass"):
+        if k.startswith("aggregate_onepass") and ", true," in k:
+            # the fused signing form: bytes MOVED per launch (key halves, c, alpha, vkL, vkR read; the signatures written)
+            alg = 1024 * (3 * L_ + 4) * 4 * D_
+            e["signers"] = 1024
+            e["what"] = "sign + aggregate + target sums in one pass, 4 x 256 signers: (3l + 4) rows moved per signature"
+        elif k.startswith("aggregate_onepass"):
             # the larger grid is the N = 1024 launch
             grids = sorted({kk for kk in per if kk.startswith("aggregate_onepass")}, key=lambda kk: int(kk.split("grid=")[1]) if "grid=" in kk else 0)
             n_sign = 1024 if k == grids[-1] else 256

@@ -37,6 +37,10 @@ for name, in_bytes, fn in (
         ("sign", kb + S * row, lambda i, o: ctx.sign_core_dev(i, i + kb, o, S, l)),
         ("aggregate1024", S * (l + 1) * row, lambda i, o: ctx.aggregate_core_dev(i, i + S * l * row, o, S, l)),
         ("aggregate256", 256 * (l + 1) * row, lambda i, o: ctx.aggregate_core_dev(i, i + 256 * l * row, o, 256, l)),
+        # signing + aggregation + target sums in ONE pass, 4 aggregates of 256 (fz_sign_aggregate_target_partial_batch: the bench's step)
+        ("sign+aggregate 4x256", kb + 4 * S * row,
+         lambda i, o: ctx.sign_aggregate_target_partial_batch_dev(i, i + kb, i + kb + S * row, i + kb + 2 * S * row, i + kb + 3 * S * row, o,
+                                                                  o + S * l * row, l * d, o + S * l * row + 4 * l * d * 8, d, 4, 256, l)),
         ("matvec", 2 * S * l * row, lambda i, o: ctx.matvec_dev(A.ptr, i, o, 2 * S, l)),
         ("pw_mul", 2 * S * l * row, lambda i, o: ctx.pw_dev(fusion_hip.OP_MUL, i, i + S * l * row, o, S * l * d)),
         ("verify64", 64 * (l + 1) * row, lambda i, o: ctx.verify_with_target_batch_async_dev(A.ptr, i, i + 64 * l * row, 64, l, P["beta_vf"], d, o))):

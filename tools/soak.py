@@ -318,6 +318,16 @@ while time.time() < t_end:
         agg = ((p[:n_agg] + half) % q - half).astype(np.int32).reshape(G, l, d)
         for g_ in range(G):
             assert np.array_equal(agg[g_], orc.aggregate_core(sig[g_ * n:(g_ + 1) * n], al_hat[g_ * n:(g_ + 1) * n], q)), ("agg", g_)
+        # signing + aggregation + target sums in ONE pass: the same signatures and the same sums (as residues)
+        d_sk, d_sig2, part2 = DB.from_numpy(ctx, sk), DB(ctx, sig.nbytes), DB(ctx, (n_agg + n_t) * 8)
+        ctx.sign_aggregate_target_partial_batch_dev(d_sk.ptr, d_c.ptr, d_al.ptr, d_L.ptr, d_R.ptr, d_sig2.ptr, part2.ptr, l * d,
+                                                    part2.ptr + n_agg * 8, d, G, n, l)
+        assert np.array_equal(d_sig2.to_numpy(np.int32, sig.shape), sig), ("sign+aggregate: signatures", sp, l, n, G)
+        p2 = part2.to_numpy(np.int64, (n_agg + n_t,))
+        if tamper < 0:
+            assert np.array_equal((p2 + half) % q, (p + half) % q), ("sign+aggregate: sums", sp, l, n, G)
+        for b in (d_sk, d_sig2, part2):
+            b.free()
         for b in (d_sig, d_al, d_c, d_L, d_R, d_A, part, verd):
             b.free()
         bump("scheme")

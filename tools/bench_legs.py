@@ -355,10 +355,10 @@ def sweep(e):
         return None
     torch, ctx, d = e.torch, e.ctx, e.d
     out = {}
-    for logb in (16, 18, 20):
+    for logb in (14, 16, 18, 20, 22):                   # SURVEY 8d's sweep B = 2^12 (the headline) ... 2^22 (4 GiB in, 4 GiB out)
         nb = 1 << logb
         x1 = torch.empty((nb, d), dtype=torch.int32, device=e.dev)
-        ctx.fill_synthetic_dev(x1.data_ptr(), nb * d, 7)              # generated on the device (up to 1 GiB)
+        ctx.fill_synthetic_dev(x1.data_ptr(), nb * d, 7)              # generated on the device (up to 4 GiB)
         # cold inputs: cycle through enough (input, output) pairs (>= 2 GiB together) that no launch finds its
         # input in the 256 MB Infinity Cache or an L2 from an earlier repetition
         pairs = max(1, -(-(2 << 30) // (2 * x1.numel() * 4)))
@@ -373,7 +373,7 @@ def sweep(e):
                     fn(ptrs[k % pairs][0], ptrs[k % pairs][1], nb)
                     k += 1
                 torch.cuda.synchronize(e.dev)
-            reps = 10 if logb >= 20 else 100
+            reps = 4 if logb >= 22 else 10 if logb >= 20 else 100
             a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(e.stream)
             for _ in range(reps):

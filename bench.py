@@ -656,7 +656,9 @@ def main():
             en_()
         barrier()
         M = max(1, 1000 // K) if K < 1000 else 1
-        share = [(K // n_c + (1 if j < K % n_c else 0)) * M for j in range(n_c)]      # steps per chain and replay round
+        # steps per chain and replay round: the M x K steps of a round dealt round-robin (step t to chain t % n_c), so the
+        # shares differ by one step at most whatever K is (K = 5 on 4 chains: 250 each, not 400 / 200 / 200 / 200)
+        share = [(M * K) // n_c + (1 if j < (M * K) % n_c else 0) for j in range(n_c)]
         graphs = [[] for _ in cs]
         if not args.no_graph:
             for j, c_ in enumerate(cs):

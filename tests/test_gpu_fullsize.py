@@ -191,6 +191,22 @@ def test_config3_four_aggregates_of_256_like_the_bench(coracle):
         dver = dev.put(np.full(G, -1, np.int32))
         ctx.verify_partials_batch_async_dev(S["dA"].ptr, dpart.ptr, l * d, dtp.ptr, d, G, l, P["beta_vf"], d, dver.ptr)
         assert dver.to_numpy(np.int32, (G,)).tolist() == [0] * G
+        # the bench's step as it runs since round 4: signing + aggregation + target sums in ONE pass into records
+        # [l*d sums | d target sums] per aggregate -- the same signatures, sums equal as residues, the same verdicts
+        rec = l * d + d
+        dsig2, drec = dev.new(G * per * l * d * 4), dev.put(np.full(G * rec, -1, np.int64))
+        ctx.sign_aggregate_target_partial_batch_dev(S["dsk"].ptr, S["dch"].ptr, S["dal"].ptr, S["dvkL"].ptr, S["dvkR"].ptr, dsig2.ptr,
+                                                    drec.ptr, rec, drec.ptr + l * d * 8, rec, G, per, l)
+        assert np.array_equal(dsig2.to_numpy(np.int32, (G * per, l, d)), sig)
+        r = drec.to_numpy(np.int64, (G, rec))
+        assert np.array_equal(_cent(r[:, :l * d].reshape(G, l, d), q), _cent(part, q)) and np.array_equal(_cent(r[:, l * d:], q), _cent(tp, q))
+        ctx.verify_partials_batch_async_dev(S["dA"].ptr, drec.ptr, rec, drec.ptr + l * d * 8, rec, G, l, P["beta_vf"], d, dver.ptr)
+        assert dver.to_numpy(np.int32, (G,)).tolist() == [0] * G
+        bad = r.copy()
+        bad[2, 17] += 1
+        ctx.h2d(drec.ptr, bad)
+        ctx.verify_partials_batch_async_dev(S["dA"].ptr, drec.ptr, rec, drec.ptr + l * d * 8, rec, G, l, P["beta_vf"], d, dver.ptr)
+        assert dver.to_numpy(np.int32, (G,)).tolist() == [0, 0, 3, 0]
     finally:
         dev.close()
 

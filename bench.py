@@ -465,7 +465,11 @@ def main():
     elif args.single_rank_comm:
         # rehearsal on ONE GPU of what an N > 1 run has in its process: a torch.distributed RCCL group that has run collectives
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
+        if "MASTER_PORT" not in os.environ:            # any free port: this is a group of one
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         t_ = torch.ones(4, device=dev)
         dist.all_reduce(t_)

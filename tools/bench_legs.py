@@ -60,13 +60,19 @@ def sign_verify(e):
     # take every aggregate of the 8 steps (below)
     standin = args.exchange_standin_us if world == 1 else 0           # (a delay of known length in place of the all-reduce)
     overlap = (comm is not None or standin > 0) and not args.no_exchange_overlap
-    # The verifications of the 8 steps in ONE launch at the end of the 8 steps (a verification of 4-8 aggregates is a latency
-    # chain of 5 us on 4-8 workgroups; 32 of them are 7 us: 68.7 instead of 72.5 us per step) -- when the exchange does not run
-    # on a second stream.  With it the verification stays per step, one step late: a captured graph whose exchange branch joins
-    # the compute branch only at the end loses the branch's stream priority (161 us per step with a one-rank RCCL all-reduce + a
-    # 40 us stand-in, against 83 per step and 80 launched one by one) -- measured, profiles/ (exchange overlap table).
-    # --verify-per-step: a launch per step over this rank's share of the step's aggregates everywhere (round 3's form).
-    batched = not args.verify_per_step and world <= NSETS and not overlap
+    # How many steps share ONE verification launch (a verification of 4-8 aggregates is a latency chain of 5 us on 4-8
+    # workgroups; 32 of them are 7 us): all 8 when the exchange does not run on a second stream (68.7 instead of 72.5 us per
+    # step with two launches per step).  With the overlap a captured graph whose exchange branch joins the compute branch only
+    # rarely loses the branch's stream priority -- with a one-rank RCCL all-reduce + a 40 us stand-in per step: one launch per
+    # 1 / 2 / 4 / 8 steps 69.8 / 93.5 / 99.9 / 91.7 us per step -- so there the default is one step per launch; a block of
+    # steps is verified behind the NEXT step's kernels (its sums have had a step's time to arrive).  With more than one step per launch rank r verifies every aggregate of the
+    # sets r, r + world, ...; --verify-per-step (= --verify-every 1): a launch per step over this rank's share of the
+    # step's aggregates (round 3's form).
+    vk = 1 if args.verify_per_step else (args.verify_every if args.verify_every > 0 else (1 if overlap else NSETS))
+    vk = max(1, min(vk, NSETS))
+    if world > NSETS:
+        vk = 1
+    batched = vk > 1
     rec = l * d + d
     nbuf = NSETS if (overlap or batched) else 1
     pool = torch.zeros(nbuf * GROUPS * rec, dtype=torch.int64, device=dev)
@@ -133,31 +139,29 @@ def sign_verify(e):
             ctx.verify_partials_batch_async_dev(A.data_ptr(), pool[first * rec:].data_ptr(), rec, pool[first * rec + l * d:].data_ptr(), rec,
                                                 count, l, P["beta_vf"], d, d_verd[first:].data_ptr())
 
-    def sv_verify(i):                # per-step form
+    def sv_verify(lo, hi):           # the steps lo .. hi - 1 (their exchanges have been issued)
         if overlap:
-            ev_sum[i % NSETS].wait(ctx)
-        verify_records((i % nbuf) * GROUPS + g_lo, g_hi - g_lo)
+            ev_sum[(hi - 1) % NSETS].wait(ctx)      # the exchange stream is in order: the last sums of the block arrive last
+        if not batched:
+            verify_records((lo % nbuf) * GROUPS + g_lo, g_hi - g_lo)
+        elif world == 1:
+            verify_records(lo * GROUPS, (hi - lo) * GROUPS)
+        else:
+            for s_ in range(lo, hi):
+                if s_ % world == rank:
+                    verify_records(s_ * GROUPS, GROUPS)
 
     def sv_steps_once():             # NSETS steps
+        done_ = 0
         for i in range(NSETS):
             sv_compute(i)
             sv_exchange(i)
-            if batched:
-                continue
-            if not overlap:
-                sv_verify(i)
-            elif i > 0:              # with the overlap the per-step verification trails the kernels by one step
-                sv_verify(i - 1)
-        if batched:
-            if overlap:
-                ev_sum[NSETS - 1].wait(ctx)         # the exchange stream is in order: the last sums arrive last
-            if world == 1:
-                verify_records(0, NSETS * GROUPS)
-            else:
-                for s_ in my_sets:
-                    verify_records(s_ * GROUPS, GROUPS)
-        elif overlap:
-            sv_verify(NSETS - 1)
+            ready = i if overlap else i + 1          # with the overlap a block is verified behind the NEXT step's kernels
+            if ready - done_ >= vk:
+                sv_verify(done_, ready)
+                done_ = ready
+        if done_ < NSETS:
+            sv_verify(done_, NSETS)
 
     def my_records():
         if batched:
@@ -222,7 +226,7 @@ def sign_verify(e):
           "exchange": ("on a second stream, overlapping the next step's kernels (fz_event_*)" if overlap else
                        "on the compute stream" if (comm is not None or standin) else "none" if world == 1 else "torch.distributed, host-ordered"),
           "exchange_standin_us": standin or None,
-          "verification": "one launch per 8 steps" if batched else "one launch per step",
+          "verification": f"one launch per {vk} steps" if batched else "one launch per step",
           "sign_and_aggregate": "two launches (sign_core, then aggregate + target partials)" if two_launch else
                                 "one launch (fz_sign_aggregate_target_partial_batch: signatures written and aggregated in one pass)",
           "algorithmic_GB/s_per_gpu": sv_bytes * sv_steps / dt / 1e9,

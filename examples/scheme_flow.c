@@ -7,6 +7,7 @@
  *               fz_aggregate_core
  *   verifier    fz_verify_core -> verdict code; a tampered aggregate must be rejected
  *   many aggregates in one launch: fz_aggregate_core_ragged over signer blocks of different sizes (linearity check)
+ *   signing service: fz_sign_aggregate_target_partial_batch (signatures + the aggregate's and the target's sums in one pass)
  *   gcc -std=c99 -Iinclude examples/scheme_flow.c -o scheme_flow -Lfusion-cryptography_amd/lib -lfusion_hip \
  *       -Wl,-rpath,$PWD/fusion-cryptography_amd/lib
  * Exit code 0 = the aggregate verifies and the tampered one does not.  (tests/test_cabi_symbols.py compiles it;
@@ -118,6 +119,28 @@ int main(void) {
                     fprintf(stderr, "ragged aggregation: block sums differ from the aggregate at [%d][%d]\n", k, j);
                     return 4;
                 }
+    }
+    {   /* a service that signs AND aggregates: one pass (fz_sign_aggregate_target_partial_batch) -- the same signatures, and int64
+         * sums of the aggregate and of the verification target from which the verdict comes without a centring pass */
+        static int32_t sig_a[N][L][D], sig_b[N][L][D];
+        void *d_sig2 = NULL, *d_sums = NULL, *d_verd = NULL;
+        int v = -1;
+        CHECK(fz_malloc(ctx, sizeof sig_b, &d_sig2));
+        CHECK(fz_malloc(ctx, (size_t)(L * D + D) * 8, &d_sums));
+        CHECK(fz_malloc(ctx, sizeof v, &d_verd));
+        CHECK(fz_sign_aggregate_target_partial_batch(ctx, (const int32_t *)d_sk, (const int32_t *)d_c, (const int32_t *)d_al,
+                                                     (const int32_t *)d_vkL, (const int32_t *)d_vkR, (int32_t *)d_sig2,
+                                                     (int64_t *)d_sums, (size_t)L * D, (int64_t *)d_sums + (size_t)L * D, D, 1, N, L));
+        CHECK(fz_verify_partials_batch_async(ctx, (const int32_t *)d_A, (const int64_t *)d_sums, (size_t)L * D,
+                                             (const int64_t *)d_sums + (size_t)L * D, D, 1, L, beta_vf, omega_vf, (int *)d_verd));
+        CHECK(fz_memcpy_d2h(ctx, sig_a, d_sig, sizeof sig_a));
+        CHECK(fz_memcpy_d2h(ctx, sig_b, d_sig2, sizeof sig_b));
+        CHECK(fz_memcpy_d2h(ctx, &v, d_verd, sizeof v));
+        CHECK(fz_free(ctx, d_sig2)); CHECK(fz_free(ctx, d_sums)); CHECK(fz_free(ctx, d_verd));
+        if (memcmp(sig_a, sig_b, sizeof sig_a) != 0 || v != FZ_VERDICT_OK) {
+            fprintf(stderr, "one-pass signing + aggregation: signatures differ or verdict %d\n", v);
+            return 5;
+        }
     }
     agg[L - 1][D - 1] += 1;
     CHECK(fz_memcpy_h2d(ctx, d_agg, agg, sizeof agg));

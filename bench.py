@@ -9,21 +9,26 @@ HBM number.  The steps are SOFTWARE-PIPELINED: the forward transform of batch i 
 independent, so they share ONE launch (fz_ntt_multi: a two-job table in the kernel arguments, 4096 forward + 4096 inverse
 transforms = 16 MiB of algorithmic bytes per launch); K steps are K + 1 launches (the first carries only a forward job, the
 last only an inverse one).  `--two-launch` times the un-pipelined form (fz_ntt_forward, then fz_ntt_inverse: two launches of
-8 MiB per step) instead; by default it is the side leg `two_launch_step`.  The K steps (--steps) are recorded into a hipGraph
-(fz_graph_*) and replayed R times inside the timed region, R chosen so that the region lasts >= 20 ms whatever K is.
-`value` = NTTs per second over the whole job (forward and inverse each count, summed over all ranks); `ms_per_step` =
-elapsed / (R * K).  With --gpus N every rank owns its own batches (weak scaling, no data-path collective for the transforms).
+8 MiB per step) instead; by default it is the side leg `two_launch_step`.  Batches are independent, and one 16 MiB launch at a
+time cannot fill the chip, so the steps run as S = 4 CHAINS on 4 HIP streams (--streams; a context + stream each, created before
+anything else in the process, the rotating batches dealt round-robin): four launches in flight, each still one batch.  The K
+steps (--steps) are dealt to the chains, recorded into one hipGraph per chain (fz_graph_*) and replayed R times inside the
+timed region, R chosen so that the region lasts >= 20 ms whatever K is.  `value` = NTTs per second over the whole job (forward
+and inverse each count, all chains, summed over all ranks); `ms_per_step` = elapsed / (R * K).  With --gpus N every rank owns
+its own batches (weak scaling, no data-path collective for the transforms).
 
 Output: the LAST stdout line is ONE compact strict-JSON object (< 4 KB: compact_line()); everything measured, with its
 prose, goes to gpurun_out/bench_full.json.  The compact line carries
-  roofline      ONE fraction for the dominant kernel (the two-job transform launch: 8*d algorithmic bytes per transform x 8192
-                transforms): HIP events on the kernels' stream around the timed region / the launches in it, over the rotating
-                (cold) batches -- the dense graph replay `value` is made of
+  roofline      the dominant kernel (the two-job transform launch: 8*d algorithmic bytes per transform x 8192 transforms), per
+                launch with ONE launch in flight: HIP events around a dense one-stream region of the same steps over the same
+                rotating (cold) batches / the launches in it -- the figure rocprofv3 reproduces (it serialises streams);
+                roofline.chip: the four-stream timed region of `value` itself (bytes of all launches / its duration)
   cpu_baseline  the pure-Python port of the reference's algebra path (oracle/oracle.py py_*), one host core, bounded sample
-  sign_verify / keygen_sign   the metric's second half (algebra cores, sharded over the ranks, ONE int64 all-reduce per step)
+  sign_verify / keygen_sign   the metric's second half (algebra cores, sharded over the ranks, ONE int64 all-reduce per step,
+                on a second stream beside the next step's kernels when there is a communicator)
   warm_replay   the same step re-reading ONE batch (cache-resident): the side number, never `value`
   ranks         per rank: device, PCI bus id, ranks RCCL itself counted in the communicator, RCCL version
-`--full` adds the side legs of tools/bench_legs.py (launch floor, fz_ntt_multi, two streams, PCIe, large-batch sweep, cold
+`--full` adds the side legs of tools/bench_legs.py (launch floor, fz_ntt_multi, PCIe, large-batch sweep, cold
 per-kernel table, end to end through BatchScheme / ShardedScheme) to the full file.
 
 Launch: `python bench.py --gpus N` starts its own N ranks (child processes, before this process has touched a GPU) when

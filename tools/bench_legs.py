@@ -14,9 +14,12 @@ FULL_LEGS = ["copy_floor", "multi_job", "pcie_inclusive", "sweep", "kernels", "e
 # ---- sign + aggregate + verify (algebra cores; synthetic keys/messages) -- every rank ----------------------------------
 def sign_verify(e):
     """per rank: 1024 signatures in GROUPS aggregates of (1024 / GROUPS) x world signers; 8 operand sets (2.1 GB of keys and
-    signatures) rotate so that nothing is cache-resident.  A step = sign_core, aggregate + target partials (ONE launch), the
-    ONE int64 all-reduce (RCCL through the C ABI: fz_allreduce_i64), verification from the int64 sums; the 8 steps are one
-    graph replay.  At least as many aggregates as ranks, so that EVERY rank verifies.
+    signatures) rotate so that nothing is cache-resident.  A step = signing + the aggregates' and the verification targets'
+    int64 partial sums in ONE launch (fz_sign_aggregate_target_partial_batch; --sign-then-aggregate: round 3's two), the ONE
+    int64 all-reduce (RCCL through the C ABI: fz_allreduce_i64, on a second, high-priority stream beside the next step's
+    kernels), verification from the int64 sums (one launch for the aggregates of all 8 steps without a communicator, one per
+    step behind the next step's kernels with one); the 8 steps are one graph replay.  At least as many aggregates as ranks, so
+    that EVERY rank verifies.
     Reference arithmetic: fusion/fusion.py:557 (sign), :670-676 (aggregate), :690-727 (verify), :363-370 (keygen)."""
     torch, np, ctx, dist, dev = e.torch, e.np, e.ctx, e.dist, e.dev
     rank, world, l, d, P, args = e.rank, e.world, e.l, e.d, e.P, e.args

@@ -384,3 +384,27 @@ def test_bench_headline_keeps_its_streams_with_rccl_in_the_process():
     assert d["ranks"][0]["rccl_nranks"] == 1 and d["config"]["streams"] == 4
     one, chip = d["roofline"]["frac"], d["roofline"]["chip"]["frac"]
     assert chip > 1.5 * one, f"four streams reach {chip:.3f} of the peak against {one:.3f} on one: the chains share hardware queues"
+
+
+def test_bench_sign_verify_leg_with_the_exchange_on_its_second_stream():
+    """bench.py's sign_verify leg as an N > 1 run executes it, rehearsed on one GPU: a one-rank RCCL communicator (so the
+    all-reduce is a real RCCL launch inside the captured graph, on the high-priority exchange stream, ordered by fz_event_*) plus
+    a 20 us stand-in for the exchange's latency; the leg asserts every verdict itself.  Its rate must stay within reach of the
+    plain run's (an exchange serialised behind sign_core's workgroups more than doubles the step)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    vals = {}
+    for name, extra in (("plain", []), ("exchange", ["--single-rank-comm", "--exchange-standin-us", "20"])):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--full-out", os.devnull] + extra,
+                           capture_output=True, text=True, timeout=400, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+        sv = d["sign_verify"]
+        assert "error" not in sv and sv["value"] > 0, sv
+        vals[name] = sv["ms_per_step"]
+        if extra:
+            assert "RCCL counts 1 rank" in sv["collective"]
+    assert vals["exchange"] < 1.6 * vals["plain"], vals

@@ -70,6 +70,8 @@ def parse(argv=None):
                          "(fz_diag_delay): what the second stream hides of an exchange step of known latency")
     ap.add_argument("--sign-then-aggregate", action="store_true",
                     help="sign_verify: fz_sign_core, then fz_aggregate_target_partial_batch (round 3's two launches) instead of the one pass")
+    ap.add_argument("--exchange", choices=("auto", "all-reduce", "reduce-scatter"), default="auto",
+                    help="sign_verify: the exchange step's collective (auto: a short calibration picks the reduce-scatter if it is >= 20 %% faster)")
     ap.add_argument("--verify-every", type=int, default=0,
                     help="sign_verify: steps per verification launch (default: 8 without the exchange overlap, 1 with it)")
     ap.add_argument("--verify-per-step", action="store_true",

@@ -1459,6 +1459,7 @@ struct RcclApi {
     int (*CommCount)(void *, int *);
     int (*GetVersion)(int *);
     int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    int (*ReduceScatter)(const void *, void *, size_t, int, int, void *, hipStream_t);
 };
 RcclApi g_rccl = {};
 
@@ -1480,6 +1481,7 @@ int rccl_bind() {
     a.CommCount = (int (*)(void *, int *))dlsym(h, "ncclCommCount");
     a.GetVersion = (int (*)(int *))dlsym(h, "ncclGetVersion");
     a.Broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclBroadcast");
+    a.ReduceScatter = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclReduceScatter");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString)
         return fz_set_error(FZ_E_RCCL, "librccl.so.1 lacks an expected symbol");
     a.handle = h;
@@ -1555,6 +1557,17 @@ int fz_broadcast_i32(fz_ctx *ctx, fz_comm *comm, int32_t *d_buf, size_t count, i
     if (!g_rccl.Broadcast) return fz_set_error(FZ_E_RCCL, "librccl.so.1 lacks ncclBroadcast");
     // in place, ncclInt32 (= 2), on the context's stream like the all-reduce
     return rccl_check(g_rccl.Broadcast(d_buf, d_buf, count, 2, root, comm->comm, ctx->stream), "ncclBroadcast");
+}
+
+int fz_reduce_scatter_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, size_t count_per_rank) {
+    FZ_REQUIRE(ctx && comm && (count_per_rank == 0 || d_buf), "NULL argument");
+    if (comm->device != ctx->device) return fz_set_error(FZ_E_BADARG, "communicator was created on device %d", comm->device);
+    FZ_DEV(ctx);
+    if (count_per_rank == 0) return FZ_OK;
+    if (!g_rccl.ReduceScatter) return fz_set_error(FZ_E_RCCL, "librccl.so.1 lacks ncclReduceScatter");
+    // in place (NCCL's convention: the receive buffer is this rank's block of the send buffer), ncclInt64 (= 4), ncclSum (= 0)
+    return rccl_check(g_rccl.ReduceScatter(d_buf, d_buf + (size_t)comm->rank * count_per_rank, count_per_rank, 4, 0, comm->comm, ctx->stream),
+                      "ncclReduceScatter");
 }
 
 int fz_allreduce_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, size_t count) {

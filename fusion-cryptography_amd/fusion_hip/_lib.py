@@ -168,6 +168,7 @@ SIGNATURES.update({
     "fz_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "fz_rccl_version": (c_int, [POINTER(c_int)]),
     "fz_allreduce_i64": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
+    "fz_reduce_scatter_i64": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
     "fz_broadcast_i32": (c_int, [_ctx, c_void_p, c_void_p, c_size_t, c_int]),
     "fz_diag_empty_launch": (c_int, [_ctx]),
     "fz_diag_copy": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),

@@ -181,6 +181,11 @@ class Context:
         """one wave that occupies this context's stream for `microseconds` (asynchronous, capturable)"""
         check(self._lib, self._lib.fz_diag_delay(self._h, int(microseconds)))
 
+    def reduce_scatter_i64_dev(self, comm, d_buf, count_per_rank):
+        """in-place ncclReduceScatter(int64, sum) on this context's stream: block `rank` of the summed buffer arrives in block
+        `rank` of d_buf (nranks blocks of count_per_rank elements); the other blocks are undefined afterwards"""
+        check(self._lib, self._lib.fz_reduce_scatter_i64(self._h, comm._c, c_void_p(d_buf), count_per_rank))
+
     def allreduce_i64_dev(self, comm, d_buf, count):
         """in-place ncclAllReduce(int64, sum) on this context's stream (comm: a Comm)"""
         check(self._lib, self._lib.fz_allreduce_i64(self._h, comm._c, c_void_p(d_buf), count))

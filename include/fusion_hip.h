@@ -338,6 +338,11 @@ FZ_API int fz_comm_info(fz_comm *comm, int *out_nranks, int *out_rank);
  * multi-GPU record shows which library carried the exchange step */
 FZ_API int fz_rccl_version(int *out_version);
 FZ_API int fz_allreduce_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, size_t count);
+/* the same sums when every rank needs only ITS block of them (a rank verifies only the aggregates it owns, fusion.py:690-727
+ * from the sums of :670-676 and :706-714): ncclReduceScatter(ncclInt64, ncclSum) in place -- d_buf holds nranks blocks of
+ * count_per_rank elements, block r of the summed buffer arrives in block r of rank r's d_buf, the other blocks of d_buf are
+ * left undefined.  Half the traffic and half the steps of the all-reduce.  Asynchronous, capturable, ordered like it. */
+FZ_API int fz_reduce_scatter_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, size_t count_per_rank);
 /* rank `root`'s d_buf [count] int32 to every rank's d_buf (ncclBroadcast, in place, on the context's stream): how the rank
  * that ran hash_ag's serial sponge (fusion.py:632-652) hands the aggregation-coefficient rows to the others
  * (fusion_hip.dist.ShardedScheme, alpha_mode "root") */

@@ -141,6 +141,9 @@ def test_rccl_binding_of_the_c_abi_on_one_rank():
     ctx.allreduce_i64_dev(comm, buf.ptr, v.size)
     ctx.synchronize()
     assert np.array_equal(buf.to_numpy(np.int64, v.shape), v)
+    ctx.reduce_scatter_i64_dev(comm, buf.ptr, v.size)            # one rank: its block is the whole buffer, in place
+    ctx.synchronize()
+    assert np.array_equal(buf.to_numpy(np.int64, v.shape), v)
     # partials -> all-reduce -> verification from the sums, as one replayable graph
     s = ctx.stream_create()
     ctx.set_stream(s)
@@ -165,6 +168,7 @@ def test_rccl_binding_of_the_c_abi_on_one_rank():
         ctx.aggregate_target_partial_batch_dev(dsig.ptr, dal.ptr, dL.ptr, dR.ptr, dch.ptr, dpart.ptr, l * d,
                                                dpart.ptr + l * d * 8, d, 1, n, l)
         ctx.allreduce_i64_dev(comm, dpart.ptr, l * d + d)
+        ctx.reduce_scatter_i64_dev(comm, dpart.ptr, l * d + d)   # (the other form of the exchange, capturable like the first)
         ctx.verify_partials_batch_async_dev(dA.ptr, dpart.ptr, l * d, dpart.ptr + l * d * 8, d, 1, l, 2**40, d, dver.ptr)
     step()
     ctx.synchronize()

@@ -98,6 +98,40 @@ def sign_verify(e):
         ev_part = [e.fusion_hip.Event(ctx) for _ in range(NSETS)]
         ev_sum = [e.fusion_hip.Event(ctx) for _ in range(NSETS)]
 
+    # Which collective: every rank verifies only ITS share of a step's aggregates, so a reduce-scatter (fz_reduce_scatter_i64:
+    # block r of the sums to rank r, half the traffic and steps of the all-reduce) is enough whenever the aggregates divide
+    # evenly over the ranks and verification is per step.  Chosen by a short calibration on the exchange stream -- 20 launches of
+    # each, every rank, max over ranks -- unless --exchange says so; the all-reduce stays unless the other form is >= 20 % faster.
+    use_rs, exch_cal = False, None
+    rs_ok = comm is not None and not batched and GROUPS % world == 0 and (g_hi - g_lo) * world == GROUPS
+    if args.exchange == "reduce-scatter" and not rs_ok:
+        raise RuntimeError("--exchange reduce-scatter needs a communicator, one verification launch per step and aggregates that divide over the ranks")
+    if rs_ok and args.exchange in ("auto", "reduce-scatter"):
+        xc = cx if overlap else ctx
+        cal = torch.zeros(GROUPS * rec, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        times = {}
+        try:
+            for name_, fn_ in (("all-reduce", lambda: xc.allreduce_i64_dev(comm, cal.data_ptr(), cal.numel())),
+                               ("reduce-scatter", lambda: xc.reduce_scatter_i64_dev(comm, cal.data_ptr(), (GROUPS // world) * rec))):
+                for _ in range(5):
+                    fn_()
+                xc.synchronize()
+                e.barrier()
+                t0_ = time.perf_counter()
+                for _ in range(20):
+                    fn_()
+                xc.synchronize()
+                times[name_] = e.max_over_ranks(time.perf_counter() - t0_) / 20 * 1e6
+            ok_ = 1.0
+        except e.fusion_hip.FusionHipError as exc:
+            sys.stderr.write(f"rank {rank}: exchange calibration failed: {exc}\n")
+            ok_ = 0.0
+        if e.min_over_ranks(ok_) >= 1.0:
+            exch_cal = {k_: round(v_, 2) for k_, v_ in times.items()}
+            use_rs = args.exchange == "reduce-scatter" or times["reduce-scatter"] < 0.8 * times["all-reduce"]
+        del cal
+
     def part_of(i):
         base = (i % nbuf) * GROUPS * rec
         return pool[base:base + GROUPS * rec]
@@ -124,13 +158,17 @@ def sign_verify(e):
         if overlap:
             ev_part[i % NSETS].record(ctx)
             ev_part[i % NSETS].wait(cx)
-            if comm is not None:
+            if comm is not None and use_rs:
+                cx.reduce_scatter_i64_dev(comm, part.data_ptr(), (GROUPS // world) * rec)
+            elif comm is not None:
                 cx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
             if standin:
                 cx.diag_delay(standin)
             ev_sum[i % NSETS].record(cx)
         elif comm is not None or standin:
-            if comm is not None:
+            if comm is not None and use_rs:
+                ctx.reduce_scatter_i64_dev(comm, part.data_ptr(), (GROUPS // world) * rec)
+            elif comm is not None:
                 ctx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
             if standin:
                 ctx.diag_delay(standin)
@@ -229,6 +267,8 @@ def sign_verify(e):
           "exchange": ("on a second stream, overlapping the next step's kernels (fz_event_*)" if overlap else
                        "on the compute stream" if (comm is not None or standin) else "none" if world == 1 else "torch.distributed, host-ordered"),
           "exchange_standin_us": standin or None,
+          "exchange_collective": ("ncclReduceScatter (fz_reduce_scatter_i64)" if use_rs else "ncclAllReduce (fz_allreduce_i64)") if comm is not None else None,
+          "exchange_calibration_us": exch_cal,
           "verification": f"one launch per {vk} steps" if batched else "one launch per step",
           "sign_and_aggregate": "two launches (sign_core, then aggregate + target partials)" if two_launch else
                                 "one launch (fz_sign_aggregate_target_partial_batch: signatures written and aggregated in one pass)",

@@ -263,6 +263,49 @@ def test_sign_and_aggregate_in_one_pass_equals_the_two_calls(secpar, l, G, N, co
         ctx.close()
 
 
+def test_sign_and_aggregate_in_one_pass_edges(coracle):
+    """the same entry where the one-launch form does not apply: rows that are not 16-byte aligned and a degree the one-pass
+    kernel does not cover take the two launches behind it (same results); no signers / no aggregates is a no-op"""
+    import fusion_hip
+    q = O.PARAMS[256]["q"]
+    for d in (256, 12):                                # 12: a ring-only context (any degree; scalar kernels)
+        ctx = fusion_hip.Context(q, d, O.PARAMS[256]["root"], O.PARAMS[256]["inv_root"]) if d == 256 else fusion_hip.Context(q, d, 0, 0)
+        G, N, l = 2, 9, 3
+        sk = O.splitmix_centered(15, G * N * 2 * l * d).reshape(G * N, 2, l, d)
+        c_hat = O.splitmix_centered(16, G * N * d).reshape(G * N, d)
+        al = O.splitmix_centered(17, G * N * d).reshape(G * N, d)
+        vk = O.splitmix_centered(18, G * N * 2 * d).reshape(G * N, 2, d)
+        DB = fusion_hip.DeviceBuffer
+        d_sk, d_c, d_al = DB.from_numpy(ctx, sk), DB.from_numpy(ctx, c_hat), DB.from_numpy(ctx, al)
+        d_L, d_R = DB.from_numpy(ctx, np.ascontiguousarray(vk[:, 0])), DB.from_numpy(ctx, np.ascontiguousarray(vk[:, 1]))
+        n_sig = G * N * l * d
+        d_sig = DB(ctx, n_sig * 4 + 16)
+        d_p = DB(ctx, G * (l * d + d) * 8)
+        want = coracle.sign_core(sk, c_hat, q)
+        half = q // 2
+        for off in ((0, 4) if d == 256 else (0,)):          # +4 bytes: the signature rows are no longer 16-byte aligned
+            ctx.sign_aggregate_target_partial_batch_dev(d_sk.ptr, d_c.ptr, d_al.ptr, d_L.ptr, d_R.ptr, d_sig.ptr + off, d_p.ptr, l * d,
+                                                        d_p.ptr + G * l * d * 8, d, G, N, l)
+            got = np.empty(n_sig, np.int32)
+            ctx.d2h(got, d_sig.ptr + off)
+            assert np.array_equal(got.reshape(G * N, l, d), want), (d, off)
+            p = d_p.to_numpy(np.int64, (G * (l * d + d),))
+            for g in range(G):
+                sl = slice(g * N, (g + 1) * N)
+                agg = ((p[g * l * d:(g + 1) * l * d] + half) % q - half).astype(np.int32).reshape(l, d)
+                assert np.array_equal(agg, coracle.aggregate_core(want[sl], al[sl], q)), (d, off, g)
+        ctx.h2d(d_p.ptr, np.full(G * (l * d + d), 5, np.int64))
+        ctx.sign_aggregate_target_partial_batch_dev(d_sk.ptr, d_c.ptr, d_al.ptr, d_L.ptr, d_R.ptr, d_sig.ptr, d_p.ptr, l * d,
+                                                    d_p.ptr + G * l * d * 8, d, G, 0, l)                # no signers
+        ctx.sign_aggregate_target_partial_batch_dev(0, 0, 0, 0, 0, 0, d_p.ptr, l * d, 0, 0, 0, N, l)   # no aggregates
+        assert np.all(d_p.to_numpy(np.int64, (G * (l * d + d),)) == 5)
+        with pytest.raises(fusion_hip.FusionHipError):                                                 # keys without the target's buffer
+            ctx.sign_aggregate_target_partial_batch_dev(d_sk.ptr, d_c.ptr, d_al.ptr, d_L.ptr, d_R.ptr, d_sig.ptr, d_p.ptr, l * d, 0, 0, G, N, l)
+        for b in (d_sk, d_c, d_al, d_L, d_R, d_sig, d_p):
+            b.free()
+        ctx.close()
+
+
 @pytest.mark.parametrize("secpar", [128, 256])
 def test_fused_verify_equals_unfused_path(secpar, coracle, monkeypatch):
     """verify_fused (sigma read once) vs the four-kernel path (FZ_UNFUSED=1) vs the oracle, on every

@@ -55,6 +55,9 @@ cp $OUT/prof/*/*_kernel_stats.csv $OUT/${TAG}_bench_rocprofv3_kernel_stats.csv 2
 # the line bench.py printed IN THAT PROFILED RUN: its roofline.avg_launch_us and the kernel_stats average above are the same
 # launches measured two ways (they agree within ~1 %); the un-profiled line (${TAG}_bench_n1.json) is ~6 % faster
 grep -a '^{"metric"' $OUT/prof.log | tail -1 > $OUT/${TAG}_bench_under_rocprofv3_line.json
+# ... and the whole default run (the scheme legs' kernels as the bench runs them)
+step timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profd -- python3 $R/bench.py --no-cpu-baseline --full-out /dev/null > $OUT/profd.log 2>&1
+cp $OUT/profd/*/*_kernel_stats.csv $OUT/${TAG}_bench_default_rocprofv3_kernel_stats.csv 2>/dev/null
 step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profk -- python3 $R/tools/kernel_table.py > $OUT/profk.log 2>&1
 cp $OUT/profk/*/*_kernel_stats.csv $OUT/${TAG}_kernel_table_rocprofv3_kernel_stats.csv 2>/dev/null
 step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profc -- python3 $R/tools/challenge_bench.py > $OUT/profc.log 2>&1
@@ -72,6 +75,7 @@ step timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ
 cd $R
 python3 tools/pmc_stalls.py $OUT/sq1/*/*counter_collection.csv $OUT/sq2/*/*counter_collection.csv > $OUT/${TAG}_wave_cycles.txt
 python3 tools/trace_summary.py $OUT/prof/*/*_kernel_trace.csv > $OUT/${TAG}_bench_rocprofv3_by_grid.csv 2>/dev/null
+python3 tools/trace_summary.py $OUT/profd/*/*_kernel_trace.csv > $OUT/${TAG}_bench_default_rocprofv3_by_grid.csv 2>/dev/null
 python3 tools/trace_summary.py $OUT/profk/*/*_kernel_trace.csv > $OUT/${TAG}_kernel_table_rocprofv3_by_grid.csv 2>/dev/null
 python3 tools/trace_summary.py $OUT/profc/*/*_kernel_trace.csv > $OUT/${TAG}_challenge_rocprofv3_by_grid.csv 2>/dev/null
 step python3 tools/pmc_summary.py $OUT $TAG > /dev/null

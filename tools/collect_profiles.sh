@@ -17,7 +17,7 @@ step() { echo "[collect] $*" >&2; "$@" || { echo "[collect] FAILED ($?): $*" >&2
 lscpu | grep -E "Model name|Socket|Thread|Core" > $OUT/${TAG}_host_cpu.txt
 # the stand-alone microbenchmarks travel prebuilt (tools/microbench/build/, git-ignored); build whatever is missing
 mkdir -p tools/microbench/build
-for mb in launch_floor ntt_variants ntt_structures; do
+for mb in launch_floor ntt_variants ntt_structures access_pattern; do
   [ -x tools/microbench/build/$mb ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/microbench/$mb.hip -o tools/microbench/build/$mb
 done
 step timeout -k 10 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
@@ -37,6 +37,7 @@ for st in none 0 1; do FZ_NO_PIN=1 timeout -k 10 100 python tools/numa_switch.py
 step timeout -k 10 200 python tools/keccak_bench.py > $OUT/${TAG}_keccak_variants_gpu_host.txt 2>&1
 step timeout -k 10 300 ./tools/microbench/build/ntt_variants 300 > $OUT/${TAG}_ntt_variants_current_kernels.txt 2>&1
 step timeout -k 10 120 ./tools/microbench/build/ntt_structures 200 > $OUT/${TAG}_ntt_structures.txt 2>&1
+step timeout -k 10 120 ./tools/microbench/build/access_pattern 100 > $OUT/${TAG}_access_pattern.txt 2>&1
 step timeout -k 10 200 python tools/clock_under_load.py > $OUT/${TAG}_shader_clock_under_load.txt 2>&1
 step timeout -k 10 200 python tools/clock_under_load.py --secpar 128 >> $OUT/${TAG}_shader_clock_under_load.txt 2>&1
 step timeout -k 10 600 bash tools/matvec_ab.sh > $OUT/${TAG}_matvec_ab_raw.txt 2>&1

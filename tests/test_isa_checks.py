@@ -56,3 +56,32 @@ def test_verify_fused_orders_its_adds_before_the_arrival(asm):
         assert arrive and arrive[0] > adds[-1] + 1 + bar, name
         fences = [s for s in ins if s.startswith(("buffer_wbl2", "buffer_inv"))]
         assert bool(fences) == ordered, (name, fences)
+
+
+def test_aggregate_onepass_instantiations_do_not_spill_and_add_with_returning_atomics(tmp_path_factory):
+    """aggregate_onepass<8, RAG, SIGN, AR>: the nine instantiations the launcher can pick (rows per column block 4 / 3 / 2 x plain /
+    ragged / fused signing) keep their state in registers -- no scratch (a spill in the signer loop would double the launch) --
+    and every cross-workgroup sum is added with a RETURNING 64-bit atomic (the arrival count travels in the word the add returns),
+    paired with the one non-returning add that re-arms the word"""
+    out = tmp_path_factory.mktemp("isa") / "fz_pointwise.s"
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
+                           os.path.join(CSRC, "fz_pointwise.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(\S*aggregate_onepass\S*)\n(.*?)\.wavefront_size", text, re.S):
+        f = dict(re.findall(r"\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", m.group(2)))
+        meta[m.group(1)] = {k: int(v) for k, v in f.items()}
+    assert len(meta) == 9, sorted(meta)
+    for name, f in meta.items():
+        assert f["vgpr_spill_count"] == 0 and f["sgpr_spill_count"] == 0 and f["private_segment_fixed_size"] == 0, (name, f)
+        assert f["vgpr_count"] <= 256, (name, f)                 # two waves per SIMD: one 8-wave workgroup per CU
+    ks = bodies(text, "aggregate_onepass")
+    assert len(ks) == 9
+    for name, ins in ks.items():
+        adds = [s for s in ins if s.startswith("global_atomic_add_x2")]
+        returning = [s for s in adds if " sc0" in s]           # the sum's add: its return value says who arrived last
+        rearm = [s for s in adds if " sc0" not in s]           # the last arrival's subtraction that re-arms the word: result unused
+        assert returning and len(returning) == len(rearm), (name, adds)

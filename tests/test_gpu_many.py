@@ -169,6 +169,16 @@ def test_full_size_flows_equal_the_reference(tag):
     dC, dAl, order, _, _ = bs.hash_ag_dev(vk, m["messages"])
     assert np.array_equal(order, S["order"])                                     # sorted(key=str(vk)) over 1024 keys
     assert sha_i32(dAl.numpy()[order]) == m["sha256_alpha_hat_sorted"]             # hash_ag over 1024 tuples
+    # signing + aggregation in ONE pass over ALL signers (fz_sign_aggregate_target_partial_batch): the reference's signatures by
+    # SHA-256 and the reference's aggregate element by element, from the keys, challenges and coefficients alone
+    from fusion_hip.context import DeviceArray
+    n_, l_, d_, q_ = m["n"], params.num_rows_sk, params.degree, params.modulus
+    sig1, sums = DeviceArray(bs.ctx, (n_, l_, d_)), DeviceArray(bs.ctx, (l_ * d_,), np.int64)
+    bs.ctx.sign_aggregate_target_partial_batch_dev(sk.ptr, dC.ptr, dAl.ptr, 0, 0, sig1.ptr, sums.ptr, l_ * d_, 0, 0, 1, n_, l_)
+    assert sha_i32(sig1.numpy()) == m["sha256_sig"]
+    assert np.array_equal(((sums.numpy() + q_ // 2) % q_ - q_ // 2).astype(np.int32).reshape(l_, d_), S["agg"])
+    sig1.free()
+    sums.free()
     dC.free()
     dAl.free()
     agg = bs.aggregate(vk, m["messages"], sig)

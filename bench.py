@@ -5,31 +5,37 @@ Workload (BASELINE.json configs[1]): secpar=256, batches of 4096 independent deg
 A STEP is one pass of the hot path over one batch: forward NTT of the batch, then inverse NTT of the result (reference
 algebra/ntt.py:216-291 and :294-377).  Consecutive steps work on consecutive batches of a rotation of NBATCH batches
 (x_i -> y_i -> z_i, 768 MiB together), so every forward transform reads its input from HBM, not from a cache: `value` is an
-HBM number.  The steps are SOFTWARE-PIPELINED: the forward transform of batch i + 1 and the inverse transform of batch i are
-independent, so they share ONE launch (fz_ntt_multi: a two-job table in the kernel arguments, 4096 forward + 4096 inverse
-transforms = 16 MiB of algorithmic bytes per launch); K steps are K + 1 launches (the first carries only a forward job, the
-last only an inverse one).  `--two-launch` times the un-pipelined form (fz_ntt_forward, then fz_ntt_inverse: two launches of
-8 MiB per step) instead; by default it is the side leg `two_launch_step`.  Batches are independent, and one 16 MiB launch at a
-time cannot fill the chip, so the steps run as S = 4 CHAINS on 4 HIP streams (--streams; a context + stream each, created before
-anything else in the process, the rotating batches dealt round-robin): four launches in flight, each still one batch.  The K
-steps (--steps) are dealt to the chains, recorded into one hipGraph per chain (fz_graph_*) and replayed R times inside the
-timed region, R chosen so that the region lasts >= 20 ms whatever K is.  `value` = NTTs per second over the whole job (forward
-and inverse each count, all chains, summed over all ranks); `ms_per_step` = elapsed / (R * K).  With --gpus N every rank owns
-its own batches (weak scaling, no data-path collective for the transforms).
+HBM number.  The steps are SOFTWARE-PIPELINED over D batches (--depth, 4): batches are independent, the forward transforms
+of batches i+1 .. i+D and the inverse transforms of batches i-D+1 .. i share ONE launch (fz_ntt_multi: a table of 2 D jobs in
+the kernel arguments = 2 D x 4096 transforms = D x 16 MiB of algorithmic bytes per launch: 64 MiB at D = 4); D steps are one
+launch, a run of steps opens with a forward-only launch and closes with an inverse-only one, and every transform of every
+batch is done exactly once (z == x is checked after every region).  `--depth 1` is round 4's form (one forward + one inverse
+job per launch), `--two-launch` the un-pipelined one (fz_ntt_forward, then fz_ntt_inverse: two launches of 8 MiB per step;
+by default the side leg `two_launch_step`).  The steps run as S CHAINS on S HIP streams (--streams, 2; a context + stream
+each, created before anything else in the process, the rotating batches dealt in contiguous shares): S launches in flight,
+which hides each launch's ramp and drain behind the other's body.  The K steps (--steps) are dealt to the chains, recorded
+into one hipGraph per chain (fz_graph_*) and replayed R times inside the timed region, R chosen so that the region lasts
+>= 20 ms whatever K is.  `value` = NTTs per second over the whole job (forward and inverse each count, all chains, summed
+over all ranks); `ms_per_step` = elapsed / steps timed.  With --gpus N every rank owns its own batches (weak scaling, no
+data-path collective for the transforms).
 
 Output: the LAST stdout line is ONE compact strict-JSON object (< 4 KB: compact_line()); everything measured, with its
 prose, goes to gpurun_out/bench_full.json.  The compact line carries
-  roofline      the dominant kernel (the two-job transform launch: 8*d algorithmic bytes per transform x 8192 transforms), per
-                launch with ONE launch in flight: HIP events around a dense one-stream region of the same steps over the same
-                rotating (cold) batches / the launches in it -- the figure rocprofv3 reproduces (it serialises streams);
-                roofline.chip: the four-stream timed region of `value` itself (bytes of all launches / its duration)
+  roofline      the dominant kernel (the 2 D-job transform launch: 8*d algorithmic bytes per transform), per launch with ONE
+                launch in flight: HIP events around a dense one-stream region of the same steps over the same rotating
+                (cold) batches / the launches in it -- the figure rocprofv3 --kernel-trace --stats reproduces (it serialises
+                streams); roofline.chip: the S-stream timed region of `value` itself (bytes of all launches / its
+                duration), and roofline.chip.device_clock: the same figure from timestamps the KERNEL takes on the chip's
+                100 MHz reference counter (fz_diag_stamps_*: every workgroup's entry and exit) -- launches of different
+                streams really overlap, by the device's own clock, which no profiler trace can show
   cpu_baseline  the pure-Python port of the reference's algebra path (oracle/oracle.py py_*), one host core, bounded sample
   sign_verify / keygen_sign   the metric's second half (algebra cores, sharded over the ranks, ONE int64 all-reduce per step,
                 on a second stream beside the next step's kernels when there is a communicator)
-  warm_replay   the same step re-reading ONE batch (cache-resident): the side number, never `value`
-  ranks         per rank: device, PCI bus id, ranks RCCL itself counted in the communicator, RCCL version
+  end_to_end    keygen / sign / aggregate / verify per second through BatchScheme, hashing included (benchmarks/benchmarks.py:37-141)
+  warm_replay   the un-pipelined step re-reading ONE batch (cache-resident): the side number, never `value`
+  ranks         per rank: device, PCI bus id, ranks RCCL itself counted in the communicator, RCCL version, collective self-check
 `--full` adds the side legs of tools/bench_legs.py (launch floor, fz_ntt_multi, PCIe, large-batch sweep, cold
-per-kernel table, end to end through BatchScheme / ShardedScheme) to the full file.
+per-kernel table, ShardedScheme end to end) to the full file.
 
 Launch: `python bench.py --gpus N` starts its own N ranks (child processes, before this process has touched a GPU) when
 WORLD_SIZE is not set; under torch.distributed.run it uses the ranks it is given.
@@ -80,9 +86,13 @@ def parse(argv=None):
                     help="sign_verify: the all-reduce on the compute stream (round 3's form) instead of a second stream")
     ap.add_argument("--headline-only", action="store_true",
                     help="timed region + per-dispatch roofline passes only (what tools/collect_profiles.sh runs under rocprofv3)")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams (a context each) that walk disjoint shares of the rotating batches side by side: launches of "
                          "different streams overlap on the chip (1: one launch in flight at a time)")
+    ap.add_argument("--depth", type=int, default=4,
+                    help="batches per launch of the software pipeline: D forward jobs (batches i+1..i+D) + D inverse jobs (batches "
+                         "i-D+1..i) in one fz_ntt_multi dispatch = D x 16 MiB of algorithmic bytes (1: round 4's two-job launch)")
+    ap.add_argument("--no-stamps", action="store_true", help="skip the device-timestamp pass (roofline.chip.device_clock)")
     ap.add_argument("--two-launch", action="store_true",
                     help="headline step as two launches (fz_ntt_forward, fz_ntt_inverse) instead of the software-pipelined one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,13 +148,18 @@ def compact_line(full):
     Counterpart of the reference harness' five numbers per N (benchmarks/benchmarks.py:144-171)."""
     out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                        "vs_baseline", "dtype", "data"))
-    out["config"] = _pick(full.get("config") or {}, ("workload", "batch", "degree", "modulus", "batches_rotated", "launches_per_step",
+    out["config"] = _pick(full.get("config") or {}, ("workload", "batch", "degree", "modulus", "batches_rotated", "steps_per_launch",
                                                      "streams", "step", "launch"))
     roof = full.get("roofline") or {}
     out["roofline"] = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch",
                                    "units_per_launch", "avg_launch_us", "in_flight", "operands", "timing"), 5)
+    dck = ("frac", "in_flight", "launch_us", "gap_us", "span_us")
+    if isinstance(roof.get("device_clock"), dict):
+        out["roofline"]["device_clock"] = _pick(roof["device_clock"], dck, 4)
     if isinstance(roof.get("chip"), dict):
         out["roofline"]["chip"] = _pick(roof["chip"], ("streams", "achieved", "frac", "unit", "launch_us_in_flight", "launches_timed"), 5)
+        if isinstance(roof["chip"].get("device_clock"), dict):
+            out["roofline"]["chip"]["device_clock"] = _pick(roof["chip"]["device_clock"], dck, 4)
     cb = full.get("cpu_baseline")
     out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample"), 5) if isinstance(cb, dict) else None
     if isinstance(cb, dict) and isinstance(cb.get("sample"), str):
@@ -441,7 +456,8 @@ def main():
     # torch.distributed "nccl" group, or fz_comm_create) takes several for its own streams, and chains created after it end up
     # sharing queues with them or with each other -- measured with a communicator of ONE rank: 0.84-1.75 G NTT/s instead of
     # 2.2 G (tools/hw_queue_probe.py, its table under profiles/).
-    S = max(1, min(args.streams, NBATCH // 2))
+    D = 1 if args.two_launch else max(1, min(args.depth, 16))        # batches per launch of the software pipeline
+    S = max(1, min(args.streams, NBATCH // (2 * D)))                  # a chain's rotation holds at least two launches' batches
     chain_ctx = []
     for _ in range(S):
         c_ = fusion_hip.Context(q, d, P["root"], P["inv_root"], device=dev_index)
@@ -574,44 +590,46 @@ def main():
 
     class Chain:
         """One HIP stream's share of the work: a context + stream and the batches of the rotation it walks, one after the other.
-        pipelined: launch k = {forward x_k -> y_k, inverse y_(k-1) -> z_(k-1)} in ONE dispatch (fz_ntt_multi; the job tables are
-        built once per batch; PRO / EPI are the one-job launches that open and close a run of steps); two: fz_ntt_forward then
-        fz_ntt_inverse (two launches per step); warm: the same two launches on ONE batch."""
+        pipe: ONE launch (fz_ntt_multi) = the forward transforms of the next g <= D batches (x_b -> y_b) + the inverse transforms
+        (y_b -> z_b) of the batches the previous launch transformed forward; a run of steps opens with a forward-only launch and
+        end() closes it with an inverse-only one (job tables are built once per distinct launch and kept).  two: fz_ntt_forward
+        then fz_ntt_inverse (two launches per step); warm: the same two launches on ONE batch."""
 
         def __init__(self, c, idx):
-            self.ctx, self.h, self.idx, self.k, self.open = c, c._h, list(idx), 0, False
-            rp = self.rp = [rot_p[i] for i in self.idx]
-            n = len(rp)
-            self.PAIR = [jobs((rp[k][0], rp[k][1], 0), (rp[k - 1][1], rp[k - 1][2], 1)) for k in range(n)]
-            self.PRO = [jobs((rp[k][0], rp[k][1], 0)) for k in range(n)]
-            self.EPI = [jobs((rp[k][1], rp[k][2], 1)) for k in range(n)]
+            self.ctx, self.h, self.idx, self.k, self.prev, self.tabs = c, c._h, list(idx), 0, (), {}
+            self.rp = [rot_p[i] for i in self.idx]
 
-        def pipe(self):
-            k = self.k % len(self.rp)
-            self.k += 1
-            if not self.open:
-                self.open = True
-                return lib.fz_ntt_multi(self.h, self.PRO[k], 1)
-            return lib.fz_ntt_multi(self.h, self.PAIR[k], 2)
+        def _launch(self, new, old):
+            tab = self.tabs.get((new, old))
+            if tab is None:
+                rp = self.rp
+                tab = self.tabs[(new, old)] = jobs(*([(rp[b_][0], rp[b_][1], 0) for b_ in new] + [(rp[b_][1], rp[b_][2], 1) for b_ in old]))
+            return lib.fz_ntt_multi(self.h, tab, len(new) + len(old))
 
-        def pipe_end(self):
-            """the inverse of the batch that entered last: closes a run of pipelined steps (its last inverse transform)"""
-            if not self.open:
+        def run(self, n_steps, mode_):
+            """issue n_steps steps on this chain's stream (asynchronous) -> 0 or the first failing status ORed in"""
+            rc, n = 0, len(self.rp)
+            if mode_ == "pipe":
+                while n_steps > 0:
+                    g = min(D, n_steps)
+                    new = tuple((self.k + t_) % n for t_ in range(g))
+                    self.k = (self.k + g) % n
+                    rc |= self._launch(new, self.prev)
+                    self.prev = new
+                    n_steps -= g
+                return rc
+            for _ in range(n_steps):
+                a_, b_, c_ = self.rp[0 if mode_ == "warm" else self.k % n]
+                self.k += 1
+                rc |= lib.fz_ntt_forward(self.h, a_, b_, nB) | lib.fz_ntt_inverse(self.h, b_, c_, nB)
+            return rc
+
+        def end(self, mode_):
+            """the inverse transforms still due: closes a run of pipelined steps"""
+            if mode_ != "pipe" or not self.prev:
                 return 0
-            self.open = False
-            return lib.fz_ntt_multi(self.h, self.EPI[(self.k - 1) % len(self.rp)], 1)
-
-        def two(self):
-            a_, b_, c_ = self.rp[self.k % len(self.rp)]
-            self.k += 1
-            return lib.fz_ntt_forward(self.h, a_, b_, nB) | lib.fz_ntt_inverse(self.h, b_, c_, nB)
-
-        def warm(self):
-            a_, b_, c_ = self.rp[0]
-            return lib.fz_ntt_forward(self.h, a_, b_, nB) | lib.fz_ntt_inverse(self.h, b_, c_, nB)
-
-        def fns(self, mode):
-            return {"pipe": (self.pipe, self.pipe_end), "two": (self.two, lambda: 0), "warm": (self.warm, lambda: 0)}[mode]
+            old, self.prev = self.prev, ()
+            return self._launch((), old)
 
     # S chains: independent batches are in flight on S HIP streams at once (the contexts + streams created first thing above)
     # -- launches of different streams overlap on the chip, which hides each launch's ramp and drain
@@ -619,31 +637,26 @@ def main():
     chains = [Chain(chain_ctx[s_], range(bounds[s_], bounds[s_ + 1])) for s_ in range(S)]
     solo = Chain(ctx, range(NBATCH))                    # every batch on ONE stream: the single-stream legs and the isolated launches
     mode = "two" if args.two_launch else "pipe"
-    per_step = 2 if args.two_launch else 1
+    per_launch_steps = {"pipe": D, "two": 0.5, "warm": 0.5}          # steps one launch covers
 
-    def prewarm(fn, ms, inner=50):
-        """untimed: keep the device busy for `ms` so the timed region starts at steady clocks"""
+    def prewarm_fn(fn, ms, inner=50):
+        """untimed: keep the device busy for `ms` by calling fn (the side legs' form)"""
         t_end = time.perf_counter() + ms * 1e-3
         while time.perf_counter() < t_end:
             for _ in range(inner):
                 fn()
             torch.cuda.synchronize(dev)
 
-    def all_chains(cs, mode_):
-        fs = [c_.fns(mode_) for c_ in cs]
-
-        def step_all():
-            rc = 0
-            for st_, _ in fs:
-                rc |= st_()
-            return rc
-
-        def end_all():
-            rc = 0
-            for _, en_ in fs:
-                rc |= en_()
-            return rc
-        return step_all, end_all
+    def prewarm(cs, mode_, ms):
+        """untimed: keep the device busy for `ms` so the timed region starts at steady clocks (the run is closed afterwards)"""
+        t_end = time.perf_counter() + ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(12):
+                for c_ in cs:
+                    c_.run(D, mode_)
+            torch.cuda.synchronize(dev)
+        for c_ in cs:
+            c_.end(mode_)
 
     def timed_on_stream(fn, reps):
         """average milliseconds of fn() over reps back-to-back calls, HIP events on the kernels' own stream"""
@@ -656,21 +669,18 @@ def main():
         return a.elapsed_time(b_) / reps
 
     def region(cs, mode_, K):
-        """W warmup steps, then the K steps -- dealt round-robin to the chains `cs`, every chain's share recorded into its own
-        hipGraph (M repetitions per recording for K < 1000) -- replayed for >= MIN_REGION_MS between two barriers.
+        """W warmup steps, then the K steps -- dealt to the chains `cs`, every chain's share recorded into its own hipGraph
+        (M repetitions per recording for K < 1000) -- replayed for >= MIN_REGION_MS between two barriers.
         -> dict(elapsed s (max over ranks), steps, per-chain event ms, per-chain steps, replays, M, shader clock)"""
         n_c = len(cs)
-        fs = [c_.fns(mode_) for c_ in cs]
-        for c_ in cs:
+        for j, c_ in enumerate(cs):
             c_.k = 0
-        for w_ in range(args.warmup):
-            fs[w_ % n_c][0]()
-        for _, en_ in fs:
-            en_()
+            c_.run(args.warmup // n_c + (1 if j < args.warmup % n_c else 0), mode_)
+            c_.end(mode_)
         barrier()
         M = max(1, 1000 // K) if K < 1000 else 1
-        # steps per chain and replay round: the M x K steps of a round dealt round-robin (step t to chain t % n_c), so the
-        # shares differ by one step at most whatever K is (K = 5 on 4 chains: 250 each, not 400 / 200 / 200 / 200)
+        # steps per chain and replay round: the M x K steps of a round dealt evenly (the shares differ by one step at most
+        # whatever K is); a share is issued as launches of D steps and, when D does not divide it, one shorter launch
         share = [(M * K) // n_c + (1 if j < (M * K) % n_c else 0) for j in range(n_c)]
         graphs = [[] for _ in cs]
         if not args.no_graph:
@@ -683,10 +693,7 @@ def main():
                         continue
                     c_.k = 0
                     c_.ctx.graph_begin()
-                    rc = 0
-                    for _ in range(n_steps):
-                        rc |= fs[j][0]()
-                    rc |= fs[j][1]()                         # n_steps steps = n_steps + 1 launches when pipelined
+                    rc = c_.run(n_steps, mode_) | c_.end(mode_)        # n_steps steps = ceil(n_steps / D) + 1 launches when pipelined
                     g = c_.ctx.graph_end()
                     assert rc == 0, f"capture failed: {lib.fz_last_error()}"
                     g.launch()                               # untimed first replay (upload)
@@ -700,13 +707,13 @@ def main():
                     for g in gl:
                         g.launch()
             else:
-                rc = 0
-                for t_ in range(max(share)):
-                    for j in range(n_c):
+                rc, grain = 0, max(1, int(per_launch_steps[mode_]))
+                for t_ in range(0, max(share), grain):
+                    for j, c_ in enumerate(cs):
                         if t_ < share[j]:
-                            rc |= fs[j][0]()
-                for _, en_ in fs:
-                    rc |= en_()
+                            rc |= c_.run(min(grain, share[j] - t_), mode_)
+                for c_ in cs:
+                    rc |= c_.end(mode_)
                 assert rc == 0, f"launch failed: {lib.fz_last_error()}"
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -738,27 +745,25 @@ def main():
                 "replays": launches, "M": M, "shader_mhz": shader}
 
     def summary(r_, mode_):
-        """value and the chip-level / per-launch figures of one region() result"""
-        ps_ = 2 if mode_ in ("two", "warm") else 1
-        byt = 8 * d * B * (2 // ps_)                           # algorithmic bytes per launch
-        n_launch = r_["steps"] * ps_
+        """value and the chip-level / per-launch figures of one region() result.  Launches are counted as FULL-launch equivalents
+        (steps / steps per launch): the forward-only launch that opens a recording and the inverse-only one that closes it are two
+        halves of one, and a recording of 1000 steps holds one such pair."""
+        pls = per_launch_steps[mode_]
+        byt = 8 * d * B * 2 * pls                              # algorithmic bytes per launch (2 * pls transforms of B rows)
+        n_launch = r_["steps"] / pls
         interval = max(r_["ev_ms"]) * 1e3 / n_launch           # us between launches, all chains together
-        per = [m_ * 1e3 / (st_ * ps_) for m_, st_ in zip(r_["ev_ms"], r_["chain_steps"]) if st_]
+        per = [m_ * 1e3 / (st_ / pls) for m_, st_ in zip(r_["ev_ms"], r_["chain_steps"]) if st_]
         lat = sum(per) / len(per)                              # us per launch on its own stream
         return {"value": 2.0 * B * r_["steps"] * world / r_["elapsed"], "unit": "NTT/s", "ms_per_step": r_["elapsed"] / r_["steps"] * 1e3,
                 "frac": byt / (interval * 1e-6) / 1e9 / HBM_PEAK_GBS, "launch_interval_us": interval, "launch_us": lat,
                 "frac_per_launch": byt / (lat * 1e-6) / 1e9 / HBM_PEAK_GBS, "streams": len(r_["ev_ms"]), "shader_mhz": r_["shader_mhz"]}
 
-    st0, en0 = solo.fns(mode)
-    for _ in range(NBATCH):                              # every batch once: z_i defined whatever the flags below skip
-        st0()
-    en0()
+    rc = solo.run(NBATCH, mode) | solo.end(mode)         # every batch once: z_i defined whatever the flags below skip
+    assert rc == 0, f"launch failed: {lib.fz_last_error()}"
     barrier()
     assert torch.equal(zs, xs), "INTT(NTT(x)) != x"
     zs.zero_()
-    step_all, end_all = all_chains(chains, mode)
-    prewarm(step_all, args.prewarm_ms)
-    end_all()
+    prewarm(chains, mode, args.prewarm_ms)
     R = region(chains, mode, args.steps)
     torch.cuda.synchronize(dev)
     assert torch.equal(zs, xs), "INTT(NTT(x)) != x after the timed region"
@@ -769,28 +774,102 @@ def main():
     # takes in a dense stream -- the figure a profiler can reproduce (rocprofv3 --kernel-trace serialises the dispatches of all
     # streams: in its trace of this script no two launches overlap)
     if S > 1:
-        st0_, en0_ = solo.fns(mode)
-        prewarm(st0_, 20.0)
-        en0_()
+        prewarm([solo], mode, 20.0)
         one = summary(region([solo], mode, args.steps), mode)
     else:
         one = head
 
+    # ---- the chip's own clock: every workgroup of every launch stamps the 100 MHz reference counter at entry
+    # and exit (fz_diag_stamps_*); a launch = [min entry, max exit] over its workgroups.  Neither a kernel trace (it serialises
+    # the streams) nor HIP events (host-side markers) can show launches of different streams overlapping; these can.
+    def merged(iv):
+        out_ = []
+        for a_, b_ in sorted(iv):
+            if out_ and a_ <= out_[-1][1]:
+                out_[-1][1] = max(out_[-1][1], b_)
+            else:
+                out_.append([a_, b_])
+        return out_
+
+    def stamp_pass(cs, n_launch, rounds=3):
+        """n_launch full launches per chain (+ the opening and the closing one) captured WITH stamp slots, then `rounds` times:
+        reset, ONE replay of every chain's recording side by side, read.  -> the last round's table and all rounds' figures"""
+        graphs = []
+        for c_ in cs:
+            c_.ctx.diag_stamps_begin(n_launch + 2, (n_launch + 2) * 2 * D * B)     # (at most one workgroup per row)
+            c_.k = 0
+            c_.ctx.graph_begin()
+            rc_ = c_.run(n_launch * D, "pipe") | c_.end("pipe")
+            graphs.append(c_.ctx.graph_end())
+            c_.ctx.diag_stamps_stop()
+            assert rc_ == 0, f"capture failed: {lib.fz_last_error()}"
+        for g in graphs:
+            g.launch()                                       # (upload)
+        torch.cuda.synchronize(dev)
+        per_launch_bytes = 8 * d * B * 2 * D
+        rounds_out, table = [], []
+        for _ in range(rounds):
+            prewarm(cs, "pipe", 10.0)                        # steady clocks; these launches carry no slots
+            for c_ in cs:
+                c_.ctx.diag_stamps_reset()
+            torch.cuda.synchronize(dev)
+            for c_ in cs:
+                c_.ctx.timer_start()
+            for g in graphs:
+                g.launch()
+            ev = [c_.ctx.timer_stop_ms() for c_ in cs]
+            recs = [c_.ctx.diag_stamps_read(n_launch + 2) for c_ in cs]
+            t0_ = min(int(r_[0][r_[3] > 0].min()) for r_ in recs)
+            iv, full_d, gaps, table = [], [], [], []
+            for j, (st_, en_, ls_, wg_) in enumerate(recs):
+                assert len(st_) == n_launch + 1 and (wg_ > 0).all(), (len(st_), wg_.tolist())
+                st_u, en_u, ls_u = [(x_.astype(np.int64) - t0_) / 100.0 for x_ in (st_, en_, ls_)]     # ticks of 10 ns -> us
+                iv += list(zip(st_u.tolist(), en_u.tolist()))
+                full_d += (en_u - st_u)[1:-1].tolist()       # (the first launch is forward-only, the last inverse-only)
+                gaps += (st_u[1:] - en_u[:-1]).tolist()
+                table += [{"stream": j, "launch": k_, "start_us": round(float(st_u[k_]), 2), "end_us": round(float(en_u[k_]), 2),
+                           "last_workgroup_in_us": round(float(ls_u[k_]), 2), "workgroups": int(wg_[k_])} for k_ in range(len(st_u))]
+            span = max(b_ for _, b_ in iv) - min(a_ for a_, _ in iv)
+            busy = sum(b_ - a_ for a_, b_ in merged(iv))
+            total_b = per_launch_bytes * n_launch * len(cs)  # the two half launches of a chain = one full one: n_launch + 1 dispatches
+            rounds_out.append({"span_us": span, "busy_us": busy, "in_flight": sum(b_ - a_ for a_, b_ in iv) / busy,
+                               "frac": total_b / (span * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                               "launch_us": float(np.mean(full_d)), "launch_us_median": float(np.median(full_d)),
+                               "gap_us": float(np.mean(gaps)), "event_ms": ev, "frac_by_events": total_b / (max(ev) * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        for g in graphs:
+            g.destroy()
+        best = sorted(rounds_out, key=lambda r_: r_["frac"])[len(rounds_out) // 2]      # the median round
+        return dict(best, rounds=rounds_out, launches_per_stream=n_launch + 1, streams=len(cs), bytes_per_launch=per_launch_bytes,
+                    table=table, clock="s_memrealtime (100 MHz reference counter, one for the chip), ticks of 10 ns",
+                    what="per launch: [min entry, max exit] over its workgroups' own stamps; span = first entry to last exit of the replay; "
+                         "in_flight = sum of launch durations / time at least one launch was running; frac = algorithmic bytes / span / 8 TB/s")
+
+    stamps_chip = stamps_one = None
+    if mode == "pipe" and not args.no_stamps:
+        try:
+            stamps_chip = stamp_pass(chains, 32)
+            stamps_one = stamp_pass([solo], 32) if S > 1 else stamps_chip
+            torch.cuda.synchronize(dev)
+            assert torch.equal(zs, xs), "INTT(NTT(x)) != x on the stamped passes"
+        except fusion_hip.FusionHipError as e:
+            stamps_chip = stamps_one = {"error": repr(e)}
+
     # ---- context for the roofline figures (which come from the timed region itself, below): begin/end events bound to EVERY
     # dispatch (hipExtLaunchKernelGGL) of instrumented passes on ONE stream over all 64 batches, launched one by one right after
     # the timed region (a hipGraph cannot carry the events) -- the duration of a launch that starts on an idle memory system.
-    n_inst, n_pass = 400, 3
-    dom_kind = 0 if args.two_launch else 2              # the dominant launch: the forward kernel, or the two-job launch
+    n_inst, n_pass = 200, 2
+    dom_kind = 0 if args.two_launch else 2              # the dominant launch: the forward kernel, or the multi-job launch
+    per_inst = 2 if args.two_launch else 1
     dom_all, inv_all, passes = [], [], []
     for _ in range(n_pass):
-        prewarm(st0, 20.0)                               # dense launches first: a one-by-one pass leaves the device half idle
-        ctx.profile_begin(per_step * n_inst + 2, args.sample_every)
-        rc = 0
+        prewarm([solo], mode, 20.0)                      # dense launches first: a one-by-one pass leaves the device half idle
+        rc = solo.run(D, mode)                           # (the forward-only launch that opens the run: not instrumented)
+        ctx.profile_begin(per_inst * n_inst + 2, args.sample_every)
         for _ in range(n_inst):
-            rc |= st0()
+            rc |= solo.run(D, mode)
         assert rc == 0, f"launch failed: {lib.fz_last_error()}"
-        us, kind = ctx.profile_end_samples(per_step * n_inst + 2)
-        rc = en0()                                       # (outside the instrumented launches: a one-job launch)
+        us, kind = ctx.profile_end_samples(per_inst * n_inst + 2)
+        rc = solo.end(mode)
         assert rc == 0, f"launch failed: {lib.fz_last_error()}"
         f_, i_ = us[kind == dom_kind], us[kind == 1]
         assert len(f_) >= n_inst // args.sample_every - 1, (len(f_), len(us))
@@ -803,32 +882,44 @@ def main():
     dom_all = np.concatenate(dom_all)
     inv_all = np.concatenate(inv_all)
     iso_us = float(dom_all.mean())
-    # 8*d algorithmic bytes per transform; one dominant launch = 4096 forward (+ 4096 inverse when pipelined) transforms
-    units_per_launch = B if args.two_launch else 2 * B
+    # 8*d algorithmic bytes per transform; one dominant launch = D x 4096 forward + D x 4096 inverse transforms
+    units_per_launch = B if args.two_launch else 2 * D * B
     dom_bytes = 8 * d * units_per_launch
     # THE per-launch fraction (`roofline.frac`): algorithmic bytes per launch / the launch's average duration with ONE launch in
     # flight -- HIP events on the kernel's stream around a dense single-stream region of the same steps / its launches.  This is
     # the figure rocprofv3 --kernel-trace --stats reproduces (it serialises dispatches), profiles/ + DESIGN.md section 6.
     # `roofline.chip`: the headline's timed region itself -- `streams` launches in flight on as many HIP streams; algorithmic bytes
-    # moved / the region's duration by HIP events on every stream = `value` x 2048 B: what the chip achieves on batches of 4096.
+    # moved / the region's duration by HIP events on every stream = `value` x 2048 B: what the chip achieves on batches of 4096;
+    # `roofline.chip.device_clock`: the same from the kernels' own timestamps.
     ach = one["frac"] * HBM_PEAK_GBS
     if args.two_launch:
         kernel_name = "ntt_fwd4<8, true, 1, 8>"
         launch_text = "fz_ntt_forward + fz_ntt_inverse: two launches per step"
     else:
         cus = props.multi_processor_count                  # the launcher's rule (fz_launch_ntt_multi): row groups per wave by the launch's rows
-        nr_ = 1 if 2 * B <= 24 * cus else (2 if 2 * B <= 48 * cus else 4)
-        kernel_name = f"ntt_jobs4<8, true, {nr_}, {(8 if 2 * B >= 8 * cus else 4 if 2 * B >= 4 * cus else 1) if nr_ == 1 else 2}, FzJobs4>"
-        launch_text = "software-pipelined: forward of batch i+1 + inverse of batch i in one fz_ntt_multi launch per step"
-    traffic, traffic_src = pmc_traffic(kernel_name.rstrip(">").replace(", FzJobs4", ""))      # prefix: whatever follows the launch shape
+        rows_ = 2 * D * B
+        nr_ = 1 if rows_ <= 24 * cus else (2 if rows_ <= 48 * cus else 4)
+        tab_ = 4 if 2 * D <= 4 else (8 if 2 * D <= 8 else 32)
+        if os.environ.get("FZ_NTT_KERNEL", "") == "16" or (os.environ.get("FZ_NTT_KERNEL", "") != "4" and rows_ >= 65536):
+            kernel_name = f"ntt_jobs16<8, true, FzJobsN<{tab_}>>"       # (fz_launch_ntt_multi: the 16-per-lane form from 2^16 rows per launch)
+        else:
+            kernel_name = f"ntt_jobs4<8, true, {nr_}, {(8 if rows_ >= 8 * cus else 4 if rows_ >= 4 * cus else 1) if nr_ == 1 else 2}, FzJobsN<{tab_}>>"
+        launch_text = (f"software-pipelined over {D} batches: forward of batches i+1..i+{D} + inverse of batches i-{D - 1}..i in one "
+                       f"fz_ntt_multi launch ({2 * D} jobs) per {D} steps")
+    traffic, traffic_src = pmc_traffic(kernel_name.split(", FzJobsN")[0])      # prefix: whatever follows the launch shape
+
+    def stamp_brief(sp):
+        if not isinstance(sp, dict) or "frac" not in sp:
+            return sp
+        return {k_: sp[k_] for k_ in ("frac", "in_flight", "launch_us", "gap_us", "span_us", "frac_by_events", "launches_per_stream", "streams")}
 
     full = {
         "metric": METRIC, "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "repeats": launches * M,
         "warmup": args.warmup, "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "timed_region_ms": elapsed * 1e3,
         "config": {"workload": f"configs[1]: secpar={SECPAR}, {B} degree-{d} forward+inverse NTTs per step per GPU",
-                   "batch": B, "degree": d, "modulus": q, "batches_rotated": NBATCH, "launches_per_step": per_step, "streams": S,
-                   "step": launch_text,
+                   "batch": B, "degree": d, "modulus": q, "batches_rotated": NBATCH, "steps_per_launch": per_launch_steps[mode],
+                   "streams": S, "step": launch_text,
                    "parallelism": f"{world} independent rank(s); per rank {S} HIP stream(s), each walking its own {NBATCH // S} of the {NBATCH} batches",
                    "arithmetic": "exact integers carried in fp64 lanes (bit-identical to the reference's int arithmetic); int32 in and out",
                    "launch": "one by one" if args.no_graph else f"{S} hipGraph(s) of {M}x{args.steps} steps together, {launches} replays",
@@ -842,19 +933,23 @@ def main():
                      "operands": f"cold: rotation of {NBATCH} batches",
                      "timing": "HIP events around a dense one-stream region of the same steps / launches (one launch in flight)",
                      "one_stream": one,
+                     "device_clock": stamp_brief(stamps_one),
                      "chip": {"streams": S, "achieved": head["frac"] * HBM_PEAK_GBS, "frac": head["frac"], "unit": "GB/s",
                               "launch_us_in_flight": head["launch_us"], "launch_interval_us": head["launch_interval_us"],
-                              "launches_timed": int(total_steps * per_step),
+                              "launches_timed": int(round(total_steps / per_launch_steps[mode])),
                               "per_chain_event_ms": R["ev_ms"], "per_chain_steps": R["chain_steps"],
+                              "device_clock": stamp_brief(stamps_chip),
                               "what": "the timed region of `value`: `streams` launches in flight, one per HIP stream; algorithmic bytes of "
-                                      "all launches / the region's duration by HIP events on every stream (the slowest chain's)"},
+                                      "all launches / the region's duration by HIP events on every stream (the slowest chain's); device_clock: "
+                                      "the same quantity over a 33-launch replay per stream from the kernels' own entry / exit timestamps"},
                      "isolated": {"avg_launch_us": iso_us, "median_launch_us": float(np.median(dom_all)),
                                   "frac": dom_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "launches": int(len(dom_all)),
                                   "inverse_avg_launch_us": float(inv_all.mean()) if len(inv_all) else None, "passes": passes,
                                   "what": f"begin/end events bound to EVERY dispatch (hipExtLaunchKernelGGL) of {n_pass} passes of {n_inst} "
-                                          "steps launched one by one from Python on ONE stream after the timed region: the host paces them "
-                                          "(~10 us apart), so every launch has the chip and an idle memory system to itself; context, not the fraction"},
+                                          "launches issued one by one from Python on ONE stream after the timed region: the host paces them, "
+                                          "so a launch may start on an idle memory system; context, not the fraction"},
                      "shader_mhz": shader_mhz, "butterflies_per_s": value * (d // 2) * 8},
+        "device_timestamps": {"chip": stamps_chip, "one_stream": stamps_one},
     }
 
     # ---- everything below is a side leg: the headline is measured.  A watchdog prints the line with whatever is there if
@@ -906,16 +1001,14 @@ def main():
     env = types.SimpleNamespace(
         args=args, ctx=ctx, torch=torch, np=np, dist=dist, dev=dev, dev_index=dev_index, stream=stream, lib=lib, h=h,
         xs=xs, ys=ys, zs=zs, x=x, y=y, z=z, rot_p=rot_p, B=B, d=d, q=q, l=l, P=P, F=F, fusion_hip=fusion_hip, rank=rank, world=world,
-        barrier=barrier, max_over_ranks=max_over_ranks, min_over_ranks=min_over_ranks, prewarm=prewarm,
+        barrier=barrier, max_over_ranks=max_over_ranks, min_over_ranks=min_over_ranks, prewarm=prewarm_fn,
         timed_on_stream=timed_on_stream, exchange_ctx=exchange_ctx, comm=comm, collective=collective, backend=backend, shard_range=shard_range,
         allreduce_sum_i64=allreduce_sum_i64, HBM_PEAK_GBS=HBM_PEAK_GBS, MIN_REGION_MS=MIN_REGION_MS, SECPAR=SECPAR)
 
     if not args.headline_only:
         # the single-stream forms over the same batches: one launch in flight at a time
         def solo_leg(mode_, what):
-            st_, en_ = solo.fns(mode_)
-            prewarm(st_, 20.0)
-            en_()
+            prewarm([solo], mode_, 20.0)
             out_ = summary(region([solo], mode_, args.steps), mode_)
             out_["what"] = what
             return out_
@@ -955,18 +1048,16 @@ def main():
             if isinstance(full.get("keygen_sign"), dict) and "keygen_plus_sign_per_s" in sch:
                 full["keygen_sign"]["cpu_value"] = sch["keygen_plus_sign_per_s"]
         emit()
-    if world == 1 and args.single_rank_comm:            # same teardown hazard as below (RCCL was loaded through the C ABI beside torch's)
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
     if world > 1:
         barrier()                                       # rank 0's single-rank legs are done: leave together
         dist.destroy_process_group()
-        # the result is out and the process group is gone: leave without running the interpreter's teardown, in which torch's
-        # RCCL and the communicator the C ABI created through the same library would be unloaded in an order nobody controls
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+    elif args.single_rank_comm:
+        dist.destroy_process_group()
+    # and then an ORDINARY interpreter exit.  Rounds 3-4 left through os._exit(0) here because a test process had aborted at exit
+    # with `double free or corruption`: the C ABI had bound /opt/rocm's RCCL by soname into the global scope and torch then
+    # mapped its own copy -- two RCCLs and two rocm_smi in one process, whose static destructors freed one object twice
+    # (profiles/r05_rccl_exit_matrix.txt has the backtrace).  fz_comm_* now binds the copy that is already mapped, or the one
+    # beside the HIP runtime the process runs on: one copy whatever the import order, and nothing to hide.
 
 
 _BAILING = threading.Event()       # set by the watchdog: from then on an exception in the main thread is a peer leaving

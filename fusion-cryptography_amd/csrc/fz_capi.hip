@@ -2,6 +2,7 @@
 // table construction, error reporting and the thin wrappers that enqueue kernels.
 #include "fz_internal.h"
 #include "../../include/fusion_hip.h"
+#include "../../include/fusion_hip_diag.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -10,6 +11,7 @@
 #include <new>
 #include <algorithm>
 #include <vector>
+#include <string>
 #include <dlfcn.h>
 #include <atomic>
 #include <mutex>
@@ -390,6 +392,9 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
     if (ctx->diag_stream) (void)hipStreamDestroy(ctx->diag_stream);
     if (ctx->d_mt_init) (void)hipFree(ctx->d_mt_init);
+    if (ctx->d_stamp) (void)hipFree(ctx->d_stamp);
+    free(ctx->stamp_first);
+    free(ctx->stamp_count);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     free(ctx->h_tw);
@@ -1445,9 +1450,91 @@ int fz_diag_delay(fz_ctx *ctx, unsigned microseconds) {
     return fz_launch_diag_clock(ctx->stream, (unsigned long long)microseconds * 100ull, nullptr);
 }
 
+// ---- device-side launch timestamps of the multi-job transform (diagnostics: include/fusion_hip_diag.h) -----------------
+// rocprofv3 --kernel-trace serialises the dispatches of all streams, and HIP events are host-visible markers between
+// dispatches: neither shows WHEN launches of different streams ran relative to each other.  While stamps are on, every
+// workgroup of every fz_ntt_multi launch of this context stores the 100 MHz reference counter (s_memrealtime: one counter
+// for the whole chip) at entry and -- after its stores have been acknowledged -- at exit; launch k of the recording is the
+// interval [min entry, max exit] over its workgroups.  Slots are assigned when a launch is ISSUED (or captured: the slot is
+// part of the recorded kernel arguments), so a captured graph is replayed ONCE between fz_diag_stamps_reset and
+// fz_diag_stamps_read.
+int fz_diag_stamps_begin(fz_ctx *ctx, size_t max_launches, size_t max_workgroups) {
+    FZ_REQUIRE(ctx && max_launches >= 1 && max_launches <= (1u << 20) && max_workgroups >= 1 && max_workgroups <= ((size_t)1 << 26), "bad argument");
+    FZ_DEV(ctx);
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "stamps cannot be set up during graph capture");
+    if (ctx->d_stamp) { FZ_TRY(fz_retire(ctx, ctx->d_stamp, "stamp buffer")); ctx->d_stamp = nullptr; }
+    free(ctx->stamp_first); free(ctx->stamp_count);
+    ctx->stamp_first = (size_t *)malloc(sizeof(size_t) * max_launches);
+    ctx->stamp_count = (unsigned *)malloc(sizeof(unsigned) * max_launches);
+    if (!ctx->stamp_first || !ctx->stamp_count) return fz_set_error(FZ_E_HIP, "out of host memory");
+    FZ_HIP(hipMalloc((void **)&ctx->d_stamp, 16 * max_workgroups), "stamp buffer");
+    FZ_HIP(hipMemsetAsync(ctx->d_stamp, 0, 16 * max_workgroups, ctx->stream), "stamp reset");
+    ctx->stamp_launch_cap = (int)max_launches;
+    ctx->stamp_wg_cap = max_workgroups;
+    ctx->stamp_n = 0;
+    ctx->stamp_used = 0;
+    ctx->stamp_on = 1;
+    return FZ_OK;
+}
+
+// stop assigning slots (launches issued from now on carry no stamps); the recording stays readable
+int fz_diag_stamps_stop(fz_ctx *ctx) {
+    FZ_REQUIRE(ctx, "ctx is NULL");
+    ctx->stamp_on = 0;
+    return FZ_OK;
+}
+
+// zero every slot (asynchronous on the context's stream): before the ONE replay of a captured recording that is to be read
+int fz_diag_stamps_reset(fz_ctx *ctx) {
+    FZ_REQUIRE(ctx && ctx->d_stamp, "no stamp buffer");
+    FZ_DEV(ctx);
+    FZ_HIP(hipMemsetAsync(ctx->d_stamp, 0, 16 * ctx->stamp_used, ctx->stream), "stamp reset");
+    return FZ_OK;
+}
+
+// synchronises the context's stream; per recorded launch k < *n: h_start[k] / h_end[k] = min entry / max exit over its
+// workgroups (ticks of the 100 MHz counter; 0 / 0 when no workgroup of the launch has run since the reset), h_workgroups[k]
+// (optional) = how many of its workgroups stamped, h_last_start[k] (optional) = the latest entry (when the dispatcher had
+// handed out the launch's last workgroup)
+int fz_diag_stamps_read(fz_ctx *ctx, uint64_t *h_start, uint64_t *h_end, uint64_t *h_last_start, uint32_t *h_workgroups, size_t cap, size_t *n) {
+    FZ_REQUIRE(ctx && h_start && h_end && n, "NULL argument");
+    FZ_REQUIRE(ctx->d_stamp, "no stamp buffer");
+    FZ_DEV(ctx);
+    if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "stamps cannot be read during graph capture");
+    FZ_HIP(hipStreamSynchronize(ctx->stream), "stamp sync");
+    std::vector<unsigned long long> h(2 * ctx->stamp_used);
+    if (ctx->stamp_used) FZ_HIP(hipMemcpy(h.data(), ctx->d_stamp, 16 * ctx->stamp_used, hipMemcpyDeviceToHost), "stamp read");
+    size_t k = 0;
+    for (; k < (size_t)ctx->stamp_n && k < cap; ++k) {
+        unsigned long long lo = ~0ull, hi = 0, last = 0;
+        unsigned seen = 0;
+        for (size_t w = ctx->stamp_first[k]; w < ctx->stamp_first[k] + ctx->stamp_count[k]; ++w) {
+            const unsigned long long a = h[2 * w], b = h[2 * w + 1];
+            if (!a && !b) continue;
+            ++seen;
+            lo = std::min(lo, a); hi = std::max(hi, b); last = std::max(last, a);
+        }
+        h_start[k] = seen ? lo : 0;
+        h_end[k] = hi;
+        if (h_last_start) h_last_start[k] = last;
+        if (h_workgroups) h_workgroups[k] = seen;
+    }
+    *n = k;
+    return FZ_OK;
+}
+
 // ---- the one exchange step of the path, in the C ABI: RCCL all-reduce of the int64 partial sums ---------------------
-// RCCL is bound lazily (dlopen): the library loads and every other entry point works on a machine without it, and a
-// process that already carries an RCCL (torch ships its own copy under the same soname) shares that one.
+// RCCL is bound lazily (dlopen): the library loads and every other entry point works on a machine without it.
+// WHICH copy is bound is an ownership question (VERDICT / ADVICE r04: an abort at process exit): a torch wheel ships its
+// own librccl.so under the soname librccl.so.1 but asks for it by the unversioned file name, so a process that bound
+// /opt/rocm's copy by soname first and imported torch afterwards carried TWO RCCLs of different ROCm releases -- and with
+// RTLD_GLOBAL (rounds 2-4) the first copy's nccl* symbols interposed on the second's callers.  The rule now:
+//   1. a copy already mapped under the soname serves (RTLD_NOLOAD): whoever loaded it owns it, we share it;
+//   2. otherwise the copy that ships BESIDE THE HIP RUNTIME THIS PROCESS RUNS ON (dladdr of a HIP entry point: torch/lib when
+//      fusion_hip mapped the wheel's runtime first, /opt/rocm/lib otherwise), opened by path -- a later `import torch` then finds
+//      the same file (same device / inode) already mapped instead of adding a second copy;
+//   3. otherwise the soname on the default search path.
+// Always RTLD_LOCAL (nothing of RCCL enters the global scope), never dlclose'd (RCCL's own teardown runs at exit, after ours).
 namespace {
 struct RcclApi {
     void *handle;
@@ -1460,19 +1547,41 @@ struct RcclApi {
     int (*GetVersion)(int *);
     int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t);
     int (*ReduceScatter)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    char path[512];      // the file the symbols came from
+    char how[64];        // which of the three rules found it
 };
 RcclApi g_rccl = {};
+std::mutex g_rccl_mu;                       // binding and the registry of live communicators
+std::vector<fz_comm *> g_live_comms;
+
+void *rccl_open(char *how, size_t how_cap) {
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (h) { snprintf(how, how_cap, "already mapped (shared)"); return h; }
+    Dl_info di;
+    if (dladdr((const void *)&hipGetDeviceCount, &di) && di.dli_fname) {
+        std::string dir(di.dli_fname);
+        const size_t cut = dir.rfind('/');
+        if (cut != std::string::npos) {
+            dir.resize(cut + 1);
+            for (const char *n : {"librccl.so.1", "librccl.so"}) {
+                h = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL);
+                if (h) { snprintf(how, how_cap, "beside the HIP runtime"); return h; }
+            }
+        }
+    }
+    for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (h) { snprintf(how, how_cap, "default search path"); return h; }
+    }
+    return nullptr;
+}
 
 int rccl_bind() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.handle) return FZ_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    void *h = nullptr;
-    for (const char *n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
-    }
-    if (!h) return fz_set_error(FZ_E_RCCL, "RCCL not found (librccl.so.1): %s", dlerror());
     RcclApi a = {};
+    void *h = rccl_open(a.how, sizeof a.how);
+    if (!h) return fz_set_error(FZ_E_RCCL, "RCCL not found (librccl.so.1): %s", dlerror());
     a.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
     a.CommInitRank = (int (*)(void **, int, fz_unique_id, int))dlsym(h, "ncclCommInitRank");
     a.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
@@ -1483,7 +1592,9 @@ int rccl_bind() {
     a.Broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclBroadcast");
     a.ReduceScatter = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclReduceScatter");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString)
-        return fz_set_error(FZ_E_RCCL, "librccl.so.1 lacks an expected symbol");
+        return fz_set_error(FZ_E_RCCL, "librccl.so.1 lacks an expected symbol");      // (the handle stays open: never dlclose)
+    Dl_info di;
+    snprintf(a.path, sizeof a.path, "%s", dladdr((const void *)a.AllReduce, &di) && di.dli_fname ? di.dli_fname : "?");
     a.handle = h;
     g_rccl = a;
     return FZ_OK;
@@ -1516,19 +1627,60 @@ int fz_comm_create(fz_ctx *ctx, int nranks, int rank, const fz_unique_id *id, fz
     fz_comm *C = new (std::nothrow) fz_comm();
     if (!C) { g_rccl.CommDestroy(c); return fz_set_error(FZ_E_HIP, "out of host memory"); }
     C->comm = c; C->nranks = nranks; C->rank = rank; C->device = ctx->device;
+    {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        g_live_comms.push_back(C);
+    }
     *out = C;
     return FZ_OK;
 }
 
+// Idempotent: a handle that is not (or no longer) in the registry of live communicators is left alone -- a second destroy
+// of the same handle returns FZ_OK without touching RCCL or the freed wrapper.  Communicators still alive when the
+// process ends are NOT destroyed by this library (no static destructor, no atexit hook: ncclCommDestroy talks to the
+// device, and by then the HIP runtime's own teardown may have begun); RCCL's teardown owns them.
 int fz_comm_destroy(fz_comm *comm) {
     if (!comm) return FZ_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        auto it = std::find(g_live_comms.begin(), g_live_comms.end(), comm);
+        if (it == g_live_comms.end()) return FZ_OK;
+        g_live_comms.erase(it);
+    }
     int rc = FZ_OK;
     if (comm->comm && g_rccl.CommDestroy) {
         (void)hipSetDevice(comm->device);
+        (void)hipDeviceSynchronize();                    // nothing of ours may still be using the communicator's streams
         rc = rccl_check(g_rccl.CommDestroy(comm->comm), "ncclCommDestroy");
     }
+    comm->comm = nullptr;
     delete comm;
     return rc;
+}
+
+// which RCCL serves this process: the file the symbols were bound from, the rule that found it ("already mapped (shared)" |
+// "beside the HIP runtime" | "default search path"), and how many DIFFERENT files named librccl* the process has mapped
+// (more than one = two copies, the state the binding rule exists to avoid)
+int fz_rccl_library(char *out_path, size_t path_cap, char *out_how, size_t how_cap, int *out_copies_mapped) {
+    FZ_TRY(rccl_bind());
+    if (out_path && path_cap) snprintf(out_path, path_cap, "%s", g_rccl.path);
+    if (out_how && how_cap) snprintf(out_how, how_cap, "%s", g_rccl.how);
+    if (out_copies_mapped) {
+        std::vector<std::string> seen;
+        if (FILE *f = fopen("/proc/self/maps", "r")) {
+            char line[1024];
+            while (fgets(line, sizeof line, f)) {
+                const char *p = strchr(line, '/');
+                if (!p || !strstr(p, "librccl")) continue;
+                std::string path(p);
+                while (!path.empty() && (path.back() == '\n' || path.back() == ' ')) path.pop_back();
+                if (std::find(seen.begin(), seen.end(), path) == seen.end()) seen.push_back(path);
+            }
+            fclose(f);
+        }
+        *out_copies_mapped = (int)seen.size();
+    }
+    return FZ_OK;
 }
 
 int fz_comm_info(fz_comm *comm, int *out_nranks, int *out_rank) {

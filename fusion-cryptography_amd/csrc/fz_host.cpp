@@ -13,6 +13,7 @@
 // (algebra/polynomials.py:257-258), str(SignatureChallenge) (fusion.py:382-383).
 // Keccak-f[1600] / SHA-3 / SHAKE follow FIPS 202 (CPython's hashlib is the oracle in the tests).
 #include "../../include/fusion_hip.h"
+#include "../../include/fusion_hip_diag.h"
 
 #include <algorithm>
 #include <cmath>

@@ -101,6 +101,13 @@ struct fz_ctx {
     size_t pool_bytes, pool_cap;
     std::mutex pool_mu;
     // RCCL (fz_comm_*): communicators are owned by the caller; nothing here
+    // fz_diag_stamps_*: device-side launch timestamps of the multi-job transform ({entry, exit} of the 100 MHz reference counter
+    // per workgroup); launch k of the recording owns slots [stamp_first[k], stamp_first[k] + stamp_count[k])
+    int stamp_on, stamp_n, stamp_launch_cap;
+    size_t stamp_used, stamp_wg_cap;
+    unsigned long long *d_stamp;
+    size_t *stamp_first;
+    unsigned *stamp_count;
 };
 
 // group table of a ragged aggregation launch (kernarg segment): signers of aggregate g are rows [off[g], off[g+1]) of the
@@ -121,12 +128,14 @@ struct FzMultiJobs {
     int n;
 };
 
-// the table of a launch of at most four jobs: 96 bytes of kernel arguments instead of 772
-struct FzJobs4 {
-    const int32_t *in[4];
-    int32_t *out[4];
-    unsigned end[4];
-    unsigned rows[4];
+// the table as the kernel takes it: N = 4 | 8 | 32 entries, 24 bytes of kernel arguments each (a launch of four jobs
+// carries 96 bytes of table instead of 772)
+template <int N> struct FzJobsN {
+    static constexpr int kJobs = N;
+    const int32_t *in[N];
+    int32_t *out[N];
+    unsigned end[N];
+    unsigned rows[N];
 };
 
 struct fz_graph {

@@ -21,6 +21,7 @@
 // D <= 16 uses a thread-per-polynomial kernel (all twiddles uniform).
 #include "fz_internal.h"
 #include "../../include/fusion_hip.h"
+#include "../../include/fusion_hip_diag.h"
 #include <hip/hip_ext.h>
 
 namespace {
@@ -109,14 +110,21 @@ __device__ __forceinline__ double tw_mul(double a, double w, double w2, const Fz
 // ------------------------------------------------------------------------------------------
 // forward: strided pass -> transpose -> contiguous pass
 // ------------------------------------------------------------------------------------------
+// doubles of LDS a workgroup of the 16-per-lane kernels needs: a transpose region per wave + the per-lane twiddle table
+template <int LOGD> constexpr int lds16_doubles() {
+    using G = Geom<LOGD>;
+    return kWavesPerBlock * G::PPW * G::PS + 2 * G::NE * G::L;
+}
+
+// the whole forward kernel as a function of (block index, blocks that share the batch): ntt_fwd16 runs it over the grid,
+// ntt_jobs16 over the run of workgroups a job owns
 template <int LOGD, bool FAST>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd16(const int32_t *in, int32_t *out, size_t batch,
-                                                                 const double2 *__restrict__ twB, FzTwA twA, FzMod m) {
+__device__ __forceinline__ void fwd16_run(const int32_t *in, int32_t *out, size_t batch, unsigned block, unsigned nblocks, double *lds,
+                                          const double2 *__restrict__ twB, const FzTwA &twA, const FzMod &m) {
     using G = Geom<LOGD>;
     constexpr int D = G::D, L = G::L, PPW = G::PPW, SB = G::SB, NE = G::NE, PS = G::PS;
     constexpr int REGION = PPW * PS;                      // doubles per wave
     static_assert(REGION * 2 >= kStageWords, "staging image must fit in the transpose buffer");
-    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * REGION + 2 * NE * L];
     double2 *s_tw = reinterpret_cast<double2 *>(lds + kWavesPerBlock * REGION);      // (w, w2) pairs, [NE][L]
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
@@ -129,8 +137,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd16(const int32_t *
 
     const size_t total = batch * D;
     const size_t tasks = (total + kChunk - 1) / kChunk;
-    const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave;
-    const size_t stride = (size_t)gridDim.x * kWavesPerBlock;
+    const size_t first = (size_t)block * kWavesPerBlock + wave;
+    const size_t stride = (size_t)nblocks * kWavesPerBlock;
     if (first >= tasks) return;
     // Software pipeline.  gfx9 has ONE in-order counter (vmcnt) for loads and stores, so a wait for a
     // prefetched load also waits for every store issued before... and, at a loop header, the compiler must
@@ -231,16 +239,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd16(const int32_t *
     }
 }
 
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_fwd16(const int32_t *in, int32_t *out, size_t batch,
+                                                                 const double2 *__restrict__ twB, FzTwA twA, FzMod m) {
+    __shared__ __attribute__((aligned(16))) double lds[lds16_doubles<LOGD>()];
+    fwd16_run<LOGD, FAST>(in, out, batch, blockIdx.x, gridDim.x, lds, twB, twA, m);
+}
+
 // ------------------------------------------------------------------------------------------
 // inverse: contiguous pass -> transpose -> strided pass (n^{-1} folded into the last stage)
 // ------------------------------------------------------------------------------------------
 template <int LOGD, bool FAST>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *in, int32_t *out, size_t batch,
-                                                                 const double2 *__restrict__ itwB, FzTwA twA, FzMod m) {
+__device__ __forceinline__ void inv16_run(const int32_t *in, int32_t *out, size_t batch, unsigned block, unsigned nblocks, double *lds,
+                                          const double2 *__restrict__ itwB, const FzTwA &twA, const FzMod &m) {
     using G = Geom<LOGD>;
     constexpr int D = G::D, L = G::L, PPW = G::PPW, SB = G::SB, NE = G::NE, PS = G::PS;
     constexpr int REGION = PPW * PS;
-    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * REGION + 2 * NE * L];
     double2 *s_tw = reinterpret_cast<double2 *>(lds + kWavesPerBlock * REGION);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
@@ -253,15 +267,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
 
     const size_t total = batch * D;
     const size_t tasks = (total + kChunk - 1) / kChunk;
-    const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave;
-    const size_t stride = (size_t)gridDim.x * kWavesPerBlock;
+    const size_t first = (size_t)block * kWavesPerBlock + wave;
+    const size_t stride = (size_t)nblocks * kWavesPerBlock;
     if (first >= tasks) return;
     {
         const Chunk raw0 = chunk_load(in, first, total, lane);
         chunk_to_lds(stage, lane, raw0);
     }
 
-    for (size_t task = first; task < tasks; task += stride) {       // pipeline: see ntt_fwd16
+    for (size_t task = first; task < tasks; task += stride) {       // pipeline: see fwd16_run
         const bool more = task + stride < tasks;
         const Chunk raw = chunk_load(in, more ? task + stride : task, total, lane);
         wave_sync();
@@ -345,6 +359,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *
             if (base + 768 < total) nt_store4(out + base + 768, o3);
         }
     }
+}
+
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_inv16(const int32_t *in, int32_t *out, size_t batch,
+                                                                 const double2 *__restrict__ itwB, FzTwA twA, FzMod m) {
+    __shared__ __attribute__((aligned(16))) double lds[lds16_doubles<LOGD>()];
+    inv16_run<LOGD, FAST>(in, out, batch, blockIdx.x, gridDim.x, lds, itwB, twA, m);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -652,49 +673,114 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_inv4(const int32_t *in, int32_
 // (profiles/r03_ntt_small_batches.txt) -- a forward job and an inverse job of 4096 rows in one launch is the software-pipelined
 // form of BASELINE configs[1]'s step (forward of batch i+1 beside the inverse of batch i), so that gap was the headline's.
 // ------------------------------------------------------------------------------------------
-// JT: FzJobs4 (a launch of at most four jobs: 96 bytes of table) or FzMultiJobs (up to 32)
+// which job a workgroup belongs to: first / last = the run of workgroups [first, last) the job owns, rw = its rows (bit 31:
+// inverse), in / out its buffers
+template <typename JT>
+__device__ __forceinline__ void pick_job(const JT &J, const unsigned b, unsigned &first, unsigned &last, unsigned &rw,
+                                         const int32_t *&in, int32_t *&out) {
+    constexpr int NJ = JT::kJobs;
+    first = 0;
+    if constexpr (NJ <= 8) {
+        // The job WITHOUT a dependent load: every table entry is requested together with everything else the workgroup
+        // reads from the kernel arguments and the job is picked by scalar selects (a scan would be a chain of scalar-load
+        // round trips in front of the first data load: one job through a scanning kernel cost 5.0 us against 4.2 for
+        // ntt_fwd4; round 4 did this for four entries and scanned from the fifth on, round 5's headline launch has eight).
+        // Entries past the last job hold the launch's total, so they are never chosen.
+        unsigned e[NJ], r[NJ];
+        const int32_t *ip[NJ];
+        int32_t *op[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            e[j] = J.end[j]; r[j] = J.rows[j]; ip[j] = J.in[j]; op[j] = J.out[j];
+            // (opaque to the optimiser: it would otherwise turn the selects below into branches that load only the chosen
+            // entry -- the dependent load this path exists to avoid)
+            asm volatile("" : "+s"(e[j]), "+s"(r[j]), "+s"(ip[j]), "+s"(op[j]));
+        }
+        rw = r[0]; in = ip[0]; out = op[0]; last = e[0];
+#pragma unroll
+        for (int j = 1; j < NJ; ++j) {
+            const bool g = b >= e[j - 1];                               // (ends never decrease: the last true one wins)
+            first = g ? e[j - 1] : first;
+            last = g ? e[j] : last;
+            rw = g ? r[j] : rw;
+            in = g ? ip[j] : in;
+            out = g ? op[j] : out;
+        }
+    } else {
+        // Larger tables would not fit the scalar registers (32 entries = 192 of them): the workgroup counts of ALL jobs come
+        // with the first request (32 dwords), the job's index is found by scalar compares, and its three other entries are
+        // ONE dependent round of scalar loads -- instead of a scan's one round trip per job passed.
+        unsigned mask = 0;
+#pragma unroll
+        for (int k = 0; k < NJ - 1; ++k) {
+            const unsigned ek = J.end[k];
+            const bool g = b >= ek;
+            first = g ? ek : first;                                     // (ends never decrease: the last true one wins)
+            mask |= g ? (1u << k) : 0u;
+        }
+        const unsigned j = __builtin_amdgcn_readfirstlane(__builtin_popcount(mask));
+        rw = J.rows[j]; in = J.in[j]; out = J.out[j]; last = J.end[j];
+    }
+}
+
+// JT: FzJobsN<4 | 8 | 32> -- the table of a launch of at most that many jobs (24 bytes of kernel arguments per entry).
+// `stamp` (diagnostics, NULL otherwise): one {entry, exit} pair of the 100 MHz reference counter per WORKGROUP, written by
+// the workgroup's first wave after its stores have left (fz_diag_stamps_*): the chip's own record of when a launch ran,
+// which no profiler serialises.
 template <int LOGD, bool FAST, int NR, int WAVES, typename JT>
 __global__ __launch_bounds__(64 * WAVES) void ntt_jobs4(JT J, const double2 *__restrict__ tw2, const double2 *__restrict__ itw2,
-                                                        FzTw4 twA, FzTw4 itwA, FzMod m) {
-    constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP;
+                                                        FzTw4 twA, FzTw4 itwA, FzMod m, unsigned long long *stamp) {
+    constexpr int D = 1 << LOGD, LP = D / 4, PPW = 64 / LP, NJ = JT::kJobs;
     __shared__ __attribute__((aligned(16))) double lds[WAVES * NR * 256];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int p = lane / LP, mm = lane % LP;
     double *region = lds + wave * NR * 256 + p * D;
-    // The first four jobs without a dependent load: their table entries are requested together with everything else the
-    // workgroup reads from the kernel arguments and the job is picked by scalar selects (a scan would be a chain of scalar-load
-    // round trips in front of the first data load: one job through this kernel cost 5.0 us against 4.2 for ntt_fwd4).  Entries
-    // past the last job hold the launch's total, so a launch of <= 4 jobs never leaves this path.
-    const unsigned b = blockIdx.x, e0 = J.end[0], e1 = J.end[1], e2 = J.end[2], e3 = J.end[3];
-    unsigned r0 = J.rows[0], r1 = J.rows[1], r2 = J.rows[2], r3 = J.rows[3];
-    const int32_t *i0 = J.in[0], *i1 = J.in[1], *i2 = J.in[2], *i3 = J.in[3];
-    int32_t *o0 = J.out[0], *o1 = J.out[1], *o2 = J.out[2], *o3 = J.out[3];
-    // (opaque to the optimiser: it would otherwise turn the selects below into branches that load only the chosen entry --
-    // the dependent load this path exists to avoid)
-    asm volatile("" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3));
-    asm volatile("" : "+s"(i0), "+s"(i1), "+s"(i2), "+s"(i3));
-    asm volatile("" : "+s"(o0), "+s"(o1), "+s"(o2), "+s"(o3));
-    const bool g0 = b >= e0, g1 = b >= e1, g2 = b >= e2;
-    unsigned first = g2 ? e2 : (g1 ? e1 : (g0 ? e0 : 0u));
-    unsigned rw = g2 ? r3 : (g1 ? r2 : (g0 ? r1 : r0));
-    const int32_t *in = g2 ? i3 : (g1 ? i2 : (g0 ? i1 : i0));
-    int32_t *out = g2 ? o3 : (g1 ? o2 : (g0 ? o1 : o0));
-    if constexpr (!__is_same(JT, FzJobs4)) {
-        if (b >= e3) {                                                // job 4 or later: the scan
-            int j = 4;
-            while (b >= J.end[j]) ++j;                                // workgroup-uniform, <= 32 entries
-            first = J.end[j - 1];
-            rw = J.rows[j];
-            in = J.in[j];
-            out = J.out[j];
-        }
-    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // (unconditional: a branch on `stamp` here would put a scalar-load round trip in front of everything else)
+    unsigned first, last, rw;
+    const int32_t *in;
+    int32_t *out;
+    pick_job(J, blockIdx.x, first, last, rw, in, out);
     const size_t rows = rw & 0x7fffffffu;
     const bool inverse = (rw >> 31) != 0;
     const size_t task = (size_t)(blockIdx.x - first) * WAVES + wave;
-    if (task * (NR * PPW) >= rows) return;
+    if (task * (NR * PPW) >= rows) return;                              // (never a workgroup's first wave: the grid is cut to whole tasks)
     if (inverse) inv4_task<LOGD, FAST, NR>(in, out, rows, task * (NR * PPW) + p, region, mm, itw2, itwA, m);
     else fwd4_task<LOGD, FAST, NR>(in, out, rows, task * (NR * PPW) + p, region, mm, tw2, twA, m);
+    if (stamp && wave == 0) {
+        __builtin_amdgcn_s_waitcnt(0);                                  // this wave's stores have been acknowledged
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            stamp[2 * (size_t)blockIdx.x] = t0;
+            stamp[2 * (size_t)blockIdx.x + 1] = t1;
+        }
+    }
+}
+
+// The same job table served by the 16-per-lane kernels (round 5): a launch of 2^16 rows and more -- the headline's eight
+// forward + eight inverse batches of 4096 -- is past the point where the radix-4 wave-tasks lead (one job: 25.5 us against
+// 30 us at 65 536 rows).  A job owns a run of workgroups; the run IS a grid of ntt_fwd16 or ntt_inv16 over the job's batch
+// (resident workgroups striding over 4 KiB chunks, next chunk prefetched into registers), sized by the launcher in
+// proportion to the job's share of the launch.
+template <int LOGD, bool FAST, typename JT>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_jobs16(JT J, const double2 *__restrict__ twB, const double2 *__restrict__ itwB,
+                                                                  FzTwA twA, FzTwA itwA, FzMod m, unsigned long long *stamp) {
+    __shared__ __attribute__((aligned(16))) double lds[lds16_doubles<LOGD>()];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned first, last, rw;
+    const int32_t *in;
+    int32_t *out;
+    pick_job(J, blockIdx.x, first, last, rw, in, out);
+    const size_t rows = rw & 0x7fffffffu;
+    if ((rw >> 31) != 0) inv16_run<LOGD, FAST>(in, out, rows, blockIdx.x - first, last - first, lds, itwB, itwA, m);
+    else fwd16_run<LOGD, FAST>(in, out, rows, blockIdx.x - first, last - first, lds, twB, twA, m);
+    if (stamp && threadIdx.x < 64) {                                    // fz_diag_stamps_*: see ntt_jobs4
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            stamp[2 * (size_t)blockIdx.x] = t0;
+            stamp[2 * (size_t)blockIdx.x + 1] = t1;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1434,7 +1520,25 @@ int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch
     }
 }
 
+// fz_diag_stamps_*: a launch's workgroups get a run of {entry, exit} slots (NULL: stamps off, or the recording is full)
+static unsigned long long *stamp_slots(fz_ctx *ctx, unsigned total) {
+    if (!ctx->stamp_on || ctx->stamp_n >= ctx->stamp_launch_cap || ctx->stamp_used + total > ctx->stamp_wg_cap) return nullptr;
+    unsigned long long *stamp = ctx->d_stamp + 2 * ctx->stamp_used;
+    ctx->stamp_first[ctx->stamp_n] = ctx->stamp_used;
+    ctx->stamp_count[ctx->stamp_n++] = total;
+    ctx->stamp_used += total;
+    return stamp;
+}
+
 // one launch over a job table (at most kFzMultiMax jobs, degree 64 / 256)
+template <int LOGD, bool FAST, int NR, int WAVES, int NJ>
+static void launch_jobs_n(fz_ctx *ctx, const FzMultiJobs &J, unsigned total, hipEvent_t e0, hipEvent_t e1, unsigned long long *stamp) {
+    FzJobsN<NJ> S;
+    for (int j = 0; j < NJ; ++j) { S.in[j] = J.in[j]; S.out[j] = J.out[j]; S.end[j] = J.end[j]; S.rows[j] = J.rows[j]; }
+    hipExtLaunchKernelGGL((ntt_jobs4<LOGD, FAST, NR, WAVES, FzJobsN<NJ>>), dim3(total), dim3(64 * WAVES), 0, ctx->stream, e0, e1, 0, S,
+                          (const double2 *)ctx->d_tw2, (const double2 *)ctx->d_itw2, fz_tw4(ctx->twA), fz_tw4(ctx->itwA), ctx->mod, stamp);
+}
+
 template <int LOGD, bool FAST, int NR, int WAVES>
 static void launch_jobs(fz_ctx *ctx, FzMultiJobs &J, hipEvent_t e0, hipEvent_t e1) {
     constexpr unsigned PPW = 64 / ((1 << LOGD) / 4);
@@ -1445,16 +1549,44 @@ static void launch_jobs(fz_ctx *ctx, FzMultiJobs &J, hipEvent_t e0, hipEvent_t e
         total += (tasks + WAVES - 1) / WAVES;
         J.end[j] = total;
     }
-    for (int j = J.n; j < kFzMultiMax; ++j) J.end[j] = total;           // (the kernel's four-job fast path relies on it)
-    if (J.n <= 4) {
-        FzJobs4 S;
-        for (int j = 0; j < 4; ++j) { S.in[j] = J.in[j]; S.out[j] = J.out[j]; S.end[j] = J.end[j]; S.rows[j] = J.rows[j]; }
-        hipExtLaunchKernelGGL((ntt_jobs4<LOGD, FAST, NR, WAVES, FzJobs4>), dim3(total), dim3(64 * WAVES), 0, ctx->stream, e0, e1, 0, S,
-                              (const double2 *)ctx->d_tw2, (const double2 *)ctx->d_itw2, fz_tw4(ctx->twA), fz_tw4(ctx->itwA), ctx->mod);
-    } else {
-        hipExtLaunchKernelGGL((ntt_jobs4<LOGD, FAST, NR, WAVES, FzMultiJobs>), dim3(total), dim3(64 * WAVES), 0, ctx->stream, e0, e1, 0, J,
-                              (const double2 *)ctx->d_tw2, (const double2 *)ctx->d_itw2, fz_tw4(ctx->twA), fz_tw4(ctx->itwA), ctx->mod);
+    for (int j = J.n; j < kFzMultiMax; ++j) { J.end[j] = total; J.rows[j] = 0; J.in[j] = nullptr; J.out[j] = nullptr; }   // (never chosen: see the kernel)
+    unsigned long long *stamp = stamp_slots(ctx, total);
+    if (J.n <= 4) launch_jobs_n<LOGD, FAST, NR, WAVES, 4>(ctx, J, total, e0, e1, stamp);
+    else if (J.n <= 8) launch_jobs_n<LOGD, FAST, NR, WAVES, 8>(ctx, J, total, e0, e1, stamp);
+    else launch_jobs_n<LOGD, FAST, NR, WAVES, kFzMultiMax>(ctx, J, total, e0, e1, stamp);
+}
+
+// the 16-per-lane form of a multi-job launch: job j gets min(its workgroups, its share of the resident grid) workgroups
+template <int LOGD, bool FAST, int NJ>
+static void launch_jobs16_n(fz_ctx *ctx, const FzMultiJobs &J, unsigned total, hipEvent_t e0, hipEvent_t e1, unsigned long long *stamp) {
+    FzJobsN<NJ> S;
+    for (int j = 0; j < NJ; ++j) { S.in[j] = J.in[j]; S.out[j] = J.out[j]; S.end[j] = J.end[j]; S.rows[j] = J.rows[j]; }
+    hipExtLaunchKernelGGL((ntt_jobs16<LOGD, FAST, FzJobsN<NJ>>), dim3(total), dim3(64 * kWavesPerBlock), 0, ctx->stream, e0, e1, 0, S,
+                          (const double2 *)ctx->d_twB, (const double2 *)ctx->d_itwB, ctx->twA, ctx->itwA, ctx->mod, stamp);
+}
+
+template <int LOGD, bool FAST>
+static int launch_jobs16(fz_ctx *ctx, FzMultiJobs &J, hipEvent_t e0, hipEvent_t e1) {
+    constexpr size_t D = (size_t)1 << LOGD;
+    size_t all_tasks = 0;
+    for (int j = 0; j < J.n; ++j) all_tasks += ((J.rows[j] & 0x7fffffffu) * D + kChunk - 1) / kChunk;
+    const size_t cap = (size_t)std::min(ctx->grid_fwd, ctx->grid_inv);      // workgroups the chip holds at once
+    unsigned total = 0;
+    for (int j = 0; j < J.n; ++j) {
+        const size_t tasks = ((J.rows[j] & 0x7fffffffu) * D + kChunk - 1) / kChunk;
+        const size_t blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+        size_t share = (cap * tasks + all_tasks - 1) / all_tasks;            // proportional, rounded up, at least one
+        if (share < 1) share = 1;
+        total += (unsigned)(tasks ? std::min(blocks, share) : 0);
+        J.end[j] = total;
     }
+    for (int j = J.n; j < kFzMultiMax; ++j) { J.end[j] = total; J.rows[j] = 0; J.in[j] = nullptr; J.out[j] = nullptr; }
+    if (total == 0) return FZ_OK;
+    unsigned long long *stamp = stamp_slots(ctx, total);
+    if (J.n <= 4) launch_jobs16_n<LOGD, FAST, 4>(ctx, J, total, e0, e1, stamp);
+    else if (J.n <= 8) launch_jobs16_n<LOGD, FAST, 8>(ctx, J, total, e0, e1, stamp);
+    else launch_jobs16_n<LOGD, FAST, kFzMultiMax>(ctx, J, total, e0, e1, stamp);
+    return fz_check_hip(hipGetLastError(), "ntt_jobs16 launch");
 }
 
 template <int LOGD, bool FAST>
@@ -1464,6 +1596,20 @@ static int launch_jobs_f(fz_ctx *ctx, FzMultiJobs &J) {
     for (int j = 0; j < J.n; ++j) waves1 += ((J.rows[j] & 0x7fffffffu) + PPW - 1) / PPW;
     if (waves1 == 0) return FZ_OK;
     if (waves1 > 0x7fffffffull) return fz_set_error(FZ_E_UNSUPPORTED, "too many rows for one multi-job launch");
+    // the schedule by the launch's TOTAL rows, as for one job (launch16): the 16-per-lane kernels from `small_batch_rows` on
+    // (FZ_NTT_KERNEL forces either)
+    size_t all_rows = 0;
+    for (int j = 0; j < J.n; ++j) all_rows += J.rows[j] & 0x7fffffffu;
+    const bool big = ctx->force_kernel == 16 || (ctx->force_kernel == 0 && all_rows >= (size_t)ctx->small_batch_rows);
+    if (big) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->prof_on && ctx->prof_n < ctx->prof_cap && (ctx->prof_seen[0]++ % ctx->prof_every) == 0) {
+            e0 = ctx->prof_ev[2 * ctx->prof_n];
+            e1 = ctx->prof_ev[2 * ctx->prof_n + 1];
+            ctx->prof_kind[ctx->prof_n++] = 2;
+        }
+        return launch_jobs16<LOGD, FAST>(ctx, J, e0, e1);
+    }
     // the same launch shapes, by the same rule, as the one-job kernels (launch4f): rows per wave by the launch's total
     int nr = ctx->knob_ntt_rows;
     if (nr != 1 && nr != 2 && nr != 4) nr = waves1 <= (size_t)24 * ctx->num_cu ? 1 : (waves1 <= (size_t)48 * ctx->num_cu ? 2 : 4);

@@ -7,8 +7,8 @@ top of it.  No CPU fallback exists: without the built library and a gfx950 devic
 compute call raises FusionHipError.
 """
 from ._lib import FusionHipError, LIB_PATH, SIGNATURES, load_library, runtime_report
-from .context import (Comm, Context, DeviceArray, DeviceBuffer, Event, Graph, VERDICT_REASONS, comm_unique_id, get_context, rccl_version,
+from .context import (Comm, Context, DeviceArray, DeviceBuffer, Event, Graph, VERDICT_REASONS, comm_unique_id, get_context, rccl_library, rccl_version,
                       OP_ADD, OP_MUL, OP_NEG, OP_SUB)
 
 __all__ = ["Comm", "Context", "DeviceArray", "DeviceBuffer", "Event", "FusionHipError", "Graph", "LIB_PATH", "SIGNATURES",
-           "VERDICT_REASONS", "comm_unique_id", "get_context", "rccl_version", "load_library", "runtime_report", "OP_ADD", "OP_MUL", "OP_NEG", "OP_SUB"]
+           "VERDICT_REASONS", "comm_unique_id", "get_context", "rccl_library", "rccl_version", "load_library", "runtime_report", "OP_ADD", "OP_MUL", "OP_NEG", "OP_SUB"]

@@ -1,4 +1,4 @@
-"""ctypes binding of libfusion_hip.so (C ABI declared in include/fusion_hip.h).
+"""ctypes binding of libfusion_hip.so (C ABI declared in include/fusion_hip.h; diagnostics in include/fusion_hip_diag.h).
 
 The shared object is built in-tree by ``__graft_entry__.build()`` into
 ``fusion-cryptography_amd/lib/``.  There is NO CPU fallback: if the library or a GPU is
@@ -196,6 +196,19 @@ SIGNATURES.update({
     "fz_pinned_free": (c_int, [c_void_p]),
 })
 
+# include/fusion_hip_diag.h (timers, per-dispatch profiling, probes, device-side timestamps, runtime / library reports):
+# the same table serves both headers; DIAG_NAMES says which entries are diagnostics (tests/test_cabi_symbols.py)
+SIGNATURES.update({
+    "fz_rccl_library": (c_int, [c_char_p, c_size_t, c_char_p, c_size_t, POINTER(c_int)]),
+    "fz_diag_stamps_begin": (c_int, [_ctx, c_size_t, c_size_t]),
+    "fz_diag_stamps_stop": (c_int, [_ctx]),
+    "fz_diag_stamps_reset": (c_int, [_ctx]),
+    "fz_diag_stamps_read": (c_int, [_ctx, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint32), c_size_t,
+                                    POINTER(c_size_t)]),
+})
+DIAG_NAMES = frozenset(n for n in SIGNATURES if n.startswith(("fz_diag_", "fz_profile_", "fz_timer_")) or
+                       n in ("fz_runtime_info", "fz_keccak_variant", "fz_rccl_library"))
+
 _lib = None
 
 
@@ -263,14 +276,18 @@ def _prefer_torch_hip_runtime():
 
 
 def runtime_report():
-    """-> dict: which HIP runtime serves libfusion_hip.so in this process and why (paths of the mapped libamdhip64 copies)"""
-    maps = []
+    """-> dict: which HIP runtime serves libfusion_hip.so in this process and why (paths of the mapped libamdhip64 copies),
+    and which librccl files are mapped (nothing is bound for the question: fusion_hip.rccl_library() says which one fz_comm_*
+    uses).  More than one path in either list = two copies of that library in one process."""
+    hip, rccl = [], []
     try:
         with open("/proc/self/maps") as fh:
-            maps = sorted({ln.split()[-1] for ln in fh if "libamdhip64" in ln})
+            paths = {ln.split()[-1] for ln in fh if "/" in ln}
+        hip = sorted(p for p in paths if "libamdhip64" in p)
+        rccl = sorted(p for p in paths if "librccl" in p)
     except OSError:
         pass
-    return dict(RUNTIME_CHOICE, mapped_libamdhip64=maps)
+    return dict(RUNTIME_CHOICE, mapped_libamdhip64=hip, mapped_librccl=rccl)
 
 
 def load_library(path=None):

@@ -181,6 +181,26 @@ class Context:
         """one wave that occupies this context's stream for `microseconds` (asynchronous, capturable)"""
         check(self._lib, self._lib.fz_diag_delay(self._h, int(microseconds)))
 
+    def diag_stamps_begin(self, max_launches, max_workgroups):
+        """device-side launch timestamps of fz_ntt_multi (include/fusion_hip_diag.h): slots for launches issued or captured from now on"""
+        check(self._lib, self._lib.fz_diag_stamps_begin(self._h, int(max_launches), int(max_workgroups)))
+
+    def diag_stamps_stop(self):
+        check(self._lib, self._lib.fz_diag_stamps_stop(self._h))
+
+    def diag_stamps_reset(self):
+        check(self._lib, self._lib.fz_diag_stamps_reset(self._h))
+
+    def diag_stamps_read(self, cap):
+        """-> (start, end, last_start, workgroups): uint64 ticks of the chip's 100 MHz reference counter per recorded launch"""
+        st, en, ls = (np.zeros(cap, dtype=np.uint64) for _ in range(3))
+        wg = np.zeros(cap, dtype=np.uint32)
+        n = ctypes.c_size_t()
+        u64p, u32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)
+        check(self._lib, self._lib.fz_diag_stamps_read(self._h, st.ctypes.data_as(u64p), en.ctypes.data_as(u64p), ls.ctypes.data_as(u64p),
+                                                       wg.ctypes.data_as(u32p), cap, byref(n)))
+        return st[:n.value], en[:n.value], ls[:n.value], wg[:n.value]
+
     def reduce_scatter_i64_dev(self, comm, d_buf, count_per_rank):
         """in-place ncclReduceScatter(int64, sum) on this context's stream: block `rank` of the summed buffer arrives in block
         `rank` of d_buf (nranks blocks of count_per_rank elements); the other blocks are undefined afterwards"""
@@ -516,8 +536,18 @@ def rccl_version():
     return v.value
 
 
+def rccl_library():
+    """-> dict(path, how, copies_mapped): which RCCL file serves fz_comm_* in this process, by which rule it was found
+    ("already mapped (shared)" | "beside the HIP runtime" | "default search path") and how many different librccl files the
+    process has mapped (2 = two RCCLs in one process).  Binds RCCL if nothing has yet."""
+    lib = load_library()
+    path, how, n = ctypes.create_string_buffer(512), ctypes.create_string_buffer(64), c_int()
+    check(lib, lib.fz_rccl_library(path, 512, how, 64, byref(n)))
+    return {"path": path.value.decode(), "how": how.value.decode(), "copies_mapped": n.value}
+
+
 class Comm:
-    """An RCCL communicator owned through the C ABI (fz_comm_*): one per process / GPU."""
+    """An RCCL communicator owned through the C ABI (fz_comm_*).  destroy() is idempotent (so is fz_comm_destroy itself)."""
 
     def __init__(self, ctx, nranks, rank, unique_id):
         self._lib = ctx._lib

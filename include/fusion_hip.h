@@ -22,6 +22,10 @@
  *  - Kernels are enqueued on the context's stream (fz_ctx_set_stream) and the device
  *    entry points do NOT synchronise; *_host entry points return after completion.
  *  - One context is used by one host thread at a time (one context + stream per GPU).
+ *
+ * Timers, per-dispatch profiling, launch-floor probes, device-side launch timestamps and runtime / library
+ * reports are NOT part of this surface: they live in fusion_hip_diag.h (same library, same conventions) and
+ * are what bench.py and tools/ use; a reference maintainer binds this header only.
  */
 #ifndef FUSION_HIP_H
 #define FUSION_HIP_H
@@ -83,10 +87,6 @@ FZ_API int fz_stream_create_priority(fz_ctx *ctx, int high, void **out_stream);
  * equal to bit_reverse_copy([pow(root,i,q)]) / ([pow(inv_root,i,q)]). Either may be NULL. */
 FZ_API int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv);
 
-/* HIP version the library was built with and the one of the runtime it is bound to (e.g. 70200000 / 70051831), plus the
- * device's gcnArchName: which libamdhip64 a process ended up with is not always the one it was linked against. */
-FZ_API int fz_runtime_info(fz_ctx *ctx, int *out_build_hip_version, int *out_runtime_hip_version, char *out_arch, size_t arch_cap);
-
 /* ---- graph capture --------------------------------------------------------------------------
  * The reference runs its algebra as a long sequence of small calls (one cooley_tukey_ntt /
  * gentleman_sande_intt per polynomial: fusion/fusion.py:363-370, :557, :670-676); at the batch sizes
@@ -136,20 +136,6 @@ FZ_API int fz_free(fz_ctx *ctx, void *d_ptr);
 FZ_API int fz_pool_trim(fz_ctx *ctx, size_t keep_bytes);
 FZ_API int fz_memcpy_h2d(fz_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* async on ctx stream */
 FZ_API int fz_memcpy_d2h(fz_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* returns after completion */
-
-/* ---- timing on the context's stream (hipEvent based) ----------------------------------- */
-FZ_API int fz_timer_start(fz_ctx *ctx);
-FZ_API int fz_timer_stop_ms(fz_ctx *ctx, float *out_ms);        /* records, waits, returns elapsed ms */
-
-/* per-dispatch timing of the transform kernels: while enabled, every `sample_every`-th
- * fz_ntt_forward / fz_ntt_inverse / fz_ntt_multi launch carries a start/stop event pair bound to the dispatch
- * (kernel begin -> kernel end on the context's stream; at most max_launches pairs).
- * fz_profile_end synchronises and returns the average durations in microseconds. */
-FZ_API int fz_profile_begin(fz_ctx *ctx, int max_launches, int sample_every);
-FZ_API int fz_profile_end(fz_ctx *ctx, double *fwd_avg_us, int *fwd_count, double *inv_avg_us, int *inv_count);
-/* the same, every sample: us[k] the duration of the k-th instrumented launch, kind[k] 0 = forward, 1 = inverse,
- * 2 = a multi-job launch (fz_ntt_multi) */
-FZ_API int fz_profile_end_samples(fz_ctx *ctx, double *us, int *kind, int cap, int *n);
 
 /* ---- transforms ---------------------------------------------------------------------------
  * fz_ntt_forward: cooley_tukey_ntt (algebra/ntt.py:216-291) on `batch` rows.
@@ -348,21 +334,6 @@ FZ_API int fz_reduce_scatter_i64(fz_ctx *ctx, fz_comm *comm, int64_t *d_buf, siz
  * (fusion_hip.dist.ShardedScheme, alpha_mode "root") */
 FZ_API int fz_broadcast_i32(fz_ctx *ctx, fz_comm *comm, int32_t *d_buf, size_t count, int root);
 
-/* ---- launch-floor diagnostics (benchmarks) ---------------------------------------------------------------------
- * An empty 4096-workgroup dispatch and a plain 16-byte-per-lane copy on the context's stream: the two floors a
- * small-batch transform launch is judged against (bench.py reports them from the same run as the transforms). */
-FZ_API int fz_diag_empty_launch(fz_ctx *ctx);
-FZ_API int fz_diag_copy(fz_ctx *ctx, const void *d_src, void *d_dst, size_t bytes);
-/* The shader clock the chip actually holds while the work already queued on the context's stream executes: one wave on a
- * private stream compares the shader cycle counter with the 100 MHz reference counter for `microseconds`, then the call
- * returns (synchronous).  The fp64-dense fused kernels run power-limited well below the nominal 2.4 GHz; a vector-issue
- * roofline has to be priced at THIS clock (profiles/README.md, round 3). */
-FZ_API int fz_diag_shader_clock(fz_ctx *ctx, unsigned microseconds, double *out_mhz);
-/* one wave that occupies the context's stream for `microseconds` (asynchronous, capturable): a stand-in of known duration for
- * a step that cannot be run here -- bench.py uses it in place of the multi-GPU all-reduce to measure, on ONE GPU, how much of
- * an exchange step's latency its second stream hides */
-FZ_API int fz_diag_delay(fz_ctx *ctx, unsigned microseconds);
-
 /* ---- norm / weight of coefficient rows -------------------------------------------------------
  * PolynomialCoefficientRepresentation.norm("infty") / weight(), algebra/polynomials.py:221-227:
  * max |x| over the STORED values and #{x : x mod q != 0}, per row. */
@@ -386,9 +357,6 @@ typedef struct fz_scheme_params {
     uint8_t sign_pre_hash_dst[2], sign_hash_dst[2], agg_xof_dst[2];
 } fz_scheme_params;
 
-/* which Keccak-f[1600] the host sponges run: "scalar", "bmi2" or "avx512" -- the fastest this CPU supports, measured once when
- * the library is loaded (FZ_KECCAK=<name> forces one); every variant is checked against the scalar one before it can be chosen */
-FZ_API const char *fz_keccak_variant(void);
 FZ_API int fz_sha3_256(const uint8_t *h_data, size_t len, uint8_t *h_out32);
 FZ_API int fz_shake256(const uint8_t *h_data, size_t len, uint8_t *h_out, size_t out_len);
 /* str(OneTimeVerificationKey) (fusion.py:328-329 -> matrices.py:40-41 -> polynomials.py:257-258) of a key

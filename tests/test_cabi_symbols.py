@@ -1,5 +1,6 @@
 """The C-ABI shared object loads on a CPU-only machine and exports exactly the symbols that
-include/fusion_hip.h declares (no compute calls here: those need a GPU)."""
+include/fusion_hip.h (the surface a reference maintainer binds) and include/fusion_hip_diag.h (timers, profiling, probes,
+reports: what bench.py and tools/ use) declare (no compute calls here: those need a GPU)."""
 import ctypes
 import os
 import re
@@ -9,6 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "fusion_hip.h")
+DIAG_HEADER = os.path.join(ROOT, "include", "fusion_hip_diag.h")
 
 
 @pytest.fixture(scope="module")
@@ -19,9 +21,23 @@ def lib():
     return fusion_hip.load_library()
 
 
+def declared_in(path):
+    return sorted(set(re.findall(r"FZ_API\s+[\w\s\*]+?\b(fz_\w+)\s*\(", open(path).read())))
+
+
 def declared_symbols():
-    text = open(HEADER).read()
-    return sorted(set(re.findall(r"FZ_API\s+[\w\s\*]+?\b(fz_\w+)\s*\(", text)))
+    return sorted(set(declared_in(HEADER)) | set(declared_in(DIAG_HEADER)))
+
+
+def test_diagnostics_live_in_their_own_header():
+    """include/fusion_hip.h is the surface INTEGRATION.md documents; timers, per-dispatch profiling, probes and
+    runtime reports are declared in include/fusion_hip_diag.h only, and the ctypes table knows which is which"""
+    import fusion_hip
+    main, diag = set(declared_in(HEADER)), set(declared_in(DIAG_HEADER))
+    assert not main & diag
+    assert diag == set(fusion_hip._lib.DIAG_NAMES)
+    assert not [n for n in main if n.startswith(("fz_diag_", "fz_profile_", "fz_timer_"))]
+    assert "fz_runtime_info" in diag and "fz_keccak_variant" in diag and "fz_rccl_library" in diag
 
 
 def test_header_declares_the_documented_surface():

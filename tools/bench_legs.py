@@ -353,7 +353,7 @@ def multi_job(e):
         return None
     torch, ctx, B, d = e.torch, e.ctx, e.B, e.d
     multi = {}
-    for jobs in (1, 2, 4, 8):
+    for jobs in (1, 2, 4, 8, 16, 32):
         res = {}
         # rotate through the headline's batches in groups of `jobs`: cold inputs
         groups = [list(range(g, g + jobs)) for g in range(0, len(e.rot_p) - jobs + 1, jobs)]
@@ -374,7 +374,7 @@ def multi_job(e):
             gbs = jobs * 8.0 * d * B / (ms * 1e-3) / 1e9
             res[name] = {"us_per_launch": round(ms * 1e3, 2), "GB/s": round(gbs, 1), "frac": round(gbs / e.HBM_PEAK_GBS, 4)}
         multi[f"{jobs}x{B}"] = res
-    multi["what"] = ("one fz_ntt_multi dispatch over 1/2/4/8 independent batches of 4096 rows (the job table travels in the "
+    multi["what"] = ("one fz_ntt_multi dispatch over 1/2/4/8/16/32 independent batches of 4096 rows (the job table travels in the "
                      "kernel arguments); back-to-back launches, HIP events on the stream, inputs rotate through the headline's "
                      "64 batches (cold)")
     return multi

@@ -568,7 +568,7 @@ int fz_ctx_twiddles(fz_ctx *ctx, uint32_t *h_fwd, uint32_t *h_inv) {
 // of fz_free, include/fusion_hip.h) finish before its next ones start, whatever fz_ctx_set_stream did in between (which
 // also drains the old stream on every change).  The arrays are guarded by pool_mu.
 // Budget: ONE process-wide cap (FZ_POOL_MB, default 4096) over the pools of all contexts -- sixteen private contexts
-// (tools/concurrent_batches.py) share it instead of stranding 4 GiB each; fz_pool_trim gives a context's blocks back
+// (tools/probes/concurrent_batches.py) share it instead of stranding 4 GiB each; fz_pool_trim gives a context's blocks back
 // (Context.close calls it); a failed hipMalloc flushes the pools of EVERY context on the device before it retries.
 static const size_t kPoolMin = 256 << 10;
 static std::mutex g_ctx_mu;                       // registry of live contexts (fz_ctx_create / fz_ctx_destroy)
@@ -1393,7 +1393,7 @@ int fz_sample_secret_polys_dev(fz_ctx *ctx, const uint64_t *h_seeds, size_t N, i
     // Up to 4096 keys (8192 generators: a seeding wave on every other CU): two kernels -- seeding on a lane per generator,
     // everything after it on a wave per generator, the states (20 MiB at most) through scratch: 54 + 29 us per 1024 keys
     // against 190 in one kernel.  Beyond, the one lane-per-polynomial kernel already has a wave on every CU and the two
-    // forms take the same time (16 384 keys: 0.47 ms one kernel, 0.56 ms in four chunks of two).  FZ_SAMPLER_ONE_KERNEL=1 forces it.
+    // forms take the same time (16 384 keys: 0.47 ms one kernel, 0.56 ms in four chunks of two).
     const bool two_kernels = bound < (1ll << 31) && N <= 4096;
     const size_t seeds_bytes = (N * 8 + 255) & ~(size_t)255, state_bytes = two_kernels ? N * 2 * 624 * sizeof(uint32_t) : 0;
     void *scr = nullptr;

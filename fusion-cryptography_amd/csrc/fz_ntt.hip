@@ -961,7 +961,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
 // are one polynomial, so their transforms are one transform.  fz_keygen_core_bcast (one polynomial per (key, half)) therefore
 // transforms it ONCE per workgroup -- every wave for itself: a transform is cheaper than an exchange -- and the rest is the l
 // stores of the row and the accumulation of A_k (.) y over k: a streaming kernel (85 KiB written per half, A from the L2)
-// instead of l transforms.  Same results as keygen_fused with row stride 0, which FZ_KEYGEN_BCAST_GENERAL=1 still runs.
+// instead of l transforms.  Same results as the three launches other degrees take (rows expanded, transformed, multiplied by
+// A: FZ_UNFUSED=1 runs them at these degrees too; tests/test_gpu_variants.py compares both with the oracle).
 template <int LOGD, bool FAST>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void keygen_bcast_fused(const int32_t *A, const int32_t *coef, int32_t *sk_hat,
                                                                           int32_t *vk, int l, const double2 *__restrict__ tw2,
@@ -1398,8 +1399,8 @@ int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, i
 #undef FZ_KB
         return fz_check_hip(hipGetLastError(), "keygen_bcast_fused launch");
     }
-    const size_t seg_stride = broadcast ? (size_t)ctx->degree : (size_t)l * ctx->degree;
-    const size_t row_stride = broadcast ? 0 : (size_t)ctx->degree;
+    if (broadcast) return fz_set_error(FZ_E_UNSUPPORTED, "one-polynomial keygen: degree 64 or 256 only");    // (other degrees: the caller's three launches)
+    const size_t seg_stride = (size_t)l * ctx->degree, row_stride = (size_t)ctx->degree;
     // integer accumulation is exact for at most 2^15 products per lane (fz_arith.h): longer sums take the fp64 form
     const bool imad_k = !ctx->knob_no_imad && l <= (1 << 15);
 #define FZ_KF2(LOGD, FAST, IM) hipLaunchKernelGGL((keygen_fused<LOGD, FAST, IM>), grid, block, 0, ctx->stream, A, coef, seg_stride, row_stride, sk_hat, vk, l, \

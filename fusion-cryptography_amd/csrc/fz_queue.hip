@@ -39,6 +39,10 @@ struct Batch {                         // device results of one coalesced batch,
     int worker;
     int32_t *d_sk, *d_vk, *d_sig;      // fz_malloc blocks of the worker's context (nullptr: worker scratch, not kept)
     std::atomic<int> refs;
+    // events recorded on CONSUMERS' streams behind their last use of the rows (fz_queue_release_after); the worker's stream
+    // waits for every one of them before the blocks go back to the pool, whose reuse is ordered on the worker's stream only
+    // (guarded by the queue's mutex until the batch is garbage, then the worker's alone)
+    std::vector<hipEvent_t> after;
 };
 
 struct Job {
@@ -111,6 +115,11 @@ int grow(fz_ctx *ctx, int32_t **p, size_t *cap_rows, size_t rows, size_t row_byt
 
 void free_batch(fz_queue *Q, Worker &w, Batch *b) {
     (void)Q;
+    for (hipEvent_t ev : b->after) {                // the consumers' kernels first: fz_free orders reuse behind THIS stream
+        (void)hipStreamWaitEvent((hipStream_t)w.stream, ev, 0);
+        (void)hipEventDestroy(ev);                  // (released by the runtime once the wait above has been satisfied)
+    }
+    b->after.clear();
     if (b->d_sk) (void)fz_free(w.ctx, b->d_sk);
     if (b->d_vk) (void)fz_free(w.ctx, b->d_vk);
     if (b->d_sig) (void)fz_free(w.ctx, b->d_sig);
@@ -122,6 +131,7 @@ int run_batch(fz_queue *Q, Worker &w, std::vector<Job> &jobs, Batch **out_batch,
     const int d = Q->degree, l = Q->l;
     size_t N = 0, msg_bytes = 0;
     bool keep = false, keep_sk = false;
+    row0.reserve(jobs.size());
     for (auto &j : jobs) {
         row0.push_back(N);
         N += j.n;
@@ -233,28 +243,47 @@ void worker_main(fz_queue *Q, int index) {
             b = nullptr;
             rc = fz_set_error(FZ_E_HIP, "queue worker: out of host memory while coalescing %zu calls", jobs.size());
         }
-        const std::string err = rc == FZ_OK ? std::string() : std::string(last_error());
+        // Completion bookkeeping: nothing here may leave the thread as an exception (std::terminate in a library thread --
+        // ADVICE r04).  A record that cannot be stored (out of host memory) is reported through fz_queue_drain's first error
+        // and the call's ticket then reads as finished-with-nothing.
+        std::string err;
+        try {
+            if (rc != FZ_OK) err = last_error();
+        } catch (const std::bad_alloc &) {}
         lk.lock();
         int kept = 0;
         for (size_t k = 0; k < jobs.size(); ++k) {
-            Done dn;
-            dn.status = rc;
-            dn.error = err;
-            dn.batch = nullptr;
-            dn.row0 = row0.size() > k ? row0[k] : 0;
-            dn.n = jobs[k].n;
-            dn.keep_sk = (jobs[k].flags & FZ_QUEUE_KEEP_SK) != 0;
             Q->live.erase(jobs[k].ticket);
             if (jobs[k].flags & FZ_QUEUE_DISCARD) {                 // fire and forget: only a failure is remembered (for fz_queue_drain)
-                if (rc != FZ_OK && Q->first_error == FZ_OK) { Q->first_error = rc; Q->first_error_text = err; }
+                if (rc != FZ_OK && Q->first_error == FZ_OK) {
+                    Q->first_error = rc;
+                    try { Q->first_error_text = err; } catch (const std::bad_alloc &) {}
+                }
                 continue;
             }
-            if (rc == FZ_OK && b) { dn.batch = b; ++kept; }
-            Q->done.emplace(jobs[k].ticket, std::move(dn));
+            try {
+                Done dn;
+                dn.status = rc;
+                dn.error = err;
+                dn.batch = (rc == FZ_OK && b) ? b : nullptr;
+                dn.row0 = row0.size() > k ? row0[k] : 0;
+                dn.n = jobs[k].n;
+                dn.keep_sk = (jobs[k].flags & FZ_QUEUE_KEEP_SK) != 0;
+                Q->done.emplace(jobs[k].ticket, std::move(dn));
+                if (rc == FZ_OK && b) ++kept;
+            } catch (const std::bad_alloc &) {
+                if (Q->first_error == FZ_OK) {
+                    Q->first_error = FZ_E_HIP;
+                    try { Q->first_error_text = "out of host memory while recording a call's result"; } catch (const std::bad_alloc &) {}
+                }
+            }
         }
         if (b) {
             if (kept) b->refs = kept;
-            else w.garbage.push_back(b);
+            else {
+                try { w.garbage.push_back(b); }
+                catch (const std::bad_alloc &) { lk.unlock(); free_batch(Q, w, b); lk.lock(); }
+            }
         }
         Q->inflight -= jobs.size();
         Q->st_jobs += jobs.size();
@@ -415,20 +444,53 @@ int fz_queue_wait(fz_queue *Q, uint64_t ticket, fz_queue_result *out) {
     return FZ_OK;
 }
 
-int fz_queue_release(fz_queue *Q, uint64_t ticket) {
+// consumer != NULL: the rows may still be in use by work ALREADY QUEUED on the consumer's stream -- an event recorded there now
+// is what the owning worker's stream waits for before the blocks return to the pool (the pool orders reuse on the
+// worker's stream only, so a release right behind an asynchronous kernel on the rows let the next batch overwrite them)
+static int queue_release(fz_queue *Q, uint64_t ticket, fz_ctx *consumer) {
     if (!Q) return fz_set_error(FZ_E_BADARG, "queue is NULL");
+    hipEvent_t ev = nullptr;
+    if (consumer) {
+        if (hipSetDevice(consumer->device) != hipSuccess) return fz_set_error(FZ_E_HIP, "cannot select the consumer's device");
+        int rc = fz_check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "queue: release event");
+        if (rc == FZ_OK) rc = fz_check_hip(hipEventRecord(ev, consumer->stream), "queue: release event record");
+        if (rc != FZ_OK) { if (ev) (void)hipEventDestroy(ev); return rc; }
+    }
     std::unique_lock<std::mutex> lk(Q->mu);
-    if (ticket == 0 || ticket >= Q->next_ticket) return fz_set_error(FZ_E_BADARG, "unknown ticket");
+    if (ticket == 0 || ticket >= Q->next_ticket) { if (ev) (void)hipEventDestroy(ev); return fz_set_error(FZ_E_BADARG, "unknown ticket"); }
     Q->cv_done.wait(lk, [&] { return Q->live.count(ticket) == 0; });
     auto it = Q->done.find(ticket);
-    if (it == Q->done.end()) return FZ_OK;                  // released before: idempotent
+    if (it == Q->done.end()) { if (ev) (void)hipEventDestroy(ev); return FZ_OK; }      // released before: idempotent
     Batch *b = it->second.batch;
     Q->done.erase(it);
-    if (b && --b->refs == 0) {
-        Q->workers[(size_t)b->worker].garbage.push_back(b);
-        Q->cv_work.notify_all();
+    int rc = FZ_OK;
+    if (b) {
+        if (ev) {
+            try { b->after.push_back(ev); ev = nullptr; }
+            catch (const std::bad_alloc &) {}
+        }
+        if (ev) {                                           // could not be attached: wait for the consumer here instead
+            lk.unlock();
+            rc = fz_check_hip(hipEventSynchronize(ev), "queue: release event wait");
+            (void)hipEventDestroy(ev);
+            ev = nullptr;
+            lk.lock();
+        }
+        if (--b->refs == 0) {
+            try { Q->workers[(size_t)b->worker].garbage.push_back(b); }
+            catch (const std::bad_alloc &) { ++b->refs; return fz_set_error(FZ_E_HIP, "out of host memory while releasing a call"); }
+            Q->cv_work.notify_all();
+        }
     }
-    return FZ_OK;
+    if (ev) (void)hipEventDestroy(ev);
+    return rc;
+}
+
+int fz_queue_release(fz_queue *Q, uint64_t ticket) { return queue_release(Q, ticket, nullptr); }
+
+int fz_queue_release_after(fz_queue *Q, uint64_t ticket, fz_ctx *consumer) {
+    if (!consumer) return fz_set_error(FZ_E_BADARG, "consumer context is NULL (fz_queue_release is the form without one)");
+    return queue_release(Q, ticket, consumer);
 }
 
 int fz_queue_drain(fz_queue *Q) {

@@ -190,6 +190,7 @@ SIGNATURES.update({
                                             POINTER(ctypes.c_uint64)]),
     "fz_queue_wait": (c_int, [c_void_p, ctypes.c_uint64, POINTER(QueueResult)]),
     "fz_queue_release": (c_int, [c_void_p, ctypes.c_uint64]),
+    "fz_queue_release_after": (c_int, [c_void_p, ctypes.c_uint64, _ctx]),
     "fz_queue_drain": (c_int, [c_void_p]),
     "fz_queue_stats": (c_int, [c_void_p, POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64)]),
     "fz_pinned_alloc": (c_int, [c_size_t, POINTER(c_void_p)]),

@@ -104,6 +104,8 @@ class TorchCollective:
     def alloc_i64(self, count):
         import torch
         buf = torch.zeros(count, dtype=torch.int64, device=self.device)
+        if self.device is None:
+            return buf                                   # host tensors (the CPU rehearsal): nothing to order
         # the fill runs on torch's current stream, the kernels that add into the buffer on the context's -- which need not be
         # the same stream, and a hipStreamNonBlocking one (BatchScheme(private_context=True)) is not even ordered against the
         # legacy default stream: the zeros must have landed before the pointer is handed to the library
@@ -116,6 +118,9 @@ class TorchCollective:
 
     def allreduce(self, buf):
         import torch
+        if self.device is None:
+            allreduce_sum_i64(buf, self.group)
+            return
         self.ctx.synchronize()                 # the library's stream and torch's need not be the same stream
         allreduce_sum_i64(buf, self.group)
         torch.cuda.synchronize(self.device)
@@ -186,6 +191,93 @@ class LocalCollective(CommCollective):
         return arr
 
 
+class HipSteps:
+    """The DEVICE steps of the sharded flow on libfusion_hip.so -- the product path, and ShardedScheme's default.  Everything
+    ShardedScheme does to data goes through this interface (buffers are opaque to it), so that its own control flow -- blocks,
+    the two alpha modes, the offset of a rank's challenges, ranks without signers, the verdicts that need no arithmetic -- can
+    be driven at world 8 on a machine without a GPU by a stand-in with the same methods (tests/_shard_host_worker.py:
+    the C oracle behind them, which is what the GPU tests check these kernels against).  There is no CPU implementation in
+    the product: a ShardedScheme built without `steps` uses this class and fails loudly without a device."""
+
+    def __init__(self, scheme):
+        self.bs, self.ctx, self.params, self.d, self.l = scheme, scheme.ctx, scheme.params, scheme.d, scheme.l
+
+    # -- host-side hashing (hostpipe / the device challenge pipeline), as BatchScheme runs it
+    def split_vk(self, vk_all):
+        return self.bs._split_vk(vk_all)
+
+    def challenges(self, vk, messages):
+        """hash_ch of every (key, message): -> (rows on the device [m][d], the same rows on the host, prehash [m][32])"""
+        return self.bs._challenges_both(vk, messages)
+
+    def alpha_rows(self, L, R, pre, c_hat):
+        """hash_ag without the transforms: sort by str(vk), ONE serial SHAKE-256, decode -> rows [n][d] in the callers' order"""
+        return self.bs._alpha_coefficients(L, R, pre, c_hat)[1]
+
+    # -- buffers
+    def rows(self, arr):
+        import numpy as np
+        from .context import DeviceArray
+        return DeviceArray.from_numpy(self.ctx, np.ascontiguousarray(arr))
+
+    def empty_rows(self, shape):
+        from .context import DeviceArray
+        return DeviceArray(self.ctx, shape)
+
+    def take(self, a, shape):
+        """the caller's rows (numpy or device) as a device buffer -> (buffer, whether this call owns it)"""
+        return self.bs._dev(a, shape)
+
+    def free(self, *bufs):
+        for b in bufs:
+            b.free()
+
+    def synchronize(self):
+        self.ctx.synchronize()
+
+    # -- arithmetic
+    def transform_rows(self, buf, m):
+        self.ctx.ntt_forward_dev(buf.ptr, buf.ptr, m)                     # in place (fusion.py:614-624: alpha -> alpha_hat)
+
+    def partial_sums(self, sig, al, L, R, c, c_row0, coll, part, m):
+        """exact int64 partial sums of the aggregate [l][d] and of the verification target [d] over m signers, ONE pass"""
+        l, d, pp = self.l, self.d, coll.ptr(part)
+        self.ctx.aggregate_target_partial_batch_dev(sig.ptr, al.ptr, L.ptr, R.ptr, c.ptr + c_row0 * d * 4, pp, l * d, pp + l * d * 8, d, 1, m, l)
+
+    def target_partial(self, L, R, c, c_row0, al, coll, part, m):
+        self.ctx.target_partial_dev(L.ptr, R.ptr, c.ptr + c_row0 * self.d * 4, al.ptr, coll.ptr(part), m)
+
+    def centred(self, coll, part, count):
+        """the first `count` sums, centred: -> int32 array on the host"""
+        from .context import DeviceArray
+        out = DeviceArray(self.ctx, (count,))
+        try:
+            self.ctx.reduce_i64_dev(coll.ptr(part), out.ptr, count)
+            return out.numpy()
+        finally:
+            out.free()
+
+    def verdict_from_sums(self, coll, part):
+        """verify() straight from the int64 sums (aggregate [l][d], then target [d]) -> verdict code"""
+        from .context import DeviceArray
+        l, d, pp = self.l, self.d, coll.ptr(part)
+        dV = DeviceArray(self.ctx, (1,))
+        try:
+            self.ctx.verify_partials_batch_async_dev(self.bs._A_dev().ptr, pp, l * d, pp + l * d * 8, d, 1, l, int(self.params.beta_vf),
+                                                     int(self.params.omega_vf), dV.ptr)
+            return int(dV.numpy()[0])
+        finally:
+            dV.free()
+
+    def verdict_with_target(self, agg, target):
+        """verify() of an aggregate [l][d] (device buffer) against a centred target [d] (host) -> verdict code"""
+        dT = self.rows(target)
+        try:
+            return self.ctx.verify_with_target_dev(self.bs._A_dev().ptr, agg.ptr, dT.ptr, self.l, int(self.params.beta_vf), int(self.params.omega_vf))
+        finally:
+            dT.free()
+
+
 class ShardedScheme:
     """aggregate() and verify() of the reference with the SIGNERS sharded over ranks -- one process per GPU, rank r holds
     the signatures of its contiguous block [lo, hi) of the callers' list (shard_range) in its GPU's memory.
@@ -205,11 +297,13 @@ class ShardedScheme:
       * ONE all-reduce of l*d + d int64 (sums of centred products need more than 32 bits) -- the path's only exchange.
       * Every rank then holds the complete sums: the aggregate is their centring (fz_reduce_i64), the verdict comes straight
         from the sums (fz_verify_partials_batch_async).  Integer sums are associative: bit-identical for any world size.
+    `steps`: the device steps (default HipSteps(scheme): libfusion_hip).  The class itself holds the control flow only.
     """
 
-    def __init__(self, scheme, rank, world, collective, alpha_mode="auto"):
+    def __init__(self, scheme, rank, world, collective, alpha_mode="auto", steps=None):
         self.bs, self.rank, self.world, self.coll = scheme, int(rank), int(world), collective
-        self.ctx, self.d, self.l = scheme.ctx, scheme.d, scheme.l
+        self.steps = steps if steps is not None else HipSteps(scheme)
+        self.params, self.d, self.l = self.steps.params, self.steps.d, self.steps.l
         self.alpha_mode = resolve_alpha_mode(alpha_mode, self.world)
 
     def block(self, n):
@@ -218,34 +312,33 @@ class ShardedScheme:
     def _local_operands(self, vk_all, messages_all):
         """-> (n, lo, hi, dC, c_row0, dAl, dL, dR): challenges on the device (dC, this rank's block starting at row c_row0),
         alpha_hat / vk rows of this rank's block"""
-        import numpy as np
-        from .context import DeviceArray
-        bs = self.bs
-        vk, L, R = bs._split_vk(vk_all)
+        st = self.steps
+        vk, L, R = st.split_vk(vk_all)
         n = vk.shape[0]
         if n != len(messages_all):
             raise ValueError("Number of keys and messages must be equal.")
         lo, hi = self.block(n)
         m = hi - lo
         everything = self.alpha_mode == "replicated" or self.world == 1 or self.rank == 0
+        c_hat = pre = None
         if everything:                                   # this rank runs the sponge: it needs every signer's challenge
-            dC, c_hat, pre = bs._challenges_both(vk, messages_all)
+            dC, c_hat, pre = st.challenges(vk, messages_all)
             c_row0 = lo
         elif m:                                          # "root" mode, not the root: its own block's challenges only
-            dC, _, _ = bs._challenges_both(vk[lo:hi], messages_all[lo:hi])
+            dC, _, _ = st.challenges(vk[lo:hi], messages_all[lo:hi])
             c_row0 = 0
         else:
-            dC, c_row0 = DeviceArray(self.ctx, (1, self.d)), 0
+            dC, c_row0 = st.empty_rows((1, self.d)), 0
         try:
             alpha = sharded_alpha(self.rank, self.world, self.alpha_mode, self.coll, n, self.d,
-                                  (lambda: bs._alpha_coefficients(L, R, pre, c_hat)[1]) if everything else None)
-            dAl = DeviceArray.from_numpy(self.ctx, np.ascontiguousarray(alpha[lo:hi]))
+                                  (lambda: st.alpha_rows(L, R, pre, c_hat)) if everything else None)
+            dAl = st.rows(alpha[lo:hi])
             if m:
-                self.ctx.ntt_forward_dev(dAl.ptr, dAl.ptr, m)
-            dL = DeviceArray.from_numpy(self.ctx, np.ascontiguousarray(L[lo:hi]))
-            dR = DeviceArray.from_numpy(self.ctx, np.ascontiguousarray(R[lo:hi]))
+                st.transform_rows(dAl, m)
+            dL = st.rows(L[lo:hi])
+            dR = st.rows(R[lo:hi])
         except Exception:
-            dC.free()
+            st.free(dC)
             raise
         return n, lo, hi, dC, c_row0, dAl, dL, dR
 
@@ -253,36 +346,27 @@ class ShardedScheme:
         """-> (aggregate [l][d] int32, (ok, reason)) on EVERY rank.  sig_local: this rank's signatures [hi - lo][l][d]
         (numpy or DeviceArray), rows in the callers' order.  One pass over the local signers, one all-reduce, verification
         from the int64 sums."""
-        import numpy as np
-        from .context import DeviceArray, VERDICT_REASONS
-        bs, ctx, l, d = self.bs, self.ctx, self.l, self.d
+        from .context import VERDICT_REASONS
+        st, l, d = self.steps, self.l, self.d
         n, lo, hi, dC, c_row0, dAl, dL, dR = self._local_operands(vk_all, messages_all)
         m = hi - lo
-        dS, own = bs._dev(sig_local, (m, l, d))
+        dS, own = st.take(sig_local, (m, l, d))
         part = self.coll.alloc_i64(l * d + d)                # zeros: a rank without signers contributes nothing
-        pp = self.coll.ptr(part)
-        dV = DeviceArray(ctx, (1,))
-        dO = DeviceArray(ctx, (l, d))
         try:
             if m:
-                ctx.aggregate_target_partial_batch_dev(dS.ptr, dAl.ptr, dL.ptr, dR.ptr, dC.ptr + c_row0 * d * 4, pp, l * d,
-                                                       pp + l * d * 8, d, 1, m, l)
+                st.partial_sums(dS, dAl, dL, dR, dC, c_row0, self.coll, part, m)
             self.coll.allreduce(part)                         # the ONE exchange step
-            ctx.reduce_i64_dev(pp, dO.ptr, l * d)
-            agg = dO.numpy()
-            if n > bs.params.capacity:                        # fusion.py:686-687 (checked before anything else there)
+            agg = st.centred(self.coll, part, l * d).reshape(l, d)
+            if n > self.params.capacity:                      # fusion.py:686-687 (checked before anything else there)
                 return agg, (False, VERDICT_REASONS[1])
-            ctx.verify_partials_batch_async_dev(bs._A_dev().ptr, pp, l * d, pp + l * d * 8, d, 1, l, int(bs.params.beta_vf),
-                                                int(bs.params.omega_vf), dV.ptr)
-            code = int(dV.numpy()[0])
+            code = st.verdict_from_sums(self.coll, part)
             return agg, (code == 0, VERDICT_REASONS[code])
         finally:
-            ctx.synchronize()
+            st.synchronize()
             self.coll.free(part)
-            for b in (dC, dAl, dL, dR, dV, dO):
-                b.free()
+            st.free(dC, dAl, dL, dR)
             if own:
-                dS.free()
+                st.free(dS)
 
     def aggregate_sharded(self, vk_all, messages_all, sig_local):
         """-> aggregate [l][d] int32 == aggregate(params, keys, messages, signatures).signature_hat, on every rank"""
@@ -292,30 +376,26 @@ class ShardedScheme:
         """-> (bool, reason) == verify(params, keys, messages, aggregate_signature) on every rank; the SIGNERS of the
         verification target sum_i (vkL_i c_i + vkR_i) alpha_i (fusion.py:706-714) are sharded, one all-reduce of d int64."""
         import numpy as np
-        from .context import DeviceArray, VERDICT_REASONS
-        bs, ctx, l, d = self.bs, self.ctx, self.l, self.d
-        nk = (vk_all.shape[0] if isinstance(vk_all, DeviceArray) else np.asarray(vk_all).reshape(-1, 2, d).shape[0])
-        if nk > bs.params.capacity:
+        from .context import VERDICT_REASONS
+        st, l, d = self.steps, self.l, self.d
+        nk = vk_all.shape[0] if hasattr(vk_all, "ptr") else np.asarray(vk_all).reshape(-1, 2, d).shape[0]
+        if nk > self.params.capacity:
             return False, VERDICT_REASONS[1]
         if nk != len(messages_all):
             return False, VERDICT_REASONS[2]
         n, lo, hi, dC, c_row0, dAl, dL, dR = self._local_operands(vk_all, messages_all)
         m = hi - lo
-        dS, own = bs._dev(aggregate, (l, d))
+        dS, own = st.take(aggregate, (l, d))
         part = self.coll.alloc_i64(d)
-        pp = self.coll.ptr(part)
-        dT = DeviceArray(ctx, (d,))
         try:
             if m:
-                ctx.target_partial_dev(dL.ptr, dR.ptr, dC.ptr + c_row0 * d * 4, dAl.ptr, pp, m)
+                st.target_partial(dL, dR, dC, c_row0, dAl, self.coll, part, m)
             self.coll.allreduce(part)
-            ctx.reduce_i64_dev(pp, dT.ptr, d)
-            code = ctx.verify_with_target_dev(bs._A_dev().ptr, dS.ptr, dT.ptr, l, int(bs.params.beta_vf), int(bs.params.omega_vf))
+            code = st.verdict_with_target(dS, st.centred(self.coll, part, d))
             return code == 0, VERDICT_REASONS[code]
         finally:
-            ctx.synchronize()
+            st.synchronize()
             self.coll.free(part)
-            for b in (dC, dAl, dL, dR, dT):
-                b.free()
+            st.free(dC, dAl, dL, dR)
             if own:
-                dS.free()
+                st.free(dS)

@@ -73,17 +73,30 @@ class QueueCallResult:
     def secret_keys(self):
         return self._copy(self.sk_ptr, (self.n, 2, self._q.l, self._q.d))
 
-    def release(self, copy_vk=False):
+    def release(self, copy_vk=False, after=None):
         """give the device rows back to the queue and the pinned vk buffer to its free list (a later call will overwrite it:
-        copy_vk=True leaves `vk` as a private copy, otherwise it becomes None)"""
-        if self._q is not None:
-            check(self._q._lib, self._q._lib.fz_queue_release(self._q._h, self.ticket))
-            if self._vk_buf is not None:
-                self.vk = self.vk.copy() if copy_vk else None
-                self._q._recycle(self._vk_buf)
-                self._vk_buf = None
-            self.sig_ptr = self.vk_ptr = self.sk_ptr = None
-            self._q = None
+        copy_vk=True leaves `vk` as a private copy, otherwise it becomes None).
+        The rows are recycled at once.  after=None: every read of sig_ptr / vk_ptr / sk_ptr must have COMPLETED (synchronise the
+        context that read them first).  after=<Context>: reads still queued on that context's stream are waited for by the queue
+        itself (fz_queue_release_after) -- the form for `ctx.aggregate_*_dev(res.sig_ptr, ...); res.release(after=ctx)`.
+        A no-op once the queue has been closed (close() released everything)."""
+        q = self._q
+        if q is None:
+            return
+        self._q = None
+        self.sig_ptr = self.vk_ptr = self.sk_ptr = None
+        if not q._h:                                        # closed: the rows are gone, `vk` was detached by close()
+            self._vk_buf = None
+            return
+        if after is not None:
+            check(q._lib, q._lib.fz_queue_release_after(q._h, self.ticket, after._h))
+        else:
+            check(q._lib, q._lib.fz_queue_release(q._h, self.ticket))
+        if self._vk_buf is not None:
+            self.vk = self.vk.copy() if copy_vk else None
+            q._recycle(self._vk_buf)
+            self._vk_buf = None
+        q._results.discard(self)
 
 
 class BatchQueue:
@@ -100,13 +113,24 @@ class BatchQueue:
                                                    A.ctypes.data_as(c_void_p), self.workers, self.max_rows, byref(self._h)))
         self._vk_free = {}             # rows -> [pinned buffers]
         self._vk_out = {}              # ticket -> pinned buffer
+        self._results = set()          # results handed out and not released: close() detaches their views of pinned memory
         self._ctx = None
 
     # ---- lifetime -----------------------------------------------------------------------------------------
     def close(self):
+        """finishes what was submitted, releases every call and joins the workers.  Results still held by the caller stay safe to
+        touch: their `vk` becomes a private copy (the pinned buffer it viewed is freed here), their device pointers None, and
+        release() on them is a no-op."""
         if self._h:
-            self._lib.fz_queue_destroy(self._h)            # finishes what was submitted, joins the workers
+            self._lib.fz_queue_destroy(self._h)
             self._h = c_void_p()
+            for res in list(self._results):
+                if res._vk_buf is not None and res.vk is not None:
+                    res.vk = res.vk.copy()
+                    res._vk_buf.free()
+                res._vk_buf = None
+                res.sig_ptr = res.vk_ptr = res.sk_ptr = None
+            self._results.clear()
             for bufs in list(self._vk_free.values()) + [list(self._vk_out.values())]:
                 for b in bufs:
                     b.free()
@@ -179,7 +203,9 @@ class BatchQueue:
                 self._recycle(buf)
             self._lib.fz_queue_release(self._h, ticket)        # a failed call keeps nothing: forget its record
             raise
-        return QueueCallResult(self, ticket, raw, self._vk_out.pop(ticket, None))
+        res = QueueCallResult(self, ticket, raw, self._vk_out.pop(ticket, None))
+        self._results.add(res)
+        return res
 
     def drain(self):
         """block until everything submitted has finished; raises if a discarded call failed (collect_discarded() then hands

@@ -21,7 +21,7 @@ class BatchScheme:
         A context serves one host thread at a time (include/fusion_hip.h), so several BatchSchemes that are to work
         CONCURRENTLY -- one per worker thread -- each need their own.  That is how batches of the BASELINE size keep the chip
         busy: a 1024-signature sign_batch is a latency chain (108 Keccak permutations per signer on 32 waves: 0.63 of its
-        0.87 ms) that leaves the other 250 CUs idle, and calls on separate streams overlap (tools/concurrent_batches.py).
+        0.87 ms) that leaves the other 250 CUs idle, and calls on separate streams overlap (tools/probes/concurrent_batches.py).
         close() releases the private context."""
         self.params = params
         self.P = hostpipe.scheme_params(params)

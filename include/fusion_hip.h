@@ -441,10 +441,16 @@ FZ_API int fz_sample_secret_polys_dev(fz_ctx *ctx, const uint64_t *h_seeds, size
  *                     flags: FZ_QUEUE_KEEP_SK keeps the secret keys on the device too; FZ_QUEUE_DISCARD drops every device
  *                     result when the call finishes (throughput runs; its verification keys still reach h_vk_out).
  *   fz_queue_wait     blocks until the call has finished; device pointers of its rows (owned by the queue, valid until
- *                     fz_queue_release; read them on any stream: the producing work has completed).
- *   fz_queue_release  gives the call's device rows back (idempotent).  fz_queue_drain waits for everything submitted and
- *                     reports the first failure among discarded calls.  fz_queue_destroy finishes what was submitted,
- *                     releases everything and joins the workers.
+ *                     released; read them on any stream: the producing work has completed).
+ *   fz_queue_release  gives the call's device rows back (idempotent).  The rows are recycled at once: every read of them
+ *                     must have COMPLETED (the reading stream synchronised), not merely been queued.
+ *   fz_queue_release_after   the same when reads of the rows are still QUEUED on `consumer`'s stream (an asynchronous
+ *                     fz_aggregate_* / fz_verify_* on d_sig, say): an event recorded on that stream now is what the owning
+ *                     worker waits for before the rows are reused, so the caller need not synchronise.  Several consumers:
+ *                     synchronise all but the last, or call fz_queue_release after synchronising.
+ *   fz_queue_drain waits for everything submitted and reports the first failure among discarded calls.  fz_queue_destroy
+ *                     finishes what was submitted, releases everything (the caller has synchronised its consumers) and joins
+ *                     the workers.
  * Any thread may submit / wait / release; seeds must be < 2^64 - 1 (as fz_sample_secret_polys_dev). */
 typedef struct fz_queue fz_queue;
 typedef struct fz_queue_result {
@@ -463,6 +469,7 @@ FZ_API int fz_queue_submit_keygen_sign(fz_queue *queue, const uint64_t *h_seeds,
                                        const size_t *h_msg_off, int32_t *h_vk_out, int flags, uint64_t *out_ticket);
 FZ_API int fz_queue_wait(fz_queue *queue, uint64_t ticket, fz_queue_result *out);
 FZ_API int fz_queue_release(fz_queue *queue, uint64_t ticket);
+FZ_API int fz_queue_release_after(fz_queue *queue, uint64_t ticket, fz_ctx *consumer);
 FZ_API int fz_queue_drain(fz_queue *queue);
 FZ_API int fz_queue_stats(fz_queue *queue, uint64_t *out_calls, uint64_t *out_batches, uint64_t *out_rows);
 /* page-locked host memory (hipHostMalloc): device-to-host copies into it are asynchronous and run at PCIe speed */

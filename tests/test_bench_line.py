@@ -28,7 +28,8 @@ def canned(world=1, prose=2000):
     blob = "x" * prose
     ranks = [{"rank": r, "local_rank": r, "device_index": r, "device": "AMD Instinct MI355X", "pci_bus_id": f"0000:{5 + r:02x}:00",
               "world_size_seen": world, "backend": "nccl" if world > 1 else "none", "rccl_nranks": world if world > 1 else None,
-              "rccl_version": 22703 if world > 1 else None} for r in range(world)]
+              "rccl_version": 22703 if world > 1 else None,
+              "collective_check": "ok:allreduce_i64+reduce_scatter_i64" if world > 1 else None} for r in range(world)]
     return {
         "metric": "batched NTT/s (deg-256, secpar=256) + aggregate sign+verify/sec at 1/2/4/8 GPU",
         "value": 976706523.2615083 * world, "unit": "NTT/s", "n_gpus": world, "steps": 20, "repeats": 150, "warmup": 5,
@@ -36,15 +37,20 @@ def canned(world=1, prose=2000):
         "data": "synthetic", "timed_region_ms": 25.1,
         "config": {"workload": "configs[1]: secpar=256, 4096 degree-256 forward+inverse NTTs per step per GPU", "batch": 4096,
                    "degree": 256, "modulus": 2147465729, "batches_rotated": 64, "kernels_per_step": 2, "arithmetic": blob,
-                   "launch": "4 hipGraph(s) of 50x20 steps together, 3 replays", "parallelism": f"{world} independent rank(s)",
-                   "streams": 4, "launches_per_step": 1, "step": "software-pipelined: forward of batch i+1 + inverse of batch i in one fz_ntt_multi launch per step",
+                   "launch": "2 hipGraph(s) of 50x20 steps together, 3 replays", "parallelism": f"{world} independent rank(s)",
+                   "streams": 2, "steps_per_launch": 8,
+                   "step": "software-pipelined over 8 batches: forward of batches i+1..i+8 + inverse of batches i-7..i in one fz_ntt_multi launch (16 jobs) per 8 steps",
                    "host_threads_on": blob},
         "ranks": ranks,
-        "roofline": {"bound": "hbm", "kernel": "ntt_jobs4<8, true, 2, 2, FzJobs4>", "achieved": 2581.1, "peak": 8000.0, "unit": "GB/s",
-                     "frac": 0.32264, "traffic": 16955408.0, "traffic_source": blob, "bytes_per_launch": 16777216.0, "in_flight": 1,
-                     "units_per_launch": 8192, "avg_launch_us": 6.5, "operands": "cold: rotation of 64 batches", "one_stream": {"what": blob},
-                     "chip": {"streams": 4, "achieved": 4553.5, "frac": 0.56919, "unit": "GB/s", "launch_us_in_flight": 14.67,
-                              "launches_timed": 12000, "per_chain_event_ms": [43.7] * 4, "what": blob},
+        "roofline": {"bound": "hbm", "kernel": "ntt_jobs16<8, true, FzJobsN<32>>", "achieved": 4634.4, "peak": 8000.0, "unit": "GB/s",
+                     "frac": 0.5793, "traffic": 135100000.0, "traffic_source": blob, "bytes_per_launch": 134217728.0, "in_flight": 1,
+                     "units_per_launch": 65536, "avg_launch_us": 28.961, "operands": "cold: rotation of 64 batches", "one_stream": {"what": blob},
+                     "device_clock": {"frac": 0.5793, "in_flight": 1.0, "launch_us": 27.33, "gap_us": 1.405, "span_us": 926.8,
+                                      "table": [{"stream": 0, "launch": k, "start_us": 1.0 * k, "end_us": 1.0 * k + 27.0} for k in range(33)], "what": blob},
+                     "chip": {"streams": 2, "achieved": 5228.5, "frac": 0.65356, "unit": "GB/s", "launch_us_in_flight": 51.3,
+                              "launches_timed": 750, "per_chain_event_ms": [43.7] * 2, "what": blob,
+                              "device_clock": {"frac": 0.6411, "in_flight": 1.862, "launch_us": 48.72, "gap_us": 3.119, "span_us": 1675.0,
+                                               "rounds": [{"frac": 0.64}] * 3, "what": blob}},
                      "isolated": {"passes": [{"avg_us": 4.5, "note": blob}] * 3, "what": blob},
                      "timing": "HIP events on the kernels' stream around the timed region (dense graph replays) / launches in it",
                      "shader_mhz": 2392},
@@ -52,17 +58,19 @@ def canned(world=1, prose=2000):
         "single_stream": {"value": 1.25e9, "unit": "NTT/s", "ms_per_step": 0.00655, "frac": 0.32, "what": blob},
         "two_launch_step": {"value": 0.94e9, "unit": "NTT/s", "ms_per_step": 0.0087, "frac": 0.24, "what": blob},
         "sign_verify": {"value": 14410006.6, "unit": "signatures signed+aggregated+verified per s", "ms_per_step": 0.0711,
-                        "hbm_frac_per_gpu": 0.6234, "aggregates": 4, "signers_per_aggregate": 256, "note": blob,
+                        "moved_frac_per_gpu": 0.6094, "aggregates": 4, "signers_per_aggregate": 256, "note": blob,
                         "collective": "fz_allreduce_i64 (ncclAllReduce int64 sum, C ABI), RCCL counts 8 ranks",
                         "cpu_value": 81.2, "ranks": ranks},
+        "sign_verify_1x1024": {"value": 17.1e6, "unit": "signatures signed+aggregated+verified per s", "ms_per_step": 0.0599,
+                               "moved_frac_per_gpu": 0.554, "aggregates": 1, "signers_per_aggregate": 1024, "verification": blob},
         "keygen_sign": {"value": 8569658.8, "unit": "keygen+sign per s", "ms_per_step": 0.119, "hbm_frac_per_gpu": 0.64, "note": blob,
                         "cpu_value": 14.1},
         "cpu_baseline": {"value": 2998.1234, "unit": "NTT/s", "cores": 1, "kind": "port",
                          "sample": "18000 rows of the 4096-row batch, forward+inverse degree-256 NTT each, pure-Python port, 12.0 s on 1 core of 256; " * 2 + blob,
                          "all_cores": {"value": 41600.0, "cores": 16, "sample": blob}, "scheme": {"sample": blob}},
         "kernels": {f"kernel {i}": {"avg_us": 1.0, "note": blob} for i in range(40)},
-        "end_to_end": {"keygen_per_s": 4.2e6, "sign_per_s": 1.2e6, "aggregate_per_s": 43e3, "verify_per_s": 43e3, "note": blob,
-                       "queue_pairs_per_s": 4.1e6},
+        "end_to_end": {"signatures": 1024, "keygen_per_s": 4.2e6, "sign_per_s": 1.2e6, "aggregate_per_s": 43e3, "verify_per_s": 43e3, "note": blob,
+                       "queue_pairs_per_s": 4.1e6, "many_aggregates": {"4x256": {"note": blob}}},
         "full": "gpurun_out/bench_full.json",
     }
 
@@ -86,17 +94,26 @@ def test_compact_line_is_strict_json_under_the_limit_with_the_contract_keys(benc
     # the judge's recomputation: bytes per launch / average launch duration (one launch in flight: what rocprofv3's per-kernel
     # average reproduces); the chip-level figure of the multi-stream timed region sits beside it
     assert abs(r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9 / 8000.0 - r["frac"]) < 0.005 and r["in_flight"] == 1
-    assert r["chip"]["streams"] == 4 and r["chip"]["frac"] > r["frac"] and "what" not in r["chip"] and "per_chain_event_ms" not in r["chip"]
+    assert r["chip"]["streams"] == 2 and r["chip"]["frac"] > r["frac"] and "what" not in r["chip"] and "per_chain_event_ms" not in r["chip"]
+    # the chip's own clock beside both figures (fz_diag_stamps_*): numbers only, never the table
+    assert r["device_clock"]["launch_us"] == 27.33 and "table" not in r["device_clock"] and "what" not in r["device_clock"]
+    assert r["chip"]["device_clock"]["in_flight"] > 1.5 and "rounds" not in r["chip"]["device_clock"]
     c = out["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] == "port" and len(c["sample"]) <= 160
     assert out["sign_verify"]["value"] > 0 and out["keygen_sign"]["value"] > 0 and out["warm_replay"]["value"] > 0
-    assert out["single_stream"]["frac"] == 0.32 and out["two_launch_step"]["value"] > 0 and out["config"]["streams"] == 4
+    assert out["single_stream"]["frac"] == 0.32 and out["two_launch_step"]["value"] > 0 and out["config"]["streams"] == 2
+    assert out["config"]["steps_per_launch"] == 8
+    # the metric's second half: what the fused launch MOVES (never the two kernels' bytes it does not move), configs[3]'s own
+    # shape beside the default split, and the end-to-end rates (hashing included) beside the algebra cores
+    assert "hbm_frac_per_gpu" not in out["sign_verify"] and out["sign_verify"]["moved_frac_per_gpu"] == 0.6094
+    assert out["sign_verify_1x1024"]["signers_per_aggregate"] == 1024 and out["sign_verify_1x1024"]["aggregates"] == 1
+    assert set(("keygen_per_s", "sign_per_s", "aggregate_per_s", "verify_per_s")) <= set(out["end_to_end"]) and "many_aggregates" not in out["end_to_end"]
     assert len(out["ranks"]) == world
     if world > 1:
-        assert all(rk["rccl_nranks"] == world and rk["rccl_version"] == 22703 for rk in out["ranks"])
+        assert all(rk["rccl_nranks"] == world and rk["rccl_version"] == 22703 and rk["collective_check"].startswith("ok:") for rk in out["ranks"])
     # one number per side leg, no prose
     assert "xxxx" not in line and "kernels" not in out and "passes" not in r and "isolated" not in r and "one_stream" not in r
-    assert r["bytes_per_launch"] == 16777216 and isinstance(r["bytes_per_launch"], int)
+    assert r["bytes_per_launch"] == 134217728 and isinstance(r["bytes_per_launch"], int)
 
 
 def test_compact_line_never_emits_nan_or_infinity(bench):
@@ -136,6 +153,8 @@ def test_newest_profile_is_found_by_round_number_not_by_a_hard_coded_name(bench)
                     __import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_ntt.json")))
     assert int(os.path.basename(p)[1:3]) == rounds[-1]
     text = open(os.path.join(ROOT, "bench.py")).read()
-    assert "r03_" not in text and "r04_" not in text, "bench.py names a round's profile file literally"
+    # a round's file may be CITED in a comment (where a number came from), never named in code
+    named = [ln for ln in text.splitlines() if __import__("re").search(r"\br\d\d_[a-z]", ln) and "#" not in ln.split("r0")[0]]
+    assert not named, f"bench.py names a round's profile file literally: {named}"
     traffic, src = bench.pmc_traffic()
     assert src.startswith("profiles/") or traffic is None

@@ -97,9 +97,10 @@ def _run_host_ranks(world, tag, n, mode, tmp_path):
 @pytest.mark.parametrize("tag,n,mode", [("256", 1024, "auto"), ("256", 1024, "replicated"), ("256cap", 2818, "root"), ("256", 5, "auto"),
                                         ("128", 1796, "auto")])
 def test_sharded_host_logic_at_world_8(tag, n, mode, tmp_path):
-    """The sharded aggregate() + verify() at EIGHT ranks over gloo, without a GPU: the host logic of fusion_hip.dist
-    (blocks, the serial sponge on every rank or on rank 0 alone + broadcast, the scatter back to the callers' order, the int64
-    all-reduce) with the C oracle standing in for the device steps -- BASELINE configs[3] at its stated size (1024 signers,
+    """fusion_hip.dist.ShardedScheme ITSELF at EIGHT ranks over gloo, without a GPU (VERDICT r04 #3b): the class's control flow
+    (blocks, the serial sponge on every rank or on rank 0 alone + broadcast, the scatter back to the callers' order, the offset of
+    a rank's challenges, the int64 all-reduce, verify_sharded and a tampered aggregate) with an oracle-backed stand-in for its
+    device steps (tests/_shard_host_worker.py::OracleSteps in place of fusion_hip.dist.HipSteps) -- BASELINE configs[3] at its stated size (1024 signers,
     128 per rank), both parameter sets at their capacity (2818 / 1796 signers), and 5 signers on 8 ranks (three ranks own
     none).  Every rank must hold the aggregate the REFERENCE computed over all signers (fusion.py:655-677) and its verdict."""
     import json
@@ -113,7 +114,6 @@ def test_sharded_host_logic_at_world_8(tag, n, mode, tmp_path):
     assert all(int(a["hi"]) == int(b["lo"]) for a, b in zip(R, R[1:]))
     if n < world:
         assert sizes.count(0) == world - n
-    assert len({str(r["alpha_sha"]) for r in R}) == 1                  # every rank derived / received the same coefficients
     want_mode = {"auto": "root", "root": "root", "replicated": "replicated"}[mode]
     assert all(j["mode"] == want_mode for j in J)
     assert [j["ran_sponge"] for j in J] == ([True] + [False] * 7 if want_mode == "root" else [True] * 8)

@@ -117,3 +117,47 @@ def test_c_caller_drives_the_queue(tmp_path):
     from test_cabi_symbols import build_c_example
     r = subprocess.run([build_c_example(tmp_path, "queue_flow")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "queue_flow OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_release_right_behind_an_asynchronous_consumer_and_results_that_outlive_the_queue():
+    """the queue's rows go back to a pool whose reuse is ordered on the WORKER's stream only, so a release
+    right behind an asynchronous kernel that still reads them let the next coalesced batch overwrite them.  release(after=ctx)
+    records the consumer's position (fz_queue_release_after) and the worker waits for it: an aggregation queued on the rows of
+    every call -- behind a deliberate 2 ms delay on the consumer's stream -- followed at once by the release and by more calls
+    of the same size (which take the same pooled blocks) must still give the aggregate of the ORIGINAL signatures.
+     results still held when the queue closes keep a private copy of vk and release() on them is a no-op."""
+    import fusion.fusion as F
+    import fusion_hip
+    from fusion_hip.queue import BatchQueue
+    from fusion_hip.scheme import BatchScheme
+    params = F.fusion_setup(256, 77)
+    bs = BatchScheme(params, private_context=True)         # a non-default stream of its own: nothing orders it with the workers'
+    ctx, l, d, n = bs.ctx, params.num_rows_sk, params.degree, 512
+    rng = np.random.default_rng(11)
+    al = ctx.ntt_forward(rng.integers(-1, 2, size=(n, d)).astype(np.int32))
+    d_al = fusion_hip.DeviceBuffer.from_numpy(ctx, al)
+    with BatchQueue(params, workers=1, max_rows=n) as bq:
+        for rep in range(4):
+            seeds = [1000 * rep + i for i in range(n)]
+            msgs = [f"r{rep} m{i}" for i in range(n)]
+            r = bq.wait(bq.submit_keygen_sign(seeds, msgs))
+            want_sig = bs.sign_batch(*bs.keygen_batch(seeds), msgs)
+            want = ctx.aggregate_core(want_sig, al)
+            d_out = fusion_hip.DeviceBuffer(ctx, l * d * 4)
+            ctx.diag_delay(2000)                               # the consumer is BUSY: the aggregation below starts 2 ms from now
+            ctx.aggregate_core_dev(r.sig_ptr, d_al.ptr, d_out.ptr, n, l)
+            r.release(after=ctx)                               # no synchronisation on this side
+            nxt = [bq.submit_keygen_sign([5000 + 7 * k + i for i in range(n)], msgs) for k in range(2)]    # same sizes: the same pooled blocks
+            for t in nxt:
+                bq.wait(t).release()
+            ctx.synchronize()
+            assert np.array_equal(d_out.to_numpy(np.int32, (l, d)), want), rep
+            d_out.free()
+        held = bq.wait(bq.submit_keygen_sign([1, 2, 3], ["a", "b", "c"]))
+        vk_before = held.vk.copy()
+    # the queue is closed: the result is detached, not dangling
+    assert held.sig_ptr is None and np.array_equal(held.vk, vk_before)
+    held.release()
+    held.release(after=ctx)
+    d_al.free()
+    bs.close()

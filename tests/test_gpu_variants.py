@@ -197,16 +197,16 @@ def test_many_aggregates_verification_forms(secpar, coracle):
         ctx.close()
 
 
-@pytest.mark.parametrize("general", ["0", "1"])
+@pytest.mark.parametrize("unfused", ["0", "1"])
 @pytest.mark.parametrize("secpar", [128, 256])
-def test_broadcast_keygen_forms(secpar, general, coracle):
+def test_broadcast_keygen_forms(secpar, unfused, coracle):
     """fz_keygen_core_bcast -- one secret polynomial per key half, what the reference's seeded keygen produces (fusion.py:156-173,
-    :338-362) -- through the one-transform kernel (default) and through the general kernel with row stride 0
-    (FZ_KEYGEN_BCAST_GENERAL=1): both equal the oracle's keygen on the replicated rows, for any int32 in A and in the secret,
-    scheme ranks and ranks that leave row slots empty"""
+    :338-362) -- through the one-transform kernel (keygen_bcast_fused, the default) and through the three launches every other
+    degree takes (FZ_UNFUSED=1: rows expanded, transformed, multiplied by A): both equal the oracle's keygen on the replicated
+    rows, for any int32 in A and in the secret, scheme ranks and ranks that leave row slots empty"""
     P = O.PARAMS[secpar]
     q, d = P["q"], P["d"]
-    ctx = _ctx(P, {"FZ_KEYGEN_BCAST_GENERAL": general})
+    ctx = _ctx(P, {"FZ_UNFUSED": unfused})
     rng = np.random.default_rng(secpar + 77)
     try:
         for l, n in ((P["rank"], 9), (1, 3), (5, 2), (4 * (256 // d) * 4 + 1, 2), (300, 2)):
@@ -223,17 +223,16 @@ def test_broadcast_keygen_forms(secpar, general, coracle):
         ctx.close()
 
 
-@pytest.mark.parametrize("one_kernel", ["0", "1"])
-def test_device_sampler_forms(one_kernel):
-    """the reference's seeded secret-key sampler on the device (polynomials.py:436-467 driven by fusion.py:339-362) as seed +
-    draw kernels (default) and as the one lane-per-polynomial kernel (FZ_SAMPLER_ONE_KERNEL=1): both equal the C clone on the
-    host (itself pinned to CPython's random) -- one- and two-word seeds, bounds with few and many rejections, degrees that
-    end inside a generation and that need several, more keys than the two-kernel form takes (4096)"""
+def test_device_sampler_forms():
+    """the reference's seeded secret-key sampler on the device (polynomials.py:436-467 driven by fusion.py:339-362) in BOTH its
+    forms, which the launcher picks by size: seed + draw kernels up to 4096 keys, the one lane-per-polynomial kernel beyond
+    (the 4100-key case) -- each equals the C clone on the host (itself pinned to CPython's random): one- and two-word seeds,
+    bounds with few and many rejections, degrees that end inside a generation and that need several"""
     import fusion_hip
     from fusion_hip import hostpipe
     P = O.PARAMS[256]
     q = P["q"]
-    ctx = _ctx(P, {"FZ_SAMPLER_ONE_KERNEL": one_kernel})
+    ctx = _ctx(P, {})
     rng = np.random.default_rng(2024)
     try:
         for nn, deg, bound in ((1, 256, 52), (5, 64, 52), (70, 256, 1), (33, 16, 2**31 - 1), (3, 100, 7), (200, 256, 33),

@@ -25,10 +25,6 @@ def sign_verify(e):
     rank, world, l, d, P, args = e.rank, e.world, e.l, e.d, e.P, e.args
     comm, collective = e.comm, e.collective
     S, NSETS = 1024, 8
-    GROUPS = max(4, world)
-    while S % GROUPS:
-        GROUPS += 1
-    per = S // GROUPS
     rng = np.random.default_rng(1234 + rank)
     A = torch.empty((l, d), dtype=torch.int32, device=dev)                           # same on every rank
     ctx.fill_synthetic_dev(A.data_ptr(), l * d, 99)
@@ -58,237 +54,254 @@ def sign_verify(e):
         sets.append(dict(coef=coef, sk_hat=sk_hat, vk=vk, c_hat=c_hat, al_hat=al_hat, vkL=vk[:, 0].contiguous(),
                          vkR=vk[:, 1].contiguous(), sig=torch.empty((S, l, d), dtype=torch.int32, device=dev)))
     del coef0, cc0, aa0
-    # int64 sums as RECORDS: [set][aggregate][l*d sums of the aggregate | d sums of its verification target] -- one all-reduce
-    # per step covers a set's GROUPS records, and the records of all sets are uniformly strided, so ONE verification launch can
-    # take every aggregate of the 8 steps (below)
-    standin = args.exchange_standin_us if world == 1 else 0           # (a delay of known length in place of the all-reduce)
-    overlap = (comm is not None or standin > 0) and not args.no_exchange_overlap
-    # How many steps share ONE verification launch (a verification of 4-8 aggregates is a latency chain of 5 us on 4-8
-    # workgroups; 32 of them are 7 us): all 8 when the exchange does not run on a second stream (68.7 instead of 72.5 us per
-    # step with two launches per step).  With the overlap a captured graph whose exchange branch joins the compute branch only
-    # rarely loses the branch's stream priority -- with a one-rank RCCL all-reduce + a 40 us stand-in per step: one launch per
-    # 1 / 2 / 4 / 8 steps 69.8 / 93.5 / 99.9 / 91.7 us per step -- so there the default is one step per launch; a block of
-    # steps is verified behind the NEXT step's kernels (its sums have had a step's time to arrive).  With more than one step per launch rank r verifies every aggregate of the
-    # sets r, r + world, ...; --verify-per-step (= --verify-every 1): a launch per step over this rank's share of the
-    # step's aggregates (round 3's form).
-    vk = 1 if args.verify_per_step else (args.verify_every if args.verify_every > 0 else (1 if overlap else NSETS))
-    vk = max(1, min(vk, NSETS))
-    if world > NSETS:
-        vk = 1
-    batched = vk > 1
-    rec = l * d + d
-    nbuf = NSETS if (overlap or batched) else 1
-    pool = torch.zeros(nbuf * GROUPS * rec, dtype=torch.int64, device=dev)
-    g_lo, g_hi = e.shard_range(GROUPS, rank, world)      # per-step form: aggregates of every step verified by this rank
-    my_sets = [s_ for s_ in range(NSETS) if s_ % world == rank] if batched else list(range(NSETS))
-    d_verd = torch.full((NSETS * GROUPS,), -1, dtype=torch.int32, device=dev)        # verdict codes, read after the loops
-    torch.cuda.synchronize(dev)                       # the fills ran on torch's stream; the kernels below run on the context's
-    # The exchange step on a stream of its own (overlap): a second context issues fz_allreduce_i64 there behind an event per
-    # step ("partials written", compute -> exchange), so the all-reduce of step i (a latency of tens of microseconds at 2-8
-    # ranks, 0.7-1.4 MB) runs beside sign_core + the partial sums of step i + 1 instead of stalling the chip; the compute stream
-    # waits for the sums where it verifies (once per 8 steps, or per step one step late with --verify-per-step).  Same
-    # launches per signature, same results; round 3's form (everything on one stream): --no-exchange-overlap.
-    # The exchange stream has HIGH priority (bench.py): at normal priority the all-reduce kernel's workgroups wait for slots behind
-    # sign_core's 1024 -- 154 instead of 85 us per step with a one-rank RCCL all-reduce + a 40 us stand-in.
-    # (Measured and dropped: the verification on the exchange stream as well -- beside sign_core, which saturates the memory
-    # system, the verification's latency chain takes 4-10 times as long: 127-131 instead of 73-85 us per step, at either priority.)
-    cx = ev_part = ev_sum = None
-    if overlap:
-        cx = e.exchange_ctx           # created with its stream at the start of the process (bench.py: hardware queues go to streams in order)
-        ev_part = [e.fusion_hip.Event(ctx) for _ in range(NSETS)]
-        ev_sum = [e.fusion_hip.Event(ctx) for _ in range(NSETS)]
-
-    # Which collective: every rank verifies only ITS share of a step's aggregates, so a reduce-scatter (fz_reduce_scatter_i64:
-    # block r of the sums to rank r, half the traffic and steps of the all-reduce) is enough whenever the aggregates divide
-    # evenly over the ranks and verification is per step.  Chosen by a short calibration on the exchange stream -- 20 launches of
-    # each, every rank, max over ranks -- unless --exchange says so; the all-reduce stays unless the other form is >= 20 % faster.
-    use_rs, exch_cal = False, None
-    rs_ok = comm is not None and not batched and GROUPS % world == 0 and (g_hi - g_lo) * world == GROUPS
-    if args.exchange == "reduce-scatter" and not rs_ok:
-        raise RuntimeError("--exchange reduce-scatter needs a communicator, one verification launch per step and aggregates that divide over the ranks")
-    if rs_ok and args.exchange in ("auto", "reduce-scatter"):
-        xc = cx if overlap else ctx
-        cal = torch.zeros(GROUPS * rec, dtype=torch.int64, device=dev)
-        torch.cuda.synchronize(dev)
-        times = {}
-        try:
-            for name_, fn_ in (("all-reduce", lambda: xc.allreduce_i64_dev(comm, cal.data_ptr(), cal.numel())),
-                               ("reduce-scatter", lambda: xc.reduce_scatter_i64_dev(comm, cal.data_ptr(), (GROUPS // world) * rec))):
-                for _ in range(5):
-                    fn_()
-                xc.synchronize()
-                e.barrier()
-                t0_ = time.perf_counter()
-                for _ in range(20):
-                    fn_()
-                xc.synchronize()
-                times[name_] = e.max_over_ranks(time.perf_counter() - t0_) / 20 * 1e6
-            ok_ = 1.0
-        except e.fusion_hip.FusionHipError as exc:
-            sys.stderr.write(f"rank {rank}: exchange calibration failed: {exc}\n")
-            ok_ = 0.0
-        if e.min_over_ranks(ok_) >= 1.0:
-            exch_cal = {k_: round(v_, 2) for k_, v_ in times.items()}
-            use_rs = args.exchange == "reduce-scatter" or times["reduce-scatter"] < 0.8 * times["all-reduce"]
-        del cal
-
-    def part_of(i):
-        base = (i % nbuf) * GROUPS * rec
-        return pool[base:base + GROUPS * rec]
-
-    two_launch = args.sign_then_aggregate
-
-    def sv_compute(i):
-        s_, part = sets[i % NSETS], part_of(i)
-        if two_launch:               # round 3's form: the signatures are written, then read back by the aggregation
-            ctx.sign_core_dev(s_["sk_hat"].data_ptr(), s_["c_hat"].data_ptr(), s_["sig"].data_ptr(), S, l)
-            # aggregate partials and the verification target's partials: one pass over this rank's signers, one launch
-            ctx.aggregate_target_partial_batch_dev(s_["sig"].data_ptr(), s_["al_hat"].data_ptr(), s_["vkL"].data_ptr(),
-                                                   s_["vkR"].data_ptr(), s_["c_hat"].data_ptr(), part.data_ptr(), rec,
-                                                   part[l * d:].data_ptr(), rec, GROUPS, per, l)
-            return
-        # ONE pass: every signature is written as it is computed and enters its aggregate's sums (and the key pair the target's)
-        # from registers -- fz_sign_aggregate_target_partial_batch
-        ctx.sign_aggregate_target_partial_batch_dev(s_["sk_hat"].data_ptr(), s_["c_hat"].data_ptr(), s_["al_hat"].data_ptr(),
-                                                    s_["vkL"].data_ptr(), s_["vkR"].data_ptr(), s_["sig"].data_ptr(), part.data_ptr(), rec,
-                                                    part[l * d:].data_ptr(), rec, GROUPS, per, l)
-
-    def sv_exchange(i):              # the ONE exchange step (RCCL over xGMI)
-        part = part_of(i)
+    def measure(GROUPS):
+        """the leg for one split of a rank's 1024 signatures into GROUPS aggregates"""
+        per = S // GROUPS
+        # int64 sums as RECORDS: [set][aggregate][l*d sums of the aggregate | d sums of its verification target] -- one all-reduce
+        # per step covers a set's GROUPS records, and the records of all sets are uniformly strided, so ONE verification launch can
+        # take every aggregate of the 8 steps (below)
+        standin = args.exchange_standin_us if world == 1 else 0           # (a delay of known length in place of the all-reduce)
+        overlap = (comm is not None or standin > 0) and not args.no_exchange_overlap
+        # How many steps share ONE verification launch (a verification of 4-8 aggregates is a latency chain of 5 us on 4-8
+        # workgroups; 32 of them are 7 us): all 8 when the exchange does not run on a second stream (68.7 instead of 72.5 us per
+        # step with two launches per step).  With the overlap a captured graph whose exchange branch joins the compute branch only
+        # rarely loses the branch's stream priority -- with a one-rank RCCL all-reduce + a 40 us stand-in per step: one launch per
+        # 1 / 2 / 4 / 8 steps 69.8 / 93.5 / 99.9 / 91.7 us per step -- so there the default is one step per launch; a block of
+        # steps is verified behind the NEXT step's kernels (its sums have had a step's time to arrive).  With more than one step per launch rank r verifies every aggregate of the
+        # sets r, r + world, ...; --verify-per-step (= --verify-every 1): a launch per step over this rank's share of the
+        # step's aggregates (round 3's form).
+        vk = 1 if args.verify_per_step else (args.verify_every if args.verify_every > 0 else (1 if overlap else NSETS))
+        vk = max(1, min(vk, NSETS))
+        if world > NSETS:
+            vk = 1
+        batched = vk > 1
+        rec = l * d + d
+        nbuf = NSETS if (overlap or batched) else 1
+        pool = torch.zeros(nbuf * GROUPS * rec, dtype=torch.int64, device=dev)
+        g_lo, g_hi = e.shard_range(GROUPS, rank, world)      # per-step form: aggregates of every step verified by this rank
+        my_sets = [s_ for s_ in range(NSETS) if s_ % world == rank] if batched else list(range(NSETS))
+        d_verd = torch.full((NSETS * GROUPS,), -1, dtype=torch.int32, device=dev)        # verdict codes, read after the loops
+        torch.cuda.synchronize(dev)                       # the fills ran on torch's stream; the kernels below run on the context's
+        # The exchange step on a stream of its own (overlap): a second context issues fz_allreduce_i64 there behind an event per
+        # step ("partials written", compute -> exchange), so the all-reduce of step i (a latency of tens of microseconds at 2-8
+        # ranks, 0.7-1.4 MB) runs beside sign_core + the partial sums of step i + 1 instead of stalling the chip; the compute stream
+        # waits for the sums where it verifies (once per 8 steps, or per step one step late with --verify-per-step).  Same
+        # launches per signature, same results; round 3's form (everything on one stream): --no-exchange-overlap.
+        # The exchange stream has HIGH priority (bench.py): at normal priority the all-reduce kernel's workgroups wait for slots behind
+        # sign_core's 1024 -- 154 instead of 85 us per step with a one-rank RCCL all-reduce + a 40 us stand-in.
+        # (Measured and dropped: the verification on the exchange stream as well -- beside sign_core, which saturates the memory
+        # system, the verification's latency chain takes 4-10 times as long: 127-131 instead of 73-85 us per step, at either priority.)
+        cx = ev_part = ev_sum = None
         if overlap:
-            ev_part[i % NSETS].record(ctx)
-            ev_part[i % NSETS].wait(cx)
-            if comm is not None and use_rs:
-                cx.reduce_scatter_i64_dev(comm, part.data_ptr(), (GROUPS // world) * rec)
-            elif comm is not None:
-                cx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
-            if standin:
-                cx.diag_delay(standin)
-            ev_sum[i % NSETS].record(cx)
-        elif comm is not None or standin:
-            if comm is not None and use_rs:
-                ctx.reduce_scatter_i64_dev(comm, part.data_ptr(), (GROUPS // world) * rec)
-            elif comm is not None:
-                ctx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
-            if standin:
-                ctx.diag_delay(standin)
-        else:
-            e.allreduce_sum_i64(part)
+            cx = e.exchange_ctx           # created with its stream at the start of the process (bench.py: hardware queues go to streams in order)
+            ev_part = [e.fusion_hip.Event(ctx) for _ in range(NSETS)]
+            ev_sum = [e.fusion_hip.Event(ctx) for _ in range(NSETS)]
 
-    def verify_records(first, count):      # verdicts straight from the int64 sums, left on the device: no host synchronisation
-        if count > 0:
-            ctx.verify_partials_batch_async_dev(A.data_ptr(), pool[first * rec:].data_ptr(), rec, pool[first * rec + l * d:].data_ptr(), rec,
-                                                count, l, P["beta_vf"], d, d_verd[first:].data_ptr())
-
-    def sv_verify(lo, hi):           # the steps lo .. hi - 1 (their exchanges have been issued)
-        if overlap:
-            ev_sum[(hi - 1) % NSETS].wait(ctx)      # the exchange stream is in order: the last sums of the block arrive last
-        if not batched:
-            verify_records((lo % nbuf) * GROUPS + g_lo, g_hi - g_lo)
-        elif world == 1:
-            verify_records(lo * GROUPS, (hi - lo) * GROUPS)
-        else:
-            for s_ in range(lo, hi):
-                if s_ % world == rank:
-                    verify_records(s_ * GROUPS, GROUPS)
-
-    def sv_steps_once():             # NSETS steps
-        done_ = 0
-        for i in range(NSETS):
-            sv_compute(i)
-            sv_exchange(i)
-            ready = i if overlap else i + 1          # with the overlap a block is verified behind the NEXT step's kernels
-            if ready - done_ >= vk:
-                sv_verify(done_, ready)
-                done_ = ready
-        if done_ < NSETS:
-            sv_verify(done_, NSETS)
-
-    def my_records():
-        if batched:
-            return [s_ * GROUPS + g_ for s_ in my_sets for g_ in range(GROUPS)]
-        return [b_ * GROUPS + g_ for b_ in range(nbuf) for g_ in range(g_lo, g_hi)]
-
-    def verdicts_ok():
-        v = d_verd.tolist()
-        return all(v[k] == 0 for k in my_records())
-
-    sv_steps_once()
-    e.barrier()
-    torch.cuda.synchronize(dev)
-    assert verdicts_ok(), f"verify verdicts {d_verd.tolist()}"
-    # one graph = NSETS steps (every set once); refused together if any rank cannot capture (e.g. the collective)
-    sv_graph, captured = None, 0.0
-    if not args.no_graph and (world == 1 or comm is not None):      # (a stand-in delay is a kernel: capturable)
-        try:
-            ctx.graph_begin()
+        # Which collective: every rank verifies only ITS share of a step's aggregates, so a reduce-scatter (fz_reduce_scatter_i64:
+        # block r of the sums to rank r, half the traffic and steps of the all-reduce) is enough whenever the aggregates divide
+        # evenly over the ranks and verification is per step.  Chosen by a short calibration on the exchange stream -- 20 launches of
+        # each, every rank, max over ranks -- unless --exchange says so; the all-reduce stays unless the other form is >= 20 % faster.
+        use_rs, exch_cal = False, None
+        rs_ok = comm is not None and not batched and GROUPS % world == 0 and (g_hi - g_lo) * world == GROUPS
+        if args.exchange == "reduce-scatter" and not rs_ok:
+            raise RuntimeError("--exchange reduce-scatter needs a communicator, one verification launch per step and aggregates that divide over the ranks")
+        if rs_ok and args.exchange in ("auto", "reduce-scatter"):
+            xc = cx if overlap else ctx
+            cal = torch.zeros(GROUPS * rec, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize(dev)
+            times = {}
             try:
-                sv_steps_once()
-            finally:
-                sv_graph = ctx.graph_end()
-            captured = 1.0
-        except e.fusion_hip.FusionHipError as exc:
-            sys.stderr.write(f"rank {rank}: sign_verify capture failed: {exc}\n")
+                for name_, fn_ in (("all-reduce", lambda: xc.allreduce_i64_dev(comm, cal.data_ptr(), cal.numel())),
+                                   ("reduce-scatter", lambda: xc.reduce_scatter_i64_dev(comm, cal.data_ptr(), (GROUPS // world) * rec))):
+                    for _ in range(5):
+                        fn_()
+                    xc.synchronize()
+                    e.barrier()
+                    t0_ = time.perf_counter()
+                    for _ in range(20):
+                        fn_()
+                    xc.synchronize()
+                    times[name_] = e.max_over_ranks(time.perf_counter() - t0_) / 20 * 1e6
+                ok_ = 1.0
+            except e.fusion_hip.FusionHipError as exc:
+                sys.stderr.write(f"rank {rank}: exchange calibration failed: {exc}\n")
+                ok_ = 0.0
+            if e.min_over_ranks(ok_) >= 1.0:
+                exch_cal = {k_: round(v_, 2) for k_, v_ in times.items()}
+                use_rs = args.exchange == "reduce-scatter" or times["reduce-scatter"] < 0.8 * times["all-reduce"]
+            del cal
+
+        def part_of(i):
+            base = (i % nbuf) * GROUPS * rec
+            return pool[base:base + GROUPS * rec]
+
+        two_launch = args.sign_then_aggregate
+
+        def sv_compute(i):
+            s_, part = sets[i % NSETS], part_of(i)
+            if two_launch:               # round 3's form: the signatures are written, then read back by the aggregation
+                ctx.sign_core_dev(s_["sk_hat"].data_ptr(), s_["c_hat"].data_ptr(), s_["sig"].data_ptr(), S, l)
+                # aggregate partials and the verification target's partials: one pass over this rank's signers, one launch
+                ctx.aggregate_target_partial_batch_dev(s_["sig"].data_ptr(), s_["al_hat"].data_ptr(), s_["vkL"].data_ptr(),
+                                                       s_["vkR"].data_ptr(), s_["c_hat"].data_ptr(), part.data_ptr(), rec,
+                                                       part[l * d:].data_ptr(), rec, GROUPS, per, l)
+                return
+            # ONE pass: every signature is written as it is computed and enters its aggregate's sums (and the key pair the target's)
+            # from registers -- fz_sign_aggregate_target_partial_batch
+            ctx.sign_aggregate_target_partial_batch_dev(s_["sk_hat"].data_ptr(), s_["c_hat"].data_ptr(), s_["al_hat"].data_ptr(),
+                                                        s_["vkL"].data_ptr(), s_["vkR"].data_ptr(), s_["sig"].data_ptr(), part.data_ptr(), rec,
+                                                        part[l * d:].data_ptr(), rec, GROUPS, per, l)
+
+        def sv_exchange(i):              # the ONE exchange step (RCCL over xGMI)
+            part = part_of(i)
+            if overlap:
+                ev_part[i % NSETS].record(ctx)
+                ev_part[i % NSETS].wait(cx)
+                if comm is not None and use_rs:
+                    cx.reduce_scatter_i64_dev(comm, part.data_ptr(), (GROUPS // world) * rec)
+                elif comm is not None:
+                    cx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
+                if standin:
+                    cx.diag_delay(standin)
+                ev_sum[i % NSETS].record(cx)
+            elif comm is not None or standin:
+                if comm is not None and use_rs:
+                    ctx.reduce_scatter_i64_dev(comm, part.data_ptr(), (GROUPS // world) * rec)
+                elif comm is not None:
+                    ctx.allreduce_i64_dev(comm, part.data_ptr(), part.numel())
+                if standin:
+                    ctx.diag_delay(standin)
+            else:
+                e.allreduce_sum_i64(part)
+
+        def verify_records(first, count):      # verdicts straight from the int64 sums, left on the device: no host synchronisation
+            if count > 0:
+                ctx.verify_partials_batch_async_dev(A.data_ptr(), pool[first * rec:].data_ptr(), rec, pool[first * rec + l * d:].data_ptr(), rec,
+                                                    count, l, P["beta_vf"], d, d_verd[first:].data_ptr())
+
+        def sv_verify(lo, hi):           # the steps lo .. hi - 1 (their exchanges have been issued)
+            if overlap:
+                ev_sum[(hi - 1) % NSETS].wait(ctx)      # the exchange stream is in order: the last sums of the block arrive last
+            if not batched:
+                verify_records((lo % nbuf) * GROUPS + g_lo, g_hi - g_lo)
+            elif world == 1:
+                verify_records(lo * GROUPS, (hi - lo) * GROUPS)
+            else:
+                for s_ in range(lo, hi):
+                    if s_ % world == rank:
+                        verify_records(s_ * GROUPS, GROUPS)
+
+        def sv_steps_once():             # NSETS steps
+            done_ = 0
+            for i in range(NSETS):
+                sv_compute(i)
+                sv_exchange(i)
+                ready = i if overlap else i + 1          # with the overlap a block is verified behind the NEXT step's kernels
+                if ready - done_ >= vk:
+                    sv_verify(done_, ready)
+                    done_ = ready
+            if done_ < NSETS:
+                sv_verify(done_, NSETS)
+
+        def my_records():
+            if batched:
+                return [s_ * GROUPS + g_ for s_ in my_sets for g_ in range(GROUPS)]
+            return [b_ * GROUPS + g_ for b_ in range(nbuf) for g_ in range(g_lo, g_hi)]
+
+        def verdicts_ok():
+            v = d_verd.tolist()
+            return all(v[k] == 0 for k in my_records())
+
+        sv_steps_once()
+        e.barrier()
+        torch.cuda.synchronize(dev)
+        assert verdicts_ok(), f"verify verdicts {d_verd.tolist()}"
+        # one graph = NSETS steps (every set once); refused together if any rank cannot capture (e.g. the collective)
+        sv_graph, captured = None, 0.0
+        if not args.no_graph and (world == 1 or comm is not None):      # (a stand-in delay is a kernel: capturable)
+            try:
+                ctx.graph_begin()
+                try:
+                    sv_steps_once()
+                finally:
+                    sv_graph = ctx.graph_end()
+                captured = 1.0
+            except e.fusion_hip.FusionHipError as exc:
+                sys.stderr.write(f"rank {rank}: sign_verify capture failed: {exc}\n")
+                sv_graph = None
+        if e.min_over_ranks(captured) < 1.0:
             sv_graph = None
-    if e.min_over_ranks(captured) < 1.0:
-        sv_graph = None
 
-    def sv_round():
+        def sv_round():
+            if sv_graph is not None:
+                sv_graph.launch()
+            else:
+                sv_steps_once()
+        for _ in range(2):
+            sv_round()
+        for _ in range(40 if args.prewarm_ms > 0 else 0):      # count-based: every rank must issue the same collectives
+            sv_round()
+        e.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        sv_round()
+        torch.cuda.synchronize(dev)
+        t_once = max(time.perf_counter() - t0, 1e-6)
+        sv_rounds = int(e.max_over_ranks(max(3.0, -(-2 * e.MIN_REGION_MS * 1e-3 // t_once))))
+        e.barrier()
+        t0 = time.perf_counter()
+        for _ in range(sv_rounds):
+            sv_round()
+        e.barrier()
+        dt = e.max_over_ranks(time.perf_counter() - t0)
+        torch.cuda.synchronize(dev)
+        assert verdicts_ok(), "a verification failed inside the timed region"
+        sv_steps = sv_rounds * NSETS
+        sv_bytes = S * ((3 * l + 1) + (l + 5)) * 4 * d
+        sv = {"value": S * world * sv_steps / dt, "unit": "signatures signed+aggregated+verified per s",
+              "signatures_per_rank": S, "aggregates": GROUPS, "signers_per_aggregate": per * world,
+              "steps": sv_steps, "ms_per_step": dt / sv_steps * 1e3, "operand_sets_cycled": NSETS,
+              "launch": "hipGraph replay of %d steps (fz_graph_*)" % NSETS if sv_graph is not None else "one by one",
+              "collective": collective,
+              "exchange": ("on a second stream, overlapping the next step's kernels (fz_event_*)" if overlap else
+                           "on the compute stream" if (comm is not None or standin) else "none" if world == 1 else "torch.distributed, host-ordered"),
+              "exchange_standin_us": standin or None,
+              "exchange_collective": ("ncclReduceScatter (fz_reduce_scatter_i64)" if use_rs else "ncclAllReduce (fz_allreduce_i64)") if comm is not None else None,
+              "exchange_calibration_us": exch_cal,
+              "verification": f"one launch per {vk} steps" if batched else "one launch per step",
+              "sign_and_aggregate": "two launches (sign_core, then aggregate + target partials)" if two_launch else
+                                    "one launch (fz_sign_aggregate_target_partial_batch: signatures written and aggregated in one pass)",
+              # SURVEY 8d's bytes of the TWO kernels ((3l + 1) + (l + 5) rows per signature), for reference only: the fraction of the
+              # peak is quoted on what the launches MOVE (moved_frac_per_gpu) -- round 4's hbm_frac_per_gpu counted bytes the fused
+              # launch never moves and is gone (VERDICT r04 weak #5)
+              "survey_8d_GB/s_per_gpu": sv_bytes * sv_steps / dt / 1e9,
+              # what the launches actually move per signature: in one pass the l rows of a signature are written and never read
+              # back ((3l + 4) rows instead of SURVEY 8d's (3l + 1) + (l + 5) for the two kernels the algorithmic figure counts)
+              "moved_frac_per_gpu": S * ((3 * l + 4) if not two_launch else ((3 * l + 1) + (l + 5))) * 4 * d * sv_steps / dt / 1e9 / e.HBM_PEAK_GBS,
+              "note": "algebra cores only: signing + aggregate and target partials (ONE pass, one launch: fz_sign_aggregate_target_partial_batch), int64 all-reduce, "
+                      "verification from the int64 sums (ONE launch for the aggregates of all 8 steps unless --verify-per-step); every step works on "
+                      "the next of 8 operand sets (2.1 GB), so keys and signatures come from HBM; host hashing of str(vk) excluded"}
+        sv_graph_used = sv_graph is not None
         if sv_graph is not None:
-            sv_graph.launch()
-        else:
-            sv_steps_once()
-    for _ in range(2):
-        sv_round()
-    for _ in range(40 if args.prewarm_ms > 0 else 0):      # count-based: every rank must issue the same collectives
-        sv_round()
-    e.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    sv_round()
-    torch.cuda.synchronize(dev)
-    t_once = max(time.perf_counter() - t0, 1e-6)
-    sv_rounds = int(e.max_over_ranks(max(3.0, -(-2 * e.MIN_REGION_MS * 1e-3 // t_once))))
-    e.barrier()
-    t0 = time.perf_counter()
-    for _ in range(sv_rounds):
-        sv_round()
-    e.barrier()
-    dt = e.max_over_ranks(time.perf_counter() - t0)
-    torch.cuda.synchronize(dev)
-    assert verdicts_ok(), "a verification failed inside the timed region"
-    sv_steps = sv_rounds * NSETS
-    sv_bytes = S * ((3 * l + 1) + (l + 5)) * 4 * d
-    sv = {"value": S * world * sv_steps / dt, "unit": "signatures signed+aggregated+verified per s",
-          "signatures_per_rank": S, "aggregates": GROUPS, "signers_per_aggregate": per * world,
-          "steps": sv_steps, "ms_per_step": dt / sv_steps * 1e3, "operand_sets_cycled": NSETS,
-          "launch": "hipGraph replay of %d steps (fz_graph_*)" % NSETS if sv_graph is not None else "one by one",
-          "collective": collective,
-          "exchange": ("on a second stream, overlapping the next step's kernels (fz_event_*)" if overlap else
-                       "on the compute stream" if (comm is not None or standin) else "none" if world == 1 else "torch.distributed, host-ordered"),
-          "exchange_standin_us": standin or None,
-          "exchange_collective": ("ncclReduceScatter (fz_reduce_scatter_i64)" if use_rs else "ncclAllReduce (fz_allreduce_i64)") if comm is not None else None,
-          "exchange_calibration_us": exch_cal,
-          "verification": f"one launch per {vk} steps" if batched else "one launch per step",
-          "sign_and_aggregate": "two launches (sign_core, then aggregate + target partials)" if two_launch else
-                                "one launch (fz_sign_aggregate_target_partial_batch: signatures written and aggregated in one pass)",
-          "algorithmic_GB/s_per_gpu": sv_bytes * sv_steps / dt / 1e9,
-          "hbm_frac_per_gpu": sv_bytes * sv_steps / dt / 1e9 / e.HBM_PEAK_GBS,
-          # what the launches actually move per signature: in one pass the l rows of a signature are written and never read
-          # back ((3l + 4) rows instead of SURVEY 8d's (3l + 1) + (l + 5) for the two kernels the algorithmic figure counts)
-          "moved_frac_per_gpu": S * ((3 * l + 4) if not two_launch else ((3 * l + 1) + (l + 5))) * 4 * d * sv_steps / dt / 1e9 / e.HBM_PEAK_GBS,
-          "note": "algebra cores only: signing + aggregate and target partials (ONE pass, one launch: fz_sign_aggregate_target_partial_batch), int64 all-reduce, "
-                  "verification from the int64 sums (ONE launch for the aggregates of all 8 steps unless --verify-per-step); every step works on "
-                  "the next of 8 operand sets (2.1 GB), so keys and signatures come from HBM; host hashing of str(vk) excluded"}
-    sv_graph_used = sv_graph is not None
-    if sv_graph is not None:
-        sv_graph.destroy()
-    if overlap:
-        ctx.synchronize()
-        cx.synchronize()
-        for ev in ev_part + ev_sum:
-            ev.destroy()
+            sv_graph.destroy()
+        if overlap:
+            ctx.synchronize()
+            cx.synchronize()
+            for ev in ev_part + ev_sum:
+                ev.destroy()
+        return sv, sv_graph_used
 
+    GROUPS = max(4, world)
+    while S % GROUPS:
+        GROUPS += 1
+    per = S // GROUPS
+    sv, sv_graph_used = measure(GROUPS)
+    if world == 1 and comm is None and not args.exchange_standin_us:
+        # BASELINE configs[3]'s own shape on one GPU: ONE aggregate over all 1024 signers (VERDICT r04 #4; the default above splits
+        # the rank's 1024 signatures into four aggregates of 256 -- at N ranks: N aggregates of 128 x N signers, every rank verifying)
+        one, _ = measure(1)
+        sv["one_aggregate"] = {k_: one[k_] for k_ in ("value", "unit", "ms_per_step", "moved_frac_per_gpu", "aggregates", "signers_per_aggregate",
+                                                       "steps", "verification", "sign_and_aggregate")}
     # BASELINE configs[2]: 1024 independent keygen + sign per step (keygen_core: 2*l transforms + two A.s products per
     # key; sign_core: sigma = L*c + R), no exchange step: ranks are independent
     def ks_step(i):
@@ -531,7 +544,7 @@ def end_to_end(e):
 def _queue_leg(e, bs, params):
     """keygen_batch + sign_batch at BASELINE's 1024 per call from ONE Python thread through the asynchronous batch queue
     (fusion_hip.queue.BatchQueue = fz_queue_* below Python) -- reference call pattern fusion.py:338-373, :534-557.  The same
-    work per call as tools/concurrent_batches.py (verification keys come back to the host, keys and signatures are dropped on
+    work per call as tools/probes/concurrent_batches.py (verification keys come back to the host, keys and signatures are dropped on
     the device), which needed 8-16 Python threads for 3.8-4.3 M pairs/s (profiles/r03_concurrent_batches.txt)."""
     from fusion_hip.queue import BatchQueue, PackedMessages
     np = e.np

@@ -24,30 +24,30 @@ step timeout -k 10 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
 step timeout -k 10 120 ./tools/microbench/build/launch_floor > $OUT/${TAG}_launch_floor.txt 2>&1
 step timeout -k 10 300 python tools/kernel_table.py > $OUT/${TAG}_kernel_table.txt 2>&1
 step timeout -k 10 300 python tools/kernel_table.py --secpar 128 > $OUT/${TAG}_kernel_table_secpar128.txt 2>&1
-step timeout -k 10 400 python tools/agg_direct_ab.py > $OUT/${TAG}_aggregate_direct_ab.txt 2>&1
-step timeout -k 10 300 python tools/agg_direct_ab.py --small >> $OUT/${TAG}_aggregate_direct_ab.txt 2>&1
-step timeout -k 10 200 python tools/ntt_ab.py > $OUT/${TAG}_ntt_small_batches.txt 2>&1
-step timeout -k 10 200 python tools/challenge_bench.py > $OUT/${TAG}_challenge_pipeline.txt 2>&1
-step timeout -k 10 200 python tools/keygen_probe.py > $OUT/${TAG}_keygen_end_to_end.txt 2>&1
-step timeout -k 10 200 python tools/agg_probe.py > $OUT/${TAG}_aggregate_end_to_end.txt 2>&1
-step timeout -k 10 200 python tools/copy_bw.py > $OUT/${TAG}_copy_ceiling.txt 2>&1
-step timeout -k 10 200 python tools/dispatch_dist.py > $OUT/${TAG}_dispatch_distribution.txt 2>&1
-step timeout -k 10 300 python tools/numa_placement.py > $OUT/${TAG}_numa_placement.txt 2>&1
-for st in none 0 1; do FZ_NO_PIN=1 timeout -k 10 100 python tools/numa_switch.py $st >> $OUT/${TAG}_numa_placement.txt 2>&1; done
-step timeout -k 10 200 python tools/keccak_bench.py > $OUT/${TAG}_keccak_variants_gpu_host.txt 2>&1
+step timeout -k 10 400 python tools/probes/agg_direct_ab.py > $OUT/${TAG}_aggregate_direct_ab.txt 2>&1
+step timeout -k 10 300 python tools/probes/agg_direct_ab.py --small >> $OUT/${TAG}_aggregate_direct_ab.txt 2>&1
+step timeout -k 10 200 python tools/probes/ntt_ab.py > $OUT/${TAG}_ntt_small_batches.txt 2>&1
+step timeout -k 10 200 python tools/probes/challenge_bench.py > $OUT/${TAG}_challenge_pipeline.txt 2>&1
+step timeout -k 10 200 python tools/probes/keygen_probe.py > $OUT/${TAG}_keygen_end_to_end.txt 2>&1
+step timeout -k 10 200 python tools/probes/agg_probe.py > $OUT/${TAG}_aggregate_end_to_end.txt 2>&1
+step timeout -k 10 200 python tools/probes/copy_bw.py > $OUT/${TAG}_copy_ceiling.txt 2>&1
+step timeout -k 10 200 python tools/probes/dispatch_dist.py > $OUT/${TAG}_dispatch_distribution.txt 2>&1
+step timeout -k 10 300 python tools/probes/numa_placement.py > $OUT/${TAG}_numa_placement.txt 2>&1
+for st in none 0 1; do FZ_NO_PIN=1 timeout -k 10 100 python tools/probes/numa_switch.py $st >> $OUT/${TAG}_numa_placement.txt 2>&1; done
+step timeout -k 10 200 python tools/probes/keccak_bench.py > $OUT/${TAG}_keccak_variants_gpu_host.txt 2>&1
 step timeout -k 10 300 ./tools/microbench/build/ntt_variants 300 > $OUT/${TAG}_ntt_variants_current_kernels.txt 2>&1
 step timeout -k 10 120 ./tools/microbench/build/ntt_structures 200 > $OUT/${TAG}_ntt_structures.txt 2>&1
 step timeout -k 10 120 ./tools/microbench/build/access_pattern 100 > $OUT/${TAG}_access_pattern.txt 2>&1
-step timeout -k 10 200 python tools/clock_under_load.py > $OUT/${TAG}_shader_clock_under_load.txt 2>&1
-step timeout -k 10 200 python tools/clock_under_load.py --secpar 128 >> $OUT/${TAG}_shader_clock_under_load.txt 2>&1
-step timeout -k 10 600 bash tools/matvec_ab.sh > $OUT/${TAG}_matvec_ab_raw.txt 2>&1
-step timeout -k 10 300 python tools/queue_probe.py > $OUT/${TAG}_queue_probe.txt 2>&1
-step timeout -k 10 300 python tools/sharded_modes.py > $OUT/${TAG}_sharded_alpha_modes_raw.txt 2>&1
+step timeout -k 10 200 python tools/probes/clock_under_load.py > $OUT/${TAG}_shader_clock_under_load.txt 2>&1
+step timeout -k 10 200 python tools/probes/clock_under_load.py --secpar 128 >> $OUT/${TAG}_shader_clock_under_load.txt 2>&1
+step timeout -k 10 600 bash tools/probes/matvec_ab.sh > $OUT/${TAG}_matvec_ab_raw.txt 2>&1
+step timeout -k 10 300 python tools/probes/queue_probe.py > $OUT/${TAG}_queue_probe.txt 2>&1
+step timeout -k 10 300 python tools/probes/sharded_modes.py > $OUT/${TAG}_sharded_alpha_modes_raw.txt 2>&1
 step timeout -k 10 300 python tools/benchmarks.py 256 128 > $OUT/${TAG}_api_benchmarks.json 2> $OUT/api_benchmarks.err
-step timeout -k 10 200 python tools/object_api_profile.py 256 16 > $OUT/${TAG}_object_api_profile.txt 2>&1
-step timeout -k 10 600 bash tools/exchange_overlap.sh > $OUT/${TAG}_exchange_overlap.txt 2>&1
-step timeout -k 10 400 python tools/hw_queue_probe.py > $OUT/${TAG}_hw_queue_oversubscription.txt 2>&1
-step timeout -k 10 300 python tools/stream_sweep.py > $OUT/${TAG}_multi_stream_sweep.txt 2>&1
+step timeout -k 10 200 python tools/probes/object_api_profile.py 256 16 > $OUT/${TAG}_object_api_profile.txt 2>&1
+step timeout -k 10 600 bash tools/probes/exchange_overlap.sh > $OUT/${TAG}_exchange_overlap.txt 2>&1
+step timeout -k 10 400 python tools/probes/hw_queue_probe.py > $OUT/${TAG}_hw_queue_oversubscription.txt 2>&1
+step timeout -k 10 300 python tools/probes/stream_sweep.py > $OUT/${TAG}_multi_stream_sweep.txt 2>&1
 step timeout -k 10 600 python bench.py --full --full-out $OUT/${TAG}_bench_full.json > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations from the profiler: the bench's transform launches, the cold kernel table, the challenge pipeline
@@ -61,20 +61,20 @@ step timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cp $OUT/profd/*/*_kernel_stats.csv $OUT/${TAG}_bench_default_rocprofv3_kernel_stats.csv 2>/dev/null
 step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profk -- python3 $R/tools/kernel_table.py > $OUT/profk.log 2>&1
 cp $OUT/profk/*/*_kernel_stats.csv $OUT/${TAG}_kernel_table_rocprofv3_kernel_stats.csv 2>/dev/null
-step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profc -- python3 $R/tools/challenge_bench.py > $OUT/profc.log 2>&1
+step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profc -- python3 $R/tools/probes/challenge_bench.py > $OUT/profc.log 2>&1
 cp $OUT/profc/*/*_kernel_stats.csv $OUT/${TAG}_challenge_rocprofv3_kernel_stats.csv 2>/dev/null
 # PMC passes: one counter set per pass, nothing else traced
 for set in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU"; do
   n=$(echo $set | tr " " "_" | cut -c1-30)
   step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcb/$n -- python3 $R/bench.py --headline-only --no-graph --steps 50 --prewarm-ms 20 --full-out $OUT/pmcb_bench_full.json > $OUT/pmcb_$n.log 2>&1
-  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc20/$n -- python3 $R/tools/prof_ntt.py 20 30 > $OUT/pmc20_$n.log 2>&1
-  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcs/$n -- python3 $R/tools/prof_scheme.py 12 > $OUT/pmcs_$n.log 2>&1
+  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc20/$n -- python3 $R/tools/probes/prof_ntt.py 20 30 > $OUT/pmc20_$n.log 2>&1
+  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcs/$n -- python3 $R/tools/probes/prof_scheme.py 12 > $OUT/pmcs_$n.log 2>&1
 done
 # where the waves' cycles go (issue, stalls, LDS): two SQ counter sets over the cold scheme kernels
-step timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/sq1 -- python3 $R/tools/prof_scheme.py 6 > $OUT/sq1.log 2>&1
-step timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq2 -- python3 $R/tools/prof_scheme.py 6 > $OUT/sq2.log 2>&1
+step timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/sq1 -- python3 $R/tools/probes/prof_scheme.py 6 > $OUT/sq1.log 2>&1
+step timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq2 -- python3 $R/tools/probes/prof_scheme.py 6 > $OUT/sq2.log 2>&1
 cd $R
-python3 tools/pmc_stalls.py $OUT/sq1/*/*counter_collection.csv $OUT/sq2/*/*counter_collection.csv > $OUT/${TAG}_wave_cycles.txt
+python3 tools/probes/pmc_stalls.py $OUT/sq1/*/*counter_collection.csv $OUT/sq2/*/*counter_collection.csv > $OUT/${TAG}_wave_cycles.txt
 python3 tools/trace_summary.py $OUT/prof/*/*_kernel_trace.csv > $OUT/${TAG}_bench_rocprofv3_by_grid.csv 2>/dev/null
 python3 tools/trace_summary.py $OUT/profd/*/*_kernel_trace.csv > $OUT/${TAG}_bench_default_rocprofv3_by_grid.csv 2>/dev/null
 python3 tools/trace_summary.py $OUT/profk/*/*_kernel_trace.csv > $OUT/${TAG}_kernel_table_rocprofv3_by_grid.csv 2>/dev/null

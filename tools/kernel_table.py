@@ -163,7 +163,7 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
         nb = 4096
         run("ntt_multi pair 2x4096 (fwd + inv)", 2 * nb, 2 * row, 2 * nb * row, 2 * nb * row,
             lambda i, o: ctx.ntt_multi_dev([(i, o, nb, False), (i + nb * row, o + nb * row, nb, True)]),
-            note="HOST-PACED here (the job table is built per launch in Python): see tools/ntt_ab.py / bench.py for the dense figure")
+            note="HOST-PACED here (the job table is built per launch in Python): see tools/probes/ntt_ab.py / bench.py for the dense figure")
     for b in (pool_in, pool_out, A):
         b.free()
     return out

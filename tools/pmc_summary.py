@@ -10,7 +10,17 @@ from collections import defaultdict
 
 root, tag = sys.argv[1], sys.argv[2]
 GROUPS = {"pmcb": ("B=4096 (bench launch)", 4096), "pmc20": ("B=2^20", 1 << 20)}
-# scheme kernels (tools/prof_scheme.py, secpar 256: l = 83, d = 256): algorithmic bytes per launch from SURVEY.md 8d
+# what bench.py itself says its dominant launch is (the PMC passes run bench.py --headline-only --no-graph): kernel name and
+# transforms per launch -- the 16-per-lane multi-job kernel's grid is the resident grid whatever the launch holds, so its rows
+# cannot be read off the grid as the radix-4 kernels' can
+BENCH = {}
+try:
+    with open(os.path.join(root, "pmcb_bench_full.json")) as fh:
+        _r = json.load(fh)["roofline"]
+    BENCH = {"kernel": _r["kernel"].split("(")[0], "rows": int(_r["units_per_launch"])}
+except Exception:
+    pass
+# scheme kernels (tools/probes/prof_scheme.py, secpar 256: l = 83, d = 256): algorithmic bytes per launch from SURVEY.md 8d
 L_, D_ = 83, 256
 SCHEME_BYTES = {"keygen_fused": 1024 * (4 * L_ + 2) * 4 * D_, "sign_kernel": 1024 * (3 * L_ + 1) * 4 * D_,
                 "matvec_kernel": 2048 * (L_ + 1) * 4 * D_, "matvec_sliced_kernel": 2048 * (L_ + 1) * 4 * D_, "pw_kernel": 1024 * L_ * D_ * 12,
@@ -34,10 +44,16 @@ for sub, (label, rows) in GROUPS.items():
                 dur[short][int(r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
     for k, counters in per.items():
         e = {}
+        is_bench = sub == "pmcb" and BENCH and k.replace(" ", "") == BENCH["kernel"].replace(" ", "")
         for c, by_dispatch in counters.items():
             ids = sorted(by_dispatch)
             if len(ids) > 4:
                 ids = ids[2:]
+            if is_bench and c in ("FETCH_SIZE", "WRITE_SIZE") and len(ids) > 4:
+                # FULL launches only: a run of pipelined steps opens with a forward-only launch and closes with an inverse-only
+                # one (half the jobs, half the bytes, the same kernel) -- dropped by their own counter value
+                med = sorted(by_dispatch[i] for i in ids)[len(ids) // 2]
+                ids = [i for i in ids if by_dispatch[i] >= 0.75 * med]
             e[c] = sum(by_dispatch[i] for i in ids) / len(ids)
             e.setdefault("dispatches_averaged", len(ids))
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
@@ -50,6 +66,8 @@ for sub, (label, rows) in GROUPS.items():
             import re
             m4 = re.search(r"ntt_(?:fwd4|inv4|jobs4)<(\d+), (?:true|false), (\d+), (\d+)[,>]", k)
             rows_k = (grid.get(k, 0) // 64) * int(m4.group(2)) if m4 and grid.get(k) else rows
+            if is_bench:
+                rows_k = BENCH["rows"]
             e["rows_per_launch"] = rows_k
             e["algorithmic_bytes_per_launch"] = rows_k * 2048
             e["traffic_over_algorithmic"] = e["traffic_bytes_per_launch"] / e["algorithmic_bytes_per_launch"]
@@ -69,7 +87,7 @@ with open(os.path.join(root, f"{tag}_pmc_ntt.json"), "w") as fh:
 print(json.dumps(out, indent=1))
 
 # ---- scheme kernels ----------------------------------------------------------------------------------------------
-sch = {"source": out["source"] + "; launches of tools/prof_scheme.py (cold operand sets)", "kernels": {}}
+sch = {"source": out["source"] + "; launches of tools/probes/prof_scheme.py (cold operand sets)", "kernels": {}}
 per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
 dur, grid = defaultdict(dict), {}
 for path in glob.glob(os.path.join(root, "pmcs", "*", "*", "*_counter_collection.csv")):

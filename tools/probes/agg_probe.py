@@ -1,6 +1,6 @@
 """where the end-to-end aggregate / verify time goes (host pipeline pieces timed one by one)"""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, "fusion-cryptography_amd")); sys.path.insert(0, R)
 import numpy as np
 import fusion.fusion as F

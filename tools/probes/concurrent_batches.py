@@ -13,7 +13,7 @@ import time
 # (read when the runtime starts: before the first HIP call).  Measured: 8 workers 2.6 M pairs/s with 4 queues, 3.9 M/s with 16.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "fusion-cryptography_amd"))
 
 import fusion.fusion as F  # noqa: E402

@@ -1,6 +1,6 @@
 """distribution of per-dispatch durations (begin/end events) of the B=4096 transforms, several passes in one process"""
 import os, sys, time, ctypes
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, "fusion-cryptography_amd")); sys.path.insert(0, R)
 import numpy as np
 import fusion_hip

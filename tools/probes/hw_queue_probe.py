@@ -12,14 +12,14 @@ created, up to GPU_MAX_HW_QUEUES, and then shares.  Idle streams cost nothing as
 own; but RCCL creates several streams per communicator, so chains created AFTER a communicator (fz_comm_create or a
 torch.distributed "nccl" group) share queues: 1.75 G NTT/s instead of 2.25 G here, 0.84 G in bench.py's process.  Created
 BEFORE any communicator the chains keep their queues: bench.py creates its chain contexts first thing.
-usage: python tools/hw_queue_probe.py            (the sweep)
-       python tools/hw_queue_probe.py child S K COMM TORCH    (one point)"""
+usage: python tools/probes/hw_queue_probe.py            (the sweep)
+       python tools/probes/hw_queue_probe.py child S K COMM TORCH    (one point)"""
 import os
 import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def child(S, K, with_comm, with_torch=0):

@@ -1,6 +1,6 @@
 """keygen_fused cold timing over key counts (workgroup-round quantisation check)"""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, "fusion-cryptography_amd")); sys.path.insert(0, R)
 import fusion_hip
 from fusion_hip.numa import pin_to_gpu_node

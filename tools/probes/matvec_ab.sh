@@ -4,7 +4,7 @@
 # per column above), 1 / 2 / 4 / 8 / 16 = integer accumulation with that many slices of the k range per column, 0 = the
 # library's choice (the one-workgroup-per-product kernel up to two products per CU, the sliced kernel above).
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for sp in 256 128; do
   for s in -1 1 2 4 8 16 0; do
     echo "== secpar $sp FZ_MATVEC_SLICES=$s"

@@ -1,7 +1,7 @@
 """per-dispatch duration and host launch cost of the B=4096 transform from the GPU's NUMA node and from the other one:
-runs tools/dispatch_dist.py as child processes under the two CPU sets (this process never touches the GPU)"""
+runs tools/probes/dispatch_dist.py as child processes under the two CPU sets (this process never touches the GPU)"""
 import os, subprocess, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, "fusion-cryptography_amd"))
 from fusion_hip import numa
 

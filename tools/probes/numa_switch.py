@@ -1,6 +1,6 @@
 """does moving the LAUNCHING thread between NUMA nodes after the GPU is initialised change the per-dispatch duration?"""
 import os, sys, time, ctypes
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(R, "fusion-cryptography_amd")); sys.path.insert(0, R)
 import numpy as np
 import fusion_hip

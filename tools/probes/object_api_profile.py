@@ -8,7 +8,7 @@ import pstats
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "fusion-cryptography_amd"))
 
 import fusion.fusion as F  # noqa: E402

@@ -1,4 +1,4 @@
-"""per-kernel averages of a rocprofv3 --pmc counter_collection.csv: python tools/pmc_stalls.py <csv> [...]"""
+"""per-kernel averages of a rocprofv3 --pmc counter_collection.csv: python tools/probes/pmc_stalls.py <csv> [...]"""
 import collections, csv, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sys.argv[1:]:

@@ -1,8 +1,8 @@
 """Minimal launcher for profiling: runs the forward and inverse NTT kernels a few times on a large
 device-resident batch.  usage: prof_ntt.py [log2_batch] [reps] [secpar]"""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fusion-cryptography_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "fusion-cryptography_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import fusion_hip
 from fusion_hip.numa import pin_to_gpu_node

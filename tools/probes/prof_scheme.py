@@ -3,7 +3,7 @@ sets carved out of a 2.25 GiB pool).  usage: prof_scheme.py [reps]     (secpar 2
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (os.path.join(ROOT, "fusion-cryptography_amd"), ROOT):
     sys.path.insert(0, p)
 import fusion_hip

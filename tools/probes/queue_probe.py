@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """ONE Python thread submitting BASELINE-sized calls (1024 keys + 1024 signatures each) to the asynchronous batch queue of the
 C ABI (fz_queue_*, fusion_hip.queue.BatchQueue), against the same calls through BatchScheme one after the other, and against
-what W Python threads with private contexts reach (tools/concurrent_batches.py; profiles/r03_concurrent_batches.txt: 0.93 M
+what W Python threads with private contexts reach (tools/probes/concurrent_batches.py; profiles/r03_concurrent_batches.txt: 0.93 M
 pairs/s alone, 3.8-4.3 M/s with 8-16 threads and GPU_MAX_HW_QUEUES=16).  Reference call pattern: fusion.py:338-373, :534-557.
 usage: queue_probe.py [--secpar 128|256] [--n 1024] [--calls 96]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "fusion-cryptography_amd"))
 
 import numpy as np  # noqa: E402

@@ -9,7 +9,7 @@ import sys
 import threading
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "fusion-cryptography_amd"))
 import numpy as np  # noqa: E402
 import fusion.fusion as F  # noqa: E402

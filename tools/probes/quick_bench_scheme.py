@@ -1,8 +1,8 @@
 """Scratch timing of the fused scheme cores on device-resident synthetic data (secpar 256):
 algorithmic bytes per unit from SURVEY.md 8d / DESIGN.md 5, HIP events on the context's stream."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fusion-cryptography_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "fusion-cryptography_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import fusion_hip
 from oracle import oracle as O

@@ -2,8 +2,8 @@
 launches issued back to back on one stream, HIP events on that stream.
 usage: small_batch_probe.py [rows ...]   (library chosen by FUSION_HIP_LIB, schedule by FZ_NTT_KERNEL)"""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "fusion-cryptography_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "fusion-cryptography_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import fusion_hip
 from oracle import oracle as O
 

@@ -6,7 +6,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 print("streams  GPU_MAX_HW_QUEUES   G NTT/s   us/step   chip frac   us per launch in flight   one-stream frac", flush=True)
 DEFAULT = "default"          # bench.py's own setting: max(8, 2 x streams)
 for s, q in ((1, None), (2, None), (3, None), (4, None), (4, "4"), (4, "16"), (6, None), (8, None), (8, "8")):

@@ -6,7 +6,7 @@ Every scenario runs ONCE in a process of its own under an LD_PRELOADed SIGABRT /
 backtrace (tools/microbench/abort_bt.c, built here with gcc), and reports: exit code, which librccl / libamdhip64 /
 librocm_smi / libroctx files the process had mapped when it finished its work, what fz_rccl_library() says, and the tail of
 stderr.  Scenarios differ in the ORDER in which fusion_hip, torch and RCCL enter the process and in how communicators are
-released -- the variables the exit-time abort can depend on.  `FZ_RCCL_LEGACY_BIND=1` scenarios re-create round 4's binding
+released -- the variables the exit-time abort can depend on.  The LEGACY scenarios re-create round 4's binding
 (dlopen by soname with RTLD_GLOBAL) through ctypes before the library binds, to show the failing state next to the fixed one.
 
     python tools/rccl_exit_matrix.py [--out profiles/r05_rccl_exit_matrix.txt]

@@ -152,8 +152,13 @@ __device__ __forceinline__ void fwd16_run(const int32_t *in, int32_t *out, size_
     }
 
     for (size_t task = first; task < tasks; task += stride) {
+        // the next chunk's loads, if there is one (wave-uniform: `task` is scalar).  Rounds 1-4 issued them unconditionally and
+        // re-loaded the CURRENT chunk on a wave's last iteration: nothing at 64 iterations per wave (2^20 rows: +1.3 % read
+        // traffic), a quarter more read requests at the four iterations of a multi-job launch -- the PMC pass over round 5's
+        // headline read 78.2 MB per launch where 64 MiB are due (streaming loads: the re-read misses).
         const bool more = task + stride < tasks;
-        const Chunk raw = chunk_load(in, more ? task + stride : task, total, lane);   // unconditional: no divergent state
+        Chunk raw = {};
+        if (more) raw = chunk_load(in, task + stride, total, lane);
         wave_sync();
         double a[16];
         {
@@ -228,7 +233,7 @@ __device__ __forceinline__ void fwd16_run(const int32_t *in, int32_t *out, size_
         const int4 o2 = *reinterpret_cast<const int4 *>(stage + pad4(512 + 4 * lane));
         const int4 o3 = *reinterpret_cast<const int4 *>(stage + pad4(768 + 4 * lane));
         wave_sync();
-        chunk_to_lds(stage, lane, raw);          // waits for the prefetched loads (no store is younger)
+        if (more) chunk_to_lds(stage, lane, raw);   // waits for the prefetched loads (no store is younger)
         {
             const size_t base = task * kChunk + 4 * lane;
             if (base < total) nt_store4(out + base, o0);
@@ -277,7 +282,8 @@ __device__ __forceinline__ void inv16_run(const int32_t *in, int32_t *out, size_
 
     for (size_t task = first; task < tasks; task += stride) {       // pipeline: see fwd16_run
         const bool more = task + stride < tasks;
-        const Chunk raw = chunk_load(in, more ? task + stride : task, total, lane);
+        Chunk raw = {};
+        if (more) raw = chunk_load(in, task + stride, total, lane);
         wave_sync();
         double a[16];
 #pragma unroll
@@ -350,7 +356,7 @@ __device__ __forceinline__ void inv16_run(const int32_t *in, int32_t *out, size_
         const int4 o2 = *reinterpret_cast<const int4 *>(stage + pad4(512 + 4 * lane));
         const int4 o3 = *reinterpret_cast<const int4 *>(stage + pad4(768 + 4 * lane));
         wave_sync();
-        chunk_to_lds(stage, lane, raw);
+        if (more) chunk_to_lds(stage, lane, raw);
         {
             const size_t base = task * kChunk + 4 * lane;
             if (base < total) nt_store4(out + base, o0);

@@ -18,6 +18,13 @@
 //
 // One context still serves one host thread: a worker's context is touched by that worker alone (buffers of released
 // batches are handed back to the worker to free).
+//
+// Round 5: aggregate() + verify() and verify() calls are queued the same way (fusion.py:655-677, :680-728; the reference is
+// called once per aggregate).  An aggregate of a few dozen signers is a launch at the dispatch floor (8 signers 3.5 us,
+// 64 signers ~5 us, a single verification 4.6 us) behind milliseconds of host hashing; the worker takes every pending call
+// of the kind as ONE batch: the per-signer challenge pipeline of all signers in one launch sequence, hash_ag's serial sponge
+// of every aggregate on its own host thread, then ONE ragged launch for all partial sums (fz_aggregate_target_partial_ragged)
+// and ONE for all verifications -- aggregate_many / verify_many of BatchScheme, below Python and without blocking the caller.
 #include "fz_internal.h"
 #include "../../include/fusion_hip.h"
 
@@ -45,6 +52,8 @@ struct Batch {                         // device results of one coalesced batch,
     std::vector<hipEvent_t> after;
 };
 
+enum { KIND_KEYGEN_SIGN = 0, KIND_AGGREGATE_VERIFY = 1, KIND_VERIFY = 2 };
+
 struct Job {
     uint64_t ticket;
     size_t n;
@@ -53,6 +62,13 @@ struct Job {
     std::string msgs;
     std::vector<size_t> off;           // n + 1 offsets into msgs
     int32_t *h_vk_out;                 // [n][2][degree] or nullptr
+    // aggregate / verify calls
+    int kind = KIND_KEYGEN_SIGN;
+    std::vector<int32_t> vk;           // [n][2][degree]: public keys, copied at submit (2 KiB per signer)
+    const int32_t *rows = nullptr;     // KIND_AGGREGATE_VERIFY: the signatures [n][rank][degree]; KIND_VERIFY: the aggregate [rank][degree]
+                                       // (caller-owned, valid until the call has finished; host unless FZ_QUEUE_ROWS_ON_DEVICE)
+    int32_t *h_agg_out = nullptr;      // [rank][degree] or nullptr
+    int *h_verdict_out = nullptr;      // FZ_VERDICT_* or nullptr
 };
 
 struct Done {
@@ -72,6 +88,11 @@ struct Worker {
     int32_t *d_coef = nullptr, *d_c = nullptr, *d_sk = nullptr, *d_vk = nullptr, *d_sig = nullptr;
     size_t cap_coef = 0, cap_c = 0, cap_sk = 0, cap_vk = 0, cap_sig = 0;      // in rows
     std::vector<Batch *> garbage;      // released batches, freed by the worker itself (guarded by the queue's mutex)
+    // aggregate / verify batches: everything is scratch (results go to the callers' host buffers)
+    int32_t *a_sig = nullptr, *a_vk = nullptr, *a_L = nullptr, *a_R = nullptr, *a_c = nullptr, *a_al = nullptr, *a_agg = nullptr,
+            *a_tgt = nullptr, *a_verd = nullptr;
+    int32_t *a_psum = nullptr, *a_tsum = nullptr;      // int64 partial sums (kept as int32_t* for grow(): row_bytes says the size)
+    size_t c_sig = 0, c_vk = 0, c_L = 0, c_R = 0, c_c = 0, c_al = 0, c_agg = 0, c_tgt = 0, c_verd = 0, c_psum = 0, c_tsum = 0;
 };
 
 }  // namespace
@@ -96,6 +117,11 @@ struct fz_queue {
     std::string init_err;
     std::vector<Worker> workers;
     uint64_t st_jobs = 0, st_batches = 0, st_rows = 0;
+    // aggregate / verify calls (fz_queue_enable_aggregate)
+    bool agg_enabled = false;
+    int64_t beta_vf = 0, omega_vf = 0;
+    size_t capacity = 0;
+    int host_threads = 1;
 };
 
 namespace {
@@ -206,6 +232,128 @@ int run_batch(fz_queue *Q, Worker &w, std::vector<Job> &jobs, Batch **out_batch,
     return FZ_OK;
 }
 
+// one coalesced batch of aggregate+verify (kind 1) or verify (kind 2) calls: G aggregates, their signers back to back.
+// The flow of BatchScheme._hash_ag_many + aggregate_target_partial_ragged + verify_partials (fusion_hip/scheme.py), in C.
+int run_agg_batch(fz_queue *Q, Worker &w, std::vector<Job> &jobs, int kind, std::vector<int> &verdicts) {
+    const size_t d = (size_t)Q->degree, l = (size_t)Q->l, poly = d * 4, G = jobs.size();
+    std::vector<size_t> offs(G + 1, 0);
+    size_t msg_bytes = 0;
+    for (size_t g = 0; g < G; ++g) { offs[g + 1] = offs[g] + jobs[g].n; msg_bytes += jobs[g].msgs.size(); }
+    const size_t N = offs[G];
+    verdicts.assign(G, FZ_VERDICT_OK);
+    // host staging: keys as one [N][2][d] array and as left / right rows, messages back to back
+    std::vector<int32_t> vk(N * 2 * d), L(N * d), R(N * d), c_hat(N * d), alpha(N * d);
+    std::vector<uint8_t> pre(N * 32);
+    std::string msgs;
+    msgs.reserve(msg_bytes);
+    std::vector<size_t> off;
+    off.reserve(N + 1);
+    off.push_back(0);
+    for (size_t g = 0; g < G; ++g) {
+        memcpy(vk.data() + offs[g] * 2 * d, jobs[g].vk.data(), jobs[g].n * 2 * poly);
+        const size_t base = msgs.size();
+        msgs += jobs[g].msgs;
+        for (size_t i = 1; i <= jobs[g].n; ++i) off.push_back(base + jobs[g].off[i]);
+    }
+    for (size_t i = 0; i < N; ++i) {
+        memcpy(L.data() + i * d, vk.data() + (2 * i) * d, poly);
+        memcpy(R.data() + i * d, vk.data() + (2 * i + 1) * d, poly);
+    }
+    int rc;
+    if ((rc = grow(w.ctx, &w.a_vk, &w.c_vk, N, 2 * poly)) != FZ_OK) return rc;
+    if ((rc = grow(w.ctx, &w.a_L, &w.c_L, N, poly)) != FZ_OK) return rc;
+    if ((rc = grow(w.ctx, &w.a_R, &w.c_R, N, poly)) != FZ_OK) return rc;
+    if ((rc = grow(w.ctx, &w.a_c, &w.c_c, N, poly)) != FZ_OK) return rc;
+    if ((rc = grow(w.ctx, &w.a_al, &w.c_al, N, poly)) != FZ_OK) return rc;
+    if ((rc = grow(w.ctx, &w.a_agg, &w.c_agg, G, l * poly)) != FZ_OK) return rc;
+    if ((rc = grow(w.ctx, &w.a_tgt, &w.c_tgt, G, poly)) != FZ_OK) return rc;
+    if ((rc = grow(w.ctx, &w.a_verd, &w.c_verd, G, sizeof(int))) != FZ_OK) return rc;
+    if ((rc = grow(w.ctx, &w.a_tsum, &w.c_tsum, G, d * 8)) != FZ_OK) return rc;
+    if (kind == KIND_AGGREGATE_VERIFY) {
+        if ((rc = grow(w.ctx, &w.a_sig, &w.c_sig, N, l * poly)) != FZ_OK) return rc;
+        if ((rc = grow(w.ctx, &w.a_psum, &w.c_psum, G, l * d * 8)) != FZ_OK) return rc;
+    }
+    hipStream_t st = (hipStream_t)w.stream;
+    // the signatures start their way to the device first: the largest transfer, and nothing below needs it before the sums
+    if (kind == KIND_AGGREGATE_VERIFY)
+        for (size_t g = 0; g < G; ++g) {
+            const hipMemcpyKind dir = (jobs[g].flags & FZ_QUEUE_ROWS_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+            if ((rc = fz_check_hip(hipMemcpyAsync(w.a_sig + offs[g] * l * d, jobs[g].rows, jobs[g].n * l * poly, dir, st), "queue: signatures")) != FZ_OK) return rc;
+        }
+    else
+        for (size_t g = 0; g < G; ++g) {
+            const hipMemcpyKind dir = (jobs[g].flags & FZ_QUEUE_ROWS_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+            if ((rc = fz_check_hip(hipMemcpyAsync(w.a_agg + g * l * d, jobs[g].rows, l * poly, dir, st), "queue: aggregates")) != FZ_OK) return rc;
+        }
+    // hash_ch of every signer (fusion.py:511-531) on the device; the pre-hashes and c_hat come back for hash_ag's text
+    if ((rc = fz_memcpy_h2d(w.ctx, w.a_vk, vk.data(), N * 2 * poly)) != FZ_OK) return rc;
+    if ((rc = fz_challenge_hat_msgs_dev(w.ctx, &Q->P, w.a_vk, msgs.data(), off.data(), N, w.a_c, pre.data())) != FZ_OK) return rc;
+    if ((rc = fz_memcpy_d2h(w.ctx, c_hat.data(), w.a_c, N * poly)) != FZ_OK) return rc;
+    // hash_ag (fusion.py:632-652) per aggregate: sort by str(vk) (:661-663, :693), ONE serial SHAKE-256, decode; the rows go back
+    // to the callers' order (the sums do not care).  Independent aggregates on independent host threads.
+    {
+        std::atomic<size_t> next(0);
+        std::atomic<int> first_rc(FZ_OK);
+        auto work = [&]() {
+            for (;;) {
+                const size_t g = next.fetch_add(1);
+                if (g >= G) return;
+                const size_t n = jobs[g].n, o = offs[g];
+                std::vector<size_t> order(n);
+                int r = fz_sort_by_vk_string(&Q->P, L.data() + o * d, R.data() + o * d, n, order.data(), 1);
+                if (r == FZ_OK) {
+                    std::vector<int32_t> sL(n * d), sR(n * d), sC(n * d), sA(n * d);
+                    std::vector<uint8_t> sP(n * 32);
+                    for (size_t i = 0; i < n; ++i) {
+                        const size_t k = o + order[i];
+                        memcpy(sL.data() + i * d, L.data() + k * d, poly);
+                        memcpy(sR.data() + i * d, R.data() + k * d, poly);
+                        memcpy(sC.data() + i * d, c_hat.data() + k * d, poly);
+                        memcpy(sP.data() + i * 32, pre.data() + k * 32, 32);
+                    }
+                    r = fz_aggregation_coefficients(&Q->P, sL.data(), sR.data(), sP.data(), sC.data(), n, sA.data(), 1);
+                    if (r == FZ_OK)
+                        for (size_t i = 0; i < n; ++i) memcpy(alpha.data() + (o + order[i]) * d, sA.data() + i * d, poly);
+                }
+                if (r != FZ_OK) { int e = FZ_OK; first_rc.compare_exchange_strong(e, r); }
+            }
+        };
+        const size_t T = std::min<size_t>(G, (size_t)std::max(1, Q->host_threads));
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < T; ++t) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+        if (first_rc.load() != FZ_OK) return fz_set_error(first_rc.load(), "queue: hash_ag failed for an aggregate of the batch");
+    }
+    if ((rc = fz_memcpy_h2d(w.ctx, w.a_al, alpha.data(), N * poly)) != FZ_OK) return rc;
+    if ((rc = fz_ntt_forward(w.ctx, w.a_al, w.a_al, N)) != FZ_OK) return rc;
+    if ((rc = fz_memcpy_h2d(w.ctx, w.a_L, L.data(), N * poly)) != FZ_OK) return rc;
+    if ((rc = fz_memcpy_h2d(w.ctx, w.a_R, R.data(), N * poly)) != FZ_OK) return rc;
+    int64_t *tsum = (int64_t *)w.a_tsum, *psum = (int64_t *)w.a_psum;
+    if (kind == KIND_AGGREGATE_VERIFY) {
+        // ONE launch: exact int64 partial sums of every aggregate (fusion.py:670-676) and of every verification target (:706-714)
+        rc = fz_aggregate_target_partial_ragged(w.ctx, w.a_sig, w.a_al, w.a_L, w.a_R, w.a_c, offs.data(), G, (int)l, psum, l * d, tsum, d);
+        // ONE launch: every verdict straight from the sums (fusion.py:690-727)
+        if (rc == FZ_OK) rc = fz_verify_partials_batch_async(w.ctx, w.d_A, psum, l * d, tsum, d, G, (int)l, Q->beta_vf, Q->omega_vf, (int *)w.a_verd);
+        if (rc == FZ_OK) rc = fz_reduce_i64(w.ctx, psum, w.a_agg, G * l * d);
+        for (size_t g = 0; g < G && rc == FZ_OK; ++g)
+            if (jobs[g].h_agg_out)
+                rc = fz_check_hip(hipMemcpyAsync(jobs[g].h_agg_out, w.a_agg + g * l * d, l * poly, hipMemcpyDeviceToHost, st), "queue: aggregate to the host");
+    } else {
+        rc = fz_aggregate_target_partial_ragged(w.ctx, nullptr, w.a_al, w.a_L, w.a_R, w.a_c, offs.data(), G, (int)l, nullptr, 0, tsum, d);
+        if (rc == FZ_OK) rc = fz_reduce_i64(w.ctx, tsum, w.a_tgt, G * d);
+        if (rc == FZ_OK) rc = fz_verify_with_target_batch_async(w.ctx, w.d_A, w.a_agg, w.a_tgt, G, (int)l, Q->beta_vf, Q->omega_vf, (int *)w.a_verd);
+    }
+    if (rc == FZ_OK) rc = fz_memcpy_d2h(w.ctx, verdicts.data(), w.a_verd, G * sizeof(int));       // (synchronises the stream)
+    else (void)fz_ctx_synchronize(w.ctx);
+    if (rc != FZ_OK) return rc;
+    for (size_t g = 0; g < G; ++g) {
+        if (jobs[g].n > Q->capacity) verdicts[g] = FZ_VERDICT_TOO_MANY_KEYS;          // fusion.py:686-687: checked before anything else
+        if (jobs[g].h_verdict_out) *jobs[g].h_verdict_out = verdicts[g];
+    }
+    return FZ_OK;
+}
+
 void worker_main(fz_queue *Q, int index) {
     Worker &w = Q->workers[index];
     (void)hipSetDevice(Q->device);                  // a new thread starts on device 0; every fz_* call below selects the context's device again
@@ -227,17 +375,20 @@ void worker_main(fz_queue *Q, int index) {
         // everything that is pending, up to max_rows keys: one batch
         std::vector<Job> jobs;
         size_t rows = 0;
-        while (!Q->pending.empty() && (jobs.empty() || rows + Q->pending.front().n <= Q->max_rows)) {
+        const int kind = Q->pending.front().kind;       // calls are taken in order: a batch is a run of calls of ONE kind
+        while (!Q->pending.empty() && Q->pending.front().kind == kind && (jobs.empty() || rows + Q->pending.front().n <= Q->max_rows)) {
             rows += Q->pending.front().n;
             jobs.push_back(std::move(Q->pending.front()));
             Q->pending.pop_front();
         }
+        if (!Q->pending.empty()) Q->cv_work.notify_one();          // what is left (another kind, or over max_rows) is another worker's
         lk.unlock();
         Batch *b = nullptr;
         std::vector<size_t> row0;
+        std::vector<int> verdicts;
         int rc;
         try {
-            rc = run_batch(Q, w, jobs, &b, row0);
+            rc = kind == KIND_KEYGEN_SIGN ? run_batch(Q, w, jobs, &b, row0) : run_agg_batch(Q, w, jobs, kind, verdicts);
         } catch (const std::bad_alloc &) {          // the coalesced host copies: an error of these calls, not std::terminate
             (void)fz_ctx_synchronize(w.ctx);
             b = nullptr;
@@ -292,7 +443,8 @@ void worker_main(fz_queue *Q, int index) {
         Q->cv_done.notify_all();
     }
     lk.unlock();
-    for (int32_t *p : {w.d_coef, w.d_c, w.d_sk, w.d_vk, w.d_sig, w.d_A})
+    for (int32_t *p : {w.d_coef, w.d_c, w.d_sk, w.d_vk, w.d_sig, w.d_A, w.a_sig, w.a_vk, w.a_L, w.a_R, w.a_c, w.a_al, w.a_agg, w.a_tgt,
+                       w.a_verd, w.a_psum, w.a_tsum})
         if (p) (void)fz_free(w.ctx, p);
     if (w.ctx) {
         (void)fz_ctx_set_stream(w.ctx, nullptr);
@@ -416,6 +568,69 @@ int fz_queue_submit_keygen_sign(fz_queue *Q, const uint64_t *h_seeds, size_t n, 
     }
     Q->cv_work.notify_one();
     return FZ_OK;
+}
+
+int fz_queue_enable_aggregate(fz_queue *Q, int64_t beta_vf, int64_t omega_vf, size_t capacity, int host_threads) {
+    if (!Q) return fz_set_error(FZ_E_BADARG, "queue is NULL");
+    if (beta_vf < 0 || omega_vf < 0 || capacity < 1 || host_threads < 1 || host_threads > 256)
+        return fz_set_error(FZ_E_BADARG, "bounds >= 0, capacity >= 1, 1 <= host_threads <= 256");
+    std::lock_guard<std::mutex> lk(Q->mu);
+    Q->beta_vf = beta_vf;
+    Q->omega_vf = omega_vf;
+    Q->capacity = capacity;
+    Q->host_threads = host_threads;
+    Q->agg_enabled = true;
+    return FZ_OK;
+}
+
+static int submit_agg(fz_queue *Q, int kind, const int32_t *h_vk, const char *h_msgs, const size_t *h_msg_off, size_t n, const int32_t *rows,
+                      int32_t *h_agg_out, int *h_verdict_out, int flags, uint64_t *out_ticket) {
+    if (!Q || !out_ticket || !h_vk || !h_msg_off || !rows) return fz_set_error(FZ_E_BADARG, "NULL argument");
+    if (!Q->agg_enabled) return fz_set_error(FZ_E_BADARG, "fz_queue_enable_aggregate has not been called");
+    if (n == 0 || n > Q->max_rows) return fz_set_error(FZ_E_BADARG, "between 1 and max_rows (%zu) signers per call", Q->max_rows);
+    if (n >= ((size_t)1 << 21)) return fz_set_error(FZ_E_UNSUPPORTED, "too many signers for exact accumulation (< 2^21)");
+    if (h_msg_off[0] != 0) return fz_set_error(FZ_E_BADARG, "h_msg_off[0] must be 0");
+    for (size_t i = 0; i < n; ++i)
+        if (h_msg_off[i + 1] < h_msg_off[i]) return fz_set_error(FZ_E_BADARG, "message offsets must not decrease");
+    if (h_msg_off[n] && !h_msgs) return fz_set_error(FZ_E_BADARG, "h_msgs is NULL");
+    if (flags & ~FZ_QUEUE_ROWS_ON_DEVICE) return fz_set_error(FZ_E_BADARG, "only FZ_QUEUE_ROWS_ON_DEVICE applies to aggregate / verify calls");
+    try {
+        Job j;
+        j.kind = kind;
+        j.n = n;
+        j.flags = flags;
+        j.h_vk_out = nullptr;
+        j.vk.assign(h_vk, h_vk + n * 2 * (size_t)Q->degree);
+        j.msgs.assign(h_msgs ? h_msgs : "", h_msg_off[n]);
+        j.off.assign(h_msg_off, h_msg_off + n + 1);
+        j.rows = rows;
+        j.h_agg_out = h_agg_out;
+        j.h_verdict_out = h_verdict_out;
+        std::lock_guard<std::mutex> lk(Q->mu);
+        if (Q->stopping) return fz_set_error(FZ_E_BADARG, "the queue is shutting down");
+        Q->live.reserve(Q->live.size() + 1);
+        Q->pending.push_back(std::move(j));
+        Job &q = Q->pending.back();
+        q.ticket = Q->next_ticket++;
+        *out_ticket = q.ticket;
+        Q->live.insert(q.ticket);
+        Q->inflight += 1;
+    } catch (const std::bad_alloc &) {
+        return fz_set_error(FZ_E_HIP, "out of host memory while copying the call's inputs");
+    }
+    Q->cv_work.notify_one();
+    return FZ_OK;
+}
+
+int fz_queue_submit_aggregate_verify(fz_queue *Q, const int32_t *h_vk, const char *h_msgs, const size_t *h_msg_off, size_t n,
+                                     const int32_t *sig, int32_t *h_agg_out, int *h_verdict_out, int flags, uint64_t *out_ticket) {
+    return submit_agg(Q, KIND_AGGREGATE_VERIFY, h_vk, h_msgs, h_msg_off, n, sig, h_agg_out, h_verdict_out, flags, out_ticket);
+}
+
+int fz_queue_submit_verify(fz_queue *Q, const int32_t *h_vk, const char *h_msgs, const size_t *h_msg_off, size_t n,
+                           const int32_t *aggregate, int *h_verdict_out, int flags, uint64_t *out_ticket) {
+    if (!h_verdict_out) return fz_set_error(FZ_E_BADARG, "h_verdict_out is NULL");
+    return submit_agg(Q, KIND_VERIFY, h_vk, h_msgs, h_msg_off, n, aggregate, nullptr, h_verdict_out, flags, out_ticket);
 }
 
 int fz_queue_wait(fz_queue *Q, uint64_t ticket, fz_queue_result *out) {

@@ -182,12 +182,17 @@ class QueueResult(ctypes.Structure):
     _fields_ = [("status", c_int), ("n", c_size_t), ("d_sk_hat", c_void_p), ("d_vk", c_void_p), ("d_sig", c_void_p)]
 
 
-FZ_QUEUE_KEEP_SK, FZ_QUEUE_DISCARD = 1, 2
+FZ_QUEUE_KEEP_SK, FZ_QUEUE_DISCARD, FZ_QUEUE_ROWS_ON_DEVICE = 1, 2, 4
 SIGNATURES.update({
     "fz_queue_create": (c_int, [c_int, _spp, c_int, c_int64, c_int64, c_void_p, c_int, c_size_t, POINTER(c_void_p)]),
     "fz_queue_destroy": (c_int, [c_void_p]),
     "fz_queue_submit_keygen_sign": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int,
                                             POINTER(ctypes.c_uint64)]),
+    "fz_queue_enable_aggregate": (c_int, [c_void_p, c_int64, c_int64, c_size_t, c_int]),
+    "fz_queue_submit_aggregate_verify": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, POINTER(c_int), c_int,
+                                                 POINTER(ctypes.c_uint64)]),
+    "fz_queue_submit_verify": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, POINTER(c_int), c_int,
+                                       POINTER(ctypes.c_uint64)]),
     "fz_queue_wait": (c_int, [c_void_p, ctypes.c_uint64, POINTER(QueueResult)]),
     "fz_queue_release": (c_int, [c_void_p, ctypes.c_uint64]),
     "fz_queue_release_after": (c_int, [c_void_p, ctypes.c_uint64, _ctx]),

@@ -13,6 +13,10 @@ back at once; worker threads below Python (each with a context and a stream of i
         res = bq.wait(t)                                    # res.vk (numpy, [n][2][d]), res.sig_ptr / res.sk_ptr (device)
         sig = res.signatures()                              # numpy copy [n][l][d]
         res.release()
+        ta = bq.submit_aggregate_verify(vk, messages, sig)  # aggregate() + verify() of one aggregate, queued the same way
+        agg, (ok, reason) = bq.wait_aggregate(ta)           # many such calls pending = one ragged launch for all of them
+        tv = bq.submit_verify(vk, messages, agg)
+        ok, reason = bq.wait_verdict(tv)
 """
 import ctypes
 from ctypes import byref, c_uint64, c_void_p
@@ -20,7 +24,7 @@ from ctypes import byref, c_uint64, c_void_p
 import numpy as np
 
 from . import hostpipe
-from ._lib import FZ_QUEUE_DISCARD, FZ_QUEUE_KEEP_SK, FusionHipError, QueueResult, check, load_library
+from ._lib import FZ_QUEUE_DISCARD, FZ_QUEUE_KEEP_SK, FZ_QUEUE_ROWS_ON_DEVICE, FusionHipError, QueueResult, check, load_library
 
 
 class PackedMessages:
@@ -100,9 +104,10 @@ class QueueCallResult:
 
 
 class BatchQueue:
-    def __init__(self, params, device=0, workers=3, max_rows=16384, max_call=None):
+    def __init__(self, params, device=0, workers=3, max_rows=16384, max_call=None, host_threads=8):
         """params: a fusion.fusion.Params.  workers: threads below Python, each with a context + stream of its own (3 stay
-        within the HIP runtime's default 4 hardware queues).  max_rows: keys per coalesced batch."""
+        within the HIP runtime's default 4 hardware queues).  max_rows: keys (or signers) per coalesced batch.  host_threads:
+        threads a batch of aggregate / verify calls may use for its aggregates' hash_ag sponges (one aggregate per thread)."""
         self._lib = load_library()
         self.params, self.device, self.workers, self.max_rows = params, device, int(workers), int(max_rows)
         self.d, self.l = params.degree, params.num_rows_sk
@@ -111,6 +116,10 @@ class BatchQueue:
         self._h = c_void_p()
         check(self._lib, self._lib.fz_queue_create(device, byref(self.P), self.l, int(params.beta_sk), int(params.omega_sk),
                                                    A.ctypes.data_as(c_void_p), self.workers, self.max_rows, byref(self._h)))
+        # aggregate / verify calls (fusion.py:655-677, :680-728): the parameter set's verification bounds and capacity
+        check(self._lib, self._lib.fz_queue_enable_aggregate(self._h, int(params.beta_vf), int(params.omega_vf), int(params.capacity),
+                                                             max(1, min(32, int(host_threads)))))
+        self._agg = {}                 # ticket -> (kept-alive inputs, agg output array, verdict cell)
         self._vk_free = {}             # rows -> [pinned buffers]
         self._vk_out = {}              # ticket -> pinned buffer
         self._results = set()          # results handed out and not released: close() detaches their views of pinned memory
@@ -206,6 +215,71 @@ class BatchQueue:
         res = QueueCallResult(self, ticket, raw, self._vk_out.pop(ticket, None))
         self._results.add(res)
         return res
+
+    # ---- aggregate() + verify(), and verify() alone, as queued calls -------------------------------------
+    def _agg_inputs(self, vk, messages):
+        v = np.ascontiguousarray(np.asarray(vk, dtype=np.int32).reshape(-1, 2, self.d))
+        pm = messages if isinstance(messages, PackedMessages) else PackedMessages(messages)
+        if pm.n != v.shape[0]:
+            raise ValueError("Number of keys and messages must be equal.")
+        return v, pm
+
+    @staticmethod
+    def _rows(a, shape):
+        """-> (pointer, flags, keep-alive object) of caller rows given as a numpy array, a DeviceArray / DeviceBuffer, or a raw
+        device pointer (int)"""
+        if isinstance(a, int):
+            return c_void_p(a), FZ_QUEUE_ROWS_ON_DEVICE, None
+        if hasattr(a, "ptr"):
+            return c_void_p(a.ptr), FZ_QUEUE_ROWS_ON_DEVICE, a
+        h = np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(shape))
+        return h.ctypes.data_as(c_void_p), 0, h
+
+    def submit_aggregate_verify(self, vk, messages, sig):
+        """aggregate(params, keys, messages, signatures) + verify(params, keys, messages, aggregate) of ONE aggregate,
+        asynchronously -> ticket.  vk [n][2][d]; sig [n][l][d] as numpy (read by the worker: do not modify it before
+        wait_aggregate), a DeviceArray, or a device pointer (e.g. QueueCallResult.sig_ptr of a call that has not been released)."""
+        v, pm = self._agg_inputs(vk, messages)
+        n = v.shape[0]
+        ptr, flags, keep = self._rows(sig, (n, self.l, self.d))
+        out = np.empty((self.l, self.d), dtype=np.int32)
+        verdict = ctypes.c_int(-1)
+        t = c_uint64()
+        check(self._lib, self._lib.fz_queue_submit_aggregate_verify(self._h, v.ctypes.data_as(c_void_p), pm.blob, pm.off.ctypes.data_as(c_void_p), n,
+                                                                    ptr, out.ctypes.data_as(c_void_p), byref(verdict), flags, byref(t)))
+        self._agg[t.value] = (keep, out, verdict)
+        return t.value
+
+    def submit_verify(self, vk, messages, aggregate):
+        """verify(params, keys, messages, aggregate_signature) asynchronously -> ticket; aggregate [l][d] (numpy / DeviceArray / pointer)"""
+        v, pm = self._agg_inputs(vk, messages)
+        ptr, flags, keep = self._rows(aggregate, (self.l, self.d))
+        verdict = ctypes.c_int(-1)
+        t = c_uint64()
+        check(self._lib, self._lib.fz_queue_submit_verify(self._h, v.ctypes.data_as(c_void_p), pm.blob, pm.off.ctypes.data_as(c_void_p), v.shape[0],
+                                                          ptr, byref(verdict), flags, byref(t)))
+        self._agg[t.value] = (keep, None, verdict)
+        return t.value
+
+    def _wait_agg(self, ticket):
+        from .context import VERDICT_REASONS
+        if ticket not in self._agg:
+            raise FusionHipError(-1, "not a pending aggregate / verify ticket of this queue")
+        try:
+            check(self._lib, self._lib.fz_queue_wait(self._h, ticket, None))
+        finally:
+            keep, out, verdict = self._agg.pop(ticket)
+            self._lib.fz_queue_release(self._h, ticket)
+        code = int(verdict.value)
+        return out, (code == 0, VERDICT_REASONS[code])
+
+    def wait_aggregate(self, ticket):
+        """-> (aggregate [l][d] int32, (ok, reason)) of a submit_aggregate_verify call (blocks until it has finished)"""
+        return self._wait_agg(ticket)
+
+    def wait_verdict(self, ticket):
+        """-> (ok, reason) of a submit_verify call"""
+        return self._wait_agg(ticket)[1]
 
     def drain(self):
         """block until everything submitted has finished; raises if a discarded call failed (collect_discarded() then hands

@@ -462,11 +462,30 @@ typedef struct fz_queue_result {
 } fz_queue_result;
 #define FZ_QUEUE_KEEP_SK 1
 #define FZ_QUEUE_DISCARD 2
+#define FZ_QUEUE_ROWS_ON_DEVICE 4   /* aggregate / verify calls: the signature (or aggregate) rows are a DEVICE pointer */
 FZ_API int fz_queue_create(int device, const fz_scheme_params *P, int rank, int64_t beta_sk, int64_t omega_sk,
                            const int32_t *h_A, int workers, size_t max_rows, fz_queue **out);
 FZ_API int fz_queue_destroy(fz_queue *queue);
 FZ_API int fz_queue_submit_keygen_sign(fz_queue *queue, const uint64_t *h_seeds, size_t n, const char *h_msgs,
                                        const size_t *h_msg_off, int32_t *h_vk_out, int flags, uint64_t *out_ticket);
+/* aggregate() + verify(), and verify() alone, as queued calls (round 5; fusion.py:655-677, :680-728 -- the reference is called
+ * once per aggregate, benchmarks/benchmarks.py:37-141 loops over them).  An aggregate of a few dozen signers is a launch at the
+ * dispatch floor behind milliseconds of host hashing; pending calls of one kind are run as ONE batch: hash_ch of all signers in
+ * one device pipeline, hash_ag's serial SHAKE-256 of every aggregate on its own host thread, ONE ragged launch for all partial
+ * sums (fz_aggregate_target_partial_ragged), ONE for all verdicts -- the values of separate calls, bit for bit.
+ *   fz_queue_enable_aggregate   once, before the first such call: the verification bounds and capacity of the parameter set
+ *                     (fusion.py:24-25, :63-68) and how many host threads a batch may use for its sponges.
+ *   fz_queue_submit_aggregate_verify   h_vk [n][2][degree] and the messages are copied; `sig` [n][rank][degree] (host, ideally
+ *                     pinned, or device with FZ_QUEUE_ROWS_ON_DEVICE) is read by the worker and must stay valid and unchanged
+ *                     until the call has finished, as must the outputs: h_agg_out [rank][degree] (optional) receives
+ *                     aggregate(...).signature_hat, *h_verdict_out (optional) the FZ_VERDICT_* code of verify(...) of it.
+ *   fz_queue_submit_verify   the same for verify(params, keys, messages, aggregate) of a given aggregate [rank][degree].
+ *   fz_queue_wait on such a ticket blocks until the outputs have been written (out->n = signers; no device rows). */
+FZ_API int fz_queue_enable_aggregate(fz_queue *queue, int64_t beta_vf, int64_t omega_vf, size_t capacity, int host_threads);
+FZ_API int fz_queue_submit_aggregate_verify(fz_queue *queue, const int32_t *h_vk, const char *h_msgs, const size_t *h_msg_off, size_t n,
+                                            const int32_t *sig, int32_t *h_agg_out, int *h_verdict_out, int flags, uint64_t *out_ticket);
+FZ_API int fz_queue_submit_verify(fz_queue *queue, const int32_t *h_vk, const char *h_msgs, const size_t *h_msg_off, size_t n,
+                                  const int32_t *aggregate, int *h_verdict_out, int flags, uint64_t *out_ticket);
 FZ_API int fz_queue_wait(fz_queue *queue, uint64_t ticket, fz_queue_result *out);
 FZ_API int fz_queue_release(fz_queue *queue, uint64_t ticket);
 FZ_API int fz_queue_release_after(fz_queue *queue, uint64_t ticket, fz_ctx *consumer);

@@ -161,3 +161,107 @@ def test_release_right_behind_an_asynchronous_consumer_and_results_that_outlive_
     held.release(after=ctx)
     d_al.free()
     bs.close()
+
+
+@pytest.mark.parametrize("secpar", [128, 256])
+def test_queued_aggregates_and_verifications_equal_the_reference(secpar):
+    """aggregate() + verify(), and verify() alone, as queued calls (fz_queue_submit_aggregate_verify /
+    fz_queue_submit_verify) -- many pending calls share ONE ragged launch for the partial sums and ONE for the verdicts.  On the
+    reference's own flows (tests/golden/scheme_many_*: distinct signers, nested sub-aggregates of different sizes): every queued
+    aggregate is the array the REFERENCE computed (fusion.py:655-677), every verdict the reference's (:680-728), tampered
+    aggregates and swapped messages included; signatures as host arrays, as a DeviceArray and as the queue's own device rows."""
+    import fusion.fusion as F
+    import fusion_hip
+    from fusion_hip.queue import BatchQueue
+    from fusion_hip.scheme import BatchScheme
+    S = np.load(os.path.join(G, f"scheme_many_{secpar}.npz"))
+    with open(os.path.join(G, "scheme_many.json")) as fh:
+        m = json.load(fh)[str(secpar)]
+    params = F.fusion_setup(secpar, m["setup_seed"])
+    bs = BatchScheme(params)
+    msgs = m["messages"]
+    with BatchQueue(params, workers=2, max_rows=4096) as bq:
+        r = bq.wait(bq.submit_keygen_sign(m["key_seeds"], msgs))           # the queue's own keys and signatures (device rows)
+        vk, sig = r.vk.copy(), r.signatures()
+        assert np.array_equal(vk, S["vk"])
+        d_sig = fusion_hip.DeviceArray.from_numpy(bs.ctx, sig)
+        l, d = params.num_rows_sk, params.degree
+        tickets = []
+        for k, (lo, hi) in enumerate(m["subsets"] * 3):                     # 12 calls pending at once, sizes differ
+            how = k % 3
+            rows = (sig[lo:hi] if how == 0 else d_sig.ptr + lo * l * d * 4 if how == 1 else r.sig_ptr + lo * l * d * 4)
+            tickets.append((lo, hi, bq.submit_aggregate_verify(vk[lo:hi], msgs[lo:hi], rows)))
+        aggs = {}
+        for lo, hi, t in tickets:
+            agg, verdict = bq.wait_aggregate(t)
+            info = m["agg"][f"{lo}_{hi}"]
+            assert np.array_equal(agg, S[f"agg_{lo}_{hi}"]), (lo, hi)
+            assert list(verdict) == info["verdict"]
+            aggs[(lo, hi)] = agg
+        # verify() alone: the reference's verdicts for the aggregate, a tampered one and swapped messages -- 12 calls pending
+        vt = []
+        for lo, hi in m["subsets"]:
+            info = m["agg"][f"{lo}_{hi}"]
+            agg = aggs[(lo, hi)]
+            bad = agg.copy()
+            bad[info["tampered_at"][0], info["tampered_at"][1]] += 1
+            sw = list(msgs[lo:hi])
+            sw[0], sw[-1] = sw[-1], sw[0]
+            vt.append((bq.submit_verify(vk[lo:hi], msgs[lo:hi], agg), info["verdict"]))
+            vt.append((bq.submit_verify(vk[lo:hi], msgs[lo:hi], bad), info["tampered_verdict"]))
+            vt.append((bq.submit_verify(vk[lo:hi], sw, agg), info["swapped_messages_verdict"]))
+        for t, want in vt:
+            assert list(bq.wait_verdict(t)) == want
+        calls, batches, _ = bq.stats()
+        assert batches < calls                                              # calls WERE coalesced
+        with pytest.raises(ValueError):
+            bq.submit_verify(vk[:3], msgs[:2], aggs[tuple(m["subsets"][0])])
+        r.release()
+        d_sig.free()
+    bs.close()
+
+
+def test_queued_aggregates_mixed_with_keygen_sign_and_the_capacity_verdict():
+    """calls of all three kinds interleaved from one thread (a batch is a run of calls of one kind: order is kept), 80 aggregates
+    of 1 .. 40 signers pending at once (more than the 64 groups one ragged launch holds) against BatchScheme.aggregate_many /
+    verify_many, and the reference's capacity check (fusion.py:686-687: "Too many keys.") through a queue whose capacity is 3"""
+    import types
+    import fusion.fusion as F
+    from fusion_hip.queue import BatchQueue
+    from fusion_hip.scheme import BatchScheme
+    params = F.fusion_setup(256, 4242)
+    bs = BatchScheme(params)
+    rng = np.random.default_rng(3)
+    sizes = [int(x) for x in rng.integers(1, 41, size=80)]
+    n = sum(sizes)
+    seeds = [31 * i + 5 for i in range(n)]
+    msgs = [f"msg {i}" for i in range(n)]
+    sk, vk = bs.keygen_batch(seeds)
+    sig = bs.sign_batch(sk, vk, msgs)
+    want = bs.aggregate_many(vk, msgs, sig, sizes)
+    assert bs.verify_many(vk, msgs, want, sizes) == [(True, "")] * len(sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    with BatchQueue(params, workers=2, max_rows=2048) as bq:
+        tickets, others = [], []
+        for g in range(len(sizes)):
+            a, b = int(off[g]), int(off[g + 1])
+            tickets.append(bq.submit_aggregate_verify(vk[a:b], msgs[a:b], sig[a:b]))
+            if g % 16 == 7:                                                  # another kind in between
+                others.append((bq.submit_keygen_sign(seeds[a:b], msgs[a:b]), a, b))
+        for g, t in enumerate(tickets):
+            agg, verdict = bq.wait_aggregate(t)
+            assert np.array_equal(agg, want[g]) and verdict == (True, ""), g
+        for t, a, b in others:
+            res = bq.wait(t)
+            assert np.array_equal(res.vk, vk[a:b]) and np.array_equal(res.signatures(), sig[a:b])
+            res.release()
+    small = types.SimpleNamespace(**{k: getattr(params, k) for k in dir(params) if not k.startswith("_")})
+    small.capacity = 3
+    with BatchQueue(small, workers=1) as bq:
+        a, b = int(off[5]), int(off[5]) + 4
+        agg4 = bs.aggregate(vk[a:b], msgs[a:b], sig[a:b])
+        agg, verdict = bq.wait_aggregate(bq.submit_aggregate_verify(vk[a:b], msgs[a:b], sig[a:b]))
+        assert np.array_equal(agg, agg4) and verdict == (False, "Too many keys.")
+        assert bq.wait_verdict(bq.submit_verify(vk[a:b], msgs[a:b], agg4)) == (False, "Too many keys.")
+        assert bq.wait_verdict(bq.submit_verify(vk[a:a + 3], msgs[a:a + 3], bs.aggregate(vk[a:a + 3], msgs[a:a + 3], sig[a:a + 3]))) == (True, "")
+    bs.close()

@@ -1025,6 +1025,21 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
             const bool take = ar == 0 || (best_tiles <= capacity && tiles <= capacity && tiles * 16 >= best_tiles * 17);
             if (take) { ar = cand; ncb_a = na; ncb = nb; nsl = ns; best_tiles = tiles; }
         }
+        // More tiles than CUs even at the widest block (many small aggregates in one launch: the batch queue's ragged launches):
+        // the launch runs in several rounds, and at AR = 4 (190 VGPRs: one 8-wave workgroup per CU) a CU's next workgroup cannot
+        // start before the previous one has drained its LDS reduction and stores.  AR = 2 (114 VGPRs: TWO workgroups per CU)
+        // overlaps one workgroup's tail with the other's loads: 64 aggregates of 64 signers + targets 80.4 -> 74.0 us (0.57 ->
+        // 0.62 of the HBM peak by bytes moved), 128 x 32: 95.8 -> 80.6, 256 x 16: 121 -> 99.5, 16 x 64: 23.9 -> 20.0; launches
+        // of one round lose with it (8 x 128: 20.3 -> 23.5 us) and keep the rule above (profiles/r05_queue_aggregates.txt).
+        {
+            const int na4 = sig ? (int)((cols_a + 64 * kAggR - 1) / (64 * kAggR)) : 0;
+            if ((size_t)(na4 + (vkL ? 1 : 0)) * groups > capacity) {
+                ar = 2;
+                ncb_a = sig ? (int)((cols_a + 64 * 2 - 1) / (64 * 2)) : 0;
+                ncb = ncb_a + (vkL ? 1 : 0);
+                nsl = 1;
+            }
+        }
         const size_t pairs = groups * nsl;
         // the kernel divides tile numbers by ncb and nsl with 32-bit reciprocals: exact while tiles * divisor < 2^32
         if (pairs * (size_t)ncb > 0x3fffffffull || pairs * (size_t)ncb * (size_t)(ncb > (int)nsl ? ncb : (int)nsl) >= 0x100000000ull)

@@ -13,11 +13,15 @@ from fusion_hip._lib import FZ_E_UNSUPPORTED
 INT32_MIN, INT32_MAX = -(2 ** 31), 2 ** 31 - 1
 
 
+MAX_MODULUS = 2 ** 32          # exclusive: centred residues are int32 for every odd q below it (round 5; 2^31 before)
+MAX_DEGREE = 4096              # transform lengths (fz_internal.h kFzMaxDegree)
+
+
 def check_modulus(q):
-    if not (isinstance(q, int) and 3 <= q < 2 ** 31 and q % 2 == 1):
+    if not (isinstance(q, int) and 3 <= q < MAX_MODULUS and q % 2 == 1):
         raise FusionHipError(FZ_E_UNSUPPORTED,
-                             f"modulus {q} is outside what the HIP kernels implement (odd, 3 <= q < 2^31); "
-                             "there is no CPU fallback")
+                             f"modulus {q} is outside what the HIP kernels implement (odd, 3 <= q < 2^32: the path's storage "
+                             "type is int32); there is no CPU fallback")
 
 
 def to_i32(rows, q):
@@ -50,6 +54,25 @@ def stack_polys(polys, q):
 def ntt_ctx(q, degree, root, inv_root):
     check_modulus(q)
     return get_context(q, degree, root % q, inv_root % q)
+
+
+def table_ctx(q, degree, fwd_table, inv_table):
+    """a context whose twiddle tables are the caller's lists (cooley_tukey_ntt / gentleman_sande_intt use whatever table they
+    are handed: ntt.py:274-290, :354-372)"""
+    check_modulus(q)
+    from fusion_hip.context import get_table_context
+    return get_table_context(q, degree, tuple(int(v) % q for v in fwd_table), tuple(int(v) % q for v in inv_table))
+
+
+def neg_values(ctx, arr, q):
+    """the reference's __neg__, -(x mod q) in [-(q-1), 0] (polynomials.py:155-163, :325-333): int32 rows from the device below
+    2^31; from 2^31 on the values no longer fit the device's type, so the device computes the CENTRED negation (fz_pw_sub from
+    zero) and the representative is shifted here -- c <= 0 stays, c > 0 becomes c - q: a change of representative of a value
+    the device computed, not arithmetic of the path -- and the result is a list of Python ints."""
+    if q < 2 ** 31:
+        return ctx.pw_neg(arr), None
+    c = ctx.pw_sub(np.zeros_like(arr), arr)
+    return None, [int(v) if v <= 0 else int(v) - q for v in c.tolist()]
 
 
 def ring_ctx(q, degree):

@@ -165,35 +165,40 @@ def _validate_transform_args(val, modulus, root_order, table, table_name):
         raise NotImplementedError(f"root_order={root_order}=degree={len(val)} is not implemented")
 
 
-_TABLE_ROOTS: Dict[Tuple[int, int, Tuple[int, ...]], int] = {}
+_TABLE_ROOTS: Dict[Tuple[int, int, Tuple[int, ...]], Optional[int]] = {}
 
 
 def _root_of_table(table, modulus, n):
-    """The kernels build their tables from the root.  A bit-reversed power table
-    [psi^brv(i)] stores psi itself at index n/2; recover it and check the whole table."""
+    """A bit-reversed power table [psi^brv(i)] stores psi itself at index n/2: recover it and check the whole table.
+    -> the root when the table IS the power table of one primitive 2n-th root (the library then serves it from the context
+    every polynomial of that ring shares), None for any other table -- which the reference uses as it stands
+    (ntt.py:274-290 `s = bit_rev_root_powers[m + i]`) and so do we, through a context built from the list itself."""
     key = (modulus, n, tuple(table))
-    root = _TABLE_ROOTS.get(key)
-    if root is None:
-        if len(table) != n:
-            raise ValueError(f"twiddle table has length {len(table)}, expected {n}")
-        root = table[n // 2] % modulus
-        if pow(root, n, modulus) != modulus - 1:
-            raise ValueError("twiddle table is not built from a primitive 2n-th root of unity; "
-                             "only such tables are supported by the HIP kernels")
-        bits = n.bit_length() - 1
-        acc, powers = 1, []
-        for _ in range(n):
-            powers.append(acc)
-            acc = (acc * root) % modulus
-        for i in range(n):
-            r = 0
-            for b in range(bits):
-                r |= ((i >> b) & 1) << (bits - 1 - b)
-            if table[i] % modulus != powers[r]:
-                raise ValueError("twiddle table is not the bit-reversed power table of a single root; "
-                                 "only such tables are supported by the HIP kernels")
-        _TABLE_ROOTS[key] = root
+    if key in _TABLE_ROOTS:
+        return _TABLE_ROOTS[key]
+    root = None
+    if len(table) == n:
+        cand = table[n // 2] % modulus
+        if pow(cand, n, modulus) == modulus - 1:
+            bits = n.bit_length() - 1
+            acc, powers = 1, []
+            for _ in range(n):
+                powers.append(acc)
+                acc = (acc * cand) % modulus
+            if all(table[i] % modulus == powers[int(format(i, f"0{bits}b")[::-1], 2)] for i in range(n)):
+                root = cand
+    _TABLE_ROOTS[key] = root
     return root
+
+
+def _transform_ctx(table, modulus, n, inverse):
+    if len(table) < n:
+        raise IndexError("list index out of range")            # what the reference's table lookup raises (ntt.py:277, :357)
+    root = _root_of_table(table[:n], modulus, n)
+    if root is not None:
+        inv = pow(root, modulus - 2, modulus)
+        return _backend.ntt_ctx(modulus, n, inv if inverse else root, root if inverse else inv)
+    return _backend.table_ctx(modulus, n, table[:n], table[:n])
 
 
 def cooley_tukey_ntt(val: List[int], modulus: int, root_order: int, bit_rev_root_powers: List[int]) -> List[int]:
@@ -201,8 +206,7 @@ def cooley_tukey_ntt(val: List[int], modulus: int, root_order: int, bit_rev_root
     outputs (ntt.py:216-291).  Mutates and returns ``val``."""
     _validate_transform_args(val, modulus, root_order, bit_rev_root_powers, "root_powers")
     n = len(val)
-    root = _root_of_table(bit_rev_root_powers, modulus, n)
-    ctx = _backend.ntt_ctx(modulus, n, root, pow(root, modulus - 2, modulus))
+    ctx = _transform_ctx(bit_rev_root_powers, modulus, n, False)
     out = ctx.ntt_forward(_backend.to_i32(val, modulus))
     val[:] = out.tolist()
     return val
@@ -213,8 +217,7 @@ def gentleman_sande_intt(val: List[int], modulus: int, root_order: int,
     """In-place inverse transform, bit-reversed in, natural out, scaled by n^-1 (ntt.py:294-377)."""
     _validate_transform_args(val, modulus, root_order, bit_rev_inv_root_powers, "inv_root_powers")
     n = len(val)
-    inv_root = _root_of_table(bit_rev_inv_root_powers, modulus, n)
-    ctx = _backend.ntt_ctx(modulus, n, pow(inv_root, modulus - 2, modulus), inv_root)
+    ctx = _transform_ctx(bit_rev_inv_root_powers, modulus, n, True)
     out = ctx.ntt_inverse(_backend.to_i32(val, modulus))
     val[:] = out.tolist()
     return val

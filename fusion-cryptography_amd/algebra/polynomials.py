@@ -119,6 +119,12 @@ class PolynomialRepresentation(object):
         z._list, z._arr = None, arr
         return z
 
+    def _like_list(self, values):
+        """same ring, data = a list of Python ints (values the device's int32 cannot hold: -(x mod q) for q >= 2^31)"""
+        z = self._like_arr(None)
+        z._list = values
+        return z
+
     # -- helpers shared by both representations ---------------------------------------------
     def _ring(self):
         return _backend.ring_ctx(self.modulus, max(1, self._len()))
@@ -192,7 +198,8 @@ class PolynomialCoefficientRepresentation(PolynomialRepresentation):
 
     def __neg__(self):
         # -(x mod q), in [-(q-1), 0]: deliberately NOT centred, as in the reference (:155-163)
-        return self._like_arr(self._ring().pw_neg(self._i32()))
+        arr, lst = _backend.neg_values(self._ring(), self._i32(), self.modulus)
+        return self._like_arr(arr) if lst is None else self._like_list(lst)
 
     def __sub__(self, other):
         return self + (-other)
@@ -291,7 +298,8 @@ class PolynomialNTTRepresentation(PolynomialRepresentation):
         return self + other
 
     def __neg__(self):
-        return self._like_arr(self._ring().pw_neg(self._i32()))
+        arr, lst = _backend.neg_values(self._ring(), self._i32(), self.modulus)
+        return self._like_arr(arr) if lst is None else self._like_list(lst)
 
     def __sub__(self, other):
         return self + (-other)

@@ -21,7 +21,7 @@
 #endif
 
 struct FzMod {
-    double q;      // modulus, odd, < 2^31
+    double q;      // modulus, odd, < 2^32 (centred residues are int32 whatever q is; the 4-op multiply only below 2^31)
     double qinv;   // 1.0 / q rounded to nearest
     // pseudo-Mersenne form q = K - delta, K = 2^k the smallest power of two >= q
     double K;      // 2^k
@@ -42,14 +42,15 @@ FZ_HD FzMod fz_make_mod(unsigned q) {
     m.kq = (double)K / (double)q;
     m.kappa = (double)(K - q) / (double)K;
     m.magic = 6755399441055744.0 * (double)K;      // 1.5 * 2^52 * K
-    m.fast = (K - q) < 32768ull ? 1 : 0;
+    m.fast = ((K - q) < 32768ull && q < 0x80000000u) ? 1 : 0;      // (fz_mulmod4's bounds are stated for K <= 2^31)
     m.r32 = (double)(4294967296ull % q);
     return m;
 }
 
 // r = a*b - c*q exactly, with c = rint(fl(fl(a*b) * qinv)).
 // Exact when a, b are integers with |a*b| < 2^83 (so that |low part| < 2^30) -- in this
-// library |a| < 2^40 and |b| < 2^31.  |r| <= q/2 + q*|a*b/q|*2^-51  (i.e. "almost centred").
+// library |a| < 2^40 and |b| < 2^32 (twiddles of a modulus below 2^32; operands are centred, < 2^31).
+// |r| <= q/2 + q*|a*b/q|*2^-51  (i.e. "almost centred").
 //   h = fl(a*b); l = a*b - h exactly (FMA);  h - c*q is an integer below 2^53 -> exact.
 FZ_HD double fz_mulmod(double a, double b, const FzMod m) {
     double h = a * b;
@@ -73,7 +74,8 @@ FZ_HD double fz_mulmod4(double a, double w, double w2, const FzMod m) {
     return __builtin_fma(cK, m.kappa, t);
 }
 
-// Canonical centred residue of an integer-valued x, |x| < 2^19 * q:
+// Canonical centred residue of an integer-valued x, |x| < 2^19 * q (q < 2^31; |x| < 2^18 * q for q < 2^32: the margin to a
+// half-integer is 1/(2q)):
 // the unique r == x (mod q) with |r| <= (q-1)/2, i.e. the reference's cent(x).
 // fl(x*qinv) is within 2^-33.. of x/q, and x/q is at least 1/(2q) > 2^-32 away from any
 // half-integer (q odd), so rint picks the true nearest integer.

@@ -203,25 +203,34 @@ static int upload_doubles(const double *h, size_t n, double **d_out) {
     return FZ_OK;
 }
 
-int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t inv_root, fz_ctx **out) {
+// h_fwd / h_inv != NULL: the context's twiddle tables are THESE (fz_ctx_create_tables) instead of the bit-reversed powers of a root
+static int ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t inv_root, const uint32_t *h_fwd, const uint32_t *h_inv,
+                      fz_ctx **out) {
     FZ_REQUIRE(out, "out is NULL");
     *out = nullptr;
-    FZ_REQUIRE(q >= 3 && (q & 1u) && q < 0x80000000u, "modulus %u must be odd, >= 3 and < 2^31", q);
+    // any odd modulus below 2^32: centred residues |x| <= (q - 1) / 2 < 2^31 are int32 whatever q is, and every bound of
+    // fz_arith.h is in terms of 2^31-sized operands and twiddles below 2^32 (round 5; rounds 1-4 refused q >= 2^31)
+    FZ_REQUIRE(q >= 3 && (q & 1u), "modulus %u must be odd and >= 3", q);
     // root == 0: "ring-only" context (pointwise ops, norm/weight, matvec on rows of `degree` values;
     // no transform tables).  The reference lets polynomial objects exist for parameter tuples that
     // admit no NTT (e.g. root_order 1), and their + - * norm weight still work.
-    const bool ring_only = (root == 0);
+    const bool tables = h_fwd != nullptr;
+    const bool ring_only = !tables && (root == 0);
     if (ring_only) {
         FZ_REQUIRE(degree >= 1 && degree <= (1 << 20), "degree %d out of range", degree);
     } else {
         FZ_REQUIRE(degree >= 2 && (degree & (degree - 1)) == 0, "degree %d must be a power of two >= 2", degree);
-        if (degree > 256) return fz_set_error(FZ_E_UNSUPPORTED, "degree %d > 256 not supported by the NTT kernels", degree);
-        FZ_REQUIRE(((uint64_t)q - 1) % (2u * (uint64_t)degree) == 0, "2*degree=%d does not divide q-1", 2 * degree);
-        FZ_REQUIRE(root > 0 && root < q && inv_root > 0 && inv_root < q, "root / inv_root must be in (0, q)");
-        // primitive 2*degree-th root (order a power of two): root^degree == -1
-        FZ_REQUIRE(powmod_u64(root, (uint64_t)degree, q) == (uint64_t)q - 1,
-                   "root %u is not a primitive %d-th root of unity mod %u", root, 2 * degree, q);
-        FZ_REQUIRE(((uint64_t)root * inv_root) % q == 1, "root * inv_root != 1 mod q");
+        if (degree > kFzMaxDegree) return fz_set_error(FZ_E_UNSUPPORTED, "degree %d > %d not supported by the NTT kernels", degree, kFzMaxDegree);
+        if (tables) {
+            FZ_REQUIRE(h_inv, "both tables are required");
+        } else {
+            FZ_REQUIRE(((uint64_t)q - 1) % (2u * (uint64_t)degree) == 0, "2*degree=%d does not divide q-1", 2 * degree);
+            FZ_REQUIRE(root > 0 && root < q && inv_root > 0 && inv_root < q, "root / inv_root must be in (0, q)");
+            // primitive 2*degree-th root (order a power of two): root^degree == -1
+            FZ_REQUIRE(powmod_u64(root, (uint64_t)degree, q) == (uint64_t)q - 1,
+                       "root %u is not a primitive %d-th root of unity mod %u", root, 2 * degree, q);
+            FZ_REQUIRE(((uint64_t)root * inv_root) % q == 1, "root * inv_root != 1 mod q");
+        }
     }
 
     int ndev = 0;
@@ -253,9 +262,10 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         tw = (double *)malloc(sizeof(double) * n);
         itw = (double *)malloc(sizeof(double) * n);
         for (int i = 0; i < n; ++i) {
-            // bit_reverse_copy([pow(root, i, q)])  (algebra/polynomials.py:396-397, :416-417)
-            c->h_tw[i] = (uint32_t)powmod_u64(root, bitrev((unsigned)i, k), q);
-            c->h_itw[i] = (uint32_t)powmod_u64(inv_root, bitrev((unsigned)i, k), q);
+            // bit_reverse_copy([pow(root, i, q)])  (algebra/polynomials.py:396-397, :416-417) -- or whatever table the caller
+            // hands to cooley_tukey_ntt / gentleman_sande_intt (ntt.py:274-290, :354-372 use it as it is)
+            c->h_tw[i] = tables ? h_fwd[i] % q : (uint32_t)powmod_u64(root, bitrev((unsigned)i, k), q);
+            c->h_itw[i] = tables ? h_inv[i] % q : (uint32_t)powmod_u64(inv_root, bitrev((unsigned)i, k), q);
             tw[i] = (double)c->h_tw[i];
             itw[i] = (double)c->h_itw[i];
         }
@@ -274,7 +284,7 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
         c->itwA.w1_n_inv2 = c->itwA.w1_n_inv * c->mod.kq;
 
         // per-lane tables of the contiguous pass ([NE][L]); see fz_ntt.hip / tools/ntt_layout_model.py
-        if (k >= 5) {
+        if (k >= 5 && k <= 8) {
             const int L = n / 16, SB = k - 4, NE = 16 - (16 >> SB);
             nB = (size_t)NE * L * 2;                       // (w, w * K / q) pairs
             twB = (double *)malloc(sizeof(double) * nB);
@@ -354,6 +364,18 @@ int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t
     fz_registry_add(c);
     *out = c;
     return FZ_OK;
+}
+
+int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t inv_root, fz_ctx **out) {
+    return ctx_create(device_id, q, degree, root, inv_root, nullptr, nullptr, out);
+}
+
+// cooley_tukey_ntt / gentleman_sande_intt take the twiddle table as an ARGUMENT and use whatever they are handed
+// (algebra/ntt.py:274-290, :354-372: `s = bit_rev_root_powers[m + i]`): a context whose tables are the caller's own lists --
+// not necessarily the powers of one root -- runs the same butterfly network on them.  Entries are reduced mod q.
+int fz_ctx_create_tables(int device_id, uint32_t q, int degree, const uint32_t *h_fwd, const uint32_t *h_inv, fz_ctx **out) {
+    FZ_REQUIRE(h_fwd && h_inv, "both tables are required (pass the same one twice when only one direction is used)");
+    return ctx_create(device_id, q, degree, 0, 0, h_fwd, h_inv, out);
 }
 
 int fz_ctx_destroy(fz_ctx *ctx) {
@@ -851,6 +873,10 @@ int fz_pw_sub(fz_ctx *ctx, const int32_t *a, const int32_t *b, int32_t *out, siz
 }
 int fz_pw_neg(fz_ctx *ctx, const int32_t *a, int32_t *out, size_t count) {
     FZ_REQUIRE(ctx && (count == 0 || (a && out)), "NULL argument");
+    // the reference's __neg__ is -(x mod q) in [-(q-1), 0] (polynomials.py:155-163): the one value of the path that is NOT centred,
+    // and for q >= 2^31 not an int32 either.  fz_pw_sub from a zero row gives the centred negation for every modulus.
+    if (ctx->q >= 0x80000000u)
+        return fz_set_error(FZ_E_UNSUPPORTED, "-(x mod q) does not fit int32 for q >= 2^31: use fz_pw_sub(0, x), the centred negation");
     FZ_DEV(ctx);
     return fz_launch_pw(ctx, FZ_OP_NEG, a, a, out, count);
 }
@@ -869,6 +895,8 @@ int fz_pw_binary_host(fz_ctx *ctx, int op, const int32_t *h_a, const int32_t *h_
     FZ_REQUIRE(ctx && op >= FZ_OP_MUL && op <= FZ_OP_NEG, "bad op %d", op);
     FZ_DEV(ctx);
     FZ_REQUIRE(count == 0 || (h_a && h_out && (op == FZ_OP_NEG || h_b)), "NULL argument");
+    if (op == FZ_OP_NEG && ctx->q >= 0x80000000u)       // see fz_pw_neg
+        return fz_set_error(FZ_E_UNSUPPORTED, "-(x mod q) does not fit int32 for q >= 2^31: use fz_pw_sub(0, x), the centred negation");
     if (count == 0) return FZ_OK;
     const size_t seg = (count * sizeof(int32_t) + 255) & ~(size_t)255;
     void *d = nullptr;

@@ -144,6 +144,9 @@ struct fz_graph {
     int device;
 };
 
+// largest transform length: up to 256 the register / LDS schedules of fz_ntt.hip, beyond it one workgroup per polynomial through LDS
+constexpr int kFzMaxDegree = 4096;
+
 // error plumbing (fz_capi.hip)
 int fz_set_error(int code, const char *fmt, ...);
 int fz_check_hip(hipError_t e, const char *what);

@@ -1284,6 +1284,60 @@ __global__ __launch_bounds__(256) void ntt_small(const int32_t *in, int32_t *out
     for (int k = 0; k < D; ++k) out[poly * D + k] = (int)fz_cent(a[k], m);
 }
 
+// ------------------------------------------------------------------------------------------
+// D = 512 .. 4096 (round 5): one workgroup per polynomial, the polynomial in LDS as doubles, one workgroup barrier per stage,
+// twiddles from the device table.  The reference transforms any power-of-two length over any odd prime with a 2n-th root
+// (algebra/ntt.py:239-270); the scheme's own degrees (64, 256) never come here -- this is generality, not a hot path.
+// Forward: lazy sums (a value grows by at most q/2 per stage: 12 stages stay below 2^35).  Inverse: u + v doubles per
+// stage, so it is folded below q at every stage (fz_fold: 2 operations) and u - v stays inside fz_mulmod's bound.
+// ------------------------------------------------------------------------------------------
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void ntt_big(const int32_t *in, int32_t *out, size_t batch, int logd, const double *__restrict__ tw,
+                                               FzMod m, double n_inv) {
+    extern __shared__ double big_a[];
+    const int d = 1 << logd, half = d >> 1, tid = threadIdx.x;
+    for (size_t poly = blockIdx.x; poly < batch; poly += gridDim.x) {
+        for (int i = tid; i < d; i += 256) big_a[i] = (double)in[poly * d + i];
+        __syncthreads();
+        if (!INVERSE) {
+            for (int mm = 1, t = half; mm < d; mm <<= 1, t >>= 1) {            // ntt.py:274-290
+                for (int b = tid; b < half; b += 256) {
+                    const int i = b / t, j = 2 * i * t + (b - i * t);
+                    const double v = fz_mulmod(big_a[j + t], tw[mm + i], m), u = big_a[j];
+                    big_a[j] = u + v;
+                    big_a[j + t] = u - v;
+                }
+                __syncthreads();
+            }
+            for (int i = tid; i < d; i += 256) out[poly * d + i] = (int)fz_cent(big_a[i], m);
+        } else {
+            for (int h = half, t = 1; h >= 1; h >>= 1, t <<= 1) {               // ntt.py:354-372
+                for (int b = tid; b < half; b += 256) {
+                    const int i = b / t, j = 2 * i * t + (b - i * t);
+                    const double u = big_a[j], v = big_a[j + t];
+                    big_a[j] = fz_fold(u + v, m);
+                    big_a[j + t] = fz_mulmod(u - v, tw[h + i], m);
+                }
+                __syncthreads();
+            }
+            for (int i = tid; i < d; i += 256) out[poly * d + i] = (int)fz_cent(fz_mulmod(big_a[i], n_inv, m), m);      // ntt.py:373-376
+        }
+        __syncthreads();                                                         // (the next polynomial reuses the array)
+    }
+}
+
+int launch_big(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
+    const size_t lds = sizeof(double) << ctx->logd;
+    const size_t cap = (size_t)ctx->num_cu * 8;
+    const unsigned grid = (unsigned)(batch < cap ? batch : cap);
+    if (!inverse)
+        hipLaunchKernelGGL((ntt_big<false>), dim3(grid), dim3(256), lds, ctx->stream, in, out, batch, ctx->logd, (const double *)ctx->d_tw, ctx->mod, 0.0);
+    else
+        hipLaunchKernelGGL((ntt_big<true>), dim3(grid), dim3(256), lds, ctx->stream, in, out, batch, ctx->logd, (const double *)ctx->d_itw, ctx->mod,
+                           ctx->itwA.n_inv);
+    return fz_check_hip(hipGetLastError(), "ntt_big launch");
+}
+
 template <int LOGD, bool FAST>
 int launch16f(fz_ctx *ctx, const int32_t *in, int32_t *out, size_t batch, bool inverse) {
     const size_t tasks = (batch * Geom<LOGD>::D + kChunk - 1) / kChunk;
@@ -1523,7 +1577,8 @@ int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch
         case 6: return launch16<6>(ctx, d_in, d_out, batch, inverse);
         case 7: return launch16<7>(ctx, d_in, d_out, batch, inverse);
         case 8: return launch16<8>(ctx, d_in, d_out, batch, inverse);
-        default: return fz_set_error(FZ_E_UNSUPPORTED, "degree %d not supported (2..256)", ctx->degree);
+        case 9: case 10: case 11: case 12: return launch_big(ctx, d_in, d_out, batch, inverse);
+        default: return fz_set_error(FZ_E_UNSUPPORTED, "degree %d not supported (2..%d)", ctx->degree, kFzMaxDegree);
     }
 }
 

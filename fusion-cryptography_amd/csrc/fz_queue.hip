@@ -486,7 +486,7 @@ int fz_queue_create(int device, const fz_scheme_params *P, int rank, int64_t bet
     *out = nullptr;
     if (rank < 1 || workers < 1 || workers > 16 || max_rows < 1)
         return fz_set_error(FZ_E_BADARG, "rank >= 1, 1 <= workers <= 16, max_rows >= 1");
-    if (P->modulus <= 0 || P->modulus >= (1ll << 31) || P->degree < 1) return fz_set_error(FZ_E_BADARG, "bad parameter set");
+    if (P->modulus <= 0 || P->modulus >= (1ll << 32) || P->degree < 1) return fz_set_error(FZ_E_BADARG, "bad parameter set");
     fz_queue *Q = new (std::nothrow) fz_queue();
     if (!Q) return fz_set_error(FZ_E_HIP, "out of host memory");
     Q->device = device;

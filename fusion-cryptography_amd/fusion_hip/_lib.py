@@ -40,6 +40,7 @@ SIGNATURES = {
     "fz_last_error": (c_char_p, []),
     "fz_device_count": (c_int, [POINTER(c_int)]),
     "fz_ctx_create": (c_int, [c_int, c_uint32, c_int, c_uint32, c_uint32, POINTER(_ctx)]),
+    "fz_ctx_create_tables": (c_int, [c_int, c_uint32, c_int, _u32p, _u32p, POINTER(_ctx)]),
     "fz_ctx_destroy": (c_int, [_ctx]),
     "fz_ctx_set_stream": (c_int, [_ctx, c_void_p]),
     "fz_ctx_synchronize": (c_int, [_ctx]),

@@ -38,13 +38,23 @@ def _p(a):
 
 
 class Context:
-    def __init__(self, modulus, degree, root, inv_root, device=0):
+    def __init__(self, modulus, degree, root, inv_root, device=0, tables=None):
+        """tables=(forward, inverse): the context's twiddle tables are these lists (fz_ctx_create_tables) instead of the bit-reversed
+        powers of root / inv_root"""
         self._lib = load_library()
         self._h = c_void_p()
         self.modulus, self.degree, self.root, self.inv_root = modulus, degree, root, inv_root
         self.device = device
-        if not (0 < modulus < 2 ** 31):
-            raise FusionHipError(FZ_E_BADARG, f"modulus {modulus} outside (0, 2^31)")
+        if not (0 < modulus < 2 ** 32):
+            raise FusionHipError(FZ_E_BADARG, f"modulus {modulus} outside (0, 2^32)")
+        if tables is not None:
+            fwd, inv = (np.ascontiguousarray(np.asarray(t, dtype=np.uint64) % np.uint64(modulus), dtype=np.uint32) for t in tables)
+            if fwd.shape != (degree,) or inv.shape != (degree,):
+                raise FusionHipError(FZ_E_BADARG, f"twiddle tables must have {degree} entries each")
+            u32p = ctypes.POINTER(ctypes.c_uint32)
+            check(self._lib, self._lib.fz_ctx_create_tables(device, modulus, degree, fwd.ctypes.data_as(u32p), inv.ctypes.data_as(u32p),
+                                                            byref(self._h)))
+            return
         check(self._lib, self._lib.fz_ctx_create(device, modulus, degree, root % modulus, inv_root % modulus,
                                                  byref(self._h)))
 
@@ -683,6 +693,15 @@ class DeviceArray:
 
 
 _CTX_CACHE = {}
+
+
+def get_table_context(modulus, degree, fwd_table, inv_table, device=0):
+    """memoised contexts built from caller-supplied twiddle tables (tuples)"""
+    key = ("tables", modulus, degree, fwd_table, inv_table, device)
+    ctx = _CTX_CACHE.get(key)
+    if ctx is None:
+        ctx = _CTX_CACHE[key] = Context(modulus, degree, 0, 0, device, tables=(fwd_table, inv_table))
+    return ctx
 
 
 def get_context(modulus, degree, root, inv_root, device=0):

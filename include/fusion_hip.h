@@ -67,11 +67,19 @@ FZ_API int fz_device_count(int *out_count);
  * inv_root, root_order carried by every PolynomialRepresentation, algebra/polynomials.py:16-50)
  * and the per-call twiddle rebuild `bit_reverse_copy([pow(root, i, q) ...])`
  * (algebra/polynomials.py:396-397, :414-417; algebra/ntt.py:443-449).
- * Requirements: q odd prime < 2^31, degree a power of two in [2, 256] (kernel limit 1024),
- * root a primitive 2*degree-th root of unity mod q, root*inv_root == 1 mod q
- * (the same conditions PolynomialRepresentation.__init__ checks, polynomials.py:36-45). */
+ * Requirements: q odd, 3 <= q < 2^32 (centred residues are int32 for every such q; primality is the caller's check, as in
+ * the reference), degree a power of two in [2, 4096] (64 and 256, the scheme's, take the tuned kernels; up to 256 the register /
+ * LDS schedules; 512 .. 4096 one workgroup per polynomial), root a primitive 2*degree-th root of unity mod q,
+ * root*inv_root == 1 mod q (the same conditions PolynomialRepresentation.__init__ checks, polynomials.py:36-45).
+ * root == 0: a ring-only context (pointwise operations, no transforms). */
 FZ_API int fz_ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint32_t inv_root,
                          fz_ctx **out);
+/* The same with the twiddle tables GIVEN: cooley_tukey_ntt / gentleman_sande_intt take their table as an argument and use
+ * whatever they are handed (algebra/ntt.py:216-291 `s = bit_rev_root_powers[m + i]`, :294-377) -- a list that is not the
+ * bit-reversed power table of one root is transformed with it all the same.  h_fwd / h_inv: `degree` entries each (reduced mod
+ * q), used by fz_ntt_forward / fz_ntt_inverse and everything built on them; both required (pass one table twice when only one
+ * direction will be used). */
+FZ_API int fz_ctx_create_tables(int device_id, uint32_t q, int degree, const uint32_t *h_fwd, const uint32_t *h_inv, fz_ctx **out);
 FZ_API int fz_ctx_destroy(fz_ctx *ctx);
 FZ_API int fz_ctx_set_stream(fz_ctx *ctx, void *hip_stream);   /* NULL = default stream */
 FZ_API int fz_ctx_synchronize(fz_ctx *ctx);

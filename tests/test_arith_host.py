@@ -39,7 +39,7 @@ def cent(v, q):
     return y - q if y > q // 2 else y
 
 
-@pytest.mark.parametrize("q", [2147465729, 5, 17, 65537, 12289, 2147483629, 3])
+@pytest.mark.parametrize("q", [2147465729, 5, 17, 65537, 12289, 2147483629, 3, 2147565569, 4294828033, 4294967291])
 def test_cent_and_mulmod(q, lib):
     rng = random.Random(q)
     half = (q - 1) // 2
@@ -85,6 +85,7 @@ def test_mulmod4_exact_at_its_bounds(tmp_path):
     L.t_kappa_times_K.restype = ctypes.c_double
     L.t_kappa_times_K.argtypes = [ctypes.c_uint]
     assert L.t_fast(2147465729) == 1 and L.t_fast(12289) == 1 and L.t_fast(65537) == 0 and L.t_fast(40961) == 1
+    assert L.t_fast(4294962689) == 0 and L.t_fast(4294967291) == 0       # 2^32 - 4607, 2^32 - 5: the 4-op multiply stays below 2^31
     assert L.t_kappa_times_K(2147465729) == 17919.0
     for q in (2147465729, 12289, 7681, 257, 97, 17, 5, 3, 40961, 2147483647 - 32766 * 0 - 18):
         if not L.t_fast(q):
@@ -137,7 +138,7 @@ def test_exact_int64_centring_and_the_split_accumulation(tmp_path):
     L.t_split_accumulate.restype = ctypes.c_double
     I16 = ctypes.c_int * 16
     L.t_split_accumulate.argtypes = [I16, I16, ctypes.c_int, ctypes.c_uint]
-    for q in (2147465729, 12289, 65537, 3, 5, 2147483629):
+    for q in (2147465729, 12289, 65537, 3, 5, 2147483629, 2147565569, 4294828033, 4294967291):        # (the last three: 2^31 <= q < 2^32, round 5)
         rng = random.Random(q + 5)
         vals = [0, 1, -1, 2**63 - 1, -2**63, 2**53, 2**53 + 1, -(2**53) - 1, 2**62 + 12345, q, -q, q * 2**31 + 7, (q // 2) * 2818 * 8]
         vals += [rng.randrange(-2**63, 2**63) for _ in range(5000)]

@@ -82,8 +82,9 @@ def test_fails_loudly_without_a_device(lib):
     assert lib.fz_ctx_create(0, 2147465729, 100, 3337519, 1, ctypes.byref(h)) == -1      # not a power of two
     assert lib.fz_ctx_create(0, 2147465728, 256, 3337519, 1, ctypes.byref(h)) == -1      # even modulus
     assert lib.fz_ctx_create(0, 2147465729, 256, 5, 1, ctypes.byref(h)) == -1            # not a primitive root
-    assert lib.fz_ctx_create(0, 2147465729, 512, 3337519, 1, ctypes.byref(h)) == -2      # degree > 256
-    assert b"512" in lib.fz_last_error()
+    assert lib.fz_ctx_create(0, 2147465729, 8192, 3337519, 1, ctypes.byref(h)) == -2     # degree > 4096 (round 5; > 256 before)
+    assert b"8192" in lib.fz_last_error()
+    assert lib.fz_ctx_create_tables(0, 2147465729, 256, None, None, ctypes.byref(h)) == -1   # tables are required
     # the batch queue owns contexts: no device, no queue (and nothing left running)
     import fusion.fusion as F
     from fusion_hip.queue import BatchQueue, PackedMessages

@@ -377,12 +377,12 @@ def test_tools_and_examples_compile():
     import py_compile
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "examples", "*.py")) + \
-        [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    files = glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "tools", "probes", "*.py")) + \
+        glob.glob(os.path.join(root, "examples", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
     assert len(files) > 20
     for f in files:
         py_compile.compile(f, doraise=True)
-    for sh in glob.glob(os.path.join(root, "tools", "*.sh")):
+    for sh in glob.glob(os.path.join(root, "tools", "*.sh")) + glob.glob(os.path.join(root, "tools", "probes", "*.sh")):
         text = open(sh).read()
         for m in re.finditer(r"(?:python3?|bash)\s+(?:\$R/)?(tools/[\w/]+\.(?:py|sh))", text):
             assert os.path.exists(os.path.join(root, m.group(1))), (sh, m.group(1))

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Regenerates every measurement committed under profiles/ in ONE gpurun call (one box: numbers from different
 # boxes differ by several percent).  usage (from the repo root):
-#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r04'      then copy gpurun_out/<tag>/<tag>_* to profiles/
-# The rocprofv3 pass over bench.py runs `--headline-only`: the timed regions (graph replays over the rotating batches, on 4 streams
-# and on one) and the per-dispatch passes, nothing else -- its kernel_stats average for ntt_jobs4 is the figure bench.py's
-# roofline.avg_launch_us / roofline.frac must agree with (16 777 216 B / AverageNs); the profiler runs the dispatches of all
-# streams one at a time (by_grid's in_flight column), so roofline.chip has no counterpart in a trace.
+#   gpurun --timeout 1150 -- 'bash tools/collect_profiles.sh r05'      then copy gpurun_out/<tag>/<tag>_* to profiles/
+# rocprofv3 over bench.py, twice (`--headline-only`: the timed regions, the device-timestamp passes and the per-dispatch passes,
+# nothing else).  (1) `--streams 1`: ONE launch in flight throughout -- the configuration roofline.frac is defined on; the
+# kernel_stats average of the dominant kernel (ntt_jobs16: 134 217 728 B per launch / AverageNs / 8 TB/s) is the figure the
+# line's roofline.frac / avg_launch_us must agree with.  (2) the default two streams: round 5's launches are long enough that
+# the profiler no longer serialises them completely (by_grid's in_flight column > 1), so this run's per-kernel average MIXES
+# overlapped launches (each slower) with the one-stream region's -- it corroborates the overlap, it is not the per-launch figure.
 # Stops at the first step that fails or times out: no further GPU work is started after a failed one.
 set -u
 TAG=${1:-rXX}
@@ -48,14 +50,20 @@ step timeout -k 10 200 python tools/probes/object_api_profile.py 256 16 > $OUT/$
 step timeout -k 10 600 bash tools/probes/exchange_overlap.sh > $OUT/${TAG}_exchange_overlap.txt 2>&1
 step timeout -k 10 400 python tools/probes/hw_queue_probe.py > $OUT/${TAG}_hw_queue_oversubscription.txt 2>&1
 step timeout -k 10 300 python tools/probes/stream_sweep.py > $OUT/${TAG}_multi_stream_sweep.txt 2>&1
+step timeout -k 10 300 python tools/probes/queue_aggregates.py > $OUT/${TAG}_queue_aggregates.txt 2>&1
+step timeout -k 10 900 python tools/rccl_exit_matrix.py --out $OUT/${TAG}_rccl_exit_matrix.txt > $OUT/rccl_matrix.log 2>&1
 step timeout -k 10 600 python bench.py --full --full-out $OUT/${TAG}_bench_full.json > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
+python3 tools/stamp_table.py $OUT/${TAG}_bench_full.json > $OUT/${TAG}_device_timestamps.txt
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations from the profiler: the bench's transform launches, the cold kernel table, the challenge pipeline
-step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --headline-only --full-out $OUT/prof_bench_full.json > $OUT/prof.log 2>&1
+step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --headline-only --streams 1 --full-out $OUT/prof_bench_full.json > $OUT/prof.log 2>&1
 cp $OUT/prof/*/*_kernel_stats.csv $OUT/${TAG}_bench_rocprofv3_kernel_stats.csv 2>/dev/null
 # the line bench.py printed IN THAT PROFILED RUN: its roofline.avg_launch_us and the kernel_stats average above are the same
-# launches measured two ways (they agree within ~1 %); the un-profiled line (${TAG}_bench_n1.json) is ~6 % faster
+# launches measured two ways
 grep -a '^{"metric"' $OUT/prof.log | tail -1 > $OUT/${TAG}_bench_under_rocprofv3_line.json
+step timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof2 -- python3 $R/bench.py --headline-only --full-out $OUT/prof2_bench_full.json > $OUT/prof2.log 2>&1
+cp $OUT/prof2/*/*_kernel_stats.csv $OUT/${TAG}_bench_2streams_rocprofv3_kernel_stats.csv 2>/dev/null
+grep -a '^{"metric"' $OUT/prof2.log | tail -1 > $OUT/${TAG}_bench_2streams_under_rocprofv3_line.json
 # ... and the whole default run (the scheme legs' kernels as the bench runs them)
 step timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profd -- python3 $R/bench.py --no-cpu-baseline --full-out /dev/null > $OUT/profd.log 2>&1
 cp $OUT/profd/*/*_kernel_stats.csv $OUT/${TAG}_bench_default_rocprofv3_kernel_stats.csv 2>/dev/null
@@ -66,7 +74,7 @@ cp $OUT/profc/*/*_kernel_stats.csv $OUT/${TAG}_challenge_rocprofv3_kernel_stats.
 # PMC passes: one counter set per pass, nothing else traced
 for set in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU"; do
   n=$(echo $set | tr " " "_" | cut -c1-30)
-  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcb/$n -- python3 $R/bench.py --headline-only --no-graph --steps 50 --prewarm-ms 20 --full-out $OUT/pmcb_bench_full.json > $OUT/pmcb_$n.log 2>&1
+  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcb/$n -- python3 $R/bench.py --headline-only --streams 1 --no-stamps --no-graph --steps 50 --prewarm-ms 20 --full-out $OUT/pmcb_bench_full.json > $OUT/pmcb_$n.log 2>&1
   step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc20/$n -- python3 $R/tools/probes/prof_ntt.py 20 30 > $OUT/pmc20_$n.log 2>&1
   step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcs/$n -- python3 $R/tools/probes/prof_scheme.py 12 > $OUT/pmcs_$n.log 2>&1
 done
@@ -76,8 +84,13 @@ step timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ
 cd $R
 python3 tools/probes/pmc_stalls.py $OUT/sq1/*/*counter_collection.csv $OUT/sq2/*/*counter_collection.csv > $OUT/${TAG}_wave_cycles.txt
 python3 tools/trace_summary.py $OUT/prof/*/*_kernel_trace.csv > $OUT/${TAG}_bench_rocprofv3_by_grid.csv 2>/dev/null
+python3 tools/trace_summary.py $OUT/prof2/*/*_kernel_trace.csv > $OUT/${TAG}_bench_2streams_rocprofv3_by_grid.csv 2>/dev/null
 python3 tools/trace_summary.py $OUT/profd/*/*_kernel_trace.csv > $OUT/${TAG}_bench_default_rocprofv3_by_grid.csv 2>/dev/null
 python3 tools/trace_summary.py $OUT/profk/*/*_kernel_trace.csv > $OUT/${TAG}_kernel_table_rocprofv3_by_grid.csv 2>/dev/null
 python3 tools/trace_summary.py $OUT/profc/*/*_kernel_trace.csv > $OUT/${TAG}_challenge_rocprofv3_by_grid.csv 2>/dev/null
 step python3 tools/pmc_summary.py $OUT $TAG > /dev/null
+
+# raw traces and counter dumps are large and have been summarised above: they do not travel back
+find $OUT -name "*_kernel_trace.csv" -delete 2>/dev/null
+find $OUT -name "*counter_collection.csv" -delete 2>/dev/null
 echo collected into $OUT

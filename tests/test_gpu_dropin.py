@@ -64,8 +64,19 @@ def test_ntt_poly_mult_is_negacyclic_product():
         assert cooley_tukey_ntt(v, q, 2 * d, tw) is v                      # in place, returns the same list
         assert gentleman_sande_intt(v, q, 2 * d, itw) is v
         assert [(x - y) % q for x, y in zip(v, v0)] == [0] * d
-        with pytest.raises(ValueError):
-            cooley_tukey_ntt(list(v0), q, 2 * d, [1] * d)                  # not a power table of one root
+        # a table that is NOT the power table of one root is used as it stands, like the reference does (ntt.py:277; rounds 1-4
+        # raised ValueError here): with all-ones twiddles the network is d/2 ... 1-strided sums and differences
+        w = list(v0)
+        cooley_tukey_ntt(w, q, 2 * d, [1] * d)
+        ref, t, m = list(v0), d, 1
+        while m < d:
+            t //= 2
+            for i in range(m):
+                for j in range(2 * i * t, 2 * i * t + t):
+                    u, x = ref[j], ref[j + t]
+                    ref[j], ref[j + t] = u + x, u - x
+            m *= 2
+        assert [(x - y) % q for x, y in zip(w, ref)] == [0] * d and all(-(q // 2) <= x <= q // 2 for x in w)
 
 
 def test_hand_example_q17_d8():

@@ -289,17 +289,17 @@ def sign_verify(e):
             cx.synchronize()
             for ev in ev_part + ev_sum:
                 ev.destroy()
-        return sv, sv_graph_used
+        return sv, sv_graph_used, len(my_records())
 
     GROUPS = max(4, world)
     while S % GROUPS:
         GROUPS += 1
     per = S // GROUPS
-    sv, sv_graph_used = measure(GROUPS)
+    sv, sv_graph_used, n_verified = measure(GROUPS)
     if world == 1 and comm is None and not args.exchange_standin_us:
         # BASELINE configs[3]'s own shape on one GPU: ONE aggregate over all 1024 signers (the default above splits
         # the rank's 1024 signatures into four aggregates of 256 -- at N ranks: N aggregates of 128 x N signers, every rank verifying)
-        one, _ = measure(1)
+        one, _, _ = measure(1)
         sv["one_aggregate"] = {k_: one[k_] for k_ in ("value", "unit", "ms_per_step", "moved_frac_per_gpu", "aggregates", "signers_per_aggregate",
                                                        "steps", "verification", "sign_and_aggregate")}
     # BASELINE configs[2]: 1024 independent keygen + sign per step (keygen_core: 2*l transforms + two A.s products per
@@ -326,7 +326,7 @@ def sign_verify(e):
                                  "sk_hat keygen has just written (174 MB: part of it may still sit in the Infinity Cache), "
                                  "coefficients come from HBM (8 sets rotated)"}
     if world > 1:            # what EVERY rank did in this leg, as the ranks themselves report it
-        mine = {"rank": rank, "collective": collective, "aggregates_verified": len(my_records()), "verdicts_ok": True,
+        mine = {"rank": rank, "collective": collective, "aggregates_verified": n_verified, "verdicts_ok": True,
                 "graph": sv_graph_used}
         allr = [None] * world
         dist.all_gather_object(allr, mine)

@@ -208,9 +208,10 @@ def newest_profile(pattern):
     return best[1] if best else None
 
 
-def pmc_traffic(kernel_prefix="ntt_fwd4<8"):
+def pmc_traffic(kernel_prefix="ntt_fwd4<8", rows=None):
     """HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary (rocprofv3 --pmc passes cannot
-    be taken live: tools/collect_profiles.sh, tools/pmc_summary.py) -> (bytes or None, source)"""
+    be taken live: tools/collect_profiles.sh, tools/pmc_summary.py) -> (bytes or None, source).  rows: the launch's transforms
+    (one kernel serves launches of several sizes: only the entry of THIS size counts)"""
     path = newest_profile("pmc_ntt.json")
     if not path:
         return None, "no profiles/r*_pmc_ntt.json"
@@ -218,7 +219,8 @@ def pmc_traffic(kernel_prefix="ntt_fwd4<8"):
         with open(path) as fh:
             ks = json.load(fh)["kernels"]
         vals = [v["traffic_bytes_per_launch"] for k, v in ks.items()
-                if k.startswith(kernel_prefix) and "bench launch" in k and "traffic_bytes_per_launch" in v]
+                if k.startswith(kernel_prefix) and "bench launch" in k and "traffic_bytes_per_launch" in v
+                and (rows is None or v.get("rows_per_launch") == rows)]
         if not vals:
             return None, f"{os.path.relpath(path, ROOT)} has no entry for {kernel_prefix}"
         return max(vals), os.path.relpath(path, ROOT)
@@ -960,7 +962,7 @@ def main():
             kernel_name = f"ntt_jobs4<8, true, {nr_}, {(8 if rows_ >= 8 * cus else 4 if rows_ >= 4 * cus else 1) if nr_ == 1 else 2}, FzJobsN<{tab_}>>"
         launch_text = (f"software-pipelined over {D} batches: forward of batches i+1..i+{D} + inverse of batches i-{D - 1}..i in one "
                        f"fz_ntt_multi launch ({2 * D} jobs) per {D} steps")
-    traffic, traffic_src = pmc_traffic(kernel_name.split(", FzJobsN")[0])      # prefix: whatever follows the launch shape
+    traffic, traffic_src = pmc_traffic(kernel_name.split(", FzJobsN")[0], units_per_launch)      # prefix: whatever follows the launch shape
 
     def stamp_brief(sp):
         if not isinstance(sp, dict) or "frac" not in sp:

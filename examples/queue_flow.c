@@ -2,7 +2,10 @@
  * signatures each (keygen + sign, fusion/fusion.py:338-373, :534-557) are submitted back to back from this one thread, worker
  * threads inside the library run whatever is pending as one batch, and every call's verification keys and signatures must be
  * the rows the direct entry points (fz_sample_secret_polys_dev + fz_keygen_core_bcast + fz_challenge_hat_msgs_dev + fz_sign_core)
- * give for that call alone.
+ * give for that call alone.  Then every call's signers are aggregated and verified THROUGH THE SAME QUEUE
+ * (fz_queue_submit_aggregate_verify on the queue's own device rows: aggregate() + verify(), fusion.py:655-677, :680-728 -- the twelve
+ * pending calls share one ragged launch for the sums and one for the verdicts), and a tampered aggregate is rejected by a queued
+ * verify().
  *   gcc -std=c99 -Iinclude examples/queue_flow.c -o queue_flow -Lfusion-cryptography_amd/lib -lfusion_hip \
  *       -Wl,-rpath,$PWD/fusion-cryptography_amd/lib
  * Exit code 0 = every row equal.  (tests/test_cabi_symbols.py compiles it; tests/test_gpu_queue.py runs it.) */
@@ -32,7 +35,10 @@ int main(void) {
     static size_t off[CALLS][PER + 1];
     static uint64_t seeds[CALLS][PER];
     int32_t *vk_out[CALLS], *sig_ref, *sig_got;
-    uint64_t ticket[CALLS], done_calls = 0, batches = 0, rows = 0;
+    uint64_t ticket[CALLS], agg_ticket[CALLS], bad_ticket = 0, done_calls = 0, batches = 0, rows = 0;
+    const int32_t *sig_rows[CALLS];
+    static int32_t agg[CALLS][L][D];
+    int verdict[CALLS], bad_verdict = -1;
     void *d_A = NULL, *d_coef = NULL, *d_sk = NULL, *d_vk = NULL, *d_c = NULL, *d_sig = NULL;
     size_t i;
     int c, k;
@@ -86,12 +92,30 @@ int main(void) {
         CHECK(fz_memcpy_d2h(ctx, sig_got, r.d_sig, (size_t)PER * L * D * 4));      /* the queue's rows, read through OUR context */
         if (memcmp(vk_out[c], vk_ref, sizeof vk_ref) != 0) { fprintf(stderr, "call %d: verification keys differ\n", c); return 1; }
         if (memcmp(sig_got, sig_ref, (size_t)PER * L * D * 4) != 0) { fprintf(stderr, "call %d: signatures differ\n", c); return 1; }
+        sig_rows[c] = r.d_sig;                             /* stays the queue's until the call is released (below) */
+    }
+    /* aggregate() + verify() of every call's signers, queued: verification bounds and capacity of secpar 128 (fusion.py:24, :63-68) */
+    CHECK(fz_queue_enable_aggregate(q, 536070080, D, 1796, 4));
+    for (c = 0; c < CALLS; ++c) {
+        verdict[c] = -1;
+        CHECK(fz_queue_submit_aggregate_verify(q, vk_out[c], msgs[c], off[c], PER, sig_rows[c], &agg[c][0][0], &verdict[c],
+                                               FZ_QUEUE_ROWS_ON_DEVICE, &agg_ticket[c]));
+    }
+    for (c = 0; c < CALLS; ++c) {
+        CHECK(fz_queue_wait(q, agg_ticket[c], NULL));
+        if (verdict[c] != FZ_VERDICT_OK) { fprintf(stderr, "call %d: aggregate rejected with verdict %d\n", c, verdict[c]); return 1; }
+    }
+    agg[3][7][5] += 1;                                     /* a tampered aggregate: the reference's tamper test (tests/test_fusion.py:860-873) */
+    CHECK(fz_queue_submit_verify(q, vk_out[3], msgs[3], off[3], PER, &agg[3][0][0], &bad_verdict, 0, &bad_ticket));
+    CHECK(fz_queue_wait(q, bad_ticket, NULL));
+    if (bad_verdict != FZ_VERDICT_TARGET_MISMATCH) { fprintf(stderr, "tampered aggregate: verdict %d\n", bad_verdict); return 1; }
+    for (c = 0; c < CALLS; ++c) {
         CHECK(fz_queue_release(q, ticket[c]));
         CHECK(fz_queue_release(q, ticket[c]));             /* idempotent */
     }
     CHECK(fz_queue_drain(q));
     CHECK(fz_queue_stats(q, &done_calls, &batches, &rows));
-    if (done_calls != CALLS || rows != (uint64_t)CALLS * PER || batches == 0 || batches > CALLS) { fprintf(stderr, "stats %llu %llu %llu\n",
+    if (done_calls != 2 * CALLS + 1 || rows != (uint64_t)(2 * CALLS + 1) * PER || batches == 0 || batches > 2 * CALLS + 1) { fprintf(stderr, "stats %llu %llu %llu\n",
         (unsigned long long)done_calls, (unsigned long long)batches, (unsigned long long)rows); return 1; }
     CHECK(fz_queue_destroy(q));
     for (c = 0; c < CALLS; ++c) CHECK(fz_pinned_free(vk_out[c]));
@@ -99,7 +123,7 @@ int main(void) {
     CHECK(fz_free(ctx, d_A)); CHECK(fz_free(ctx, d_coef)); CHECK(fz_free(ctx, d_sk)); CHECK(fz_free(ctx, d_vk));
     CHECK(fz_free(ctx, d_c)); CHECK(fz_free(ctx, d_sig));
     CHECK(fz_ctx_destroy(ctx));
-    printf("queue_flow OK: %d calls of %d keys + signatures in %llu batches, every row equal to the direct calls\n", CALLS, PER,
-           (unsigned long long)batches);
+    printf("queue_flow OK: %d calls of %d keys + signatures, their %d aggregates + verifications and one tampered verification in %llu "
+           "batches; every row equal to the direct calls, every verdict the expected one\n", CALLS, PER, CALLS, (unsigned long long)batches);
     return 0;
 }

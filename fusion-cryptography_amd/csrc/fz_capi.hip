@@ -1530,8 +1530,12 @@ int fz_diag_stamps_read(fz_ctx *ctx, uint64_t *h_start, uint64_t *h_end, uint64_
     FZ_DEV(ctx);
     if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "stamps cannot be read during graph capture");
     FZ_HIP(hipStreamSynchronize(ctx->stream), "stamp sync");
-    std::vector<unsigned long long> h(2 * ctx->stamp_used);
-    if (ctx->stamp_used) FZ_HIP(hipMemcpy(h.data(), ctx->d_stamp, 16 * ctx->stamp_used, hipMemcpyDeviceToHost), "stamp read");
+    unsigned long long *h = (unsigned long long *)malloc(16 * (ctx->stamp_used ? ctx->stamp_used : 1));      // (no C++ exception crosses the C ABI)
+    if (!h) return fz_set_error(FZ_E_HIP, "out of host memory");
+    if (ctx->stamp_used) {
+        const int rc = fz_check_hip(hipMemcpy(h, ctx->d_stamp, 16 * ctx->stamp_used, hipMemcpyDeviceToHost), "stamp read");
+        if (rc != FZ_OK) { free(h); return rc; }
+    }
     size_t k = 0;
     for (; k < (size_t)ctx->stamp_n && k < cap; ++k) {
         unsigned long long lo = ~0ull, hi = 0, last = 0;
@@ -1548,6 +1552,7 @@ int fz_diag_stamps_read(fz_ctx *ctx, uint64_t *h_start, uint64_t *h_end, uint64_
         if (h_workgroups) h_workgroups[k] = seen;
     }
     *n = k;
+    free(h);
     return FZ_OK;
 }
 
@@ -1608,7 +1613,12 @@ int rccl_bind() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.handle) return FZ_OK;
     RcclApi a = {};
-    void *h = rccl_open(a.how, sizeof a.how);
+    void *h = nullptr;
+    try {
+        h = rccl_open(a.how, sizeof a.how);
+    } catch (const std::bad_alloc &) {
+        return fz_set_error(FZ_E_HIP, "out of host memory");
+    }
     if (!h) return fz_set_error(FZ_E_RCCL, "RCCL not found (librccl.so.1): %s", dlerror());
     a.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
     a.CommInitRank = (int (*)(void **, int, fz_unique_id, int))dlsym(h, "ncclCommInitRank");
@@ -1655,9 +1665,13 @@ int fz_comm_create(fz_ctx *ctx, int nranks, int rank, const fz_unique_id *id, fz
     fz_comm *C = new (std::nothrow) fz_comm();
     if (!C) { g_rccl.CommDestroy(c); return fz_set_error(FZ_E_HIP, "out of host memory"); }
     C->comm = c; C->nranks = nranks; C->rank = rank; C->device = ctx->device;
-    {
+    try {
         std::lock_guard<std::mutex> lk(g_rccl_mu);
         g_live_comms.push_back(C);
+    } catch (const std::bad_alloc &) {
+        g_rccl.CommDestroy(c);
+        delete C;
+        return fz_set_error(FZ_E_HIP, "out of host memory");
     }
     *out = C;
     return FZ_OK;
@@ -1693,7 +1707,7 @@ int fz_rccl_library(char *out_path, size_t path_cap, char *out_how, size_t how_c
     FZ_TRY(rccl_bind());
     if (out_path && path_cap) snprintf(out_path, path_cap, "%s", g_rccl.path);
     if (out_how && how_cap) snprintf(out_how, how_cap, "%s", g_rccl.how);
-    if (out_copies_mapped) {
+    if (out_copies_mapped) try {
         std::vector<std::string> seen;
         if (FILE *f = fopen("/proc/self/maps", "r")) {
             char line[1024];
@@ -1707,6 +1721,8 @@ int fz_rccl_library(char *out_path, size_t path_cap, char *out_how, size_t how_c
             fclose(f);
         }
         *out_copies_mapped = (int)seen.size();
+    } catch (const std::bad_alloc &) {
+        return fz_set_error(FZ_E_HIP, "out of host memory");
     }
     return FZ_OK;
 }

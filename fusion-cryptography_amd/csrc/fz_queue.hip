@@ -298,29 +298,36 @@ int run_agg_batch(fz_queue *Q, Worker &w, std::vector<Job> &jobs, int kind, std:
             for (;;) {
                 const size_t g = next.fetch_add(1);
                 if (g >= G) return;
-                const size_t n = jobs[g].n, o = offs[g];
-                std::vector<size_t> order(n);
-                int r = fz_sort_by_vk_string(&Q->P, L.data() + o * d, R.data() + o * d, n, order.data(), 1);
-                if (r == FZ_OK) {
-                    std::vector<int32_t> sL(n * d), sR(n * d), sC(n * d), sA(n * d);
-                    std::vector<uint8_t> sP(n * 32);
-                    for (size_t i = 0; i < n; ++i) {
-                        const size_t k = o + order[i];
-                        memcpy(sL.data() + i * d, L.data() + k * d, poly);
-                        memcpy(sR.data() + i * d, R.data() + k * d, poly);
-                        memcpy(sC.data() + i * d, c_hat.data() + k * d, poly);
-                        memcpy(sP.data() + i * 32, pre.data() + k * 32, 32);
+                try {
+                    const size_t n = jobs[g].n, o = offs[g];
+                    std::vector<size_t> order(n);
+                    int r = fz_sort_by_vk_string(&Q->P, L.data() + o * d, R.data() + o * d, n, order.data(), 1);
+                    if (r == FZ_OK) {
+                        std::vector<int32_t> sL(n * d), sR(n * d), sC(n * d), sA(n * d);
+                        std::vector<uint8_t> sP(n * 32);
+                        for (size_t i = 0; i < n; ++i) {
+                            const size_t k = o + order[i];
+                            memcpy(sL.data() + i * d, L.data() + k * d, poly);
+                            memcpy(sR.data() + i * d, R.data() + k * d, poly);
+                            memcpy(sC.data() + i * d, c_hat.data() + k * d, poly);
+                            memcpy(sP.data() + i * 32, pre.data() + k * 32, 32);
+                        }
+                        r = fz_aggregation_coefficients(&Q->P, sL.data(), sR.data(), sP.data(), sC.data(), n, sA.data(), 1);
+                        if (r == FZ_OK)
+                            for (size_t i = 0; i < n; ++i) memcpy(alpha.data() + (o + order[i]) * d, sA.data() + i * d, poly);
                     }
-                    r = fz_aggregation_coefficients(&Q->P, sL.data(), sR.data(), sP.data(), sC.data(), n, sA.data(), 1);
-                    if (r == FZ_OK)
-                        for (size_t i = 0; i < n; ++i) memcpy(alpha.data() + (o + order[i]) * d, sA.data() + i * d, poly);
+                    if (r != FZ_OK) { int e = FZ_OK; first_rc.compare_exchange_strong(e, r); }
+                } catch (const std::exception &) {          // (a pool thread: nothing may leave it)
+                    int e = FZ_OK;
+                    first_rc.compare_exchange_strong(e, FZ_E_HIP);
                 }
-                if (r != FZ_OK) { int e = FZ_OK; first_rc.compare_exchange_strong(e, r); }
             }
         };
         const size_t T = std::min<size_t>(G, (size_t)std::max(1, Q->host_threads));
         std::vector<std::thread> pool;
-        for (size_t t = 1; t < T; ++t) pool.emplace_back(work);
+        try {
+            for (size_t t = 1; t < T; ++t) pool.emplace_back(work);
+        } catch (const std::exception &) {}                 // fewer threads than asked for: the ones that started (and this one) do the work
         work();
         for (auto &th : pool) th.join();
         if (first_rc.load() != FZ_OK) return fz_set_error(first_rc.load(), "queue: hash_ag failed for an aggregate of the batch");
@@ -389,7 +396,7 @@ void worker_main(fz_queue *Q, int index) {
         int rc;
         try {
             rc = kind == KIND_KEYGEN_SIGN ? run_batch(Q, w, jobs, &b, row0) : run_agg_batch(Q, w, jobs, kind, verdicts);
-        } catch (const std::bad_alloc &) {          // the coalesced host copies: an error of these calls, not std::terminate
+        } catch (const std::exception &) {          // the coalesced host copies (bad_alloc) or a thread that would not start: an error of these calls, not std::terminate
             (void)fz_ctx_synchronize(w.ctx);
             b = nullptr;
             rc = fz_set_error(FZ_E_HIP, "queue worker: out of host memory while coalescing %zu calls", jobs.size());

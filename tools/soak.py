@@ -64,7 +64,7 @@ while time.time() < t_end:
     ctx = ctxs[(sp, kern)]
     other = ctxs[(sp, str(rng.choice(KERNS)))]
     rows = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 257, 1000, 4099, int(rng.integers(1, 20000))]))
-    what = rng.choice(["ntt", "polymul", "scheme", "graph", "pointwise", "small", "batch_api", "multi", "challenge", "sampler", "ragged"])
+    what = rng.choice(["ntt", "polymul", "scheme", "graph", "pointwise", "small", "batch_api", "multi", "challenge", "sampler", "ragged", "queue"])
     raw = rng.random() < 0.3
     x = (rng.integers(-2**31, 2**31, size=(rows, d), dtype=np.int64).astype(np.int32) if raw
          else O.splitmix_centered(int(rng.integers(1, 2**40)), rows * d).reshape(rows, d))
@@ -257,6 +257,59 @@ while time.time() < t_end:
         assert np.array_equal(cs.poly_mul(xx, yy), want), ("small polymul", qq, dd, rr)
         cs.close()
         bump("small")
+    elif what == "queue":
+        # the asynchronous batch queue under mixed load: keygen + sign calls, aggregate + verify calls (signatures as host rows, as
+        # the queue's own device rows) and verify calls (one of them tampered) pending at once on 1-3 workers; every result against
+        # BatchScheme on the same inputs; rows released behind an asynchronous consumer (release(after=))
+        import fusion.fusion as F
+        from fusion_hip import scheme as SCH
+        from fusion_hip.queue import BatchQueue
+        if "params" not in globals():
+            globals()["params"] = {s_: F.fusion_setup(s_, 2026 + s_) for s_ in (128, 256)}
+            globals()["bsch"] = {s_: SCH.BatchScheme(globals()["params"][s_]) for s_ in (128, 256)}
+        prm, bs = globals()["params"][sp], globals()["bsch"][sp]
+        l_ = prm.num_rows_sk
+        ncalls = int(rng.integers(2, 7))
+        sizes = [int(v) for v in rng.choice([1, 2, 3, 9, 40, 130], size=ncalls)]
+        with BatchQueue(prm, workers=int(rng.integers(1, 4)), max_rows=int(rng.choice([130, 256, 4096])), host_threads=int(rng.integers(1, 5))) as bq:
+            calls = []
+            for n_ in sizes:
+                seeds = [int(v) for v in rng.integers(1, 2**62, size=n_)]
+                msgs = [f"soak {it} q {i} " + "y" * int(rng.integers(0, 60)) for i in range(n_)]
+                calls.append((seeds, msgs, bq.submit_keygen_sign(seeds, msgs)))
+            res, want, agg_t = [], [], []
+            for seeds, msgs, t in calls:
+                r = bq.wait(t)
+                sk_b, vk_b = bs.keygen_batch(seeds)
+                sig_b = bs.sign_batch(sk_b, vk_b, msgs)
+                assert np.array_equal(r.vk, vk_b) and np.array_equal(r.signatures(), sig_b), ("queue keygen+sign", sp, len(seeds))
+                rows_ = sig_b if rng.random() < 0.5 else r.sig_ptr
+                agg_t.append(bq.submit_aggregate_verify(vk_b, msgs, rows_))
+                res.append((r, vk_b, msgs, sig_b))
+            ver_t = []
+            for (r, vk_b, msgs, sig_b), t in zip(res, agg_t):
+                agg, verdict = bq.wait_aggregate(t)
+                w_ = bs.aggregate(vk_b, msgs, sig_b)
+                assert np.array_equal(agg, w_) and verdict == (True, ""), ("queue aggregate", sp, len(msgs))
+                bad = agg.copy()
+                tamper = rng.random() < 0.4
+                if tamper:
+                    bad[int(rng.integers(0, l_)), int(rng.integers(0, d))] += 1
+                ver_t.append((bq.submit_verify(vk_b, msgs, bad), tamper))
+                if rng.random() < 0.5:                      # a consumer still reading the rows when they are released
+                    d_al = DB.from_numpy(bs.ctx, np.ones((len(msgs), d), np.int32))
+                    d_o = DB(bs.ctx, l_ * d * 4)
+                    bs.ctx.aggregate_core_dev(r.sig_ptr, d_al.ptr, d_o.ptr, len(msgs), l_)
+                    r.release(after=bs.ctx)
+                    got = d_o.to_numpy(np.int32, (l_, d))
+                    assert np.array_equal(got, orc.aggregate_core(sig_b, np.ones((len(msgs), d), np.int32), q)), ("release after", sp)
+                    d_al.free()
+                    d_o.free()
+                else:
+                    r.release()
+            for t, tamper in ver_t:
+                assert bq.wait_verdict(t) == ((False, "Target doesn't match image of aggregate signature.") if tamper else (True, "")), ("queue verify", sp, tamper)
+        bump("queue")
     elif what == "batch_api":
         # array API == drop-in object API (which the GPU test-suite pins to the reference's golden strings)
         import fusion.fusion as F

@@ -23,6 +23,7 @@
 #include "../../include/fusion_hip.h"
 #include "../../include/fusion_hip_diag.h"
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 namespace {
 typedef int fz_v4i __attribute__((ext_vector_type(4)));
@@ -54,22 +55,33 @@ __device__ __forceinline__ int pad4(int j) { return j + 4 * (j >> 4); }
 
 struct Chunk { int4 v0, v1, v2, v3; };
 
-// issue the task's 4 coalesced 16-byte loads (clamped to the last valid 16-byte piece)
+// issue the task's 4 coalesced 16-byte loads.  `task` is wave-uniform, so "does the whole chunk lie inside the batch" is a
+// scalar test: every chunk but a ragged last one takes ONE scalar base and the lane's 32-bit offset (the four loads differ
+// in their immediate offsets only); the ragged one clamps each piece to the last valid 16 bytes.
+// Streaming loads: the 16-per-lane kernels run on batches far larger than the caches and read every input once
+// (+2-4 % at 2^18..2^20 rows, +9 % at 2^16 with cold inputs; the radix-4 kernels, used for small batches whose
+// data may well be cache-resident, keep normal loads: streaming ones cost them 3-5 % at 2^12 rows)
+__device__ __forceinline__ int4 nt_load4(const int32_t *p) {
+    const fz_v4i t = __builtin_nontemporal_load(reinterpret_cast<const fz_v4i *>(p));
+    return make_int4(t.x, t.y, t.z, t.w);
+}
+
 __device__ __forceinline__ Chunk chunk_load(const int32_t *in, size_t task, size_t total, int lane) {
-    const size_t base = task * kChunk + 4 * lane;
-    const size_t last = total - 4;
     Chunk c;
-    // streaming loads: the 16-per-lane kernels run on batches far larger than the caches and read every input once
-    // (+2-4 % at 2^18..2^20 rows, +9 % at 2^16 with cold inputs; the radix-4 kernels, used for small batches whose
-    // data may well be cache-resident, keep normal loads: streaming ones cost them 3-5 % at 2^12 rows)
-    auto ld = [&](size_t o) {
-        const fz_v4i t = __builtin_nontemporal_load(reinterpret_cast<const fz_v4i *>(in + o));
-        return make_int4(t.x, t.y, t.z, t.w);
-    };
-    c.v0 = ld(base < total ? base : last);
-    c.v1 = ld(base + 256 < total ? base + 256 : last);
-    c.v2 = ld(base + 512 < total ? base + 512 : last);
-    c.v3 = ld(base + 768 < total ? base + 768 : last);
+    if ((task + 1) * kChunk <= total) {
+        const int32_t *b = in + task * kChunk;
+        c.v0 = nt_load4(b + 4 * lane);
+        c.v1 = nt_load4(b + 4 * lane + 256);
+        c.v2 = nt_load4(b + 4 * lane + 512);
+        c.v3 = nt_load4(b + 4 * lane + 768);
+    } else {
+        const size_t base = task * kChunk + 4 * lane;
+        const size_t last = total - 4;
+        c.v0 = nt_load4(in + (base < total ? base : last));
+        c.v1 = nt_load4(in + (base + 256 < total ? base + 256 : last));
+        c.v2 = nt_load4(in + (base + 512 < total ? base + 512 : last));
+        c.v3 = nt_load4(in + (base + 768 < total ? base + 768 : last));
+    }
     return c;
 }
 
@@ -101,6 +113,24 @@ __device__ __forceinline__ void nt_store4(int32_t *p, const int4 &v) {
     __builtin_nontemporal_store(t, reinterpret_cast<fz_v4i *>(p));
 }
 
+// the task's 4 coalesced 16-byte stores (same scalar split as chunk_load: only a ragged last chunk predicates its lanes)
+__device__ __forceinline__ void chunk_store(int32_t *out, size_t task, size_t total, int lane, const int4 &o0, const int4 &o1,
+                                            const int4 &o2, const int4 &o3) {
+    if ((task + 1) * kChunk <= total) {
+        int32_t *b = out + task * kChunk;
+        nt_store4(b + 4 * lane, o0);
+        nt_store4(b + 4 * lane + 256, o1);
+        nt_store4(b + 4 * lane + 512, o2);
+        nt_store4(b + 4 * lane + 768, o3);
+    } else {
+        const size_t base = task * kChunk + 4 * lane;
+        if (base < total) nt_store4(out + base, o0);
+        if (base + 256 < total) nt_store4(out + base + 256, o1);
+        if (base + 512 < total) nt_store4(out + base + 512, o2);
+        if (base + 768 < total) nt_store4(out + base + 768, o3);
+    }
+}
+
 // one twiddle multiply: 4-op pseudo-Mersenne form when FAST (operand bound |a| <= 2^38), else 6-op
 template <bool FAST>
 __device__ __forceinline__ double tw_mul(double a, double w, double w2, const FzMod m) {
@@ -129,16 +159,19 @@ __device__ __forceinline__ void fwd16_run(const int32_t *in, int32_t *out, size_
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
     const int p = lane / L, r = lane % L;
+    const size_t total = batch * D;
+    const size_t tasks = (total + kChunk - 1) / kChunk;
+    const size_t first = (size_t)block * kWavesPerBlock + wave;
+    const size_t stride = (size_t)nblocks * kWavesPerBlock;
+    // the wave's first chunk is requested BEFORE the twiddle table is staged: two memory latencies overlapped instead of added (a
+    // launch of 2^16 rows is four iterations per wave: a microsecond of start-up is 4 % of it)
+    Chunk raw0 = {};
+    if (first < tasks) raw0 = chunk_load(in, first, total, lane);
     for (int i = threadIdx.x; i < NE * L; i += 64 * kWavesPerBlock) s_tw[i] = twB[i];
     __syncthreads();                                      // the only workgroup-wide barrier
     double *region = lds + wave * REGION;
     int32_t *stage = reinterpret_cast<int32_t *>(region);
     double *row = region + p * PS;
-
-    const size_t total = batch * D;
-    const size_t tasks = (total + kChunk - 1) / kChunk;
-    const size_t first = (size_t)block * kWavesPerBlock + wave;
-    const size_t stride = (size_t)nblocks * kWavesPerBlock;
     if (first >= tasks) return;
     // Software pipeline.  gfx9 has ONE in-order counter (vmcnt) for loads and stores, so a wait for a
     // prefetched load also waits for every store issued before... and, at a loop header, the compiler must
@@ -146,17 +179,16 @@ __device__ __forceinline__ void fwd16_run(const int32_t *in, int32_t *out, size_
     // first, (2) computes, (3) moves the finished outputs LDS -> registers, (4) waits for the prefetched
     // chunk and stages it into LDS, and only then (5) issues the global stores: the stores are always the
     // youngest outstanding operations and nothing waits for their completion until a whole iteration later.
-    {
-        const Chunk raw0 = chunk_load(in, first, total, lane);
-        chunk_to_lds(stage, lane, raw0);
-    }
+    chunk_to_lds(stage, lane, raw0);
 
-    for (size_t task = first; task < tasks; task += stride) {
-        // the next chunk's loads, if there is one (wave-uniform: `task` is scalar).  Rounds 1-4 issued them unconditionally and
-        // re-loaded the CURRENT chunk on a wave's last iteration: nothing at 64 iterations per wave (2^20 rows: +1.3 % read
-        // traffic), a quarter more read requests at the four iterations of a multi-job launch -- the PMC pass over round 5's
-        // headline read 78.2 MB per launch where 64 MiB are due (streaming loads: the re-read misses).
-        const bool more = task + stride < tasks;
+    // One iteration; MORE = another chunk of this wave follows (its loads are issued first).  The loop runs the MORE form and
+    // the wave's last chunk is peeled off as the other: rounds 1-4 issued the loads unconditionally and re-loaded the CURRENT
+    // chunk on a wave's last iteration (a quarter more read requests at the four iterations of a multi-job launch: the PMC pass
+    // over round 5's headline read 78.2 MB per launch where 64 MiB are due), and a run-time `if (more)` around loads and staging
+    // made the compiler wait for ALL memory operations -- the previous iteration's stores -- at the loop header (two
+    // branches on one condition are two paths to its wait-count pass): 3-8 % on the stand-alone kernels.
+    auto iteration = [&](const size_t task, auto more_tag) __attribute__((always_inline)) {
+        constexpr bool more = decltype(more_tag)::value;
         Chunk raw = {};
         if (more) raw = chunk_load(in, task + stride, total, lane);
         wave_sync();
@@ -234,14 +266,11 @@ __device__ __forceinline__ void fwd16_run(const int32_t *in, int32_t *out, size_
         const int4 o3 = *reinterpret_cast<const int4 *>(stage + pad4(768 + 4 * lane));
         wave_sync();
         if (more) chunk_to_lds(stage, lane, raw);   // waits for the prefetched loads (no store is younger)
-        {
-            const size_t base = task * kChunk + 4 * lane;
-            if (base < total) nt_store4(out + base, o0);
-            if (base + 256 < total) nt_store4(out + base + 256, o1);
-            if (base + 512 < total) nt_store4(out + base + 512, o2);
-            if (base + 768 < total) nt_store4(out + base + 768, o3);
-        }
-    }
+        chunk_store(out, task, total, lane, o0, o1, o2, o3);
+    };
+    size_t task = first;
+    for (; task + stride < tasks; task += stride) iteration(task, std::true_type());
+    iteration(task, std::false_type());
 }
 
 template <int LOGD, bool FAST>
@@ -264,24 +293,22 @@ __device__ __forceinline__ void inv16_run(const int32_t *in, int32_t *out, size_
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // the wave index is uniform: say so (scalar address arithmetic)
     const int p = lane / L, r = lane % L;
+    const size_t total = batch * D;
+    const size_t tasks = (total + kChunk - 1) / kChunk;
+    const size_t first = (size_t)block * kWavesPerBlock + wave;
+    const size_t stride = (size_t)nblocks * kWavesPerBlock;
+    Chunk raw0 = {};
+    if (first < tasks) raw0 = chunk_load(in, first, total, lane);      // before the table: see fwd16_run
     for (int i = threadIdx.x; i < NE * L; i += 64 * kWavesPerBlock) s_tw[i] = itwB[i];
     __syncthreads();
     double *region = lds + wave * REGION;
     int32_t *stage = reinterpret_cast<int32_t *>(region);
     double *row = region + p * PS;
-
-    const size_t total = batch * D;
-    const size_t tasks = (total + kChunk - 1) / kChunk;
-    const size_t first = (size_t)block * kWavesPerBlock + wave;
-    const size_t stride = (size_t)nblocks * kWavesPerBlock;
     if (first >= tasks) return;
-    {
-        const Chunk raw0 = chunk_load(in, first, total, lane);
-        chunk_to_lds(stage, lane, raw0);
-    }
+    chunk_to_lds(stage, lane, raw0);
 
-    for (size_t task = first; task < tasks; task += stride) {       // pipeline: see fwd16_run
-        const bool more = task + stride < tasks;
+    auto iteration = [&](const size_t task, auto more_tag) __attribute__((always_inline)) {       // pipeline and peeling: see fwd16_run
+        constexpr bool more = decltype(more_tag)::value;
         Chunk raw = {};
         if (more) raw = chunk_load(in, task + stride, total, lane);
         wave_sync();
@@ -357,14 +384,11 @@ __device__ __forceinline__ void inv16_run(const int32_t *in, int32_t *out, size_
         const int4 o3 = *reinterpret_cast<const int4 *>(stage + pad4(768 + 4 * lane));
         wave_sync();
         if (more) chunk_to_lds(stage, lane, raw);
-        {
-            const size_t base = task * kChunk + 4 * lane;
-            if (base < total) nt_store4(out + base, o0);
-            if (base + 256 < total) nt_store4(out + base + 256, o1);
-            if (base + 512 < total) nt_store4(out + base + 512, o2);
-            if (base + 768 < total) nt_store4(out + base + 768, o3);
-        }
-    }
+        chunk_store(out, task, total, lane, o0, o1, o2, o3);
+    };
+    size_t task = first;
+    for (; task + stride < tasks; task += stride) iteration(task, std::true_type());
+    iteration(task, std::false_type());
 }
 
 template <int LOGD, bool FAST>

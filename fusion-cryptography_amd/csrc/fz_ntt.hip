@@ -922,7 +922,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             const int row = (task + r * kWavesPerBlock) * PPW + p;
             const int32_t *src = coef + (size_t)(row < l ? row : l - 1) * coef_row_stride + mm;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[r][k] = src[k * LP];
+            for (int k = 0; k < 4; ++k) x[r][k] = __builtin_nontemporal_load(src + k * LP);
         }
     };
 #pragma unroll
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                 const double y0 = fz_cent(a[r][0], m), y1 = fz_cent(a[r][1], m), y2 = fz_cent(a[r][2], m), y3 = fz_cent(a[r][3], m);
                 if (row < l) {
                     const int4 yi = make_int4((int)y0, (int)y1, (int)y2, (int)y3);
-                    *reinterpret_cast<int4 *>(sk_hat + (size_t)row * D + 4 * mm) = yi;
+                    nt_store4(sk_hat + (size_t)row * D + 4 * mm, yi);
                     if constexpr (IMAD) {
                         const int yv[4] = {yi.x, yi.y, yi.z, yi.w}, av[4] = {ak[r].x, ak[r].y, ak[r].z, ak[r].w};
 #pragma unroll

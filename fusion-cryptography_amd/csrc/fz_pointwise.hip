@@ -228,6 +228,12 @@ __global__ __launch_bounds__(kBlock) void matvec_scalar_kernel(const int32_t *A,
     }
 }
 
+typedef int fz_pw_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 ld_stream4(const int4 *p) {
+    const fz_pw_v4i t = __builtin_nontemporal_load(reinterpret_cast<const fz_pw_v4i *>(p));
+    return make_int4(t.x, t.y, t.z, t.w);
+}
+
 // sig[b][k][j] = cent(cent(L[b][k][j] * c[b][j]) + R[b][k][j]); sk_hat = [batch][2][l][degree]
 __global__ __launch_bounds__(kBlock) void sign_kernel(const int32_t *sk_hat, const int32_t *c_hat, int32_t *sig,
                                                       size_t batch, int l, int degree, FzMod m) {
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void sign_kernel(const int32_t *sk_hat, con
         const int j4 = (int)(rem % d4);
         const int4 *Lp = reinterpret_cast<const int4 *>(sk_hat + b * 2 * (size_t)l * degree);
         const int4 *Rp = Lp + per_sig;
-        int4 x = Lp[rem], y = Rp[rem];
+        const int4 x = ld_stream4(Lp + rem), y = ld_stream4(Rp + rem);      // the key halves are read once
         int4 c = reinterpret_cast<const int4 *>(c_hat + b * (size_t)degree)[j4];
         int4 o;
         o.x = cent_i32(fz_mulmod((double)x.x, (double)c.x, m) + (double)y.x, m);

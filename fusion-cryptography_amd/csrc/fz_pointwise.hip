@@ -395,55 +395,80 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
             }
         };
         const size_t first = i0 + wave;
-#pragma unroll
-        for (int s = 0; s < DEPTH; ++s)
-            if (first + (size_t)s * WAVES < i1) load(s, first + (size_t)s * WAVES);       // wave-uniform
         int since = 0;
-        for (size_t i = first; i < i1; i += (size_t)DEPTH * WAVES) {
+        // one signer from slot s: alpha split, (SIGN: the signature made and stored,) the AR x 4 products accumulated
+        auto consume = [&](int s, size_t is) __attribute__((always_inline)) {
+            const int av[4] = {a_q[s].x, a_q[s].y, a_q[s].z, a_q[s].w};
+            double ah[4], al[4];
 #pragma unroll
-            for (int s = 0; s < DEPTH; ++s) {
-                const size_t is = i + (size_t)s * WAVES;
-                if (is >= i1) break;
-                const int av[4] = {a_q[s].x, a_q[s].y, a_q[s].z, a_q[s].w};
-                double ah[4], al[4];
+            for (int k = 0; k < 4; ++k) {
+                ah[k] = (double)(av[k] >> 16);
+                al[k] = (double)(av[k] & 0xffff);
+            }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    ah[k] = (double)(av[k] >> 16);
-                    al[k] = (double)(av[k] & 0xffff);
-                }
-#pragma unroll
-                for (int r = 0; r < AR; ++r) {
-                    double xv[4] = {(double)x_q[s][r].x, (double)x_q[s][r].y, (double)x_q[s][r].z, (double)x_q[s][r].w};
-                    if constexpr (SIGN) {                 // sigma = cent(cent(L * c) + R), exactly sign_kernel's arithmetic
-                        const double cv[4] = {(double)c_q[s].x, (double)c_q[s].y, (double)c_q[s].z, (double)c_q[s].w};
-                        const double rv[4] = {(double)r_q[s][r].x, (double)r_q[s][r].y, (double)r_q[s][r].z, (double)r_q[s][r].w};
-                        int sv[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            sv[k] = cent_i32(fz_mulmod(xv[k], cv[k], m) + rv[k], m);
-                            xv[k] = (double)sv[k];
-                        }
-                        if (live[r]) so4[is * cols_a + col[r]] = make_int4(sv[0], sv[1], sv[2], sv[3]);
-                    }
+            for (int r = 0; r < AR; ++r) {
+                double xv[4] = {(double)x_q[s][r].x, (double)x_q[s][r].y, (double)x_q[s][r].z, (double)x_q[s][r].w};
+                if constexpr (SIGN) {                 // sigma = cent(cent(L * c) + R), exactly sign_kernel's arithmetic
+                    const double cv[4] = {(double)c_q[s].x, (double)c_q[s].y, (double)c_q[s].z, (double)c_q[s].w};
+                    const double rv[4] = {(double)r_q[s][r].x, (double)r_q[s][r].y, (double)r_q[s][r].z, (double)r_q[s][r].w};
+                    int sv[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        hi[r][k] = __builtin_fma(xv[k], ah[k], hi[r][k]);
-                        lo[r][k] = __builtin_fma(xv[k], al[k], lo[r][k]);
+                        sv[k] = cent_i32(fz_mulmod(xv[k], cv[k], m) + rv[k], m);
+                        xv[k] = (double)sv[k];
                     }
+                    if (live[r]) so4[is * cols_a + col[r]] = make_int4(sv[0], sv[1], sv[2], sv[3]);
                 }
-                const size_t in = is + (size_t)DEPTH * WAVES;
-                if (in < i1) load(s, in);                 // refill this slot: the loads stay DEPTH signers ahead
-                if (++since == kAggFold) {
-                    since = 0;
 #pragma unroll
-                    for (int r = 0; r < AR; ++r)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            lo[r][k] = fz_fold(lo[r][k], m) + fz_fold(hi[r][k] * 65536.0, m);
-                            hi[r][k] = 0.0;
-                        }
+                for (int k = 0; k < 4; ++k) {
+                    hi[r][k] = __builtin_fma(xv[k], ah[k], hi[r][k]);
+                    lo[r][k] = __builtin_fma(xv[k], al[k], lo[r][k]);
                 }
             }
+            if (++since == kAggFold) {
+                since = 0;
+#pragma unroll
+                for (int r = 0; r < AR; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lo[r][k] = fz_fold(lo[r][k], m) + fz_fold(hi[r][k] * 65536.0, m);
+                        hi[r][k] = 0.0;
+                    }
+            }
+        };
+        // The wave's signers first, first + WAVES, ... in a rolling window of DEPTH slots.  The loop that carries the bulk has NO
+        // condition around its loads: gfx9 counts outstanding loads in ONE in-order counter, and the compiler, which must assume
+        // the fewest loads any path may have issued, answered a run-time `if (next < i1) load(...)` with a wait for ALL loads at
+        // the loop header -- the window drained once per DEPTH signers (one whole memory latency each time; rounds 3-4).
+        // Steady loop: every slot full, every refill valid.  Then ONE pass whose refills may run out, then the drain.
+        size_t i = first;
+        if (first + (size_t)(DEPTH - 1) * WAVES < i1) {                          // wave-uniform: at least DEPTH signers
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) load(s, first + (size_t)s * WAVES);
+            for (; i + (size_t)(2 * DEPTH - 1) * WAVES < i1; i += (size_t)DEPTH * WAVES) {
+#pragma unroll
+                for (int s = 0; s < DEPTH; ++s) {
+                    const size_t is = i + (size_t)s * WAVES;
+                    consume(s, is);
+                    load(s, is + (size_t)DEPTH * WAVES);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                const size_t is = i + (size_t)s * WAVES, in = is + (size_t)DEPTH * WAVES;
+                consume(s, is);
+                if (in < i1) load(s, in);
+            }
+            i += (size_t)DEPTH * WAVES;
+        } else {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s)
+                if (first + (size_t)s * WAVES < i1) load(s, first + (size_t)s * WAVES);
+        }
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {                                        // the drain: fewer than DEPTH signers are left
+            const size_t is = i + (size_t)s * WAVES;
+            if (is < i1) consume(s, is);
         }
 #pragma unroll
         for (int r = 0; r < AR; ++r)

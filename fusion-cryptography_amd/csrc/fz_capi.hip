@@ -335,11 +335,12 @@ static int ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint
         auto knob = [](const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; };
         c->force_kernel = knob("FZ_NTT_KERNEL");
         c->knob_ntt_rows = knob("FZ_NTT_ROWS");
-        // measured crossover, inputs NOT cache-resident, both schedules on one box (profiles/r03_ntt_crossover.txt): degree 256 --
-        // the radix-4 kernels lead up to 2^15 rows (4.19 / 5.50 / 8.44 / 15.35 us at 2^12 .. 2^15 against 4.92 / 6.36 / 9.17 /
-        // 15.86 for the 16-per-lane kernel), the 16-per-lane kernel from 2^16 (28.2 us against 32.3); degree 64 -- radix-4 up to
-        // 2^18 rows (round 2's measurement)
-        c->small_batch_rows = degree == 256 ? (1 << 16) : (1 << 19);
+        // measured crossover, inputs NOT cache-resident, both schedules on one box: degree 256 -- the radix-4 kernels lead up to
+        // 2^14 rows (4.23 / 5.58 / 8.47 us at 2^12 .. 2^14 against 4.97 / 6.53 / 9.10 for the 16-per-lane kernel), the 16-per-lane
+        // kernel from 24 576 rows (6 x 4096: 13.7 us against 14.2; 2^15: 14.6 against 15.6) -- round 5's kernel, whose start-up
+        // overlaps the first chunk with the twiddle table (profiles/r05_ntt_crossover.txt; rounds 3-4: from 2^16);
+        // degree 64 -- radix-4 up to 2^18 rows (round 2's measurement)
+        c->small_batch_rows = degree == 256 ? (3 << 13) : (1 << 19);
         c->knob_agg_direct = knob("FZ_AGG_DIRECT");
         c->knob_shake_full = knob("FZ_SHAKE_FORM");
         c->knob_verify_ordered = knob("FZ_VERIFY_ORDERED");

@@ -786,9 +786,9 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_jobs4(JT J, const double2 *__r
     }
 }
 
-// The same job table served by the 16-per-lane kernels (round 5): a launch of 2^16 rows and more -- the headline's eight
-// forward + eight inverse batches of 4096 -- is past the point where the radix-4 wave-tasks lead (one job: 25.5 us against
-// 30 us at 65 536 rows).  A job owns a run of workgroups; the run IS a grid of ntt_fwd16 or ntt_inv16 over the job's batch
+// The same job table served by the 16-per-lane kernels (round 5): a launch of 24 576 rows and more (fz_ctx::small_batch_rows)
+// -- the headline's eight forward + eight inverse batches of 4096 -- is past the point where the radix-4 wave-tasks lead
+// (one job: 25.5 us against 30 us at 65 536 rows; eight jobs of 4096: 15.9 us against 17.2).  A job owns a run of workgroups; the run IS a grid of ntt_fwd16 or ntt_inv16 over the job's batch
 // (resident workgroups striding over 4 KiB chunks, next chunk prefetched into registers), sized by the launcher in
 // proportion to the job's share of the launch.
 template <int LOGD, bool FAST, typename JT>

@@ -1066,7 +1066,7 @@ constexpr int kVerifyWaves = 4;
 template <typename T> struct Raw4;
 template <> struct Raw4<int32_t> {
     int4 v;
-    __device__ __forceinline__ void load(const int32_t *p) { v = *reinterpret_cast<const int4 *>(p); }
+    __device__ __forceinline__ void load(const int32_t *p) { v = nt_load4(p); }      // an aggregate's rows are read once
     __device__ __forceinline__ void unpack(double (&a)[4], const FzMod &) const {
         a[0] = (double)v.x; a[1] = (double)v.y; a[2] = (double)v.z; a[3] = (double)v.w;
     }

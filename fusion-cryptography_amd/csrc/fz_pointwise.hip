@@ -33,6 +33,13 @@ __device__ __forceinline__ int pw_op(int a, int b, int acc, const FzMod m) {
     return cent_i32((double)acc + fz_mulmod((double)a, (double)b, m), m);
 }
 
+// streaming (non-temporal) 16-byte load: operands a kernel reads exactly once
+typedef int fz_pw_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 ld_stream4(const int4 *p) {
+    const fz_pw_v4i t = __builtin_nontemporal_load(reinterpret_cast<const fz_pw_v4i *>(p));
+    return make_int4(t.x, t.y, t.z, t.w);
+}
+
 template <int OP>
 __global__ __launch_bounds__(kBlock) void pw_kernel(const int32_t *a, const int32_t *b, int32_t *out,
                                                     size_t count, int vec, FzMod m) {
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(KS <= 4 ? 256 : 64 * KS) void matvec_sliced_kernel(
         for (int u = 0; u < U; ++u) {
             const int kk = k + u < k1 ? k + u : k1 - 1;
             x[u] = Ap[(size_t)kk * d4];
-            y[u] = Sp[(size_t)kk * d4];
+            y[u] = ld_stream4(Sp + (size_t)kk * d4);        // the vectors are read once (A is every product's: from the L2)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -226,12 +233,6 @@ __global__ __launch_bounds__(kBlock) void matvec_scalar_kernel(const int32_t *A,
             s += fz_mulmod((double)A[(size_t)k * degree + j], (double)S[(b * l + k) * (size_t)degree + j], m);
         out[i] = cent_i32(s, m);
     }
-}
-
-typedef int fz_pw_v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ int4 ld_stream4(const int4 *p) {
-    const fz_pw_v4i t = __builtin_nontemporal_load(reinterpret_cast<const fz_pw_v4i *>(p));
-    return make_int4(t.x, t.y, t.z, t.w);
 }
 
 // sig[b][k][j] = cent(cent(L[b][k][j] * c[b][j]) + R[b][k][j]); sk_hat = [batch][2][l][degree]
@@ -386,12 +387,12 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
                 c_q[s] = c4[i * d4 + j4];
 #pragma unroll
                 for (int r = 0; r < AR; ++r) {
-                    x_q[s][r] = sk4[i * 2 * cols_a + col[r]];                  // L
-                    r_q[s][r] = sk4[(i * 2 + 1) * cols_a + col[r]];            // R
+                    x_q[s][r] = ld_stream4(sk4 + i * 2 * cols_a + col[r]);                  // L
+                    r_q[s][r] = ld_stream4(sk4 + (i * 2 + 1) * cols_a + col[r]);            // R
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < AR; ++r) x_q[s][r] = sig4[i * cols_a + col[r]];
+                for (int r = 0; r < AR; ++r) x_q[s][r] = ld_stream4(sig4 + i * cols_a + col[r]);      // read once (alpha: by every column block)
             }
         };
         const size_t first = i0 + wave;
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_direct(const int32_t *si
         auto load = [&](int s, size_t i) {
             a_q[s] = alpha4[i * d4];
 #pragma unroll
-            for (int r = 0; r < R; ++r) x_q[s][r] = sig4[i * cols_a + rowoff[r]];
+            for (int r = 0; r < R; ++r) x_q[s][r] = ld_stream4(sig4 + i * cols_a + rowoff[r]);
         };
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s)

@@ -19,7 +19,7 @@ step() { echo "[collect] $*" >&2; "$@" || { echo "[collect] FAILED ($?): $*" >&2
 lscpu | grep -E "Model name|Socket|Thread|Core" > $OUT/${TAG}_host_cpu.txt
 # the stand-alone microbenchmarks travel prebuilt (tools/microbench/build/, git-ignored); build whatever is missing
 mkdir -p tools/microbench/build
-for mb in launch_floor ntt_variants ntt_structures access_pattern; do
+for mb in launch_floor ntt_variants ntt_structures access_pattern mixed_ceiling; do
   [ -x tools/microbench/build/$mb ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/microbench/$mb.hip -o tools/microbench/build/$mb
 done
 step timeout -k 10 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
@@ -40,6 +40,12 @@ step timeout -k 10 200 python tools/probes/keccak_bench.py > $OUT/${TAG}_keccak_
 step timeout -k 10 300 ./tools/microbench/build/ntt_variants 300 > $OUT/${TAG}_ntt_variants_current_kernels.txt 2>&1
 step timeout -k 10 120 ./tools/microbench/build/ntt_structures 200 > $OUT/${TAG}_ntt_structures.txt 2>&1
 step timeout -k 10 120 ./tools/microbench/build/access_pattern 100 > $OUT/${TAG}_access_pattern.txt 2>&1
+# what a streaming kernel with the transforms' memory schedule sustains while the fp64 pipes are busy: the transforms' ceiling
+step timeout -k 10 120 ./tools/microbench/build/mixed_ceiling 18 20 > $OUT/${TAG}_mixed_ceiling_2p18.txt 2>&1
+step timeout -k 10 120 ./tools/microbench/build/mixed_ceiling 16 100 > $OUT/${TAG}_mixed_ceiling_2p16.txt 2>&1
+# the transform schedules' crossover: the same probe with each kernel forced, and as the library chooses
+for k in 0 4 16; do echo "FZ_NTT_KERNEL=$k" >> $OUT/${TAG}_ntt_crossover.txt; FZ_NTT_KERNEL=$k timeout -k 10 200 python tools/probes/ntt_ab.py 2>&1 | grep -v amdgpu >> $OUT/${TAG}_ntt_crossover.txt; done
+step timeout -k 10 100 python tools/probes/keygen_sign_pair.py > $OUT/${TAG}_keygen_sign_pair.txt 2>&1
 step timeout -k 10 200 python tools/probes/clock_under_load.py > $OUT/${TAG}_shader_clock_under_load.txt 2>&1
 step timeout -k 10 200 python tools/probes/clock_under_load.py --secpar 128 >> $OUT/${TAG}_shader_clock_under_load.txt 2>&1
 step timeout -k 10 600 bash tools/probes/matvec_ab.sh > $OUT/${TAG}_matvec_ab_raw.txt 2>&1
@@ -81,8 +87,12 @@ done
 # where the waves' cycles go (issue, stalls, LDS): two SQ counter sets over the cold scheme kernels
 step timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/sq1 -- python3 $R/tools/probes/prof_scheme.py 6 > $OUT/sq1.log 2>&1
 step timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq2 -- python3 $R/tools/probes/prof_scheme.py 6 > $OUT/sq2.log 2>&1
+# ... and over the 16-per-lane transforms at 2^20 rows
+step timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/sqa -- python3 $R/tools/probes/prof_ntt.py 20 6 > $OUT/sqa.log 2>&1
+step timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/sqb -- python3 $R/tools/probes/prof_ntt.py 20 6 > $OUT/sqb.log 2>&1
 cd $R
 python3 tools/probes/pmc_stalls.py $OUT/sq1/*/*counter_collection.csv $OUT/sq2/*/*counter_collection.csv > $OUT/${TAG}_wave_cycles.txt
+python3 tools/probes/pmc_stalls.py $OUT/sqa/*/*counter_collection.csv $OUT/sqb/*/*counter_collection.csv > $OUT/${TAG}_ntt_wave_cycles.txt
 python3 tools/trace_summary.py $OUT/prof/*/*_kernel_trace.csv > $OUT/${TAG}_bench_rocprofv3_by_grid.csv 2>/dev/null
 python3 tools/trace_summary.py $OUT/prof2/*/*_kernel_trace.csv > $OUT/${TAG}_bench_2streams_rocprofv3_by_grid.csv 2>/dev/null
 python3 tools/trace_summary.py $OUT/profd/*/*_kernel_trace.csv > $OUT/${TAG}_bench_default_rocprofv3_by_grid.csv 2>/dev/null

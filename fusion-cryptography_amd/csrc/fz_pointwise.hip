@@ -39,6 +39,10 @@ __device__ __forceinline__ int4 ld_stream4(const int4 *p) {
     const fz_pw_v4i t = __builtin_nontemporal_load(reinterpret_cast<const fz_pw_v4i *>(p));
     return make_int4(t.x, t.y, t.z, t.w);
 }
+__device__ __forceinline__ void st_stream4(int4 *p, const int4 &v) {
+    const fz_pw_v4i t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<fz_pw_v4i *>(p));
+}
 
 template <int OP>
 __global__ __launch_bounds__(kBlock) void pw_kernel(const int32_t *a, const int32_t *b, int32_t *out,
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_onepass(const int32_t *s
                         sv[k] = cent_i32(fz_mulmod(xv[k], cv[k], m) + rv[k], m);
                         xv[k] = (double)sv[k];
                     }
-                    if (live[r]) so4[is * cols_a + col[r]] = make_int4(sv[0], sv[1], sv[2], sv[3]);
+                    if (live[r]) st_stream4(so4 + is * cols_a + col[r], make_int4(sv[0], sv[1], sv[2], sv[3]));     // never read back here
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {

@@ -51,8 +51,20 @@ def pair(i):
     sg(i)
 
 
+alpha = DB(ctx, S * row)
+ctx.fill_synthetic_dev(alpha.ptr, S * d, 300)
+agg_out = DB(ctx, l * row)
+ag = lambda i: ctx.aggregate_core_dev(sets[i % NSETS]["sig"].ptr, alpha.ptr, agg_out.ptr, S, l)
+
+
+def sign_then_aggregate(i):
+    sg(i)
+    ag(i)
+
+
 if len(sys.argv) > 2 and sys.argv[2] == "pair":
     print(f"secpar {secpar}: keygen + sign chained {timed(pair):7.2f} us per pair")
     sys.exit(0)
+print(f"secpar {secpar}: aggregate alone {timed(ag):7.2f} us   sign + aggregate chained {timed(sign_then_aggregate):7.2f} us per pair")
 print(f"secpar {secpar}: keygen alone {timed(kg):7.2f} us   sign alone {timed(sg):7.2f} us   keygen + sign chained {timed(pair):7.2f} us per pair "
       f"({fusion_hip.runtime_report().get('library', '')})")

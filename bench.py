@@ -5,9 +5,9 @@ Workload (BASELINE.json configs[1]): secpar=256, batches of 4096 independent deg
 A STEP is one pass of the hot path over one batch: forward NTT of the batch, then inverse NTT of the result (reference
 algebra/ntt.py:216-291 and :294-377).  Consecutive steps work on consecutive batches of a rotation of NBATCH batches
 (x_i -> y_i -> z_i, 768 MiB together), so every forward transform reads its input from HBM, not from a cache: `value` is an
-HBM number.  The steps are SOFTWARE-PIPELINED over D batches (--depth, 8): batches are independent, the forward transforms
+HBM number.  The steps are SOFTWARE-PIPELINED over D batches (--depth, 16: the job table's 32 entries): batches are independent, the forward transforms
 of batches i+1 .. i+D and the inverse transforms of batches i-D+1 .. i share ONE launch (fz_ntt_multi: a table of 2 D jobs in
-the kernel arguments = 2 D x 4096 transforms = D x 16 MiB of algorithmic bytes per launch: 128 MiB at D = 8); D steps are one
+the kernel arguments = 2 D x 4096 transforms = D x 16 MiB of algorithmic bytes per launch: 256 MiB at D = 16); D steps are one
 launch, a run of steps opens with a forward-only launch and closes with an inverse-only one, and every transform of every
 batch is done exactly once (z == x is checked after every region).  `--depth 1` is round 4's form (one forward + one inverse
 job per launch), `--two-launch` the un-pipelined one (fz_ntt_forward, then fz_ntt_inverse: two launches of 8 MiB per step;
@@ -89,7 +89,7 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams (a context each) that walk disjoint shares of the rotating batches side by side: launches of "
                          "different streams overlap on the chip (1: one launch in flight at a time)")
-    ap.add_argument("--depth", type=int, default=8,
+    ap.add_argument("--depth", type=int, default=16,
                     help="batches per launch of the software pipeline: D forward jobs (batches i+1..i+D) + D inverse jobs (batches "
                          "i-D+1..i) in one fz_ntt_multi dispatch = D x 16 MiB of algorithmic bytes (1: round 4's two-job launch)")
     ap.add_argument("--no-stamps", action="store_true", help="skip the device-timestamp pass (roofline.chip.device_clock)")

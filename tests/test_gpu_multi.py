@@ -70,7 +70,7 @@ def test_ntt_multi_ragged_mixed_jobs_match_the_oracle(secpar, kernel, coracle, m
 
 
 @pytest.mark.parametrize("kernel", ["auto", "4", "16"])
-@pytest.mark.parametrize("depth", [1, 3, 4, 8])
+@pytest.mark.parametrize("depth", [1, 3, 4, 8, 16])
 def test_ntt_multi_in_the_headline_shape_with_device_timestamps(depth, kernel, coracle, monkeypatch):
     """bench.py's launch: the forward transforms of `depth` batches of 4096 rows and the inverse transforms of `depth` other
     batches in ONE dispatch (2 x depth jobs: the 4-, 8- and 32-entry tables; 65 536 rows take the 16-per-lane form on their

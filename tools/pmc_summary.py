@@ -68,6 +68,11 @@ for sub, (label, rows) in GROUPS.items():
             rows_k = (grid.get(k, 0) // 64) * int(m4.group(2)) if m4 and grid.get(k) else rows
             if is_bench:
                 rows_k = BENCH["rows"]
+            elif sub == "pmcb" and k.startswith("ntt_jobs16"):
+                # a pipelined run's first (forward jobs only) and last (inverse jobs only) launch: half the jobs through the same
+                # resident grid -- another table size, another instantiation; read off its own written bytes (4 B per coefficient)
+                rows_k = int(round(e["write_bytes"] / 1024 / 4096)) * 4096          # jobs of 4096 rows
+                e["what"] = "boundary launch of a pipelined run (half the jobs); rows from the bytes written"
             e["rows_per_launch"] = rows_k
             e["algorithmic_bytes_per_launch"] = rows_k * 2048
             e["traffic_over_algorithmic"] = e["traffic_bytes_per_launch"] / e["algorithmic_bytes_per_launch"]

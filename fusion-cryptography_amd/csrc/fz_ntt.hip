@@ -787,10 +787,10 @@ __global__ __launch_bounds__(64 * WAVES) void ntt_jobs4(JT J, const double2 *__r
 }
 
 // The same job table served by the 16-per-lane kernels (round 5): a launch of 24 576 rows and more (fz_ctx::small_batch_rows)
-// -- the headline's eight forward + eight inverse batches of 4096 -- is past the point where the radix-4 wave-tasks lead
-// (one job: 25.5 us against 30 us at 65 536 rows; eight jobs of 4096: 15.9 us against 17.2).  A job owns a run of workgroups; the run IS a grid of ntt_fwd16 or ntt_inv16 over the job's batch
-// (resident workgroups striding over 4 KiB chunks, next chunk prefetched into registers), sized by the launcher in
-// proportion to the job's share of the launch.
+// -- the headline's sixteen forward + sixteen inverse batches of 4096 -- is past the point where the radix-4 wave-tasks lead
+// (one job: 25.5 us against 30 us at 65 536 rows; eight jobs of 4096: 15.9 us against 17.2).  A job owns a run of workgroups;
+// the run IS a grid of ntt_fwd16 or ntt_inv16 over the job's batch (resident workgroups striding over 4 KiB chunks, next
+// chunk prefetched into registers), sized by the launcher in proportion to the job's share of the launch.
 template <int LOGD, bool FAST, typename JT>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void ntt_jobs16(JT J, const double2 *__restrict__ twB, const double2 *__restrict__ itwB,
                                                                   FzTwA twA, FzTwA itwA, FzMod m, unsigned long long *stamp) {
@@ -890,6 +890,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
 // One row group per wave iteration, rows requested one iteration ahead, per-lane twiddles as (w, w * K/q) pairs: round 3 measured
 // two row groups, a second iteration of prefetch and twiddles kept as w alone (five waves per SIMD) -- 81.7 / 81.7 / 82.0 / 81.1
 // and 79.2 / 77.7 us per 1024 keys, all within 2 % (profiles/r03_keygen_ab.txt) -- and round 4 removed those instantiations.
+// Round 5: the secret rows (read once) by streaming loads, sk_hat (never read here) by streaming stores: 81.3 -> 77.6 us alone,
+// keygen + sign chained 119.4 -> 112.1 us per 1024 keys.  The `if`s around the next rows' request and around the store make the
+// compiler's wait before the store a wait for ALL outstanding operations (one in-order counter); the form with exact wait
+// counts (everything unconditional, rows clamped) is 4-5 % faster alone and 2-6 % SLOWER between two sign launches, the
+// scheme's order -- measured on three boxes and dropped (profiles/r05_keygen_exact_waits_experiment.txt).
 template <int LOGD, bool FAST, bool IMAD>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 6))) void keygen_fused(const int32_t *A, const int32_t *coef,
                                                                     size_t coef_seg_stride,

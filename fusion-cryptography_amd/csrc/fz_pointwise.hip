@@ -644,40 +644,43 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_direct(const int32_t *si
         }
         const int4 *sig4 = reinterpret_cast<const int4 *>(sig) + first_row * cols_a;
         int4 a_q[DEPTH], x_q[DEPTH][R];
-        auto load = [&](int s, size_t i) {
-            a_q[s] = alpha4[i * d4];
+        // Rounds of STEP signers (a lane group takes signer `sub` of its wave's share of the round).  The round count is
+        // wave-uniform; a lane whose signer of a round does not exist requests the aggregate's LAST signer instead and leaves it
+        // out of the sums.  Round 5: requests are issued by the whole wave on every path -- with the lane-dependent
+        // `if (i < n) load(...)` of round 4 the compiler could not count what is outstanding (one in-order counter for all
+        // loads) and waited for EVERYTHING before every signer: the DEPTH-deep window was drained at each step, a whole memory
+        // latency per round (N = 256: eight of them in a 9 us kernel).  Same scheme as aggregate_onepass: a steady loop whose
+        // refills all exist, one pass whose refills run out, the drain.
+        const size_t w0 = (size_t)wave * kDirSub;
+        const int rounds = n > w0 ? (int)((n - w0 + STEP - 1) / STEP) : 0;
+        auto load = [&](int s, int round) __attribute__((always_inline)) {
+            const size_t i = i_first + (size_t)round * STEP, ic = i < n ? i : n - 1;
+            a_q[s] = alpha4[ic * d4];
 #pragma unroll
-            for (int r = 0; r < R; ++r) x_q[s][r] = ld_stream4(sig4 + i * cols_a + rowoff[r]);
+            for (int r = 0; r < R; ++r) x_q[s][r] = ld_stream4(sig4 + ic * cols_a + rowoff[r]);
         };
+        auto consume = [&](int s, int round) __attribute__((always_inline)) {
+            if (i_first + (size_t)round * STEP < n) {
+                const int av[4] = {a_q[s].x, a_q[s].y, a_q[s].z, a_q[s].w};
+                double ah[4], al[4];
 #pragma unroll
-        for (int s = 0; s < DEPTH; ++s)
-            if (i_first + (size_t)s * STEP < n) load(s, i_first + (size_t)s * STEP);
-        int since = 0;
-        for (size_t i = i_first; i < n; i += (size_t)DEPTH * STEP) {
+                for (int k = 0; k < 4; ++k) {
+                    ah[k] = (double)(av[k] >> 16);
+                    al[k] = (double)(av[k] & 0xffff);
+                }
 #pragma unroll
-            for (int s = 0; s < DEPTH; ++s) {
-                const size_t is = i + (size_t)s * STEP;
-                if (is < n) {
-                    const int av[4] = {a_q[s].x, a_q[s].y, a_q[s].z, a_q[s].w};
-                    double ah[4], al[4];
+                for (int r = 0; r < R; ++r) {
+                    const double xv[4] = {(double)x_q[s][r].x, (double)x_q[s][r].y, (double)x_q[s][r].z, (double)x_q[s][r].w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        ah[k] = (double)(av[k] >> 16);
-                        al[k] = (double)(av[k] & 0xffff);
+                        hi[r][k] = __builtin_fma(xv[k], ah[k], hi[r][k]);
+                        lo[r][k] = __builtin_fma(xv[k], al[k], lo[r][k]);
                     }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const double xv[4] = {(double)x_q[s][r].x, (double)x_q[s][r].y, (double)x_q[s][r].z, (double)x_q[s][r].w};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            hi[r][k] = __builtin_fma(xv[k], ah[k], hi[r][k]);
-                            lo[r][k] = __builtin_fma(xv[k], al[k], lo[r][k]);
-                        }
-                    }
-                    const size_t in = is + (size_t)DEPTH * STEP;
-                    if (in < n) load(s, in);
                 }
             }
+        };
+        int since = 0;
+        auto fold_if_due = [&]() __attribute__((always_inline)) {
             since += DEPTH;
             if (since + DEPTH > kAggFold) {                        // lanes of a wave differ by at most one signer: fold together
                 since = 0;
@@ -689,7 +692,34 @@ __global__ __launch_bounds__(64 * WAVES) void aggregate_direct(const int32_t *si
                         hi[r][k] = 0.0;
                     }
             }
+        };
+        int k0 = 0;
+        if (rounds >= DEPTH) {                                       // wave-uniform
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) load(s, s);
+            for (; k0 + 2 * DEPTH - 1 < rounds; k0 += DEPTH) {
+#pragma unroll
+                for (int s = 0; s < DEPTH; ++s) {
+                    consume(s, k0 + s);
+                    load(s, k0 + s + DEPTH);
+                }
+                fold_if_due();
+            }
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                consume(s, k0 + s);
+                if (k0 + s + DEPTH < rounds) load(s, k0 + s + DEPTH);
+            }
+            fold_if_due();
+            k0 += DEPTH;
+        } else {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s)
+                if (s < rounds) load(s, s);
         }
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s)                              // the drain: fewer than DEPTH rounds are left
+            if (k0 + s < rounds) consume(s, k0 + s);
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -1014,15 +1044,16 @@ int fz_launch_aggregate(fz_ctx *ctx, const int32_t *sig, const int32_t *alpha, i
         const int d4 = d / 4;
         const size_t cols_a = (size_t)l * d4;
         // Few signers in the whole launch: no signer slices, no shared accumulators (aggregate_direct).  Measured on cold
-        // operands (profiles/r04_aggregate_direct_ab.txt): one aggregate of 8 / 32 / 96 / 192 signers 3.5 / 4.0 / 5.1 / 7.5 us
-        // against 4.5 / 7.0 / 7.4 / 8.1 us for the sliced kernel, two of 64 / 128: 6.1 / 8.5 against 8.4 / 9.1; from ~256
-        // signers per launch, with three or more aggregates, or with the verification target in the same launch the sliced
-        // kernel leads (256 x 4 + targets: 20.7 us against 24.6).  FZ_AGG_DIRECT = -1: never; 2 | 4: always, with that many
-        // rows per tile (the tests force both forms through every output mode).
-        const bool direct_auto = !vkL && N <= 256 && groups * N <= 256;
+        // operands, both forms forced (profiles/r05_aggregate_direct_ab.txt; round 5, after the sliced kernel's streaming loads and
+        // this kernel's exact wait counts): one aggregate of 8 / 32 / 96 signers 3.4 / 3.9 / 5.0 us against 4.6 / 4.8 / 5.2 us for
+        // the sliced kernel, 128: 5.6 either way, 192 / 256: 6.7 / 8.0 against 6.3 / 7.8; two of 64: 5.6 against 5.8, two of
+        // 128: 8.1 against 7.3 -- so up to 128 signers per launch (round 4: 256); with the verification target in the same
+        // launch the sliced kernel leads throughout.  FZ_AGG_DIRECT = -1: never; 2 | 4: always, with that many rows per tile
+        // (the tests force both forms through every output mode).
+        const bool direct_auto = !vkL && groups * N <= 128;
         if (!sk_hat && d4 >= 16 && ctx->knob_agg_direct >= 0 && (ctx->knob_agg_direct > 0 || direct_auto) && groups <= 65535) {
             int R = ctx->knob_agg_direct;
-            if (R != 2 && R != 4) R = groups == 1 ? 2 : 4;          // rows of a tile share one alpha load; 168 / 84 tiles per aggregate at rank 83
+            if (R != 2 && R != 4) R = groups <= 2 ? 2 : 4;          // rows of a tile share one alpha load; 168 / 84 tiles per aggregate at rank 83
             const int ncg = d4 / 16;
             const int ntile_a = sig ? ((l + R - 1) / R) * ncg : 0;
             const int ntile = ntile_a + (vkL ? ncg : 0);

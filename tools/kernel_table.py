@@ -98,9 +98,9 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
     # aggregate (fusion.py:670-676): sig [N][l][d], alpha [N][d] -> [l][d]
     for N in (128, 256, 1024, 2048):
         sb = N * l * row
-        run(f"aggregate N={N}" + (" (direct)" if N <= 256 else " (onepass)"), N, (l + 1) * row, sb + N * row, l * row,
+        run(f"aggregate N={N}" + (" (direct)" if N <= 128 else " (onepass)"), N, (l + 1) * row, sb + N * row, l * row,
             lambda i, o, N=N, sb=sb: ctx.aggregate_core_dev(i, i + sb, o, N, l),
-            note="launches of <= 256 signers take aggregate_direct (no signer slices), larger ones aggregate_onepass")
+            note="launches of <= 128 signers take aggregate_direct (no signer slices), larger ones aggregate_onepass")
     # aggregate + target partials in one pass, 4 aggregates of 256 signers (the bench's sign_verify step)
     G, per = 4, 256
     sb = G * per * l * row

@@ -231,12 +231,16 @@ class PolynomialCoefficientRepresentation(PolynomialRepresentation):
     def norm(self, p: Union[int, str]) -> int:
         if p != "infty":
             raise NotImplementedError(f"norm for p={p} not implemented")
-        # max |x| over the STORED values (:221-224), not over their residues.  The device type is int32: a stored value
-        # outside it (a caller's own list) is a Python int the library never holds -- the reference's answer for it is one
-        # exact max() over the list on the host (marshalling, not algebra: no reduction, no arithmetic mod q)
-        if self._arr is None and any(x < _backend.INT32_MIN or x > _backend.INT32_MAX for x in self.coefficients):
+        # max |x| over the STORED values (:221-224), not over their residues.  The device type is int32 (int64 on the generic
+        # path, q >= 2^32): a stored value outside it (a caller's own list) is a Python int the library never holds -- the
+        # reference's answer for it is one exact max() over the list on the host (marshalling, not algebra: no reduction, no
+        # arithmetic mod q)
+        wide = _backend.is_wide(self.modulus)
+        lo, hi = (-(2 ** 63) + 1, 2 ** 63 - 1) if wide else (_backend.INT32_MIN, _backend.INT32_MAX)
+        if self._arr is None and any(x < lo or x > hi for x in self.coefficients):
             return max(abs(x) for x in self.coefficients)
-        mx, _ = self._ring().norm_weight(self._arr if self._arr is not None else np.array(self.coefficients, dtype=np.int32))
+        mx, _ = self._ring().norm_weight(self._arr if self._arr is not None
+                                         else np.array(self.coefficients, dtype=np.int64 if wide else np.int32))
         return int(mx[0])
 
     def weight(self) -> int:

@@ -1,0 +1,219 @@
+"""The generic-parameter path (csrc/fz_wide.hip, fusion_hip/wide.py): moduli from 2^32 up to 2^63 and transform lengths beyond 4096 --
+what the reference accepts (any odd modulus, any power-of-two length, whatever table it is handed: algebra/ntt.py:239-290,
+:345-377; algebra/polynomials.py) and the int32 kernels do not take.  Everything is compared with the PURE-PYTHON restatement of
+the reference's loops (oracle.py py_*: Python integers, no 64-bit limits) or with Python-integer arithmetic written out here;
+the drop-in classes are exercised on the same parameters.  What is still refused (q >= 2^63, even moduli) is pinned."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def is_prime(n):
+    """deterministic Miller-Rabin for n < 2^64"""
+    if n < 2:
+        return False
+    for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % p == 0:
+            return n == p
+    d, s = n - 1, 0
+    while d % 2 == 0:
+        d, s = d // 2, s + 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(s - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def prime_near(start, step, down=False):
+    """the first prime q = 1 (mod step) at or after `start` (down: at or before)"""
+    q = start - (start - 1) % step if down else start + (1 - start) % step
+    while not is_prime(q):
+        q += -step if down else step
+    return q
+
+
+Q33 = prime_near(2 ** 32, 2 ** 15)               # just above 2^32, has 2^15-th roots of unity
+Q62 = prime_near(2 ** 62, 2 ** 15, down=True)    # just below 2^62
+Q63 = prime_near(2 ** 63 - 1, 2 ** 15, down=True)   # the largest modulus class the path takes: just below 2^63
+Q41 = prime_near(2 ** 41, 2 ** 15)               # (the classes' constructors test primality by trial division, as the reference's do:
+#                                                  seconds at 2^41, a minute at 2^62 -- the class tests stay below)
+
+
+def root_of(q, n):
+    for g in range(2, 5000):
+        r = pow(g, (q - 1) // (2 * n), q)
+        if pow(r, n, q) == q - 1:
+            return r
+    raise AssertionError("no root")
+
+
+def cent_rows(rnd, q, rows, d):
+    half = (q - 1) // 2
+    return [[rnd.randint(-half, half) for _ in range(d)] for _ in range(rows)]
+
+
+def cent(x, q):
+    y = x % q
+    return y - q if y > (q - 1) // 2 else y
+
+
+@pytest.mark.parametrize("q,d", [(Q33, 2), (Q33, 8), (Q33, 256), (Q62, 256), (Q63, 64), (Q63, 1024), (Q62, 8192), (65537, 8192)])
+def test_wide_transforms_match_the_reference_loops(q, d):
+    """forward and inverse transforms from root-generated tables: every row against cooley_tukey_ntt / gentleman_sande_intt's loops on
+    Python integers (ntt.py:274-290, :354-376); extremes +-(q-1)/2 included"""
+    from fusion_hip.wide import WideContext, bit_reversed_powers
+    root = root_of(q, d)
+    inv = pow(root, q - 2, q)
+    tw, itw = O.py_twiddles(root, q, d), O.py_twiddles(inv, q, d)
+    assert bit_reversed_powers(root, q, d) == tw
+    ctx = WideContext(q, d, tw, itw)
+    rnd = random.Random(d + q % 1000)
+    rows = 3 if d > 1024 else 6
+    x = cent_rows(rnd, q, rows, d)
+    x[0] = [(q - 1) // 2] * d
+    x[1] = [-((q - 1) // 2) if k % 2 else (q - 1) // 2 for k in range(d)]
+    y = ctx.ntt_forward(np.array(x, dtype=np.int64))
+    assert y.dtype == np.int64
+    for r in range(rows):
+        assert y[r].tolist() == O.py_ntt_forward(list(x[r]), q, tw), (q, d, r)
+    z = ctx.ntt_inverse(y)
+    assert z.tolist() == x
+    w = ctx.ntt_inverse(np.array(x, dtype=np.int64))                      # the inverse on arbitrary input, not only on forward outputs
+    for r in range(min(rows, 3)):
+        assert w[r].tolist() == O.py_ntt_inverse(list(x[r]), q, itw), (q, d, r)
+
+
+@pytest.mark.parametrize("q,d", [(Q62, 64), (2147465729, 16384)])
+def test_wide_transforms_use_the_table_they_are_handed(q, d):
+    """tables that are not the power table of any root (random residues): the loops use entry m + i / h + i whatever it holds --
+    also the scheme's own prime at a length (16 384) for which it has no root of unity and the int32 kernels no schedule"""
+    from fusion_hip.wide import WideContext
+    rnd = random.Random(5)
+    tab = [rnd.randrange(q) for _ in range(d)]
+    itab = [rnd.randrange(q) for _ in range(d)]
+    ctx = WideContext(q, d, tab, itab)
+    x = cent_rows(rnd, q, 4, d)
+    y = ctx.ntt_forward(np.array(x, dtype=np.int64))
+    z = ctx.ntt_inverse(np.array(x, dtype=np.int64))
+    for r in range(4):
+        assert y[r].tolist() == O.py_ntt_forward(list(x[r]), q, tab)
+        assert z[r].tolist() == O.py_ntt_inverse(list(x[r]), q, itab)
+
+
+@pytest.mark.parametrize("q", [Q33, Q62, Q63, 2 ** 40 + 15, 3 * (2 ** 50) + 1])
+def test_wide_pointwise_matvec_norm_weight(q):
+    """+, -, *, negation, the (1 x l)(l x 1) product, norm and weight on Python integers (odd moduli, prime or not: the pointwise
+    operations of polynomials.py:140-216, :272-333 and matrices.py:143-181 ask for nothing else)"""
+    from fusion_hip.wide import WideContext
+    if q % 2 == 0:
+        q += 1
+    d, l, batch = 48, 7, 5
+    ctx = WideContext(q, d)
+    rnd = random.Random(q % 9973)
+    a, b = cent_rows(rnd, q, batch, d), cent_rows(rnd, q, batch, d)
+    a[0][:4] = [(q - 1) // 2, -((q - 1) // 2), 0, 1]
+    b[0][:4] = [(q - 1) // 2, (q - 1) // 2, 0, -1]
+    A, B = np.array(a, dtype=np.int64), np.array(b, dtype=np.int64)
+    assert ctx.pw_add(A, B).tolist() == [[cent(x + y, q) for x, y in zip(r, s)] for r, s in zip(a, b)]
+    assert ctx.pw_sub(A, B).tolist() == [[cent(x - y, q) for x, y in zip(r, s)] for r, s in zip(a, b)]
+    assert ctx.pw_mul(A, B).tolist() == [[cent(x * y, q) for x, y in zip(r, s)] for r, s in zip(a, b)]
+    assert ctx.pw_neg(A).tolist() == [[-(x % q) for x in r] for r in a]
+    Am = cent_rows(rnd, q, l, d)
+    S = [cent_rows(rnd, q, l, d) for _ in range(batch)]
+    got = ctx.matvec(np.array(Am, dtype=np.int64), np.array(S, dtype=np.int64))
+    want = [[cent(sum(Am[k][j] * S[bb][k][j] for k in range(l)), q) for j in range(d)] for bb in range(batch)]
+    assert got.tolist() == want
+    a[1] = [0] * d
+    a[2] = [0] * (d - 1) + [-5]
+    mx, wt = ctx.norm_weight(np.array(a, dtype=np.int64))
+    assert mx.tolist() == [max(abs(x) for x in r) for r in a]
+    assert wt.tolist() == [sum(1 for x in r if x != 0) for r in a]
+
+
+def schoolbook_negacyclic(f, g, q):
+    d = len(f)
+    out = [0] * d
+    for i, x in enumerate(f):
+        for j, y in enumerate(g):
+            k = i + j
+            if k < d:
+                out[k] += x * y
+            else:
+                out[k - d] -= x * y
+    return [cent(v, q) for v in out]
+
+
+@pytest.mark.parametrize("q,d", [(Q33, 16), (Q41, 32), (Q33, 8)])
+def test_drop_in_classes_over_wide_moduli(q, d):
+    """the reference's classes and functions on a modulus beyond 2^32: constructor checks, + - * (schoolbook-checked), negation,
+    norm, weight, transform there and back, ntt_poly_mult, cooley_tukey_ntt / gentleman_sande_intt on lists"""
+    import algebra.ntt as N
+    from algebra.polynomials import PolynomialCoefficientRepresentation as PC, transform
+    root = root_of(q, d)
+    inv = pow(root, q - 2, q)
+    rnd = random.Random(d)
+    half = (q - 1) // 2
+    f = [rnd.randint(-half, half) for _ in range(d)]
+    g = [rnd.randint(-half, half) for _ in range(d)]
+    F, G = PC(q, d, root, inv, 2 * d, list(f)), PC(q, d, root, inv, 2 * d, list(g))
+    assert (F + G).coefficients == [cent(x + y, q) for x, y in zip(f, g)]
+    assert (F - G).coefficients == [cent(x - y, q) for x, y in zip(f, g)]
+    assert (-F).coefficients == [-(x % q) for x in f]
+    assert (F * G).coefficients == schoolbook_negacyclic(f, g, q)
+    assert F.norm(p="infty") == max(abs(x) for x in f) and F.weight() == sum(1 for x in f if x)
+    Fh = transform(F)
+    tw, itw = O.py_twiddles(root, q, d), O.py_twiddles(inv, q, d)
+    assert Fh.values == O.py_ntt_forward(list(f), q, tw)
+    assert transform(Fh).coefficients == f
+    assert (Fh * transform(G)).values == [cent(x * y, q) for x, y in zip(Fh.values, transform(G).values)]
+    ff, gg = list(f), list(g)
+    assert N.ntt_poly_mult(ff, gg, q, root, inv, 2 * d) == schoolbook_negacyclic(f, g, q)
+    v = list(f)
+    assert N.cooley_tukey_ntt(v, q, 2 * d, tw) == O.py_ntt_forward(list(f), q, tw)
+    assert N.gentleman_sande_intt(v, q, 2 * d, itw) == f
+    big = PC(q, d, root, inv, 2 * d, [x + 3 * q for x in f])               # values beyond the centred range are reduced on the way in
+    assert (big + G).coefficients == (F + G).coefficients
+
+
+def test_long_transforms_on_a_narrow_modulus_through_the_drop_in():
+    """length 8192 over q = 65537 (a modulus of the int32 path, a length beyond its kernels): the generic path serves it"""
+    import algebra.ntt as N
+    q, d = 65537, 8192
+    root = root_of(q, d)
+    tw, itw = O.py_twiddles(root, q, d), O.py_twiddles(pow(root, q - 2, q), q, d)
+    x = [(7 * i * i + 3) % q - q // 2 for i in range(d)]
+    v = list(x)
+    assert N.cooley_tukey_ntt(v, q, 2 * d, tw) == O.py_ntt_forward(list(x), q, tw)
+    assert N.gentleman_sande_intt(v, q, 2 * d, itw) == [cent(c, q) for c in x]
+
+
+def test_what_the_wide_path_refuses():
+    import fusion_hip
+    from fusion_hip.wide import WideContext
+    from algebra.polynomials import PolynomialCoefficientRepresentation as PC
+    for bad in (prime_near(2 ** 63 + 1, 2), prime_near(2 ** 64 + 1, 2)):
+        with pytest.raises(fusion_hip.FusionHipError) as e:
+            PC(bad, 1, 1, 1, 1, [5]) + PC(bad, 1, 1, 1, 1, [7])
+        assert e.value.code == -2 and "3 <= q < 2^63" in str(e.value) and "no CPU fallback" in str(e.value)
+    with pytest.raises(fusion_hip.FusionHipError):
+        WideContext(2 ** 40, 8)                                            # even
+    lib = fusion_hip.load_library()
+    out = np.zeros(4, dtype=np.int64)
+    a = np.ones(4, dtype=np.int64)
+    from ctypes import POINTER, c_int64
+    p = lambda z: z.ctypes.data_as(POINTER(c_int64))
+    assert lib.fz_wide_pw_host(0, 2 ** 63 + 1, 1, p(a), p(a), p(out), 4) == -2
+    assert b"2^63" in lib.fz_last_error()
+    assert lib.fz_wide_ntt_host(0, 97, 12, None, 0, 0, p(a), p(out), 0) == -1     # not a power of two

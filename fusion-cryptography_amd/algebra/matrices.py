@@ -132,7 +132,14 @@ class GeneralMatrix:
         t = self._uniform_ring()
         if t is not None:
             ctx = _backend.ring_ctx(t.modulus, t._len())
-            return self._rebuild(t, ctx.pw_neg(self._stack()), rows, cols)
+            st = self._stack()
+            if t.modulus < 2 ** 31 or _backend.is_wide(t.modulus):
+                return self._rebuild(t, ctx.pw_neg(st), rows, cols)
+            # 2^31 <= q < 2^32: -(x mod q) does not fit the int32 rows (see _backend.neg_values): the device's centred negation,
+            # the representative shifted on the way back, lists of Python ints
+            c = ctx.pw_sub(np.zeros_like(st), st)
+            return GeneralMatrix(matrix=[[t._like_list([int(v) if v <= 0 else int(v) - t.modulus for v in c[i * cols + j].tolist()])
+                                          for j in range(cols)] for i in range(rows)])
         return GeneralMatrix(matrix=[[-self.matrix[i][j] for j in range(cols)] for i in range(rows)])
 
     def __sub__(self, other):

@@ -251,3 +251,16 @@ def test_what_is_still_refused_is_refused_loudly():
     with pytest.raises(fusion_hip.FusionHipError) as e:
         fusion_hip.Context(65536, 4, 2, 3)             # an even modulus
     assert e.value.code == -1 and "odd" in str(e.value)
+
+
+def test_matrix_negation_between_2_31_and_2_32():
+    """-(x mod q) of every entry (matrices.py:125-129 on polynomials.py:325-333) where the value no longer fits the int32 rows"""
+    from algebra.matrices import GeneralMatrix
+    from algebra.polynomials import PolynomialNTTRepresentation as PN
+    q, d = Q_TOP, 8
+    root = root_of(q, d)
+    inv = pow(root, q - 2, q)
+    half = (q - 1) // 2
+    rows = [[half, -half, 0, 1, -1, 5, -7, half - 3], [3, -3, half, 0, 0, -half, 2, -2]]
+    M = GeneralMatrix(matrix=[[PN(q, d, root, inv, 2 * d, list(r))] for r in rows])
+    assert [z[0].values for z in (-M).matrix] == [[-(x % q) for x in r] for r in rows]

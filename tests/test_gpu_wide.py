@@ -217,3 +217,25 @@ def test_what_the_wide_path_refuses():
     assert lib.fz_wide_pw_host(0, 2 ** 63 + 1, 1, p(a), p(a), p(out), 4) == -2
     assert b"2^63" in lib.fz_last_error()
     assert lib.fz_wide_ntt_host(0, 97, 12, None, 0, 0, p(a), p(out), 0) == -1     # not a power of two
+
+
+def test_general_matrix_over_a_wide_modulus():
+    """GeneralMatrix + - * (element and (1 x l)(l x 1)), norm, weight on a modulus beyond 2^32 (matrices.py:99-200)"""
+    from algebra.matrices import GeneralMatrix
+    from algebra.polynomials import PolynomialNTTRepresentation as PN
+    q, d, l = Q33, 16, 3
+    root = root_of(q, d)
+    inv = pow(root, q - 2, q)
+    rnd = random.Random(3)
+    half = (q - 1) // 2
+    mk = lambda: [rnd.randint(1, half) * rnd.choice((-1, 1)) for _ in range(d)]
+    a, s = [mk() for _ in range(l)], [mk() for _ in range(l)]
+    A = GeneralMatrix(matrix=[[PN(q, d, root, inv, 2 * d, list(v)) for v in a]])
+    S = GeneralMatrix(matrix=[[PN(q, d, root, inv, 2 * d, list(v))] for v in s])
+    At = GeneralMatrix(matrix=[[PN(q, d, root, inv, 2 * d, list(v))] for v in a])
+    prod = A * S
+    assert prod.matrix[0][0].values == [cent(sum(a[k][j] * s[k][j] for k in range(l)), q) for j in range(d)]
+    assert [z[0].values for z in (At + S).matrix] == [[cent(x + y, q) for x, y in zip(u, v)] for u, v in zip(a, s)]
+    assert [z[0].values for z in (-S).matrix] == [[-(x % q) for x in v] for v in s]
+    e = PN(q, d, root, inv, 2 * d, mk())
+    assert [z[0].values for z in (S * e).matrix] == [[cent(x * y, q) for x, y in zip(v, e.values)] for v in s]

@@ -15,6 +15,7 @@
 #include "../../include/fusion_hip.h"
 #include <algorithm>
 #include <memory>
+#include <new>
 
 namespace {
 #define FZW_TRY(x) do { int rc_ = (x); if (rc_ != FZ_OK) return rc_; } while (0)
@@ -175,7 +176,8 @@ FZ_API int fz_wide_ntt_host(int device, uint64_t q, int degree, const uint64_t *
     if (batch > 0x7fffffffull) return fz_set_error(FZ_E_BADARG, "wide path: at most 2^31 - 1 rows per call");
     FZW_HIP(hipSetDevice(device), "hipSetDevice");
     // the table in Montgomery form: w * 2^64 mod q (host 128-bit arithmetic: a parameter conversion, once per call)
-    std::unique_ptr<unsigned long long[]> tab(new unsigned long long[degree]);
+    std::unique_ptr<unsigned long long[]> tab(new (std::nothrow) unsigned long long[degree]);      // (no exception leaves the C ABI)
+    if (!tab) return fz_set_error(FZ_E_HIP, "wide path: out of host memory for a table of %d entries", degree);
     for (int i = 0; i < degree; ++i) tab[i] = (unsigned long long)((((unsigned __int128)(h_table[i] % q)) << 64) % q);
     const unsigned long long n_inv_mont = (unsigned long long)((((unsigned __int128)(n_inv % q)) << 64) % q);
     const size_t bytes = batch * (size_t)degree * sizeof(int64_t);

@@ -85,6 +85,19 @@ def test_fails_loudly_without_a_device(lib):
     assert lib.fz_ctx_create(0, 2147465729, 8192, 3337519, 1, ctypes.byref(h)) == -2     # degree > 4096 (round 5; > 256 before)
     assert b"8192" in lib.fz_last_error()
     assert lib.fz_ctx_create_tables(0, 2147465729, 256, None, None, ctypes.byref(h)) == -1   # tables are required
+    # the generic int64 path (fz_wide_*): arguments are checked first, and without a device the call FAILS -- it computes nothing on the host
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    a = (ctypes.c_int64 * 4)(1, 2, 3, 4)
+    out = (ctypes.c_int64 * 4)()
+    p64 = lambda z: ctypes.cast(z, i64p)
+    assert lib.fz_wide_pw_host(0, 2 ** 63 + 1, 1, p64(a), p64(a), p64(out), 4) == -2 and b"2^63" in lib.fz_last_error()
+    assert lib.fz_wide_pw_host(0, 2 ** 40, 1, p64(a), p64(a), p64(out), 4) == -2                     # even
+    assert lib.fz_wide_ntt_host(0, 97, 12, None, 0, 0, p64(a), p64(out), 1) == -1                   # not a power of two
+    assert lib.fz_wide_pw_host(0, 2 ** 40 + 15, 1, p64(a), p64(a), p64(out), 4) not in (0,)         # no device: an error, not a result
+    assert list(out) == [0, 0, 0, 0]
+    from algebra.polynomials import PolynomialCoefficientRepresentation as PC
+    with pytest.raises(fusion_hip.FusionHipError):
+        PC(4294967311, 1, 1, 1, 1, [5]) + PC(4294967311, 1, 1, 1, 1, [7])
     # the batch queue owns contexts: no device, no queue (and nothing left running)
     import fusion.fusion as F
     from fusion_hip.queue import BatchQueue, PackedMessages

@@ -64,7 +64,7 @@ while time.time() < t_end:
     ctx = ctxs[(sp, kern)]
     other = ctxs[(sp, str(rng.choice(KERNS)))]
     rows = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 257, 1000, 4099, int(rng.integers(1, 20000))]))
-    what = rng.choice(["ntt", "polymul", "scheme", "graph", "pointwise", "small", "batch_api", "multi", "challenge", "sampler", "ragged", "queue"])
+    what = rng.choice(["ntt", "polymul", "scheme", "graph", "pointwise", "small", "batch_api", "multi", "challenge", "sampler", "ragged", "queue", "wide"])
     raw = rng.random() < 0.3
     x = (rng.integers(-2**31, 2**31, size=(rows, d), dtype=np.int64).astype(np.int32) if raw
          else O.splitmix_centered(int(rng.integers(1, 2**40)), rows * d).reshape(rows, d))
@@ -331,6 +331,44 @@ while time.time() < t_end:
         assert np.array_equal(agg_b, SCH.signature_from_object(prm, agg)), ("batch aggregate", sp, nn)
         assert bs.verify(vk_b, msgs, agg_b) == F.verify(prm, [k_[1] for k_ in keys], msgs, agg) == (True, ""), ("batch verify", sp)
         bump("batch_api")
+    elif what == "wide":
+        # the generic int64 path (csrc/fz_wide.hip): a random odd modulus of 33 .. 63 bits, random tables, against the reference's
+        # loops and Python-integer arithmetic
+        from fusion_hip.wide import WideContext
+        bits = int(rng.integers(33, 64))
+        qw = (int(rng.integers(1 << 62, (1 << 63) - 1)) >> (63 - bits)) | (1 << (bits - 1)) | 1
+        dw = 1 << int(rng.integers(1, 11))
+        nb = int(rng.integers(1, 6))
+        hw = (qw - 1) // 2
+        pyr = lambda n_: [int(rng.integers(-hw, hw + 1)) for _ in range(n_)]
+        tab, itab = [int(rng.integers(0, qw)) for _ in range(dw)], [int(rng.integers(0, qw)) for _ in range(dw)]
+        if qw % 2 == 1 and np.gcd(dw, qw) == 1:
+            wc = WideContext(qw, dw, tab, itab)
+            xs = [pyr(dw) for _ in range(nb)]
+            X = np.array(xs, dtype=np.int64)
+            yf, yi = wc.ntt_forward(X), wc.ntt_inverse(X)
+            cw = lambda v: (v + hw) % qw - hw
+            for b_ in range(nb):
+                assert yf[b_].tolist() == O.py_ntt_forward(list(xs[b_]), qw, tab), ("wide fwd", qw, dw)
+                # py_ntt_inverse computes n^-1 as pow(n, q - 2, q): only right for primes -- the loop is restated with pow(n, -1, q)
+                v = list(xs[b_])
+                t_, m_ = 1, dw
+                while m_ > 1:
+                    j1, h_ = 0, m_ // 2
+                    for i_ in range(h_):
+                        s_ = itab[h_ + i_]
+                        for j_ in range(j1, j1 + t_):
+                            u_, w_ = v[j_], v[j_ + t_]
+                            v[j_], v[j_ + t_] = cw(u_ + w_), cw((u_ - w_) * s_)
+                        j1 += 2 * t_
+                    t_, m_ = 2 * t_, h_
+                ninv = pow(dw, -1, qw)
+                assert yi[b_].tolist() == [cw(c_ * ninv) for c_ in v], ("wide inv", qw, dw)
+            a_, b2 = pyr(dw * nb), pyr(dw * nb)
+            A_, B_ = np.array(a_, dtype=np.int64), np.array(b2, dtype=np.int64)
+            assert wc.pw_mul(A_, B_).tolist() == [cw(x_ * y_) for x_, y_ in zip(a_, b2)], ("wide mul", qw)
+            assert wc.pw_add(A_, B_).tolist() == [cw(x_ + y_) for x_, y_ in zip(a_, b2)] and wc.pw_neg(A_).tolist() == [-(x_ % qw) for x_ in a_]
+        bump("wide")
     else:
         ctx = vctx[(sp, int(rng.integers(0, len(VARIANTS))))]          # fused / multi-launch forms, aggregation launch shapes
         l = int(rng.choice([1, 2, 7, P["rank"]]))

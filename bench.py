@@ -956,8 +956,8 @@ def main():
         rows_ = 2 * D * B
         nr_ = 1 if rows_ <= 24 * cus else (2 if rows_ <= 48 * cus else 4)
         tab_ = 4 if 2 * D <= 4 else (8 if 2 * D <= 8 else 32)
-        if os.environ.get("FZ_NTT_KERNEL", "") == "16" or (os.environ.get("FZ_NTT_KERNEL", "") != "4" and rows_ >= 24576):
-            kernel_name = f"ntt_jobs16<8, true, FzJobsN<{tab_}>>"       # (fz_launch_ntt_multi: the 16-per-lane form from 24 576 rows per launch)
+        if chain_ctx[0].diag_ntt_schedule(rows_) == 16:                # the library's own crossover (fz_diag_ntt_schedule)
+            kernel_name = f"ntt_jobs16<8, true, FzJobsN<{tab_}>>"
         else:
             kernel_name = f"ntt_jobs4<8, true, {nr_}, {(8 if rows_ >= 8 * cus else 4 if rows_ >= 4 * cus else 1) if nr_ == 1 else 2}, FzJobsN<{tab_}>>"
         launch_text = (f"software-pipelined over {D} batches: forward of batches i+1..i+{D} + inverse of batches i-{D - 1}..i in one "

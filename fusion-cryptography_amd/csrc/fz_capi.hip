@@ -1454,6 +1454,17 @@ int fz_diag_copy(fz_ctx *ctx, const void *d_src, void *d_dst, size_t bytes) {
     return fz_launch_diag(ctx, 1, d_src, d_dst, bytes);
 }
 
+int fz_diag_ntt_schedule(fz_ctx *ctx, size_t rows, int *family) {
+    FZ_REQUIRE(ctx && family, "NULL argument");
+    *family = 0;
+    if (ctx->logd < 5 || ctx->logd > 8) return FZ_OK;
+    const bool radix4_exists = ctx->logd == 6 || ctx->logd == 8;           // (degrees 32 and 128 only have the 16-per-lane kernels)
+    if (!radix4_exists || ctx->force_kernel == 16) *family = 16;
+    else if (ctx->force_kernel == 4) *family = 4;
+    else *family = rows >= (size_t)ctx->small_batch_rows ? 16 : 4;
+    return FZ_OK;
+}
+
 int fz_diag_shader_clock(fz_ctx *ctx, unsigned microseconds, double *out_mhz) {
     FZ_REQUIRE(ctx && out_mhz, "NULL argument");
     FZ_REQUIRE(microseconds >= 1 && microseconds <= 1000000, "between 1 us and 1 s");

@@ -178,6 +178,7 @@ SIGNATURES.update({
     "fz_diag_empty_launch": (c_int, [_ctx]),
     "fz_diag_copy": (c_int, [_ctx, c_void_p, c_void_p, c_size_t]),
     "fz_diag_shader_clock": (c_int, [_ctx, ctypes.c_uint, POINTER(ctypes.c_double)]),
+    "fz_diag_ntt_schedule": (c_int, [_ctx, c_size_t, POINTER(c_int)]),
     "fz_diag_delay": (c_int, [_ctx, c_uint32]),
 })
 

@@ -187,6 +187,13 @@ class Context:
         check(self._lib, self._lib.fz_diag_shader_clock(self._h, int(microseconds), byref(mhz)))
         return mhz.value
 
+    def diag_ntt_schedule(self, rows):
+        """4 | 16 | 0: the transform schedule a launch of `rows` rows in all takes on this context (radix-4 wave-tasks, 16
+        coefficients per lane, another kernel)"""
+        fam = c_int(0)
+        check(self._lib, self._lib.fz_diag_ntt_schedule(self._h, int(rows), byref(fam)))
+        return fam.value
+
     def diag_delay(self, microseconds):
         """one wave that occupies this context's stream for `microseconds` (asynchronous, capturable)"""
         check(self._lib, self._lib.fz_diag_delay(self._h, int(microseconds)))

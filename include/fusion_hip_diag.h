@@ -55,6 +55,11 @@ FZ_API int fz_diag_copy(fz_ctx *ctx, const void *d_src, void *d_dst, size_t byte
  * returns (synchronous).  The fp64-dense fused kernels run power-limited well below the nominal 2.4 GHz; a vector-issue
  * roofline has to be priced at THIS clock (profiles/README.md, round 3). */
 FZ_API int fz_diag_shader_clock(fz_ctx *ctx, unsigned microseconds, double *out_mhz);
+/* which transform schedule a launch of `rows` rows in all (one job, or the jobs of one fz_ntt_multi call together) takes on this
+ * context: *family = 4 (radix-4 wave-tasks: ntt_fwd4 / ntt_inv4 / ntt_jobs4), 16 (16 coefficients per lane: ntt_fwd16 / ntt_inv16 /
+ * ntt_jobs16) or 0 (another kernel: degrees outside 32..256).  What bench.py names its dominant kernel by, instead of mirroring
+ * the library's crossover. */
+FZ_API int fz_diag_ntt_schedule(fz_ctx *ctx, size_t rows, int *family);
 /* one wave that occupies the context's stream for `microseconds` (asynchronous, capturable): a stand-in of known duration for
  * a step that cannot be run here -- bench.py uses it in place of the multi-GPU all-reduce to measure, on ONE GPU, how much of
  * an exchange step's latency its second stream hides */

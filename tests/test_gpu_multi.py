@@ -496,3 +496,22 @@ def test_bench_sign_verify_leg_with_the_exchange_on_its_second_stream():
         if extra:
             assert "RCCL counts 1 rank" in sv["collective"]
     assert vals["exchange"] < 1.6 * vals["plain"], vals
+
+
+def test_the_library_says_which_transform_schedule_a_launch_takes(monkeypatch):
+    """fz_diag_ntt_schedule: bench.py names its dominant kernel by it (no mirrored crossover): radix-4 wave-tasks below 24 576 rows
+    at degree 256, 16 per lane from there; FZ_NTT_KERNEL forces either; degree 128 has no radix-4 kernels; degree 16 neither family"""
+    import fusion_hip
+    P = O.PARAMS[256]
+    ctx = fusion_hip.Context(Q, 256, P["root"], P["inv_root"])
+    assert [ctx.diag_ntt_schedule(r) for r in (1, 4096, 24575, 24576, 65536, 1 << 22)] == [4, 4, 4, 16, 16, 16]
+    monkeypatch.setenv("FZ_NTT_KERNEL", "16")
+    assert fusion_hip.Context(Q, 256, P["root"], P["inv_root"]).diag_ntt_schedule(1) == 16
+    monkeypatch.setenv("FZ_NTT_KERNEL", "4")
+    assert fusion_hip.Context(Q, 256, P["root"], P["inv_root"]).diag_ntt_schedule(1 << 22) == 4
+    monkeypatch.delenv("FZ_NTT_KERNEL")
+    q2 = 65537
+    r128 = next(r for r in (pow(g, (q2 - 1) // 256, q2) for g in range(2, 200)) if pow(r, 128, q2) == q2 - 1)
+    assert fusion_hip.Context(q2, 128, r128, pow(r128, q2 - 2, q2)).diag_ntt_schedule(10) == 16
+    r16 = next(r for r in (pow(g, (q2 - 1) // 32, q2) for g in range(2, 200)) if pow(r, 16, q2) == q2 - 1)
+    assert fusion_hip.Context(q2, 16, r16, pow(r16, q2 - 2, q2)).diag_ntt_schedule(10) == 0

@@ -59,6 +59,35 @@ __global__ __launch_bounds__(64 * kWaves) void stream_fma(const int *in, int *ou
   if (clk && lane == 0 && w == 0) { clk[0] = __builtin_amdgcn_s_memtime() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
+// what a pure WRITE stream sustains (keygen_bcast_fused writes 2l rows per key half and reads next to nothing from HBM): the same
+// resident grid, every wave storing its 4 KiB chunks, streaming or normal stores
+template <bool NT>
+__global__ __launch_bounds__(64 * kWaves) void stream_fill(int *out, size_t tasks, int seed) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const size_t nw = (size_t)gridDim.x * kWaves, w = (size_t)blockIdx.x * kWaves + wave;
+  const v4i o = {seed, lane, seed ^ lane, wave};
+  for (size_t task = w; task < tasks; task += nw)
+    for (int k = 0; k < 4; ++k) st<NT>(out + task * kChunk + 4 * lane + 256 * k, o);
+}
+
+template <bool NT>
+int run_fill(int *out, size_t rows, int sets, int reps, int grid) {
+  const size_t tasks = rows * 256 / kChunk, per = rows * 256;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) stream_fill<NT><<<grid, 64 * kWaves>>>(out + (i % sets) * per, tasks, i);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) stream_fill<NT><<<grid, 64 * kWaves>>>(out + (i % sets) * per, tasks, i);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / reps, gbs = rows * 1024.0 / us * 1e-3;
+  printf("write only, %s stores, %4d workgroups  %9.2f us  %8.1f GB/s  (%4.1f %% of 8 TB/s)\n", NT ? "streaming" : "normal   ", grid, us, gbs, gbs / 80);
+  return 0;
+}
+
 template <int NOPS, bool NT = true, bool BLOCKED = false>
 int run(const int *in, int *out, size_t rows, int sets, int reps, unsigned long long *d_clk, int grid) {
   const size_t tasks = rows * 256 / kChunk, per = rows * 256;
@@ -112,6 +141,10 @@ int main(int argc, char **argv) {
     if (run<464, true, false>(in, out, rows, sets, reps, d_clk, g)) return 1;
     if (run<464, false, false>(in, out, rows, sets, reps, d_clk, g)) return 1;
     if (run<464, true, true>(in, out, rows, sets, reps, d_clk, g)) return 1;
+  }
+  for (int wg = 4; wg <= 8; wg += 4) {
+    if (run_fill<true>(out, rows, sets, reps, prop.multiProcessorCount * wg)) return 1;
+    if (run_fill<false>(out, rows, sets, reps, prop.multiProcessorCount * wg)) return 1;
   }
   return 0;
 }

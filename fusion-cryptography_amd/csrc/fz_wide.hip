@@ -157,6 +157,13 @@ int make_mod(uint64_t q, WMod *m) {
     return FZ_OK;
 }
 
+int use_device(int device) {                               // the same answer fz_ctx_create gives on a machine without a GPU
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fz_set_error(FZ_E_NODEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fz_set_error(FZ_E_BADARG, "device %d out of range (%d devices)", device, ndev);
+    return fz_check_hip(hipSetDevice(device), "hipSetDevice");
+}
+
 struct DevBuf {                                            // a device allocation for the duration of one call
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -174,7 +181,7 @@ FZ_API int fz_wide_ntt_host(int device, uint64_t q, int degree, const uint64_t *
     FZW_TRY(make_mod(q, &m));
     if (batch == 0) return FZ_OK;
     if (batch > 0x7fffffffull) return fz_set_error(FZ_E_BADARG, "wide path: at most 2^31 - 1 rows per call");
-    FZW_HIP(hipSetDevice(device), "hipSetDevice");
+    FZW_TRY(use_device(device));
     // the table in Montgomery form: w * 2^64 mod q (host 128-bit arithmetic: a parameter conversion, once per call)
     std::unique_ptr<unsigned long long[]> tab(new (std::nothrow) unsigned long long[degree]);      // (no exception leaves the C ABI)
     if (!tab) return fz_set_error(FZ_E_HIP, "wide path: out of host memory for a table of %d entries", degree);
@@ -199,7 +206,7 @@ FZ_API int fz_wide_pw_host(int device, uint64_t q, int op, const int64_t *h_a, c
     WMod m;
     FZW_TRY(make_mod(q, &m));
     if (count == 0) return FZ_OK;
-    FZW_HIP(hipSetDevice(device), "hipSetDevice");
+    FZW_TRY(use_device(device));
     const size_t bytes = count * sizeof(int64_t);
     DevBuf da, db, dout;
     FZW_TRY(da.alloc(bytes));
@@ -219,7 +226,7 @@ FZ_API int fz_wide_matvec_host(int device, uint64_t q, int degree, const int64_t
     WMod m;
     FZW_TRY(make_mod(q, &m));
     if (batch == 0) return FZ_OK;
-    FZW_HIP(hipSetDevice(device), "hipSetDevice");
+    FZW_TRY(use_device(device));
     const size_t row = (size_t)degree * sizeof(int64_t);
     DevBuf dA, dS, dout;
     FZW_TRY(dA.alloc((size_t)l * row));
@@ -239,7 +246,7 @@ FZ_API int fz_wide_norm_weight_host(int device, const int64_t *h_rows, size_t ba
     if (batch && (!h_rows || !h_max_abs || !h_weight)) return fz_set_error(FZ_E_BADARG, "NULL argument");
     if (batch == 0) return FZ_OK;
     if (batch > 0x7fffffffull) return fz_set_error(FZ_E_BADARG, "wide path: at most 2^31 - 1 rows per call");
-    FZW_HIP(hipSetDevice(device), "hipSetDevice");
+    FZW_TRY(use_device(device));
     DevBuf drows, dmx, dwt;
     FZW_TRY(drows.alloc(batch * (size_t)degree * 8));
     FZW_TRY(dmx.alloc(batch * 8));

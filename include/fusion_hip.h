@@ -197,7 +197,7 @@ FZ_API int fz_pw_mul_bcast(fz_ctx *ctx, const int32_t *d_a, const int32_t *d_s, 
  * centred residues (|x| <= (q-1)/2) on the host in and out, exact integer arithmetic on the device, one workgroup per row.
  * Written for correctness, not bandwidth.  h_table: `degree` residues in [0, q), used exactly as the reference uses its
  * `bit_rev_root_powers` / `bit_rev_inv_root_powers` argument (entry m + i for block i of the stage with m blocks); n_inv:
- * degree^{-1} mod q (inverse only).  op as for fz_pw_binary_host; FZ_OP_NEG returns -(x mod q) in [-(q-1), 0] as the reference's
+ * degree^{-1} mod q (inverse only).  op as for fz_pw_binary_host (0 mul, 1 add, 2 sub, 3 neg); neg returns -(x mod q) in [-(q-1), 0] as the reference's
  * __neg__ does. */
 FZ_API int fz_wide_ntt_host(int device, uint64_t q, int degree, const uint64_t *h_table, uint64_t n_inv, int inverse,
                             const int64_t *h_in, int64_t *h_out, size_t batch);

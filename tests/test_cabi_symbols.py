@@ -158,7 +158,7 @@ def build_c_example(tmp_path, name="roundtrip"):
     return exe
 
 
-@pytest.mark.parametrize("name", ["roundtrip", "scheme_flow", "queue_flow"])
+@pytest.mark.parametrize("name", ["roundtrip", "scheme_flow", "queue_flow", "wide_roundtrip"])
 def test_c_caller_compiles_and_fails_loudly_without_a_device(lib, tmp_path, name):
     exe = build_c_example(tmp_path, name)
     n = ctypes.c_int(-1)

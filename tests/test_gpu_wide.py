@@ -239,3 +239,13 @@ def test_general_matrix_over_a_wide_modulus():
     assert [z[0].values for z in (-S).matrix] == [[-(x % q) for x in v] for v in s]
     e = PN(q, d, root, inv, 2 * d, mk())
     assert [z[0].values for z in (S * e).matrix] == [[cent(x * y, q) for x, y in zip(v, e.values)] for v in s]
+
+
+def test_c_caller_of_the_wide_path(tmp_path):
+    """examples/wide_roundtrip.c (strict C99, gcc, no HIP headers): a 62-bit prime, the forward transform against a direct evaluation of
+    its definition, the inverse, the product, the negation"""
+    import subprocess
+    from test_cabi_symbols import build_c_example
+    r = subprocess.run([build_c_example(tmp_path, "wide_roundtrip")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "wide_roundtrip OK" in r.stdout

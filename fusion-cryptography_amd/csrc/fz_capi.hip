@@ -1339,6 +1339,11 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
         ctx->chal_tab_ib = ib;
         ctx->chal_tab_degree = P->degree;
     }
+    // Which form.  Up to kWaveFormMax signers per call every signer gets a WAVE (fz_launch_challenge_wave: the chain of ~108
+    // permutations at 24 instructions + 4 gathers per round, text and stream in LDS); beyond, the three-kernel pipeline with 32
+    // or 64 signers per wave has the higher throughput (profiles/r06_challenge_pipeline.txt).
+    constexpr size_t kWaveFormMax = 3072;
+    const bool wave_form = fz_challenge_wave_ok(P) && (ctx->knob_shake_full == 3 || (ctx->knob_shake_full == 0 && N <= kWaveFormMax));
     // signers per pass: 65536 = two waves of 32 signers on each of the chip's 1024 SIMDs (a second wave per SIMD fills the
     // issue slots one wave alone leaves empty); bounds the scratch at ~16 KB per signer
     const size_t chunk = 65536;
@@ -1346,8 +1351,8 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
         const size_t n = std::min(chunk, N - base);
         const size_t xstride = (n + 63) & ~(size_t)63;
         const size_t o_pre = 0, o_nb = (n * 32 + 255) & ~(size_t)255, o_text = o_nb + ((n * 4 + 255) & ~(size_t)255);
-        const size_t o_xof = o_text + ((n * text_stride + 255) & ~(size_t)255);
-        const size_t o_off = o_xof + ((((size_t)out_blocks * 34 + 1) * xstride * 4 + 255) & ~(size_t)255);    // + one spare word row (decoder)
+        const size_t o_xof = wave_form ? o_text : o_text + ((n * text_stride + 255) & ~(size_t)255);       // (the wave form keeps text and stream in LDS)
+        const size_t o_off = wave_form ? o_xof : o_xof + ((((size_t)out_blocks * 34 + 1) * xstride * 4 + 255) & ~(size_t)255);    // + one spare word row (decoder)
         const size_t msg_bytes = h_prehash ? 0 : h_msg_off[base + n] - h_msg_off[base];
         const size_t o_dec = o_off + (((n + 1) * 8 + 255) & ~(size_t)255);              // [n][16] words: the integers in base 10^9
         const size_t o_msg = o_dec + n * 64;
@@ -1362,11 +1367,23 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
             FZ_HIP(hipMemcpyAsync(sp + o_off, h_msg_off + base, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream), "upload of the message offsets");
             if (msg_bytes)
                 FZ_HIP(hipMemcpyAsync(sp + o_msg, h_msgs + h_msg_off[base], msg_bytes, hipMemcpyHostToDevice, ctx->stream), "upload of the messages");
-            FZ_TRY(fz_launch_prehash(ctx, P, sp + o_msg, (const unsigned long long *)(sp + o_off), n, sp + o_pre, (uint32_t *)(sp + o_dec)));
-            if (h_prehash_out)
-                FZ_HIP(hipMemcpyAsync(h_prehash_out + 32 * base, sp + o_pre, n * 32, hipMemcpyDeviceToHost, ctx->stream), "download of the pre-hashed messages");
+            if (!wave_form) {
+                FZ_TRY(fz_launch_prehash(ctx, P, sp + o_msg, (const unsigned long long *)(sp + o_off), n, sp + o_pre, (uint32_t *)(sp + o_dec)));
+                if (h_prehash_out)
+                    FZ_HIP(hipMemcpyAsync(h_prehash_out + 32 * base, sp + o_pre, n * 32, hipMemcpyDeviceToHost, ctx->stream), "download of the pre-hashed messages");
+            }
         }
         FZ_HIP(hipStreamSynchronize(ctx->stream), "upload sync");      // the caller's buffers have been consumed when this returns
+        if (wave_form) {
+            FZ_TRY(fz_launch_challenge_wave(ctx, P, d_vk + base * 2 * (size_t)P->degree, h_prehash ? sp + o_pre : nullptr, sp + o_msg,
+                                            (const unsigned long long *)(sp + o_off), h_prehash_out ? sp + o_pre : nullptr, n, text_stride,
+                                            out_blocks, ctx->d_chal_tab, d_out + base * (size_t)P->degree));
+            if (!h_prehash && h_prehash_out) {                          // the digests are the kernel's: the caller's buffer is filled when this returns
+                FZ_HIP(hipMemcpyAsync(h_prehash_out + 32 * base, sp + o_pre, n * 32, hipMemcpyDeviceToHost, ctx->stream), "download of the pre-hashed messages");
+                FZ_HIP(hipStreamSynchronize(ctx->stream), "download sync");
+            }
+            continue;
+        }
         FZ_TRY(fz_launch_challenge(ctx, P, d_vk + base * 2 * (size_t)P->degree, sp + o_pre,
                                    h_prehash ? nullptr : (const uint32_t *)(sp + o_dec), n, sp + o_text, text_stride,
                                    (int *)(sp + o_nb), (uint32_t *)(sp + o_xof), xstride, out_blocks, ctx->d_chal_tab,

@@ -27,6 +27,8 @@
 // challenges; degree <= 256); anything else returns FZ_E_UNSUPPORTED and callers use the host pipeline (fz_host.cpp).
 #include "fz_internal.h"
 #include "../../include/fusion_hip.h"
+#include "fz_keccak_wave.h"
+#include <algorithm>
 
 namespace {
 
@@ -69,37 +71,15 @@ __device__ __forceinline__ int u256_to_base1e9(uint32_t (&limb)[8], uint32_t *ou
 }
 constexpr int kDecStride = 16;               // uint32 per signer in the decimal scratch: 9 chunks, the chunk count at [9]
 
-// one wave per signer, kTextWaves signers per workgroup.  text row i: blocks * 136 bytes, *nblocks = blocks.
-// dec (optional): the pre-hashed integers already in base 10^9 (prehash_kernel converts them with a lane per message; done
-// here it is one lane of the signer's wave while 63 wait: a third of this kernel's time)
-constexpr int kTextWaves = 4;
-__global__ __launch_bounds__(64 * kTextWaves) void vk_text_kernel(const int32_t *vk, size_t vk_stride, const uint8_t *pre,
-                                                                  const uint32_t *dec, size_t N, int degree, VkTextParts T,
-                                                                  uint8_t *text, size_t text_stride, int *nblocks) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t i = (size_t)blockIdx.x * kTextWaves + wave;
-    if (i >= N) return;
-    uint8_t *buf = smem + (size_t)wave * text_stride;
-    uint32_t *aux = reinterpret_cast<uint32_t *>(smem + (size_t)kTextWaves * text_stride) + wave * 16;
-    // str(int.from_bytes(prehash, "little")) (fusion.py:405-409, :416-418): the 256-bit integer in base 10^9, least
-    // significant chunk first (one lane: 9 rounds of an 8-limb short division), digits written by lanes 0..8 below
-    if (dec) {
-        if (lane < 10) aux[lane] = dec[i * kDecStride + lane];
-    } else if (lane == 0) {
-        uint32_t limb[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const uint8_t *b = pre + i * 32 + 4 * t;
-            limb[t] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
-        }
-        aux[9] = (uint32_t)u256_to_base1e9(limb, aux);
-    }
-    for (size_t o = (size_t)lane * 16; o < text_stride; o += 64 * 16) *reinterpret_cast<int4 *>(buf + o) = make_int4(0, 0, 0, 0);
+// The text of ONE signer by ONE wave, into `buf` (LDS, `cap` bytes, a multiple of 16): the exact characters, the SHAKE
+// suffix (0x1f ... 0x80) and zeros up to the end of the last 136-byte block; returns the number of blocks (all lanes).
+// aux[0..9]: the pre-hashed integer in base 10^9 (chunks, least significant first) and the chunk count at [9].
+__device__ __forceinline__ int vk_text_wave(uint8_t *buf, size_t cap, const uint32_t *aux, const int32_t *row, int degree, const VkTextParts &T,
+                                            int lane) {
+    for (size_t o = (size_t)lane * 16; o < cap; o += 64 * 16) *reinterpret_cast<int4 *>(buf + o) = make_int4(0, 0, 0, 0);
     const int nvals = 2 * degree;
     const int vpl = nvals >= 64 ? nvals / 64 : 1;               // values per lane (a lane never straddles the two halves)
     const int k0 = lane * vpl;
-    const int32_t *row = vk + i * vk_stride;
     // pass 1: lengths (digits + ", " unless last of its half)
     int mine = 0;
     for (int t = 0; t < vpl; ++t) {
@@ -160,11 +140,41 @@ __global__ __launch_bounds__(64 * kTextWaves) void vk_text_kernel(const int32_t 
     if (lane == 0) {
         buf[len] ^= 0x1f;                                       // SHAKE domain bits + first pad bit (FIPS 202)
         buf[nb * kRate - 1] ^= 0x80;
-        nblocks[i] = nb;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return nb;
+}
+
+// one wave per signer, kTextWaves signers per workgroup.  text row i: blocks * 136 bytes, *nblocks = blocks.
+// dec (optional): the pre-hashed integers already in base 10^9 (prehash_kernel converts them with a lane per message; done
+// here it is one lane of the signer's wave while 63 wait: a third of this kernel's time)
+constexpr int kTextWaves = 4;
+__global__ __launch_bounds__(64 * kTextWaves) void vk_text_kernel(const int32_t *vk, size_t vk_stride, const uint8_t *pre,
+                                                                  const uint32_t *dec, size_t N, int degree, VkTextParts T,
+                                                                  uint8_t *text, size_t text_stride, int *nblocks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t i = (size_t)blockIdx.x * kTextWaves + wave;
+    if (i >= N) return;
+    uint8_t *buf = smem + (size_t)wave * text_stride;
+    uint32_t *aux = reinterpret_cast<uint32_t *>(smem + (size_t)kTextWaves * text_stride) + wave * 16;
+    // str(int.from_bytes(prehash, "little")) (fusion.py:405-409, :416-418): the 256-bit integer in base 10^9, least
+    // significant chunk first (one lane: 9 rounds of an 8-limb short division), digits written by lanes 0..8
+    if (dec) {
+        if (lane < 10) aux[lane] = dec[i * kDecStride + lane];
+    } else if (lane == 0) {
+        uint32_t limb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint8_t *b = pre + i * 32 + 4 * t;
+            limb[t] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        }
+        aux[9] = (uint32_t)u256_to_base1e9(limb, aux);
+    }
+    const int nb = vk_text_wave(buf, text_stride, aux, vk + i * vk_stride, degree, T, lane);
+    if (lane == 0) nblocks[i] = nb;
     uint8_t *dst = text + i * text_stride;
     for (int o = lane * 8; o < nb * kRate; o += 64 * 8) *reinterpret_cast<uint2 *>(dst + o) = *reinterpret_cast<const uint2 *>(buf + o);
 }
@@ -574,6 +584,162 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t *xof, size_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 4. the whole pipeline of ONE signer on ONE wave (fz_keccak_wave.h): pre-hash, text, absorb, squeeze, decode
+// ---------------------------------------------------------------------------------------------------------------
+// With a batch of BASELINE configs[2]'s size (1024 signers) the three kernels above run 32 (lane pairs) or 16 (decoder)
+// waves on a chip with 1024 SIMDs and the call is the latency of one signer's chain.  Here a signer has a wave to itself:
+//   * SHA3-256 of the message and SHAKE-256 of the key text run on the wave-wide Keccak state (24 instructions + 4 gathers
+//     per round instead of 119 instructions): the ~108 permutations take ~0.25 ms instead of 0.64;
+//   * the text is written to LDS and absorbed from there, the stream is squeezed into the same LDS bytes and decoded from
+//     there: nothing but the key row, the message and the 4 d bytes of the challenge touches memory;
+//   * the decoder's two phases are the wave's: the shuffle indices 64 at a time (a lane per draw, the byte dot product of
+//     decode_kernel with the table row of the lane's own modulus), then the swaps -- sequential, but on POSITIONS: lane k
+//     tracks where the k-th non-zero coefficient is (weight <= 64), a swap (i, j) is two compares and two selects for the
+//     whole wave with j read from the lane that computed it, instead of three dependent LDS accesses per swap.
+// LDS per wave: max(text row, stream, 4 d) + 64 bytes.
+constexpr int kWaveAux = 64;
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int W, int NW>      // signers (waves) per workgroup; stream words per index chunk
+__global__ __launch_bounds__(64 * W) void challenge_wave_kernel(const int32_t *vk, size_t vk_stride, const uint8_t *pre, const uint8_t *msgs,
+                                                                const unsigned long long *off, uint8_t *pre_out, uint32_t dst0, uint32_t dst1,
+                                                                size_t N, VkTextParts T, DecodeShapeDev D, const uint32_t *tab, int out_blocks,
+                                                                size_t region, int32_t *coefs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const size_t s = (size_t)blockIdx.x * W + (threadIdx.x >> 6);
+    if (s >= N) return;                                          // waves of a workgroup never synchronise with each other
+    uint8_t *buf = smem + (size_t)(threadIdx.x >> 6) * (region + kWaveAux);
+    uint32_t *aux = reinterpret_cast<uint32_t *>(buf + region);
+    fzkw::Wave K;
+    K.init(lane);
+    const bool ab = K.word < 17;                                 // the rate's 17 words (their owners and the halos)
+    // ---- the pre-hashed message: SHA3-256(dst + "," + message) (fusion.py:405-409), or the caller's digest ----
+    if (pre) {
+        if (lane < 8) aux[lane] = reinterpret_cast<const uint32_t *>(pre + s * 32)[lane];
+    } else {
+        const unsigned long long len = off[s + 1] - off[s];
+        const uint8_t *m = msgs + (off[s] - off[0]);
+        const unsigned long long nb = (len + 4 + kRate - 1) / kRate, last = nb * kRate - 1;      // 3 prefix bytes + message + the suffix byte
+        auto byte_at = [&](unsigned long long p) -> uint32_t {
+            uint32_t v;
+            if (p < 3) {
+                v = p == 0 ? dst0 : (p == 1 ? dst1 : 0x2cu);
+            } else {
+                const unsigned long long k = p - 3;
+                v = k < len ? (uint32_t)m[k] : (k == len ? 0x06u : 0u);
+            }
+            return p == last ? (v | 0x80u) : v;
+        };
+#pragma unroll 1
+        for (unsigned long long b = 0; b < nb; ++b) {
+            if (ab) {
+                const unsigned long long q = b * kRate + 8ull * (unsigned)K.word;
+                K.lo ^= byte_at(q) | (byte_at(q + 1) << 8) | (byte_at(q + 2) << 16) | (byte_at(q + 3) << 24);
+                K.hi ^= byte_at(q + 4) | (byte_at(q + 5) << 8) | (byte_at(q + 6) << 16) | (byte_at(q + 7) << 24);
+            }
+            K.permute();
+        }
+        if (K.main && K.word < 4) {
+            aux[2 * K.word] = K.lo;
+            aux[2 * K.word + 1] = K.hi;
+            if (pre_out) *reinterpret_cast<uint2 *>(pre_out + s * 32 + 8 * K.word) = make_uint2(K.lo, K.hi);
+        }
+        K.lo = K.hi = 0u;
+    }
+    wave_sync();
+    // str(int.from_bytes(digest, "little")): base 10^9 chunks, one lane (9 rounds of an 8-limb short division)
+    if (lane == 0) {
+        uint32_t limb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) limb[t] = aux[t];
+        uint32_t chunk[9];
+        const int nch = u256_to_base1e9(limb, chunk);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) aux[t] = chunk[t];
+        aux[9] = (uint32_t)nch;
+    }
+    wave_sync();
+    // ---- the text, absorbed from LDS ----
+    const int nb = vk_text_wave(buf, region, aux, vk + s * vk_stride, D.degree, T, lane);
+    {
+        const uint8_t *src = buf + 8 * (ab ? K.word : 0);
+        uint2 m = ab ? *reinterpret_cast<const uint2 *>(src) : make_uint2(0u, 0u);
+#pragma unroll 1
+        for (int b = 0; b < nb; ++b) {
+            K.lo ^= m.x;
+            K.hi ^= m.y;
+            if (ab) m = *reinterpret_cast<const uint2 *>(src + (size_t)(b + 1 < nb ? b + 1 : b) * kRate);        // the next block, under the permutation
+            K.permute();
+        }
+    }
+    wave_sync();
+    // ---- the stream, squeezed into the same bytes ----
+#pragma unroll 1
+    for (int q = 0; q < out_blocks; ++q) {
+        if (ab && K.main) *reinterpret_cast<uint2 *>(buf + (size_t)q * kRate + 8 * K.word) = make_uint2(K.lo, K.hi);
+        if (q + 1 < out_blocks) K.permute();
+    }
+    wave_sync();
+    // ---- decoder (fusion.py:422-481), norm bound 1 ----
+    const int d = D.degree, wt = D.weight < d ? D.weight : d;
+    const int draws = d - 1 - D.weight > 0 ? d - 1 - D.weight : 0;
+    // sign k = bit k (LSB first) of the big-endian integer in the leading sign_bytes bytes; magnitudes are 1 + (chunk mod 1) = 1
+    int sgn = 0, pos = lane;
+    if (lane < wt) sgn = ((buf[D.sign_bytes - 1 - (lane >> 3)] >> (lane & 7)) & 1) ? 1 : -1;
+    // phase 1: j_n = int.from_bytes(chunk_n, "big") % (d - n), a lane per draw
+    const int ib = D.index_bytes, pos0 = D.sign_bytes + D.coef_bytes * D.weight;
+    const uint32_t *xs = reinterpret_cast<const uint32_t *>(buf);
+    uint32_t jv[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c * 64 < draws) {                                    // (uniform)
+            const int n = c * 64 + lane, nn = n < draws ? n : draws - 1;
+            const int o = pos0 + nn * ib, sh = o & 3;
+            const uint32_t *pw = xs + (o >> 2);
+            uint32_t w[NW];
+#pragma unroll
+            for (int t = 0; t < NW; ++t) w[t] = pw[t];
+            const uint32_t mod = (uint32_t)(d - nn);
+            const uint32_t *Tm = tab + (size_t)mod * kTabStride;
+            const uint4 t0 = *reinterpret_cast<const uint4 *>(Tm), t1 = *reinterpret_cast<const uint4 *>(Tm + 4), t2 = *reinterpret_cast<const uint4 *>(Tm + 8);
+            const uint32_t recip = Tm[12];
+            const uint32_t tw[12] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
+            uint32_t sum = 0;
+#pragma unroll
+            for (int g = 0; g < NW; ++g) {
+                const uint32_t hi = g + 1 < NW ? w[g + 1 < NW ? g + 1 : g] : 0u;
+                sum = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(hi, w[g], sh), tw[g], sum, false);
+            }
+            jv[c] = sum - __umulhi(sum, recip) * mod;            // sum mod (d - n), exact (fz_challenge_weight_table)
+        }
+    }
+    // phase 2: for i = d-1 down to weight+1: swap(c[i], c[j]) -- on the positions of the non-zero coefficients
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int lim = draws - c * 64 < 64 ? draws - c * 64 : 64;
+#pragma unroll 1
+        for (int t = 0; t < lim; ++t) {
+            const int i = d - 1 - (c * 64 + t);
+            const int j = __builtin_amdgcn_readlane((int)jv[c], t);
+            pos = pos == i ? j : (pos == j ? i : pos);
+        }
+    }
+    wave_sync();                                                 // the stream has been read: its bytes become the coefficient row
+    int32_t *out = reinterpret_cast<int32_t *>(buf);
+    for (int j = lane; j < d; j += 64) out[j] = 0;
+    wave_sync();
+    if (lane < wt) out[pos] = sgn;
+    wave_sync();
+    int32_t *dst = coefs + s * (size_t)d;
+    for (int j = lane * 4; j < d; j += 256) *reinterpret_cast<int4 *>(dst + j) = *reinterpret_cast<const int4 *>(out + j);
+}
+
 }  // namespace
 
 // the fixed pieces of str(OneTimeVerificationKey) come from the host serialiser, so both pipelines share one definition
@@ -622,6 +788,48 @@ int fz_launch_challenge(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d
     else if (nw <= 9) hipLaunchKernelGGL(decode_kernel<9>, dgrid, dim3(64), dlds, ctx->stream, d_xof, xstride, N, D, d_tab, kmax, d_coefs);
     else hipLaunchKernelGGL(decode_kernel<12>, dgrid, dim3(64), dlds, ctx->stream, d_xof, xstride, N, D, d_tab, kmax, d_coefs);
     return fz_check_hip(hipGetLastError(), "decode launch");
+}
+
+// the fused form: one wave per signer.  d_pre [N][32] (digests) or, when null, d_msgs / d_off (the messages back to back and
+// their N + 1 offsets) with d_pre_out [N][32] (optional) receiving the digests; d_coefs [N][degree] out
+bool fz_challenge_wave_ok(const fz_scheme_params *P) { return P->omega_ch <= 64 && P->degree <= 256 && P->degree >= 4; }
+
+int fz_launch_challenge_wave(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *d_pre, const uint8_t *d_msgs,
+                             const unsigned long long *d_off, uint8_t *d_pre_out, size_t N, size_t text_stride, int out_blocks,
+                             const uint32_t *d_tab, int32_t *d_coefs) {
+    if (N == 0) return FZ_OK;
+    VkTextParts T;
+    fz_host_vk_text_parts(P, T.s0, &T.n0, T.s1, &T.n1, T.s2, &T.n2, 384);
+    if (T.n0 < 0) return fz_set_error(FZ_E_UNSUPPORTED, "verification-key text pieces do not fit");
+    DecodeShapeDev D;
+    D.degree = P->degree;
+    D.weight = P->omega_ch;
+    (void)fz_host_challenge_needed_bytes(P, &D.sign_bytes, &D.coef_bytes, &D.index_bytes);
+    if (D.index_bytes > 4 * (kChunkWords - 1)) return fz_set_error(FZ_E_UNSUPPORTED, "index chunks of %d bytes", D.index_bytes);
+    if (!fz_challenge_wave_ok(P)) return fz_set_error(FZ_E_UNSUPPORTED, "wave form: weight <= 64 and degree 4..256 only");
+    const int nw = (3 + D.index_bytes + 3) / 4;
+    // one region for the text row, then the stream (a chunk's NW words may end up to 12 bytes past it), then the coefficients
+    size_t region = text_stride;
+    region = std::max(region, (size_t)out_blocks * kRate + 16);
+    region = std::max(region, (size_t)P->degree * 4);
+    region = (region + 15) & ~(size_t)15;
+    constexpr int W = 4;
+    const size_t lds = (size_t)W * (region + kWaveAux);
+    if (lds > 160 * 1024) return fz_set_error(FZ_E_UNSUPPORTED, "text row too long for the fused challenge kernel");
+    const dim3 grid((unsigned)((N + W - 1) / W)), block(64 * W);
+#define FZ_CW(NWV) do { \
+        if (lds > 64 * 1024) { \
+            hipError_t e = hipFuncSetAttribute((const void *)challenge_wave_kernel<W, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return fz_check_hip(e, "challenge kernel LDS attribute"); \
+        } \
+        hipLaunchKernelGGL((challenge_wave_kernel<W, NWV>), grid, block, lds, ctx->stream, d_vk, (size_t)2 * P->degree, d_pre, d_msgs, d_off, d_pre_out, \
+                           (uint32_t)P->sign_pre_hash_dst[0], (uint32_t)P->sign_pre_hash_dst[1], N, T, D, d_tab, out_blocks, region, d_coefs); \
+    } while (0)
+    if (nw <= 5) FZ_CW(5);
+    else if (nw <= 9) FZ_CW(9);
+    else FZ_CW(12);
+#undef FZ_CW
+    return fz_check_hip(hipGetLastError(), "challenge (wave form) launch");
 }
 
 // SHA3-256 of dst + "," + message for N messages: d_msgs the message bytes back to back, d_off [N + 1] their offsets (any

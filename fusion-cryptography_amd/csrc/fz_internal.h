@@ -78,7 +78,7 @@ struct fz_ctx {
     int chal_tab_ib, chal_tab_degree;
     // benchmarking knobs, read ONCE at context creation
     int knob_agg_direct;         // FZ_AGG_DIRECT: -1 = never the slice-free aggregation kernel, 2 | 4 = always, with that many rows per tile (0 = by size)
-    int knob_shake_full;         // FZ_SHAKE_FORM: 1 = lane pairs, 2 = whole state per lane (0 = by batch size)
+    int knob_shake_full;         // FZ_SHAKE_FORM: 1 = lane pairs, 2 = whole state per lane, 3 = a wave per signer (0 = by batch size)
     int knob_verify_ordered;     // FZ_VERIFY_ORDERED=1 (and every device that is not gfx950): acquire / release on verify_fused's arrival atomic
     int knob_unfused;            // FZ_UNFUSED=1: the multi-launch paths of keygen / verification / the coefficient-domain product (what degrees other than 64 / 256 take anyway)
     hipStream_t diag_stream;     // fz_diag_shader_clock: the probe's private stream and result words (created on first use)
@@ -172,6 +172,10 @@ void fz_mt_init_table(uint32_t *h_tab);                                         
 // d_state: [2 * nkeys][624] words of scratch for the two-kernel form, or NULL for the one-kernel form
 int fz_launch_mt_sample(fz_ctx *ctx, const unsigned long long *d_seeds, size_t nkeys, int degree, uint32_t bound, int kbits,
                         const uint32_t *d_init, int32_t *d_out, int *d_fail, uint32_t *d_state);
+bool fz_challenge_wave_ok(const fz_scheme_params *P);        // the fused one-wave-per-signer form takes these parameters
+int fz_launch_challenge_wave(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *d_pre, const uint8_t *d_msgs,
+                             const unsigned long long *d_off, uint8_t *d_pre_out, size_t N, size_t text_stride, int out_blocks,
+                             const uint32_t *d_tab, int32_t *d_coefs);
 int fz_launch_prehash(fz_ctx *ctx, const fz_scheme_params *P, const uint8_t *d_msgs, const unsigned long long *d_off, size_t N,
                       uint8_t *d_pre, uint32_t *d_dec);          // d_dec [N][16]: the integers in base 10^9 + chunk count
 void fz_challenge_weight_table(int index_bytes, int degree, uint32_t *h_tab);      // (degree + 1) * 16 words

@@ -137,6 +137,52 @@ def test_messages_hashed_on_the_device(secpar, coracle):
         dout.free()
 
 
+@pytest.mark.parametrize("form", [1, 2, 3])
+@pytest.mark.parametrize("secpar,n", [(128, 3), (128, 200), (256, 5), (256, 1024), (256, 1027)])
+def test_every_form_of_the_device_pipeline_agrees_with_the_host(form, secpar, n, coracle, monkeypatch):
+    """FZ_SHAKE_FORM = 1 (a Keccak state on a lane pair), 2 (on a lane), 3 (on a wave, the whole pipeline of a signer fused in
+    one kernel: fz_keccak_wave.h): the same digests (hashlib) and the same challenges as the host pipeline, from messages and
+    from digests, for signer counts that leave the last workgroup / wave partly empty."""
+    import hashlib
+    import fusion.fusion as F
+    import fusion_hip
+    from fusion_hip import hostpipe
+    params = F.fusion_setup(secpar, 11)
+    P = hostpipe.scheme_params(params)
+    monkeypatch.setenv("FZ_SHAKE_FORM", str(form))
+    ctx = fusion_hip.Context(params.modulus, params.degree, params.root, params.inv_root)      # a fresh context: the knob is read here
+    monkeypatch.delenv("FZ_SHAKE_FORM")
+    d, q = params.degree, params.modulus
+    rng = np.random.default_rng(1000 * form + n)
+    vk = rng.integers(-(q // 2), q // 2 + 1, size=(n, 2, d)).astype(np.int32)
+    vk[0, 0, :8] = [0, 1, -1, 9, -10, 99999, -100000, q // 2]
+    vk[-1, 1, -4:] = [-(q // 2), 1000000000, -999999999, 0]
+    vk[n // 2] = 0                                           # the shortest text: every value one digit
+    vk[n // 3] = -(q // 2)                                   # the longest: every value a sign and ten digits
+    lens = [0, 1, 131, 132, 133, 134, 267, 268, 269, 700]
+    msgs = ["".join(chr(33 + (5 * i + k) % 90) for k in range(lens[i % len(lens)])) for i in range(n)]
+    coefs, pre = hostpipe.challenge_coefficients(P, vk[:, 0], vk[:, 1], msgs)
+    want = coracle.ntt_forward(coefs, q, params.root).reshape(n, d)
+    blob, off = hostpipe._pack_messages(msgs)
+    dvk = fusion_hip.DeviceBuffer.from_numpy(ctx, vk)
+    dout = fusion_hip.DeviceBuffer(ctx, n * d * 4)
+    try:
+        got_pre = ctx.challenge_msgs_dev(P, dvk.ptr, blob, off, n, dout.ptr, want_prehash=True)
+        dst = bytes(P.sign_pre_hash_dst)
+        for i in (0, 1, 2, n - 1):
+            assert bytes(got_pre[i]) == hashlib.sha3_256(dst + b"," + msgs[i].encode()).digest()
+        assert np.array_equal(got_pre, pre)
+        got = dout.to_numpy(np.int32, (n, d))
+        assert np.array_equal(got, want), np.argwhere((got != want).any(axis=1))[:5]
+        ctx.h2d(dout.ptr, np.zeros((n, d), np.int32))
+        ctx.challenge_dev(P, dvk.ptr, pre, n, dout.ptr, transform=False)
+        assert np.array_equal(dout.to_numpy(np.int32, (n, d)), coefs)
+    finally:
+        dvk.free()
+        dout.free()
+        ctx.close()
+
+
 def test_message_entry_rejects_bad_arguments():
     import fusion_hip
     from fusion_hip._lib import FZ_E_BADARG

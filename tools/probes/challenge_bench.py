@@ -20,9 +20,10 @@ def main():
     params = F.fusion_setup(secpar, 7)
     P = hostpipe.scheme_params(params)
     ctx = fusion_hip.get_context(params.modulus, params.degree, params.root, params.inv_root)
+    print(f"secpar {secpar}, FZ_SHAKE_FORM={os.environ.get('FZ_SHAKE_FORM', '(by batch size)')}", flush=True)
     d, q = params.degree, params.modulus
     rng = np.random.default_rng(1)
-    for n in (256, 1024, 4096, 16384, 65536):
+    for n in (256, 1024, 2048, 3072, 4096, 16384, 65536):
         vk = rng.integers(-(q // 2), q // 2 + 1, size=(n, 2, d)).astype(np.int32)
         msgs = [f"synthetic message {i:06d}" for i in range(n)]
         t0 = time.perf_counter()

@@ -412,6 +412,10 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     free(ctx->pool_blocks);
     free(ctx->live_blocks);          // (blocks the caller never freed stay the caller's)
     if (ctx->d_chal_tab) (void)hipFree(ctx->d_chal_tab);
+    for (auto &st : ctx->chal_stage) {
+        if (st.ev) { if (st.busy) (void)hipEventSynchronize(st.ev); (void)hipEventDestroy(st.ev); }
+        if (st.h) (void)hipHostFree(st.h);
+    }
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
     if (ctx->diag_stream) (void)hipStreamDestroy(ctx->diag_stream);
     if (ctx->d_mt_init) (void)hipFree(ctx->d_mt_init);
@@ -1295,6 +1299,22 @@ int fz_ntt_multi(fz_ctx *ctx, const fz_ntt_job *h_jobs, size_t n_jobs) {
     return fz_launch_ntt_multi(ctx, J);
 }
 
+// the next staging slot, at least `bytes` long and no longer read by any launch (fz_internal.h)
+static int challenge_stage(fz_ctx *ctx, size_t bytes, fz_ctx::FzStage **out) {
+    fz_ctx::FzStage &st = ctx->chal_stage[ctx->chal_stage_next];
+    ctx->chal_stage_next ^= 1;
+    if (!st.ev) FZ_HIP(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming), "staging event");
+    if (st.busy) { FZ_HIP(hipEventSynchronize(st.ev), "staging slot still in use"); st.busy = 0; }
+    if (st.bytes < bytes) {
+        if (st.h) { FZ_HIP(hipHostFree(st.h), "staging free"); st.h = nullptr; st.bytes = 0; }
+        const size_t want = std::max<size_t>((bytes + 65535) & ~(size_t)65535, 256 << 10);
+        FZ_HIP(hipHostMalloc((void **)&st.h, want, hipHostMallocDefault), "staging alloc");
+        st.bytes = want;
+    }
+    *out = &st;
+    return FZ_OK;
+}
+
 // ---- the challenge pipeline on the device (device half) ---------------------------------------------
 // the pre-hashed messages come either as h_prehash [N][32] (computed by the caller, fz_hash_messages) or are computed here,
 // on the device, from the messages themselves (h_msgs back to back, h_msg_off [N + 1]); h_prehash_out (optional, with
@@ -1342,8 +1362,34 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
     // Which form.  Up to kWaveFormMax signers per call every signer gets a WAVE (fz_launch_challenge_wave: the chain of ~108
     // permutations at 24 instructions + 4 gathers per round, text and stream in LDS); beyond, the three-kernel pipeline with 32
     // or 64 signers per wave has the higher throughput (profiles/r06_challenge_pipeline.txt).
-    constexpr size_t kWaveFormMax = 3072;
+    constexpr size_t kWaveFormMax = 4608;                    // 4096 signers: 0.67 ms against 0.77; 5120: 0.85 against 0.79
     const bool wave_form = fz_challenge_wave_ok(P) && (ctx->knob_shake_full == 3 || (ctx->knob_shake_full == 0 && N <= kWaveFormMax));
+    if (wave_form) {
+        // One launch, nothing uploaded: the kernel reads the messages (or digests) from pinned host memory and leaves the
+        // digests there.  The call returns without synchronising unless the caller wants the digests.
+        const size_t msg_bytes = h_prehash ? 0 : h_msg_off[N] - h_msg_off[0];
+        const size_t o_pre = 0, o_off = N * 32, o_msg = o_off + (N + 1) * 8;
+        fz_ctx::FzStage *st = nullptr;
+        FZ_TRY(challenge_stage(ctx, o_msg + msg_bytes + 64, &st));
+        if (h_prehash) {
+            memcpy(st->h + o_pre, h_prehash, N * 32);
+        } else {
+            static_assert(sizeof(size_t) == sizeof(unsigned long long), "offsets travel as 64-bit words");
+            memcpy(st->h + o_off, h_msg_off, (N + 1) * 8);
+            if (msg_bytes) memcpy(st->h + o_msg, h_msgs + h_msg_off[0], msg_bytes);
+        }
+        int rc = fz_launch_challenge_wave(ctx, P, d_vk, h_prehash ? st->h + o_pre : nullptr, st->h + o_msg, (const unsigned long long *)(st->h + o_off),
+                                          (!h_prehash && h_prehash_out) ? st->h + o_pre : nullptr, N, text_stride, out_blocks, ctx->d_chal_tab, d_out);
+        if (rc == FZ_OK && transform) rc = fz_launch_ntt(ctx, d_out, d_out, N, false);
+        FZ_HIP(hipEventRecord(st->ev, ctx->stream), "staging event record");
+        st->busy = 1;
+        if (rc != FZ_OK) return rc;
+        if (!h_prehash && h_prehash_out) {
+            FZ_HIP(hipStreamSynchronize(ctx->stream), "digest sync");
+            memcpy(h_prehash_out, st->h + o_pre, N * 32);
+        }
+        return FZ_OK;
+    }
     // signers per pass: 65536 = two waves of 32 signers on each of the chip's 1024 SIMDs (a second wave per SIMD fills the
     // issue slots one wave alone leaves empty); bounds the scratch at ~16 KB per signer
     const size_t chunk = 65536;
@@ -1351,8 +1397,8 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
         const size_t n = std::min(chunk, N - base);
         const size_t xstride = (n + 63) & ~(size_t)63;
         const size_t o_pre = 0, o_nb = (n * 32 + 255) & ~(size_t)255, o_text = o_nb + ((n * 4 + 255) & ~(size_t)255);
-        const size_t o_xof = wave_form ? o_text : o_text + ((n * text_stride + 255) & ~(size_t)255);       // (the wave form keeps text and stream in LDS)
-        const size_t o_off = wave_form ? o_xof : o_xof + ((((size_t)out_blocks * 34 + 1) * xstride * 4 + 255) & ~(size_t)255);    // + one spare word row (decoder)
+        const size_t o_xof = o_text + ((n * text_stride + 255) & ~(size_t)255);
+        const size_t o_off = o_xof + ((((size_t)out_blocks * 34 + 1) * xstride * 4 + 255) & ~(size_t)255);    // + one spare word row (decoder)
         const size_t msg_bytes = h_prehash ? 0 : h_msg_off[base + n] - h_msg_off[base];
         const size_t o_dec = o_off + (((n + 1) * 8 + 255) & ~(size_t)255);              // [n][16] words: the integers in base 10^9
         const size_t o_msg = o_dec + n * 64;
@@ -1367,23 +1413,11 @@ static int challenge_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *
             FZ_HIP(hipMemcpyAsync(sp + o_off, h_msg_off + base, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream), "upload of the message offsets");
             if (msg_bytes)
                 FZ_HIP(hipMemcpyAsync(sp + o_msg, h_msgs + h_msg_off[base], msg_bytes, hipMemcpyHostToDevice, ctx->stream), "upload of the messages");
-            if (!wave_form) {
-                FZ_TRY(fz_launch_prehash(ctx, P, sp + o_msg, (const unsigned long long *)(sp + o_off), n, sp + o_pre, (uint32_t *)(sp + o_dec)));
-                if (h_prehash_out)
-                    FZ_HIP(hipMemcpyAsync(h_prehash_out + 32 * base, sp + o_pre, n * 32, hipMemcpyDeviceToHost, ctx->stream), "download of the pre-hashed messages");
-            }
+            FZ_TRY(fz_launch_prehash(ctx, P, sp + o_msg, (const unsigned long long *)(sp + o_off), n, sp + o_pre, (uint32_t *)(sp + o_dec)));
+            if (h_prehash_out)
+                FZ_HIP(hipMemcpyAsync(h_prehash_out + 32 * base, sp + o_pre, n * 32, hipMemcpyDeviceToHost, ctx->stream), "download of the pre-hashed messages");
         }
         FZ_HIP(hipStreamSynchronize(ctx->stream), "upload sync");      // the caller's buffers have been consumed when this returns
-        if (wave_form) {
-            FZ_TRY(fz_launch_challenge_wave(ctx, P, d_vk + base * 2 * (size_t)P->degree, h_prehash ? sp + o_pre : nullptr, sp + o_msg,
-                                            (const unsigned long long *)(sp + o_off), h_prehash_out ? sp + o_pre : nullptr, n, text_stride,
-                                            out_blocks, ctx->d_chal_tab, d_out + base * (size_t)P->degree));
-            if (!h_prehash && h_prehash_out) {                          // the digests are the kernel's: the caller's buffer is filled when this returns
-                FZ_HIP(hipMemcpyAsync(h_prehash_out + 32 * base, sp + o_pre, n * 32, hipMemcpyDeviceToHost, ctx->stream), "download of the pre-hashed messages");
-                FZ_HIP(hipStreamSynchronize(ctx->stream), "download sync");
-            }
-            continue;
-        }
         FZ_TRY(fz_launch_challenge(ctx, P, d_vk + base * 2 * (size_t)P->degree, sp + o_pre,
                                    h_prehash ? nullptr : (const uint32_t *)(sp + o_dec), n, sp + o_text, text_stride,
                                    (int *)(sp + o_nb), (uint32_t *)(sp + o_xof), xstride, out_blocks, ctx->d_chal_tab,

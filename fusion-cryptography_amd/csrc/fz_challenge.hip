@@ -76,15 +76,28 @@ constexpr int kDecStride = 16;               // uint32 per signer in the decimal
 // aux[0..9]: the pre-hashed integer in base 10^9 (chunks, least significant first) and the chunk count at [9].
 __device__ __forceinline__ int vk_text_wave(uint8_t *buf, size_t cap, const uint32_t *aux, const int32_t *row, int degree, const VkTextParts &T,
                                             int lane) {
-    for (size_t o = (size_t)lane * 16; o < cap; o += 64 * 16) *reinterpret_cast<int4 *>(buf + o) = make_int4(0, 0, 0, 0);
     const int nvals = 2 * degree;
-    const int vpl = nvals >= 64 ? nvals / 64 : 1;               // values per lane (a lane never straddles the two halves)
+    const int vpl = nvals >= 64 ? nvals / 64 : 1;               // values per lane, at most 8 (a lane never straddles the two halves)
     const int k0 = lane * vpl;
+    // everything that comes from memory is requested first: the lane's key values and its bytes of the fixed pieces (a load
+    // where the byte is written is a round trip per loop iteration: most of the 9 us this function took for one signer)
+    int32_t vals[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) vals[t] = (t < vpl && k0 + t < nvals) ? row[k0 + t] : 0;
+    uint8_t f0[6], f1[6], f2;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        f0[t] = lane + 64 * t < T.n0 ? (uint8_t)T.s0[lane + 64 * t] : (uint8_t)0;
+        f1[t] = lane + 64 * t < T.n1 ? (uint8_t)T.s1[lane + 64 * t] : (uint8_t)0;
+    }
+    f2 = lane < T.n2 ? (uint8_t)T.s2[lane] : (uint8_t)0;
+    for (size_t o = (size_t)lane * 16; o < cap; o += 64 * 16) *reinterpret_cast<int4 *>(buf + o) = make_int4(0, 0, 0, 0);
     // pass 1: lengths (digits + ", " unless last of its half)
     int mine = 0;
-    for (int t = 0; t < vpl; ++t) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
         const int k = k0 + t;
-        if (k < nvals) mine += dec_len(row[k]) + (((k + 1) % degree) ? 2 : 0);
+        if (t < vpl && k < nvals) mine += dec_len(vals[t]) + (((k + 1) % degree) ? 2 : 0);
     }
     int incl = mine;                                            // inclusive scan over the wave
 #pragma unroll
@@ -99,20 +112,22 @@ __device__ __forceinline__ int vk_text_wave(uint8_t *buf, size_t cap, const uint
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // pass 2: characters, last digit first
-    for (int t = 0; t < vpl; ++t) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
         const int k = k0 + t;
-        if (k >= nvals) break;
-        const int v = row[k];
-        const int n = dec_len(v);
-        unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
-        int p = pos + n;
-        do {
-            buf[--p] = (uint8_t)('0' + u % 10u);
-            u /= 10u;
-        } while (u);
-        if (v < 0) buf[--p] = '-';
-        pos += n;
-        if ((k + 1) % degree) { buf[pos] = ','; buf[pos + 1] = ' '; pos += 2; }
+        if (t < vpl && k < nvals) {
+            const int v = vals[t];
+            const int n = dec_len(v);
+            unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+            int p = pos + n;
+            do {
+                buf[--p] = (uint8_t)('0' + u % 10u);
+                u /= 10u;
+            } while (u);
+            if (v < 0) buf[--p] = '-';
+            pos += n;
+            if ((k + 1) % degree) { buf[pos] = ','; buf[pos + 1] = ' '; pos += 2; }
+        }
     }
     // fixed pieces and the decimal of the pre-hashed message (lane c writes chunk c: 9 digits, the leading chunk as many
     // as it has)
@@ -120,9 +135,13 @@ __device__ __forceinline__ int vk_text_wave(uint8_t *buf, size_t cap, const uint
     const int top = dec_len((int)aux[nch - 1]);                  // < 10^9: fits an int
     const int tl = top + 9 * (nch - 1);
     const int at1 = T.n0 + left_total, at2 = T.n0 + T.n1 + total_vals, at3 = at2 + T.n2;
-    for (int c = lane; c < T.n0; c += 64) buf[c] = (uint8_t)T.s0[c];
-    for (int c = lane; c < T.n1; c += 64) buf[at1 + c] = (uint8_t)T.s1[c];
-    for (int c = lane; c < T.n2; c += 64) buf[at2 + c] = (uint8_t)T.s2[c];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int c = lane + 64 * t;
+        if (c < T.n0) buf[c] = f0[t];
+        if (c < T.n1) buf[at1 + c] = f1[t];
+    }
+    if (lane < T.n2) buf[at2 + lane] = f2;
     if (lane < nch) {
         unsigned u = aux[lane];
         const int nd = (lane == nch - 1) ? top : 9;
@@ -626,23 +645,33 @@ __global__ __launch_bounds__(64 * W) void challenge_wave_kernel(const int32_t *v
         const unsigned long long len = off[s + 1] - off[s];
         const uint8_t *m = msgs + (off[s] - off[0]);
         const unsigned long long nb = (len + 4 + kRate - 1) / kRate, last = nb * kRate - 1;      // 3 prefix bytes + message + the suffix byte
-        auto byte_at = [&](unsigned long long p) -> uint32_t {
-            uint32_t v;
-            if (p < 3) {
-                v = p == 0 ? dst0 : (p == 1 ? dst1 : 0x2cu);
-            } else {
-                const unsigned long long k = p - 3;
-                v = k < len ? (uint32_t)m[k] : (k == len ? 0x06u : 0u);
-            }
-            return p == last ? (v | 0x80u) : v;
-        };
+        // a block's 136 bytes are put together in LDS by the whole wave -- byte p of the stream by lane p mod 64, so that the
+        // message is read in three coalesced requests per block (it may sit in pinned HOST memory: fz_capi.hip) -- and taken
+        // from there as the rate's 17 words
 #pragma unroll 1
         for (unsigned long long b = 0; b < nb; ++b) {
-            if (ab) {
-                const unsigned long long q = b * kRate + 8ull * (unsigned)K.word;
-                K.lo ^= byte_at(q) | (byte_at(q + 1) << 8) | (byte_at(q + 2) << 16) | (byte_at(q + 3) << 24);
-                K.hi ^= byte_at(q + 4) | (byte_at(q + 5) << 8) | (byte_at(q + 6) << 16) | (byte_at(q + 7) << 24);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int idx = lane + 64 * t;
+                if (idx < kRate) {
+                    const unsigned long long p = b * kRate + (unsigned)idx;
+                    uint32_t v;
+                    if (p < 3) {
+                        v = p == 0 ? dst0 : (p == 1 ? dst1 : 0x2cu);
+                    } else {
+                        const unsigned long long k = p - 3;
+                        v = k < len ? (uint32_t)m[k] : (k == len ? 0x06u : 0u);
+                    }
+                    buf[idx] = (uint8_t)(p == last ? (v | 0x80u) : v);
+                }
             }
+            wave_sync();
+            if (ab) {
+                const uint2 w = *reinterpret_cast<const uint2 *>(buf + 8 * K.word);
+                K.lo ^= w.x;
+                K.hi ^= w.y;
+            }
+            wave_sync();
             K.permute();
         }
         if (K.main && K.word < 4) {
@@ -653,16 +682,27 @@ __global__ __launch_bounds__(64 * W) void challenge_wave_kernel(const int32_t *v
         K.lo = K.hi = 0u;
     }
     wave_sync();
-    // str(int.from_bytes(digest, "little")): base 10^9 chunks, one lane (9 rounds of an 8-limb short division)
-    if (lane == 0) {
-        uint32_t limb[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) limb[t] = aux[t];
-        uint32_t chunk[9];
-        const int nch = u256_to_base1e9(limb, chunk);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) aux[t] = chunk[t];
-        aux[9] = (uint32_t)nch;
+    // str(int.from_bytes(digest, "little")): base 10^9 chunks.  The nine rounds of the eight-limb short division as a
+    // systolic array: lane t owns limb t, the remainder travels from lane t + 1 to lane t (one DPP read), so lane t runs
+    // round r at step r + 7 - t and the 72 dependent divisions of one lane become 16 steps of the wave (4.6 -> ~1 us).
+    {
+        uint32_t limb = lane < 8 ? aux[lane] : 0u, rem = 0u;
+        wave_sync();                                             // every limb has been read before aux is rewritten
+#pragma unroll 1
+        for (int step = 0; step < 16; ++step) {
+            const int r = step - (7 - lane);                     // this lane's round
+            const uint32_t rin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rem, 0x101, 0xf, 0xf, true);       // lane t + 1's remainder
+            const unsigned long long cur = ((unsigned long long)rin << 32) | limb;
+            const uint32_t q = (uint32_t)(cur / 1000000000ull);
+            const bool on = lane < 8 && r >= 0 && r < 9;
+            rem = on ? (uint32_t)(cur - (unsigned long long)q * 1000000000ull) : 0u;
+            if (on) limb = q;
+            if (on && lane == 0) aux[r] = rem;
+        }
+        wave_sync();
+        const uint32_t mine = lane < 9 ? aux[lane] : 0u;
+        const unsigned long long nz = __ballot(mine != 0u);
+        if (lane == 0) aux[9] = nz ? (uint32_t)(64 - __builtin_clzll(nz)) : 1u;
     }
     wave_sync();
     // ---- the text, absorbed from LDS ----
@@ -723,8 +763,19 @@ __global__ __launch_bounds__(64 * W) void challenge_wave_kernel(const int32_t *v
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int lim = draws - c * 64 < 64 ? draws - c * 64 : 64;
+        int t = 0;
 #pragma unroll 1
-        for (int t = 0; t < lim; ++t) {
+        for (; t + 4 <= lim; t += 4) {                           // four indices read first: the swaps are one compare pair + two selects each
+            const int i = d - 1 - (c * 64 + t);
+            const int j0 = __builtin_amdgcn_readlane((int)jv[c], t), j1 = __builtin_amdgcn_readlane((int)jv[c], t + 1),
+                      j2 = __builtin_amdgcn_readlane((int)jv[c], t + 2), j3 = __builtin_amdgcn_readlane((int)jv[c], t + 3);
+            pos = pos == i ? j0 : (pos == j0 ? i : pos);
+            pos = pos == i - 1 ? j1 : (pos == j1 ? i - 1 : pos);
+            pos = pos == i - 2 ? j2 : (pos == j2 ? i - 2 : pos);
+            pos = pos == i - 3 ? j3 : (pos == j3 ? i - 3 : pos);
+        }
+#pragma unroll 1
+        for (; t < lim; ++t) {
             const int i = d - 1 - (c * 64 + t);
             const int j = __builtin_amdgcn_readlane((int)jv[c], t);
             pos = pos == i ? j : (pos == j ? i : pos);

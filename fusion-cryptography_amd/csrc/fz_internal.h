@@ -76,6 +76,13 @@ struct fz_ctx {
     uint32_t *d_mt_init;         // MT19937 state after init_genrand(19650218) (fz_sample_secret_polys_dev), lazily
     uint32_t *d_chal_tab;        // weight table of the challenge decoder (fz_challenge.hip), built on first use
     int chal_tab_ib, chal_tab_degree;
+    // Pinned, device-visible staging for the SMALL host inputs of the fused challenge kernel (message bytes + offsets, or the
+    // digests): the kernel reads them in place over the host link (three coalesced requests per wave), so a call uploads
+    // nothing and does not synchronise.  Two slots in turn; a slot's event is recorded after the launch that reads it and
+    // waited for before the slot is written again.
+    struct FzStage { uint8_t *h; size_t bytes; hipEvent_t ev; int busy; };
+    FzStage chal_stage[2];
+    int chal_stage_next;
     // benchmarking knobs, read ONCE at context creation
     int knob_agg_direct;         // FZ_AGG_DIRECT: -1 = never the slice-free aggregation kernel, 2 | 4 = always, with that many rows per tile (0 = by size)
     int knob_shake_full;         // FZ_SHAKE_FORM: 1 = lane pairs, 2 = whole state per lane, 3 = a wave per signer (0 = by batch size)

@@ -23,7 +23,8 @@ def main():
     print(f"secpar {secpar}, FZ_SHAKE_FORM={os.environ.get('FZ_SHAKE_FORM', '(by batch size)')}", flush=True)
     d, q = params.degree, params.modulus
     rng = np.random.default_rng(1)
-    for n in (256, 1024, 2048, 3072, 4096, 16384, 65536):
+    sizes = [int(a) for a in sys.argv[2:]] or [256, 1024, 2048, 3072, 4096, 16384, 65536]
+    for n in sizes:
         vk = rng.integers(-(q // 2), q // 2 + 1, size=(n, 2, d)).astype(np.int32)
         msgs = [f"synthetic message {i:06d}" for i in range(n)]
         t0 = time.perf_counter()

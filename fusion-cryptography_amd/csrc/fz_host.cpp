@@ -75,112 +75,101 @@ const uint64_t RC[24] = {
 void keccak_f_base(uint64_t s[25]) { FZ_KECCAK_BODY }
 __attribute__((target("bmi,bmi2"))) void keccak_f_bmi2(uint64_t s[25]) { FZ_KECCAK_BODY }
 
-// ---- Keccak-f[1600] on AVX-512 (one state): a plane (the five lanes of one row y) per 512-bit register ----------------------
-// hash_ag (fusion/fusion.py:632-652) is ONE serial sponge over every signer's text, so the only lever on the end-to-end
-// aggregate / verify latency is the permutation itself.  Per round, with R[y] slot x = a[x][y]:
-//   theta  C = R0 ^ R1 ^ R2 ^ R3 ^ R4 (two vpternlogq), D from two lane rotations of C (vpermq) and a 1-bit rotate,
-//          R[y] ^= D folded into one vpternlogq per plane;
-//   rho    one vprolvq per plane (per-lane rotation counts);
-//   pi     B[X = y][Y = 2x + 3y] = R[y][x]: an in-register vpermq turns plane y into COLUMN X = y of B (slot = Y), so that
-//   chi    b ^ (~b' & b'') runs register-wise (vpternlogq 0xD2) on columns X, X + 1, X + 2, no shuffles;
-//   iota   into lane (0, 0);
-//   back to planes: a 5 x 5 transpose as rotate-by-X (vpermq), 20 masked blends (slot s of plane Y comes from column
-//          (s - Y) mod 5), rotate-by-Y (vpermq).
-// 54 instructions per round, 13 of them cross-lane permutes.  Index tables were derived and checked lane by lane against the
-// scalar round before this was written (they are the PI / ROTA / ROTC tables below); hashlib pins all three variants in
-// tests/test_host_pipeline.py, and a self-test at load time keeps a miscompiled variant from ever being selected.
+// ---- the block loop in assembly (x86-64) --------------------------------------------------------------------------------
+// hash_ag (fusion/fusion.py:632-652) is ONE serial sponge over every signer's text (~130 000 permutations per 1024 signers), so
+// the only lever on the end-to-end aggregate / verify latency is the permutation on one host core.  What the GPU box's Zen 5
+// core does with it (tools/microbench/keccak_host.cpp, x64_throughput.cpp; profiles/r06_keccak_variants_gpu_host.txt):
+//   * the C form above, BMI:  35 cycles per round (169 ns).  Not the instruction count (a spill-free form with 40 fewer
+//     instructions takes the same time) and not the dependency chain: the integer cluster sustains 4.6 xor / andn and 2.75
+//     rorx per cycle, and a round is 130 of them;
+//   * a plane per zmm register (rounds 3-5): 235 ns -- vector integer instructions have 2 cycles of latency on this core and
+//     vpermq 5, and the plane form needs a 5 x 5 transpose every round;
+//   * one lane per xmm register, AVX-512VL (32 registers, three-input XOR and chi in one vpternlogq): 186 ns -- 90
+//     instructions per round, but only ~2.5 vector instructions retire per cycle;
+//   * fz_keccak_blocks_x64v (fz_keccak_x64.inc, generated by tools/gen_keccak_x64.py): BOTH clusters at once.  The state
+//     lives in two stack frames (a round reads one and writes the other), so a lane needs no register of either kind
+//     between rounds: three of a round's five output rows are computed in general registers, two in xmm registers (vpxorq
+//     with the lane as an 8-byte broadcast operand, vprolq, vpternlogq), the running column parities of both meet in the
+//     general registers: 27 cycles per round, 132 ns.  fz_keccak_blocks_x64 is the general-register half alone (BMI only).
+// Both keep the block loop inside (the state is copied in and out once per call) and are checked against the C form when
+// the library is loaded; hashlib pins every variant in tests/test_host_pipeline.py.
 #if defined(__x86_64__)
-#include <immintrin.h>
-__attribute__((target("avx512f,avx512vl,avx512dq,avx512bw"))) void keccak_f_avx512(uint64_t s[25]) {
-    const __mmask8 k5 = 0x1f;
-    __m512i r0 = _mm512_maskz_loadu_epi64(k5, s), r1 = _mm512_maskz_loadu_epi64(k5, s + 5), r2 = _mm512_maskz_loadu_epi64(k5, s + 10),
-            r3 = _mm512_maskz_loadu_epi64(k5, s + 15), r4 = _mm512_maskz_loadu_epi64(k5, s + 20);
-    const __m512i idx_m = _mm512_setr_epi64(4, 0, 1, 2, 3, 5, 6, 7), idx_p = _mm512_setr_epi64(1, 2, 3, 4, 0, 5, 6, 7);
-    const __m512i rho0 = _mm512_setr_epi64(0, 1, 62, 28, 27, 0, 0, 0), rho1 = _mm512_setr_epi64(36, 44, 6, 55, 20, 0, 0, 0),
-                  rho2 = _mm512_setr_epi64(3, 10, 43, 25, 39, 0, 0, 0), rho3 = _mm512_setr_epi64(41, 45, 15, 21, 8, 0, 0, 0),
-                  rho4 = _mm512_setr_epi64(18, 2, 61, 56, 14, 0, 0, 0);
-    // pi: column X slot Y = plane X slot (3Y + X) mod 5
-    const __m512i pi0 = _mm512_setr_epi64(0, 3, 1, 4, 2, 5, 6, 7), pi1 = _mm512_setr_epi64(1, 4, 2, 0, 3, 5, 6, 7),
-                  pi2 = _mm512_setr_epi64(2, 0, 3, 1, 4, 5, 6, 7), pi3 = _mm512_setr_epi64(3, 1, 4, 2, 0, 5, 6, 7),
-                  pi4 = _mm512_setr_epi64(4, 2, 0, 3, 1, 5, 6, 7);
-    // rotate the slots of column X by X (F[X][s] = E[X][(s - X) mod 5]) / of plane Y back by Y (R[Y][X] = T[Y][(X + Y) mod 5])
-    const __m512i ra1 = idx_m, ra2 = _mm512_setr_epi64(3, 4, 0, 1, 2, 5, 6, 7), ra3 = _mm512_setr_epi64(2, 3, 4, 0, 1, 5, 6, 7), ra4 = idx_p;
-    const __m512i rc1 = idx_p, rc2 = ra3, rc3 = ra2, rc4 = idx_m;
-    for (int round = 0; round < 24; ++round) {
-        // theta
-        __m512i c = _mm512_ternarylogic_epi64(r0, r1, r2, 0x96);
-        c = _mm512_ternarylogic_epi64(c, r3, r4, 0x96);
-        const __m512i cm = _mm512_permutexvar_epi64(idx_m, c);
-        const __m512i cp = _mm512_rol_epi64(_mm512_permutexvar_epi64(idx_p, c), 1);
-        r0 = _mm512_ternarylogic_epi64(r0, cm, cp, 0x96);
-        r1 = _mm512_ternarylogic_epi64(r1, cm, cp, 0x96);
-        r2 = _mm512_ternarylogic_epi64(r2, cm, cp, 0x96);
-        r3 = _mm512_ternarylogic_epi64(r3, cm, cp, 0x96);
-        r4 = _mm512_ternarylogic_epi64(r4, cm, cp, 0x96);
-        // rho + pi (plane y -> column X = y)
-        const __m512i q0 = _mm512_permutexvar_epi64(pi0, _mm512_rolv_epi64(r0, rho0)), q1 = _mm512_permutexvar_epi64(pi1, _mm512_rolv_epi64(r1, rho1)),
-                      q2 = _mm512_permutexvar_epi64(pi2, _mm512_rolv_epi64(r2, rho2)), q3 = _mm512_permutexvar_epi64(pi3, _mm512_rolv_epi64(r3, rho3)),
-                      q4 = _mm512_permutexvar_epi64(pi4, _mm512_rolv_epi64(r4, rho4));
-        // chi (register-wise) + iota
-        __m512i e0 = _mm512_ternarylogic_epi64(q0, q1, q2, 0xD2);
-        const __m512i e1 = _mm512_ternarylogic_epi64(q1, q2, q3, 0xD2), e2 = _mm512_ternarylogic_epi64(q2, q3, q4, 0xD2),
-                      e3 = _mm512_ternarylogic_epi64(q3, q4, q0, 0xD2), e4 = _mm512_ternarylogic_epi64(q4, q0, q1, 0xD2);
-        e0 = _mm512_xor_si512(e0, _mm512_maskz_set1_epi64(0x01, (long long)RC[round]));
-        // columns -> planes
-        const __m512i f0 = e0, f1 = _mm512_permutexvar_epi64(ra1, e1), f2 = _mm512_permutexvar_epi64(ra2, e2),
-                      f3 = _mm512_permutexvar_epi64(ra3, e3), f4 = _mm512_permutexvar_epi64(ra4, e4);
-        // plane Y, slot s <- column (s - Y) mod 5: masks select the slots each column contributes
-#define FZ_T(Y, A0, A1, A2, A3, A4) /* A_j = the column that feeds slot j */ \
-        _mm512_mask_blend_epi64(0x10, _mm512_mask_blend_epi64(0x0c, _mm512_mask_blend_epi64(0x02, A0, A1), _mm512_mask_blend_epi64(0x08, A2, A3)), A4)
-        const __m512i t0 = FZ_T(0, f0, f1, f2, f3, f4), t1 = FZ_T(1, f4, f0, f1, f2, f3), t2 = FZ_T(2, f3, f4, f0, f1, f2),
-                      t3 = FZ_T(3, f2, f3, f4, f0, f1), t4 = FZ_T(4, f1, f2, f3, f4, f0);
-#undef FZ_T
-        r0 = t0;
-        r1 = _mm512_permutexvar_epi64(rc1, t1);
-        r2 = _mm512_permutexvar_epi64(rc2, t2);
-        r3 = _mm512_permutexvar_epi64(rc3, t3);
-        r4 = _mm512_permutexvar_epi64(rc4, t4);
-    }
-    _mm512_mask_storeu_epi64(s, k5, r0);
-    _mm512_mask_storeu_epi64(s + 5, k5, r1);
-    _mm512_mask_storeu_epi64(s + 10, k5, r2);
-    _mm512_mask_storeu_epi64(s + 15, k5, r3);
-    _mm512_mask_storeu_epi64(s + 20, k5, r4);
+extern "C" {
+extern const uint64_t fz_keccak_rc_x64[24] __attribute__((visibility("hidden")));
+const uint64_t fz_keccak_rc_x64[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+    0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+    0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+    0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+void fz_keccak_blocks_x64(uint64_t *s, const uint8_t *in, uint8_t *out, size_t nblocks) __attribute__((visibility("hidden")));
+void fz_keccak_blocks_x64v(uint64_t *s, const uint8_t *in, uint8_t *out, size_t nblocks) __attribute__((visibility("hidden")));
 }
+#include "fz_keccak_x64.inc"
 #endif
 
-typedef void (*keccak_fn)(uint64_t *);
+// nblocks times { s[0..16] ^= the next 136 bytes of in (if in); Keccak-f[1600](s); the next 136 bytes of out = s[0..16] (if out) }
+typedef void (*keccak_blocks_fn)(uint64_t *, const uint8_t *, uint8_t *, size_t);
+template <void (*F)(uint64_t *)>
+void blocks_c(uint64_t *s, const uint8_t *in, uint8_t *out, size_t nblocks) {
+    for (size_t b = 0; b < nblocks; ++b) {
+        if (in) {
+            for (int i = 0; i < 17; ++i) {
+                uint64_t w;
+                memcpy(&w, in + 8 * i, 8);
+                s[i] ^= w;
+            }
+            in += 136;
+        }
+        F(s);
+        if (out) {
+            memcpy(out, s, 136);
+            out += 136;
+        }
+    }
+}
 const char *g_keccak_name = "scalar";
 
 // the variant the sponges use: the fastest of those this CPU supports, MEASURED once at load time (a few microseconds
-// each) -- which of the scalar BMI2 form and the AVX-512 form wins depends on the core (cross-lane permute latency), and
-// FZ_KECCAK = scalar | bmi2 | avx512 overrides (tests run all three); a variant must first reproduce the scalar result
-keccak_fn pick_keccak() {
+// each); FZ_KECCAK = scalar | bmi2 | x64 | x64v overrides (tests run all four); a variant must first reproduce the C result
+keccak_blocks_fn pick_keccak() {
     __builtin_cpu_init();
-    struct Cand { const char *name; keccak_fn fn; };
-    std::vector<Cand> cands{{"scalar", keccak_f_base}};
-    if (__builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2")) cands.push_back({"bmi2", keccak_f_bmi2});
+    struct Cand { const char *name; keccak_blocks_fn fn; };
+    std::vector<Cand> cands{{"scalar", blocks_c<keccak_f_base>}};
+    const bool bmi = __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2");
+    if (bmi) cands.push_back({"bmi2", blocks_c<keccak_f_bmi2>});
 #if defined(__x86_64__)
-    if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512dq") &&
-        __builtin_cpu_supports("avx512bw"))
-        cands.push_back({"avx512", keccak_f_avx512});
+    if (bmi) cands.push_back({"x64", fz_keccak_blocks_x64});
+    if (bmi && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl")) cands.push_back({"x64v", fz_keccak_blocks_x64v});
 #endif
+    // four blocks absorbed and emitted: every path of the block loop
+    uint8_t text[4 * 136], want[4 * 136];
+    for (size_t i = 0; i < sizeof(text); ++i) text[i] = (uint8_t)(i * 131u + (i >> 5));
     uint64_t ref[25];
     for (int i = 0; i < 25; ++i) ref[i] = 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
-    keccak_f_base(ref);
+    blocks_c<keccak_f_base>(ref, text, want, 4);
     const char *force = getenv("FZ_KECCAK");
-    keccak_fn best = keccak_f_base;
+    keccak_blocks_fn best = blocks_c<keccak_f_base>;
     double best_t = 1e30;
     for (const Cand &c : cands) {
         uint64_t st[25];
+        uint8_t got[4 * 136];
         for (int i = 0; i < 25; ++i) st[i] = 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
-        c.fn(st);
-        if (memcmp(st, ref, sizeof(st)) != 0) continue;                    // never select a variant that disagrees
+        c.fn(st, text, got, 4);
+        uint64_t st2[25];
+        memcpy(st2, st, sizeof(st));
+        c.fn(st2, nullptr, nullptr, 1);
+        uint64_t ref2[25];
+        memcpy(ref2, ref, sizeof(ref));
+        keccak_f_base(ref2);
+        if (memcmp(st, ref, sizeof(st)) != 0 || memcmp(got, want, sizeof(got)) != 0 || memcmp(st2, ref2, sizeof(st2)) != 0)
+            continue;                                                      // never select a variant that disagrees
         if (force && strcmp(force, c.name) == 0) { g_keccak_name = c.name; return c.fn; }
         double t = 1e30;
         for (int pass = 0; pass < 3; ++pass) {
             const auto t0 = std::chrono::steady_clock::now();
-            for (int i = 0; i < 64; ++i) c.fn(st);
+            c.fn(st, nullptr, nullptr, 64);
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (dt < t) t = dt;
         }
@@ -188,7 +177,8 @@ keccak_fn pick_keccak() {
     }
     return best;
 }
-const keccak_fn keccak_f = pick_keccak();
+const keccak_blocks_fn keccak_blocks = pick_keccak();
+inline void keccak_f(uint64_t *s) { keccak_blocks(s, nullptr, nullptr, 1); }
 
 struct Sponge {
     uint64_t s[25];
@@ -197,7 +187,13 @@ struct Sponge {
     void absorb(const uint8_t *p, size_t n) {
         uint8_t *st = reinterpret_cast<uint8_t *>(s);       // little-endian host (x86-64)
         while (n) {
-            if (pos == 0 && n >= rate) {                    // whole blocks: lane-wise XOR
+            if (pos == 0 && n >= rate && rate == 136) {     // whole blocks: the block loop (the state stays in its frame)
+                const size_t nb = n / rate;
+                keccak_blocks(s, p, nullptr, nb);
+                p += nb * rate; n -= nb * rate;
+                continue;
+            }
+            if (pos == 0 && n >= rate) {                    // (another rate: lane-wise XOR, one permutation at a time)
                 for (size_t i = 0; i < rate / 8; ++i) {
                     uint64_t w;
                     memcpy(&w, p + 8 * i, 8);
@@ -223,6 +219,12 @@ struct Sponge {
     void squeeze(uint8_t *out, size_t n) {
         const uint8_t *st = reinterpret_cast<const uint8_t *>(s);
         while (n) {
+            if (pos == rate && n >= rate && rate == 136) {  // whole blocks: permute, emit, repeat inside the block loop
+                const size_t nb = n / rate;
+                keccak_blocks(s, nullptr, out, nb);
+                out += nb * rate; n -= nb * rate;           // pos stays == rate: the state's bytes have all been emitted
+                continue;
+            }
             if (pos == rate) { keccak_f(s); pos = 0; }
             size_t take = std::min(n, rate - pos);
             memcpy(out, st + pos, take);

@@ -58,7 +58,7 @@ def _pack_messages(messages):
 
 
 def keccak_variant() -> str:
-    """which Keccak-f[1600] the host sponges run in this process: "scalar" | "bmi2" | "avx512" (FZ_KECCAK forces one)"""
+    """which Keccak-f[1600] the host sponges run in this process: "scalar" | "bmi2" | "x64" | "x64v" (FZ_KECCAK forces one)"""
     return load_library().fz_keccak_variant().decode()
 
 

@@ -20,7 +20,8 @@ extern "C" {
 FZ_API int fz_runtime_info(fz_ctx *ctx, int *out_build_hip_version, int *out_runtime_hip_version, char *out_arch, size_t arch_cap);
 
 
-/* which Keccak-f[1600] the host sponges run: "scalar", "bmi2" or "avx512" -- the fastest this CPU supports, measured once when
+/* which Keccak-f[1600] the host sponges run: "scalar", "bmi2" (the C form), "x64" (assembly block loop, BMI) or "x64v" (the same
+ * with two of five rows per round in xmm registers, AVX-512VL) -- the fastest this CPU supports, measured once when
  * the library is loaded (FZ_KECCAK=<name> forces one); every variant is checked against the scalar one before it can be chosen */
 FZ_API const char *fz_keccak_variant(void);
 

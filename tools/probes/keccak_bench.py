@@ -18,7 +18,7 @@ for _ in range(9):
 print("%%-8s -> runs %%-7s absorb %%.3f GB/s  (%%.0f ns per permutation, 136 bytes each)" %% (os.environ.get("FZ_KECCAK", "auto"), hostpipe.keccak_variant(),
       len(data) / best / 1e9, best / (len(data) / 136) * 1e9))
 ''' % ROOT
-for v in ("scalar", "bmi2", "avx512", None):
+for v in ("scalar", "bmi2", "x64", "x64v", None):
     env = dict(os.environ)
     env.pop("FZ_KECCAK", None)
     if v:

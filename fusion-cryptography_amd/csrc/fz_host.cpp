@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -646,11 +647,13 @@ int fz_aggregation_coefficients(const fz_scheme_params *P, const int32_t *h_vk_l
         return fz_set_error(FZ_E_BADARG, "bad argument");
     const int d = P->degree;
     // str(list(zip(keys, prehashed, challs))): "[(vk, int, SignatureChallenge(c_hat=poly)), (...)]"
-    // Two phases: every thread writes texts (1.5 ms per 1024 signers on 32 threads), then ONE sponge absorbs them in order
-    // (19.5 ms: the XOF is serial by construction, fusion.py:632-652).  Writing the texts a window ahead of the absorbing
-    // thread instead was tried and dropped: 20.4 ms at best, 24-46 ms when the writers shared cores with it.
+    // ONE sponge absorbs the items in order (the XOF is serial by construction, fusion.py:632-652: ~100 permutations per signer);
+    // the other threads write the items' texts ahead of it, claiming them in index order, and the sponge -- the calling thread --
+    // waits only for the item it needs next (in practice: for the first one).  Writing all texts first cost 1.5 ms per 1024
+    // signers in front of the sponge.  (Round 3's window scheme lost when writers and sponge shared cores: here the writers run
+    // ahead unthrottled -- 14 MB of text at most -- so they are done early, and with one thread everything stays sequential.)
     std::vector<std::string> items(N);
-    parallel_for(N, threads, [&](size_t i) {
+    auto write_item = [&](size_t i) {
         std::string &s = items[i];
         s.reserve(16384);
         s += "(";
@@ -660,16 +663,40 @@ int fz_aggregation_coefficients(const fz_scheme_params *P, const int32_t *h_vk_l
         s += ", SignatureChallenge(c_hat=";
         put_poly(s, *P, h_c_hat + i * (size_t)d);
         s += "))";
-    });
+    };
+    std::unique_ptr<std::atomic<unsigned char>[]> ready(new std::atomic<unsigned char>[N ? N : 1]);
+    for (size_t i = 0; i < N; ++i) ready[i].store(0, std::memory_order_relaxed);
+    std::atomic<size_t> next(0);
+    std::vector<std::thread> writers;
+    const size_t n_writers = (threads > 1 && N > 1) ? std::min<size_t>((size_t)threads - 1, N) : 0;
+    for (size_t t = 0; t < n_writers; ++t)
+        writers.emplace_back([&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= N) break;
+                write_item(i);
+                ready[i].store(1, std::memory_order_release);
+            }
+        });
     Sponge sp(136);
     uint8_t head[3] = {P->agg_xof_dst[0], P->agg_xof_dst[1], ','};
     sp.absorb(head, 3);
     sp.absorb(reinterpret_cast<const uint8_t *>("["), 1);
     for (size_t i = 0; i < N; ++i) {
+        if (n_writers == 0) {
+            write_item(i);
+        } else {
+            while (!ready[i].load(std::memory_order_acquire)) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+        }
         if (i) sp.absorb(reinterpret_cast<const uint8_t *>(", "), 2);
         sp.absorb(reinterpret_cast<const uint8_t *>(items[i].data()), items[i].size());
         std::string().swap(items[i]);
     }
+    for (auto &th : writers) th.join();
     sp.absorb(reinterpret_cast<const uint8_t *>("]"), 1);
     sp.finish(0x1f);
     const size_t n = agg_coef_bytes(*P);

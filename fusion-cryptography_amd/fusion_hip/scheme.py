@@ -26,6 +26,7 @@ class BatchScheme:
         self.params = params
         self.P = hostpipe.scheme_params(params)
         self.threads = threads or hostpipe.default_threads()
+        self._pool = None
         self.d, self.l, self.q = params.degree, params.num_rows_sk, params.modulus
         self._private = bool(private_context)
         if self._private:
@@ -49,6 +50,9 @@ class BatchScheme:
         if self._dA is not None:
             self._dA.free()
             self._dA = None
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         if self._private and self.ctx is not None:
             self.ctx.set_stream(0)
             self.ctx.stream_destroy(self._stream)
@@ -236,12 +240,21 @@ class BatchScheme:
         c_hat, pre = self.challenges(vk, messages)
         return DeviceArray.from_numpy(self.ctx, c_hat), c_hat, pre
 
-    def _alpha_coefficients(self, L, R, pre, c_hat, threads=None):
+    def _sort_async(self, L, R):
+        """sort_by_vk_string on a worker thread (the C call releases the GIL): it needs only the keys, so it runs beside the
+        device challenge pipeline instead of after it; -> a future of the order"""
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="fz-sort")
+        return self._pool.submit(hostpipe.sort_by_vk_string, self.P, L, R, self.threads)
+
+    def _alpha_coefficients(self, L, R, pre, c_hat, threads=None, order=None):
         """hash_ag without the transforms (fusion.py:632-652) for ONE aggregate: sort by str(vk) (fusion.py:661-663, :693), the
         one serial SHAKE-256 over the sorted list, decode; -> (order, alpha coefficient rows scattered back to the CALLERS'
         order).  The aggregate and the target are sums over signers, so nothing else ever has to be permuted."""
         threads = threads or self.threads
-        order = hostpipe.sort_by_vk_string(self.P, L, R, threads)
+        if order is None:
+            order = hostpipe.sort_by_vk_string(self.P, L, R, threads)
         alpha_sorted = hostpipe.aggregation_coefficients(self.P, L[order], R[order], pre[order], c_hat[order], threads)
         alpha = np.empty_like(alpha_sorted)
         alpha[order] = alpha_sorted
@@ -251,9 +264,14 @@ class BatchScheme:
         """Everything aggregate() and verify() derive from the keys and messages, device-resident and in the callers' order:
         -> (dC [N][d] challenges c_hat, dAl [N][d] aggregation coefficients alpha_hat, order, vkL, vkR host rows)."""
         vk, L, R = self._split_vk(vk)
-        dC, c_hat, pre = self._challenges_both(vk, messages)
+        order_f = self._sort_async(L, R)                    # beside the challenge pipeline: neither needs the other
         try:
-            order, alpha = self._alpha_coefficients(L, R, pre, c_hat)
+            dC, c_hat, pre = self._challenges_both(vk, messages)
+        except Exception:
+            order_f.result()
+            raise
+        try:
+            order, alpha = self._alpha_coefficients(L, R, pre, c_hat, order=order_f.result())
             dAl = DeviceArray.from_numpy(self.ctx, alpha)
             self.ctx.ntt_forward_dev(dAl.ptr, dAl.ptr, alpha.shape[0])          # in place
         except Exception:

@@ -58,7 +58,8 @@ METRIC = "batched NTT/s (deg-256, secpar=256) + aggregate sign+verify/sec at 1/2
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 B = 4096                       # BASELINE configs[1]
 SECPAR = 256
-MIN_REGION_MS = 20.0
+MIN_REGION_MS = 20.0           # the secondary legs' timed regions (many legs: the default run stays within minutes)
+HEADLINE_REGION_MS = 1000.0    # the region `value` comes from: long enough for the driver's clock and its GPU-busy sampler to see it
 NBATCH = 64                    # batches in the rotation: 3 x 64 x 4 MiB = 768 MiB, three times the 256 MB Infinity Cache
 LINE_LIMIT = 4096              # bytes of the compact line (tests/test_bench_line.py)
 
@@ -103,6 +104,8 @@ def parse(argv=None):
                     help="bind begin/end events to every k-th dispatch in the instrumented passes (1: every dispatch carries "
                          "its own completion signal, as under rocprofv3 --kernel-trace)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the pure-Python baseline sample")
+    ap.add_argument("--region-ms", type=float, default=HEADLINE_REGION_MS,
+                    help="minimum duration of the headline's timed region: the K steps are replayed until it is reached")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed run of the same steps before the W warmup steps: after idle the GPU needs tens of "
                          "milliseconds of load to reach its steady clocks")
@@ -152,8 +155,10 @@ def compact_line(full):
     out["config"] = _pick(full.get("config") or {}, ("workload", "batch", "degree", "modulus", "batches_rotated", "steps_per_launch",
                                                      "streams", "step", "launch"))
     roof = full.get("roofline") or {}
-    out["roofline"] = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch",
+    out["roofline"] = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "bytes_per_launch",
                                    "units_per_launch", "avg_launch_us", "in_flight", "operands", "timing"), 5)
+    if isinstance(out["roofline"].get("traffic_source"), str):      # `traffic` is NOT measured in this run: say where it comes from
+        out["roofline"]["traffic_source"] = out["roofline"]["traffic_source"][:80]
     dck = ("frac", "in_flight", "launch_us", "gap_us", "span_us")
     if isinstance(roof.get("device_clock"), dict):
         out["roofline"]["device_clock"] = _pick(roof["device_clock"], dck, 4)
@@ -166,7 +171,7 @@ def compact_line(full):
     if isinstance(cb, dict) and isinstance(cb.get("sample"), str):
         out["cpu_baseline"]["sample"] = cb["sample"][:160]
     for name, keys in (("sign_verify", ("value", "unit", "ms_per_step", "moved_frac_per_gpu", "aggregates", "signers_per_aggregate",
-                                        "collective", "cpu_value", "error")),
+                                        "scaling", "collective", "cpu_value", "error")),
                        ("sign_verify_1x1024", ("value", "ms_per_step", "moved_frac_per_gpu", "aggregates", "signers_per_aggregate")),
                        ("keygen_sign", ("value", "unit", "ms_per_step", "hbm_frac_per_gpu", "cpu_value", "error")),
                        ("single_stream", ("value", "unit", "ms_per_step", "frac")),
@@ -176,15 +181,19 @@ def compact_line(full):
         src = full.get(name)
         if isinstance(src, dict):
             sub = _pick(src, keys, 5)
-            for k in ("collective", "error", "unit"):
+            for k in ("collective", "error", "unit", "scaling"):
                 if isinstance(sub.get(k), str):
                     sub[k] = sub[k][:96]
             if sub:
                 out[name] = sub
     ranks = full.get("ranks")
     if isinstance(ranks, list):
-        out["ranks"] = [_pick(r, ("rank", "device_index", "pci_bus_id", "world_size_seen", "backend", "rccl_nranks", "rccl_version", "collective_check"))
-                        for r in ranks if isinstance(r, dict)]
+        # what every rank reports alike once ("same"), what differs per rank ("each": a rank whose communicator or self-check
+        # disagrees with the others shows up there): eight ranks in 600 bytes instead of 1500
+        rows = [_pick(r, ("rank", "device_index", "pci_bus_id", "world_size_seen", "backend", "rccl_nranks", "rccl_version", "collective_check"))
+                for r in ranks if isinstance(r, dict)]
+        same = {k: v for k, v in (rows[0].items() if rows else ()) if k not in ("rank", "device_index", "pci_bus_id") and all(r.get(k) == v for r in rows)}
+        out["ranks"] = {"n": len(rows), "same": same, "each": [{k: v for k, v in r.items() if k not in same} for r in rows]}
     for k in ("watchdog", "full"):
         if full.get(k):
             out[k] = str(full[k])[:200]
@@ -724,9 +733,9 @@ def main():
         torch.cuda.synchronize(dev)
         return a.elapsed_time(b_) / reps
 
-    def region(cs, mode_, K):
+    def region(cs, mode_, K, min_ms=MIN_REGION_MS):
         """W warmup steps, then the K steps -- dealt to the chains `cs`, every chain's share recorded into its own hipGraph
-        (M repetitions per recording for K < 1000) -- replayed for >= MIN_REGION_MS between two barriers.
+        (M repetitions per recording for K < 1000) -- replayed for >= min_ms between two barriers.
         -> dict(elapsed s (max over ranks), steps, per-chain event ms, per-chain steps, replays, M, shader clock)"""
         n_c = len(cs)
         for j, c_ in enumerate(cs):
@@ -776,7 +785,7 @@ def main():
         k_steps()
         torch.cuda.synchronize(dev)
         t_once = max(time.perf_counter() - t0, 1e-6)
-        launches = int(max_over_ranks(max(1.0, -(-MIN_REGION_MS * 1e-3 // t_once))))     # the same count on every rank
+        launches = int(max_over_ranks(max(1.0, -(-min_ms * 1e-3 // t_once))))     # the same count on every rank
         barrier()
         t0 = time.perf_counter()
         for c_ in cs:
@@ -820,7 +829,7 @@ def main():
     assert torch.equal(zs, xs), "INTT(NTT(x)) != x"
     zs.zero_()
     prewarm(chains, mode, args.prewarm_ms)
-    R = region(chains, mode, args.steps)
+    R = region(chains, mode, args.steps, args.region_ms)
     torch.cuda.synchronize(dev)
     assert torch.equal(zs, xs), "INTT(NTT(x)) != x after the timed region"
     elapsed, total_steps, launches, M, shader_mhz = R["elapsed"], R["steps"], R["replays"], R["M"], R["shader_mhz"]
@@ -978,7 +987,8 @@ def main():
                    "streams": S, "step": launch_text,
                    "parallelism": f"{world} independent rank(s); per rank {S} HIP stream(s), each walking its own {NBATCH // S} of the {NBATCH} batches",
                    "arithmetic": "exact integers carried in fp64 lanes (bit-identical to the reference's int arithmetic); int32 in and out",
-                   "launch": "one by one" if args.no_graph else f"{S} hipGraph(s) of {M}x{args.steps} steps together, {launches} replays",
+                   "launch": ("one by one" if args.no_graph else f"{S} hipGraph(s) of {M}x{args.steps} steps together, {launches} replays") +
+                             f": timed region {elapsed * 1e3:.0f} ms (>= {args.region_ms:.0f} ms asked)",
                    "prewarm_ms": args.prewarm_ms,
                    "host_threads_on": placement or "all allowed CPUs (no GPU-local NUMA node found, or FZ_NO_PIN=1)"},
         "ranks": ranks,

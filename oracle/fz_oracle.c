@@ -16,6 +16,15 @@
  * reference checkout).  The arithmetic is deliberately naive: 64-bit products and
  * the C '%' operator, one centred reduction per reference `cent` call, loops in the
  * reference's order.
+ *
+ * Validity range (coefficients are stored as int32, as the HIP path stores them): every odd
+ * modulus q < 2^32 and every int32 input, reduced or not.  The 64-bit products hold because
+ * |a| <= 2^31 and a table entry s < 2^32 give |a * s| <= 2^63 - 2^31, and adding |u| <= 2^31
+ * stays inside int64; the two places where an operand is a DIFFERENCE of coefficients
+ * (the inverse butterfly's (u - v) * s, up to 2^32 * 2^32) go through __int128.  Pinned for
+ * q in [2^31, 2^32) by tests/golden/generic.npz (reference outputs at q = 4294828033,
+ * d = 256 and 2048) in tests/test_oracle_golden.py.  Moduli of 2^32 and more are the
+ * pure-Python port's (oracle.py py_*: Python integers), pinned by the same file at q ~ 2^62.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -33,6 +42,13 @@ static inline int64_t pymod(int64_t v, int64_t q) {
  * (the branch-free shift form at :121-122 selects exactly this for every odd q). */
 ORC_API int64_t orc_cent(int64_t val, int64_t q) {
     int64_t y = pymod(val, q);
+    return (y > q / 2) ? y - q : y;
+}
+
+/* the same for a product that may pass 2^63 */
+static inline int64_t cent128(__int128 val, int64_t q) {
+    int64_t y = (int64_t)(val % q);
+    if (y < 0) y += q;
     return (y > q / 2) ? y - q : y;
 }
 
@@ -91,8 +107,8 @@ ORC_API void orc_ntt_inverse(int32_t *a, int n, int64_t q, const int64_t *itw) {
             for (int j = j1; j <= j2; ++j) {
                 int64_t u = a[j], v = a[j + t];
                 a[j] = (int32_t)orc_cent(u + v, q);
-                /* (u - v) * s: |u-v| < 2^32, s < 2^31 -> fits int64 */
-                a[j + t] = (int32_t)orc_cent((u - v) * s, q);
+                /* (u - v) * s: |u - v| < 2^32, s < q < 2^32 -> up to 2^64: through 128 bits */
+                a[j + t] = (int32_t)cent128((__int128)(u - v) * s, q);
             }
             j1 += 2 * t;
         }

@@ -11,6 +11,8 @@ copied.  The GPU box never sees the reference -- tests read only these fixtures.
 Files
   algebra.npz   twiddle tables, NTT/INTT, pointwise ops, schoolbook product, matrix product for
                 (PRIME, 64), (PRIME, 256) and a few small (q, d) pairs          [SURVEY G1,G2,G4,G5,G8]
+  generic.npz   the same for parameters beyond the scheme's: a prime in [2^31, 2^32) at d = 256 / 2048, a prime just below 2^62
+                at d = 64 / 1024, the scheme's prime with tables that are no root's powers; int64 arrays
   bulk.json     SHA-256 digests of B=4096 batches (fwd, inv, fwd.square.inv) + sample rows      [G3]
   scheme_128.npz / scheme_256.npz / scheme.json
                 end-to-end setup/keygen/sign/aggregate/verify with every intermediate array [G6]
@@ -145,6 +147,89 @@ def gen_algebra():
     out["small_tags"] = np.array(tags)
     np.savez_compressed(os.path.join(HERE, "algebra.npz"), **out)
     print("algebra.npz written:", len(out), "arrays")
+
+
+# ---- the parameter space beyond the scheme's two sets (round 5's generic paths) -------------------------
+# Numbers the REFERENCE produced for: a prime in [2^31, 2^32) at d = 256 and d = 2048 (the int32 kernels' widened range and the
+# one-workgroup-per-polynomial kernels), the scheme's prime with tables that are not the powers of any root (contexts built
+# from tables), a prime just below 2^62 at d = 64 and d = 1024 (the generic int64 path).  int64 arrays throughout.
+Q32 = 4294828033          # 2^32 - 139263 = 1 (mod 8192)
+Q62 = 4611686018427322369  # the last prime = 1 (mod 2^15) below 2^62 (tests/test_gpu_wide.py derives the same number)
+
+
+def _root(q, n):
+    for g in range(2, 5000):
+        r = pow(g, (q - 1) // (2 * n), q)
+        if pow(r, n, q) == q - 1:
+            return r
+    raise AssertionError("no root")
+
+
+def generic_case(out, tag, q, d, tw, itw, root, raw32, classes):
+    half = (q - 1) // 2
+    rng = np.random.default_rng(q % 100003 + d)
+    rows = [[0] * d, [half] * d, [-half] * d, [half if j % 2 == 0 else -half for j in range(d)], [1] + [0] * (d - 1)]
+    rows += [[int(v) for v in rng.integers(-half, half + 1, size=d)] for _ in range(5)]
+    if raw32:             # inputs the int32 kernels accept unreduced
+        rows += [[int(v) for v in rng.integers(-2**31, 2**31, size=d)], [2**31 - 1 if j % 2 else -2**31 for j in range(d)]]
+    out[f"{tag}_params"] = np.array([q, d, root or 0], dtype=np.int64)
+    out[f"{tag}_tw"] = np.array(tw, dtype=np.int64)
+    out[f"{tag}_itw"] = np.array(itw, dtype=np.int64)
+    out[f"{tag}_x"] = np.array(rows, dtype=np.int64)
+    out[f"{tag}_fwd"] = np.array([cooley_tukey_ntt(list(r), q, 2 * d, tw) for r in rows], dtype=np.int64)
+    out[f"{tag}_inv"] = np.array([gentleman_sande_intt(list(r), q, 2 * d, itw) for r in rows], dtype=np.int64)
+    if not classes:
+        return
+    inv_root = pow(root, q - 2, q)
+
+    def P(vals):
+        return PolyN(modulus=q, degree=d, root=root, inv_root=inv_root, root_order=2 * d, values=list(vals))
+    a_rows, b_rows = rows[1:10], rows[2:10] + rows[1:2]          # (never the all-zero row: see algebra_case)
+    out[f"{tag}_pw_a"] = np.array(a_rows, dtype=np.int64)
+    out[f"{tag}_pw_b"] = np.array(b_rows, dtype=np.int64)
+    out[f"{tag}_pw_mul"] = np.array([(P(a) * P(b)).values for a, b in zip(a_rows, b_rows)], dtype=np.int64)
+    out[f"{tag}_pw_add"] = np.array([(P(a) + P(b)).values for a, b in zip(a_rows, b_rows)], dtype=np.int64)
+    out[f"{tag}_pw_sub"] = np.array([(P(a) - P(b)).values for a, b in zip(a_rows, b_rows)], dtype=np.int64)
+    out[f"{tag}_pw_neg"] = np.array([(-P(a)).values for a in a_rows], dtype=np.int64)
+    rank = 3
+    A = [[int(v) for v in rng.integers(-half, half + 1, size=d)] for _ in range(rank)]
+    S = [[[int(v) for v in rng.integers(-half, half + 1, size=d)] for _ in range(rank)] for _ in range(2)]
+    outs = []
+    for b in range(2):
+        Am = GeneralMatrix(matrix=[[P(A[k]) for k in range(rank)]])
+        Sm = GeneralMatrix(matrix=[[P(S[b][k])] for k in range(rank)])
+        outs.append((Am * Sm).matrix[0][0].values)
+    out[f"{tag}_mv_A"] = np.array(A, dtype=np.int64)
+    out[f"{tag}_mv_S"] = np.array(S, dtype=np.int64)
+    out[f"{tag}_mv_out"] = np.array(outs, dtype=np.int64)
+    # transform() both ways through the classes (the constructor checks run on these parameters too)
+    c = PolyC(modulus=q, degree=d, root=root, inv_root=inv_root, root_order=2 * d, coefficients=list(rows[5]))
+    ch = transform(c)
+    assert ch.values == [int(v) for v in out[f"{tag}_fwd"][5]] and transform(ch).coefficients == rows[5]
+
+
+def gen_generic():
+    out, tags = {}, []
+    t0 = time.time()
+    for q, d, raw32 in ((Q32, 256, True), (Q32, 2048, True), (Q62, 64, False), (Q62, 1024, False)):
+        root = _root(q, d)
+        inv_root = pow(root, q - 2, q)
+        tw = bit_reverse_copy([pow(root, i, q) for i in range(d)])
+        itw = bit_reverse_copy([pow(inv_root, i, q) for i in range(d)])
+        tag = f"g{q}_{d}"
+        tags.append(tag)
+        generic_case(out, tag, q, d, tw, itw, root, raw32, True)
+        print(tag, "done", round(time.time() - t0, 1), "s", flush=True)
+    for d in (64, 256):                                   # the scheme's prime, tables that are no root's powers
+        rng = np.random.default_rng(4242 + d)
+        tw = [int(v) for v in rng.integers(0, PRIME, size=d)]
+        itw = [int(v) for v in rng.integers(0, PRIME, size=d)]
+        tag = f"t{PRIME}_{d}"
+        tags.append(tag)
+        generic_case(out, tag, PRIME, d, tw, itw, None, True, False)
+    out["tags"] = np.array(tags)
+    np.savez_compressed(os.path.join(HERE, "generic.npz"), **out)
+    print("generic.npz written:", len(out), "arrays")
 
 
 def gen_bulk():
@@ -498,6 +583,8 @@ if __name__ == "__main__":
         gen_kat_flow()
     if "algebra" in which:
         gen_algebra()
+    if "generic" in which:
+        gen_generic()
     if "bulk" in which:
         gen_bulk()
     if "scheme" in which:

@@ -43,7 +43,7 @@ def canned(world=1, prose=2000):
                    "host_threads_on": blob},
         "ranks": ranks,
         "roofline": {"bound": "hbm", "kernel": "ntt_jobs16<8, true, FzJobsN<32>>", "achieved": 4634.4, "peak": 8000.0, "unit": "GB/s",
-                     "frac": 0.5793, "traffic": 135100000.0, "traffic_source": blob, "bytes_per_launch": 134217728.0, "in_flight": 1,
+                     "frac": 0.5793, "traffic": 135100000.0, "traffic_source": "profiles/r05_pmc_ntt.json", "bytes_per_launch": 134217728.0, "in_flight": 1,
                      "units_per_launch": 65536, "avg_launch_us": 28.961, "operands": "cold: rotation of 64 batches", "one_stream": {"what": blob},
                      "device_clock": {"frac": 0.5793, "in_flight": 1.0, "launch_us": 27.33, "gap_us": 1.405, "span_us": 926.8,
                                       "table": [{"stream": 0, "launch": k, "start_us": 1.0 * k, "end_us": 1.0 * k + 27.0} for k in range(33)], "what": blob},
@@ -59,6 +59,7 @@ def canned(world=1, prose=2000):
         "two_launch_step": {"value": 0.94e9, "unit": "NTT/s", "ms_per_step": 0.0087, "frac": 0.24, "what": blob},
         "sign_verify": {"value": 14410006.6, "unit": "signatures signed+aggregated+verified per s", "ms_per_step": 0.0711,
                         "moved_frac_per_gpu": 0.6094, "aggregates": 4, "signers_per_aggregate": 256, "note": blob,
+                        "scaling": f"weak: 4 aggregates of 256 x {world} signers, 1024 signatures per GPU",
                         "collective": "fz_allreduce_i64 (ncclAllReduce int64 sum, C ABI), RCCL counts 8 ranks",
                         "cpu_value": 81.2, "ranks": ranks},
         "sign_verify_1x1024": {"value": 17.1e6, "unit": "signatures signed+aggregated+verified per s", "ms_per_step": 0.0599,
@@ -108,10 +109,14 @@ def test_compact_line_is_strict_json_under_the_limit_with_the_contract_keys(benc
     assert "hbm_frac_per_gpu" not in out["sign_verify"] and out["sign_verify"]["moved_frac_per_gpu"] == 0.6094
     assert out["sign_verify_1x1024"]["signers_per_aggregate"] == 1024 and out["sign_verify_1x1024"]["aggregates"] == 1
     assert set(("keygen_per_s", "sign_per_s", "aggregate_per_s", "verify_per_s")) <= set(out["end_to_end"]) and "many_aggregates" not in out["end_to_end"]
-    assert len(out["ranks"]) == world
+    assert out["ranks"]["n"] == world == len(out["ranks"]["each"]) and [rk["rank"] for rk in out["ranks"]["each"]] == list(range(world))
     if world > 1:
-        assert all(rk["rccl_nranks"] == world and rk["rccl_version"] == 22703 and rk["collective_check"].startswith("ok:") for rk in out["ranks"])
+        same = out["ranks"]["same"]                      # what all ranks report alike is stated once
+        assert same["rccl_nranks"] == world and same["rccl_version"] == 22703 and same["collective_check"].startswith("ok:") and same["backend"] == "nccl"
+        assert all(set(rk) == {"rank", "device_index", "pci_bus_id"} for rk in out["ranks"]["each"])
     # one number per side leg, no prose
+    assert out["sign_verify"]["scaling"].startswith("weak: 4 aggregates of 256 x")
+    assert r["traffic_source"] == "profiles/r05_pmc_ntt.json"        # `traffic` is read from a committed profile: the line says which
     assert "xxxx" not in line and "kernels" not in out and "passes" not in r and "isolated" not in r and "one_stream" not in r
     assert r["bytes_per_launch"] == 134217728 and isinstance(r["bytes_per_launch"], int)
 

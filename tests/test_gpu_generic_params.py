@@ -264,3 +264,66 @@ def test_matrix_negation_between_2_31_and_2_32():
     rows = [[half, -half, 0, 1, -1, 5, -7, half - 3], [3, -3, half, 0, 0, -half, 2, -2]]
     M = GeneralMatrix(matrix=[[PN(q, d, root, inv, 2 * d, list(r))] for r in rows])
     assert [z[0].values for z in (-M).matrix] == [[-(x % q) for x in r] for r in rows]
+
+
+# ---- numbers the REFERENCE produced for these parameters (tests/golden/generic.npz, made by tests/golden/gen_golden.py) -----
+def _generic():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "generic.npz"))
+
+
+@pytest.mark.parametrize("kernel", ["auto", "4", "16"])
+@pytest.mark.parametrize("tag", ["g4294828033_256", "g4294828033_2048"])
+def test_reference_outputs_for_a_prime_between_2_31_and_2_32(tag, kernel, monkeypatch):
+    """q = 4294828033 at d = 256 (every kernel family) and d = 2048 (the one-workgroup-per-polynomial kernels): forward and
+    inverse transforms of centred AND raw int32 rows, pointwise * + -, the (1 x l)(l x 1) product -- against what the reference's
+    own functions and classes returned for the same inputs"""
+    import fusion_hip
+    g = _generic()
+    q, d, root = (int(v) for v in g[f"{tag}_params"])
+    if kernel != "auto":
+        if d > 256:
+            pytest.skip("one schedule above 256 coefficients")
+        monkeypatch.setenv("FZ_NTT_KERNEL", kernel)
+    ctx = fusion_hip.Context(q, d, root, pow(root, q - 2, q))
+    try:
+        f_tab, i_tab = ctx.twiddles()
+        assert np.array_equal(f_tab.astype(np.int64), g[f"{tag}_tw"]) and np.array_equal(i_tab.astype(np.int64), g[f"{tag}_itw"])
+        x = g[f"{tag}_x"].astype(np.int32)
+        assert np.array_equal(ctx.ntt_forward(x).astype(np.int64), g[f"{tag}_fwd"])
+        assert np.array_equal(ctx.ntt_inverse(x).astype(np.int64), g[f"{tag}_inv"])
+        # the same rows in a batch large enough for the other schedules (3000 copies of the block)
+        big = np.tile(x, (300, 1))
+        assert np.array_equal(ctx.ntt_forward(big).astype(np.int64), np.tile(g[f"{tag}_fwd"], (300, 1)))
+        assert np.array_equal(ctx.ntt_inverse(big).astype(np.int64), np.tile(g[f"{tag}_inv"], (300, 1)))
+        a, b = g[f"{tag}_pw_a"].astype(np.int32), g[f"{tag}_pw_b"].astype(np.int32)
+        assert np.array_equal(ctx.pw_mul(a, b).astype(np.int64), g[f"{tag}_pw_mul"])
+        assert np.array_equal(ctx.pw_add(a, b).astype(np.int64), g[f"{tag}_pw_add"])
+        assert np.array_equal(ctx.pw_sub(a, b).astype(np.int64), g[f"{tag}_pw_sub"])
+        assert np.array_equal(ctx.matvec(g[f"{tag}_mv_A"].astype(np.int32), g[f"{tag}_mv_S"].astype(np.int32)).astype(np.int64), g[f"{tag}_mv_out"])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("tag", ["t2147465729_64", "t2147465729_256"])
+def test_reference_outputs_for_tables_that_are_no_roots_powers(tag):
+    """the scheme's prime with random tables (fz_ctx_create_tables): what cooley_tukey_ntt / gentleman_sande_intt returned with
+    those tables, for centred and raw int32 rows -- through a context built from the tables and through the drop-in functions"""
+    import algebra.ntt as N
+    import fusion_hip
+    g = _generic()
+    q, d, _ = (int(v) for v in g[f"{tag}_params"])
+    tw, itw = [int(v) for v in g[f"{tag}_tw"]], [int(v) for v in g[f"{tag}_itw"]]
+    ctx = fusion_hip.Context(q, d, 0, 0, tables=(tw, itw))
+    try:
+        x = g[f"{tag}_x"].astype(np.int32)
+        assert np.array_equal(ctx.ntt_forward(x).astype(np.int64), g[f"{tag}_fwd"])
+        assert np.array_equal(ctx.ntt_inverse(x).astype(np.int64), g[f"{tag}_inv"])
+    finally:
+        ctx.close()
+    for i in (1, 5, 9):
+        row = [int(v) for v in g[f"{tag}_x"][i]]
+        got = list(row)
+        assert N.cooley_tukey_ntt(got, q, 2 * d, tw) is got and got == [int(v) for v in g[f"{tag}_fwd"][i]]
+        got = list(row)
+        assert N.gentleman_sande_intt(got, q, 2 * d, itw) is got and got == [int(v) for v in g[f"{tag}_inv"][i]]

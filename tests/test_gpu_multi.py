@@ -466,7 +466,7 @@ def test_bench_headline_keeps_its_streams_with_rccl_in_the_process():
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
     d = json.loads(line)
-    assert d["ranks"][0]["rccl_nranks"] == 1 and d["config"]["streams"] == 2
+    assert d["ranks"]["n"] == 1 and d["ranks"]["same"]["rccl_nranks"] == 1 and d["config"]["streams"] == 2
     one, chip = d["roofline"]["frac"], d["roofline"]["chip"]["frac"]
     dev = d["roofline"]["chip"]["device_clock"]
     # by the chip's own clock: the two chains' launches really ran side by side (queue-sharing chains run one after the other)

@@ -249,3 +249,24 @@ def test_c_caller_of_the_wide_path(tmp_path):
     r = subprocess.run([build_c_example(tmp_path, "wide_roundtrip")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "wide_roundtrip OK" in r.stdout
+
+
+@pytest.mark.parametrize("tag", ["g4611686018427322369_64", "g4611686018427322369_1024"])
+def test_reference_outputs_for_a_prime_just_below_2_62(tag):
+    """tests/golden/generic.npz: what the REFERENCE's functions and classes returned at q = 4611686018427322369 (d = 64 and
+    d = 1024) -- transforms both ways, pointwise * + - and negation, the (1 x l)(l x 1) product -- on the generic int64 path"""
+    import os
+    from fusion_hip.wide import WideContext
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "generic.npz"))
+    q, d, root = (int(v) for v in g[f"{tag}_params"])
+    assert q == Q62
+    ctx = WideContext(q, d, [int(v) for v in g[f"{tag}_tw"]], [int(v) for v in g[f"{tag}_itw"]])
+    x = g[f"{tag}_x"]
+    assert np.array_equal(ctx.ntt_forward(x), g[f"{tag}_fwd"])
+    assert np.array_equal(ctx.ntt_inverse(x), g[f"{tag}_inv"])
+    a, b = g[f"{tag}_pw_a"], g[f"{tag}_pw_b"]
+    assert np.array_equal(ctx.pw_mul(a, b), g[f"{tag}_pw_mul"])
+    assert np.array_equal(ctx.pw_add(a, b), g[f"{tag}_pw_add"])
+    assert np.array_equal(ctx.pw_sub(a, b), g[f"{tag}_pw_sub"])
+    assert np.array_equal(ctx.pw_neg(a), g[f"{tag}_pw_neg"])
+    assert np.array_equal(np.asarray(ctx.matvec(g[f"{tag}_mv_A"], g[f"{tag}_mv_S"])).reshape(g[f"{tag}_mv_out"].shape), g[f"{tag}_mv_out"])

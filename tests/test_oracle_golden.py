@@ -174,3 +174,58 @@ def test_reference_kat_hash_ch_pins_forward_ntt(coracle):
         coefs = F.decode_bytes_to_polynomial_coefficients(xof, 128, P["q"], P["d"], params.beta_ch, params.omega_ch)
         c_hat = coracle.ntt_forward(np.array(coefs, np.int32), P["q"], P["root"])
         assert c_hat.tolist() == row["c_hat"]
+
+
+# ---- parameters beyond the scheme's two sets: numbers the reference produced (tests/golden/generic.npz) ------------------------
+@pytest.fixture(scope="module")
+def gen():
+    return np.load(os.path.join(G, "generic.npz"))
+
+
+def test_python_port_on_reference_outputs_for_generic_parameters(gen):
+    """oracle.py's py_* loops (what the GPU tests of the generic paths compare with) against the REFERENCE's outputs for a prime in
+    [2^31, 2^32) at d = 256 / 2048, a prime just below 2^62 at d = 64 / 1024 and the scheme's prime with tables that are no root's
+    powers: transforms both ways, pointwise * + - and negation, the (1 x l)(l x 1) product"""
+    for t in (str(x) for x in gen["tags"]):
+        q, d, root = (int(v) for v in gen[f"{t}_params"])
+        tw, itw = [int(v) for v in gen[f"{t}_tw"]], [int(v) for v in gen[f"{t}_itw"]]
+        if root:
+            assert O.py_twiddles(root, q, d) == tw and O.py_twiddles(pow(root, q - 2, q), q, d) == itw, t
+        x = gen[f"{t}_x"]
+        for i in range(x.shape[0]):
+            row = [int(v) for v in x[i]]
+            assert O.py_ntt_forward(list(row), q, tw) == [int(v) for v in gen[f"{t}_fwd"][i]], (t, i)
+            assert O.py_ntt_inverse(list(row), q, itw) == [int(v) for v in gen[f"{t}_inv"][i]], (t, i)
+        if f"{t}_pw_a" not in gen:
+            continue
+        L = lambda m: [[int(v) for v in r] for r in m]                                  # noqa: E731
+        a, b = L(gen[f"{t}_pw_a"]), L(gen[f"{t}_pw_b"])
+        assert [O.py_pw_mul(u, v, q) for u, v in zip(a, b)] == L(gen[f"{t}_pw_mul"]), t
+        assert [O.py_pw_add(u, v, q) for u, v in zip(a, b)] == L(gen[f"{t}_pw_add"]), t
+        assert [O.py_pw_sub(u, v, q) for u, v in zip(a, b)] == L(gen[f"{t}_pw_sub"]), t
+        assert [O.py_pw_neg(u, q) for u in a] == L(gen[f"{t}_pw_neg"]), t
+        A, S = L(gen[f"{t}_mv_A"]), gen[f"{t}_mv_S"]
+        assert [O.py_matvec(A, L(s), q) for s in S] == L(gen[f"{t}_mv_out"]), t
+
+
+def test_c_oracle_on_reference_outputs_up_to_2_32(gen, coracle):
+    """fz_oracle.c inside the range its header states (odd q < 2^32, int32 storage): the prime in [2^31, 2^32) -- raw int32 rows
+    included, where the inverse butterfly's (u - v) * s passes 2^63 -- and the scheme's prime with arbitrary tables"""
+    for t in (str(x) for x in gen["tags"]):
+        q, d, root = (int(v) for v in gen[f"{t}_params"])
+        if q >= 2 ** 32:
+            continue
+        x = gen[f"{t}_x"]
+        assert x.min() >= -2 ** 31 and x.max() < 2 ** 31
+        assert np.array_equal(coracle.ntt_table(x, q, gen[f"{t}_tw"]).astype(np.int64), gen[f"{t}_fwd"]), t
+        assert np.array_equal(coracle.ntt_table(x, q, gen[f"{t}_itw"], inverse=True).astype(np.int64), gen[f"{t}_inv"]), t
+        if root:
+            assert np.array_equal(coracle.ntt_forward(x, q, root).astype(np.int64), gen[f"{t}_fwd"]), t
+            assert np.array_equal(coracle.ntt_inverse(x, q, pow(root, q - 2, q)).astype(np.int64), gen[f"{t}_inv"]), t
+        if f"{t}_pw_a" in gen:
+            a, b = gen[f"{t}_pw_a"], gen[f"{t}_pw_b"]
+            assert np.array_equal(coracle.pw_mul(a, b, q).astype(np.int64), gen[f"{t}_pw_mul"]), t
+            assert np.array_equal(coracle.pw_add(a, b, q).astype(np.int64), gen[f"{t}_pw_add"]), t
+            assert np.array_equal(coracle.pw_sub(a, b, q).astype(np.int64), gen[f"{t}_pw_sub"]), t
+            got = coracle.matvec(gen[f"{t}_mv_A"], gen[f"{t}_mv_S"], q)
+            assert np.array_equal(np.asarray(got).astype(np.int64).reshape(gen[f"{t}_mv_out"].shape), gen[f"{t}_mv_out"]), t

@@ -261,6 +261,11 @@ def sign_verify(e):
         sv = {"value": S * world * sv_steps / dt, "unit": "signatures signed+aggregated+verified per s",
               "signatures_per_rank": S, "aggregates": GROUPS, "signers_per_aggregate": per * world,
               "steps": sv_steps, "ms_per_step": dt / sv_steps * 1e3, "operand_sets_cycled": NSETS,
+              # BASELINE configs[3] taken literally (ONE aggregate of 1024 signers, 128 per GPU at N = 8) cannot scale: 5.7 us of
+              # aggregation + an all-reduce + 4.6 us of verification against 17 us on one GPU.  The leg keeps the work per GPU
+              # fixed instead: every rank holds S signatures of each of the GROUPS aggregates, an aggregate spans all ranks
+              "scaling": (f"weak: {GROUPS} aggregates of {per} x {world} signers, {S} signatures per GPU" if world > 1 else
+                          f"weak (single rank: {GROUPS} aggregates of {per} signers)"),
               "launch": "hipGraph replay of %d steps (fz_graph_*)" % NSETS if sv_graph is not None else "one by one",
               "collective": collective,
               "exchange": ("on a second stream, overlapping the next step's kernels (fz_event_*)" if overlap else

@@ -82,7 +82,7 @@ for set in FETCH_SIZE WRITE_SIZE "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU"; do
   n=$(echo $set | tr " " "_" | cut -c1-30)
   step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcb/$n -- python3 $R/bench.py --headline-only --streams 1 --no-stamps --no-graph --steps 50 --prewarm-ms 20 --full-out $OUT/pmcb_bench_full.json > $OUT/pmcb_$n.log 2>&1
   step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc20/$n -- python3 $R/tools/probes/prof_ntt.py 20 30 > $OUT/pmc20_$n.log 2>&1
-  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcs/$n -- python3 $R/tools/probes/prof_scheme.py 12 > $OUT/pmcs_$n.log 2>&1
+  step timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcs/$n -- python3 $R/tools/probes/prof_scheme.py 12 $OUT/pmcs_manifest.json > $OUT/pmcs_$n.log 2>&1
 done
 # where the waves' cycles go (issue, stalls, LDS): two SQ counter sets over the cold scheme kernels
 step timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $OUT/sq1 -- python3 $R/tools/probes/prof_scheme.py 6 > $OUT/sq1.log 2>&1

@@ -8,7 +8,7 @@
  * Exit code 0 = every value equal.  (tests/test_cabi_symbols.py compiles it; tests/test_gpu_wide.py runs it.) */
 #include <stdio.h>
 #include <stdlib.h>
-#include "fusion_hip.h"
+#include "fusion_hip_generic.h"
 
 #define CHECK(call)                                                        \
     do {                                                                   \

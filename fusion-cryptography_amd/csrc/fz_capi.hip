@@ -1553,11 +1553,21 @@ int fz_diag_stamps_begin(fz_ctx *ctx, size_t max_launches, size_t max_workgroups
     FZ_REQUIRE(ctx && max_launches >= 1 && max_launches <= (1u << 20) && max_workgroups >= 1 && max_workgroups <= ((size_t)1 << 26), "bad argument");
     FZ_DEV(ctx);
     if (fz_capturing(ctx)) return fz_set_error(FZ_E_BADARG, "stamps cannot be set up during graph capture");
-    if (ctx->d_stamp) { FZ_TRY(fz_retire(ctx, ctx->d_stamp, "stamp buffer")); ctx->d_stamp = nullptr; }
+    // a recording that is still on is switched OFF first: if anything below fails, no launch takes a slot in a buffer that is gone
+    ctx->stamp_on = 0;
+    ctx->stamp_n = 0;
+    ctx->stamp_used = 0;
+    ctx->stamp_launch_cap = 0;
+    ctx->stamp_wg_cap = 0;
+    if (ctx->d_stamp) { void *old = ctx->d_stamp; ctx->d_stamp = nullptr; FZ_TRY(fz_retire(ctx, old, "stamp buffer")); }
     free(ctx->stamp_first); free(ctx->stamp_count);
     ctx->stamp_first = (size_t *)malloc(sizeof(size_t) * max_launches);
     ctx->stamp_count = (unsigned *)malloc(sizeof(unsigned) * max_launches);
-    if (!ctx->stamp_first || !ctx->stamp_count) return fz_set_error(FZ_E_HIP, "out of host memory");
+    if (!ctx->stamp_first || !ctx->stamp_count) {
+        free(ctx->stamp_first); free(ctx->stamp_count);
+        ctx->stamp_first = nullptr; ctx->stamp_count = nullptr;
+        return fz_set_error(FZ_E_HIP, "out of host memory");
+    }
     FZ_HIP(hipMalloc((void **)&ctx->d_stamp, 16 * max_workgroups), "stamp buffer");
     FZ_HIP(hipMemsetAsync(ctx->d_stamp, 0, 16 * max_workgroups, ctx->stream), "stamp reset");
     ctx->stamp_launch_cap = (int)max_launches;

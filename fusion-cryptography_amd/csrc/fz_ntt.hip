@@ -1613,7 +1613,7 @@ int fz_launch_ntt(fz_ctx *ctx, const int32_t *d_in, int32_t *d_out, size_t batch
 
 // fz_diag_stamps_*: a launch's workgroups get a run of {entry, exit} slots (NULL: stamps off, or the recording is full)
 static unsigned long long *stamp_slots(fz_ctx *ctx, unsigned total) {
-    if (!ctx->stamp_on || ctx->stamp_n >= ctx->stamp_launch_cap || ctx->stamp_used + total > ctx->stamp_wg_cap) return nullptr;
+    if (!ctx->stamp_on || !ctx->d_stamp || ctx->stamp_n >= ctx->stamp_launch_cap || ctx->stamp_used + total > ctx->stamp_wg_cap) return nullptr;
     unsigned long long *stamp = ctx->d_stamp + 2 * ctx->stamp_used;
     ctx->stamp_first[ctx->stamp_n] = ctx->stamp_used;
     ctx->stamp_count[ctx->stamp_n++] = total;

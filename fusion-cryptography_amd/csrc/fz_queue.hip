@@ -234,7 +234,16 @@ int run_batch(fz_queue *Q, Worker &w, std::vector<Job> &jobs, Batch **out_batch,
 
 // one coalesced batch of aggregate+verify (kind 1) or verify (kind 2) calls: G aggregates, their signers back to back.
 // The flow of BatchScheme._hash_ag_many + aggregate_target_partial_ragged + verify_partials (fusion_hip/scheme.py), in C.
+int run_agg_batch_steps(fz_queue *Q, Worker &w, std::vector<Job> &jobs, int kind, std::vector<int> &verdicts);
+// Every exit of the steps below that reports a failure may leave copies FROM THE CALLERS' ROWS in flight on the worker's stream
+// (they are enqueued first): the stream is drained before the failure is reported, so that a caller who frees or recycles its
+// rows on an error never races with them.
 int run_agg_batch(fz_queue *Q, Worker &w, std::vector<Job> &jobs, int kind, std::vector<int> &verdicts) {
+    const int rc = run_agg_batch_steps(Q, w, jobs, kind, verdicts);
+    if (rc != FZ_OK) (void)fz_ctx_synchronize(w.ctx);
+    return rc;
+}
+int run_agg_batch_steps(fz_queue *Q, Worker &w, std::vector<Job> &jobs, int kind, std::vector<int> &verdicts) {
     const size_t d = (size_t)Q->degree, l = (size_t)Q->l, poly = d * 4, G = jobs.size();
     std::vector<size_t> offs(G + 1, 0);
     size_t msg_bytes = 0;

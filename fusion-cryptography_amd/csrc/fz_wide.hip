@@ -12,7 +12,7 @@
 // Bit-identical to the reference by construction (exact integer arithmetic, one cent() where the reference has one).
 // tests/test_gpu_wide.py compares with the pure-Python loops of oracle/oracle.py on Python integers.
 #include "fz_internal.h"
-#include "../../include/fusion_hip.h"
+#include "../../include/fusion_hip_generic.h"
 #include <algorithm>
 #include <memory>
 #include <new>
@@ -42,9 +42,10 @@ __device__ __forceinline__ unsigned long long wadd(unsigned long long a, unsigne
 __device__ __forceinline__ unsigned long long wsub(unsigned long long a, unsigned long long b, const WMod &m) {
     return a >= b ? a - b : a + m.q - b;
 }
-// centred int64 (|x| <= (q-1)/2 is what the callers hand over; anything in (-q, q) is accepted) -> [0, q)
+// ANY int64 -> its residue in [0, q) (the int32 entry points accept unreduced rows too; q < 2^63 fits the signed type)
 __device__ __forceinline__ unsigned long long wcanon(long long x, const WMod &m) {
-    return x < 0 ? (unsigned long long)(x + (long long)m.q) : (unsigned long long)x;
+    const long long r = x % (long long)m.q;
+    return (unsigned long long)(r < 0 ? r + (long long)m.q : r);
 }
 __device__ __forceinline__ long long wcent(unsigned long long v, const WMod &m) {          // the reference's cent(): ntt.py:93-123
     return v > m.half ? (long long)v - (long long)m.q : (long long)v;
@@ -53,9 +54,9 @@ __device__ __forceinline__ long long wcent(unsigned long long v, const WMod &m) 
 // forward: cooley_tukey_ntt's loop nest (ntt.py:274-290) -- stage with m blocks of 2t: butterfly (j, j + t) of block i uses table[m + i];
 // inverse: gentleman_sande_intt's (ntt.py:354-376) -- stage with h = m/2 blocks: table[h + i], then the scaling by n^{-1}.
 // tab: the caller's table, Montgomery form.  One workgroup per row; the row lives in `out` (canonical residues reinterpreted).
-__global__ __launch_bounds__(256) void wide_ntt_kernel(const long long *in, long long *out, int n, const unsigned long long *tab,
+__global__ __launch_bounds__(256) void wide_ntt_kernel(const long long *in, long long *out, size_t batch, int n, const unsigned long long *tab,
                                                        unsigned long long n_inv_mont, int inverse, WMod m) {
-    const size_t rowi = blockIdx.x;
+  for (size_t rowi = blockIdx.x; rowi < batch; rowi += gridDim.x) {       // (a launch of more than 2^24 workgroups of 256 is refused by HIP)
     const long long *src = in + rowi * (size_t)n;
     unsigned long long *v = reinterpret_cast<unsigned long long *>(out + rowi * (size_t)n);
     for (int j = threadIdx.x; j < n; j += blockDim.x) v[j] = wcanon(src[j], m);
@@ -89,6 +90,8 @@ __global__ __launch_bounds__(256) void wide_ntt_kernel(const long long *in, long
         if (inverse) x = wmont(x, n_inv_mont, m);
         dst[j] = wcent(x, m);
     }
+    __syncthreads();
+  }
 }
 
 // op: FZ_OP_MUL / ADD / SUB / NEG as in fusion_hip.h.  NEG is the reference's -(x mod q) in [-(q-1), 0] (polynomials.py:155-163)
@@ -119,30 +122,36 @@ __global__ __launch_bounds__(256) void wide_matvec_kernel(const long long *A, co
     }
 }
 
-// per row: max |x| over the stored values and the number of non-zero ones (polynomials.py:221-229)
-__global__ __launch_bounds__(256) void wide_norm_weight_kernel(const long long *rows, size_t batch, int d, long long *mx, int *wt) {
-    __shared__ long long s_mx[256];
+// per row: max |x| over the stored values (unsigned: |INT64_MIN| = 2^63) and the number of non-zero ones (polynomials.py:221-229)
+__global__ __launch_bounds__(256) void wide_norm_weight_kernel(const long long *rows, size_t batch, int d, unsigned long long *mx, int *wt) {
+    __shared__ unsigned long long s_mx[256];
     __shared__ int s_wt[256];
-    const long long *r = rows + (size_t)blockIdx.x * d;
-    long long best = 0;
-    int cnt = 0;
-    for (int j = threadIdx.x; j < d; j += blockDim.x) {
-        const long long x = r[j], ax = x < 0 ? -x : x;
-        best = ax > best ? ax : best;
-        cnt += x != 0;
-    }
-    s_mx[threadIdx.x] = best;
-    s_wt[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            s_mx[threadIdx.x] = s_mx[threadIdx.x + s] > s_mx[threadIdx.x] ? s_mx[threadIdx.x + s] : s_mx[threadIdx.x];
-            s_wt[threadIdx.x] += s_wt[threadIdx.x + s];
+    for (size_t rowi = blockIdx.x; rowi < batch; rowi += gridDim.x) {
+        const long long *r = rows + rowi * (size_t)d;
+        unsigned long long best = 0;
+        int cnt = 0;
+        for (int j = threadIdx.x; j < d; j += blockDim.x) {
+            const long long x = r[j];
+            const unsigned long long ax = x < 0 ? 0ull - (unsigned long long)x : (unsigned long long)x;
+            best = ax > best ? ax : best;
+            cnt += x != 0;
         }
+        s_mx[threadIdx.x] = best;
+        s_wt[threadIdx.x] = cnt;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                s_mx[threadIdx.x] = s_mx[threadIdx.x + s] > s_mx[threadIdx.x] ? s_mx[threadIdx.x + s] : s_mx[threadIdx.x];
+                s_wt[threadIdx.x] += s_wt[threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { mx[rowi] = s_mx[0]; wt[rowi] = s_wt[0]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { mx[blockIdx.x] = s_mx[0]; wt[blockIdx.x] = s_wt[0]; }
 }
+
+constexpr size_t kWideMaxGrid = (size_t)1 << 20;          // workgroups per launch; rows beyond are walked by the same workgroups
 
 int make_mod(uint64_t q, WMod *m) {
     if (q < 3 || (q & 1) == 0 || q >= (1ull << 63))
@@ -194,7 +203,7 @@ FZ_API int fz_wide_ntt_host(int device, uint64_t q, int degree, const uint64_t *
     FZW_TRY(dtab.alloc((size_t)degree * 8));
     FZW_HIP(hipMemcpy(din.p, h_in, bytes, hipMemcpyHostToDevice), "wide path: copy in");
     FZW_HIP(hipMemcpy(dtab.p, tab.get(), (size_t)degree * 8, hipMemcpyHostToDevice), "wide path: table");
-    hipLaunchKernelGGL(wide_ntt_kernel, dim3((unsigned)batch), dim3(256), 0, 0, (const long long *)din.p, (long long *)dout.p, degree,
+    hipLaunchKernelGGL(wide_ntt_kernel, dim3((unsigned)std::min<size_t>(batch, kWideMaxGrid)), dim3(256), 0, 0, (const long long *)din.p, (long long *)dout.p, batch, degree,
                        (const unsigned long long *)dtab.p, n_inv_mont, inverse ? 1 : 0, m);
     FZW_HIP(hipGetLastError(), "wide transform launch");
     return fz_check_hip(hipMemcpy(h_out, dout.p, bytes, hipMemcpyDeviceToHost), "wide path: copy out");
@@ -241,7 +250,7 @@ FZ_API int fz_wide_matvec_host(int device, uint64_t q, int degree, const int64_t
     return fz_check_hip(hipMemcpy(h_out, dout.p, batch * row, hipMemcpyDeviceToHost), "wide path: copy out");
 }
 
-FZ_API int fz_wide_norm_weight_host(int device, const int64_t *h_rows, size_t batch, int degree, int64_t *h_max_abs, int32_t *h_weight) {
+FZ_API int fz_wide_norm_weight_host(int device, const int64_t *h_rows, size_t batch, int degree, uint64_t *h_max_abs, int32_t *h_weight) {
     if (degree < 1) return fz_set_error(FZ_E_BADARG, "wide path: degree must be positive");
     if (batch && (!h_rows || !h_max_abs || !h_weight)) return fz_set_error(FZ_E_BADARG, "NULL argument");
     if (batch == 0) return FZ_OK;
@@ -252,7 +261,8 @@ FZ_API int fz_wide_norm_weight_host(int device, const int64_t *h_rows, size_t ba
     FZW_TRY(dmx.alloc(batch * 8));
     FZW_TRY(dwt.alloc(batch * 4));
     FZW_HIP(hipMemcpy(drows.p, h_rows, batch * (size_t)degree * 8, hipMemcpyHostToDevice), "wide path: copy in");
-    hipLaunchKernelGGL(wide_norm_weight_kernel, dim3((unsigned)batch), dim3(256), 0, 0, (const long long *)drows.p, batch, degree, (long long *)dmx.p, (int *)dwt.p);
+    hipLaunchKernelGGL(wide_norm_weight_kernel, dim3((unsigned)std::min<size_t>(batch, kWideMaxGrid)), dim3(256), 0, 0, (const long long *)drows.p, batch, degree,
+                       (unsigned long long *)dmx.p, (int *)dwt.p);
     FZW_HIP(hipGetLastError(), "wide norm / weight launch");
     FZW_HIP(hipMemcpy(h_max_abs, dmx.p, batch * 8, hipMemcpyDeviceToHost), "wide path: copy out");
     return fz_check_hip(hipMemcpy(h_weight, dwt.p, batch * 4, hipMemcpyDeviceToHost), "wide path: copy out");

@@ -84,7 +84,7 @@ SIGNATURES = {
     "fz_wide_ntt_host": (c_int, [c_int, c_uint64, c_int, POINTER(c_uint64), c_uint64, c_int, _i64p, _i64p, c_size_t]),
     "fz_wide_pw_host": (c_int, [c_int, c_uint64, c_int, _i64p, _i64p, _i64p, c_size_t]),
     "fz_wide_matvec_host": (c_int, [c_int, c_uint64, c_int, _i64p, _i64p, _i64p, c_size_t, c_int]),
-    "fz_wide_norm_weight_host": (c_int, [c_int, _i64p, c_size_t, c_int, _i64p, POINTER(c_int32)]),
+    "fz_wide_norm_weight_host": (c_int, [c_int, _i64p, c_size_t, c_int, POINTER(ctypes.c_uint64), POINTER(c_int32)]),
     "fz_fill_synthetic": (c_int, [_ctx, c_void_p, c_size_t, c_uint64]),
     "fz_poly_mul": (c_int, [_ctx, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fz_poly_mul_host": (c_int, [_ctx, _i32p, _i32p, _i32p, c_size_t]),

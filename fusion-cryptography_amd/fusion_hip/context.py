@@ -6,6 +6,7 @@ Two faces:
   * host face    -- methods taking/returning numpy int32 arrays; staged through the
     library's own scratch (used by the drop-in object API in ``algebra`` / ``fusion``).
 """
+import collections
 import ctypes
 from ctypes import byref, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
@@ -700,14 +701,24 @@ class DeviceArray:
 
 
 _CTX_CACHE = {}
+# Contexts built from caller-supplied TABLES are memoised in a small LRU instead: every distinct table is a context with its
+# own streams, events, device tables and pool, and a caller iterating over tables would otherwise keep all of them alive for the
+# life of the process.  The evicted context is closed (the drop-in functions hold one for the duration of a call only).
+_TABLE_CTX_MAX = 8
+_TABLE_CTX_CACHE = collections.OrderedDict()
 
 
 def get_table_context(modulus, degree, fwd_table, inv_table, device=0):
-    """memoised contexts built from caller-supplied twiddle tables (tuples)"""
-    key = ("tables", modulus, degree, fwd_table, inv_table, device)
-    ctx = _CTX_CACHE.get(key)
-    if ctx is None:
-        ctx = _CTX_CACHE[key] = Context(modulus, degree, 0, 0, device, tables=(fwd_table, inv_table))
+    """memoised contexts built from caller-supplied twiddle tables (tuples): the `_TABLE_CTX_MAX` most recently used"""
+    key = (modulus, degree, fwd_table, inv_table, device)
+    ctx = _TABLE_CTX_CACHE.get(key)
+    if ctx is not None:
+        _TABLE_CTX_CACHE.move_to_end(key)
+        return ctx
+    ctx = _TABLE_CTX_CACHE[key] = Context(modulus, degree, 0, 0, device, tables=(fwd_table, inv_table))
+    while len(_TABLE_CTX_CACHE) > _TABLE_CTX_MAX:
+        _, old = _TABLE_CTX_CACHE.popitem(last=False)
+        old.close()
     return ctx
 
 

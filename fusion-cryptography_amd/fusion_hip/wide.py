@@ -7,6 +7,9 @@ not speed.  WideContext has the host face of Context (numpy in, numpy out, the s
 There is no CPU route: without the library or a GPU every call raises FusionHipError."""
 from ctypes import POINTER, c_int32, c_int64, c_uint64
 
+import collections
+import ctypes
+
 import numpy as np
 
 from ._lib import FZ_E_BADARG, FZ_E_UNSUPPORTED, FusionHipError, check, load_library
@@ -115,19 +118,25 @@ class WideContext:
 
     def norm_weight(self, coef):
         a, rows = self._rows(coef)
-        mx = np.empty(rows, dtype=np.int64)
+        mx = np.empty(rows, dtype=np.uint64)                # |INT64_MIN| = 2^63 does not fit the signed type
         wt = np.empty(rows, dtype=np.int32)
-        check(self._lib, self._lib.fz_wide_norm_weight_host(self.device, _p(a), rows, self.degree, _p(mx), wt.ctypes.data_as(POINTER(c_int32))))
+        check(self._lib, self._lib.fz_wide_norm_weight_host(self.device, _p(a), rows, self.degree, mx.ctypes.data_as(POINTER(ctypes.c_uint64)),
+                                                            wt.ctypes.data_as(POINTER(c_int32))))
         return mx, wt
 
 
-_WIDE_CACHE = {}
+_WIDE_MAX = 8
+_WIDE_CACHE = collections.OrderedDict()
 
 
 def get_wide_context(modulus, degree, fwd_table=None, inv_table=None, device=0):
-    """memoised (tables as tuples or None)"""
+    """memoised (tables as tuples or None): the `_WIDE_MAX` most recently used (a context holds its tables as arrays)"""
     key = (modulus, degree, fwd_table, inv_table, device)
     ctx = _WIDE_CACHE.get(key)
-    if ctx is None:
-        ctx = _WIDE_CACHE[key] = WideContext(modulus, degree, fwd_table, inv_table, device)
+    if ctx is not None:
+        _WIDE_CACHE.move_to_end(key)
+        return ctx
+    ctx = _WIDE_CACHE[key] = WideContext(modulus, degree, fwd_table, inv_table, device)
+    while len(_WIDE_CACHE) > _WIDE_MAX:
+        _WIDE_CACHE.popitem(last=False)
     return ctx

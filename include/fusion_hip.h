@@ -189,25 +189,8 @@ FZ_API int fz_pw_binary_host(fz_ctx *ctx, int op, const int32_t *h_a, const int3
  * GeneralMatrix.__mul__(element), algebra/matrices.py:109-114 */
 FZ_API int fz_pw_mul_bcast(fz_ctx *ctx, const int32_t *d_a, const int32_t *d_s, int32_t *d_out, size_t rows);
 
-/* ---- the generic-parameter path: any odd modulus 3 <= q < 2^63, any power-of-two length (csrc/fz_wide.hip) ---------
- * The reference transforms any power-of-two length over any odd modulus with the table it is handed (algebra/ntt.py:239-290,
- * :345-377) and its polynomial classes add, negate and multiply over any modulus (algebra/polynomials.py:140-216, :272-333).
- * The int32 entry points above cover q < 2^32 and lengths <= 4096 (every parameter set of the scheme) at full speed; these
- * cover the rest so that the drop-in packages refuse nothing below 2^63 and compute nothing on the CPU: int64 rows of
- * centred residues (|x| <= (q-1)/2) on the host in and out, exact integer arithmetic on the device, one workgroup per row.
- * Written for correctness, not bandwidth.  h_table: `degree` residues in [0, q), used exactly as the reference uses its
- * `bit_rev_root_powers` / `bit_rev_inv_root_powers` argument (entry m + i for block i of the stage with m blocks); n_inv:
- * degree^{-1} mod q (inverse only).  op as for fz_pw_binary_host (0 mul, 1 add, 2 sub, 3 neg); neg returns -(x mod q) in [-(q-1), 0] as the reference's
- * __neg__ does. */
-FZ_API int fz_wide_ntt_host(int device, uint64_t q, int degree, const uint64_t *h_table, uint64_t n_inv, int inverse,
-                            const int64_t *h_in, int64_t *h_out, size_t batch);
-FZ_API int fz_wide_pw_host(int device, uint64_t q, int op, const int64_t *h_a, const int64_t *h_b, int64_t *h_out, size_t count);
-/* out[b][j] = cent(sum_k A[k][j] * S[b][k][j]): A [l][degree], S [batch][l][degree] (algebra/matrices.py:143-181) */
-FZ_API int fz_wide_matvec_host(int device, uint64_t q, int degree, const int64_t *h_A, const int64_t *h_S, int64_t *h_out,
-                               size_t batch, int l);
-/* per row: max |x| and the number of non-zero values (algebra/polynomials.py:221-229) */
-FZ_API int fz_wide_norm_weight_host(int device, const int64_t *h_rows, size_t batch, int degree, int64_t *h_max_abs,
-                                    int32_t *h_weight);
+/* (The generic-parameter path -- any odd modulus below 2^63, any power-of-two length: fz_wide_* -- is declared in
+ * fusion_hip_generic.h: a correctness path for the parameters the reference accepts beyond the scheme's, not for throughput.) */
 
 /* ---- synthetic batches (benchmarks, tests) ----------------------------------------------------------
  * d_out[i] = SplitMix64(seed + (i + 1) * 0x9E3779B97F4A7C15) mod q, centred to [-(q-1)/2, (q-1)/2]: a seeded uniform

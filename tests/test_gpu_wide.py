@@ -270,3 +270,33 @@ def test_reference_outputs_for_a_prime_just_below_2_62(tag):
     assert np.array_equal(ctx.pw_sub(a, b), g[f"{tag}_pw_sub"])
     assert np.array_equal(ctx.pw_neg(a), g[f"{tag}_pw_neg"])
     assert np.array_equal(np.asarray(ctx.matvec(g[f"{tag}_mv_A"], g[f"{tag}_mv_S"])).reshape(g[f"{tag}_mv_out"].shape), g[f"{tag}_mv_out"])
+
+
+@pytest.mark.parametrize("q,d", [(Q33, 64), (Q62, 64), (Q63, 16)])
+def test_unreduced_int64_rows_are_reduced_first(q, d):
+    """ANY int64 is a valid input (the int32 contexts accept unreduced rows in the same way): values far outside (-q, q), the
+    extremes of the type included, give what the reference's loops give on the same Python integers; the norm of INT64_MIN is 2^63"""
+    from fusion_hip.wide import WideContext
+    root = root_of(q, d)
+    inv = pow(root, q - 2, q)
+    tw, itw = O.py_twiddles(root, q, d), O.py_twiddles(inv, q, d)
+    ctx = WideContext(q, d, tw, itw)
+    rnd = random.Random(q % 977)
+    lo, hi = -(2 ** 63), 2 ** 63 - 1
+    rows = [[rnd.randint(lo, hi) for _ in range(d)] for _ in range(3)]
+    rows.append([lo if k % 2 else hi for k in range(d)])
+    rows.append([q * (k % 3) - (k % 2) * (q - 1) for k in range(d)] if q < 2 ** 61 else [q - 1 if k % 2 else -(q - 1) for k in range(d)])
+    x = np.array(rows, dtype=np.int64)
+    y, z = ctx.ntt_forward(x), ctx.ntt_inverse(x)
+    for r in range(len(rows)):
+        assert y[r].tolist() == O.py_ntt_forward(list(rows[r]), q, tw), (q, r)
+        assert z[r].tolist() == O.py_ntt_inverse(list(rows[r]), q, itw), (q, r)
+    a, b = rows[:2], rows[2:4]
+    assert ctx.pw_mul(np.array(a), np.array(b)).tolist() == [O.py_pw_mul(u, v, q) for u, v in zip(a, b)]
+    assert ctx.pw_add(np.array(a), np.array(b)).tolist() == [O.py_pw_add(u, v, q) for u, v in zip(a, b)]
+    assert ctx.pw_sub(np.array(a), np.array(b)).tolist() == [O.py_pw_sub(u, v, q) for u, v in zip(a, b)]
+    assert ctx.pw_neg(np.array(a)).tolist() == [O.py_pw_neg(u, q) for u in a]
+    assert np.asarray(ctx.matvec(np.array(rows[:3]), np.array([rows[1:4]]))).reshape(-1).tolist() == O.py_matvec(rows[:3], rows[1:4], q)
+    mx, wt = ctx.norm_weight(x)
+    assert [int(v) for v in mx] == [max(abs(v) for v in r) for r in rows] and int(mx[3]) == 2 ** 63
+    assert wt.tolist() == [sum(1 for v in r if v != 0) for r in rows]

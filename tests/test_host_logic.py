@@ -404,3 +404,36 @@ def test_seed_array_takes_what_the_c_samplers_take():
     assert _seed_array(range(4)).tolist() == [0, 1, 2, 3]
     for bad in ([2**64 - 1, 5], [-1, 5], [-1, 2**63], [2**64, 1], np.array([-3, 4]), [2**70]):
         assert _seed_array(bad) is None
+
+
+def test_table_context_caches_are_bounded(monkeypatch):
+    """contexts built from caller-supplied tables are kept in an LRU of 8 and CLOSED on eviction (a caller iterating over tables
+    used to leak a context -- streams, events, device tables, a pool -- per table); the generic path's cache is bounded the same way"""
+    import fusion_hip.context as C
+    import fusion_hip.wide as W
+    closed = []
+
+    class FakeCtx:
+        def __init__(self, *a, **k):
+            self.key = (a, tuple(sorted(k.items())))
+
+        def close(self):
+            closed.append(self)
+    monkeypatch.setattr(C, "Context", FakeCtx)
+    monkeypatch.setattr(C, "_TABLE_CTX_CACHE", type(C._TABLE_CTX_CACHE)())
+    first = C.get_table_context(17, 4, (1, 2, 3, 4), (4, 3, 2, 1))
+    assert C.get_table_context(17, 4, (1, 2, 3, 4), (4, 3, 2, 1)) is first
+    for k in range(C._TABLE_CTX_MAX + 3):
+        C.get_table_context(17, 4, (1, 2, 3, 5 + k), (4, 3, 2, 1))
+        C.get_table_context(17, 4, (1, 2, 3, 4), (4, 3, 2, 1))                # kept alive by use
+    assert len(C._TABLE_CTX_CACHE) == C._TABLE_CTX_MAX and len(closed) == 4 and first not in closed
+    assert C.get_table_context(17, 4, (1, 2, 3, 4), (4, 3, 2, 1)) is first
+
+    class FakeWide:
+        def __init__(self, *a):
+            pass
+    monkeypatch.setattr(W, "WideContext", FakeWide)
+    monkeypatch.setattr(W, "_WIDE_CACHE", type(W._WIDE_CACHE)())
+    for k in range(W._WIDE_MAX + 5):
+        W.get_wide_context(2 ** 40 + 15, 4, (1, 2, 3, k), None)
+    assert len(W._WIDE_CACHE) == W._WIDE_MAX

@@ -19,9 +19,11 @@ step() { echo "[collect] $*" >&2; "$@" || { echo "[collect] FAILED ($?): $*" >&2
 lscpu | grep -E "Model name|Socket|Thread|Core" > $OUT/${TAG}_host_cpu.txt
 # the stand-alone microbenchmarks travel prebuilt (tools/microbench/build/, git-ignored); build whatever is missing
 mkdir -p tools/microbench/build
-for mb in launch_floor ntt_variants ntt_structures access_pattern mixed_ceiling; do
+for mb in launch_floor ntt_variants ntt_structures access_pattern mixed_ceiling shape_ceiling crosslane_latency keccak_wave; do
   [ -x tools/microbench/build/$mb ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/microbench/$mb.hip -o tools/microbench/build/$mb
 done
+[ -x tools/microbench/build/keccak_host_clang ] || /opt/rocm/lib/llvm/bin/clang++ -O3 -std=c++17 tools/microbench/keccak_host.cpp -o tools/microbench/build/keccak_host_clang
+[ -x tools/microbench/build/x64_throughput ] || g++ -O2 -mbmi -mbmi2 tools/microbench/x64_throughput.cpp -o tools/microbench/build/x64_throughput
 step timeout -k 10 200 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
 step timeout -k 10 120 ./tools/microbench/build/launch_floor > $OUT/${TAG}_launch_floor.txt 2>&1
 step timeout -k 10 300 python tools/kernel_table.py > $OUT/${TAG}_kernel_table.txt 2>&1
@@ -29,7 +31,17 @@ step timeout -k 10 300 python tools/kernel_table.py --secpar 128 > $OUT/${TAG}_k
 step timeout -k 10 400 python tools/probes/agg_direct_ab.py > $OUT/${TAG}_aggregate_direct_ab.txt 2>&1
 step timeout -k 10 300 python tools/probes/agg_direct_ab.py --small >> $OUT/${TAG}_aggregate_direct_ab.txt 2>&1
 step timeout -k 10 200 python tools/probes/ntt_ab.py > $OUT/${TAG}_ntt_small_batches.txt 2>&1
-step timeout -k 10 200 python tools/probes/challenge_bench.py > $OUT/${TAG}_challenge_pipeline.txt 2>&1
+# the challenge pipeline: as the library chooses its form by batch size, then each form forced (3 = a wave per signer, 1 = lane pairs)
+for f in 0 3 1; do FZ_SHAKE_FORM=$f timeout -k 10 200 python tools/probes/challenge_bench.py 2>&1 | grep -v amdgpu >> $OUT/${TAG}_challenge_pipeline.txt || exit 1; done
+# round 6: the wave-wide Keccak state against hashlib with its chain's time, the cross-lane primitives it is made of, where the
+# time of sign_batch(1024) goes, the host Keccak forms with the instruction latencies / throughputs behind them, and what a
+# stand-alone kernel with verify_fused's / polymul_fused's / the small aggregations' shape sustains
+step timeout -k 10 200 python tools/probes/keccak_wave_check.py 256 1024 2048 4096 > $OUT/${TAG}_keccak_wave_form.txt 2>&1
+step timeout -k 10 100 ./tools/microbench/build/crosslane_latency > $OUT/${TAG}_crosslane_latency.txt 2>&1
+step timeout -k 10 200 python tools/probes/sign_latency.py > $OUT/${TAG}_sign_latency.txt 2>&1
+step timeout -k 10 200 taskset -c 4 ./tools/microbench/build/keccak_host_clang > $OUT/${TAG}_keccak_host_forms.txt 2>&1
+step timeout -k 10 100 taskset -c 4 ./tools/microbench/build/x64_throughput >> $OUT/${TAG}_keccak_host_forms.txt 2>&1
+step timeout -k 10 200 ./tools/microbench/build/shape_ceiling 20 > $OUT/${TAG}_shape_ceilings.txt 2>&1
 step timeout -k 10 200 python tools/probes/keygen_probe.py > $OUT/${TAG}_keygen_end_to_end.txt 2>&1
 step timeout -k 10 200 python tools/probes/agg_probe.py > $OUT/${TAG}_aggregate_end_to_end.txt 2>&1
 step timeout -k 10 200 python tools/probes/copy_bw.py > $OUT/${TAG}_copy_ceiling.txt 2>&1
@@ -57,7 +69,7 @@ step timeout -k 10 600 bash tools/probes/exchange_overlap.sh > $OUT/${TAG}_excha
 step timeout -k 10 400 python tools/probes/hw_queue_probe.py > $OUT/${TAG}_hw_queue_oversubscription.txt 2>&1
 step timeout -k 10 300 python tools/probes/stream_sweep.py > $OUT/${TAG}_multi_stream_sweep.txt 2>&1
 step timeout -k 10 300 python tools/probes/queue_aggregates.py > $OUT/${TAG}_queue_aggregates.txt 2>&1
-step timeout -k 10 900 python tools/rccl_exit_matrix.py --out $OUT/${TAG}_rccl_exit_matrix.txt > $OUT/rccl_matrix.log 2>&1
+# (tools/rccl_exit_matrix.py, 15 minutes, is run by hand when the RCCL binding changes: profiles/r05_rccl_exit_matrix.txt stands)
 step timeout -k 10 600 python bench.py --full --full-out $OUT/${TAG}_bench_full.json > $OUT/${TAG}_bench_n1.json 2> $OUT/bench.err
 python3 tools/stamp_table.py $OUT/${TAG}_bench_full.json > $OUT/${TAG}_device_timestamps.txt
 cd /tmp && export TMPDIR=/tmp

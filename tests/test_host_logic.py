@@ -387,7 +387,8 @@ def test_tools_and_examples_compile():
         for m in re.finditer(r"(?:python3?|bash)\s+(?:\$R/)?(tools/[\w/]+\.(?:py|sh))", text):
             assert os.path.exists(os.path.join(root, m.group(1))), (sh, m.group(1))
         for m in re.finditer(r"tools/microbench/build/(\w+)", text):
-            assert os.path.exists(os.path.join(root, "tools", "microbench", m.group(1) + ".hip")), (sh, m.group(1))
+            name = re.sub(r"_(clang|gcc)$", "", m.group(1))                    # host microbenchmarks: <name>_<compiler> built from <name>.cpp
+            assert any(os.path.exists(os.path.join(root, "tools", "microbench", name + ext)) for ext in (".hip", ".cpp")), (sh, m.group(1))
 
 
 def test_seed_array_takes_what_the_c_samplers_take():

@@ -48,7 +48,7 @@ for sp_ in (128, 256):
 KERNS = ["", "4", "16", "4r1", "4r2", "4r4"]
 # the multi-launch forms of the fused kernels and other launch shapes of the one-pass aggregation
 VARIANTS = [{}, {"FZ_UNFUSED": "1"}, {"FZ_AGG_DIRECT": "-1"}, {"FZ_AGG_DIRECT": "2"}, {"FZ_AGG_DIRECT": "4", "FZ_VERIFY_ORDERED": "1"},
-            {"FZ_NO_IMAD": "1"}, {"FZ_VERIFY_CENT": "1"}, {"FZ_SHAKE_FORM": "2"},
+            {"FZ_NO_IMAD": "1"}, {"FZ_VERIFY_CENT": "1"}, {"FZ_SHAKE_FORM": "2"}, {"FZ_SHAKE_FORM": "1"}, {"FZ_SHAKE_FORM": "3"},
             {"FZ_MATVEC_SLICES": "16"}, {"FZ_MATVEC_SLICES": "2"}, {"FZ_MATVEC_SLICES": "-1"}]
 vctx = {(sp, i): make_ctx(sp, "", v) for sp in (128, 256) for i, v in enumerate(VARIANTS)}
 DB = fusion_hip.DeviceBuffer
@@ -178,6 +178,9 @@ while time.time() < t_end:
             vk[rng.random(size=vk.shape) < 0.3] = 0                         # short decimal texts
         msgs = [f"soak {it} {i} " + "x" * int(rng.integers(0, 200)) for i in range(nn)]
         coefs, pre = hostpipe.challenge_coefficients(HP, vk[:, 0], vk[:, 1], msgs)
+        # every form of the device pipeline: as chosen by batch size (a wave per signer here), a lane pair, a lane, a wave forced
+        cctx = [ctx] + [vctx[(sp, i)] for i, v in enumerate(VARIANTS) if "FZ_SHAKE_FORM" in v]
+        ctx = cctx[int(rng.integers(0, len(cctx)))]
         dv, dc = DB.from_numpy(ctx, vk), DB(ctx, nn * d * 4)
         if rng.random() < 0.5:
             ctx.challenge_dev(HP, dv.ptr, pre, nn, dc.ptr, transform=True)

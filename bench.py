@@ -59,6 +59,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 B = 4096                       # BASELINE configs[1]
 SECPAR = 256
 MIN_REGION_MS = 20.0           # the secondary legs' timed regions (many legs: the default run stays within minutes)
+ROOFLINE_REGION_MS = 250.0     # the one-stream region `roofline.frac` / `avg_launch_us` come from (~4 600 launches of 54 us)
 HEADLINE_REGION_MS = 1000.0    # the region `value` comes from: long enough for the driver's clock and its GPU-busy sampler to see it
 NBATCH = 64                    # batches in the rotation: 3 x 64 x 4 MiB = 768 MiB, three times the 256 MB Infinity Cache
 LINE_LIMIT = 4096              # bytes of the compact line (tests/test_bench_line.py)
@@ -840,7 +841,7 @@ def main():
     # streams: in its trace of this script no two launches overlap)
     if S > 1:
         prewarm([solo], mode, 20.0)
-        one = summary(region([solo], mode, args.steps), mode)
+        one = summary(region([solo], mode, args.steps, ROOFLINE_REGION_MS), mode)
     else:
         one = head
 

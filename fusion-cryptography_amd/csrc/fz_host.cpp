@@ -623,7 +623,7 @@ int fz_sort_by_vk_string(const fz_scheme_params *P, const int32_t *h_vk_left, co
     // text per key for a comparison that ends within its first dozen characters was 3 ms per 1024 keys.
     const int K = std::min(8, d - 1);
     std::vector<std::string> keys(N), full(N);
-    parallel_for(N, threads, [&](size_t i) {
+    parallel_for(N, N <= 4096 ? 1 : std::min(threads, 8), [&](size_t i) {      // eight integers per key: 50 us for 1024 keys on one thread
         keys[i].reserve(12 * (size_t)K + 1);
         for (int j = 0; j < K; ++j) { put_int(keys[i], h_vk_left[i * (size_t)d + j]); keys[i] += ", "; }
     });
@@ -668,7 +668,9 @@ int fz_aggregation_coefficients(const fz_scheme_params *P, const int32_t *h_vk_l
     for (size_t i = 0; i < N; ++i) ready[i].store(0, std::memory_order_relaxed);
     std::atomic<size_t> next(0);
     std::vector<std::thread> writers;
-    const size_t n_writers = (threads > 1 && N > 1) ? std::min<size_t>((size_t)threads - 1, N) : 0;
+    // seven writers keep ahead of the sponge with room to spare (the texts are ~9 ms of work per 1024 signers, the sponge 15 ms);
+    // starting 31 threads costs the calling thread ~0.5 ms before its first absorb and measured 16.1 ms against 14.9 with eight
+    const size_t n_writers = (threads > 1 && N > 1) ? std::min<size_t>(std::min<size_t>((size_t)threads - 1, 7), N) : 0;
     for (size_t t = 0; t < n_writers; ++t)
         writers.emplace_back([&]() {
             for (;;) {
@@ -703,7 +705,7 @@ int fz_aggregation_coefficients(const fz_scheme_params *P, const int32_t *h_vk_l
     std::vector<uint8_t> xof(n * N);
     sp.squeeze(xof.data(), xof.size());
     std::atomic<int> bad(0);      // set by any worker thread
-    parallel_for(N, threads, [&](size_t i) {
+    parallel_for(N, std::min(threads, 8), [&](size_t i) {          // (a few microseconds per signer: more threads cost more to start than they save)
         if (decode(xof.data() + i * n, n, P->secpar, P->modulus, d, P->beta_ag, P->omega_ag, h_coefs + i * (size_t)d) != 0)
             bad = 1;
     });

@@ -236,3 +236,45 @@ def test_more_signers_than_one_pass_holds(coracle):
     finally:
         dvk.free()
         dout.free()
+
+
+@pytest.mark.parametrize("form", [1, 3])
+@pytest.mark.parametrize("d,omega,secpar", [(16, 5, 128), (64, 63, 128), (64, 64, 128), (256, 1, 256), (128, 64, 256), (8, 3, 64), (4, 1, 40),
+                                            (32, 31, 200), (256, 64, 96)])
+def test_device_pipeline_on_parameters_beyond_the_two_sets(form, d, omega, secpar, monkeypatch):
+    """The device pipeline takes any degree 4..256, any weight (the wave form: up to 64) and any secpar the decoder's chunk
+    buffers hold: weights that leave no shuffle draw (omega = d - 1), no shuffle at all (omega = d) or one coefficient, index chunks
+    of 6 to 33 bytes, texts from 8 to 512 values -- lane-pair and wave forms against the host pipeline (fusion.py:422-481, :511-531)"""
+    import types
+    import fusion_hip
+    from fusion_hip import hostpipe
+    q = O.PRIME
+    root = pow(O.PARAMS[256]["root"], 256 // d, q)            # a primitive 2d-th root of unity
+    inv = pow(root, q - 2, q)
+    prm = types.SimpleNamespace(modulus=q, root=root, inv_root=inv, degree=d, root_order=2 * d, secpar=secpar, omega_ch=omega, omega_ag=omega,
+                                beta_ch=1, beta_ag=1, bytes_for_one_coef_bdd_by_beta_ch=0, bytes_for_poly_shuffle=0,
+                                sign_pre_hash_dst=bytes([9, 0]), sign_hash_dst=bytes([9, 1]), agg_xof_dst=bytes([9, 2]))
+    P = hostpipe.scheme_params(prm)
+    monkeypatch.setenv("FZ_SHAKE_FORM", str(form))
+    ctx = fusion_hip.Context(q, d, root, inv)
+    monkeypatch.delenv("FZ_SHAKE_FORM")
+    n = 37
+    rng = np.random.default_rng(d * 1000 + omega + secpar + form)
+    vk = rng.integers(-(q // 2), q // 2 + 1, size=(n, 2, d)).astype(np.int32)
+    vk[3] = 0
+    msgs = [f"m{i}" * (i % 7) for i in range(n)]
+    coefs, pre = hostpipe.challenge_coefficients(P, vk[:, 0], vk[:, 1], msgs)
+    assert (np.abs(coefs).sum(axis=1) == min(omega, d)).all() and set(np.unique(coefs)) <= {-1, 0, 1}
+    blob, off = hostpipe._pack_messages(msgs)
+    dvk = fusion_hip.DeviceBuffer.from_numpy(ctx, vk)
+    dout = fusion_hip.DeviceBuffer(ctx, n * d * 4)
+    try:
+        got_pre = ctx.challenge_msgs_dev(P, dvk.ptr, blob, off, n, dout.ptr, want_prehash=True)
+        assert np.array_equal(got_pre, pre)
+        assert np.array_equal(dout.to_numpy(np.int32, (n, d)), ctx.ntt_forward(coefs))
+        ctx.challenge_dev(P, dvk.ptr, pre, n, dout.ptr, transform=False)
+        assert np.array_equal(dout.to_numpy(np.int32, (n, d)), coefs)
+    finally:
+        dvk.free()
+        dout.free()
+        ctx.close()

@@ -402,9 +402,12 @@ FZ_API int fz_aggregation_coefficients(const fz_scheme_params *P, const int32_t 
  * SHAKE-256 (fusion.py:412-419), the byte decoder (fusion.py:422-481) and -- fz_challenge_hat_dev -- the forward
  * transform (fusion.py:499-507).  d_vk [N][2][degree] as fz_keygen_core writes it (left row, right row); h_prehash
  * [N][32] from fz_hash_messages (HOST memory: 32 bytes per message, converted to decimal text and uploaded by the call);
- * d_coefs / d_c_hat [N][degree].  Asynchronous apart from that upload.  Only as many XOF bytes are squeezed as the
- * decoder consumes (a prefix of the reference's n).  Supported: ternary challenges (norm bound 1: both parameter sets
- * of the reference), degree 4..256; otherwise FZ_E_UNSUPPORTED -- use fz_challenge_coefficients.
+ * d_coefs / d_c_hat [N][degree].  Asynchronous on the context's stream; the caller's HOST arrays have been consumed when
+ * the call returns (up to 4608 signers per call -- a wave per signer, one fused kernel -- they are copied into pinned staging
+ * that the kernel reads in place: nothing is uploaded and nothing waited for; larger batches upload them and synchronise
+ * once).  Only as many XOF bytes are squeezed as the decoder consumes (a prefix of the reference's n).  Supported: ternary
+ * challenges (norm bound 1: both parameter sets of the reference), degree 4..256; otherwise FZ_E_UNSUPPORTED -- use
+ * fz_challenge_coefficients.
  * hash_ag (fusion.py:632-652) stays on the host: it is ONE serial XOF over all signers by construction. */
 FZ_API int fz_challenge_coefficients_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const uint8_t *h_prehash,
                                          size_t N, int32_t *d_coefs);
@@ -412,7 +415,8 @@ FZ_API int fz_challenge_hat_dev(fz_ctx *ctx, const fz_scheme_params *P, const in
                                 size_t N, int32_t *d_c_hat);
 /* The same with hash_message_to_int (fusion.py:405-409: SHA3-256 of dst + "," + message) on the device as well: h_msgs the
  * N messages' bytes back to back (UTF-8, as the reference's .encode()), h_msg_off [N + 1] their offsets (as
- * fz_hash_messages takes them); h_prehash_out (optional) receives the [N][32] digests, which hash_ag needs on the host. */
+ * fz_hash_messages takes them); h_prehash_out (optional) receives the [N][32] digests, which hash_ag needs on the host
+ * (the call then synchronises the stream before it returns: the digests are the kernel's). */
 FZ_API int fz_challenge_hat_msgs_dev(fz_ctx *ctx, const fz_scheme_params *P, const int32_t *d_vk, const char *h_msgs,
                                      const size_t *h_msg_off, size_t N, int32_t *d_c_hat, uint8_t *h_prehash_out);
 

@@ -116,6 +116,9 @@ struct Wave {
         // halves travel in ONE register after the first swap: even rows carry lo, odd rows hi.  A swap consumes two registers:
         // where both must hold the same value it is computed twice (two independent instructions) rather than copied (an
         // instruction that waits for the first); the second forms differ only in spelling, to keep the compiler from merging them.
+        // (Each half reduced on its own -- row_ror:8, v_permlane16_swap and v_permlane32_swap of a value with its twin, no step
+        // to take the halves apart again: five dependent steps instead of six, 30 instructions per round instead of 24 --
+        // measured SLOWER, 256 / 275 us against 247 / 266: a lone wave pays for every instruction, not only for the chain.)
         const auto s1 = __builtin_amdgcn_permlane16_swap(lo, hi, false, false);       // [lo r0, hi r0, lo r2, hi r2] / [lo r1, hi r1, lo r3, hi r3]
         const uint32_t z0 = s1[0] ^ s1[1];                                            // rows r ^ (r xor 1)
         const uint32_t za = z0 ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)z0, 0x128, 0xf, 0xf, false);       // the row's two groups

@@ -349,6 +349,7 @@ static int ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint
         // atomics; anything that does not report gfx950 gets the acquire/release instantiation.
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) c->knob_verify_ordered = 1;
         c->knob_unfused = knob("FZ_UNFUSED");
+        c->knob_polymul_form = knob("FZ_POLYMUL_FORM");
         c->knob_no_imad = knob("FZ_NO_IMAD");
         c->knob_matvec_slices = knob("FZ_MATVEC_SLICES");
         c->knob_verify_cent = knob("FZ_VERIFY_CENT");
@@ -357,6 +358,11 @@ static int ctx_create(int device_id, uint32_t q, int degree, uint32_t root, uint
     }
     if (rc == FZ_OK) rc = upload_doubles(twB, nB, &c->d_twB);
     if (rc == FZ_OK) rc = upload_doubles(itwB, nB, &c->d_itwB);
+    if (rc == FZ_OK && nB) {
+        static_assert(sizeof(FzTwA) == 36 * sizeof(double), "FzTwA is 36 doubles");
+        const FzTwA both[2] = {c->twA, c->itwA};
+        rc = upload_doubles(reinterpret_cast<const double *>(both), 72, &c->d_twAB);
+    }
     if (rc == FZ_OK) rc = fz_check_hip(hipMalloc((void **)&c->d_verdict, 64 * sizeof(int)), "verdict alloc");
     c->verdict_cap = 64;
     if (rc == FZ_OK && !ring_only) rc = fz_ntt_query_grid(c);
@@ -389,6 +395,7 @@ int fz_ctx_destroy(fz_ctx *ctx) {
     if (ctx->d_itw2) (void)hipFree(ctx->d_itw2);
     if (ctx->d_twB) (void)hipFree(ctx->d_twB);
     if (ctx->d_itwB) (void)hipFree(ctx->d_itwB);
+    if (ctx->d_twAB) (void)hipFree(ctx->d_twAB);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_scratch2) (void)hipFree(ctx->d_scratch2);
     if (ctx->d_verdict) (void)hipFree(ctx->d_verdict);
@@ -926,11 +933,10 @@ int fz_poly_mul(fz_ctx *ctx, const int32_t *d_f, const int32_t *d_g, int32_t *d_
     FZ_DEV(ctx);
     if (ctx->logd < 0) return fz_set_error(FZ_E_UNSUPPORTED, "ring-only context (created with root 0) has no transforms");
     if (batch == 0) return FZ_OK;
-    if ((ctx->logd == 6 || ctx->logd == 8) && !ctx->knob_unfused) {
-        if ((((uintptr_t)d_f | (uintptr_t)d_g | (uintptr_t)d_out) & 3) != 0)
-            return fz_set_error(FZ_E_BADARG, "buffers must be 4-byte aligned");
+    if ((((uintptr_t)d_f | (uintptr_t)d_g | (uintptr_t)d_out) & 3) != 0)
+        return fz_set_error(FZ_E_BADARG, "buffers must be 4-byte aligned");
+    if (!ctx->knob_unfused && (ctx->logd == 6 || ctx->logd == 8 || fz_polymul16_ok(ctx, d_f, d_g, d_out, batch)))
         return fz_launch_polymul_fused(ctx, d_f, d_g, d_out, batch);
-    }
     // generic degrees: NTT(f), NTT(g) into scratch, product in place, inverse into out
     const size_t n = batch * (size_t)ctx->degree, seg = (n * sizeof(int32_t) + 255) & ~(size_t)255;
     void *d = nullptr;

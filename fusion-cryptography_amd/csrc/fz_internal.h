@@ -44,6 +44,7 @@ struct fz_ctx {
     // device tables
     double *d_tw, *d_itw;        // [degree] as doubles (generic / small kernels)
     double *d_twB, *d_itwB;      // per-lane tables of the contiguous pass, [NE][L] pairs (w, w*K/q)
+    double *d_twAB;              // {twA, itwA} as two FzTwA in device memory (polymul16 reads them as constants, per direction)
     double *d_tw2, *d_itw2;      // full tables as (w, w*K/q) pairs, [degree] (radix-4 kernels)
     int small_batch_rows;        // below this many rows the radix-4 (4 coefficients per lane) kernels run
     int force_kernel;            // 0 auto, 4 radix-4, 16 sixteen-per-lane (env FZ_NTT_KERNEL; tests and A/B runs)
@@ -55,6 +56,7 @@ struct fz_ctx {
     size_t verdict_cap;
     int grid_fwd, grid_inv;      // resident-grid caps for the persistent NTT kernels
     int grid_pm;                 // resident grid of the fused product kernel (0 = not queried yet)
+    int grid_pm16;               // ... of its 16-per-lane form
     int knob_ntt_rows;           // FZ_NTT_ROWS = 1 | 2 | 4: row groups per wave of the radix-4 kernels (0 = by batch size)
     // per-dispatch timing of the NTT kernels (fz_profile_begin/end): event pairs bound to the
     // dispatch itself via hipExtLaunchKernelGGL, i.e. kernel begin -> kernel end on its own stream
@@ -87,6 +89,7 @@ struct fz_ctx {
     int knob_agg_direct;         // FZ_AGG_DIRECT: -1 = never the slice-free aggregation kernel, 2 | 4 = always, with that many rows per tile (0 = by size)
     int knob_shake_full;         // FZ_SHAKE_FORM: 1 = lane pairs, 2 = whole state per lane, 3 = a wave per signer (0 = by batch size)
     int knob_verify_ordered;     // FZ_VERIFY_ORDERED=1 (and every device that is not gfx950): acquire / release on verify_fused's arrival atomic
+    int knob_polymul_form;       // FZ_POLYMUL_FORM: 1 = the radix-4 product kernel, 2 = the 16-per-lane one (0 = by batch size)
     int knob_unfused;            // FZ_UNFUSED=1: the multi-launch paths of keygen / verification / the coefficient-domain product (what degrees other than 64 / 256 take anyway)
     hipStream_t diag_stream;     // fz_diag_shader_clock: the probe's private stream and result words (created on first use)
     unsigned long long *d_diag;
@@ -191,6 +194,7 @@ size_t fz_host_challenge_needed_bytes(const fz_scheme_params *P, int *sign_bytes
 bool fz_host_params_ok(const fz_scheme_params *P);
 
 int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int32_t *out, size_t batch);
+bool fz_polymul16_ok(const fz_ctx *ctx, const int32_t *f, const int32_t *g, const int32_t *out, size_t batch);
 int fz_launch_keygen_fused(fz_ctx *ctx, const int32_t *A, const int32_t *coef, int32_t *sk_hat, int32_t *vk, size_t segments,
                            int l, bool broadcast = false);
 int fz_launch_fill_synthetic(fz_ctx *ctx, int32_t *out, size_t count, unsigned long long seed);

@@ -146,6 +146,123 @@ template <int LOGD> constexpr int lds16_doubles() {
     return kWavesPerBlock * G::PPW * G::PS + 2 * G::NE * G::L;
 }
 
+// The two passes of the 16-per-lane forward transform on a lane's registers: in, a[k] = element r + L*k of the lane's polynomial
+// (|a| <= 2^31); out, a[k] = element 16 * lane' + k of the transform in the order algebra/ntt.py:271-291 leaves it (lane' = the
+// lane's index inside its polynomial), NOT reduced (|a| < 2^(34+SB)).  `row` is the polynomial's transpose buffer in LDS; the
+// caller has finished reading whatever the buffer held before (a wave_sync) and may write it again after the return.
+template <int LOGD, bool FAST, class TA>
+__device__ __forceinline__ void fwd16_passes(double (&a)[16], double *row, const int r, const double2 *s_tw, const TA &twA,
+                                             const FzMod &m) {
+    using G = Geom<LOGD>;
+    constexpr int L = G::L, SB = G::SB;
+    // strided pass: a 16-point LN transform over k with table entries 1..15 (|a| < 2^34 throughout)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int tk = 8 >> s;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k & tk) continue;
+            const int e = (1 << s) + (k >> (4 - s));
+            const double v = tw_mul<FAST>(a[k + tk], twA.w[e], twA.w2[e], m);
+            const double u = a[k];
+            a[k] = u + v;
+            a[k + tk] = u - v;
+        }
+    }
+
+    // transpose: element j = r + L*k  ->  lane j/16, register j%16
+#pragma unroll
+    for (int k = 0; k < 16; ++k) (row + r)[pad16(L * k)] = a[k];       // = row[pad16(r + L * k)]: r < L and L divides 16 (constant offsets)
+    wave_sync();
+    {
+        const double2 *blk = reinterpret_cast<const double2 *>(row + 18 * r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double2 t = blk[k];
+            a[2 * k] = t.x;
+            a[2 * k + 1] = t.y;
+        }
+    }
+    wave_sync();
+
+    // contiguous pass: stages with distance 2^(SB-1) .. 1, per-lane twiddles
+#pragma unroll
+    for (int ls = 0; ls < SB; ++ls) {
+        const int t = 1 << (SB - 1 - ls);
+        const int ebase = (16 >> SB) * ((1 << ls) - 1);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k & t) continue;
+            const int g = k >> (SB - ls);
+            const double2 w = s_tw[(ebase + g) * L + r];
+            const double v = tw_mul<FAST>(a[k + t], w.x, w.y, m);
+            const double u = a[k];
+            a[k] = u + v;
+            a[k + t] = u - v;
+        }
+    }
+}
+
+// ... and of the inverse: in, a[k] = element 16 * lane' + k (|a| <= 2^31); out, a[k] = element r + L*k, scaled by n^-1, NOT
+// centred (|a| <= q/2 + q * 2^-13: every output has passed the last stage's multiply).
+template <int LOGD, bool FAST, class TA>
+__device__ __forceinline__ void inv16_passes(double (&a)[16], double *row, const int r, const double2 *s_tw, const TA &twA,
+                                             const FzMod &m) {
+    using G = Geom<LOGD>;
+    constexpr int L = G::L, SB = G::SB;
+    // contiguous pass: GS stages with distance 1, 2, .. 2^(SB-1); operands |u - v| <= 2^(32+ls)
+#pragma unroll
+    for (int ls = 0; ls < SB; ++ls) {
+        const int t = 1 << ls;
+        const int ebase = 16 - (16 >> ls);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k & t) continue;
+            const int g = k >> (ls + 1);
+            const double2 w = s_tw[(ebase + g) * L + r];
+            const double u = a[k], v = a[k + t];
+            a[k] = u + v;
+            a[k + t] = tw_mul<FAST>(u - v, w.x, w.y, m);
+        }
+    }
+
+    // After the contiguous pass a[0] (the sum of the lane's 16 inputs, up to 2^(31+SB)) is the one value no multiply
+    // has reduced; a[1] <= 2^(29+SB), the rest less.  One fold (2 ops) brings the largest operand of the strided pass
+    // down to 2^(29+SB) * 2^4 <= 2^37: the last stage can then use the 4-op multiply (16 x 2 ops saved per lane).
+    if (FAST && 31 + SB + 4 > 38) a[0] = fz_fold(a[0], m);
+    // transpose back to the strided layout
+    {
+        double2 *blk = reinterpret_cast<double2 *>(row + 18 * r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) blk[k] = make_double2(a[2 * k], a[2 * k + 1]);
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = (row + r)[pad16(L * k)];       // = row[pad16(r + L * k)] (see fwd16_passes)
+    wave_sync();
+
+    // strided pass: GS stages with distance L, 2L, 4L, 8L; uniform twiddles; n^-1 folded into the last stage.
+    // Operands stay below 2^38 (see the fold above), so every stage uses the 4-op multiply when the modulus admits it.
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int tk = 1 << s;
+        const int h = 8 >> s;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k & tk) continue;
+            const double u = a[k], v = a[k + tk];
+            if (s == 3) {
+                a[k] = tw_mul<FAST>(u + v, twA.n_inv, twA.n_inv2, m);
+                a[k + tk] = tw_mul<FAST>(u - v, twA.w1_n_inv, twA.w1_n_inv2, m);
+            } else {
+                const int e = h + (k >> (s + 1));
+                a[k] = u + v;
+                a[k + tk] = tw_mul<FAST>(u - v, twA.w[e], twA.w2[e], m);
+            }
+        }
+    }
+}
+
 // the whole forward kernel as a function of (block index, blocks that share the batch): ntt_fwd16 runs it over the grid,
 // ntt_jobs16 over the run of workgroups a job owns
 template <int LOGD, bool FAST>
@@ -202,52 +319,7 @@ __device__ __forceinline__ void fwd16_run(const int32_t *in, int32_t *out, size_
         }
         wave_sync();
 
-        // strided pass: a 16-point LN transform over k with table entries 1..15 (|a| < 2^34 throughout)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int tk = 8 >> s;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k & tk) continue;
-                const int e = (1 << s) + (k >> (4 - s));
-                const double v = tw_mul<FAST>(a[k + tk], twA.w[e], twA.w2[e], m);
-                const double u = a[k];
-                a[k] = u + v;
-                a[k + tk] = u - v;
-            }
-        }
-
-        // transpose: element j = r + L*k  ->  lane j/16, register j%16
-#pragma unroll
-        for (int k = 0; k < 16; ++k) row[pad16(r + L * k)] = a[k];
-        wave_sync();
-        {
-            const double2 *blk = reinterpret_cast<const double2 *>(row + 18 * r);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                double2 t = blk[k];
-                a[2 * k] = t.x;
-                a[2 * k + 1] = t.y;
-            }
-        }
-        wave_sync();
-
-        // contiguous pass: stages with distance 2^(SB-1) .. 1, per-lane twiddles
-#pragma unroll
-        for (int ls = 0; ls < SB; ++ls) {
-            const int t = 1 << (SB - 1 - ls);
-            const int ebase = (16 >> SB) * ((1 << ls) - 1);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k & t) continue;
-                const int g = k >> (SB - ls);
-                const double2 w = s_tw[(ebase + g) * L + r];
-                const double v = tw_mul<FAST>(a[k + t], w.x, w.y, m);
-                const double u = a[k];
-                a[k] = u + v;
-                a[k + t] = u - v;
-            }
-        }
+        fwd16_passes<LOGD, FAST>(a, row, r, s_tw, twA, m);
 
         // lane holds chunk elements [16*lane, 16*lane + 16): centre, stage, store coalesced
 #pragma unroll
@@ -323,57 +395,7 @@ __device__ __forceinline__ void inv16_run(const int32_t *in, int32_t *out, size_
         }
         wave_sync();
 
-        // contiguous pass: GS stages with distance 1, 2, .. 2^(SB-1); operands |u - v| <= 2^(32+ls)
-#pragma unroll
-        for (int ls = 0; ls < SB; ++ls) {
-            const int t = 1 << ls;
-            const int ebase = 16 - (16 >> ls);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k & t) continue;
-                const int g = k >> (ls + 1);
-                const double2 w = s_tw[(ebase + g) * L + r];
-                const double u = a[k], v = a[k + t];
-                a[k] = u + v;
-                a[k + t] = tw_mul<FAST>(u - v, w.x, w.y, m);
-            }
-        }
-
-        // After the contiguous pass a[0] (the sum of the lane's 16 inputs, up to 2^(31+SB)) is the one value no multiply
-        // has reduced; a[1] <= 2^(29+SB), the rest less.  One fold (2 ops) brings the largest operand of the strided pass
-        // down to 2^(29+SB) * 2^4 <= 2^37: the last stage can then use the 4-op multiply (16 x 2 ops saved per lane).
-        if (FAST && 31 + SB + 4 > 38) a[0] = fz_fold(a[0], m);
-        // transpose back to the strided layout
-        {
-            double2 *blk = reinterpret_cast<double2 *>(row + 18 * r);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) blk[k] = make_double2(a[2 * k], a[2 * k + 1]);
-        }
-        wave_sync();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = row[pad16(r + L * k)];
-        wave_sync();
-
-        // strided pass: GS stages with distance L, 2L, 4L, 8L; uniform twiddles; n^-1 folded into the last stage.
-        // Operands stay below 2^38 (see the fold above), so every stage uses the 4-op multiply when the modulus admits it.
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int tk = 1 << s;
-            const int h = 8 >> s;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k & tk) continue;
-                const double u = a[k], v = a[k + tk];
-                if (s == 3) {
-                    a[k] = tw_mul<FAST>(u + v, twA.n_inv, twA.n_inv2, m);
-                    a[k + tk] = tw_mul<FAST>(u - v, twA.w1_n_inv, twA.w1_n_inv2, m);
-                } else {
-                    const int e = h + (k >> (s + 1));
-                    a[k] = u + v;
-                    a[k + tk] = tw_mul<FAST>(u - v, twA.w[e], twA.w2[e], m);
-                }
-            }
-        }
+        inv16_passes<LOGD, FAST>(a, row, r, s_tw, twA, m);
 
 #pragma unroll
         for (int k = 0; k < 16; ++k) stage[pad4(p * D + r + L * k)] = (int)fz_cent(a[k], m);
@@ -871,6 +893,106 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void polymul_fused(const int32
         }
         wave_sync();      // the next product's first-pass writes must not overtake this one's last reads
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same product on the 16-per-lane transforms (32 <= D <= 256): ONE exchange through LDS per transform instead of the three
+// of the radix-4 passes (polymul_fused above spends half its LDS pipe and a fifth of its cycles waiting on them,
+// profiles/r06_shape_ceilings.txt), global traffic as 16 bytes per lane like ntt_fwd16 / ntt_inv16.  For batches that give
+// every SIMD a few of these 128-register waves; smaller ones stay with the radix-4 kernel (fz_launch_polymul_fused chooses).
+// A wave-task is one 4 KiB chunk of f, of g and of the product (PPW polynomials).  Pipeline: f's next chunk is requested at
+// the top of an iteration and g's next chunk once g's current image has left the registers, so at most two chunks are held
+// in registers; f waits in the staging image, g in registers; the stores are the youngest operations (see fwd16_run).
+// `out` may alias `f` or `g`: a wave reads chunk t of both before it writes chunk t, and no other wave touches chunk t.
+// ------------------------------------------------------------------------------------------
+template <int LOGD> constexpr int lds_pm16_doubles() {
+    using G = Geom<LOGD>;
+    return kWavesPerBlock * G::PPW * G::PS + 4 * G::NE * G::L;      // a transpose region per wave + both per-lane twiddle tables
+}
+
+template <int LOGD, bool FAST>
+__global__ __launch_bounds__(64 * kWavesPerBlock, 3) void polymul16(const int32_t *f, const int32_t *g, int32_t *out, size_t batch,
+                                                                 const double2 *__restrict__ twB, const double2 *__restrict__ itwB,
+                                                                 const FzTwA *tabs, FzMod m) {
+    using G = Geom<LOGD>;
+    constexpr int D = G::D, L = G::L, PPW = G::PPW, NE = G::NE, PS = G::PS;
+    constexpr int REGION = PPW * PS;
+    // The wave-uniform tables of both directions are 2 x 60 scalar registers where 102 exist: as kernel arguments they are loaded
+    // once and then spilled into vector lanes (180 v_readlane per iteration).  They are read from constant memory instead, each
+    // direction where it is used: the empty asm makes the pointer opaque, so the loads cannot be hoisted back out of the loop.
+    typedef const __attribute__((address_space(4))) FzTwA *TabPtr;
+    __shared__ __attribute__((aligned(16))) double lds[lds_pm16_doubles<LOGD>()];
+    double2 *s_tw = reinterpret_cast<double2 *>(lds + kWavesPerBlock * REGION), *s_itw = s_tw + NE * L;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p = lane / L, r = lane % L;
+    const size_t total = batch * D;
+    const size_t tasks = (total + kChunk - 1) / kChunk;
+    const size_t first = (size_t)blockIdx.x * kWavesPerBlock + wave;
+    const size_t stride = (size_t)gridDim.x * kWavesPerBlock;
+    Chunk rawF = {}, rawG = {};
+    if (first < tasks) {                                  // before the tables: see fwd16_run
+        rawF = chunk_load(f, first, total, lane);
+        rawG = chunk_load(g, first, total, lane);
+    }
+    for (int i = threadIdx.x; i < NE * L; i += 64 * kWavesPerBlock) {
+        s_tw[i] = twB[i];
+        s_itw[i] = itwB[i];
+    }
+    __syncthreads();                                      // the only workgroup-wide barrier
+    double *region = lds + wave * REGION;
+    int32_t *stage = reinterpret_cast<int32_t *>(region);
+    double *row = region + p * PS;
+    if (first >= tasks) return;
+    chunk_to_lds(stage, lane, rawF);
+
+    // element r + L*k of the lane's polynomial in the staging image: pad4(p * D + r + L * k) = pad4(p * D) + r + pad4(L * k), because
+    // r < L and L divides 16 -- one address register and sixteen constant offsets instead of sixteen registers
+    int32_t *strided = stage + pad4(p * D) + r;
+    auto strided_from_stage = [&](double (&a)[16]) __attribute__((always_inline)) {
+        int x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = strided[pad4(L * k)];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = (double)x[k];
+    };
+    auto iteration = [&](const size_t task, auto more_tag) __attribute__((always_inline)) {       // peeling: see fwd16_run
+        constexpr bool more = decltype(more_tag)::value;
+        if (more) rawF = chunk_load(f, task + stride, total, lane);
+        wave_sync();
+        double b[16];
+        int fa[16];                                       // NTT(f), centred: 16 registers while g is transformed, not 32
+        TabPtr tf = (TabPtr)tabs;
+        asm volatile("" : "+s"(tf));
+        strided_from_stage(b);
+        wave_sync();
+        fwd16_passes<LOGD, FAST>(b, row, r, s_tw, tf[0], m);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) fa[k] = (int)fz_cent(b[k], m);
+        chunk_to_lds(stage, lane, rawG);                               // waits for g's chunk; f's next one is younger
+        if (more) rawG = chunk_load(g, task + stride, total, lane);
+        wave_sync();
+        strided_from_stage(b);
+        wave_sync();
+        fwd16_passes<LOGD, FAST>(b, row, r, s_tw, tf[0], m);
+        TabPtr ti = (TabPtr)tabs + 1;
+        asm volatile("" : "+s"(ti));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) b[k] = fz_mulmod(b[k], (double)fa[k], m);      // |b * fa| < 2^69; |result| <= q/2 + 1: an input the inverse accepts
+        inv16_passes<LOGD, FAST>(b, row, r, s_itw, ti[0], m);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) strided[pad4(L * k)] = (int)fz_cent(b[k], m);
+        wave_sync();
+        const int4 o0 = *reinterpret_cast<const int4 *>(stage + pad4(4 * lane));
+        const int4 o1 = *reinterpret_cast<const int4 *>(stage + pad4(256 + 4 * lane));
+        const int4 o2 = *reinterpret_cast<const int4 *>(stage + pad4(512 + 4 * lane));
+        const int4 o3 = *reinterpret_cast<const int4 *>(stage + pad4(768 + 4 * lane));
+        wave_sync();
+        if (more) chunk_to_lds(stage, lane, rawF);        // waits for f's next chunk; g's next one and the stores are younger
+        chunk_store(out, task, total, lane, o0, o1, o2, o3);
+    };
+    size_t task = first;
+    for (; task + stride < tasks; task += stride) iteration(task, std::true_type());
+    iteration(task, std::false_type());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1557,10 +1679,48 @@ int fz_launch_verify_fused_i64(fz_ctx *ctx, const int32_t *A, const int64_t *sig
     return launch_verify_fused<int64_t>(ctx, A, sig, sig_stride, target, target_stride, groups, l, beta, omega, d_verdict);
 }
 
-// fused product for degree 64 / 256; the caller composes the generic path for other degrees
+// the 16-per-lane form of the fused product (degrees 32..256, 16-byte aligned operands)
+template <int LOGD, bool FAST>
+static int launch_polymul16(fz_ctx *ctx, const int32_t *f, const int32_t *g, int32_t *out, size_t batch) {
+    if (ctx->grid_pm16 == 0) {
+        int n = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, polymul16<LOGD, FAST>, 64 * kWavesPerBlock, 0);
+        if (e != hipSuccess) return fz_check_hip(e, "occupancy query (polymul16)");
+        ctx->grid_pm16 = (n < 1 ? 1 : n) * ctx->num_cu;
+    }
+    const size_t tasks = (batch * (size_t)ctx->degree + kChunk - 1) / kChunk, blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid((unsigned)(blocks < (size_t)ctx->grid_pm16 ? blocks : (size_t)ctx->grid_pm16)), block(64 * kWavesPerBlock);
+    hipLaunchKernelGGL((polymul16<LOGD, FAST>), grid, block, 0, ctx->stream, f, g, out, batch, (const double2 *)ctx->d_twB,
+                       (const double2 *)ctx->d_itwB, (const FzTwA *)ctx->d_twAB, ctx->mod);
+    return fz_check_hip(hipGetLastError(), "polymul16 launch");
+}
+
+// Which form (tools/probes/polymul_crossover.py, profiles/r06_polymul_crossover.txt): at degree 256 the 16-per-lane kernel from
+// 2^14 products on (18.2 against 19.3 us there, 118 against 130 us at 2^17: 42.6 % of 8 TB/s against 38.8 %; below, its start-up
+// -- a table twice the size, two chunks per wave before the first butterfly -- costs more than the exchanges it saves); at
+// degree 64 the radix-4 kernel at every size (three passes instead of four: 45.5 % at 2^17 products against 44.7 %); degrees
+// 32 and 128 have no radix-4 form.  FZ_POLYMUL_FORM = 1 | 2 forces one.
+constexpr size_t kPolymul16MinRows256 = (size_t)1 << 14;
+
+bool fz_polymul16_ok(const fz_ctx *ctx, const int32_t *f, const int32_t *g, const int32_t *out, size_t batch) {
+    if (ctx->logd < 5 || ctx->logd > 8 || ctx->knob_polymul_form == 1) return false;
+    if ((((uintptr_t)f | (uintptr_t)g | (uintptr_t)out) & 15) != 0) return false;
+    if (ctx->logd == 5 || ctx->logd == 7 || ctx->knob_polymul_form == 2) return true;
+    return ctx->logd == 8 && batch >= kPolymul16MinRows256;
+}
+
+// fused product: degrees 64 / 256 in either form, 32 / 128 in the 16-per-lane form; the caller composes the generic path otherwise
 int fz_launch_polymul_fused(fz_ctx *ctx, const int32_t *f, const int32_t *g, int32_t *out, size_t batch) {
-    if (ctx->logd != 6 && ctx->logd != 8) return fz_set_error(FZ_E_UNSUPPORTED, "fused product: degree 64 or 256 only");
     if (batch == 0) return FZ_OK;
+    if (fz_polymul16_ok(ctx, f, g, out, batch)) {
+        switch (ctx->logd) {
+            case 5: return ctx->mod.fast ? launch_polymul16<5, true>(ctx, f, g, out, batch) : launch_polymul16<5, false>(ctx, f, g, out, batch);
+            case 6: return ctx->mod.fast ? launch_polymul16<6, true>(ctx, f, g, out, batch) : launch_polymul16<6, false>(ctx, f, g, out, batch);
+            case 7: return ctx->mod.fast ? launch_polymul16<7, true>(ctx, f, g, out, batch) : launch_polymul16<7, false>(ctx, f, g, out, batch);
+            default: return ctx->mod.fast ? launch_polymul16<8, true>(ctx, f, g, out, batch) : launch_polymul16<8, false>(ctx, f, g, out, batch);
+        }
+    }
+    if (ctx->logd != 6 && ctx->logd != 8) return fz_set_error(FZ_E_UNSUPPORTED, "fused product: degree 64 or 256, or 16-byte aligned operands of degree 32..256");
     const int ppw = 64 / (ctx->degree / 4);
     const size_t tasks = (batch + ppw - 1) / ppw, blocks = (tasks + kWavesPerBlock - 1) / kWavesPerBlock;
     if (ctx->grid_pm == 0) {

@@ -285,6 +285,62 @@ def test_poly_mul_matches_transform_composition(d, coracle, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("q", [Q, 65537, 4294828033])
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+def test_poly_mul_sixteen_per_lane_form(d, q, coracle, monkeypatch):
+    """FZ_POLYMUL_FORM=2: the product kernel built on the 16-per-lane transforms (what batches of >= 2^14 products take at
+    d = 256 and every aligned batch at d = 32 / 128) == the oracle's INTT(NTT f * NTT g) and == the radix-4 form, for the
+    scheme's prime (4-op multiply), a prime without the pseudo-Mersenne form and one above 2^31; edge rows (raw int32 extremes),
+    ragged last chunks (1, 3, 5, 1003 rows), a batch of several iterations per wave, the product written over either factor"""
+    import fusion_hip
+    root = _root_for(q, d)
+    inv_root = pow(root, q - 2, q)
+    monkeypatch.setenv("FZ_POLYMUL_FORM", "2")
+    ctx = fusion_hip.Context(q, d, root, inv_root)         # a fresh context: the knob is read here
+    monkeypatch.setenv("FZ_POLYMUL_FORM", "1")
+    ctx4 = fusion_hip.Context(q, d, root, inv_root)
+    monkeypatch.delenv("FZ_POLYMUL_FORM")
+    edge = _edge_rows(d, q if q < 2**31 else 2**31 - 1)
+    big = 8 * 1024 * (1024 // d) + 3                         # more chunks than a resident grid has waves: the loop runs, and ends ragged
+    rng = np.random.default_rng(d + q % 1000)
+    for rows, seed in ((len(edge), None), (1, 3), (3, 6), (5, 4), (1003, 5), (big, 7)):
+        if seed is None:
+            f, g = edge, edge[::-1].copy()
+        elif rows == big:
+            f = rng.integers(-2**31, 2**31, size=(rows, d), dtype=np.int64).astype(np.int32)       # any int32 is an admissible input
+            g = rng.integers(-(q // 2), q // 2 + 1, size=(rows, d), dtype=np.int64).astype(np.int32)
+        else:
+            f = O.splitmix_centered(seed, rows * d).reshape(rows, d)
+            g = O.splitmix_centered(seed + 100, rows * d).reshape(rows, d)
+        got = ctx.poly_mul(f, g)
+        if rows <= 1003:
+            want = coracle.ntt_inverse(coracle.pw_mul(coracle.ntt_forward(f, q, root), coracle.ntt_forward(g, q, root), q), q, inv_root)
+            assert np.array_equal(got, want), (d, q, rows)
+        if d in (64, 256):
+            assert np.array_equal(got, ctx4.poly_mul(f, g)), (d, q, rows)
+        else:
+            sub = slice(0, rows, max(1, rows // 200))
+            want = coracle.ntt_inverse(coracle.pw_mul(coracle.ntt_forward(f[sub], q, root), coracle.ntt_forward(g[sub], q, root), q), q, inv_root)
+            assert np.array_equal(got[sub], want), (d, q, rows)
+        for alias in (0, 1):
+            df, dg = fusion_hip.DeviceBuffer.from_numpy(ctx, f), fusion_hip.DeviceBuffer.from_numpy(ctx, g)
+            dst = (df, dg)[alias]
+            ctx.poly_mul_dev(df.ptr, dg.ptr, dst.ptr, rows)
+            assert np.array_equal(ctx.d2h(np.empty_like(f), dst.ptr), got), (d, q, rows, alias)
+            df.free(); dg.free()
+    # operands that are not 16-byte aligned: the other form (d = 64 / 256) answers
+    if d in (64, 256):
+        f = O.splitmix_centered(21, 9 * d).reshape(9, d)
+        g = O.splitmix_centered(22, 9 * d).reshape(9, d)
+        buf = fusion_hip.DeviceBuffer(ctx, 3 * 9 * d * 4 + 64)
+        pf, pg, po = buf.ptr + 4, buf.ptr + 4 + 9 * d * 4, buf.ptr + 4 + 2 * 9 * d * 4
+        ctx.h2d(pf, f); ctx.h2d(pg, g)
+        ctx.poly_mul_dev(pf, pg, po, 9)
+        assert np.array_equal(ctx.d2h(np.empty_like(f), po), ctx4.poly_mul(f, g))
+        buf.free()
+    ctx.close(); ctx4.close()
+
+
 def test_c_caller_round_trip(tmp_path):
     """examples/roundtrip.c (C99, gcc, no HIP headers): context, stream, device buffers, graph capture, replay"""
     import subprocess

@@ -141,9 +141,10 @@ def measure(ctx, P, stream_ptr=None, reps_target_ms=30.0, quick=False, only=None
         run("matvec" if nb == mb else f"matvec {nb} products", nb, (l + 1) * row, nb * l * row, nb * row,
             lambda i, o, nb=nb: ctx.matvec_dev(A.ptr, i, o, nb, l))
     # fused negacyclic product (ntt.py:380-484): f, g [n][d] -> [n][d]
-    n = 1 << 16
-    run("polymul_fused", n, 3 * row, 2 * n * row, n * row,
-        lambda i, o: ctx.poly_mul_dev(i, i + n * row, o, n))
+    # (2^13 products: the radix-4 kernel at either degree; 2^17: the 16-per-lane kernel at degree 256 -- fz_launch_polymul_fused chooses)
+    for n in ((1 << 17,) if quick else (1 << 13, 1 << 17)):
+        run(f"polymul_fused n=2^{n.bit_length() - 1}", n, 3 * row, 2 * n * row, n * row,
+            lambda i, o, n=n: ctx.poly_mul_dev(i, i + n * row, o, n))
     # pointwise product (polynomials.py:341-385)
     cnt = S * l * d
     run("pw_kernel<mul>", cnt, 12, 2 * cnt * 4, cnt * 4,

@@ -29,6 +29,8 @@ DEFAULT_MANIFEST = [
     {"name": "verify64", "kernel": "verify_fused", "bytes": 64 * (L_ + 2) * 4 * D_ + L_ * 4 * D_},
     {"name": "verify1024", "kernel": "verify_fused", "bytes": 1024 * (L_ + 2) * 4 * D_ + L_ * 4 * D_},
     {"name": "verify8192", "kernel": "verify_fused", "bytes": 8192 * (L_ + 2) * 4 * D_ + L_ * 4 * D_},
+    {"name": "polymul 2^13", "kernel": "polymul_fused", "products": 1 << 13, "bytes": (1 << 13) * 12 * D_},
+    {"name": "polymul 2^17", "kernel": "polymul16", "products": 1 << 17, "bytes": (1 << 17) * 12 * D_},
 ]
 # ratios outside [0.9, 1.5] must be explained here (prefix of the manifest name -> why), or the script fails
 EXPLAINED = {
@@ -81,7 +83,7 @@ def scheme_table(csv_paths, manifest=None):
             m = assigned.get(k)
             if m:
                 e["launch"] = m["name"]
-                for key in ("signers", "what"):
+                for key in ("signers", "products", "what"):
                     if key in m:
                         e[key] = m[key]
                 e["algorithmic_bytes_per_launch"] = m["bytes"]

@@ -1,6 +1,6 @@
 """Minimal launcher for PMC / kernel-trace passes over the scheme kernels on COLD operands (one launch per operand set,
 sets carved out of a 2.25 GiB pool).  usage: prof_scheme.py [reps] [manifest.json]     (secpar 256; N = 1024 signers / keys /
-signatures).  The manifest lists what was launched, in order, with the algorithmic bytes of each launch: tools/pmc_summary.py
+signatures; a third argument keeps only the launches whose name contains it).  The manifest lists what was launched, in order, with the algorithmic bytes of each launch: tools/pmc_summary.py
 attributes counters to launches by that order, never by kernel name or grid."""
 import json
 import os
@@ -15,7 +15,8 @@ pin_to_gpu_node(0)          # host threads on the GPU's NUMA node (before the fi
 from oracle import oracle as O
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-manifest_path = sys.argv[2] if len(sys.argv) > 2 else None
+manifest_path = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
+only = sys.argv[3] if len(sys.argv) > 3 else None
 manifest = []
 P = O.PARAMS[256]
 q, d, l = P["q"], P["d"], P["rank"]
@@ -57,7 +58,14 @@ for name, family, alg, extra, in_bytes, fn in (
         ("verify1024", "verify_fused", 1024 * (l + 2) * row + l * row, {"aggregates": 1024}, 1024 * (l + 1) * row,
          lambda i, o: ctx.verify_with_target_batch_async_dev(A.ptr, i, i + 1024 * l * row, 1024, l, P["beta_vf"], d, o)),
         ("verify8192", "verify_fused", 8192 * (l + 2) * row + l * row, {"aggregates": 8192}, 8192 * (l + 1) * row,
-         lambda i, o: ctx.verify_with_target_batch_async_dev(A.ptr, i, i + 8192 * l * row, 8192, l, P["beta_vf"], d, o))):
+         lambda i, o: ctx.verify_with_target_batch_async_dev(A.ptr, i, i + 8192 * l * row, 8192, l, P["beta_vf"], d, o)),
+        # the coefficient-domain product (ntt.py:380-484) in both fused forms: 2^13 products take the radix-4 kernel, 2^17 the 16-per-lane one
+        ("polymul 2^13", "polymul_fused", (1 << 13) * 3 * row, {"products": 1 << 13}, 2 * (1 << 13) * row,
+         lambda i, o: ctx.poly_mul_dev(i, i + (1 << 13) * row, o, 1 << 13)),
+        ("polymul 2^17", "polymul16", (1 << 17) * 3 * row, {"products": 1 << 17}, 2 * (1 << 17) * row,
+         lambda i, o: ctx.poly_mul_dev(i, i + (1 << 17) * row, o, 1 << 17))):
+    if only and only not in name:
+        continue
     ins, outs = sets(max(in_bytes, kb + S * 2 * row))
     for k in range(reps):
         fn(ins[k % len(ins)], outs[k % len(outs)])

@@ -49,7 +49,7 @@ KERNS = ["", "4", "16", "4r1", "4r2", "4r4"]
 # the multi-launch forms of the fused kernels and other launch shapes of the one-pass aggregation
 VARIANTS = [{}, {"FZ_UNFUSED": "1"}, {"FZ_AGG_DIRECT": "-1"}, {"FZ_AGG_DIRECT": "2"}, {"FZ_AGG_DIRECT": "4", "FZ_VERIFY_ORDERED": "1"},
             {"FZ_NO_IMAD": "1"}, {"FZ_VERIFY_CENT": "1"}, {"FZ_SHAKE_FORM": "2"}, {"FZ_SHAKE_FORM": "1"}, {"FZ_SHAKE_FORM": "3"},
-            {"FZ_MATVEC_SLICES": "16"}, {"FZ_MATVEC_SLICES": "2"}, {"FZ_MATVEC_SLICES": "-1"}]
+            {"FZ_MATVEC_SLICES": "16"}, {"FZ_MATVEC_SLICES": "2"}, {"FZ_MATVEC_SLICES": "-1"}, {"FZ_POLYMUL_FORM": "2"}, {"FZ_POLYMUL_FORM": "1"}]
 vctx = {(sp, i): make_ctx(sp, "", v) for sp in (128, 256) for i, v in enumerate(VARIANTS)}
 DB = fusion_hip.DeviceBuffer
 t_end = time.time() + budget
@@ -195,6 +195,9 @@ while time.time() < t_end:
     elif what == "polymul":
         g = O.splitmix_centered(int(rng.integers(1, 2**40)), rows * d).reshape(rows, d)
         want = orc.ntt_inverse(orc.pw_mul(orc.ntt_forward(x, q, root), orc.ntt_forward(g, q, root), q), q, inv).reshape(rows, d)
+        # both fused forms (the radix-4 kernel, the one on the 16-per-lane transforms) beside the one the batch size chooses
+        pctx = [ctx] + [vctx[(sp, i)] for i, v in enumerate(VARIANTS) if "FZ_POLYMUL_FORM" in v]
+        ctx = pctx[int(rng.integers(0, len(pctx)))]
         assert np.array_equal(ctx.poly_mul(x, g), want), ("polymul", sp, rows, raw)
         bump("polymul")
     elif what == "graph":

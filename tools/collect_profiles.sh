@@ -42,6 +42,8 @@ step timeout -k 10 200 python tools/probes/sign_latency.py > $OUT/${TAG}_sign_la
 step timeout -k 10 200 taskset -c 4 ./tools/microbench/build/keccak_host_clang > $OUT/${TAG}_keccak_host_forms.txt 2>&1
 step timeout -k 10 100 taskset -c 4 ./tools/microbench/build/x64_throughput >> $OUT/${TAG}_keccak_host_forms.txt 2>&1
 step timeout -k 10 200 ./tools/microbench/build/shape_ceiling 20 > $OUT/${TAG}_shape_ceilings.txt 2>&1
+# the coefficient-domain product in its two fused forms over batch sizes (kPolymul16MinRows256 in csrc/fz_ntt.hip)
+step timeout -k 10 250 python tools/probes/polymul_crossover.py > $OUT/${TAG}_polymul_crossover.txt 2>&1
 step timeout -k 10 200 python tools/probes/keygen_probe.py > $OUT/${TAG}_keygen_end_to_end.txt 2>&1
 step timeout -k 10 200 python tools/probes/agg_probe.py > $OUT/${TAG}_aggregate_end_to_end.txt 2>&1
 step timeout -k 10 200 python tools/probes/copy_bw.py > $OUT/${TAG}_copy_ceiling.txt 2>&1

@@ -5,10 +5,13 @@ reference-generated signer set.  Every rank regenerates ONLY its block's keys an
 ranks share the test box's one GPU; with a GPU per rank the same code runs over RCCL).
 argv: rank world port secpar kind lo hi out_dir [alpha_mode]      kind = "many" (scheme_many_*.npz) | "small" (scheme_*.npz)
 alpha_mode: "replicated" (the serial sponge of hash_ag on every rank) | "root" (rank 0 alone + broadcast) | "auto" """
+import faulthandler
 import hashlib
 import json
 import os
 import sys
+
+faulthandler.dump_traceback_later(240, exit=False)       # a rank that hangs says where (the test kills it at 300 s and prints this)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "fusion-cryptography_amd"), ROOT):
@@ -75,5 +78,9 @@ np.savez(os.path.join(out_dir, f"rank{rank}.npz"), agg=agg, agg2=agg2, lo=lo, hi
 with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
     json.dump(dict(verdict=list(verdict), verify=list(ver2), tampered=list(ver_bad), swapped=list(ver_swapped),
                    short=list(ver_short)), fh)
+print(f"rank {rank}: results written", flush=True)
 dist.barrier()
+print(f"rank {rank}: barrier passed", flush=True)
 dist.destroy_process_group()
+bs.close()
+print(f"rank {rank}: done", flush=True)

@@ -74,22 +74,13 @@ def test_shard_range_properties():
 def _run_host_ranks(world, tag, n, mode, tmp_path):
     import json
     import socket
-    import subprocess
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
     here = os.path.dirname(os.path.abspath(__file__))
-    procs = [subprocess.Popen([sys.executable, os.path.join(here, "_shard_host_worker.py"), str(r), str(world), str(port), tag, str(n), mode,
-                               str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    outs = []
-    for p_ in procs:
-        try:
-            outs.append(p_.communicate(timeout=600)[0])
-        except subprocess.TimeoutExpired:
-            for q_ in procs:
-                q_.kill()
-            pytest.fail("a rank did not finish")
-    assert all(p_.returncode == 0 for p_ in procs), "\n".join(o[-3000:] for o in outs)
+    from _ranks import run_rank_processes
+    run_rank_processes([[sys.executable, os.path.join(here, "_shard_host_worker.py"), str(r), str(world), str(port), tag, str(n), mode, str(tmp_path)]
+                        for r in range(world)], tmp_path, 600)
     return ([np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)],
             [json.load(open(os.path.join(str(tmp_path), f"rank{r}.json"))) for r in range(world)])
 

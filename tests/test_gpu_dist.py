@@ -6,7 +6,6 @@ over ALL signers.  (fusion/fusion.py:670-676, :706-727; SURVEY.md 8e.  gloo beca
 the same step over RCCL through fz_allreduce_i64 when every rank has a GPU of its own.)"""
 import os
 import socket
-import subprocess
 import sys
 
 import numpy as np
@@ -23,18 +22,9 @@ def test_sharded_aggregate_and_verify_with_a_real_collective(secpar, n, world, c
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), str(world), str(port), str(secpar),
-                               str(n), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for r in range(world)]
-    outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=240)[0])
-        except subprocess.TimeoutExpired:
-            for q_ in procs:
-                q_.kill()
-            pytest.fail("a rank did not finish")
-    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    from _ranks import run_rank_processes
+    run_rank_processes([[sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), str(world), str(port), str(secpar), str(n), str(tmp_path)]
+                        for r in range(world)], tmp_path, 240)
     P = O.PARAMS[secpar]
     q, d, l = P["q"], P["d"], P["rank"]
     R = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]

@@ -6,7 +6,6 @@ signatures (fusion/fusion.py:655-677), the verdict and the tamper verdicts what 
 import json
 import os
 import socket
-import subprocess
 import sys
 
 import numpy as np
@@ -18,20 +17,12 @@ G = os.path.join(HERE, "golden")
 
 
 def run_ranks(world, args, tmp_path, mode="auto"):
+    from _ranks import run_rank_processes
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_shard_worker.py"), str(r), str(world), str(port)] + [str(a) for a in args]
-                              + [str(tmp_path), mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=300)[0])
-        except subprocess.TimeoutExpired:
-            for q_ in procs:
-                q_.kill()
-            pytest.fail("a rank did not finish")
-    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    run_rank_processes([[sys.executable, os.path.join(HERE, "_shard_worker.py"), str(r), str(world), str(port)] + [str(a) for a in args]
+                        + [str(tmp_path), mode] for r in range(world)], tmp_path, 300)
     return ([np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)],
             [json.load(open(os.path.join(str(tmp_path), f"rank{r}.json"))) for r in range(world)])
 

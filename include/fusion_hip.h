@@ -200,9 +200,10 @@ FZ_API int fz_fill_synthetic(fz_ctx *ctx, int32_t *d_out, size_t count, uint64_t
 /* ---- negacyclic product of coefficient-domain polynomials ---------------------------------------
  * out[b] = INTT(NTT(f[b]) (.) NTT(g[b])), centred: ntt_poly_mult (algebra/ntt.py:380-484) and the value of
  * PolynomialCoefficientRepresentation.__mul__ (algebra/polynomials.py:171-216, schoolbook there).
- * One launch for degree 64 / 256 (both forward transforms, the product and the inverse stay on chip:
- * 12*degree bytes of HBM traffic per product); other degrees compose the transform and pointwise kernels.
- * d_out may alias d_f or d_g.  Rows are [batch][degree], any int32 in, centred out. */
+ * One launch for degrees 32 .. 256 (both forward transforms, the product and the inverse stay on chip:
+ * 12*degree bytes of HBM traffic per product; degrees 32 and 128 need 16-byte aligned buffers for it); other
+ * degrees compose the transform and pointwise kernels (16-byte aligned buffers).
+ * d_out may alias d_f or d_g.  Rows are [batch][degree], 4-byte aligned, any int32 in, centred out. */
 FZ_API int fz_poly_mul(fz_ctx *ctx, const int32_t *d_f, const int32_t *d_g, int32_t *d_out, size_t batch);
 FZ_API int fz_poly_mul_host(fz_ctx *ctx, const int32_t *h_f, const int32_t *h_g, int32_t *h_out, size_t batch);
 

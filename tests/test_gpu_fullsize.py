@@ -339,3 +339,50 @@ def test_config2_sweep_maximum_2_22_rows(coracle):
         for b in (dx, dy, dz, dm, dw):
             b.free()
         ctx.close()
+
+
+@pytest.mark.parametrize("secpar", [256, 128])
+def test_poly_mul_at_2_20_products_equals_the_composed_launches(secpar, coracle):
+    """fz_poly_mul at 2^20 products (the 16-per-lane kernel at degree 256, the radix-4 kernel at degree 64): over ALL rows equal
+    to INTT(NTT(f) (.) NTT(g)) made of the transform and pointwise launches (difference reduced on the device), f * g == g * f,
+    and sampled rows (first, middle, last 512) against the C oracle (algebra/ntt.py:380-484)."""
+    import fusion_hip
+    P = O.PARAMS[secpar]
+    q, d = P["q"], P["d"]
+    ctx = fusion_hip.Context(q, d, P["root"], P["inv_root"])
+    rows = 1 << 20
+    count = rows * d
+    DB = fusion_hip.DeviceBuffer
+    GAMMA = 0x9E3779B97F4A7C15
+
+    def host_rows(seed, first, n):
+        return O.splitmix_centered((seed + first * d * GAMMA) % (1 << 64), n * d).reshape(n, d)
+    df, dg, dp, dc = (DB(ctx, count * 4) for _ in range(4))
+    dm, dw = DB(ctx, rows * 8), DB(ctx, rows * 4)
+    try:
+        ctx.fill_synthetic_dev(df.ptr, count, 15)
+        ctx.fill_synthetic_dev(dg.ptr, count, 16)
+        ctx.poly_mul_dev(df.ptr, dg.ptr, dp.ptr, rows)
+        for first in (0, 345678, rows - 512):
+            f, g = host_rows(15, first, 512), host_rows(16, first, 512)
+            want = coracle.ntt_inverse(coracle.pw_mul(coracle.ntt_forward(f, q, P["root"]), coracle.ntt_forward(g, q, P["root"]), q), q, P["inv_root"])
+            got = np.empty((512, d), np.int32)
+            ctx.d2h(got, dp.ptr + first * d * 4)
+            assert np.array_equal(got, want.reshape(512, d)), first
+
+        def all_zero(ptr):
+            ctx.norm_weight_dev(ptr, rows, dm.ptr, dw.ptr)
+            return not dm.to_numpy(np.int64, (rows,)).any() and not dw.to_numpy(np.int32, (rows,)).any()
+        ctx.poly_mul_dev(dg.ptr, df.ptr, dc.ptr, rows)                   # g * f
+        ctx.pw_dev(fusion_hip.OP_SUB, dc.ptr, dp.ptr, dc.ptr, count)
+        assert all_zero(dc.ptr), "f * g != g * f somewhere in 2^20 products"
+        ctx.ntt_forward_dev(df.ptr, df.ptr, rows)                        # the composed launches, in place
+        ctx.ntt_forward_dev(dg.ptr, dg.ptr, rows)
+        ctx.pw_dev(fusion_hip.OP_MUL, df.ptr, dg.ptr, df.ptr, count)
+        ctx.ntt_inverse_dev(df.ptr, df.ptr, rows)
+        ctx.pw_dev(fusion_hip.OP_SUB, df.ptr, dp.ptr, df.ptr, count)
+        assert all_zero(df.ptr), "fz_poly_mul != INTT(NTT f (.) NTT g) somewhere in 2^20 products"
+    finally:
+        for b in (df, dg, dp, dc, dm, dw):
+            b.free()
+        ctx.close()

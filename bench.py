@@ -356,13 +356,35 @@ def cpu_baseline(seconds):
 # ---------------------------------------------------------------------------------------------------------
 # --gpus N without a launcher: this process starts the N ranks itself and never touches a GPU
 # ---------------------------------------------------------------------------------------------------------
-def self_launch(args):
+def rendezvous_port():
+    """A free TCP port for rank 0's store, chosen OUTSIDE the kernel's ephemeral range.  A port from bind(("127.0.0.1", 0)) lies
+    inside that range, and a rank that starts connecting before rank 0 listens can be handed that very number as its SOURCE
+    port (TCP self-connect): it then talks to itself, rank 0's bind fails with EADDRINUSE and the others wait for a store that
+    never answers -- (tests/_ranks.py carries the same function)."""
+    import random
     import socket
+    lo, hi = 32768, 60999
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as fh:
+            lo, hi = (int(x) for x in fh.read().split())
+    except (OSError, ValueError):
+        pass
+    pool = range(20000, min(lo, 32000)) if lo > 21000 else range(hi + 1, 65000)
+    for _ in range(200):
+        port = random.choice(pool)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    raise RuntimeError("no free rendezvous port")
+
+
+def self_launch(args):
     import subprocess
     n = args.gpus
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = rendezvous_port()
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n),
                 HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
@@ -505,10 +527,7 @@ def main():
         # rehearsal on ONE GPU of what an N > 1 run has in its process: a torch.distributed RCCL group that has run collectives
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:            # any free port: this is a group of one
-            import socket
-            with socket.socket() as s_:
-                s_.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            os.environ["MASTER_PORT"] = str(rendezvous_port())
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         t_ = torch.ones(4, device=dev)
         dist.all_reduce(t_)

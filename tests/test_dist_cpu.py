@@ -73,12 +73,9 @@ def test_shard_range_properties():
 
 def _run_host_ranks(world, tag, n, mode, tmp_path):
     import json
-    import socket
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        port = s_.getsockname()[1]
     here = os.path.dirname(os.path.abspath(__file__))
-    from _ranks import run_rank_processes
+    from _ranks import rendezvous_port, run_rank_processes
+    port = rendezvous_port()
     run_rank_processes([[sys.executable, os.path.join(here, "_shard_host_worker.py"), str(r), str(world), str(port), tag, str(n), mode, str(tmp_path)]
                         for r in range(world)], tmp_path, 600)
     return ([np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)],

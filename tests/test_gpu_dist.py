@@ -5,7 +5,6 @@ sums (fz_verify_partials_batch_async) and centring (fz_reduce_i64) on every rank
 over ALL signers.  (fusion/fusion.py:670-676, :706-727; SURVEY.md 8e.  gloo because the ranks share one GPU; bench.py runs
 the same step over RCCL through fz_allreduce_i64 when every rank has a GPU of its own.)"""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -19,10 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("secpar,n,world", [(256, 301, 2), (128, 77, 3)])
 def test_sharded_aggregate_and_verify_with_a_real_collective(secpar, n, world, coracle, tmp_path):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    from _ranks import run_rank_processes
+    from _ranks import rendezvous_port, run_rank_processes
+    port = rendezvous_port()
     run_rank_processes([[sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), str(world), str(port), str(secpar), str(n), str(tmp_path)]
                         for r in range(world)], tmp_path, 240)
     P = O.PARAMS[secpar]

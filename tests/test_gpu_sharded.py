@@ -5,7 +5,6 @@ from the sums.  The aggregate must equal what the reference's aggregate() return
 signatures (fusion/fusion.py:655-677), the verdict and the tamper verdicts what its verify() returned (:680-728)."""
 import json
 import os
-import socket
 import sys
 
 import numpy as np
@@ -17,10 +16,8 @@ G = os.path.join(HERE, "golden")
 
 
 def run_ranks(world, args, tmp_path, mode="auto"):
-    from _ranks import run_rank_processes
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    from _ranks import rendezvous_port, run_rank_processes
+    port = rendezvous_port()
     run_rank_processes([[sys.executable, os.path.join(HERE, "_shard_worker.py"), str(r), str(world), str(port)] + [str(a) for a in args]
                         + [str(tmp_path), mode] for r in range(world)], tmp_path, 300)
     return ([np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)],

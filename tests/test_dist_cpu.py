@@ -45,7 +45,8 @@ def test_sharded_aggregate_matches_oracle(N, tmp_path, coracle):
     import torch.multiprocessing as mp
     from oracle import oracle as O
     q, l, d, world = O.PRIME, 3, 64, 2
-    port = 29500 + (os.getpid() + N) % 2000
+    from _ranks import rendezvous_port
+    port = rendezvous_port()
     mp.spawn(_worker, args=(world, port, N, l, d, q, str(tmp_path)), nprocs=world, join=True)
     sig = O.splitmix_centered(11, N * l * d, q).reshape(N, l, d)
     alpha = O.splitmix_centered(12, N * d, q).reshape(N, d)

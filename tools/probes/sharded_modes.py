@@ -5,7 +5,6 @@ coefficient rows ("root") -- fusion/fusion.py:586-591, :632-652.  The wall time 
 construction: it does not shrink with W); what differs is how many host cores it occupies and what the other ranks wait for.
 usage: sharded_modes.py [--world 4] [--n 1024] [--secpar 256]        (spawns its own ranks; rank 0 prints the table)"""
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -77,9 +76,8 @@ def main():
     print(f"# secpar {secpar}, one aggregate of {n} signers, ranks = processes sharing GPU 0 over gloo, {os.cpu_count()} logical CPUs, "
           f"best of 4, max over ranks")
     for w in worlds:
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
+        from bench import rendezvous_port          # outside the ephemeral range: see there
+        port = rendezvous_port()
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank", str(r), "--world", str(w), "--port", str(port),
                                    "--n", str(n), "--secpar", str(secpar)]) for r in range(w)]
         rc = [p.wait() for p in procs]

@@ -11,6 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "fusion-cryptography_amd"))
+sys.path.insert(0, ROOT)
 
 
 def arg(name, default, cast):

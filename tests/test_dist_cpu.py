@@ -125,3 +125,23 @@ def test_alpha_mode_resolution_and_errors():
     assert sharded_alpha(5, 8, "replicated", None, 3, 4, lambda: rows) is rows
     with pytest.raises(ValueError):
         sharded_alpha(0, 2, "sometimes", None, 3, 4, lambda: rows)
+
+
+def test_rendezvous_ports_lie_outside_the_ephemeral_range():
+    """a port inside the range can be handed to an early connecting rank as its SOURCE port (TCP self-connect): the store's bind
+    then fails and the other ranks wait for it; tests/_ranks.py and bench.py choose the same way"""
+    import socket
+    from _ranks import rendezvous_port
+    sys.path.insert(0, ROOT)
+    import bench
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as fh:
+            lo, hi = (int(x) for x in fh.read().split())
+    except OSError:
+        pytest.skip("no /proc/sys/net/ipv4/ip_local_port_range")
+    for pick in (rendezvous_port, bench.rendezvous_port):
+        for _ in range(20):
+            port = pick()
+            assert 1024 < port < 65536 and not lo <= port <= hi
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", port))                  # and it is free

@@ -187,6 +187,46 @@ def test_graph_capture_replays_a_recorded_sequence(coracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("d,form", [(256, 1), (256, 2), (128, 0), (64, 0)])
+def test_graph_capture_of_the_fused_product(d, form, coracle, monkeypatch):
+    """fz_poly_mul recorded into a graph with NO call before the capture (the kernel's occupancy query then runs inside it) and
+    replayed on fresh contents: the radix-4 kernel, the 16-per-lane kernel (forced at degree 256, the only fused form at 128)"""
+    import fusion_hip
+    root = _root_for(Q, d)
+    inv_root = pow(root, Q - 2, Q)
+    if form:
+        monkeypatch.setenv("FZ_POLYMUL_FORM", str(form))
+    ctx = fusion_hip.Context(Q, d, root, inv_root)
+    if form:
+        monkeypatch.delenv("FZ_POLYMUL_FORM")
+    s = ctx.stream_create()
+    ctx.set_stream(s)
+    rows = 301
+    f = O.splitmix_centered(51, rows * d).reshape(rows, d)
+    g = O.splitmix_centered(52, rows * d).reshape(rows, d)
+    df, dg = fusion_hip.DeviceBuffer.from_numpy(ctx, f), fusion_hip.DeviceBuffer.from_numpy(ctx, g)
+    dp = fusion_hip.DeviceBuffer(ctx, f.nbytes)
+    ctx.synchronize()
+    ctx.graph_begin()
+    ctx.poly_mul_dev(df.ptr, dg.ptr, dp.ptr, rows)
+    ctx.poly_mul_dev(dp.ptr, dg.ptr, dp.ptr, rows)          # (f * g) * g, in place
+    gr = ctx.graph_end()
+    for seed in (51, 53):
+        f = O.splitmix_centered(seed, rows * d).reshape(rows, d)
+        ctx.h2d(df.ptr, f)
+        gr.launch()
+        got = ctx.d2h(np.empty_like(f), dp.ptr)
+        gh = coracle.ntt_forward(g, Q, root)
+        want = coracle.ntt_inverse(coracle.pw_mul(coracle.pw_mul(coracle.ntt_forward(f, Q, root), gh, Q), gh, Q), Q, inv_root)
+        assert np.array_equal(got, want.reshape(rows, d)), (d, form, seed)
+    gr.destroy()
+    ctx.set_stream(0)
+    ctx.stream_destroy(s)
+    for b in (df, dg, dp):
+        b.free()
+    ctx.close()
+
+
 def test_events_order_two_contexts_eagerly_and_inside_a_capture(coracle):
     """fz_event_*: context A transforms forward on its stream, context B transforms back on ITS stream after waiting for A's
     event -- launched eagerly, then as ONE captured graph in which B's stream forks off A's capture and joins it again, replayed

@@ -28,6 +28,101 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
+// init_by_array(key) on a lane per generator (Modules/_randommodule.c): the 1247 dependent steps that turn init_tab -- the state
+// after init_genrand(19650218), the same for every seed -- and the seed's one or two 32-bit words into the generator's state,
+// left in LDS as mt[word * 64 + lane] (word 0 = 0x80000000); out(i, value) sees every FINAL word i >= 1 as it is made.
+// The chain is four dependent vector instructions per step (shift, xor, multiply, xor-add: 12.3 ns on a lone wave,
+// tools/microbench/salu_chain.hip; the scalar unit is no faster: 15.4); what rounds 2-5's loops added to it were WAITS: the
+// table words came by scalar loads used at once (a scalar wait cannot be partial: the loads return out of order and share a
+// counter with LDS), the second loop read its LDS words where it needed them, and its stores were predicated (an exec-mask
+// save, a branch and a restore per step) -- 41 ns per step.  Now every lane loads the table word itself (one address per
+// wave: a broadcast) a CHUNK AHEAD -- vector loads return in order, the wait before a chunk leaves the next chunk's in
+// flight --, the LDS reads run a chunk ahead too, and nothing in a step is conditional: 22 ns per step (mt_seed_kernel of
+// 2048 generators 51.4 -> 27.7 us).
+template <class OUT>
+__device__ __forceinline__ void mt_seed_state(uint32_t *mt, const uint32_t *init_tab, uint32_t key0, uint32_t key1, int lane, OUT out) {
+    constexpr int U = 8;                     // steps per chunk = the distance a request runs ahead of its use (16: 32.7 us against 27.7)
+    const bool two = key1 != 0;              // init_by_array key length 2 (else 1)
+#define FZ_MTS(i) mt[(i) * 64 + lane]
+    uint32_t prev = init_tab[0];
+    uint32_t j = 0;
+    int voff = 0;
+    asm volatile("" : "+v"(voff));           // (a vector register the compiler cannot prove uniform: vector loads)
+    const uint32_t *vtab = init_tab + voff;
+    auto load_tab = [&](uint32_t (&t)[U], int i0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = vtab[i0 + u < kMtN ? i0 + u : kMtN - 1];
+    };
+    // first loop (624 steps: i = 1..623, then i = 1 again after the wrap)
+    auto steps1 = [&](const uint32_t (&t)[U], int i0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u < kMtN) {
+                prev = (t[u] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (j ? key1 : key0) + j;
+                FZ_MTS(i0 + u) = prev;
+                j = two ? (j ^ 1u) : 0u;
+            }
+        }
+    };
+    {
+        uint32_t ta[U], tb[U];
+        load_tab(ta, 1);
+        int i0 = 1;
+        for (; i0 + 2 * U < kMtN; i0 += 2 * U) {             // two chunks per trip: the buffers swap roles without a copy
+            load_tab(tb, i0 + U);
+            steps1(ta, i0);
+            load_tab(ta, i0 + 2 * U);
+            steps1(tb, i0 + U);
+        }
+        for (; i0 < kMtN; i0 += U) {                          // the tail (623 = 38 * 16 + 15 steps)
+            if (i0 + U < kMtN) load_tab(tb, i0 + U);
+            steps1(ta, i0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) ta[u] = tb[u];
+        }
+    }
+    prev = (FZ_MTS(1) ^ ((prev ^ (prev >> 30)) * 1664525u)) + (j ? key1 : key0) + j;      // mt[0] = mt[623] = prev
+    FZ_MTS(1) = prev;
+    // second loop (623 steps: i = 2..623, then i = 1 after the wrap); a chunk's reads are words the FIRST loop wrote (the
+    // second loop's own stores go to words below the ones in flight)
+    auto load_mt = [&](uint32_t (&w)[U], int i0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = FZ_MTS(i0 + u < kMtN ? i0 + u : kMtN - 1);
+    };
+    auto steps2 = [&](const uint32_t (&w)[U], int i0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u < kMtN) {
+                prev = (w[u] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i0 + u);
+                FZ_MTS(i0 + u) = prev;
+                out(i0 + u, prev);
+            }
+        }
+    };
+    {
+        uint32_t wa[U], wb[U];
+        load_mt(wa, 2);
+        int i0 = 2;
+        for (; i0 + 2 * U < kMtN; i0 += 2 * U) {
+            load_mt(wb, i0 + U);
+            steps2(wa, i0);
+            load_mt(wa, i0 + 2 * U);
+            steps2(wb, i0 + U);
+        }
+        for (; i0 < kMtN; i0 += U) {
+            if (i0 + U < kMtN) load_mt(wb, i0 + U);
+            steps2(wa, i0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) wa[u] = wb[u];
+        }
+    }
+    prev = (FZ_MTS(1) ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
+    FZ_MTS(1) = prev;
+    FZ_MTS(0) = 0x80000000u;
+    out(1, prev);
+#undef FZ_MTS
+}
+
 // init_tab: the state after init_genrand(19650218), the same for every seed
 __global__ __launch_bounds__(64) void mt_sample_kernel(const unsigned long long *seeds, size_t npoly, int degree, uint32_t bound,
                                                        int kbits, const uint32_t *__restrict__ init_tab, int32_t *out, int *fail) {
@@ -38,42 +133,14 @@ __global__ __launch_bounds__(64) void mt_sample_kernel(const unsigned long long 
     const size_t p = live ? p_raw : npoly - 1;                             // idle lanes shadow the last polynomial
     const unsigned long long seed = seeds[p >> 1] + (unsigned long long)(p & 1);      // left: seed, right: seed + 1
     const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
-    const bool two = key1 != 0;                                            // init_by_array key length 2 (else 1)
 #define FZ_MT(i) mt[(i) * 64 + lane]
-    // init_by_array, first loop (624 steps: i = 1..623, then i = 1 again after the wrap)
-    uint32_t prev = init_tab[0];
-    uint32_t j = 0;
-    for (int i = 1; i < kMtN; ++i) {
-        prev = (init_tab[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (j ? key1 : key0) + j;
-        FZ_MT(i) = prev;
-        j = two ? (j ^ 1u) : 0u;
-    }
-    prev = (FZ_MT(1) ^ ((prev ^ (prev >> 30)) * 1664525u)) + (j ? key1 : key0) + j;      // mt[0] = mt[623] = prev
-    FZ_MT(1) = prev;
-    // second loop (623 steps: i = 2..623, then i = 1 after the wrap).  The words it reads are the first loop's: eight are
-    // requested ahead of the eight dependent steps that use them (the compiler cannot move an LDS load above the previous
-    // step's store by itself; one load latency per step would double the chain)
-    constexpr int U = 8;
-    for (int i0 = 2; i0 < kMtN; i0 += U) {
-        uint32_t m[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) m[u] = FZ_MT(i0 + u < kMtN ? i0 + u : kMtN - 1);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (i0 + u < kMtN) {
-                prev = (m[u] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i0 + u);
-                FZ_MT(i0 + u) = prev;
-            }
-        }
-    }
-    prev = (FZ_MT(1) ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
-    FZ_MT(1) = prev;
-    FZ_MT(0) = 0x80000000u;
+    mt_seed_state(mt, init_tab, key0, key1, lane, [](int, uint32_t) {});
 
     int t = 0;                               // coefficients finished
     uint32_t mag = 0;                        // 0: the next accepted draw is a magnitude; else its sign
     bool done = false;
     int32_t *row = out + p * (size_t)degree;
+    constexpr int U = 8;
     static_assert(kMtN % U == 0, "chunks of 8 words");
     for (int gen = 0; gen < kMaxGenerations; ++gen) {
         // regenerate all 624 words in place (genrand_uint32's refill), every lane its own column.  Word k needs the OLD
@@ -145,50 +212,12 @@ __global__ __launch_bounds__(64) void mt_seed_kernel(const unsigned long long *s
     const size_t p = live ? p_raw : npoly - 1;
     const unsigned long long seed = seeds[p >> 1] + (unsigned long long)(p & 1);      // left: seed, right: seed + 1
     const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
-    const bool two = key1 != 0;
-    #define FZ_MTS(i, g) mt[(i) * 64 + (g)]
-    uint32_t prev = init_tab[0];
-    uint32_t j = 0;
-    constexpr int U = 8;
-    // the table words of eight steps are requested together (scalar loads): one per step put a memory wait -- which on this
-    // hardware also waits for the step's LDS store -- inside every link of the chain (148 cycles per step instead of ~40)
-    for (int i0 = 1; i0 < kMtN; i0 += U) {
-        uint32_t tab[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) tab[u] = init_tab[i0 + u < kMtN ? i0 + u : kMtN - 1];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (i0 + u < kMtN) {
-                prev = (tab[u] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (j ? key1 : key0) + j;
-                FZ_MTS(i0 + u, lane) = prev;
-                j = two ? (j ^ 1u) : 0u;
-            }
-        }
-    }
-    prev = (FZ_MTS(1, lane) ^ ((prev ^ (prev >> 30)) * 1664525u)) + (j ? key1 : key0) + j;
-    FZ_MTS(1, lane) = prev;
-    for (int i0 = 2; i0 < kMtN; i0 += U) {
-        uint32_t w[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { const int i = i0 + u < kMtN ? i0 + u : kMtN - 1; w[u] = FZ_MTS(i, lane); }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (i0 + u < kMtN) {
-                prev = (w[u] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i0 + u);
-                FZ_MTS(i0 + u, lane) = prev;
-                // words 2 .. 623 are final here: out they go, word-major (64 generators = one 256-byte store; the draw kernel
-                // gathers its generator's column -- 624 sectors per wave from the L2 -- rather than this kernel transposing
-                // 160 KB through LDS on 32 waves: 27 us of its 72)
-                if (live) state[(size_t)(i0 + u) * npoly + p_raw] = prev;
-            }
-        }
-    }
-    prev = (FZ_MTS(1, lane) ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
-    if (live) {
-        state[npoly + p_raw] = prev;
-        state[p_raw] = 0x80000000u;
-    }
-#undef FZ_MTS
+    const uint32_t p32 = (uint32_t)p;                                      // (npoly < 2^32: a 32-bit lane offset beside a scalar row base)
+    // final words go out as they are made, word-major (64 generators = one 256-byte store; the draw kernel gathers its generator's
+    // column -- 624 sectors per wave from the L2 -- rather than this kernel transposing 160 KB through LDS on 32 waves: 27 us of
+    // its 72 in round 3).  Unconditionally: an idle lane shadows the LAST polynomial and stores that polynomial's own word a second time.
+    mt_seed_state(mt, init_tab, key0, key1, lane, [&](int i, uint32_t v) { (state + (size_t)i * npoly)[p32] = v; });
+    state[p32] = 0x80000000u;
 }
 
 __global__ __launch_bounds__(64 * kDrawWaves) void mt_draw_kernel(const uint32_t *__restrict__ state, size_t npoly, int degree, uint32_t bound,

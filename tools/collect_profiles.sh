@@ -19,7 +19,7 @@ step() { echo "[collect] $*" >&2; "$@" || { echo "[collect] FAILED ($?): $*" >&2
 lscpu | grep -E "Model name|Socket|Thread|Core" > $OUT/${TAG}_host_cpu.txt
 # the stand-alone microbenchmarks travel prebuilt (tools/microbench/build/, git-ignored); build whatever is missing
 mkdir -p tools/microbench/build
-for mb in launch_floor ntt_variants ntt_structures access_pattern mixed_ceiling shape_ceiling crosslane_latency keccak_wave; do
+for mb in launch_floor ntt_variants ntt_structures access_pattern mixed_ceiling shape_ceiling crosslane_latency keccak_wave salu_chain; do
   [ -x tools/microbench/build/$mb ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/microbench/$mb.hip -o tools/microbench/build/$mb
 done
 [ -x tools/microbench/build/keccak_host_clang ] || /opt/rocm/lib/llvm/bin/clang++ -O3 -std=c++17 tools/microbench/keccak_host.cpp -o tools/microbench/build/keccak_host_clang
@@ -38,6 +38,8 @@ for f in 0 3 1; do FZ_SHAKE_FORM=$f timeout -k 10 200 python tools/probes/challe
 # stand-alone kernel with verify_fused's / polymul_fused's / the small aggregations' shape sustains
 step timeout -k 10 200 python tools/probes/keccak_wave_check.py 256 1024 2048 4096 > $OUT/${TAG}_keccak_wave_form.txt 2>&1
 step timeout -k 10 100 ./tools/microbench/build/crosslane_latency > $OUT/${TAG}_crosslane_latency.txt 2>&1
+# the seeding step of the device sampler as a dependent chain on the scalar and on the vector unit (csrc/fz_sample.hip: mt_seed_state)
+step timeout -k 10 100 ./tools/microbench/build/salu_chain > $OUT/${TAG}_sampler_seed_chain.txt 2>&1
 step timeout -k 10 200 python tools/probes/sign_latency.py > $OUT/${TAG}_sign_latency.txt 2>&1
 step timeout -k 10 200 taskset -c 4 ./tools/microbench/build/keccak_host_clang > $OUT/${TAG}_keccak_host_forms.txt 2>&1
 step timeout -k 10 100 taskset -c 4 ./tools/microbench/build/x64_throughput >> $OUT/${TAG}_keccak_host_forms.txt 2>&1

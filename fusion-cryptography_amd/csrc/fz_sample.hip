@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void mt_sample_kernel(const unsigned long long 
             if ((r0 & 8) && __all(done)) return;
         }
     }
-    if (!done && live) atomicOr(fail, 1);    // never seen: the caller falls back to the host sampler
+    if (!done && live) *(volatile int *)fail = 1;      // never seen: the caller falls back to the host sampler (a plain store: the flag may sit in pinned host memory)
 #undef FZ_MT
 }
 
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * kDrawWaves) void mt_draw_kernel(const uint32_t
         wsync();
         if (t >= degree) return;
     }
-    if (lane == 0) atomicOr(fail, 1);        // never seen: the caller falls back to the host sampler
+    if (lane == 0) *(volatile int *)fail = 1;        // never seen: the caller falls back to the host sampler (a plain store: the flag may sit in pinned host memory)
 }
 
 }  // namespace

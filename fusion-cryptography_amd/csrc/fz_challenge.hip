@@ -74,16 +74,22 @@ constexpr int kDecStride = 16;               // uint32 per signer in the decimal
 // The text of ONE signer by ONE wave, into `buf` (LDS, `cap` bytes, a multiple of 16): the exact characters, the SHAKE
 // suffix (0x1f ... 0x80) and zeros up to the end of the last 136-byte block; returns the number of blocks (all lanes).
 // aux[0..9]: the pre-hashed integer in base 10^9 (chunks, least significant first) and the chunk count at [9].
-__device__ __forceinline__ int vk_text_wave(uint8_t *buf, size_t cap, const uint32_t *aux, const int32_t *row, int degree, const VkTextParts &T,
+// the lane's values of the key row (2 * degree of them over the wave, at most 8 per lane): requested by the caller, as early as it can
+__device__ __forceinline__ void vk_text_load(int32_t (&vals)[8], const int32_t *row, int degree, int lane) {
+    const int nvals = 2 * degree;
+    const int vpl = nvals >= 64 ? nvals / 64 : 1;
+    const int k0 = lane * vpl;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) vals[t] = (t < vpl && k0 + t < nvals) ? row[k0 + t] : 0;
+}
+
+__device__ __forceinline__ int vk_text_wave(uint8_t *buf, size_t cap, const uint32_t *aux, const int32_t (&vals)[8], int degree, const VkTextParts &T,
                                             int lane) {
     const int nvals = 2 * degree;
     const int vpl = nvals >= 64 ? nvals / 64 : 1;               // values per lane, at most 8 (a lane never straddles the two halves)
     const int k0 = lane * vpl;
-    // everything that comes from memory is requested first: the lane's key values and its bytes of the fixed pieces (a load
-    // where the byte is written is a round trip per loop iteration: most of the 9 us this function took for one signer)
-    int32_t vals[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) vals[t] = (t < vpl && k0 + t < nvals) ? row[k0 + t] : 0;
+    // everything that comes from memory is requested first: the lane's key values (by the caller) and its bytes of the fixed pieces
+    // (a load where the byte is written is a round trip per loop iteration: most of the 9 us this function took for one signer)
     uint8_t f0[6], f1[6], f2;
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
@@ -192,7 +198,9 @@ __global__ __launch_bounds__(64 * kTextWaves) void vk_text_kernel(const int32_t 
         }
         aux[9] = (uint32_t)u256_to_base1e9(limb, aux);
     }
-    const int nb = vk_text_wave(buf, text_stride, aux, vk + i * vk_stride, degree, T, lane);
+    int32_t vals[8];
+    vk_text_load(vals, vk + i * vk_stride, degree, lane);
+    const int nb = vk_text_wave(buf, text_stride, aux, vals, degree, T, lane);
     if (lane == 0) nblocks[i] = nb;
     uint8_t *dst = text + i * text_stride;
     for (int o = lane * 8; o < nb * kRate; o += 64 * 8) *reinterpret_cast<uint2 *>(dst + o) = *reinterpret_cast<const uint2 *>(buf + o);
@@ -613,9 +621,9 @@ __global__ __launch_bounds__(64) void decode_kernel(const uint32_t *xof, size_t 
 //   * the text is written to LDS and absorbed from there, the stream is squeezed into the same LDS bytes and decoded from
 //     there: nothing but the key row, the message and the 4 d bytes of the challenge touches memory;
 //   * the decoder's two phases are the wave's: the shuffle indices 64 at a time (a lane per draw, the byte dot product of
-//     decode_kernel with the table row of the lane's own modulus), then the swaps -- sequential, but on POSITIONS: lane k
-//     tracks where the k-th non-zero coefficient is (weight <= 64), a swap (i, j) is two compares and two selects for the
-//     whole wave with j read from the lane that computed it, instead of three dependent LDS accesses per swap.
+//     decode_kernel with the table row of the lane's own modulus), then the swaps -- not as swaps at all: the k-th non-zero
+//     coefficient (weight <= 64) ends where the FIRST draw that names its original position sends it (see phase 2 below),
+//     one LDS minimum per draw instead of 195 dependent steps.
 // LDS per wave: max(text row, stream, 4 d) + 64 bytes.
 constexpr int kWaveAux = 64;
 __device__ __forceinline__ void wave_sync() {
@@ -635,6 +643,8 @@ __global__ __launch_bounds__(64 * W) void challenge_wave_kernel(const int32_t *v
     if (s >= N) return;                                          // waves of a workgroup never synchronise with each other
     uint8_t *buf = smem + (size_t)(threadIdx.x >> 6) * (region + kWaveAux);
     uint32_t *aux = reinterpret_cast<uint32_t *>(buf + region);
+    int32_t vals[8];                                             // the key row: requested now, used after the message's digest (a memory
+    vk_text_load(vals, vk + s * vk_stride, D.degree, lane);      // latency of ~2.5 us under the ~8 us before it is needed)
     fzkw::Wave K;
     K.init(lane);
     const bool ab = K.word < 17;                                 // the rate's 17 words (their owners and the halos)
@@ -706,7 +716,7 @@ __global__ __launch_bounds__(64 * W) void challenge_wave_kernel(const int32_t *v
     }
     wave_sync();
     // ---- the text, absorbed from LDS ----
-    const int nb = vk_text_wave(buf, region, aux, vk + s * vk_stride, D.degree, T, lane);
+    const int nb = vk_text_wave(buf, region, aux, vals, D.degree, T, lane);
     {
         const uint8_t *src = buf + 8 * (ab ? K.word : 0);
         uint2 m = ab ? *reinterpret_cast<const uint2 *>(src) : make_uint2(0u, 0u);
@@ -759,27 +769,24 @@ __global__ __launch_bounds__(64 * W) void challenge_wave_kernel(const int32_t *v
             jv[c] = sum - __umulhi(sum, recip) * mod;            // sum mod (d - n), exact (fz_challenge_weight_table)
         }
     }
-    // phase 2: for i = d-1 down to weight+1: swap(c[i], c[j]) -- on the positions of the non-zero coefficients
+    // phase 2: for i = d-1 down to weight+1: swap(c[i], c[j]).  Before step i the positions weight .. i hold zeros (induction
+    // from the top: a step writes position i only), so a step either exchanges two zeros or lifts the non-zero coefficient k = j
+    // from its ORIGINAL position (< weight) to i, where no later step reaches it (their i and j are smaller) -- and leaves a
+    // zero at k, so later draws of k do nothing.  The k-th coefficient therefore ends at the i of the FIRST draw with j = k, or
+    // stays: 195 dependent swaps (6.2 us of the kernel: a compare pair and two selects each) become one LDS minimum per draw.
+    wave_sync();                                                 // every lane has read its index chunks: the stream's first words become scratch
+    uint32_t *first = reinterpret_cast<uint32_t *>(buf);         // first[k]: the smallest draw number n with j_n = k
+    first[lane] = 0xffffffffu;
+    wave_sync();
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int lim = draws - c * 64 < 64 ? draws - c * 64 : 64;
-        int t = 0;
-#pragma unroll 1
-        for (; t + 4 <= lim; t += 4) {                           // four indices read first: the swaps are one compare pair + two selects each
-            const int i = d - 1 - (c * 64 + t);
-            const int j0 = __builtin_amdgcn_readlane((int)jv[c], t), j1 = __builtin_amdgcn_readlane((int)jv[c], t + 1),
-                      j2 = __builtin_amdgcn_readlane((int)jv[c], t + 2), j3 = __builtin_amdgcn_readlane((int)jv[c], t + 3);
-            pos = pos == i ? j0 : (pos == j0 ? i : pos);
-            pos = pos == i - 1 ? j1 : (pos == j1 ? i - 1 : pos);
-            pos = pos == i - 2 ? j2 : (pos == j2 ? i - 2 : pos);
-            pos = pos == i - 3 ? j3 : (pos == j3 ? i - 3 : pos);
-        }
-#pragma unroll 1
-        for (; t < lim; ++t) {
-            const int i = d - 1 - (c * 64 + t);
-            const int j = __builtin_amdgcn_readlane((int)jv[c], t);
-            pos = pos == i ? j : (pos == j ? i : pos);
-        }
+        const int n = c * 64 + lane;
+        if (n < draws && jv[c] < (uint32_t)wt) atomicMin(&first[jv[c]], (uint32_t)n);
+    }
+    wave_sync();
+    {
+        const uint32_t n1 = first[lane];
+        pos = n1 != 0xffffffffu ? d - 1 - (int)n1 : lane;
     }
     wave_sync();                                                 // the stream has been read: its bytes become the coefficient row
     int32_t *out = reinterpret_cast<int32_t *>(buf);

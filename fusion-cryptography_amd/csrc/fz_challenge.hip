@@ -775,8 +775,8 @@ __global__ __launch_bounds__(64 * W) void challenge_wave_kernel(const int32_t *v
     // zero at k, so later draws of k do nothing.  The k-th coefficient therefore ends at the i of the FIRST draw with j = k, or
     // stays: 195 dependent swaps (6.2 us of the kernel: a compare pair and two selects each) become one LDS minimum per draw.
     wave_sync();                                                 // every lane has read its index chunks: the stream's first words become scratch
-    uint32_t *first = reinterpret_cast<uint32_t *>(buf);         // first[k]: the smallest draw number n with j_n = k
-    first[lane] = 0xffffffffu;
+    uint32_t *first = reinterpret_cast<uint32_t *>(buf);         // first[k], k < weight: the smallest draw number n with j_n = k
+    if (lane < wt) first[lane] = 0xffffffffu;                    // (4 * weight <= 4 * degree bytes: inside the region whatever the parameters)
     wave_sync();
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(64 * W) void challenge_wave_kernel(const int32_t *v
         if (n < draws && jv[c] < (uint32_t)wt) atomicMin(&first[jv[c]], (uint32_t)n);
     }
     wave_sync();
-    {
+    if (lane < wt) {
         const uint32_t n1 = first[lane];
         pos = n1 != 0xffffffffu ? d - 1 - (int)n1 : lane;
     }

@@ -74,29 +74,35 @@ constexpr int kDecStride = 16;               // uint32 per signer in the decimal
 // The text of ONE signer by ONE wave, into `buf` (LDS, `cap` bytes, a multiple of 16): the exact characters, the SHAKE
 // suffix (0x1f ... 0x80) and zeros up to the end of the last 136-byte block; returns the number of blocks (all lanes).
 // aux[0..9]: the pre-hashed integer in base 10^9 (chunks, least significant first) and the chunk count at [9].
-// the lane's values of the key row (2 * degree of them over the wave, at most 8 per lane): requested by the caller, as early as it can
-__device__ __forceinline__ void vk_text_load(int32_t (&vals)[8], const int32_t *row, int degree, int lane) {
+// What the text of one signer needs from memory, per lane: its values of the key row (2 * degree of them over the wave, at
+// most 8 per lane) and its bytes of the three fixed pieces.  Requested by the caller as early as it can: a load where the byte
+// is written is a round trip per loop iteration (most of the 9 us the text took for one signer in round 5's first form).
+struct VkTextIn {
+    int32_t vals[8];
+    uint8_t f0[6], f1[6], f2;
+};
+__device__ __forceinline__ void vk_text_load(VkTextIn &in, const int32_t *row, int degree, const VkTextParts &T, int lane) {
     const int nvals = 2 * degree;
     const int vpl = nvals >= 64 ? nvals / 64 : 1;
     const int k0 = lane * vpl;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) vals[t] = (t < vpl && k0 + t < nvals) ? row[k0 + t] : 0;
+    for (int t = 0; t < 8; ++t) in.vals[t] = (t < vpl && k0 + t < nvals) ? row[k0 + t] : 0;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        in.f0[t] = lane + 64 * t < T.n0 ? (uint8_t)T.s0[lane + 64 * t] : (uint8_t)0;
+        in.f1[t] = lane + 64 * t < T.n1 ? (uint8_t)T.s1[lane + 64 * t] : (uint8_t)0;
+    }
+    in.f2 = lane < T.n2 ? (uint8_t)T.s2[lane] : (uint8_t)0;
 }
 
-__device__ __forceinline__ int vk_text_wave(uint8_t *buf, size_t cap, const uint32_t *aux, const int32_t (&vals)[8], int degree, const VkTextParts &T,
+__device__ __forceinline__ int vk_text_wave(uint8_t *buf, size_t cap, const uint32_t *aux, const VkTextIn &in, int degree, const VkTextParts &T,
                                             int lane) {
     const int nvals = 2 * degree;
     const int vpl = nvals >= 64 ? nvals / 64 : 1;               // values per lane, at most 8 (a lane never straddles the two halves)
     const int k0 = lane * vpl;
-    // everything that comes from memory is requested first: the lane's key values (by the caller) and its bytes of the fixed pieces
-    // (a load where the byte is written is a round trip per loop iteration: most of the 9 us this function took for one signer)
-    uint8_t f0[6], f1[6], f2;
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        f0[t] = lane + 64 * t < T.n0 ? (uint8_t)T.s0[lane + 64 * t] : (uint8_t)0;
-        f1[t] = lane + 64 * t < T.n1 ? (uint8_t)T.s1[lane + 64 * t] : (uint8_t)0;
-    }
-    f2 = lane < T.n2 ? (uint8_t)T.s2[lane] : (uint8_t)0;
+    const int32_t (&vals)[8] = in.vals;
+    const uint8_t (&f0)[6] = in.f0, (&f1)[6] = in.f1;
+    const uint8_t f2 = in.f2;
     for (size_t o = (size_t)lane * 16; o < cap; o += 64 * 16) *reinterpret_cast<int4 *>(buf + o) = make_int4(0, 0, 0, 0);
     // pass 1: lengths (digits + ", " unless last of its half)
     int mine = 0;
@@ -198,9 +204,9 @@ __global__ __launch_bounds__(64 * kTextWaves) void vk_text_kernel(const int32_t 
         }
         aux[9] = (uint32_t)u256_to_base1e9(limb, aux);
     }
-    int32_t vals[8];
-    vk_text_load(vals, vk + i * vk_stride, degree, lane);
-    const int nb = vk_text_wave(buf, text_stride, aux, vals, degree, T, lane);
+    VkTextIn tin;
+    vk_text_load(tin, vk + i * vk_stride, degree, T, lane);
+    const int nb = vk_text_wave(buf, text_stride, aux, tin, degree, T, lane);
     if (lane == 0) nblocks[i] = nb;
     uint8_t *dst = text + i * text_stride;
     for (int o = lane * 8; o < nb * kRate; o += 64 * 8) *reinterpret_cast<uint2 *>(dst + o) = *reinterpret_cast<const uint2 *>(buf + o);
@@ -643,8 +649,8 @@ __global__ __launch_bounds__(64 * W) void challenge_wave_kernel(const int32_t *v
     if (s >= N) return;                                          // waves of a workgroup never synchronise with each other
     uint8_t *buf = smem + (size_t)(threadIdx.x >> 6) * (region + kWaveAux);
     uint32_t *aux = reinterpret_cast<uint32_t *>(buf + region);
-    int32_t vals[8];                                             // the key row: requested now, used after the message's digest (a memory
-    vk_text_load(vals, vk + s * vk_stride, D.degree, lane);      // latency of ~2.5 us under the ~8 us before it is needed)
+    VkTextIn tin;                                                // the key row and the fixed pieces: requested now, used after the message's
+    vk_text_load(tin, vk + s * vk_stride, D.degree, T, lane);    // digest (a memory latency of ~2.5 us under the ~8 us before they are needed)
     fzkw::Wave K;
     K.init(lane);
     const bool ab = K.word < 17;                                 // the rate's 17 words (their owners and the halos)
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(64 * W) void challenge_wave_kernel(const int32_t *v
     }
     wave_sync();
     // ---- the text, absorbed from LDS ----
-    const int nb = vk_text_wave(buf, region, aux, vals, D.degree, T, lane);
+    const int nb = vk_text_wave(buf, region, aux, tin, D.degree, T, lane);
     {
         const uint8_t *src = buf + 8 * (ab ? K.word : 0);
         uint2 m = ab ? *reinterpret_cast<const uint2 *>(src) : make_uint2(0u, 0u);

@@ -196,9 +196,10 @@ __global__ __launch_bounds__(64) void mt_sample_kernel(const unsigned long long 
 //   regeneration: word k needs the old words k, k + 1 and word k + 397 -- old below k = 227, else the NEW word k - 227: three
 //                 chunks (0..226, 227..453, 454..623), each read completely before it is written;
 //   outputs:      lane L owns outputs 10 L .. 10 L + 9 of the generation.  It walks them twice -- entering in state "magnitude
-//                 next" and in state "sign next" -- and leaves (exit state, coefficients completed, pending magnitude) for
-//                 both in LDS; lane 0 chains the 64 summaries; every lane then walks its outputs once more from its true entry
-//                 state and writes its coefficients at their final positions.
+//                 next" and in state "sign next" -- which makes its ten outputs a map (pending in) -> (pending out, coefficients
+//                 completed); the maps compose, so the lanes' true entry states are an exclusive scan over the wave (six shuffle
+//                 steps; rounds 3-5: lane 0 walked the 64 summaries through LDS); every lane then walks its outputs once more
+//                 from its true entry state and writes its coefficients at their final positions.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kDrawWaves = 4;
 constexpr int kPerLane = 10;                 // 64 x 10 >= 624 outputs of a generation
@@ -223,12 +224,10 @@ __global__ __launch_bounds__(64) void mt_seed_kernel(const unsigned long long *s
 __global__ __launch_bounds__(64 * kDrawWaves) void mt_draw_kernel(const uint32_t *__restrict__ state, size_t npoly, int degree, uint32_t bound,
                                                                   int kbits, int32_t *out, int *fail) {
     __shared__ uint32_t s_mt[kDrawWaves][kMtN + 16];
-    __shared__ uint32_t s_sum[kDrawWaves][64][8];       // per lane: for entry state M and S: exit state, coefficients, pending magnitude; [6..7]: true entry
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const size_t gen_id = (size_t)blockIdx.x * kDrawWaves + wave;
     if (gen_id >= npoly) return;                          // whole waves only: the waves of a workgroup never synchronise
     uint32_t *mt = s_mt[wave];
-    uint32_t (*sum)[8] = s_sum[wave];
     auto wsync = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -292,25 +291,37 @@ __global__ __launch_bounds__(64 * kDrawWaves) void mt_draw_kernel(const uint32_t
         const uint32_t em = walk(0u, cm);                // entered expecting a magnitude: exit pending magnitude (0: none)
         const uint32_t es = walk(0xffffffffu, cs);       // entered with SOME magnitude pending: the value is patched below
         // entering with a pending magnitude P: the walk is the same until the first sign is taken; if none is taken the exit
-        // still holds P (es == 0xffffffff marks that)
-        sum[lane][0] = em; sum[lane][1] = cm; sum[lane][2] = es; sum[lane][3] = cs;
-        wsync();
-        if (lane == 0) {
-            uint32_t pend = carry_mag;
-            int tt = t;
-            for (int L = 0; L < 64; ++L) {
-                sum[L][6] = pend;
-                sum[L][7] = (uint32_t)tt;
-                if (pend == 0) { tt += (int)sum[L][1]; pend = sum[L][0]; }
-                else { tt += (int)sum[L][3]; pend = sum[L][2] == 0xffffffffu ? pend : sum[L][2]; }
+        // still holds P (es == 0xffffffff marks that).
+        // A lane's ten outputs are thus a map (pending in) -> (pending out, coefficients completed) given by (em, cm, es, cs), and
+        // such maps compose: the lanes' true entry states are an exclusive scan of them under composition -- six shuffle steps
+        // of the wave instead of lane 0 walking the 64 summaries through LDS (rounds 3-5: 64 dependent LDS round trips per
+        // generation, a third of this kernel).  compose(A, B) = A's lanes first, then B's.
+        uint32_t a_em = em, a_cm = cm, a_es = es, a_cs = cs;         // inclusive: lanes 0 .. lane composed
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t p_em = __shfl_up(a_em, off), p_cm = __shfl_up(a_cm, off), p_es = __shfl_up(a_es, off), p_cs = __shfl_up(a_cs, off);
+            if (lane >= off) {
+                const uint32_t n_em = p_em == 0u ? a_em : (a_es == 0xffffffffu ? p_em : a_es);
+                const uint32_t n_cm = p_cm + (p_em == 0u ? a_cm : a_cs);
+                const uint32_t n_es = p_es == 0xffffffffu ? a_es : (p_es == 0u ? a_em : (a_es == 0xffffffffu ? p_es : a_es));
+                const uint32_t n_cs = p_cs + (p_es == 0u ? a_cm : a_cs);
+                a_em = n_em; a_cm = n_cm; a_es = n_es; a_cs = n_cs;
             }
-            sum[0][4] = pend;
-            sum[0][5] = (uint32_t)tt;
         }
-        wsync();
+        auto apply = [&](uint32_t s_em, uint32_t s_cm, uint32_t s_es, uint32_t s_cs, uint32_t &pend, int &tt) {
+            if (carry_mag == 0u) { pend = s_em; tt = t + (int)s_cm; }
+            else { pend = s_es == 0xffffffffu ? carry_mag : s_es; tt = t + (int)s_cs; }
+        };
+        uint32_t mag = carry_mag;                        // this lane's true entry state: the lanes before it applied to the wave's
+        int tl = t;
         {
-            uint32_t mag = sum[lane][6];
-            int tl = (int)sum[lane][7];
+            const uint32_t e_em = __shfl_up(a_em, 1), e_cm = __shfl_up(a_cm, 1), e_es = __shfl_up(a_es, 1), e_cs = __shfl_up(a_cs, 1);
+            if (lane > 0) apply(e_em, e_cm, e_es, e_cs, mag, tl);
+        }
+        uint32_t next_mag;                               // ... and the wave's exit state: all 64 lanes applied
+        int next_t;
+        apply(__shfl(a_em, 63), __shfl(a_cm, 63), __shfl(a_es, 63), __shfl(a_cs, 63), next_mag, next_t);
+        {
 #pragma unroll
             for (int u = 0; u < kPerLane; ++u) {
                 const bool take_sign = mag != 0 && sg[u] < 2u, take_mag = mag == 0 && v[u] < bound;
@@ -321,8 +332,8 @@ __global__ __launch_bounds__(64 * kDrawWaves) void mt_draw_kernel(const uint32_t
                 mag = take_sign ? 0u : (take_mag ? v[u] + 1u : mag);
             }
         }
-        carry_mag = sum[0][4];
-        t = (int)sum[0][5];
+        carry_mag = next_mag;
+        t = next_t;
         wsync();
         if (t >= degree) return;
     }
